@@ -1,0 +1,144 @@
+/* bsx_core.h -- internal host-side types of the MI355X biscuit-align path.
+ * Host code is C (the reference's language); device work goes through bsx_backend_t, whose only
+ * product implementation is the HIP one (csrc/hip). */
+#ifndef BSX_CORE_H
+#define BSX_CORE_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "bsx.h"
+
+#define BSX_API __attribute__((visibility("default")))
+
+/* ---------- tiny growable array ---------- */
+#define BSX_VEC(type) struct { size_t n, m; type *a; }
+#define bsx_vec_init(v) ((v).n = (v).m = 0, (v).a = 0)
+#define bsx_vec_free(v) (free((v).a), (v).a = 0, (v).n = (v).m = 0)
+#define bsx_vec_reserve(v, cap) do { \
+		if ((v).m < (size_t)(cap)) { size_t m_ = (v).m ? (v).m : 4; while (m_ < (size_t)(cap)) m_ <<= 1; \
+			(v).a = realloc((v).a, m_ * sizeof(*(v).a)); (v).m = m_; } } while (0)
+#define bsx_vec_push(v, x) do { if ((v).n == (v).m) bsx_vec_reserve(v, (v).n + 1); (v).a[(v).n++] = (x); } while (0)
+#define bsx_vec_pushp(v) (((v).n == (v).m ? (void)((v).m = (v).m ? (v).m << 1 : 4, (v).a = realloc((v).a, (v).m * sizeof(*(v).a))) : (void)0), &(v).a[(v).n++])
+
+#define bsx_min(a, b) ((a) < (b) ? (a) : (b))
+#define bsx_max(a, b) ((a) > (b) ? (a) : (b))
+
+/* ---------- FM index of one converted text (bwt_t, lib/aln/bwt.h:54-71) ---------- */
+typedef struct {
+	uint64_t primary;
+	uint64_t L2[5];
+	uint64_t seq_len;
+	uint64_t bwt_size;      /* in u32 words, occ blocks interleaved */
+	uint32_t *bwt;
+	int sa_intv;
+	uint64_t n_sa;
+	uint64_t *sa;
+} bsx_fmi_t;
+
+/* ---------- reference meta (bntseq_t, lib/aln/bntseq.h:41-62) ---------- */
+typedef struct {
+	int64_t offset;
+	int32_t len;
+	int32_t n_ambs;
+	uint32_t gi;
+	int32_t is_alt;
+	char *name, *anno;
+} bsx_ann_t;
+typedef struct {
+	int64_t offset;
+	int32_t len;
+	char amb;
+} bsx_amb_t;
+typedef struct {
+	int64_t l_pac;
+	int32_t n_seqs;
+	uint32_t seed;
+	bsx_ann_t *anns;
+	int32_t n_holes;
+	bsx_amb_t *ambs;
+} bsx_refmeta_t;
+
+struct bsx_index {
+	bsx_fmi_t fmi[2];       /* [1] = parent (C>T), [0] = daughter (G>A); lib/aln/bwa.c:535-536 */
+	bsx_refmeta_t ref;
+	uint8_t *pac;           /* l_pac/4+1 bytes, forward unconverted genome */
+};
+
+#define bsx_pac_get(pac, l) ((pac)[(l) >> 2] >> ((~(l) & 3) << 1) & 3)
+
+/* coordinate helpers (bntseq.c:356-452, bntseq.h:91-93) */
+static inline int64_t bsx_depos(int64_t l_pac, int64_t pos, int *is_rev)
+{
+	return (*is_rev = (pos >= l_pac)) ? (l_pac << 1) - 1 - pos : pos;
+}
+int bsx_pos2rid(const bsx_refmeta_t *r, int64_t pos_f);
+int bsx_intv2rid(const bsx_refmeta_t *r, int64_t rb, int64_t re);
+/* base at forward-reverse coordinate p in [0, 2*l_pac) (bns_get_seq, bntseq.c:402-422) */
+static inline int bsx_ref_base(int64_t l_pac, const uint8_t *pac, int64_t p)
+{
+	if (p < l_pac) return bsx_pac_get(pac, p);
+	p = (l_pac << 1) - 1 - p;
+	return 3 - bsx_pac_get(pac, p);
+}
+/* clamp [*beg,*end) to the contig containing mid; returns rid (bns_fetch_seq, bntseq.c:428-452) */
+int bsx_fetch_span(const bsx_refmeta_t *r, int64_t *beg, int64_t mid, int64_t *end);
+
+/* ---------- sorting: exact re-implementation of the reference's introsort permutation ---------- */
+typedef int (*bsx_lt_fn)(const void *a, const void *b);   /* returns a < b */
+void bsx_introsort(void *base, size_t n, size_t width, bsx_lt_fn lt);
+void bsx_introsort_u64(size_t n, uint64_t *a);
+void bsx_introsort_i64(size_t n, int64_t *a);
+uint64_t bsx_hash64(uint64_t key);
+
+/* ---------- B-tree with the reference's node geometry (t = 3) ---------- */
+typedef struct bsx_btree bsx_btree_t;
+bsx_btree_t *bsx_bt_new(void);
+void bsx_bt_clear(bsx_btree_t *t);
+void bsx_bt_free(bsx_btree_t *t);
+int  bsx_bt_size(const bsx_btree_t *t);
+void bsx_bt_put(bsx_btree_t *t, int64_t pos, int32_t id);
+/* id of the key kb_intervalp would return as `lower` (equal key or predecessor), or -1 */
+int32_t bsx_bt_lower(const bsx_btree_t *t, int64_t pos);
+/* in-order ids; returns count */
+int  bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids);
+
+/* ---------- thread pool (kt_for equivalent; results never depend on scheduling) ---------- */
+typedef void (*bsx_for_fn)(void *data, long i, int tid);
+void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n);
+
+/* ---------- device backend: the batch seams of include/bsx.h behind one vtable ---------- */
+typedef struct bsx_backend {
+	void *ctx;
+	const char *name;
+	int (*set_opt)(void *ctx, const bsx_opt_t *opt);
+	int (*set_reads)(void *ctx, const uint8_t *buf, size_t n);
+	int (*seed_batch)(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+	                  bsx_intv_t **out, int64_t *out_cap, int64_t *out_off);
+	int (*sa_batch)(void *ctx, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos);
+	int (*extend_batch)(void *ctx, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res);
+	int (*sw_batch)(void *ctx, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
+	int (*global_batch)(void *ctx, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+	                    uint32_t *cigar_pool, size_t cigar_pool_len);
+} bsx_backend_t;
+
+/* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;
+ * tests may pass the CPU restatement that lives under oracle/) */
+BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
+
+/* HIP backend constructor (csrc/hip/shim.hip) */
+int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);
+
+/* per-phase wall-clock accounting of the last bsx_process_seqs* call (seconds) */
+typedef struct {
+	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total;
+	int64_t n_tasks, n_intv, n_sa, n_ext_jobs, n_ext_rounds, n_sw_jobs, n_glb_jobs;
+} bsx_phase_stats_t;
+BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out);
+
+extern int bsx_verbose;
+
+#endif

@@ -1,0 +1,328 @@
+/* util.c -- ordering primitives whose exact behaviour leaks into the SAM output.
+ *
+ * The reference sorts with klib's non-stable ks_introsort (lib/aln/ksort.h:184-236) and chains
+ * seeds through a klib B-tree (lib/aln/kbtree.h).  The permutation an unstable sort produces for
+ * equal keys, and which of several equal keys a B-tree lookup lands on, decide which chain or
+ * region is processed first.  Both are re-implemented here from their algorithmic description
+ * (index based, element-width generic) so that the comparison/swap sequence -- and therefore the
+ * permutation -- is the same.  Pinned against the reference templates in tests/test_host_primitives.py.
+ */
+#include <pthread.h>
+#include "bsx_core.h"
+
+int bsx_verbose = 3;
+
+/* hash_64 (lib/aln/utils.h:107-117) */
+uint64_t bsx_hash64(uint64_t key)
+{
+	key += ~(key << 32);
+	key ^= (key >> 22);
+	key += ~(key << 13);
+	key ^= (key >> 8);
+	key += (key << 3);
+	key ^= (key >> 15);
+	key += ~(key << 27);
+	key ^= (key >> 31);
+	return key;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * introsort: median-of-3 quicksort that leaves runs of <=16 for one final insertion sort,
+ * with a comb-sort fallback when the depth budget 2*ceil(log2 n) is spent.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	char *base; size_t w; bsx_lt_fn lt; char *tmp, *pivot;
+} srt_t;
+
+#define EL(S, i) ((S)->base + (size_t)(i) * (S)->w)
+
+static inline void srt_swap(srt_t *S, ptrdiff_t i, ptrdiff_t j)
+{
+	memcpy(S->tmp, EL(S, i), S->w); memcpy(EL(S, i), EL(S, j), S->w); memcpy(EL(S, j), S->tmp, S->w);
+}
+
+static void srt_insertion(srt_t *S, ptrdiff_t s, ptrdiff_t t) /* [s, t) */
+{
+	ptrdiff_t i, j;
+	for (i = s + 1; i < t; ++i)
+		for (j = i; j > s && S->lt(EL(S, j), EL(S, j - 1)); --j)
+			srt_swap(S, j, j - 1);
+}
+
+static void srt_comb(srt_t *S, ptrdiff_t s, size_t n) /* ksort.h:162-183 */
+{
+	const double shrink_factor = 1.2473309501039786540366528676643;
+	int swapped;
+	size_t gap = n, i;
+	do {
+		if (gap > 2) {
+			gap = (size_t)(gap / shrink_factor);
+			if (gap == 9 || gap == 10) gap = 11;
+		}
+		swapped = 0;
+		for (i = 0; i + gap < n; ++i)
+			if (S->lt(EL(S, s + i + gap), EL(S, s + i))) { srt_swap(S, s + i, s + i + gap); swapped = 1; }
+	} while (swapped || gap > 2);
+	if (gap != 1) srt_insertion(S, s, s + n);
+}
+
+void bsx_introsort(void *base, size_t n, size_t width, bsx_lt_fn lt)
+{
+	srt_t S;
+	struct frame { ptrdiff_t left, right; int depth; } *stack, *top;
+	ptrdiff_t s, t, i, j, k;
+	int d;
+	char buf[512];
+
+	if (n < 1) return;
+	S.base = (char*)base; S.w = width; S.lt = lt;
+	S.tmp = width * 2 <= sizeof(buf) ? buf : (char*)malloc(width * 2);
+	S.pivot = S.tmp + width;
+	if (n == 2) {
+		if (lt(EL(&S, 1), EL(&S, 0))) srt_swap(&S, 0, 1);
+		goto done;
+	}
+	for (d = 2; 1ul << d < n; ++d);
+	stack = (struct frame*)malloc(sizeof(*stack) * (sizeof(size_t) * d + 2));
+	top = stack; s = 0; t = (ptrdiff_t)n - 1; d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) {
+				srt_comb(&S, s, (size_t)(t - s + 1));
+				t = s;
+				continue;
+			}
+			i = s; j = t; k = i + ((j - i) >> 1) + 1;
+			if (lt(EL(&S, k), EL(&S, i))) {
+				if (lt(EL(&S, k), EL(&S, j))) k = j;
+			} else k = lt(EL(&S, j), EL(&S, i)) ? i : j;
+			memcpy(S.pivot, EL(&S, k), width);
+			if (k != t) srt_swap(&S, k, t);
+			for (;;) {
+				do ++i; while (lt(EL(&S, i), S.pivot));
+				do --j; while (i <= j && lt(S.pivot, EL(&S, j)));
+				if (j <= i) break;
+				srt_swap(&S, i, j);
+			}
+			srt_swap(&S, i, t);
+			if (i - s > t - i) {
+				if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == stack) {
+				free(stack);
+				srt_insertion(&S, 0, (ptrdiff_t)n);
+				break;
+			}
+			--top; s = top->left; t = top->right; d = top->depth;
+		}
+	}
+done:
+	if (S.tmp != buf) free(S.tmp);
+}
+
+static int lt_u64(const void *a, const void *b) { return *(const uint64_t*)a < *(const uint64_t*)b; }
+static int lt_i64(const void *a, const void *b) { return *(const int64_t*)a < *(const int64_t*)b; }
+void bsx_introsort_u64(size_t n, uint64_t *a) { bsx_introsort(a, n, 8, lt_u64); }
+void bsx_introsort_i64(size_t n, int64_t *a) { bsx_introsort(a, n, 8, lt_i64); }
+
+/* ------------------------------------------------------------------------------------------
+ * B-tree, minimum degree 3 (the value kbtree.h:75 derives for 72-byte keys in 512-byte nodes),
+ * pre-emptive split on the way down, lower-bound search inside a node, duplicates allowed.
+ * ------------------------------------------------------------------------------------------ */
+#define BT_T 3
+#define BT_MAXK (2 * BT_T - 1)
+
+typedef struct {
+	int32_t is_internal, n;
+	int64_t key[BT_MAXK];
+	int32_t id[BT_MAXK];
+	int32_t child[BT_MAXK + 1];
+} bt_node_t;
+
+struct bsx_btree {
+	bt_node_t *nodes;
+	int32_t n_nodes, m_nodes, root, n_keys;
+};
+
+static int32_t bt_alloc(bsx_btree_t *t, int internal)
+{
+	bt_node_t *x;
+	if (t->n_nodes == t->m_nodes) {
+		t->m_nodes = t->m_nodes ? t->m_nodes << 1 : 16;
+		t->nodes = (bt_node_t*)realloc(t->nodes, sizeof(bt_node_t) * t->m_nodes);
+	}
+	x = &t->nodes[t->n_nodes];
+	memset(x, 0, sizeof(*x));
+	x->is_internal = internal;
+	return t->n_nodes++;
+}
+
+bsx_btree_t *bsx_bt_new(void)
+{
+	bsx_btree_t *t = (bsx_btree_t*)calloc(1, sizeof(*t));
+	bsx_bt_clear(t);
+	return t;
+}
+void bsx_bt_clear(bsx_btree_t *t) { t->n_nodes = 0; t->n_keys = 0; t->root = bt_alloc(t, 0); }
+void bsx_bt_free(bsx_btree_t *t) { if (t) { free(t->nodes); free(t); } }
+int bsx_bt_size(const bsx_btree_t *t) { return t->n_keys; }
+
+/* position of the last key <= pos inside a node, the first equal key when there are several;
+ * *r = sign(pos - key[found]) as in __kb_getp_aux (kbtree.h:118-131) */
+static int bt_find(const bt_node_t *x, int64_t pos, int *r)
+{
+	int begin = 0, end = x->n, rr;
+	if (x->n == 0) return -1;
+	while (begin < end) {
+		int mid = (begin + end) >> 1;
+		if (x->key[mid] < pos) begin = mid + 1;
+		else end = mid;
+	}
+	if (begin == x->n) { if (r) *r = 1; return x->n - 1; }
+	rr = (x->key[begin] < pos) - (pos < x->key[begin]);
+	if (r) *r = rr;
+	if (rr < 0) --begin;
+	return begin;
+}
+
+static void bt_split(bsx_btree_t *t, int32_t xi, int i, int32_t yi)
+{
+	int32_t zi = bt_alloc(t, t->nodes[yi].is_internal);
+	bt_node_t *x = &t->nodes[xi], *y = &t->nodes[yi], *z = &t->nodes[zi];
+	z->n = BT_T - 1;
+	memcpy(z->key, y->key + BT_T, sizeof(int64_t) * (BT_T - 1));
+	memcpy(z->id, y->id + BT_T, sizeof(int32_t) * (BT_T - 1));
+	if (y->is_internal) memcpy(z->child, y->child + BT_T, sizeof(int32_t) * BT_T);
+	y->n = BT_T - 1;
+	memmove(x->child + i + 2, x->child + i + 1, sizeof(int32_t) * (x->n - i));
+	x->child[i + 1] = zi;
+	memmove(x->key + i + 1, x->key + i, sizeof(int64_t) * (x->n - i));
+	memmove(x->id + i + 1, x->id + i, sizeof(int32_t) * (x->n - i));
+	x->key[i] = y->key[BT_T - 1];
+	x->id[i] = y->id[BT_T - 1];
+	++x->n;
+}
+
+void bsx_bt_put(bsx_btree_t *t, int64_t pos, int32_t id)
+{
+	int32_t xi;
+	++t->n_keys;
+	if (t->nodes[t->root].n == BT_MAXK) {
+		int32_t r = t->root, s = bt_alloc(t, 1);
+		t->nodes[s].child[0] = r;
+		t->root = s;
+		bt_split(t, s, 0, r);
+	}
+	xi = t->root;
+	for (;;) {
+		bt_node_t *x = &t->nodes[xi];
+		int i;
+		if (!x->is_internal) {
+			i = bt_find(x, pos, 0);
+			if (i != x->n - 1) {
+				memmove(x->key + i + 2, x->key + i + 1, sizeof(int64_t) * (x->n - i - 1));
+				memmove(x->id + i + 2, x->id + i + 1, sizeof(int32_t) * (x->n - i - 1));
+			}
+			x->key[i + 1] = pos; x->id[i + 1] = id;
+			++x->n;
+			return;
+		}
+		i = bt_find(x, pos, 0) + 1;
+		if (t->nodes[x->child[i]].n == BT_MAXK) {
+			bt_split(t, xi, i, x->child[i]);
+			x = &t->nodes[xi]; /* nodes may have been reallocated */
+			if (pos > x->key[i]) ++i;
+		}
+		xi = x->child[i];
+	}
+}
+
+int32_t bsx_bt_lower(const bsx_btree_t *t, int64_t pos)
+{
+	int32_t xi = t->root, lower = -1;
+	for (;;) {
+		const bt_node_t *x = &t->nodes[xi];
+		int r = 0, i = bt_find(x, pos, &r);
+		if (i >= 0 && r == 0) return x->id[i];
+		if (i >= 0) lower = x->id[i];
+		if (!x->is_internal) return lower;
+		xi = x->child[i + 1];
+	}
+}
+
+static void bt_walk(const bsx_btree_t *t, int32_t xi, int32_t *ids, int *n)
+{
+	const bt_node_t *x = &t->nodes[xi];
+	int i;
+	for (i = 0; i < x->n; ++i) {
+		if (x->is_internal) bt_walk(t, x->child[i], ids, n);
+		ids[(*n)++] = x->id[i];
+	}
+	if (x->is_internal) bt_walk(t, x->child[x->n], ids, n);
+}
+int bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids)
+{
+	int n = 0;
+	bt_walk(t, t->root, ids, &n);
+	return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * parallel for
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+	bsx_for_fn fn; void *data; long n; long next; long grain; int tid;
+} pf_shared_t;
+typedef struct { pf_shared_t *sh; int tid; } pf_arg_t;
+
+static void *pf_worker(void *a_)
+{
+	pf_arg_t *a = (pf_arg_t*)a_;
+	pf_shared_t *sh = a->sh;
+	for (;;) {
+		long b = __sync_fetch_and_add(&sh->next, sh->grain), e, i;
+		if (b >= sh->n) break;
+		e = b + sh->grain < sh->n ? b + sh->grain : sh->n;
+		for (i = b; i < e; ++i) sh->fn(sh->data, i, a->tid);
+	}
+	return 0;
+}
+
+void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
+{
+	long i;
+	if (n <= 0) return;
+	if (n_threads <= 1 || n == 1) {
+		for (i = 0; i < n; ++i) fn(data, i, 0);
+	} else {
+		pf_shared_t sh;
+		pthread_t *tid = (pthread_t*)alloca(sizeof(pthread_t) * n_threads);
+		pf_arg_t *args = (pf_arg_t*)alloca(sizeof(pf_arg_t) * n_threads);
+		int t;
+		sh.fn = fn; sh.data = data; sh.n = n; sh.next = 0;
+		sh.grain = n / (n_threads * 16L); if (sh.grain < 1) sh.grain = 1; if (sh.grain > 256) sh.grain = 256;
+		for (t = 0; t < n_threads; ++t) { args[t].sh = &sh; args[t].tid = t; pthread_create(&tid[t], 0, pf_worker, &args[t]); }
+		for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+	}
+}
+
+const char *bsx_version(void) { return "biscuit_amd 0.1 (gfx950)"; }
+
+const char *bsx_strerror(int code)
+{
+	switch (code) {
+	case BSX_OK: return "ok";
+	case BSX_E_NODEVICE: return "no usable HIP device (the product path has no CPU fallback)";
+	case BSX_E_ARG: return "invalid argument";
+	case BSX_E_IO: return "I/O error";
+	case BSX_E_NOMEM: return "out of memory";
+	case BSX_E_FORMAT: return "malformed index or input file";
+	case BSX_E_INTERNAL: return "internal error";
+	}
+	return "unknown error";
+}

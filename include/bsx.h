@@ -1,0 +1,265 @@
+/* bsx.h -- C ABI of the MI355X-native `biscuit align` hot path.
+ *
+ * The reference (zhou-lab/biscuit, lib/aln) has no plugin/FFI layer; its seams are plain C
+ * functions.  Every entry point below replaces one of them (cited file:line under
+ * /root/reference) with a batch form: plain pointers + sizes, int status (0 = ok, <0 = BSX_E_*)
+ * instead of abort(), no globals.  The kernel-level calls run on the GPU (HIP, gfx950); there is
+ * no CPU fallback inside the product library: without a usable HIP device every device call
+ * returns BSX_E_NODEVICE.
+ */
+#ifndef BSX_H
+#define BSX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_OK            0
+#define BSX_E_NODEVICE  (-1)   /* no HIP device / HIP runtime error */
+#define BSX_E_ARG       (-2)
+#define BSX_E_IO        (-3)
+#define BSX_E_NOMEM     (-4)
+#define BSX_E_FORMAT    (-5)
+#define BSX_E_INTERNAL  (-6)
+
+/* ---- flags: identical values to MEM_F_* (lib/aln/bwamem.h:42-52) ---- */
+#define BSX_F_PE             0x2
+#define BSX_F_NOPAIRING      0x4
+#define BSX_F_ALL            0x8
+#define BSX_F_NO_MULTI       0x10
+#define BSX_F_NO_RESCUE      0x20
+#define BSX_F_SELF_OVLP      0x40
+#define BSX_F_ALN_REG        0x80
+#define BSX_F_REF_HDR        0x100
+#define BSX_F_SOFTCLIP       0x200
+#define BSX_F_SMARTPE        0x400
+#define BSX_F_KEEP_SUPP_MAPQ 0x1000
+
+/* ksw xtra flags (lib/aln/ksw.h:31-35) */
+#define BSX_KSW_XBYTE  0x10000
+#define BSX_KSW_XSTOP  0x20000
+#define BSX_KSW_XSUBO  0x40000
+#define BSX_KSW_XSTART 0x80000
+
+/* Alignment options: field-for-field mem_opt_t (lib/aln/bwamem.h:54-124), same defaults
+ * (mem_opt_init, lib/aln/bwamem.c:77-128). */
+typedef struct bsx_opt {
+	int a, b;
+	int o_del, e_del;
+	int o_ins, e_ins;
+	int pen_unpaired;
+	int pen_clip5, pen_clip3;
+	int w;
+	int zdrop;
+	uint64_t max_mem_intv;
+	int T;
+	int flag;
+	int min_seed_len;
+	int min_chain_weight;
+	uint32_t max_chain_extend;
+	float split_factor;
+	int split_width;
+	uint32_t max_occ;
+	int max_chain_gap;
+	int n_threads;
+	int chunk_size;
+	float mask_level;
+	float drop_ratio;
+	float XA_drop_ratio;
+	float mask_level_redun;
+	float mapQ_coef_len;
+	int mapQ_coef_fac;
+	int max_ins;
+	int max_matesw;
+	int max_XA_hits, max_XA_hits_alt;
+	int8_t mat[25];
+	uint8_t parent;     /* -b */
+	uint8_t bsstrand;   /* -f */
+	int8_t ctmat[25];
+	int8_t gamat[25];
+	uint8_t *adaptor1; int l_adaptor1;
+	uint8_t *adaptor2; int l_adaptor2;
+	int clip5, clip3, min_base_qual;
+	uint8_t has_bc;
+} bsx_opt_t;
+
+/* insert-size statistics: mem_pestat_t (lib/aln/bwamem.h:126-131) */
+typedef struct bsx_pestat {
+	int low, high;
+	int set;
+	int failed;
+	double avg, std;
+} bsx_pestat_t;
+
+/* one read: the fields of bseq1_t (lib/aln/bwa.h:52-61) that mem_process_seqs reads/writes */
+typedef struct bsx_read {
+	int l_seq, id;
+	char *name, *comment, *barcode, *umi, *qual, *sam;
+	uint8_t *seq;        /* nt4 codes; advanced by clip5 after clipping */
+	uint8_t *seq0;       /* start of the unclipped sequence (owner of the allocation) */
+	int l_seq0;
+	int l_adaptor;
+	int clip5, clip3;
+} bsx_read_t;
+
+/* bi-interval: bwtintv_t (lib/aln/bwt.h:80-82) */
+typedef struct bsx_intv {
+	uint64_t x[3];
+	uint64_t info;       /* beg<<32 | end */
+} bsx_intv_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level batch jobs.  Sequences are never copied into jobs: a job names a *view*
+ *   query view : chunk read buffer offset qoff, length qlen, walking direction qdir (+1/-1),
+ *                optional complement (3-b for b<4)
+ *   target view: reference coordinate tpos in the forward-reverse space [0, 2*l_pac)
+ *                (bns_get_seq semantics, lib/aln/bntseq.c:402-422), length tlen, direction tdir
+ * element i of a view is buf[qoff + i*qdir] resp. ref(tpos + i*tdir).
+ * ------------------------------------------------------------------------------------------ */
+
+/* one strand search: mem_collect_intv (lib/aln/memchain.c:50-106) for read x parent */
+typedef struct bsx_seed_task {
+	uint32_t qoff;       /* offset of the (clipped) read in the chunk read buffer */
+	int32_t  len;
+	int32_t  parent;     /* 1: C>T read vs parent index, 0: G>A read vs daughter index */
+} bsx_seed_task_t;
+
+/* suffix-array lookup: bwt_sa (lib/aln/bwt.c:87-97) */
+typedef struct bsx_sa_job {
+	uint64_t k;
+	int32_t  parent;     /* which index */
+	int32_t  pad;
+} bsx_sa_job_t;
+
+/* banded extension: ksw_extend2 (lib/aln/ksw.c:380-479) */
+typedef struct bsx_ext_job {
+	int64_t  tpos;
+	uint32_t qoff;
+	int32_t  qlen, tlen;
+	int32_t  h0;
+	int32_t  w;
+	int32_t  end_bonus;
+	int8_t   qdir, tdir;
+	uint8_t  parent;     /* 1: ctmat, 0: gamat (lib/aln/memchain.c:654,713) */
+	uint8_t  pad;
+} bsx_ext_job_t;
+typedef struct bsx_ext_res {
+	int32_t score, qle, tle, gtle, gscore, max_off;
+} bsx_ext_res_t;
+
+/* local SW with 2nd-best + start recovery: ksw_align2 (lib/aln/ksw.c:343-365) */
+typedef struct bsx_sw_job {
+	int64_t  tpos;
+	uint32_t qoff;
+	int32_t  qlen, tlen;
+	int32_t  xtra;
+	int8_t   qdir, tdir;
+	uint8_t  qcomp;      /* complement the query view (mate rescue, lib/aln/mem_alnreg.c:411) */
+	uint8_t  use_ct;     /* 1: ctmat, 0: gamat */
+} bsx_sw_job_t;
+typedef struct bsx_sw_res {   /* kswr_t, lib/aln/ksw.h:37-43 */
+	int32_t score, te, qe, score2, te2, tb, qb;
+} bsx_sw_res_t;
+
+/* banded global alignment + traceback with the band-doubling loop of mem_alnreg_setSAM
+ * (lib/aln/mem_alnreg_format.c:63-77) and band set-up of bis_bwa_gen_cigar2
+ * (lib/aln/bwa.c:314-340) folded in.  n_try==1 && !want_cigar is the score-only call made by
+ * mem_test_reg_concatenation (lib/aln/mem_alnreg.c:92). */
+typedef struct bsx_glb_job {
+	int64_t  tpos;
+	uint32_t qoff;
+	int32_t  qlen, tlen;
+	int32_t  w0;          /* first band passed as w_ */
+	int32_t  w_max;       /* opt->w<<2 cap applied before each try */
+	int32_t  truesc;      /* stop when score >= truesc - a */
+	int32_t  n_try;       /* 3 for setSAM, 1 for the concatenation test */
+	uint32_t cigar_off;   /* where this job's CIGAR goes in the output pool (u32 units) */
+	uint32_t cigar_cap;
+	int8_t   qdir, tdir;
+	uint8_t  use_ct;
+	uint8_t  want_cigar;
+} bsx_glb_job_t;
+typedef struct bsx_glb_res {
+	int32_t score;
+	int32_t n_cigar;      /* <0: cigar_cap too small, -n_cigar needed */
+	int32_t w_used;
+	int32_t pad;
+} bsx_glb_res_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Index (host side): <base>.{par,dau}.{bwt,sa}, <base>.bis.{ann,amb,pac}[, <base>.alt]
+ * replaces bwa_idx_load_from_disk (lib/aln/bwa.c:525-554)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bsx_index bsx_index_t;
+int  bsx_index_load(const char *base, bsx_index_t **out);
+void bsx_index_free(bsx_index_t *idx);
+/* builds all seven files from a FASTA: main_biscuit_index (lib/aln/bwtindex.c:206-347) */
+int  bsx_index_build(const char *fasta, const char *base);
+int64_t bsx_index_l_pac(const bsx_index_t *idx);
+int  bsx_index_n_seqs(const bsx_index_t *idx);
+
+/* options: mem_opt_init (lib/aln/bwamem.c:77-128) + the three matrices (lib/aln/bwa.c:146-182) */
+void bsx_opt_init(bsx_opt_t *opt);
+void bsx_opt_fill_matrices(bsx_opt_t *opt);
+
+/* ------------------------------------------------------------------------------------------
+ * Device (HIP) side
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bsx_device bsx_device_t;
+/* open HIP device `ordinal`, create streams; BSX_E_NODEVICE if none */
+int  bsx_device_open(int ordinal, bsx_device_t **out);
+void bsx_device_close(bsx_device_t *dev);
+/* copy both FM indices, SA samples and pac into HBM (resident for the life of dev) */
+int  bsx_device_upload_index(bsx_device_t *dev, const bsx_index_t *idx);
+/* copy scoring matrices / penalties used by the DP kernels */
+int  bsx_device_set_opt(bsx_device_t *dev, const bsx_opt_t *opt);
+/* upload the chunk read buffer (nt4 codes of all clipped reads, concatenated) */
+int  bsx_device_set_reads(bsx_device_t *dev, const uint8_t *buf, size_t n);
+const char *bsx_device_name(const bsx_device_t *dev);
+
+/* K1+K2: all three seeding passes of mem_collect_intv + final ordering by info.
+ * out_off has n+1 entries; *out / *out_cap is a caller-owned growable array (realloc'd). */
+int bsx_seed_batch(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                   bsx_intv_t **out, int64_t *out_cap, int64_t *out_off);
+/* K3 */
+int bsx_sa_batch(bsx_device_t *dev, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos);
+/* K4 */
+int bsx_extend_batch(bsx_device_t *dev, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res);
+/* K5 */
+int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
+/* K6 */
+int bsx_global_batch(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+                     uint32_t *cigar_pool, size_t cigar_pool_len);
+
+/* device-side work counters of the last seed/sa batch (algorithmic-bytes model):
+ * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa),
+ * c[3]=bwt_sa calls */
+int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
+/* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since
+ * the last reset: k = 0 seed, 1 sa, 2 extend, 3 sw, 4 global */
+int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *launches, int reset);
+
+/* ------------------------------------------------------------------------------------------
+ * The whole path: mem_process_seqs (lib/aln/bwamem.c:432-476, declared bwamem.h:184)
+ *   reads[i].{name,comment,seq(nt4),qual,l_seq,barcode,umi} in; reads[i].sam (malloc'd) out;
+ *   PE input interleaved, n even.  Returns BSX_OK or an error instead of aborting.
+ * ------------------------------------------------------------------------------------------ */
+int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx,
+                     int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
+
+/* `biscuit align` command line: main_align (lib/aln/align.c:319-598).  SAM on `out` (stdout). */
+int bsx_align_main(int argc, char **argv);
+
+/* SAM header: bwa_print_sam_hdr (lib/aln/bwa.c:654-684); returns malloc'd text */
+char *bsx_sam_header(const bsx_index_t *idx, const char *hdr_line, const char *pg_line);
+
+const char *bsx_version(void);
+const char *bsx_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
