@@ -14,7 +14,7 @@ LIB     := biscuit_amd/libbiscuit_amd.so
 CLI     := biscuit_amd/biscuit_align
 PORT    := oracle/liboracle_port.so
 
-all: $(LIB) $(CLI) $(PORT)
+all: $(LIB) $(PORT) $(if $(wildcard biscuit_amd/csrc/cli_main.c),$(CLI))
 
 $(BUILD)/host_%.o: biscuit_amd/csrc/host/%.c $(wildcard biscuit_amd/csrc/host/*.h) include/bsx.h
 	@mkdir -p $(BUILD)

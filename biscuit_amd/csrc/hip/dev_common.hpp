@@ -1,0 +1,125 @@
+// dev_common.hpp -- device-side views of the resident index and shared helpers (gfx950 only).
+// BSX_HD functions are plain C++ so the per-lane logic can also be compiled by g++ for the
+// CPU-side kernel-logic tests (tests/test_kernel_logic_host.py); the kernels themselves are HIP.
+#pragma once
+#include <stdint.h>
+#include "bsx.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BSX_HD __host__ __device__ __forceinline__
+#define BSX_D  __device__ __forceinline__
+#else
+#define BSX_HD inline
+#define BSX_D  inline
+struct uint4 { uint32_t x, y, z, w; };
+#endif
+
+// FM index of one converted text, resident in HBM.  Block b (128 symbols) = words [16b,16b+16):
+// 4 x u64 cumulative counts then 8 x u32 of 2-bit symbols, first symbol in the top bits
+// (bwt_t, lib/aln/bwt.h:54-71,93-101).
+struct DevFmi {
+	uint64_t primary;
+	uint64_t L2[5];
+	uint64_t seq_len;
+	const uint32_t *bwt;
+	const uint64_t *sa;
+	uint32_t sa_mask;      // sa_intv - 1
+	uint32_t sa_shift;     // log2(sa_intv)
+};
+
+struct DevIndex {
+	DevFmi fmi[2];         // [1] parent, [0] daughter
+	const uint8_t *pac;
+	int64_t l_pac;
+};
+
+struct DevScoring {        // set by bsx_device_set_opt
+	int8_t ctmat[25];
+	int8_t gamat[25];
+	int32_t o_del, e_del, o_ins, e_ins, zdrop, a;
+};
+
+// reference base at forward-reverse coordinate p (bns_get_seq, lib/aln/bntseq.c:402-422)
+BSX_HD int dev_ref_base(const uint8_t *pac, int64_t l_pac, int64_t p)
+{
+	if (p >= l_pac) { p = (l_pac << 1) - 1 - p; return 3 - ((pac[p >> 2] >> ((~p & 3) << 1)) & 3); }
+	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
+}
+
+BSX_HD int dev_popc(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __popc(x);
+#else
+	return __builtin_popcount(x);
+#endif
+}
+
+// counts of A,C,G,T among symbols 0..upto (inclusive) of the 8 symbol words of one block,
+// packed as 4 x 8 bits... kept as four ints to stay simple: max 128 each.
+BSX_HD void dev_block_count(const uint32_t w[8], int upto, uint32_t cnt[4])
+{
+	uint32_t a = 0, c = 0, g = 0, t = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		int nv = upto + 1 - 16 * i;
+		nv = nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+		// top nv symbols valid
+		uint32_t valid = nv == 0 ? 0u : (0x55555555u & ~(uint32_t)((1ull << ((16 - nv) << 1)) - 1));
+		uint32_t lo = w[i] & valid, hi = (w[i] >> 1) & valid;
+		uint32_t nt = (uint32_t)dev_popc(hi & lo), ng = (uint32_t)dev_popc(hi & ~lo), nc = (uint32_t)dev_popc(lo & ~hi);
+		t += nt; g += ng; c += nc; a += (uint32_t)nv - nt - ng - nc;
+	}
+	cnt[0] = a; cnt[1] = c; cnt[2] = g; cnt[3] = t;
+}
+
+struct DevIntv { uint64_t x0, x1, x2, info; };   // bwtintv_t
+
+// Load one 64-byte block: counts (4 x u64) + symbol words.
+BSX_HD void dev_load_block(const uint32_t *bwt, uint64_t kadj, uint64_t base[4], uint32_t w[8])
+{
+	const uint4 *p = reinterpret_cast<const uint4*>(bwt + ((kadj >> 7) << 4));
+	uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+	base[0] = (uint64_t)v0.y << 32 | v0.x; base[1] = (uint64_t)v0.w << 32 | v0.z;
+	base[2] = (uint64_t)v1.y << 32 | v1.x; base[3] = (uint64_t)v1.w << 32 | v1.z;
+	w[0] = v2.x; w[1] = v2.y; w[2] = v2.z; w[3] = v2.w; w[4] = v3.x; w[5] = v3.y; w[6] = v3.z; w[7] = v3.w;
+}
+
+// bwt_2occ4 (lib/aln/bwt.c:204-236): ranks of all four symbols at k and l.
+// returns 1 when the reference would take its one-block fast path (one 64-B touch), else 0 (two).
+BSX_HD int dev_2occ4(const DevFmi &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
+{
+	const uint64_t NEG1 = ~0ull;
+	uint64_t ka = k - (k >= f.primary), la = l - (l >= f.primary);
+	uint64_t base[4]; uint32_t w[8], c[4];
+	if (k == NEG1 || l == NEG1 || (ka >> 7) != (la >> 7)) {
+		if (k == NEG1) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
+		else { dev_load_block(f.bwt, ka, base, w); dev_block_count(w, (int)(ka & 127), c); for (int i = 0; i < 4; ++i) ck[i] = base[i] + c[i]; }
+		if (l == NEG1) { cl[0] = cl[1] = cl[2] = cl[3] = 0; }
+		else { dev_load_block(f.bwt, la, base, w); dev_block_count(w, (int)(la & 127), c); for (int i = 0; i < 4; ++i) cl[i] = base[i] + c[i]; }
+		return 0;
+	}
+	dev_load_block(f.bwt, ka, base, w);
+	dev_block_count(w, (int)(ka & 127), c); for (int i = 0; i < 4; ++i) ck[i] = base[i] + c[i];
+	dev_block_count(w, (int)(la & 127), c); for (int i = 0; i < 4; ++i) cl[i] = base[i] + c[i];
+	return 1;
+}
+
+// bwt_extend (lib/aln/bwt.c:278-293), returning only the child interval for symbol c.
+BSX_HD DevIntv dev_extend(const DevFmi &f, const DevIntv &ik, int is_back, int c, uint32_t &n_slow, uint32_t &n_fast)
+{
+	uint64_t tk[4], tl[4];
+	uint64_t xa = is_back ? ik.x0 : ik.x1;   // x[!is_back]
+	uint64_t xb = is_back ? ik.x1 : ik.x0;   // x[is_back]
+	if (dev_2occ4(f, xa - 1, xa - 1 + ik.x2, tk, tl)) ++n_fast; else ++n_slow;
+	uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
+	uint64_t b3 = xb + ((xa <= f.primary && xa + ik.x2 - 1 >= f.primary) ? 1 : 0);
+	uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
+	uint64_t na = f.L2[c] + 1 + tk[c];
+	uint64_t nb = c == 3 ? b3 : c == 2 ? b2 : c == 1 ? b1 : b0;
+	uint64_t ns = c == 3 ? s3 : c == 2 ? s2 : c == 1 ? s1 : s0;
+	DevIntv o;
+	o.x0 = is_back ? na : nb; o.x1 = is_back ? nb : na; o.x2 = ns; o.info = 0;
+	return o;
+}

@@ -1,0 +1,109 @@
+// k_seed.hip -- K1+K2 (FM-index SMEM seeding) and K3 (suffix-array lookup) kernels, gfx950.
+#include <hip/hip_runtime.h>
+#include "seed_core.hpp"
+#include "kernels.h"
+
+// One lane = one strand search at a time; lanes pull the next task from a global cursor as soon
+// as they finish (reads differ a lot in seeding work), so a wave stays full until the queue drains.
+// Every trip of the outer loop issues the FM-block gathers of all 64 lanes together.
+__global__ void __launch_bounds__(256)
+k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
+       DevIntv *scratch, int list_cap, int mem_cap,
+       DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
+       long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters)
+{
+	const size_t lane_id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const size_t stride = (size_t)2 * list_cap + mem_cap;
+	SeedLane L;
+	L.bufA = scratch + lane_id * stride;
+	L.bufB = L.bufA + list_cap;
+	L.mem = L.bufB + list_cap;
+	L.list_cap = list_cap; L.mem_cap = mem_cap;
+	L.state = SD_DONE;
+	L.n_slow = L.n_fast = 0;
+	int task = -1, retired = 0;
+	uint32_t tot_slow = 0, tot_fast = 0;
+
+	for (;;) {
+		int need = 0;
+		if (!retired) {
+			for (;;) {
+				if (L.state == SD_DONE) {
+					if (task >= 0) { // publish the finished task
+						unsigned long long base = 0;
+						int n = L.mem_n;
+						if (n > 0 && !L.overflow) {
+							base = atomicAdd(out_cursor, (unsigned long long)n);
+							if (base + n <= out_cap) for (int k = 0; k < n; ++k) out[base + k] = L.mem[k];
+							else L.overflow = 1;
+						}
+						task_off[task] = (long long)base;
+						task_n[task] = L.overflow ? -n : n;
+						tot_slow += L.n_slow; tot_fast += L.n_fast;
+						task = -1;
+					}
+					unsigned int t = atomicAdd(task_cursor, 1u);
+					if (t >= (unsigned int)n_tasks) { retired = 1; break; }
+					task = (int)t;
+					L.q = reads + tasks[t].qoff; L.len = tasks[t].len; L.parent = tasks[t].parent;
+					seed_lane_begin(L);
+					if (L.len < P.min_seed_len || L.len + 1 > list_cap) { // too short to seed (memchain.c:279) / cannot fit
+						if (L.len + 1 > list_cap) L.overflow = 1;
+						L.state = SD_DONE;
+						continue;
+					}
+				}
+				need = seed_advance(L, ix.fmi[L.parent], ix.fmi[!L.parent], P);
+				if (need) break;
+			}
+		}
+		if (__all(retired)) break;
+		if (need) {
+			const DevFmi &f = L.ext_which ? ix.fmi[!L.parent] : ix.fmi[L.parent];
+			DevIntv ok = dev_extend(f, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
+			seed_post(L, ok, P);
+		}
+	}
+	// work counters for the algorithmic-bytes model: slow path = two 64-B blocks, fast = one
+	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); }
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast); }
+}
+
+// K3: bwt_sa (lib/aln/bwt.c:87-97) -- LF-walk to the next sampled rank; one lane per lookup.
+__global__ void __launch_bounds__(256)
+k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
+{
+	long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t steps = 0, calls = 0;
+	for (long long i = gid; i < n; i += (long long)gridDim.x * blockDim.x) {
+		const DevFmi &f = ix.fmi[jobs[i].parent];
+		uint64_t k = jobs[i].k, sa = 0;
+		while (k & f.sa_mask) {
+			// bwt_invPsi (bwt.c:54-60): symbol at k and its rank come from the same 64-byte block
+			if (k == f.primary) { k = 0; ++sa; ++steps; continue; }
+			uint64_t x = k - (k > f.primary);
+			uint64_t base[4]; uint32_t w[8], c4[4];
+			dev_load_block(f.bwt, x, base, w);
+			int c = (w[(x & 127) >> 4] >> ((~x & 15) << 1)) & 3;
+			dev_block_count(w, (int)(x & 127), c4);
+			k = f.L2[c] + base[c] + c4[c];
+			++sa; ++steps;
+		}
+		pos[i] = sa + f.sa[k >> f.sa_shift];
+		++calls;
+	}
+	for (int off = 32; off > 0; off >>= 1) { steps += __shfl_down(steps, off); calls += __shfl_down(calls, off); }
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[2], (unsigned long long)steps); atomicAdd(&counters[3], (unsigned long long)calls); }
+}
+
+void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
+                 DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
+                 long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters)
+{
+	hipLaunchKernelGGL(k_seed, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+	                   task_off, task_n, task_cursor, counters);
+}
+void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
+{
+	hipLaunchKernelGGL(k_sa, dim3(grid), dim3(256), 0, st, ix, jobs, n, pos, counters);
+}

@@ -1,0 +1,17 @@
+// kernels.h -- launchers of the gfx950 kernels (defined in k_*.hip), used by shim.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_common.hpp"
+#include "seed_core.hpp"
+
+void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
+                 DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
+                 long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters);
+void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters);
+// DP kernels: one wavefront per job
+void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, long long n,
+                   bsx_ext_res_t *res, int max_qlen, int max_band);
+void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, long long n,
+               bsx_sw_res_t *res, int max_qlen, int max_tlen, unsigned long long *brow_scratch, int n_slots);
+void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, long long n,
+                   bsx_glb_res_t *res, uint32_t *cigar_pool, int max_qlen, int max_band, uint8_t *z_scratch, size_t z_stride, int n_slots);

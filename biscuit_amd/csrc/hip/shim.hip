@@ -1,0 +1,285 @@
+// shim.hip -- the thin C-ABI shim between the C host code and the HIP kernels (include/bsx.h).
+// Owns: device selection, the HBM-resident index (both converted FM indices + SA samples + pac),
+// per-chunk read buffer, job/result staging, kernel timing (HIP events on the launch stream) and
+// the work counters behind the algorithmic-bytes model.  No CPU fallback: every entry point
+// returns BSX_E_NODEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+extern "C" {
+#include "bsx_core.h"
+}
+#include "kernels.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[bsx-hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return BSX_E_NODEVICE; } } while (0)
+
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t n) {
+		if (n <= cap) return BSX_OK;
+		if (p) (void)hipFree(p);
+		size_t want = n + (n >> 2) + 4096;
+		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed\n", want); return BSX_E_NOMEM; }
+		cap = want;
+		return BSX_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct bsx_device {
+	int ordinal = 0;
+	char name[256];
+	int n_cu = 0;
+	hipStream_t st = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	DevIndex ix; bool has_index = false;
+	DevBuf bwt[2], sa[2], pac;
+	DevScoring sc;
+	DevBuf reads; size_t n_reads = 0;
+	DevBuf jobs, res, scratch, out, aux, pool;
+	DevBuf small;          // counters[4] | out_cursor | task_cursor
+	double k_ms[5] = {0, 0, 0, 0, 0};
+	int64_t k_launch[5] = {0, 0, 0, 0, 0};
+};
+
+static inline unsigned long long *dev_counters(bsx_device *d) { return (unsigned long long*)d->small.p; }
+
+extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
+{
+	int n = 0;
+	*out = nullptr;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fprintf(stderr, "[bsx-hip] no HIP device available\n"); return BSX_E_NODEVICE; }
+	if (ordinal < 0 || ordinal >= n) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(ordinal));
+	bsx_device *d = new bsx_device();
+	d->ordinal = ordinal;
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, ordinal));
+	snprintf(d->name, sizeof(d->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+	d->n_cu = prop.multiProcessorCount;
+	HIPCHK(hipStreamCreate(&d->st));
+	HIPCHK(hipEventCreate(&d->ev0));
+	HIPCHK(hipEventCreate(&d->ev1));
+	if (d->small.reserve(64) != BSX_OK) return BSX_E_NOMEM;
+	HIPCHK(hipMemset(d->small.p, 0, 64));
+	memset(&d->ix, 0, sizeof(d->ix));
+	memset(&d->sc, 0, sizeof(d->sc));
+	*out = d;
+	return BSX_OK;
+}
+
+extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
+{
+	if (!d) return;
+	(void)hipSetDevice(d->ordinal);
+	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
+	d->pac.release(); d->reads.release(); d->jobs.release(); d->res.release(); d->scratch.release();
+	d->out.release(); d->aux.release(); d->pool.release(); d->small.release();
+	if (d->ev0) (void)hipEventDestroy(d->ev0);
+	if (d->ev1) (void)hipEventDestroy(d->ev1);
+	if (d->st) (void)hipStreamDestroy(d->st);
+	delete d;
+}
+
+extern "C" BSX_API const char *bsx_device_name(const bsx_device_t *d) { return d ? d->name : ""; }
+
+extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_t *idx)
+{
+	if (!d || !idx) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	for (int i = 0; i < 2; ++i) {
+		const bsx_fmi_t *f = &idx->fmi[i];
+		int rc;
+		if ((rc = d->bwt[i].reserve((size_t)f->bwt_size * 4 + 64)) != BSX_OK) return rc;
+		if ((rc = d->sa[i].reserve((size_t)f->n_sa * 8)) != BSX_OK) return rc;
+		HIPCHK(hipMemcpy(d->bwt[i].p, f->bwt, (size_t)f->bwt_size * 4, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d->sa[i].p, f->sa, (size_t)f->n_sa * 8, hipMemcpyHostToDevice));
+		DevFmi &g = d->ix.fmi[i];
+		g.primary = f->primary; for (int k = 0; k < 5; ++k) g.L2[k] = f->L2[k];
+		g.seq_len = f->seq_len; g.bwt = (const uint32_t*)d->bwt[i].p; g.sa = (const uint64_t*)d->sa[i].p;
+		g.sa_mask = (uint32_t)f->sa_intv - 1; g.sa_shift = 0;
+		while ((1 << g.sa_shift) < f->sa_intv) ++g.sa_shift;
+		if ((1 << g.sa_shift) != f->sa_intv) return BSX_E_FORMAT;
+	}
+	size_t npac = (size_t)(idx->ref.l_pac / 4 + 1);
+	int rc;
+	if ((rc = d->pac.reserve(npac + 16)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(d->pac.p, idx->pac, npac, hipMemcpyHostToDevice));
+	d->ix.pac = (const uint8_t*)d->pac.p; d->ix.l_pac = idx->ref.l_pac;
+	d->has_index = true;
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o)
+{
+	if (!d || !o) return BSX_E_ARG;
+	memcpy(d->sc.ctmat, o->ctmat, 25); memcpy(d->sc.gamat, o->gamat, 25);
+	d->sc.o_del = o->o_del; d->sc.e_del = o->e_del; d->sc.o_ins = o->o_ins; d->sc.e_ins = o->e_ins; d->sc.zdrop = o->zdrop; d->sc.a = o->a;
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_set_reads(bsx_device_t *d, const uint8_t *buf, size_t n)
+{
+	if (!d) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc;
+	if ((rc = d->reads.reserve(n + 64)) != BSX_OK) return rc;
+	if (n) HIPCHK(hipMemcpyAsync(d->reads.p, buf, n, hipMemcpyHostToDevice, d->st));
+	HIPCHK(hipStreamSynchronize(d->st));
+	d->n_reads = n;
+	return BSX_OK;
+}
+
+// time one kernel (already enqueued between ev0/ev1 on d->st)
+static int finish_timed(bsx_device *d, int k)
+{
+	float ms = 0;
+	HIPCHK(hipEventSynchronize(d->ev1));
+	HIPCHK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+	d->k_ms[k] += ms; d->k_launch[k] += 1;
+	HIPCHK(hipGetLastError());
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int reset)
+{
+	if (!d) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	HIPCHK(hipMemcpy(c, d->small.p, 32, hipMemcpyDeviceToHost));
+	if (reset) HIPCHK(hipMemset(d->small.p, 0, 32));
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
+{
+	if (!d || k < 0 || k >= 5) return BSX_E_ARG;
+	if (total_ms) *total_ms = d->k_ms[k];
+	if (launches) *launches = d->k_launch[k];
+	if (reset) { d->k_ms[k] = 0; d->k_launch[k] = 0; }
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1+K2
+// ------------------------------------------------------------------------------------------
+static bool intv_info_lt(const bsx_intv_t &a, const bsx_intv_t &b) { return a.info < b.info; }
+
+extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                                      bsx_intv_t **out, int64_t *out_cap, int64_t *out_off)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) { out_off[0] = 0; return BSX_OK; }
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc, max_len = 0;
+	for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, tasks[i].len);
+	SeedParams P;
+	P.min_seed_len = opt->min_seed_len;
+	P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
+	P.split_width = opt->split_width;
+	P.max_mem_intv = (int)opt->max_mem_intv;
+	P.start_width = (opt->flag & BSX_F_SELF_OVLP) ? 2 : 1;
+
+	std::vector<long long> h_off((size_t)n);
+	std::vector<int> h_n((size_t)n);
+	std::vector<int64_t> todo;           // task indices still to run (all, then the overflowed ones)
+	std::vector<bsx_seed_task_t> sub;
+	int mem_cap = std::max(64, max_len);
+	unsigned long long dense_cap = (unsigned long long)n * 24 + 4096;
+	std::vector<std::vector<bsx_intv_t>> redo_results;
+	std::vector<int64_t> redo_index;
+	std::vector<bsx_intv_t> h_dense;
+
+	for (int round = 0; round < 6; ++round) {
+		const bsx_seed_task_t *cur = tasks; int64_t cn = n;
+		if (round > 0) {
+			if (todo.empty()) break;
+			sub.resize(todo.size());
+			for (size_t i = 0; i < todo.size(); ++i) sub[i] = tasks[todo[i]];
+			cur = sub.data(); cn = (int64_t)sub.size();
+			mem_cap *= 8; dense_cap = (unsigned long long)cn * mem_cap + 4096;
+		}
+		int list_cap = max_len + 2;
+		int waves = (int)std::min<int64_t>((cn + 63) / 64, (int64_t)d->n_cu * 16);
+		int grid = (waves + 3) / 4;
+		size_t lanes = (size_t)grid * 256;
+		size_t scratch_bytes = lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv);
+		if ((rc = d->scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
+		if ((rc = d->jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
+		if ((rc = d->out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
+		if ((rc = d->aux.reserve((size_t)cn * 12 + 64)) != BSX_OK) return rc;
+		long long *d_off = (long long*)d->aux.p; int *d_n = (int*)((char*)d->aux.p + (size_t)cn * 8);
+		unsigned long long *ctr = dev_counters(d);
+		HIPCHK(hipMemcpyAsync(d->jobs.p, cur, (size_t)cn * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, d->st));
+		HIPCHK(hipMemsetAsync(ctr + 4, 0, 16, d->st));   // out_cursor (u64) + task_cursor (u32)
+		HIPCHK(hipEventRecord(d->ev0, d->st));
+		launch_seed(d->st, grid, d->ix, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)cn, P,
+		            (DevIntv*)d->scratch.p, list_cap, mem_cap, (DevIntv*)d->out.p, dense_cap, ctr + 4, d_off, d_n,
+		            (unsigned int*)(ctr + 5), ctr);
+		HIPCHK(hipEventRecord(d->ev1, d->st));
+		if ((rc = finish_timed(d, 0)) != BSX_OK) return rc;
+		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
+		unsigned long long used = 0;
+		HIPCHK(hipMemcpy(r_off.data(), d_off, (size_t)cn * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(r_n.data(), d_n, (size_t)cn * 4, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&used, ctr + 4, 8, hipMemcpyDeviceToHost));
+		if (used > dense_cap) used = dense_cap;
+		std::vector<bsx_intv_t> dense((size_t)used);
+		if (used) HIPCHK(hipMemcpy(dense.data(), d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+		std::vector<int64_t> next;
+		if (round == 0) {
+			h_dense.swap(dense);
+			for (int64_t i = 0; i < n; ++i) { h_off[i] = r_off[i]; h_n[i] = r_n[i]; if (r_n[i] < 0) next.push_back(i); }
+		} else {
+			for (int64_t i = 0; i < cn; ++i) {
+				if (r_n[i] < 0) { next.push_back(todo[i]); continue; }
+				redo_index.push_back(todo[i]);
+				redo_results.emplace_back(dense.begin() + r_off[i], dense.begin() + r_off[i] + r_n[i]);
+				h_n[todo[i]] = r_n[i];
+			}
+		}
+		todo.swap(next);
+		if (todo.empty()) break;
+	}
+	if (!todo.empty()) { fprintf(stderr, "[bsx-hip] seed_batch: %zu tasks still overflow\n", todo.size()); return BSX_E_INTERNAL; }
+
+	// assemble CSR in task order; each list ordered by info (ks_introsort(mem_intv), memchain.c:105 --
+	// records with equal info are identical, so any sort reproduces the reference order)
+	std::vector<int64_t> redo_slot((size_t)0);
+	int64_t tot = 0;
+	for (int64_t i = 0; i < n; ++i) { out_off[i] = tot; tot += h_n[i]; }
+	out_off[n] = tot;
+	if (*out_cap < tot) { *out_cap = tot + (tot >> 2) + 16; *out = (bsx_intv_t*)realloc(*out, sizeof(bsx_intv_t) * (size_t)*out_cap); }
+	std::vector<int64_t> redo_of((size_t)0);
+	if (!redo_index.empty()) { redo_of.assign((size_t)n, -1); for (size_t r = 0; r < redo_index.size(); ++r) redo_of[redo_index[r]] = (int64_t)r; }
+	for (int64_t i = 0; i < n; ++i) {
+		bsx_intv_t *dst = *out + out_off[i];
+		if (!redo_of.empty() && redo_of[i] >= 0) std::copy(redo_results[redo_of[i]].begin(), redo_results[redo_of[i]].end(), dst);
+		else if (h_n[i] > 0) memcpy(dst, h_dense.data() + h_off[i], sizeof(bsx_intv_t) * (size_t)h_n[i]);
+		if (h_n[i] > 1) std::sort(dst, dst + h_n[i], intv_info_lt);
+	}
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3
+// ------------------------------------------------------------------------------------------
+extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) return BSX_OK;
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc;
+	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_sa_job_t))) != BSX_OK) return rc;
+	if ((rc = d->res.reserve((size_t)n * 8)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_sa_job_t), hipMemcpyHostToDevice, d->st));
+	int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)d->n_cu * 8);
+	HIPCHK(hipEventRecord(d->ev0, d->st));
+	launch_sa(d->st, grid, d->ix, (const bsx_sa_job_t*)d->jobs.p, (long long)n, (uint64_t*)d->res.p, dev_counters(d));
+	HIPCHK(hipEventRecord(d->ev1, d->st));
+	if ((rc = finish_timed(d, 1)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(pos, d->res.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	return BSX_OK;
+}

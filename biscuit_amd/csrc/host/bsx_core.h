@@ -74,8 +74,8 @@ static inline int64_t bsx_depos(int64_t l_pac, int64_t pos, int *is_rev)
 {
 	return (*is_rev = (pos >= l_pac)) ? (l_pac << 1) - 1 - pos : pos;
 }
-int bsx_pos2rid(const bsx_refmeta_t *r, int64_t pos_f);
-int bsx_intv2rid(const bsx_refmeta_t *r, int64_t rb, int64_t re);
+BSX_API int bsx_pos2rid(const bsx_refmeta_t *r, int64_t pos_f);
+BSX_API int bsx_intv2rid(const bsx_refmeta_t *r, int64_t rb, int64_t re);
 /* base at forward-reverse coordinate p in [0, 2*l_pac) (bns_get_seq, bntseq.c:402-422) */
 static inline int bsx_ref_base(int64_t l_pac, const uint8_t *pac, int64_t p)
 {
@@ -84,30 +84,30 @@ static inline int bsx_ref_base(int64_t l_pac, const uint8_t *pac, int64_t p)
 	return 3 - bsx_pac_get(pac, p);
 }
 /* clamp [*beg,*end) to the contig containing mid; returns rid (bns_fetch_seq, bntseq.c:428-452) */
-int bsx_fetch_span(const bsx_refmeta_t *r, int64_t *beg, int64_t mid, int64_t *end);
+BSX_API int bsx_fetch_span(const bsx_refmeta_t *r, int64_t *beg, int64_t mid, int64_t *end);
 
 /* ---------- sorting: exact re-implementation of the reference's introsort permutation ---------- */
 typedef int (*bsx_lt_fn)(const void *a, const void *b);   /* returns a < b */
-void bsx_introsort(void *base, size_t n, size_t width, bsx_lt_fn lt);
-void bsx_introsort_u64(size_t n, uint64_t *a);
-void bsx_introsort_i64(size_t n, int64_t *a);
-uint64_t bsx_hash64(uint64_t key);
+BSX_API void bsx_introsort(void *base, size_t n, size_t width, bsx_lt_fn lt);
+BSX_API void bsx_introsort_u64(size_t n, uint64_t *a);
+BSX_API void bsx_introsort_i64(size_t n, int64_t *a);
+BSX_API uint64_t bsx_hash64(uint64_t key);
 
 /* ---------- B-tree with the reference's node geometry (t = 3) ---------- */
 typedef struct bsx_btree bsx_btree_t;
-bsx_btree_t *bsx_bt_new(void);
-void bsx_bt_clear(bsx_btree_t *t);
-void bsx_bt_free(bsx_btree_t *t);
-int  bsx_bt_size(const bsx_btree_t *t);
-void bsx_bt_put(bsx_btree_t *t, int64_t pos, int32_t id);
+BSX_API bsx_btree_t *bsx_bt_new(void);
+BSX_API void bsx_bt_clear(bsx_btree_t *t);
+BSX_API void bsx_bt_free(bsx_btree_t *t);
+BSX_API int  bsx_bt_size(const bsx_btree_t *t);
+BSX_API void bsx_bt_put(bsx_btree_t *t, int64_t pos, int32_t id);
 /* id of the key kb_intervalp would return as `lower` (equal key or predecessor), or -1 */
-int32_t bsx_bt_lower(const bsx_btree_t *t, int64_t pos);
+BSX_API int32_t bsx_bt_lower(const bsx_btree_t *t, int64_t pos);
 /* in-order ids; returns count */
-int  bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids);
+BSX_API int  bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids);
 
 /* ---------- thread pool (kt_for equivalent; results never depend on scheduling) ---------- */
 typedef void (*bsx_for_fn)(void *data, long i, int tid);
-void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n);
+BSX_API void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n);
 
 /* ---------- device backend: the batch seams of include/bsx.h behind one vtable ---------- */
 typedef struct bsx_backend {

@@ -17,6 +17,8 @@
 extern "C" {
 #endif
 
+#define BSX_EXPORT __attribute__((visibility("default")))
+
 #define BSX_OK            0
 #define BSX_E_NODEVICE  (-1)   /* no HIP device / HIP runtime error */
 #define BSX_E_ARG       (-2)
@@ -256,8 +258,8 @@ int bsx_align_main(int argc, char **argv);
 /* SAM header: bwa_print_sam_hdr (lib/aln/bwa.c:654-684); returns malloc'd text */
 char *bsx_sam_header(const bsx_index_t *idx, const char *hdr_line, const char *pg_line);
 
-const char *bsx_version(void);
-const char *bsx_strerror(int code);
+BSX_EXPORT const char *bsx_version(void);
+BSX_EXPORT const char *bsx_strerror(int code);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,52 @@
+// tests/host_kernel_logic.cpp -- compiles the per-lane state machine of the seed kernel
+// (biscuit_amd/csrc/hip/seed_core.hpp, the code k_seed runs per lane) with g++ so its logic can be
+// checked on a machine without a GPU.  Test infrastructure only.
+#include <vector>
+#include <algorithm>
+#include <cstring>
+extern "C" {
+#include "bsx_core.h"
+}
+#include "seed_core.hpp"
+
+static DevFmi mk(const bsx_fmi_t *f)
+{
+	DevFmi g; g.primary = f->primary; for (int k = 0; k < 5; ++k) g.L2[k] = f->L2[k];
+	g.seq_len = f->seq_len; g.bwt = f->bwt; g.sa = f->sa; g.sa_mask = f->sa_intv - 1; g.sa_shift = 5;
+	return g;
+}
+
+extern "C" int hostlogic_seed(const bsx_index_t *idx, const bsx_opt_t *opt, const uint8_t *reads, int64_t n, const bsx_seed_task_t *tasks,
+                              int mem_cap, uint64_t *out, int64_t out_cap, int64_t *out_off, uint64_t ctr[2])
+{
+	DevFmi F[2] = { mk(&idx->fmi[0]), mk(&idx->fmi[1]) };
+	SeedParams P;
+	P.min_seed_len = opt->min_seed_len; P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
+	P.split_width = opt->split_width; P.max_mem_intv = (int)opt->max_mem_intv; P.start_width = (opt->flag & BSX_F_SELF_OVLP) ? 2 : 1;
+	int64_t tot = 0;
+	ctr[0] = ctr[1] = 0;
+	for (int64_t t = 0; t < n; ++t) {
+		int len = tasks[t].len, list_cap = len + 2;
+		std::vector<DevIntv> A(list_cap), B(list_cap), M(mem_cap);
+		SeedLane L;
+		L.bufA = A.data(); L.bufB = B.data(); L.mem = M.data(); L.list_cap = list_cap; L.mem_cap = mem_cap;
+		L.q = reads + tasks[t].qoff; L.len = len; L.parent = tasks[t].parent;
+		seed_lane_begin(L);
+		out_off[t] = tot;
+		if (len >= P.min_seed_len) {
+			while (seed_advance(L, F[L.parent], F[!L.parent], P)) {
+				const DevFmi &f = L.ext_which ? F[!L.parent] : F[L.parent];
+				DevIntv ok = dev_extend(f, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
+				seed_post(L, ok, P);
+			}
+			if (L.overflow) return -1;
+			std::sort(M.begin(), M.begin() + L.mem_n, [](const DevIntv &a, const DevIntv &b) { return a.info < b.info; });
+			if (tot + L.mem_n > out_cap) return -2;
+			memcpy(out + tot * 4, M.data(), sizeof(DevIntv) * L.mem_n);
+			tot += L.mem_n;
+			ctr[0] += 2ull * L.n_slow; ctr[1] += L.n_fast;
+		}
+	}
+	out_off[n] = tot;
+	return 0;
+}
