@@ -1,0 +1,188 @@
+// k_global.hip -- K6: banded global alignment with traceback, ksw_global2 (lib/aln/ksw.c:504-606),
+// wrapped in the band set-up of bis_bwa_gen_cigar2 (lib/aln/bwa.c:314-340) and the band-doubling
+// retry loop of mem_alnreg_setSAM (lib/aln/mem_alnreg_format.c:63-77).
+//
+// One wavefront per job.  As in ksw_extend2, gaps open from M = H(i-1,j-1)+s, so F along a row is a
+// max-plus prefix scan and the 64 lanes sweep the band [i-w, i+w] of one target row per step.
+// H/E rows sit in LDS in the reference's in-place eh[] layout; the 1-byte/cell direction matrix
+// z[tlen][n_col] is streamed to a per-wave slab in HBM (it does not fit LDS for long reads) and
+// walked back by lane 0.
+#include <hip/hip_runtime.h>
+#include "dev_common.hpp"
+#include "wave.hpp"
+#include "kernels.h"
+
+#define G_MINUS_INF (-0x40000000)
+#define G_INACTIVE  (-0x7f000000)
+
+template <int NC>
+__global__ void __launch_bounds__(256)
+k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order, long long n,
+         bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap)
+{
+	extern __shared__ int32_t lds[];
+	const int lane = wave_lane();
+	const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1;
+	int32_t *H = lds + wave * stride;
+	int32_t *E = H + (qcap + 2);
+	uint8_t *qb = reinterpret_cast<uint8_t*>(E + (qcap + 2));
+	uint8_t *z = zscratch + ((size_t)blockIdx.x * wpb + wave) * zstride;
+
+	for (long long jj = (long long)blockIdx.x * wpb + wave; jj < n; jj += (long long)gridDim.x * wpb) {
+		const int job = order[jj];
+		const bsx_glb_job_t J = jobs[job];
+		const int qlen = J.qlen, tlen = J.tlen;
+		const int8_t *mat = J.use_ct ? sc.ctmat : sc.gamat;
+		const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
+		const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+		uint32_t *cig = pool + J.cigar_off;
+		for (int j = lane; j < qlen; j += 64) qb[j] = reads[(long long)J.qoff + (long long)j * J.qdir];
+		WAVE_SYNC();
+		int w_ = J.w0, score = 0, last_sc = -(1 << 30), n_cigar = 0, w_used = 0;
+		for (int it = 0; it < J.n_try; ++it, w_ <<= 1, last_sc = score) {
+			w_ = w_ < J.w_max ? w_ : J.w_max;
+			w_used = w_;
+			if (qlen == tlen && w_ == 0) { // no gap: one M run, score by direct comparison (bwa.c:314-322)
+				int part = 0;
+				for (int k = lane; k < qlen; k += 64) {
+					const int t = dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)k * J.tdir);
+					part += mat[t * 5 + qb[k]];
+				}
+				score = wave_sum_i32(part);
+				if (J.want_cigar) { if (J.cigar_cap >= 1) { if (lane == 0) cig[0] = (uint32_t)qlen << 4; n_cigar = 1; } else n_cigar = -1; }
+			} else {
+				// band (bwa.c:326-335)
+				int dl = tlen - qlen; dl = dl < 0 ? -dl : dl;
+				int max_ins = (int)((double)(((qlen + 1) >> 1) * mat[0] - o_ins) / e_ins + 1.);
+				int max_del = (int)((double)(((qlen + 1) >> 1) * mat[0] - o_del) / e_del + 1.);
+				int max_gap = max_ins > max_del ? max_ins : max_del;
+				max_gap = max_gap > 1 ? max_gap : 1;
+				int w = (max_gap + dl + 1) >> 1;
+				w = w < w_ ? w : w_;
+				{ const int min_w = dl + 3; w = w > min_w ? w : min_w; }
+				const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+				// first row (ksw.c:522-526)
+				for (int j = lane; j <= qlen; j += 64) {
+					if (j == 0) { H[0] = 0; E[0] = G_MINUS_INF; }
+					else if (j <= w) { H[j] = -(o_ins + e_ins * j); E[j] = G_MINUS_INF; }
+					else { H[j] = G_MINUS_INF; E[j] = G_MINUS_INF; }
+				}
+				WAVE_SYNC();
+				int tb_reg = 4;
+				for (int i = 0; i < tlen; ++i) {
+					if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
+					const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+					const int s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
+					const int beg = i > w ? i - w : 0;
+					const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+					const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : G_MINUS_INF;
+					if (beg < end) {
+						const int nch = (end - beg + 63) >> 6;
+						int M[NC], Ev[NC];
+#pragma unroll
+						for (int c = 0; c < NC; ++c) {
+							M[c] = G_MINUS_INF; Ev[c] = G_MINUS_INF;
+							if (c < nch) {
+								const int j = beg + (c << 6) + lane;
+								if (j < end) {
+									const int q = qb[j];
+									const int s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : q == 3 ? s3 : s4;
+									M[c] = H[j] + s; Ev[c] = E[j];
+								}
+							}
+						}
+						WAVE_SYNC();
+						int carry = G_INACTIVE;
+						uint8_t *zi = z + (size_t)i * n_col;
+#pragma unroll
+						for (int c = 0; c < NC; ++c) {
+							if (c < nch) {
+								const int j = beg + (c << 6) + lane;
+								const bool act = j < end;
+								const int g = act ? M[c] - oe_ins + j * e_ins : G_INACTIVE;
+								const int incl = wave_scan_max_incl(g);
+								int excl = wave_prev(incl, G_INACTIVE);
+								excl = excl > carry ? excl : carry;
+								{ const int tot = __shfl(incl, 63); carry = carry > tot ? carry : tot; }
+								const int f = j == beg ? G_MINUS_INF : excl - (j - 1) * e_ins;
+								if (act) {
+									const int m = M[c], e0 = Ev[c];
+									int d = m >= e0 ? 0 : 1;
+									int h = m >= e0 ? m : e0;
+									d = h >= f ? d : 2;
+									h = h >= f ? h : f;
+									int tt = m - oe_del, e = e0 - e_del;
+									d |= e > tt ? 1 << 2 : 0;
+									e = e > tt ? e : tt;
+									tt = m - oe_ins;
+									d |= (f - e_ins) > tt ? 2 << 4 : 0;
+									E[j] = e;
+									H[j + 1] = h;
+									if (j == beg) H[beg] = h1_init;
+									if (j == end - 1) E[end] = G_MINUS_INF;
+									if (J.want_cigar) zi[j - beg] = (uint8_t)d;
+								}
+							}
+						}
+						WAVE_SYNC();
+					} else {
+						if (lane == 0) { H[end] = h1_init; E[end] = G_MINUS_INF; }
+						WAVE_SYNC();
+					}
+				}
+				score = H[qlen];
+				if (J.want_cigar) { // traceback (ksw.c:587-604), lane 0
+					__threadfence_block();
+					WAVE_SYNC();
+					int n = 0;
+					if (lane == 0) {
+						int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+						uint32_t cur = 0; // pending run: len<<4|op
+						const int cap = (int)J.cigar_cap;
+						#define GPUSH(op, len) do { if (cur != 0 && (cur & 0xf) == (uint32_t)(op)) cur += (uint32_t)(len) << 4; \
+							else { if (cur != 0) { if (n < cap) cig[n] = cur; ++n; } cur = (uint32_t)(len) << 4 | (uint32_t)(op); } } while (0)
+						while (i >= 0 && k >= 0) {
+							const int d = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))];
+							which = d >> (which << 1) & 3;
+							if (which == 0) { GPUSH(0, 1); --i; --k; }
+							else if (which == 1) { GPUSH(2, 1); --i; }
+							else { GPUSH(1, 1); --k; }
+						}
+						if (i >= 0) GPUSH(2, i + 1);
+						if (k >= 0) GPUSH(1, k + 1);
+						if (cur != 0) { if (n < cap) cig[n] = cur; ++n; }
+						#undef GPUSH
+						if (n <= cap) for (int a = 0; a < n >> 1; ++a) { const uint32_t tmp = cig[a]; cig[a] = cig[n - 1 - a]; cig[n - 1 - a] = tmp; }
+						else n = -n;
+					}
+					n_cigar = __shfl(n, 0);
+				}
+			}
+			if (J.n_try == 1) break;
+			if (score == last_sc) break;
+			if (w_ == J.w_max) break;
+			if (score >= J.truesc - sc.a) break;
+		}
+		if (lane == 0) { bsx_glb_res_t r; r.score = score; r.n_cigar = n_cigar; r.w_used = w_used; r.pad = 0; res[job] = r; }
+		WAVE_SYNC();
+	}
+}
+
+template <int NC>
+static void launch_glb_nc(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
+                          long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks, int wpb)
+{
+	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1;
+	const size_t lds = (size_t)wpb * stride * 4;
+	if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_global<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(k_global<NC>, dim3(blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap);
+}
+
+void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
+                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb)
+{
+	if (nc <= 4) launch_glb_nc<4>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
+	else if (nc <= 16) launch_glb_nc<16>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
+	else launch_glb_nc<32>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
+}

@@ -1,0 +1,190 @@
+// k_sw.hip -- K5: local Smith-Waterman with 2nd-best score and start recovery, ksw_align2
+// (lib/aln/ksw.c:343-365) over ksw_u8 / ksw_i16 (ksw.c:111-334).  Used for mate rescue
+// (lib/aln/mem_alnreg.c:395-493) and the long-read seed filter (lib/aln/memchain.c:501-535).
+//
+// One wavefront per job, H/E rows held in registers (lane l owns query columns l, l+64, ...), one
+// target row per step.  The reference is Farrar's striped SSE2 kernel; what it computes is a
+// row-wise DP over the query padded with zero-scoring columns to slen*p (p = 16 lanes for u8,
+// 8 for i16) in which
+//   * F(i,j) is a max-plus prefix scan of the row (the lazy-F loop converges to it), and
+//   * E(i+1,j) opens from the H value the striped main loop had *before* lazy-F, i.e. with F
+//     restricted to the stripe [k*slen,(k+1)*slen) containing j  (ksw.c:160-169).
+// Both scans (full and stripe-segmented) are wave scans; u8 saturation/early stop (ksw.c:205,209),
+// the b[] run merging behind score2/te2 (ksw.c:191-200,218-226) and the reverse pass with
+// KSW_XSTOP (ksw.c:356-364) are reproduced exactly.
+#include <hip/hip_runtime.h>
+#include "dev_common.hpp"
+#include "wave.hpp"
+#include "kernels.h"
+
+struct SwPass { int score, te, qe, score2, te2; };
+
+template <int NC>
+__device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat, int is_u8, int qlen, const int (&qv)[NC],
+                                          int tlen, long long tpos, int tdir, int te_rev,
+                                          int o_del, int e_del, int o_ins, int e_ins, int xtra,
+                                          unsigned long long *b, int lane)
+{
+	const int p = is_u8 ? 16 : 8, slen = (qlen + p - 1) / p, Q = slen * p, nch = (Q + 63) >> 6;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	const int minsc = (xtra & BSX_KSW_XSUBO) ? (xtra & 0xffff) : 0x10000;
+	const int endsc = (xtra & BSX_KSW_XSTOP) ? (xtra & 0xffff) : 0x10000;
+	int shift = 127, mx = 0;
+	for (int a = 0; a < 25; ++a) { shift = mat[a] < shift ? mat[a] : shift; mx = mat[a] > mx ? mat[a] : mx; }
+	shift = (int)(uint8_t)(256 - (int)(uint8_t)shift);   // ksw.c:84-88
+	int Hp[NC], Hc[NC], E[NC], Hm[NC];
+#pragma unroll
+	for (int c = 0; c < NC; ++c) { Hp[c] = 0; Hc[c] = 0; E[c] = 0; Hm[c] = 0; }
+	int gmax = 0, te = -1, n_b = 0;
+	unsigned long long b_last = 0;
+	int tb_reg = 4;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) {
+			const int ii = i + lane;
+			const long long src = (ii <= te_rev) ? (long long)(te_rev - ii) : (long long)ii;  // reversed prefix in pass 2
+			tb_reg = ii < tlen ? dev_ref_base(ix.pac, ix.l_pac, tpos + src * tdir) : 4;
+		}
+		const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+		const int s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
+		int rowmax = 0, pm_full = NEG_BIG, carry_seg = NEG_BIG;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			if (c < nch) {
+				const int j = (c << 6) + lane;
+				const bool act = j < Q;
+				int d = __shfl_up(Hp[c], 1);
+				if (lane == 0) d = 0;
+				if (c > 0) { const int pv = __shfl(Hp[c > 0 ? c - 1 : 0], 63); if (lane == 0) d = pv; }
+				const int q = qv[c];
+				const int s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : q == 3 ? s3 : q == 4 ? s4 : 0;
+				int h;
+				if (is_u8) { h = d + s + shift; h = h > 255 ? 255 : h; h -= shift; h = h < 0 ? 0 : h; }
+				else { h = d + s; h = h > 32767 ? 32767 : h; }
+				h = h > E[c] ? h : E[c];
+				int tins = h - oe_ins; tins = tins > 0 ? tins : 0;
+				const int g = act ? tins + j * e_ins : NEG_BIG;
+				// full-row F
+				const int incl = wave_scan_max_incl(g);
+				int excl = wave_prev(incl, NEG_BIG);
+				excl = excl > pm_full ? excl : pm_full;
+				{ const int tot = __shfl(incl, 63); pm_full = pm_full > tot ? pm_full : tot; }
+				int ff = j == 0 ? 0 : excl - (j - 1) * e_ins;
+				ff = ff > 0 ? ff : 0;
+				// stripe-restricted F (restarts at every multiple of slen)
+				const int head = (act && (j % slen) == 0) ? 1 : 0;
+				int hflag = head;
+				int sincl = wave_segscan_max_incl(g, hflag);
+				if (!hflag) sincl = sincl > carry_seg ? sincl : carry_seg;
+				const int sexcl = wave_prev(sincl, carry_seg);
+				carry_seg = __shfl(sincl, 63);
+				int fs = head ? 0 : sexcl - (j - 1) * e_ins;
+				fs = fs > 0 ? fs : 0;
+				const int hpre = h > fs ? h : fs;
+				const int hh = h > ff ? h : ff;
+				int e = E[c] - e_del; e = e > 0 ? e : 0;
+				int tdel = hpre - oe_del; tdel = tdel > 0 ? tdel : 0;
+				e = e > tdel ? e : tdel;
+				E[c] = act ? e : 0;
+				Hc[c] = act ? hh : 0;
+				rowmax = rowmax > Hc[c] ? rowmax : Hc[c];
+			}
+		}
+		const int imax = wave_max_i32(rowmax);
+		if (imax >= minsc) { // b[]: best (score,row) of each run of consecutive rows (ksw.c:192-200)
+			if (n_b == 0 || (int)(uint32_t)b_last + 1 != i) { b_last = (unsigned long long)imax << 32 | (uint32_t)i; ++n_b; }
+			else if ((int)(b_last >> 32) < imax) b_last = (unsigned long long)imax << 32 | (uint32_t)i;
+			if (lane == 0) b[n_b - 1] = b_last;
+		}
+#pragma unroll
+		for (int c = 0; c < NC; ++c) Hp[c] = Hc[c];
+		if (imax > gmax) {
+			gmax = imax; te = i;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) Hm[c] = Hc[c];
+			if ((is_u8 && gmax + shift >= 255) || gmax >= endsc) break;
+		}
+	}
+	SwPass r;
+	r.score = is_u8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+	r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;
+	if (!is_u8 || r.score != 255) {
+		int lm = -1, lj = 0x7fffffff;
+#pragma unroll
+		for (int c = 0; c < NC; ++c) if (c < nch) { const int j = (c << 6) + lane; if (j < Q && Hm[c] > lm) { lm = Hm[c]; lj = j; } }
+		const int m = wave_max_i32(lm);
+		r.qe = wave_min_i32(lm == m ? lj : 0x7fffffff);   // smallest query index holding the maximum (ksw.c:212-216)
+		if (n_b > 0) {
+			WAVE_SYNC();
+			const int rad = (r.score + mx - 1) / mx, low = te - rad, high = te + rad;
+			int bs = -1, bi = 0x7fffffff;
+			for (int k = lane; k < n_b; k += 64) {
+				const unsigned long long v = b[k];
+				const int e = (int)(uint32_t)v, sc = (int)(v >> 32);
+				if ((e < low || e > high) && sc > bs) { bs = sc; bi = k; }
+			}
+			const int ms = wave_max_i32(bs);
+			if (ms >= 0) {
+				const int mi = wave_min_i32(bs == ms ? bi : 0x7fffffff);  // first entry with that score (ksw.c:222-225)
+				r.score2 = ms; r.te2 = (int)(uint32_t)b[mi];
+			}
+			WAVE_SYNC();
+		}
+	}
+	return r;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256)
+k_sw(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order, long long n,
+     bsx_sw_res_t *res, unsigned long long *bscratch, int bcap)
+{
+	const int lane = wave_lane();
+	const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+	unsigned long long *b = bscratch + ((size_t)blockIdx.x * wpb + wave) * (size_t)bcap;
+	for (long long jj = (long long)blockIdx.x * wpb + wave; jj < n; jj += (long long)gridDim.x * wpb) {
+		const int job = order[jj];
+		const bsx_sw_job_t J = jobs[job];
+		const int8_t *mat = J.use_ct ? sc.ctmat : sc.gamat;
+		const int is_u8 = (J.xtra & BSX_KSW_XBYTE) ? 1 : 0;
+		int qv[NC];
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int j = (c << 6) + lane;
+			int v = 5; // padding column: scores 0 against everything (ksw.c:96,105)
+			if (j < J.qlen) { v = reads[(long long)J.qoff + (long long)j * J.qdir]; if (J.qcomp) v = v < 4 ? 3 - v : 4; }
+			qv[c] = v;
+		}
+		SwPass r = sw_pass<NC>(ix, mat, is_u8, J.qlen, qv, J.tlen, J.tpos, J.tdir, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, J.xtra, b, lane);
+		bsx_sw_res_t o;
+		o.score = r.score; o.te = r.te; o.qe = r.qe; o.score2 = r.score2; o.te2 = r.te2; o.tb = -1; o.qb = -1;
+		const bool second = (J.xtra & BSX_KSW_XSTART) && !((J.xtra & BSX_KSW_XSUBO) && r.score < (J.xtra & 0xffff)) && r.qe >= 0;
+		if (second) { // reverse pass on the prefixes ending at (qe, te) (ksw.c:357-364)
+			int q2[NC];
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				const int j = (c << 6) + lane;
+				int v = 5;
+				if (j <= r.qe) { v = reads[(long long)J.qoff + (long long)(r.qe - j) * J.qdir]; if (J.qcomp) v = v < 4 ? 3 - v : 4; }
+				q2[c] = v;
+			}
+			SwPass rr = sw_pass<NC>(ix, mat, is_u8, r.qe + 1, q2, J.tlen, J.tpos, J.tdir, r.te, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins,
+			                        BSX_KSW_XSTOP | r.score, b, lane);
+			if (r.score == rr.score) { o.tb = r.te - rr.te; o.qb = r.qe - rr.qe; }
+		}
+		if (lane == 0) res[job] = o;
+	}
+}
+
+template <int NC>
+static void launch_sw_nc(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
+                         long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks)
+{
+	hipLaunchKernelGGL(k_sw<NC>, dim3(blocks), dim3(256), 0, st, ix, sc, reads, jobs, order, n, res, bscratch, bcap);
+}
+
+void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
+               long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc)
+{
+	if (nc <= 4) launch_sw_nc<4>(st, ix, sc, reads, jobs, order, n, res, bscratch, bcap, blocks);
+	else launch_sw_nc<16>(st, ix, sc, reads, jobs, order, n, res, bscratch, bcap, blocks);
+}

@@ -9,9 +9,9 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters);
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters);
 // DP kernels: one wavefront per job
-void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, long long n,
-                   bsx_ext_res_t *res, int max_qlen, int max_band);
-void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, long long n,
-               bsx_sw_res_t *res, int max_qlen, int max_tlen, unsigned long long *brow_scratch, int n_slots);
-void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, long long n,
-                   bsx_glb_res_t *res, uint32_t *cigar_pool, int max_qlen, int max_band, uint8_t *z_scratch, size_t z_stride, int n_slots);
+void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,
+                   long long n, bsx_ext_res_t *res, int qcap, int nc, int n_cu);
+void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
+               long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc);
+void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
+                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb);

@@ -283,3 +283,175 @@ extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job
 	HIPCHK(hipMemcpy(pos, d->res.p, (size_t)n * 8, hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// K4
+// ------------------------------------------------------------------------------------------
+extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) return BSX_OK;
+	HIPCHK(hipSetDevice(d->ordinal));
+	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}
+	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 512, 2048}, NCS[3] = {4, 8, 32};
+	std::vector<int> order[3];
+	for (int64_t i = 0; i < n; ++i) {
+		const bsx_ext_job_t &j = jobs[i];
+		if (j.qlen <= 0 || j.tlen < 0 || j.h0 <= 0) { fprintf(stderr, "[bsx-hip] extend job %lld: invalid (qlen=%d tlen=%d h0=%d)\n", (long long)i, j.qlen, j.tlen, j.h0); return BSX_E_ARG; }
+		long long band = std::min<long long>(j.qlen, 2LL * j.w + 1);
+		int c = 0;
+		while (c < 3 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
+		if (c == 3) { fprintf(stderr, "[bsx-hip] extend job %lld: query %d / band %lld beyond kernel limits\n", (long long)i, j.qlen, band); return BSX_E_ARG; }
+		order[c].push_back((int)i);
+	}
+	int rc;
+	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
+	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
+	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, d->st));
+	size_t off = 0;
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev0, d->st));
+	off = 0;
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+		launch_extend(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_ext_job_t*)d->jobs.p, (const int*)d->aux.p + off,
+		              (long long)order[c].size(), (bsx_ext_res_t*)d->res.p, QCAP[c], NCS[c], d->n_cu);
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev1, d->st));
+	if ((rc = finish_timed(d, 2)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_ext_res_t), hipMemcpyDeviceToHost));
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5
+// ------------------------------------------------------------------------------------------
+extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) return BSX_OK;
+	HIPCHK(hipSetDevice(d->ordinal));
+	std::vector<int> order[2];
+	int max_tlen = 1;
+	for (int64_t i = 0; i < n; ++i) {
+		const bsx_sw_job_t &j = jobs[i];
+		if (j.qlen <= 0 || j.tlen < 0) { fprintf(stderr, "[bsx-hip] sw job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
+		const int p = (j.xtra & BSX_KSW_XBYTE) ? 16 : 8, Q = (j.qlen + p - 1) / p * p;
+		if (Q > 1024) { fprintf(stderr, "[bsx-hip] sw job %lld: query %d beyond kernel limit (1024)\n", (long long)i, j.qlen); return BSX_E_ARG; }
+		order[Q <= 256 ? 0 : 1].push_back((int)i);
+		max_tlen = std::max(max_tlen, j.tlen);
+	}
+	int rc;
+	const int blocks_cap = d->n_cu * 8;
+	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_sw_job_t))) != BSX_OK) return rc;
+	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
+	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	if ((rc = d->scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t), hipMemcpyHostToDevice, d->st));
+	size_t off = 0;
+	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
+		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev0, d->st));
+	off = 0;
+	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
+		const long long m = (long long)order[c].size();
+		const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
+		launch_sw(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_sw_job_t*)d->jobs.p, (const int*)d->aux.p + off, m,
+		          (bsx_sw_res_t*)d->res.p, (unsigned long long*)d->scratch.p, max_tlen, blocks, c == 0 ? 4 : 16);
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev1, d->st));
+	if ((rc = finish_timed(d, 3)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_sw_res_t), hipMemcpyDeviceToHost));
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6
+// ------------------------------------------------------------------------------------------
+extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+                                        uint32_t *cigar_pool, size_t cigar_pool_len)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) return BSX_OK;
+	HIPCHK(hipSetDevice(d->ordinal));
+	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 1024, 2048}, NCS[3] = {4, 16, 32}, WPB[3] = {4, 4, 1};
+	std::vector<int> order[3];
+	size_t zmax[3] = {64, 64, 64};
+	const DevScoring &sc = d->sc;
+	for (int64_t i = 0; i < n; ++i) {
+		const bsx_glb_job_t &j = jobs[i];
+		if (j.qlen <= 0 || j.tlen <= 0 || j.n_try < 1) { fprintf(stderr, "[bsx-hip] global job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
+		if (j.want_cigar && (size_t)j.cigar_off + j.cigar_cap > cigar_pool_len) return BSX_E_ARG;
+		const int8_t *mat = j.use_ct ? sc.ctmat : sc.gamat;
+		long long wtop = (long long)j.w0 << (j.n_try - 1);
+		if (wtop > j.w_max) wtop = j.w_max;
+		int dl = j.tlen - j.qlen; dl = dl < 0 ? -dl : dl;
+		int max_ins = (int)((double)(((j.qlen + 1) >> 1) * mat[0] - sc.o_ins) / sc.e_ins + 1.);
+		int max_del = (int)((double)(((j.qlen + 1) >> 1) * mat[0] - sc.o_del) / sc.e_del + 1.);
+		int max_gap = std::max(std::max(max_ins, max_del), 1);
+		long long wk = std::max<long long>(std::min<long long>((max_gap + dl + 1) >> 1, wtop), dl + 3);
+		long long band = std::min<long long>(j.qlen, 2 * wk + 1);
+		int c = 0;
+		while (c < 3 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
+		if (c == 3) { fprintf(stderr, "[bsx-hip] global job %lld: query %d / band %lld beyond kernel limits\n", (long long)i, j.qlen, band); return BSX_E_ARG; }
+		order[c].push_back((int)i);
+		if (j.want_cigar) zmax[c] = std::max(zmax[c], (size_t)band * (size_t)j.tlen + 64);
+	}
+	int rc, blocks[3];
+	size_t ztot = 0;
+	for (int c = 0; c < 3; ++c) {
+		const long long m = (long long)order[c].size();
+		blocks[c] = (int)std::min<long long>((m + WPB[c] - 1) / WPB[c], (long long)d->n_cu * 8);
+		zmax[c] = (zmax[c] + 255) & ~(size_t)255;
+		ztot = std::max(ztot, (size_t)blocks[c] * WPB[c] * zmax[c]);
+	}
+	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_glb_job_t))) != BSX_OK) return rc;
+	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_glb_res_t))) != BSX_OK) return rc;
+	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	if ((rc = d->scratch.reserve(ztot + 256)) != BSX_OK) return rc;
+	if ((rc = d->pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t), hipMemcpyHostToDevice, d->st));
+	size_t off = 0;
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev0, d->st));
+	off = 0;
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+		launch_global(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_glb_job_t*)d->jobs.p, (const int*)d->aux.p + off,
+		              (long long)order[c].size(), (bsx_glb_res_t*)d->res.p, (uint32_t*)d->pool.p, (uint8_t*)d->scratch.p, zmax[c],
+		              QCAP[c], NCS[c], blocks[c], WPB[c]);
+		off += order[c].size();
+	}
+	HIPCHK(hipEventRecord(d->ev1, d->st));
+	if ((rc = finish_timed(d, 4)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_glb_res_t), hipMemcpyDeviceToHost));
+	if (cigar_pool_len) HIPCHK(hipMemcpy(cigar_pool, d->pool.p, cigar_pool_len * 4, hipMemcpyDeviceToHost));
+	return BSX_OK;
+}
+
+// the five seams as one vtable for the host pipeline
+static int be_set_opt(void *c, const bsx_opt_t *o) { return bsx_device_set_opt((bsx_device_t*)c, o); }
+static int be_set_reads(void *c, const uint8_t *b, size_t n) { return bsx_device_set_reads((bsx_device_t*)c, b, n); }
+static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_intv_t **out, int64_t *cap, int64_t *off) { return bsx_seed_batch((bsx_device_t*)c, o, n, t, out, cap, off); }
+static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return bsx_sa_batch((bsx_device_t*)c, n, j, p); }
+static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return bsx_extend_batch((bsx_device_t*)c, n, j, r); }
+static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return bsx_sw_batch((bsx_device_t*)c, n, j, r); }
+static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return bsx_global_batch((bsx_device_t*)c, n, j, r, pool, len); }
+
+extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out)
+{
+	if (!dev) return BSX_E_NODEVICE;
+	out->ctx = dev; out->name = "hip-gfx950";
+	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
+	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb;
+	return BSX_OK;
+}

@@ -5,6 +5,8 @@
 
 #define WAVE 64
 #define NEG_BIG (-(1 << 29))
+// order LDS/global accesses of the lanes of one wavefront (no instruction beyond the waitcnt the fence implies)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 __device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
 

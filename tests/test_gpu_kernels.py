@@ -89,3 +89,171 @@ def test_seed_overflow_path(small_index, port, device):
     pi, po = port.seed(opt, tasks)
     di, do = device.seed(opt, tasks)
     assert (po == do).all() and (pi == di).all()
+
+
+def _rand_ext_jobs(small_index, seqs, offs, rng, n, long_band=False):
+    from biscuit_amd.api import EXT_DT
+    l_pac = small_index.l_pac
+    jobs = np.zeros(n, dtype=EXT_DT)
+    for k in range(n):
+        r = int(rng.integers(0, len(seqs)))
+        L = len(seqs[r])
+        qlen = int(rng.integers(1, L))
+        left = rng.random() < 0.5
+        tlen = int(rng.integers(1, qlen + 220))
+        tpos = int(rng.integers(tlen + 1, 2 * l_pac - tlen - 1))
+        if tpos < l_pac <= tpos + tlen or tpos - tlen < l_pac <= tpos:
+            tpos = int(rng.integers(tlen + 1, l_pac - tlen - 1))
+        jobs[k]["tpos"] = tpos
+        jobs[k]["qoff"] = offs[r] + (qlen - 1 if left else L - qlen)
+        jobs[k]["qlen"] = qlen
+        jobs[k]["tlen"] = tlen
+        jobs[k]["h0"] = int(rng.integers(1, 160))
+        jobs[k]["w"] = int(rng.choice([100, 100, 200, 5, 30] + ([400, 1000] if long_band else [])))
+        jobs[k]["end_bonus"] = int(rng.choice([10, 5, 0]))
+        jobs[k]["qdir"] = -1 if left else 1
+        jobs[k]["tdir"] = -1 if left else 1
+        jobs[k]["parent"] = int(rng.integers(0, 2))
+    return jobs
+
+
+def _true_ext_jobs(small_index, pairs_seqs, offs, rng):
+    """extension jobs shaped like the real ones: a read against its true locus (found by seeding)"""
+    return None
+
+
+def test_extend_matches_oracle(small_index, port, device):
+    opt = default_opt()
+    rng = np.random.default_rng(11)
+    seqs = _reads(small_index, n_pairs=200, read_len=150, seed=12)
+    buf, offs = simdata.read_buffer(seqs)
+    for be in (port, device):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    jobs = _rand_ext_jobs(small_index, seqs, offs, rng, 3000)
+    # make a third of the jobs "real": target = the read's own sequence region found via seeding
+    tasks = _tasks(seqs, offs)
+    pi, po = port.seed(opt, tasks)
+    k = 0
+    from biscuit_amd.api import SA_DT
+    for t in range(0, len(tasks), 3):
+        if po[t + 1] > po[t] and k < len(jobs):
+            x0, _, x2, info = [int(v) for v in pi[po[t]]]
+            par = int(tasks[t]["parent"])
+            pos = int(port.sa(np.array([(x0, par, 0)], dtype=SA_DT))[0])
+            qb, qe = info >> 32, info & 0xffffffff
+            L = int(tasks[t]["len"])
+            if qe < L and pos + (qe - qb) + (L - qe) + 100 < 2 * small_index.l_pac and not (pos < small_index.l_pac <= pos + L + 120):
+                jobs[k]["tpos"] = pos + (qe - qb)
+                jobs[k]["qoff"] = int(tasks[t]["qoff"]) + qe
+                jobs[k]["qlen"] = L - qe
+                jobs[k]["tlen"] = min(L - qe + 100, 2 * small_index.l_pac - (pos + qe - qb) - 1)
+                jobs[k]["h0"] = qe - qb
+                jobs[k]["w"] = 100
+                jobs[k]["end_bonus"] = 10
+                jobs[k]["qdir"] = 1
+                jobs[k]["tdir"] = 1
+                jobs[k]["parent"] = par
+                k += 3
+    pr = port.extend(jobs)
+    dr = device.extend(jobs)
+    bad = np.nonzero(pr != dr)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[:3]], pr[bad[:3]], dr[bad[:3]])
+    assert (pr["score"] > jobs["h0"]).sum() > 50   # real extensions happened
+
+
+def _locus_of(small_index, port, opt, seqs, offs):
+    """(read index, parent, forward-reverse position of the read's first SMEM, qb) for reads that seed"""
+    from biscuit_amd.api import SA_DT
+    tasks = _tasks(seqs, offs)
+    pi, po = port.seed(opt, tasks)
+    out = []
+    for t in range(len(tasks)):
+        if po[t + 1] > po[t]:
+            x0, _, x2, info = [int(v) for v in pi[po[t]]]
+            pos = int(port.sa(np.array([(x0, int(tasks[t]["parent"]), 0)], dtype=SA_DT))[0])
+            out.append((t // 2, int(tasks[t]["parent"]), pos, info >> 32))
+    return out
+
+
+def test_sw_matches_oracle(small_index, port, device):
+    from biscuit_amd.api import SW_DT
+    opt = default_opt()
+    rng = np.random.default_rng(21)
+    seqs = _reads(small_index, n_pairs=150, read_len=150, seed=22) + [s for _, s in simdata.make_single(_contigs(small_index), 20, 700, 23)]
+    buf, offs = simdata.read_buffer(seqs)
+    for be in (port, device):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    loci = _locus_of(small_index, port, opt, seqs, offs)
+    l_pac = small_index.l_pac
+    jobs = []
+    for (r, par, pos, qb) in loci:
+        L = len(seqs[r])
+        for rep in range(2):
+            # window around the read's locus, as in mate rescue / seed SW
+            tlen = int(rng.integers(L // 2, L + 1100))
+            tpos = max(pos - qb - int(rng.integers(0, 600)), 0 if pos < l_pac else l_pac)
+            lim = l_pac if pos < l_pac else 2 * l_pac
+            tlen = min(tlen, lim - tpos)
+            if tlen < 20:
+                continue
+            xtra = 0x80000 | (0x40000 if rng.random() < 0.8 else 0) | 19
+            if L < 250 and rng.random() < 0.8:
+                xtra |= 0x10000
+            qlen = L if rng.random() < 0.7 else int(rng.integers(20, min(L, 199)))
+            jobs.append((tpos, offs[r], qlen, tlen, xtra, 1, 1, 0, par))
+            if rep == 0:  # reverse-complemented query against the other strand's coordinates
+                jobs.append((2 * l_pac - (tpos + tlen), offs[r] + L - 1, L, tlen, xtra, -1, 1, 1, 1 - par))
+    jobs = np.array(jobs, dtype=SW_DT)
+    assert len(jobs) > 300
+    pr = port.sw(jobs)
+    dr = device.sw(jobs)
+    bad = np.nonzero(pr != dr)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[:3]], pr[bad[:3]], dr[bad[:3]])
+    assert (pr["score"] > 60).sum() > 100 and (pr["score2"] > 0).sum() > 5 and (pr["qb"] >= 0).sum() > 100
+
+
+def test_global_matches_oracle(small_index, port, device):
+    from biscuit_amd.api import GLB_DT
+    opt = default_opt()
+    rng = np.random.default_rng(31)
+    seqs = _reads(small_index, n_pairs=200, read_len=150, seed=32) + [s for _, s in simdata.make_single(_contigs(small_index), 30, 900, 33)]
+    buf, offs = simdata.read_buffer(seqs)
+    for be in (port, device):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    loci = _locus_of(small_index, port, opt, seqs, offs)
+    l_pac = small_index.l_pac
+    jobs = []
+    cig_off = 0
+    for (r, par, pos, qb) in loci:
+        L = len(seqs[r])
+        lo = 0 if pos < l_pac else l_pac
+        hi = l_pac if pos < l_pac else 2 * l_pac
+        rb = pos - qb
+        for rep in range(2):
+            d0, d1 = (0, 0) if rep == 0 else (int(rng.integers(-6, 7)), int(rng.integers(-6, 7)))
+            b, e = max(rb + d0, lo), min(rb + L + d1, hi)
+            if e - b < 10:
+                continue
+            want = int(rng.random() < 0.85)
+            w0 = int(rng.choice([0, 0, 3, 10, 40, 100]))
+            ntry = 3 if want else 1
+            cap = 64
+            rev = b >= l_pac  # reverse-strand hits are aligned on reversed sequences (bwa.c:307-312)
+            jobs.append((e - 1 if rev else b, offs[r] + (L - 1 if rev else 0), L, e - b, w0, 400, int(rng.integers(L - 40, L + 1)), ntry,
+                         cig_off, cap, -1 if rev else 1, -1 if rev else 1, par, want))
+            cig_off += cap
+    jobs = np.array(jobs, dtype=GLB_DT)
+    assert len(jobs) > 300
+    pr, pp = port.global_(jobs, cig_off)
+    dr, dp = device.global_(jobs, cig_off)
+    bad = np.nonzero(pr != dr)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[:3]], pr[bad[:3]], dr[bad[:3]])
+    for k in range(len(jobs)):
+        n = int(pr[k]["n_cigar"])
+        if n > 0:
+            o = int(jobs[k]["cigar_off"])
+            assert (pp[o:o + n] == dp[o:o + n]).all(), k
+    assert (pr["n_cigar"] > 1).sum() > 20
