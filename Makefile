@@ -14,7 +14,8 @@ LIB     := biscuit_amd/libbiscuit_amd.so
 CLI     := biscuit_amd/biscuit_align
 PORT    := oracle/liboracle_port.so
 
-all: $(LIB) $(PORT) $(if $(wildcard biscuit_amd/csrc/cli_main.c),$(CLI))
+ORACLE_CLI := oracle/oracle_align
+all: $(LIB) $(PORT) $(CLI) $(ORACLE_CLI)
 
 $(BUILD)/host_%.o: biscuit_amd/csrc/host/%.c $(wildcard biscuit_amd/csrc/host/*.h) include/bsx.h
 	@mkdir -p $(BUILD)
@@ -34,9 +35,12 @@ $(CLI): biscuit_amd/csrc/cli_main.c $(LIB)
 $(PORT): oracle/port.c $(LIB)
 	$(CC) $(CFLAGS) -shared -o $@ oracle/port.c -Lbiscuit_amd -lbiscuit_amd -Wl,-rpath,'$$ORIGIN/../biscuit_amd' -lm -lpthread
 
+$(ORACLE_CLI): oracle/oracle_align_main.c $(PORT)
+	$(CC) -O2 -o $@ $< -Loracle -loracle_port -Lbiscuit_amd -lbiscuit_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../biscuit_amd' -Wl,-rpath,$(ROCM)/lib
+
 ref:
 	@if [ -d /root/reference/lib/aln ]; then $(MAKE) -C oracle; else echo "reference sources absent: using prebuilt oracle/_ref if present"; fi
 
 clean:
-	rm -rf $(BUILD) $(LIB) $(CLI) $(PORT)
+	rm -rf $(BUILD) $(LIB) $(CLI) $(PORT) $(ORACLE_CLI)
 .PHONY: all clean ref

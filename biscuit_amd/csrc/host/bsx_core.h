@@ -139,6 +139,14 @@ typedef struct {
 } bsx_phase_stats_t;
 BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out);
 
-extern int bsx_verbose;
+/* `biscuit align` driver over an arbitrary chunk processor (cli.c); the product entry bsx_align_main
+ * binds it to the HIP device, oracle/ binds it to the CPU restatement for tests and the CPU baseline */
+typedef int (*bsx_process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n,
+                              bsx_read_t *reads, const bsx_pestat_t *pes0);
+BSX_API int bsx_align_main_with(int argc, char **argv, bsx_process_fn process, void *ud,
+                                int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud));
+BSX_API extern char *bsx_pg_line;
+
+BSX_API extern int bsx_verbose;
 
 #endif

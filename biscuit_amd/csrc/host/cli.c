@@ -1,0 +1,393 @@
+/* cli.c -- L1: the `biscuit align` command line, main_align (lib/aln/align.c:319-598):
+ * same getopt string, option -> field mapping, -A rescaling, -x presets, header, chunk size
+ * (chunk_size x n_threads bases, align.c:576) and chunk order.  SAM goes to stdout. */
+#include <unistd.h>
+#include <ctype.h>
+#include <math.h>
+#include <getopt.h>
+#include "bsx_core.h"
+#include "fastq.h"
+#include "pipeline.h"
+
+const uint8_t *bsx_nt4_table(void);
+BSX_API char *bsx_pg_line = 0;   /* "@PG\t..." set by the program entry, printed after the header lines */
+
+static int usage(void)
+{
+	fprintf(stderr,
+		"\nUsage: biscuit_align [options] <fai-index base> <in1.fq> [in2.fq]\n\n"
+		"MI355X implementation of `biscuit align`; options, defaults and SAM output follow the reference:\n"
+		"  algorithm : -@ INT threads  -b INT parent/daughter restriction  -f INT BSW/BSC restriction\n"
+		"              -k INT min seed  -w INT band  -d INT z-drop  -r FLOAT re-seed factor  -y INT 3rd-round occ\n"
+		"              -J/-K STR adaptors  -z INT min base quality  -5/-3 INT extra clipping  -c INT max occ\n"
+		"              -D FLOAT chain drop ratio  -W INT min chain weight  -m INT mate-rescue rounds  -S -P -e -9\n"
+		"  scoring   : -A -B INT  -O -E -L INT[,INT]  -U INT\n"
+		"  I/O       : -1/-2 STR reads on the command line  -i -p -R STR -F -H STR/FILE -j -q -T INT -g INT[,INT]\n"
+		"              -a -C -V -Y -M -I FLOAT[,FLOAT[,INT[,INT]]] -v INT -h\n"
+		"  device    : $BSX_DEVICE selects the HIP device ordinal (default 0)\n\n");
+	return 1;
+}
+
+static void update_a(bsx_opt_t *opt, const bsx_opt_t *opt0)   /* align.c:169-182 */
+{
+	if (opt0->a) {
+		if (!opt0->b) opt->b *= opt->a;
+		if (!opt0->T) opt->T *= opt->a;
+		if (!opt0->o_del) opt->o_del *= opt->a;
+		if (!opt0->e_del) opt->e_del *= opt->a;
+		if (!opt0->o_ins) opt->o_ins *= opt->a;
+		if (!opt0->e_ins) opt->e_ins *= opt->a;
+		if (!opt0->zdrop) opt->zdrop *= opt->a;
+		if (!opt0->pen_clip5) opt->pen_clip5 *= opt->a;
+		if (!opt0->pen_clip3) opt->pen_clip3 *= opt->a;
+		if (!opt0->pen_unpaired) opt->pen_unpaired *= opt->a;
+	}
+}
+
+static void infer_alt(bsx_refmeta_t *r)   /* infer_alt_chromosomes, align.c:184-224 */
+{
+	int i, n, found[25];
+	for (i = 0; i < r->n_seqs; ++i) if (r->anns[i].is_alt) return;
+	memset(found, 0, sizeof(found));
+	for (i = 0; i < r->n_seqs; ++i) {
+		const char *nm = r->anns[i].name;
+		if (strncmp(nm, "chr", 3) != 0) continue;
+		if (strlen(nm) == 4) {
+			if (toupper(nm[3]) == 'X') found[22] = 1;
+			else if (toupper(nm[3]) == 'Y') found[23] = 1;
+			else if (toupper(nm[3]) == 'M') found[24] = 1;
+			else if (isdigit((unsigned char)nm[3])) { int k = nm[3] - '0'; if (k > 0 && k <= 22) found[k - 1] = 1; }
+		} else if (strlen(nm) == 5 && isdigit((unsigned char)nm[3]) && isdigit((unsigned char)nm[4])) {
+			int k = atoi(nm + 3); if (k > 0 && k <= 22) found[k - 1] = 1;
+		}
+	}
+	for (i = n = 0; i < 25; ++i) if (found[i]) ++n;
+	if (n < 20) return;
+	for (i = 0; i < r->n_seqs; ++i) {
+		const char *nm = r->anns[i].name;
+		if (strncmp(nm, "chrUn", 5) == 0 || strstr(nm, "_random") || strstr(nm, "_hap") || strstr(nm, "_alt")) r->anns[i].is_alt = 1;
+	}
+}
+
+static char *escape(char *s)   /* bwa_escape, bwa.c:686-701 */
+{
+	char *p, *q;
+	for (p = q = s; *p; ++p) {
+		if (*p == '\\') {
+			++p;
+			if (*p == 't') *q++ = '\t'; else if (*p == 'n') *q++ = '\n'; else if (*p == 'r') *q++ = '\r'; else if (*p == '\\') *q++ = '\\';
+		} else *q++ = *p;
+	}
+	*q = 0;
+	return s;
+}
+static char *insert_header(const char *s, char *hdr)   /* bwa_insert_header, bwa.c:736-748 */
+{
+	size_t len = 0;
+	if (s == 0 || s[0] != '@') return hdr;
+	if (hdr) { len = strlen(hdr); hdr = (char*)realloc(hdr, len + strlen(s) + 2); hdr[len++] = '\n'; strcpy(hdr + len, s); }
+	else hdr = strdup(s);
+	escape(hdr + len);
+	return hdr;
+}
+static char *set_rg(const char *s)   /* bwa_set_rg, bwa.c:703-734 */
+{
+	char *p, *q, *r, *rg_line;
+	memset(bsx_rg_id, 0, 256);
+	if (strstr(s, "@RG") != s) { fprintf(stderr, "[E::%s] the read group line is not started with @RG\n", __func__); return 0; }
+	rg_line = strdup(s);
+	escape(rg_line);
+	if ((p = strstr(rg_line, "\tID:")) == 0) { fprintf(stderr, "[E::%s] no ID at the read group line\n", __func__); free(rg_line); return 0; }
+	p += 4;
+	for (q = p; *q && *q != '\t' && *q != '\n'; ++q);
+	if (q - p + 1 > 256) { fprintf(stderr, "[E::%s] @RG:ID is longer than 255 characters\n", __func__); free(rg_line); return 0; }
+	for (q = p, r = bsx_rg_id; *q && *q != '\t' && *q != '\n'; ++q) *r++ = *q;
+	return rg_line;
+}
+
+static int ann_name_lt(const void *a, const void *b) { return strcmp((*(bsx_ann_t* const*)a)->name, (*(bsx_ann_t* const*)b)->name) < 0; }
+
+/* bwa_print_sam_hdr, bwa.c:654-684: @SQ lines sorted by name with the reference's introsort */
+BSX_API char *bsx_sam_header(const bsx_index_t *idx, const char *hdr_line, const char *pg_line)
+{
+	BSX_VEC(char) out;
+	int i, n_SQ = 0;
+	char buf[4096];
+	bsx_vec_init(out);
+#define OUTS(s_) do { const char *z_ = (s_); size_t l_ = strlen(z_); bsx_vec_reserve(out, out.n + l_ + 1); memcpy(out.a + out.n, z_, l_); out.n += l_; } while (0)
+	if (hdr_line) {
+		const char *p = hdr_line;
+		while ((p = strstr(p, "@SQ\t")) != 0) { if (p == hdr_line || *(p - 1) == '\n') ++n_SQ; p += 4; }
+	}
+	if (n_SQ == 0) {
+		const bsx_ann_t **ap = (const bsx_ann_t**)malloc(sizeof(*ap) * (idx->ref.n_seqs + 1));
+		for (i = 0; i < idx->ref.n_seqs; ++i) ap[i] = &idx->ref.anns[i];
+		bsx_introsort(ap, idx->ref.n_seqs, sizeof(*ap), ann_name_lt);
+		for (i = 0; i < idx->ref.n_seqs; ++i) { snprintf(buf, sizeof(buf), "@SQ\tSN:%s\tLN:%d\n", ap[i]->name, ap[i]->len); OUTS(buf); }
+		free(ap);
+	} else if (n_SQ != idx->ref.n_seqs && bsx_verbose >= 2)
+		fprintf(stderr, "[W::%s] %d @SQ lines provided with -H; %d sequences in the index. Continue anyway.\n", __func__, n_SQ, idx->ref.n_seqs);
+	if (hdr_line) { OUTS(hdr_line); OUTS("\n"); }
+	if (pg_line) { OUTS(pg_line); OUTS("\n"); }
+	bsx_vec_reserve(out, out.n + 1);
+	out.a[out.n] = 0;
+	return out.a;
+}
+
+/* bseq_classify (bwa.c:118-138) for -p: consecutive equal names form a pair */
+static void classify(int n, bsx_read_t *seqs, int m[2], bsx_read_t *sep[2])
+{
+	int i, has_last;
+	BSX_VEC(bsx_read_t) a[2];
+	bsx_vec_init(a[0]); bsx_vec_init(a[1]);
+	for (i = 1, has_last = 1; i < n; ++i) {
+		if (has_last) {
+			if (strcmp(seqs[i].name, seqs[i - 1].name) == 0) { bsx_vec_push(a[1], seqs[i - 1]); bsx_vec_push(a[1], seqs[i]); has_last = 0; }
+			else bsx_vec_push(a[0], seqs[i - 1]);
+		} else has_last = 1;
+	}
+	if (has_last && n > 0) bsx_vec_push(a[0], seqs[i - 1]);
+	sep[0] = a[0].a; m[0] = (int)a[0].n; sep[1] = a[1].a; m[1] = (int)a[1].n;
+	if (bsx_verbose >= 3) fprintf(stderr, "[%s] %d SE sequences; %d PE sequences\n", "bseq_classify", m[0], m[1]);
+}
+
+typedef int (*process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
+
+/* shared by the product entry (HIP) and the test-only entry that injects another backend */
+BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void *ud, int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud))
+{
+	bsx_opt_t opt_, opt0, *opt = &opt_;
+	int c, i, ignore_alt = 0, auto_alt = 1, copy_comment = 0, device = 0, rc = 0;
+	char *p, *rg_line = 0, *hdr_line = 0, *seq1 = 0, *seq2 = 0;
+	const char *mode = 0;
+	bsx_pestat_t *pes0 = 0;
+	bsx_index_t *idx = 0;
+	bsx_fq_t *f1 = 0, *f2 = 0;
+	int64_t n_processed = 0;
+	const uint8_t *nt4 = bsx_nt4_table();
+
+	if (getenv("BSX_DEVICE")) device = atoi(getenv("BSX_DEVICE"));
+	bsx_opt_init(opt);
+	opt->flag |= BSX_F_NO_MULTI;   /* align.c:335 */
+	memset(&opt0, 0, sizeof(opt0));
+	if (argc < 2) return usage();
+	optind = 1;
+	while ((c = getopt(argc, argv, ":@:1:2:3:5:9ab:c:d:ef:g:hijk:m:pqr:s:v:w:x:y:z:A:B:CD:E:FG:H:I:J:K:L:MN:O:PQ:R:ST:U:VW:X:Y")) >= 0) {
+		if (c == 'k') opt->min_seed_len = atoi(optarg), opt0.min_seed_len = 1;
+		else if (c == '1') seq1 = strdup(optarg);
+		else if (c == '2') seq2 = strdup(optarg);
+		else if (c == 'x') mode = optarg;
+		else if (c == 'b') opt->parent = (uint8_t)atoi(optarg);
+		else if (c == 'f') opt->bsstrand = (uint8_t)atoi(optarg);
+		else if (c == 'i') auto_alt = 0;
+		else if (c == 'w') opt->w = atoi(optarg), opt0.w = 1;
+		else if (c == 'A') opt->a = atoi(optarg), opt0.a = 1;
+		else if (c == 'B') opt->b = atoi(optarg), opt0.b = 1;
+		else if (c == 'T') opt->T = atoi(optarg), opt0.T = 1;
+		else if (c == 'U') opt->pen_unpaired = atoi(optarg), opt0.pen_unpaired = 1;
+		else if (c == '@') opt->n_threads = atoi(optarg), opt->n_threads = opt->n_threads > 1 ? opt->n_threads : 1;
+		else if (c == 'P') opt->flag |= BSX_F_NOPAIRING;
+		else if (c == 'a') opt->flag |= BSX_F_ALL;
+		else if (c == 'p') opt->flag |= BSX_F_PE | BSX_F_SMARTPE;
+		else if (c == 'q') opt->flag |= BSX_F_KEEP_SUPP_MAPQ;
+		else if (c == 'M') opt->flag |= BSX_F_NO_MULTI;
+		else if (c == 'S') opt->flag |= BSX_F_NO_RESCUE;
+		else if (c == 'e') opt->flag |= BSX_F_SELF_OVLP;
+		else if (c == 'F') opt->flag |= BSX_F_ALN_REG;
+		else if (c == 'Y') opt->flag |= BSX_F_SOFTCLIP;
+		else if (c == 'V') opt->flag |= BSX_F_REF_HDR;
+		else if (c == 'c') opt->max_occ = (uint32_t)atoi(optarg), opt0.max_occ = 1;
+		else if (c == 'd') opt->zdrop = atoi(optarg), opt0.zdrop = 1;
+		else if (c == 'v') bsx_verbose = atoi(optarg);
+		else if (c == 'j') ignore_alt = 1;
+		else if (c == 'r') opt->split_factor = (float)atof(optarg), opt0.split_factor = 1.;
+		else if (c == 'D') opt->drop_ratio = (float)atof(optarg), opt0.drop_ratio = 1.;
+		else if (c == 'm') opt->max_matesw = atoi(optarg), opt0.max_matesw = 1;
+		else if (c == 's') opt->split_width = atoi(optarg), opt0.split_width = 1;
+		else if (c == 'G') opt->max_chain_gap = atoi(optarg), opt0.max_chain_gap = 1;
+		else if (c == 'N') opt->max_chain_extend = (uint32_t)atoi(optarg), opt0.max_chain_extend = 1;
+		else if (c == 'W') opt->min_chain_weight = atoi(optarg), opt0.min_chain_weight = 1;
+		else if (c == 'y') opt->max_mem_intv = (uint64_t)atol(optarg), opt0.max_mem_intv = 1;
+		else if (c == 'C') copy_comment = 1;
+		else if (c == 'J') {
+			opt->l_adaptor1 = (int)strlen(optarg); opt->adaptor1 = (uint8_t*)calloc(opt->l_adaptor1 + 1, 1);
+			for (i = 0; i < opt->l_adaptor1; ++i) opt->adaptor1[i] = nt4[(unsigned char)optarg[i]];
+		} else if (c == 'K') {
+			opt->l_adaptor2 = (int)strlen(optarg); opt->adaptor2 = (uint8_t*)calloc(opt->l_adaptor2 + 1, 1);
+			for (i = 0; i < opt->l_adaptor2; ++i) opt->adaptor2[i] = nt4[(unsigned char)optarg[i]];
+		} else if (c == 'z') opt->min_base_qual = atoi(optarg);
+		else if (c == '5') opt->clip5 = atoi(optarg);
+		else if (c == '3') opt->clip3 = atoi(optarg);
+		else if (c == '9') opt->has_bc = 1;
+		else if (c == 'X') opt->mask_level = (float)atof(optarg);
+		else if (c == 'g') {
+			opt0.max_XA_hits = opt0.max_XA_hits_alt = 1;
+			opt->max_XA_hits = opt->max_XA_hits_alt = (int)strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt->max_XA_hits_alt = (int)strtol(p + 1, &p, 10);
+		} else if (c == 'Q') {
+			opt0.mapQ_coef_len = 1;
+			opt->mapQ_coef_len = (float)atoi(optarg);
+			opt->mapQ_coef_fac = opt->mapQ_coef_len > 0 ? log(opt->mapQ_coef_len) : 0;
+		} else if (c == 'O') {
+			opt0.o_del = opt0.o_ins = 1;
+			opt->o_del = opt->o_ins = (int)strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt->o_ins = (int)strtol(p + 1, &p, 10);
+		} else if (c == 'E') {
+			opt0.e_del = opt0.e_ins = 1;
+			opt->e_del = opt->e_ins = (int)strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt->e_ins = (int)strtol(p + 1, &p, 10);
+		} else if (c == 'L') {
+			opt0.pen_clip5 = opt0.pen_clip3 = 1;
+			opt->pen_clip5 = opt->pen_clip3 = (int)strtol(optarg, &p, 10);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) opt->pen_clip3 = (int)strtol(p + 1, &p, 10);
+		} else if (c == 'R') {
+			if ((rg_line = set_rg(optarg)) == 0) return 1;
+		} else if (c == 'H') {
+			if (optarg[0] != '@') {
+				FILE *fp;
+				if ((fp = fopen(optarg, "r")) != 0) {
+					char *buf = (char*)calloc(1, 0x10000);
+					while (fgets(buf, 0xffff, fp)) { size_t l = strlen(buf); if (l && buf[l - 1] == '\n') buf[l - 1] = 0; hdr_line = insert_header(buf, hdr_line); }
+					free(buf); fclose(fp);
+				}
+			} else hdr_line = insert_header(optarg, hdr_line);
+		} else if (c == 'I') { /* align.c:434-453 */
+			pes0 = (bsx_pestat_t*)calloc(1, sizeof(bsx_pestat_t));
+			pes0->avg = strtod(optarg, &p);
+			pes0->std = pes0->avg * .1;
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0->std = strtod(p + 1, &p);
+			pes0->high = (int)(pes0->avg + 4. * pes0->std + .499);
+			pes0->low  = (int)(pes0->avg - 4. * pes0->std + .499);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0->high = (int)(strtod(p + 1, &p) + .499);
+			if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) pes0->low = (int)(strtod(p + 1, &p) + .499);
+			if (bsx_verbose >= 3)
+				fprintf(stderr, "[M::%s] mean insert size: %.3f, stddev: %.3f, max: %d, min: %d\n", "main_align", pes0->avg, pes0->std, pes0->high, pes0->low);
+		} else if (c == 'h') return usage();
+		else if (c == ':') { usage(); fprintf(stderr, "Option needs an argument: -%c\n", optopt); return 1; }
+		else if (c == '?') { usage(); fprintf(stderr, "Unrecognized option: -%c\n", optopt); return 1; }
+		else return usage();
+	}
+	if (rg_line) { hdr_line = insert_header(rg_line, hdr_line); free(rg_line); }
+	if (opt->n_threads < 1) opt->n_threads = 1;
+	if ((optind + 1 >= argc || optind + 3 < argc) && !seq1) { usage(); fprintf(stderr, "Missing fai-index base or FASTQ file\n"); return 1; }
+	if (mode) { /* -x presets, align.c:476-512 */
+		if (strcmp(mode, "intractg") == 0) {
+			if (!opt0.o_del) opt->o_del = 16;
+			if (!opt0.o_ins) opt->o_ins = 16;
+			if (!opt0.b) opt->b = 9;
+			if (!opt0.pen_clip5) opt->pen_clip5 = 5;
+			if (!opt0.pen_clip3) opt->pen_clip3 = 5;
+		} else if (strcmp(mode, "pacbio") == 0 || strcmp(mode, "pbref") == 0 || strcmp(mode, "pbread") == 0 || strcmp(mode, "ont2d") == 0) {
+			if (!opt0.o_del) opt->o_del = 1;
+			if (!opt0.e_del) opt->e_del = 1;
+			if (!opt0.o_ins) opt->o_ins = 1;
+			if (!opt0.e_ins) opt->e_ins = 1;
+			if (!opt0.b) opt->b = 1;
+			if (opt0.split_factor == 0.) opt->split_factor = 10.;
+			if (strcmp(mode, "pbread") == 0) {
+				opt->flag |= BSX_F_ALL | BSX_F_SELF_OVLP | BSX_F_ALN_REG;
+				if (!opt0.min_chain_weight) opt->min_chain_weight = 40;
+				if (!opt0.max_occ) opt->max_occ = 1000;
+				if (!opt0.min_seed_len) opt->min_seed_len = 13;
+				if (!opt0.max_chain_extend) opt->max_chain_extend = 25;
+				if (opt0.drop_ratio == 0.) opt->drop_ratio = .001;
+			} else if (strcmp(mode, "ont2d") == 0) {
+				if (!opt0.min_chain_weight) opt->min_chain_weight = 20;
+				if (!opt0.min_seed_len) opt->min_seed_len = 14;
+				if (!opt0.pen_clip5) opt->pen_clip5 = 0;
+				if (!opt0.pen_clip3) opt->pen_clip3 = 0;
+			} else {
+				if (!opt0.min_chain_weight) opt->min_chain_weight = 40;
+				if (!opt0.min_seed_len) opt->min_seed_len = 17;
+				if (!opt0.pen_clip5) opt->pen_clip5 = 0;
+				if (!opt0.pen_clip3) opt->pen_clip3 = 0;
+			}
+		} else { fprintf(stderr, "[E::%s] unknown read type '%s'\n", "main_align", mode); return 1; }
+	} else update_a(opt, &opt0);
+	bsx_opt_fill_matrices(opt);
+	if (optind >= argc) { usage(); fprintf(stderr, "Missing fai-index base\n"); return 1; }
+	if ((rc = bsx_index_load(argv[optind], &idx)) != BSX_OK) { fprintf(stderr, "[E::%s] fail to locate the index files (%s)\n", "main_align", bsx_strerror(rc)); return 1; }
+	if (auto_alt) infer_alt(&idx->ref);
+	if (ignore_alt) for (i = 0; i < idx->ref.n_seqs; ++i) idx->ref.anns[i].is_alt = 0;
+	if (open_device && (rc = open_device(device, idx, &ud)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); bsx_index_free(idx); return 1; }
+	if (!seq1) {
+		if ((f1 = bsx_fq_open(argv[optind + 1])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 1]); return 1; }
+		if (optind + 2 < argc) {
+			if (opt->flag & BSX_F_PE) { if (bsx_verbose >= 2) fprintf(stderr, "[W::%s] when '-p' is in use, the second query file is ignored.\n", "main_align"); }
+			else {
+				if ((f2 = bsx_fq_open(argv[optind + 2])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 2]); return 1; }
+				opt->flag |= BSX_F_PE;
+			}
+		}
+	}
+	if (!(opt->flag & BSX_F_ALN_REG)) { char *h = bsx_sam_header(idx, hdr_line, bsx_pg_line); fputs(h, stdout); free(h); }
+	{
+		int chunk = opt->chunk_size * opt->n_threads, done_cmdline = 0;
+		for (;;) {
+			int n = 0;
+			bsx_read_t *seqs = 0;
+			int64_t size = 0;
+			if (seq1) { /* reads given with -1/-2 (align.c:77-81, bwa.c:749-764) */
+				if (done_cmdline) break;
+				done_cmdline = 1;
+				n = seq2 ? 2 : 1;
+				seqs = (bsx_read_t*)calloc(2, sizeof(bsx_read_t));
+				for (i = 0; i < n; ++i) {
+					const char *sq = i ? seq2 : seq1;
+					size_t l = strlen(sq), k;
+					seqs[i].name = strdup("inputread");
+					seqs[i].seq = seqs[i].seq0 = (uint8_t*)malloc(l + 1);
+					for (k = 0; k < l; ++k) seqs[i].seq[k] = nt4[(unsigned char)sq[k]];
+					seqs[i].l_seq = seqs[i].l_seq0 = (int)l;
+				}
+				if (seq2) opt->flag |= BSX_F_PE;
+			} else {
+				seqs = bsx_fq_read_chunk(f1, f2, chunk, opt->has_bc, &n);
+				if (seqs == 0 || n == 0) { free(seqs); break; }
+				if (!copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; }
+			}
+			for (i = 0; i < n; ++i) size += seqs[i].l_seq;
+			if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, (long)size);
+			if (opt->flag & BSX_F_SMARTPE) { /* -p: split into single and paired reads (align.c:108-146) */
+				bsx_read_t *sep[2]; int m[2];
+				bsx_opt_t tmp = *opt;
+				for (i = 0; i < n; ++i) seqs[i].id = i;
+				classify(n, seqs, m, sep);
+				if (m[0]) { tmp.flag &= ~BSX_F_PE; rc = process(ud, &tmp, idx, n_processed, m[0], sep[0], 0); for (i = 0; i < m[0] && rc == 0; ++i) seqs[sep[0][i].id] = sep[0][i]; }
+				if (m[1] && rc == 0) { tmp.flag |= BSX_F_PE; rc = process(ud, &tmp, idx, n_processed + m[0], m[1], sep[1], pes0); for (i = 0; i < m[1] && rc == 0; ++i) seqs[sep[1][i].id] = sep[1][i]; }
+				free(sep[0]); free(sep[1]);
+			} else rc = process(ud, opt, idx, n_processed, n, seqs, pes0);
+			if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+			n_processed += n;
+			for (i = 0; i < n; ++i) { if (rc == 0 && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
+			free(seqs);
+			if (rc) break;
+		}
+	}
+	fflush(stdout);
+	free(hdr_line); free(opt->adaptor1); free(opt->adaptor2); free(pes0); free(seq1); free(seq2);
+	bsx_fq_close(f1); bsx_fq_close(f2);
+	bsx_index_free(idx);
+	return rc;
+}
+
+/* ---- product entry: HIP device only ---- */
+static int hip_open(int ordinal, const bsx_index_t *idx, void **ud)
+{
+	bsx_device_t *dev = 0;
+	int rc = bsx_device_open(ordinal, &dev);
+	if (rc != BSX_OK) return rc;
+	if ((rc = bsx_device_upload_index(dev, idx)) != BSX_OK) { bsx_device_close(dev); return rc; }
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] index resident on %s\n", "main_align", bsx_device_name(dev));
+	*ud = dev;
+	return BSX_OK;
+}
+static int hip_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t np, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+{
+	return bsx_process_seqs((bsx_device_t*)ud, opt, idx, np, n, reads, pes0);
+}
+
+BSX_API int bsx_align_main(int argc, char **argv)
+{
+	return bsx_align_main_with(argc, argv, hip_process, 0, hip_open);
+}

@@ -1,0 +1,149 @@
+/* fastq.c -- I1: FASTA/FASTQ reader and chunker.
+ * Record grammar follows klib's kseq_read (lib/aln/kseq.h:182-222): header '>' or '@', name up to
+ * the first white space, optional comment = rest of the line, multi-line sequence until a line that
+ * starts with '>', '@' or '+', then (FASTQ) quality lines until as many characters as bases.
+ * Chunking follows bis_bseq_read (lib/aln/bwa.c:817-850): stop at the first even read count once
+ * the chunk holds >= chunk_size bases.
+ */
+#include <zlib.h>
+#include <ctype.h>
+#include "bsx_core.h"
+#include "fastq.h"
+
+const uint8_t *bsx_nt4_table(void);
+
+struct bsx_fq {
+	gzFile fp;
+	unsigned char *buf;
+	int begin, end, is_eof, last_char;
+	BSX_VEC(char) name, comment, seq, qual;
+};
+
+#define FQ_BUFSZ (1 << 18)
+
+bsx_fq_t *bsx_fq_open(const char *fn)
+{
+	bsx_fq_t *f;
+	gzFile fp = strcmp(fn, "-") == 0 ? gzdopen(0, "r") : gzopen(fn, "r");
+	if (!fp) return 0;
+	gzbuffer(fp, 1 << 20);
+	f = (bsx_fq_t*)calloc(1, sizeof(*f));
+	f->fp = fp;
+	f->buf = (unsigned char*)malloc(FQ_BUFSZ);
+	return f;
+}
+
+void bsx_fq_close(bsx_fq_t *f)
+{
+	if (!f) return;
+	gzclose(f->fp);
+	free(f->buf); bsx_vec_free(f->name); bsx_vec_free(f->comment); bsx_vec_free(f->seq); bsx_vec_free(f->qual);
+	free(f);
+}
+
+static inline int fq_getc(bsx_fq_t *f)
+{
+	if (f->is_eof && f->begin >= f->end) return -1;
+	if (f->begin >= f->end) {
+		f->begin = 0;
+		f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
+		if (f->end <= 0) { f->is_eof = 1; f->end = 0; return -1; }
+	}
+	return (int)f->buf[f->begin++];
+}
+
+/* read up to a delimiter: 0 = any white space, 2 = end of line; returns the delimiter or -1 */
+#define vec_putc(v, c) do { if ((v).n + 1 >= (v).m) bsx_vec_reserve(v, (v).n + 2); (v).a[(v).n++] = (char)(c); } while (0)
+static int fq_until(bsx_fq_t *f, int line_only, void *v_, int append)
+{
+	BSX_VEC(char) *v = v_;
+	int c, got = 0;
+	if (!append) v->n = 0;
+	for (;;) {
+		c = fq_getc(f);
+		if (c < 0) break;
+		got = 1;
+		if (line_only ? c == '\n' : isspace(c)) break;
+		vec_putc(*v, c);
+	}
+	if (!got && c < 0) return -1;
+	if (line_only && v->n > 0 && v->a[v->n - 1] == '\r') --v->n;
+	bsx_vec_reserve(*v, v->n + 1);
+	v->a[v->n] = 0;
+	return c < 0 ? -1 : c; /* -1 at EOF */
+}
+
+/* returns sequence length, -1 at end of file, -2 on a truncated quality string */
+static int fq_read(bsx_fq_t *f)
+{
+	int c;
+	if (f->last_char == 0) {
+		while ((c = fq_getc(f)) != -1 && c != '>' && c != '@');
+		if (c == -1) return -1;
+		f->last_char = c;
+	}
+	f->comment.n = f->seq.n = f->qual.n = 0;
+	if ((c = fq_until(f, 0, &f->name, 0)) < 0 && f->name.n == 0) return -1;
+	if (c != '\n' && c >= 0) fq_until(f, 1, &f->comment, 0);
+	bsx_vec_reserve(f->seq, 256);
+	while ((c = fq_getc(f)) != -1 && c != '>' && c != '+' && c != '@') {
+		if (c == '\n') continue;
+		vec_putc(f->seq, c);
+		fq_until(f, 1, &f->seq, 1);
+	}
+	if (c == '>' || c == '@') f->last_char = c;
+	bsx_vec_reserve(f->seq, f->seq.n + 1);
+	f->seq.a[f->seq.n] = 0;
+	if (c != '+') { if (c == -1) f->last_char = 0; return (int)f->seq.n; }
+	bsx_vec_reserve(f->qual, f->seq.n + 2);
+	while ((c = fq_getc(f)) != -1 && c != '\n');   /* rest of the '+' line */
+	if (c == -1) return -2;
+	while (f->qual.n < f->seq.n) { if (fq_until(f, 1, &f->qual, 1) < 0) break; }
+	f->last_char = 0;
+	if (f->seq.n != f->qual.n) return -2;
+	return (int)f->seq.n;
+}
+
+static void to_read(const bsx_fq_t *f, bsx_read_t *s, int has_bc)
+{
+	const uint8_t *nt4 = bsx_nt4_table();
+	size_t i, l = f->name.n;
+	memset(s, 0, sizeof(*s));
+	/* trim_readno, bwa.c:58-63 */
+	s->name = (char*)malloc(l + 1); memcpy(s->name, f->name.a, l); s->name[l] = 0;
+	if (l > 2 && s->name[l - 2] == '/' && isdigit((unsigned char)s->name[l - 1])) s->name[l - 2] = 0;
+	s->comment = f->comment.n ? strdup(f->comment.a) : 0;
+	if (has_bc) { /* name_..._BARCODE_UMI (bis_kseq2bseq1, bwa.c:766-815): the last two '_' fields */
+		char *tmp = strdup(s->name), *tok, *bc = 0, *umi = 0;
+		tok = strtok(tmp, "_");
+		bc = strtok(NULL, "_"); umi = strtok(NULL, "_");
+		while ((tok = strtok(NULL, "_")) != NULL) { bc = umi; umi = tok; }
+		s->barcode = bc ? strdup(bc) : 0; s->umi = umi ? strdup(umi) : 0;
+		free(tmp);
+	}
+	s->l_seq = s->l_seq0 = (int)f->seq.n;
+	s->seq = s->seq0 = (uint8_t*)malloc(f->seq.n + 1);
+	for (i = 0; i < f->seq.n; ++i) s->seq[i] = nt4[(unsigned char)f->seq.a[i]];
+	s->qual = f->qual.n ? strdup(f->qual.a) : 0;
+}
+
+bsx_read_t *bsx_fq_read_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size, int has_bc, int *n_)
+{
+	int size = 0, m = 0, n = 0;
+	bsx_read_t *seqs = 0;
+	while (fq_read(f1) >= 0) {
+		if (f2 && fq_read(f2) < 0) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", __func__); break; }
+		if (n + 2 > m) { m = m ? m << 1 : 256; seqs = (bsx_read_t*)realloc(seqs, (size_t)m * sizeof(bsx_read_t)); }
+		to_read(f1, &seqs[n], has_bc); seqs[n].id = n; size += seqs[n++].l_seq;
+		if (f2) { to_read(f2, &seqs[n], has_bc); seqs[n].id = n; size += seqs[n++].l_seq; }
+		if (size >= chunk_size && (n & 1) == 0) break;
+	}
+	if (size == 0 && f2 && fq_read(f2) >= 0) fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", __func__);
+	*n_ = n;
+	return seqs;
+}
+
+void bsx_read_free(bsx_read_t *s)
+{
+	free(s->name); free(s->comment); free(s->barcode); free(s->umi); free(s->seq0); free(s->qual); free(s->sam);
+}

@@ -1,0 +1,788 @@
+/* pipeline.c -- D1: the chunk driver, mem_process_seqs (lib/aln/bwamem.c:432-476) re-shaped for a
+ * batch device.
+ *
+ * The reference maps reads one at a time inside kt_for workers.  Here a chunk moves through the
+ * stages as whole batches so that every kernel launch carries the work of all reads:
+ *
+ *   clip -> [K1+K2 seed] -> [K3 SA] -> chain/filter (host) -> [K5 seed SW, long reads only]
+ *        -> rounds of [K4 extend] driven by the per-task state machines (extend.c)
+ *        -> merge/dedup (host, [K6 score-only] for concatenation tests)
+ *        -> insert-size statistics (host reduction over the chunk)
+ *        -> [K5 mate rescue] -> primary marking, pairing, MAPQ (host)
+ *        -> [K6 CIGAR] -> MD/NM + SAM text (host)
+ *
+ * Device stages go through bsx_backend_t; the product binds it to the HIP kernels only.
+ * Host stages are parallelised over reads with bsx_parallel_for; no result depends on scheduling.
+ */
+#include <math.h>
+#include <sys/time.h>
+#include "align_types.h"
+#include "pipeline.h"
+
+static double now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
+
+static bsx_phase_stats_t g_stats;
+BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out) { *out = g_stats; }
+
+#define CHECK(x) do { int rc_ = (x); if (rc_ != BSX_OK) { rc = rc_; goto done; } } while (0)
+
+/* ------------------------------------------------------------------ read clipping (bwamem.c:218-303) */
+static const uint8_t *find_bytes(const uint8_t *hay, size_t hlen, const uint8_t *needle, size_t nlen)
+{
+	size_t i;
+	if (!nlen || hlen < nlen) return 0;
+	for (i = 0; i + nlen <= hlen; ++i)
+		if (hay[i] == needle[0] && memcmp(hay + i, needle, nlen) == 0) return hay + i;
+	return 0;
+}
+
+static void clip_read(bsx_read_t *seq, const uint8_t *adaptor, int l_adaptor, const bsx_opt_t *opt)
+{
+	if (adaptor == 0) seq->l_adaptor = 0;
+	else { /* full adaptor anywhere, else its longest prefix that is a suffix of the read */
+		const uint8_t *hit = find_bytes(seq->seq, (size_t)seq->l_seq, adaptor, (size_t)l_adaptor);
+		if (hit) seq->l_adaptor = seq->l_seq - (int)(hit - seq->seq);
+		else {
+			int i;
+			for (i = l_adaptor - 1; i; --i)
+				if (i <= seq->l_seq && memcmp(seq->seq + seq->l_seq - i, adaptor, (size_t)i) == 0) break;
+			seq->l_adaptor = i;
+		}
+	}
+	seq->clip5 = opt->clip5;
+	seq->clip3 = opt->clip3 + seq->l_adaptor;
+	if (seq->qual) { /* clip_read_by_quality, bwamem.c:275-283 */
+		for (; seq->clip5 < seq->l_seq - seq->clip3; seq->clip5++)
+			if (seq->qual[seq->clip5] >= opt->min_base_qual + 33) break;
+		for (; seq->l_seq - seq->clip3 >= seq->clip5; seq->clip3++)
+			if (seq->l_seq - seq->clip3 - 1 < 0 || seq->qual[seq->l_seq - seq->clip3 - 1] >= opt->min_base_qual + 33) break;
+	}
+	seq->seq0 = seq->seq;
+	seq->l_seq0 = seq->l_seq;
+	seq->seq += seq->clip5;
+	seq->l_seq = seq->l_seq - seq->clip3 - seq->clip5;
+	if (seq->l_seq < 0) seq->l_seq = 0;
+}
+
+static int pair_names_ok(const char *n1, const char *n2)   /* check_paired_read_names, bwamem.c:210-216 */
+{
+	size_t l;
+	if (strcmp(n1, n2) == 0) return 1;
+	l = strlen(n1);
+	if (l > 0 && n1[l - 1] == '1' && strlen(n2) >= l && n2[l - 1] == '2' && strncmp(n1, n2, l - 1) == 0) return 1;
+	return 0;
+}
+
+/* ------------------------------------------------------------------ chunk state */
+typedef struct {
+	const bsx_backend_t *be;
+	const bsx_opt_t *opt;
+	const bsx_index_t *idx;
+	int n, is_pe, nt;
+	int64_t n_processed;
+	bsx_read_t *reads;
+	uint32_t *roff;
+	/* tasks */
+	int n_tasks;
+	c2r_t *tasks;
+	int *read_task0;             /* first task of each read; read_task0[n] = n_tasks */
+	bsx_intv_t *intv; int64_t intv_cap; int64_t *intv_off;
+	uint64_t *pos; int64_t *ipos_off;   /* per interval: its occurrences' positions */
+	int *need_more;              /* per task: 0 or 1+interval */
+	uint64_t **xpos; int64_t **xpos_off;  /* private re-lookups for tasks that needed more */
+	bsx_btree_t **trees;         /* per thread */
+	reg_v *regs;                 /* per read */
+	bsx_pestat_t pes;
+} chunk_t;
+
+/* ------------------------------------------------------------------ chaining */
+static void chain_worker(void *data, long t, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	c2r_t *T = &C->tasks[t];
+	const bsx_intv_t *iv = C->intv + C->intv_off[t];
+	int n_iv = (int)(C->intv_off[t + 1] - C->intv_off[t]);
+	int rc;
+	if (C->need_more[t] < 0) return; /* already chained */
+	bsx_chain_free(&T->chains);
+	if (C->xpos[t]) rc = bsx_chain_build(C->opt, &C->idx->ref, T->l_query, T->parent, iv, n_iv, C->xpos[t], C->xpos_off[t], C->trees[tid], &T->chains);
+	else {
+		/* this task's intervals are consecutive in the global interval list: rebase the offsets */
+		int64_t base = C->ipos_off[C->intv_off[t]];
+		int64_t *off = (int64_t*)alloca(sizeof(int64_t) * ((size_t)n_iv + 1));
+		int i;
+		for (i = 0; i <= n_iv; ++i) off[i] = C->ipos_off[C->intv_off[t] + i] - base;
+		rc = bsx_chain_build(C->opt, &C->idx->ref, T->l_query, T->parent, iv, n_iv, C->pos + base, off, C->trees[tid], &T->chains);
+	}
+	if (rc > 0) { C->need_more[t] = rc; return; }
+	C->need_more[t] = -1;
+	bsx_chain_filter(C->opt, &T->chains);
+}
+
+/* ------------------------------------------------------------------ long-read seed filter (memchain.c:501-568) */
+#define MEM_SHORT_EXT 50
+#define MEM_SHORT_LEN 200
+#define MEM_HSP_COEF 1.1f
+#define MEM_MINSC_COEF 5.5f
+#define MEM_SEEDSW_COEF 0.05f
+
+static int seed_sw_active(const bsx_opt_t *opt, int l_query, int *min_HSP_score)
+{
+	double min_l = opt->min_chain_weight ? MEM_HSP_COEF * opt->min_chain_weight : MEM_MINSC_COEF * log(l_query);
+	if (min_l > MEM_SEEDSW_COEF * l_query) return 0;
+	*min_HSP_score = (int)(opt->a * min_l + .499);
+	return 1;
+}
+
+/* mem_seed_sw window; returns 0 if the reference would return -1 without running SW */
+static int seed_sw_job(const chunk_t *C, const c2r_t *T, const seed_t *s, bsx_sw_job_t *j)
+{
+	int qb, qe;
+	int64_t rb, re, mid, l_pac = C->idx->ref.l_pac;
+	if (s->len >= MEM_SHORT_LEN) return 0;
+	qb = s->qbeg; qe = s->qbeg + s->len;
+	rb = s->rbeg; re = s->rbeg + s->len;
+	mid = (rb + re) >> 1;
+	qb -= MEM_SHORT_EXT; qb = qb > 0 ? qb : 0;
+	qe += MEM_SHORT_EXT; qe = qe < T->l_query ? qe : T->l_query;
+	rb -= MEM_SHORT_EXT; rb = rb > 0 ? rb : 0;
+	re += MEM_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+	if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return 0;
+	bsx_fetch_span(&C->idx->ref, &rb, mid, &re);
+	memset(j, 0, sizeof(*j));
+	j->qoff = T->qoff + (uint32_t)qb; j->qlen = qe - qb; j->qdir = 1;
+	j->tpos = rb; j->tlen = (int32_t)(re - rb); j->tdir = 1;
+	/* the reference asks for KSW_XSTART but only uses the score, which the forward pass fixes */
+	j->xtra = 0;
+	j->use_ct = (uint8_t)T->parent;
+	return j->tlen > 0 && j->qlen > 0;
+}
+
+static int filter_chained_seeds(chunk_t *C)
+{
+	BSX_VEC(bsx_sw_job_t) jobs;
+	bsx_sw_res_t *res = 0;
+	int t, rc = BSX_OK, minsc;
+	size_t u, j, k, cur = 0;
+	bsx_vec_init(jobs);
+	for (t = 0; t < C->n_tasks; ++t) {
+		c2r_t *T = &C->tasks[t];
+		if (!seed_sw_active(C->opt, T->l_query, &minsc)) continue;
+		for (u = 0; u < T->chains.n; ++u)
+			for (j = 0; j < T->chains.a[u].seeds.n; ++j) {
+				bsx_sw_job_t jb;
+				if (seed_sw_job(C, T, &T->chains.a[u].seeds.a[j], &jb)) bsx_vec_push(jobs, jb);
+			}
+	}
+	if (jobs.n) {
+		res = (bsx_sw_res_t*)malloc(sizeof(*res) * jobs.n);
+		rc = C->be->sw_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res);
+		g_stats.n_sw_jobs += (int64_t)jobs.n;
+	}
+	if (rc == BSX_OK) {
+		for (t = 0; t < C->n_tasks; ++t) {
+			c2r_t *T = &C->tasks[t];
+			if (!seed_sw_active(C->opt, T->l_query, &minsc)) continue;
+			for (u = 0; u < T->chains.n; ++u) {
+				chain_t *c = &T->chains.a[u];
+				for (j = k = 0; j < c->seeds.n; ++j) {
+					seed_t *s = &c->seeds.a[j];
+					bsx_sw_job_t jb;
+					s->score = seed_sw_job(C, T, s, &jb) ? res[cur++].score : -1;
+					if (s->score < 0 || s->score >= minsc) {
+						s->score = s->score < 0 ? s->len * C->opt->a : s->score;
+						c->seeds.a[k++] = *s;
+					}
+				}
+				c->seeds.n = k;
+			}
+		}
+	}
+	free(res); bsx_vec_free(jobs);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ extension rounds */
+static void advance_worker(void *data, long t, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	c2r_t *T = &C->tasks[t];
+	(void)tid;
+	if (!T->done && !T->has_job) bsx_c2r_advance(C->opt, C->idx, T);
+}
+
+typedef struct { chunk_t *C; const int *owner; const bsx_ext_res_t *res; } consume_par_t;
+static void consume_worker(void *data, long i, int tid)
+{
+	consume_par_t *P = (consume_par_t*)data;
+	(void)tid;
+	bsx_c2r_consume(P->C->opt, P->C->idx, &P->C->tasks[P->owner[i]], &P->res[i]);
+}
+
+static int extension_rounds(chunk_t *C)
+{
+	bsx_ext_job_t *jobs = (bsx_ext_job_t*)malloc(sizeof(bsx_ext_job_t) * ((size_t)C->n_tasks + 1));
+	bsx_ext_res_t *res = (bsx_ext_res_t*)malloc(sizeof(bsx_ext_res_t) * ((size_t)C->n_tasks + 1));
+	int *owner = (int*)malloc(sizeof(int) * ((size_t)C->n_tasks + 1));
+	int rc = BSX_OK;
+	for (;;) {
+		int t, nj = 0;
+		consume_par_t P;
+		bsx_parallel_for(C->nt, advance_worker, C, C->n_tasks);
+		for (t = 0; t < C->n_tasks; ++t)
+			if (C->tasks[t].has_job) { jobs[nj] = C->tasks[t].job; owner[nj++] = t; }
+		if (nj == 0) break;
+		if ((rc = C->be->extend_batch(C->be->ctx, nj, jobs, res)) != BSX_OK) break;
+		g_stats.n_ext_jobs += nj; ++g_stats.n_ext_rounds;
+		P.C = C; P.owner = owner; P.res = res;
+		bsx_parallel_for(C->nt, consume_worker, &P, nj);
+	}
+	free(jobs); free(res); free(owner);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ merge / dedup with batched concatenation tests */
+typedef struct { int64_t rb, re; int qb, qe, w, parent, score; } gcache_t;
+typedef struct {
+	chunk_t *C; int read;
+	BSX_VEC(gcache_t) cache;     /* known scores */
+	BSX_VEC(gcache_t) wanted;    /* requests raised by the last attempt */
+} merge_ud_t;
+
+static int merge_score_fn(void *ud_, const reg_t *a, const reg_t *b, int w, int *score)
+{
+	merge_ud_t *U = (merge_ud_t*)ud_;
+	gcache_t key;
+	size_t i;
+	key.rb = a->rb; key.re = b->re; key.qb = a->qb; key.qe = b->qe; key.w = w; key.parent = a->parent; key.score = 0;
+	for (i = 0; i < U->cache.n; ++i) {
+		const gcache_t *c = &U->cache.a[i];
+		if (c->rb == key.rb && c->re == key.re && c->qb == key.qb && c->qe == key.qe && c->w == key.w && c->parent == key.parent) { *score = c->score; return 0; }
+	}
+	bsx_vec_push(U->wanted, key);
+	return 1;
+}
+
+typedef struct { chunk_t *C; merge_ud_t *ud; reg_v *saved; int *pending; } merge_par_t;
+
+static void regs_copy(reg_v *dst, const reg_v *src)
+{
+	dst->n = src->n; dst->n_pri = src->n_pri;
+	if (dst->m < src->n) { dst->m = src->n + 4; dst->a = (reg_t*)realloc(dst->a, sizeof(reg_t) * dst->m); }
+	if (src->n) memcpy(dst->a, src->a, sizeof(reg_t) * src->n);
+}
+
+static void merge_worker(void *data, long i, int tid)
+{
+	merge_par_t *P = (merge_par_t*)data;
+	chunk_t *C = P->C;
+	reg_v *regs = &C->regs[i];
+	int missing = 0;
+	size_t k;
+	(void)tid;
+	if (!P->pending[i]) return;
+	regs_copy(regs, &P->saved[i]);
+	P->ud[i].wanted.n = 0;
+	bsx_regs_sort_dedup(C->opt, &C->idx->ref, 1, regs, merge_score_fn, &P->ud[i], &missing);
+	if (missing) return; /* retried once the scores have been computed */
+	P->pending[i] = 0;
+	/* mem_test_and_remove_exact (mem_alnreg.c:205-211) */
+	if ((C->opt->flag & BSX_F_SELF_OVLP) && regs->n > 0 && regs->a[0].truesc == C->reads[i].l_seq * C->opt->a) {
+		memmove(regs->a, regs->a + 1, (regs->n - 1) * sizeof(reg_t));
+		regs->n--;
+	}
+	for (k = 0; k < regs->n; ++k) {
+		reg_t *p = &regs->a[k];
+		if (p->rid >= 0 && C->idx->ref.anns[p->rid].is_alt) p->is_alt = 1;
+	}
+}
+
+static int merge_regions(chunk_t *C)
+{
+	int n = C->n, i, rc = BSX_OK, round;
+	merge_par_t P;
+	BSX_VEC(bsx_glb_job_t) jobs;
+	BSX_VEC(int) jowner;
+	P.C = C;
+	P.ud = (merge_ud_t*)calloc(n ? n : 1, sizeof(merge_ud_t));
+	P.saved = (reg_v*)calloc(n ? n : 1, sizeof(reg_v));
+	P.pending = (int*)malloc(sizeof(int) * (n ? n : 1));
+	bsx_vec_init(jobs); bsx_vec_init(jowner);
+	for (i = 0; i < n; ++i) { /* concatenate the regions of the read's strand searches in call order */
+		int t;
+		reg_v *r = &P.saved[i];
+		P.ud[i].C = C; P.ud[i].read = i;
+		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
+			c2r_t *T = &C->tasks[t];
+			if (T->regs.n) {
+				if (r->m < r->n + T->regs.n) { r->m = (r->n + T->regs.n) * 2; r->a = (reg_t*)realloc(r->a, sizeof(reg_t) * r->m); }
+				memcpy(r->a + r->n, T->regs.a, sizeof(reg_t) * T->regs.n);
+				r->n += T->regs.n;
+			}
+		}
+		P.pending[i] = 1;
+	}
+	for (round = 0; round < 64; ++round) {
+		bsx_glb_res_t *res;
+		size_t k;
+		bsx_parallel_for(C->nt, merge_worker, &P, n);
+		jobs.n = 0; jowner.n = 0;
+		for (i = 0; i < n; ++i) {
+			if (!P.pending[i]) continue;
+			for (k = 0; k < P.ud[i].wanted.n; ++k) {
+				const gcache_t *g = &P.ud[i].wanted.a[k];
+				bsx_glb_job_t j;
+				int rev = g->rb >= C->idx->ref.l_pac;
+				memset(&j, 0, sizeof(j));
+				j.qlen = g->qe - g->qb; j.tlen = (int32_t)(g->re - g->rb);
+				j.qoff = C->roff[i] + (uint32_t)(rev ? g->qe - 1 : g->qb); j.qdir = rev ? -1 : 1;
+				j.tpos = rev ? g->re - 1 : g->rb; j.tdir = rev ? -1 : 1;
+				j.w0 = g->w; j.w_max = g->w > C->opt->w << 2 ? g->w : C->opt->w << 2; j.n_try = 1; j.use_ct = (uint8_t)g->parent; j.want_cigar = 0;
+				bsx_vec_push(jobs, j); bsx_vec_push(jowner, i);
+			}
+		}
+		if (jobs.n == 0) break;
+		res = (bsx_glb_res_t*)malloc(sizeof(*res) * jobs.n);
+		rc = C->be->global_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res, 0, 0);
+		g_stats.n_glb_jobs += (int64_t)jobs.n;
+		if (rc == BSX_OK) {
+			size_t cur = 0;
+			for (i = 0; i < n; ++i) {
+				if (!P.pending[i]) continue;
+				for (k = 0; k < P.ud[i].wanted.n; ++k) { gcache_t g = P.ud[i].wanted.a[k]; g.score = res[cur++].score; bsx_vec_push(P.ud[i].cache, g); }
+			}
+		}
+		free(res);
+		if (rc != BSX_OK) break;
+	}
+	for (i = 0; i < n; ++i) { bsx_vec_free(P.ud[i].cache); bsx_vec_free(P.ud[i].wanted); free(P.saved[i].a); }
+	free(P.ud); free(P.saved); free(P.pending); bsx_vec_free(jobs); bsx_vec_free(jowner);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ mate rescue (mem_alnreg.c:395-513) */
+typedef struct { int i, j; bsx_sw_job_t job; bsx_sw_res_t res; int have; } msw_slot_t;
+typedef struct {
+	reg_v saved[2];
+	BSX_VEC(msw_slot_t) slots;
+	int pending;
+} msw_pair_t;
+
+static int no_glb(void *ud, const reg_t *a, const reg_t *b, int w, int *score) { (void)ud; (void)a; (void)b; (void)w; *score = 0; return 0; }
+
+/* one mem_alnreg_matesw_core; returns 1 if its SW result was needed but is not available yet */
+static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const reg_t *reg, int mate_read, reg_v *mregs, int apply)
+{
+	const bsx_opt_t *opt = C->opt;
+	const bsx_refmeta_t *ref = &C->idx->ref;
+	int64_t l_pac = ref->l_pac, rb, re, is;
+	int l_ms = C->reads[mate_read].l_seq, rid = -1, parent, xtra;
+	size_t k;
+	msw_slot_t *slot = 0;
+	(void)pi;
+	for (k = 0; k < mregs->n; ++k)
+		if (bsx_reg_isize(ref, reg, &mregs->a[k], &is) && is >= C->pes.low && is <= C->pes.high) return 0;
+	rb = reg->rb + C->pes.low - l_ms; rb = rb > 0 ? rb : 0;
+	re = reg->rb + C->pes.high; re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < re) rid = bsx_fetch_span(ref, &rb, (rb + re) >> 1, &re);
+	if (reg->rid != rid || re - rb < opt->min_seed_len) return 0;
+	parent = reg->bss ^ (reg->rb < l_pac);
+	xtra = BSX_KSW_XSUBO | BSX_KSW_XSTART | (l_ms * opt->a < 250 ? BSX_KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+	for (k = 0; k < M->slots.n; ++k) if (M->slots.a[k].i == i && M->slots.a[k].j == j) { slot = &M->slots.a[k]; break; }
+	if (!slot) {
+		msw_slot_t s;
+		memset(&s, 0, sizeof(s));
+		s.i = i; s.j = j;
+		s.job.qoff = C->roff[mate_read] + (uint32_t)l_ms - 1; s.job.qlen = l_ms; s.job.qdir = -1; s.job.qcomp = 1;  /* reverse complement of the mate */
+		s.job.tpos = rb; s.job.tlen = (int32_t)(re - rb); s.job.tdir = 1;
+		s.job.xtra = xtra; s.job.use_ct = (uint8_t)(parent ? 0 : 1);   /* the mate is on the other converted strand */
+		bsx_vec_push(M->slots, s);
+		return 1;
+	}
+	if (!slot->have) return 1;
+	if (!apply) return 0;
+	if (slot->res.score >= opt->min_seed_len && slot->res.qb >= 0) {
+		reg_t b;
+		int64_t d1, d2;
+		int ins, pos;
+		int missing = 0;
+		memset(&b, 0, sizeof(b));
+		b.rid = reg->rid; b.is_alt = reg->is_alt;
+		b.qb = l_ms - (slot->res.qe + 1); b.qe = l_ms - slot->res.qb;
+		b.rb = (l_pac << 1) - (rb + slot->res.te + 1); b.re = (l_pac << 1) - (rb + slot->res.tb);
+		b.score = slot->res.score; b.csub = slot->res.score2; b.secondary = -1;
+		d1 = b.re - b.rb; d2 = b.qe - b.qb;
+		b.seedcov = (int)((d1 < d2 ? d1 : d2) >> 1);
+		b.bss = reg->bss; b.parent = (uint8_t)(1 - parent);
+		/* keep the mate list ordered by score, then de-duplicate without merging (mem_alnreg.c:478-488) */
+		if (mregs->n == mregs->m) { mregs->m = mregs->m ? mregs->m << 1 : 4; mregs->a = (reg_t*)realloc(mregs->a, sizeof(reg_t) * mregs->m); }
+		++mregs->n;
+		for (ins = 0; (size_t)ins < mregs->n - 1; ++ins) if (mregs->a[ins].score < b.score) break;
+		for (pos = (int)mregs->n - 1; pos > ins; --pos) mregs->a[pos] = mregs->a[pos - 1];
+		mregs->a[ins] = b;
+		bsx_regs_sort_dedup(opt, ref, 0, mregs, no_glb, 0, &missing);
+	}
+	return 0;
+}
+
+/* mem_alnreg_matesw for pair pi, replayed on the saved lists; 0 when complete */
+static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
+{
+	const bsx_opt_t *opt = C->opt;
+	reg_v *pair = &C->regs[pi << 1];
+	reg_v good[2];
+	int i, missing = 0;
+	size_t j;
+	regs_copy(&pair[0], &M->saved[0]); regs_copy(&pair[1], &M->saved[1]);
+	memset(good, 0, sizeof(good));
+	for (i = 0; i < 2; ++i)
+		for (j = 0; j < pair[i].n; ++j)
+			if (pair[i].a[j].score >= pair[i].a[0].score - opt->pen_unpaired) {
+				if (good[i].n == good[i].m) { good[i].m = good[i].m ? good[i].m << 1 : 4; good[i].a = (reg_t*)realloc(good[i].a, sizeof(reg_t) * good[i].m); }
+				good[i].a[good[i].n++] = pair[i].a[j];
+			}
+	for (i = 0; i < 2; ++i)
+		for (j = 0; j < good[i].n && (int)j < opt->max_matesw; ++j)
+			/* once a result is missing, keep walking (without applying) only to collect further requests */
+			missing |= matesw_core(C, M, pi, i, (int)j, &good[i].a[j], (pi << 1) | !i, &pair[!i], !missing);
+	free(good[0].a); free(good[1].a);
+	return missing;
+}
+
+typedef struct { chunk_t *C; msw_pair_t *M; } msw_par_t;
+static void msw_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	(void)tid;
+	if (P->M[pi].pending) P->M[pi].pending = matesw_replay(P->C, &P->M[pi], (int)pi);
+}
+
+static int mate_rescue(chunk_t *C)
+{
+	int np = C->n >> 1, pi, rc = BSX_OK, round;
+	msw_pair_t *M = (msw_pair_t*)calloc(np ? np : 1, sizeof(msw_pair_t));
+	msw_par_t P;
+	BSX_VEC(bsx_sw_job_t) jobs;
+	bsx_vec_init(jobs);
+	for (pi = 0; pi < np; ++pi) { regs_copy(&M[pi].saved[0], &C->regs[pi << 1]); regs_copy(&M[pi].saved[1], &C->regs[pi << 1 | 1]); M[pi].pending = 1; }
+	P.C = C; P.M = M;
+	for (round = 0; round < 256; ++round) {
+		bsx_sw_res_t *res;
+		size_t k, cur;
+		bsx_parallel_for(C->nt, msw_worker, &P, np);
+		jobs.n = 0;
+		for (pi = 0; pi < np; ++pi)
+			if (M[pi].pending) for (k = 0; k < M[pi].slots.n; ++k) if (!M[pi].slots.a[k].have) bsx_vec_push(jobs, M[pi].slots.a[k].job);
+		if (jobs.n == 0) break;
+		res = (bsx_sw_res_t*)malloc(sizeof(*res) * jobs.n);
+		rc = C->be->sw_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res);
+		g_stats.n_sw_jobs += (int64_t)jobs.n;
+		if (rc == BSX_OK)
+			for (pi = 0, cur = 0; pi < np; ++pi)
+				if (M[pi].pending) for (k = 0; k < M[pi].slots.n; ++k) if (!M[pi].slots.a[k].have) { M[pi].slots.a[k].res = res[cur++]; M[pi].slots.a[k].have = 1; }
+		free(res);
+		if (rc != BSX_OK) break;
+	}
+	for (pi = 0; pi < np; ++pi) { free(M[pi].saved[0].a); free(M[pi].saved[1].a); bsx_vec_free(M[pi].slots); }
+	free(M); bsx_vec_free(jobs);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ output: plan -> K6 -> final */
+typedef struct {
+	chunk_t *C;
+	samctx_t *ctx;        /* per unit (pair or single read) */
+	int final_pass;
+} out_par_t;
+
+static void reset_flags(reg_v *r) { size_t k; for (k = 0; k < r->n; ++k) r->a[k].flag = 0; }
+
+static void out_worker(void *data, long u, int tid)
+{
+	out_par_t *P = (out_par_t*)data;
+	chunk_t *C = P->C;
+	samctx_t *ctx = &P->ctx[u];
+	(void)tid;
+	if (C->is_pe) {
+		reg_v *pair = &C->regs[u << 1];
+		if (!P->final_pass) { /* plan on a scratch copy */
+			reg_v tmp[2];
+			memset(tmp, 0, sizeof(tmp));
+			bsx_mark_primary(C->opt, &pair[0], u << 1 | 0);   /* ids are chunk-local for PE (bwamem.c:408,413) */
+			bsx_mark_primary(C->opt, &pair[1], u << 1 | 1);
+			reset_flags(&pair[0]); reset_flags(&pair[1]);
+			regs_copy(&tmp[0], &pair[0]); regs_copy(&tmp[1], &pair[1]);
+			ctx->plan = 1;
+			bsx_reg2sam_pe(C->opt, C->idx, (uint64_t)((C->n_processed >> 1) + u), &C->reads[u << 1], tmp, &C->pes, ctx, bsx_rg_id);
+			free(tmp[0].a); free(tmp[1].a);
+		} else {
+			ctx->plan = 0;
+			bsx_reg2sam_pe(C->opt, C->idx, (uint64_t)((C->n_processed >> 1) + u), &C->reads[u << 1], pair, &C->pes, ctx, bsx_rg_id);
+		}
+	} else {
+		reg_v *regs = &C->regs[u];
+		if (!P->final_pass) {
+			reg_v tmp;
+			memset(&tmp, 0, sizeof(tmp));
+			bsx_mark_primary(C->opt, regs, C->n_processed + u);
+			reset_flags(regs);
+			regs_copy(&tmp, regs);
+			ctx->plan = 1;
+			bsx_reg2sam_se(C->opt, C->idx, &C->reads[u], &tmp, ctx, bsx_rg_id);
+			free(tmp.a);
+		} else {
+			ctx->plan = 0;
+			bsx_reg2sam_se(C->opt, C->idx, &C->reads[u], regs, ctx, bsx_rg_id);
+		}
+	}
+}
+
+static int emit_sam(chunk_t *C)
+{
+	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, u, w, rc = BSX_OK, round;
+	samctx_t *ctx = (samctx_t*)calloc(n_units ? n_units : 1, sizeof(samctx_t));
+	out_par_t P;
+	BSX_VEC(bsx_glb_job_t) jobs;
+	BSX_VEC(int) jread, jreg, todo;
+	bsx_glb_res_t *res = 0;
+	uint32_t *pool = 0;
+	size_t k, pool_len = 0;
+	double t0 = now_s();
+	bsx_vec_init(jobs); bsx_vec_init(jread); bsx_vec_init(jreg); bsx_vec_init(todo);
+	P.C = C; P.ctx = ctx; P.final_pass = 0;
+	bsx_parallel_for(C->nt, out_worker, &P, n_units);
+	g_stats.t_primary += now_s() - t0; t0 = now_s();
+	for (u = 0; u < n_units; ++u)
+		for (w = 0; w < per; ++w) {
+			int ri = u * per + w;
+			reg_v *regs = &C->regs[ri];
+			ctx[u].table[w] = (samrec_t*)calloc(regs->n ? regs->n : 1, sizeof(samrec_t));
+			for (k = 0; k < ctx[u].want[w].n; ++k) {
+				bsx_glb_job_t j;
+				int gi = ctx[u].want[w].a[k];
+				bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &j);
+				j.cigar_cap = 24;
+				bsx_vec_push(jobs, j); bsx_vec_push(jread, ri); bsx_vec_push(jreg, gi);
+			}
+		}
+	res = (bsx_glb_res_t*)malloc(sizeof(*res) * (jobs.n ? jobs.n : 1));
+	for (k = 0; k < jobs.n; ++k) bsx_vec_push(todo, (int)k);
+	for (round = 0; round < 8 && todo.n && rc == BSX_OK; ++round) { /* a CIGAR that does not fit is redone with the room it asked for */
+		bsx_glb_job_t *sub = (bsx_glb_job_t*)malloc(sizeof(*sub) * todo.n);
+		bsx_glb_res_t *sres = (bsx_glb_res_t*)malloc(sizeof(*sres) * todo.n);
+		size_t off = 0, nt = 0;
+		for (k = 0; k < todo.n; ++k) { sub[k] = jobs.a[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
+		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
+		rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
+		g_stats.n_glb_jobs += (int64_t)todo.n;
+		if (rc == BSX_OK)
+			for (k = 0; k < todo.n; ++k) {
+				int jj = todo.a[k], ri = jread.a[jj];
+				res[jj] = sres[k];
+				if (sres[k].n_cigar < 0) { jobs.a[jj].cigar_cap = (uint32_t)(-sres[k].n_cigar) + 2; todo.a[nt++] = jj; continue; }
+				bsx_setsam_finish(C->opt, C->idx, &C->reads[ri], &C->regs[ri].a[jreg.a[jj]], pool + sub[k].cigar_off, sres[k].n_cigar,
+				                  &ctx[ri / per].table[ri % per][jreg.a[jj]]);
+			}
+		todo.n = nt;
+		free(sub); free(sres);
+	}
+	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
+	g_stats.t_cigar += now_s() - t0; t0 = now_s();
+	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
+	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
+	for (u = 0; u < n_units; ++u)
+		for (w = 0; w < per; ++w) {
+			reg_v *regs = &C->regs[u * per + w];
+			for (k = 0; k < regs->n; ++k) free(ctx[u].table[w][k].cigar);
+			free(ctx[u].table[w]); bsx_vec_free(ctx[u].want[w]);
+		}
+	g_stats.t_sam += now_s() - t0;
+	free(ctx); free(res); free(pool);
+	bsx_vec_free(jobs); bsx_vec_free(jread); bsx_vec_free(jreg); bsx_vec_free(todo);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ the chunk */
+BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+{
+	chunk_t C;
+	int rc = BSX_OK, i, t, nt = opt->n_threads > 0 ? opt->n_threads : 1;
+	size_t tot = 0;
+	uint8_t *buf = 0;
+	bsx_seed_task_t *stasks = 0;
+	double t0, t_all = now_s();
+
+	memset(&C, 0, sizeof(C));
+	memset(&g_stats, 0, sizeof(g_stats));
+	if (!be || !opt || !idx || n < 0) return BSX_E_ARG;
+	if (n == 0) return BSX_OK;
+	C.be = be; C.opt = opt; C.idx = idx; C.n = n; C.reads = reads; C.n_processed = n_processed; C.nt = nt;
+	C.is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
+	if (C.is_pe && (n & 1)) return BSX_E_ARG;
+
+	/* clipping + chunk read buffer */
+	for (i = 0; i < n; ++i) {
+		if (C.is_pe) {
+			if (!(i & 1) && !pair_names_ok(reads[i].name, reads[i + 1].name)) {
+				fprintf(stderr, "[bsx] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name);
+				return BSX_E_FORMAT;
+			}
+			clip_read(&reads[i], (i & 1) ? opt->adaptor2 : opt->adaptor1, (i & 1) ? opt->l_adaptor2 : opt->l_adaptor1, opt);
+		} else clip_read(&reads[i], opt->adaptor1, opt->l_adaptor1, opt);
+		reads[i].sam = 0;
+	}
+	C.roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	for (i = 0; i < n; ++i) { C.roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
+	C.roff[n] = (uint32_t)tot;
+	if (tot >= 0xffff0000ull) { free(C.roff); return BSX_E_ARG; }
+	buf = (uint8_t*)malloc(tot + 16);
+	for (i = 0; i < n; ++i) if (reads[i].l_seq) memcpy(buf + C.roff[i], reads[i].seq, (size_t)reads[i].l_seq);
+	CHECK(be->set_opt(be->ctx, opt));
+	CHECK(be->set_reads(be->ctx, buf, tot));
+
+	/* strand searches in the reference's call order (bwamem.c:325-333,352-372) */
+	C.read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
+	C.tasks = (c2r_t*)calloc((size_t)n * 2 + 1, sizeof(c2r_t));
+	for (i = 0; i < n; ++i) {
+		int order[2], no = 0, k;
+		if (!C.is_pe) {
+			if (!(opt->parent & 1) || opt->parent >> 1) order[no++] = 0;
+			if (!(opt->parent & 1) || !(opt->parent >> 1)) order[no++] = 1;
+		} else if (!(i & 1)) { order[no++] = 1; if (!opt->parent) order[no++] = 0; }
+		else { order[no++] = 0; if (!opt->parent) order[no++] = 1; }
+		C.read_task0[i] = C.n_tasks;
+		for (k = 0; k < no; ++k) {
+			c2r_t *T = &C.tasks[C.n_tasks++];
+			T->read_idx = i; T->parent = order[k]; T->qoff = C.roff[i]; T->l_query = reads[i].l_seq; T->query = reads[i].seq;
+		}
+	}
+	C.read_task0[n] = C.n_tasks;
+	g_stats.n_tasks = C.n_tasks;
+	stasks = (bsx_seed_task_t*)malloc(sizeof(*stasks) * ((size_t)C.n_tasks + 1));
+	for (t = 0; t < C.n_tasks; ++t) { stasks[t].qoff = C.tasks[t].qoff; stasks[t].len = C.tasks[t].l_query; stasks[t].parent = C.tasks[t].parent; }
+
+	/* K1+K2 */
+	t0 = now_s();
+	C.intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
+	CHECK(be->seed_batch(be->ctx, opt, C.n_tasks, stasks, &C.intv, &C.intv_cap, C.intv_off));
+	g_stats.t_seed = now_s() - t0; g_stats.n_intv = C.intv_off[C.n_tasks];
+
+	/* K3: the first min(occ, max_occ) occurrences of every interval */
+	t0 = now_s();
+	{
+		int64_t n_iv = C.intv_off[C.n_tasks], k, nj = 0, c;
+		bsx_sa_job_t *sj;
+		C.ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+		for (k = 0; k < n_iv; ++k) { C.ipos_off[k] = nj; nj += (int64_t)(C.intv[k].x[2] < opt->max_occ ? C.intv[k].x[2] : opt->max_occ); }
+		C.ipos_off[n_iv] = nj;
+		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
+		for (t = 0; t < C.n_tasks; ++t)
+			for (k = C.intv_off[t]; k < C.intv_off[t + 1]; ++k)
+				for (c = 0; c < C.ipos_off[k + 1] - C.ipos_off[k]; ++c) {
+					bsx_sa_job_t *j = &sj[C.ipos_off[k] + c];
+					j->k = C.intv[k].x[0] + (uint64_t)c; j->parent = C.tasks[t].parent; j->pad = 0;
+				}
+		C.pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+		rc = be->sa_batch(be->ctx, nj, sj, C.pos);
+		free(sj);
+		g_stats.n_sa = nj;
+		if (rc != BSX_OK) goto done;
+	}
+	g_stats.t_sa = now_s() - t0;
+
+	/* chaining (host); intervals that must be walked past max_occ get their remaining occurrences looked up */
+	t0 = now_s();
+	C.need_more = (int*)calloc((size_t)C.n_tasks + 1, sizeof(int));
+	C.xpos = (uint64_t**)calloc((size_t)C.n_tasks + 1, sizeof(uint64_t*));
+	C.xpos_off = (int64_t**)calloc((size_t)C.n_tasks + 1, sizeof(int64_t*));
+	C.trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
+	for (i = 0; i < nt; ++i) C.trees[i] = bsx_bt_new();
+	for (;;) {
+		int any = 0;
+		bsx_parallel_for(nt, chain_worker, &C, C.n_tasks);
+		for (t = 0; t < C.n_tasks; ++t) {
+			int n_iv, k, want;
+			int64_t nj, c;
+			bsx_sa_job_t *sj;
+			if (C.need_more[t] <= 0) continue;
+			any = 1;
+			n_iv = (int)(C.intv_off[t + 1] - C.intv_off[t]);
+			want = C.need_more[t] - 1;
+			if (!C.xpos_off[t]) {
+				C.xpos_off[t] = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+				for (k = 0; k <= n_iv; ++k) C.xpos_off[t][k] = C.ipos_off[C.intv_off[t] + k] - C.ipos_off[C.intv_off[t]];
+			}
+			{ /* give interval `want` all of its occurrences, keep the others */
+				int64_t *cnt = (int64_t*)malloc(sizeof(int64_t) * (size_t)n_iv);
+				for (k = 0; k < n_iv; ++k) cnt[k] = C.xpos_off[t][k + 1] - C.xpos_off[t][k];
+				cnt[want] = (int64_t)C.intv[C.intv_off[t] + want].x[2];
+				for (k = 0, nj = 0; k < n_iv; ++k) { C.xpos_off[t][k] = nj; nj += cnt[k]; }
+				C.xpos_off[t][n_iv] = nj;
+				free(cnt);
+			}
+			sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
+			for (k = 0; k < n_iv; ++k)
+				for (c = 0; c < C.xpos_off[t][k + 1] - C.xpos_off[t][k]; ++c) {
+					bsx_sa_job_t *j = &sj[C.xpos_off[t][k] + c];
+					j->k = C.intv[C.intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C.tasks[t].parent; j->pad = 0;
+				}
+			free(C.xpos[t]);
+			C.xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+			rc = be->sa_batch(be->ctx, nj, sj, C.xpos[t]);
+			free(sj);
+			g_stats.n_sa += nj;
+			if (rc != BSX_OK) goto done;
+			C.need_more[t] = 0;
+		}
+		if (!any) break;
+	}
+	CHECK(filter_chained_seeds(&C));
+	g_stats.t_chain = now_s() - t0;
+
+	/* K4 rounds */
+	t0 = now_s();
+	CHECK(extension_rounds(&C));
+	g_stats.t_extend = now_s() - t0;
+
+	/* merge */
+	t0 = now_s();
+	C.regs = (reg_v*)calloc((size_t)n + 1, sizeof(reg_v));
+	CHECK(merge_regions(&C));
+	g_stats.t_merge = now_s() - t0;
+
+	if (C.is_pe) {
+		t0 = now_s();
+		if (pes0) C.pes = *pes0;
+		else C.pes = bsx_pestat(opt, &idx->ref, n, C.regs);
+		g_stats.t_pestat = now_s() - t0;
+		t0 = now_s();
+		if (!(opt->flag & BSX_F_NO_RESCUE)) CHECK(mate_rescue(&C));
+		g_stats.t_matesw = now_s() - t0;
+	}
+	CHECK(emit_sam(&C));
+
+done:
+	if (C.tasks) {
+		for (t = 0; t < C.n_tasks; ++t) { bsx_c2r_release(&C.tasks[t]); bsx_vec_free(C.tasks[t].regs); if (C.xpos) free(C.xpos[t]); if (C.xpos_off) free(C.xpos_off[t]); }
+		free(C.tasks);
+	}
+	if (C.regs) { for (i = 0; i < n; ++i) free(C.regs[i].a); free(C.regs); }
+	if (C.trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C.trees[i]); free(C.trees); }
+	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
+	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
+	g_stats.t_total = now_s() - t_all;
+	if (bsx_verbose >= 3)
+		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", n, g_stats.t_total, be->name ? be->name : "?");
+	return rc;
+}
+
+BSX_API int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx,
+                             int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+{
+	bsx_backend_t be;
+	int rc = bsx_hip_backend(dev, &be);   /* the HIP kernels are the only product backend */
+	if (rc != BSX_OK) return rc;
+	return bsx_process_seqs_backend(&be, opt, idx, n_processed, n, reads, pes0);
+}

@@ -1,0 +1,55 @@
+/* pipeline.h -- per-chunk working records of the batch pipeline (pipeline.c) */
+#ifndef BSX_PIPELINE_H
+#define BSX_PIPELINE_H
+
+#include "align_types.h"
+
+/* one strand search (mem_align1_core call, lib/aln/bwamem.c:183-208) being turned into regions */
+typedef struct {
+	int read_idx, parent;
+	uint32_t qoff;            /* of the clipped read in the chunk read buffer */
+	int l_query;
+	const uint8_t *query;     /* clipped raw read on the host */
+	chain_v chains;
+	BSX_VEC(reg_t) regs;
+	/* state machine (extend.c) */
+	int ci, chain_open, pass, n0;
+	uint64_t *srt; int n_srt, m_srt, k;
+	int stage, tryi;
+	int64_t rmax[2]; int rid;
+	reg_t cur; int aw[2]; int sc0;
+	bsx_ext_job_t job; int has_job, done;
+} c2r_t;
+
+int  bsx_c2r_advance(const bsx_opt_t *opt, const bsx_index_t *idx, c2r_t *t);
+void bsx_c2r_consume(const bsx_opt_t *opt, const bsx_index_t *idx, c2r_t *t, const bsx_ext_res_t *res);
+void bsx_c2r_release(c2r_t *t);
+
+/* ---------------- sam.c ---------------- */
+/* one computed CIGAR (what mem_alnreg_setSAM leaves in a region, lib/aln/mem_alnreg_format.c:40-123) */
+typedef struct {
+	int valid;
+	int pos, n_cigar, NM, bss_u;
+	uint32_t is_rev, ZC, ZR;
+	uint32_t *cigar;          /* ops + MD text, malloc'd */
+} samrec_t;
+
+typedef struct {
+	/* plan mode: collect the regions whose CIGAR will be needed instead of formatting */
+	int plan;
+	BSX_VEC(int) want[2];     /* region indices per read of the pair (or [0] for SE) */
+	samrec_t *table[2];       /* per region, filled between plan and final pass */
+} samctx_t;
+
+void bsx_reg2sam_se(const bsx_opt_t *opt, const bsx_index_t *idx, bsx_read_t *s, reg_v *regs, samctx_t *ctx, const char *rg_id);
+void bsx_reg2sam_pe(const bsx_opt_t *opt, const bsx_index_t *idx, uint64_t id, bsx_read_t s[2], reg_v regs[2],
+                    const bsx_pestat_t *pes, samctx_t *ctx, const char *rg_id);
+/* K6 job for one region (band inference of mem_alnreg_setSAM) */
+void bsx_setsam_job(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, uint32_t qoff, const reg_t *reg, bsx_glb_job_t *job);
+/* finish a region's SAM record from the device CIGAR: MD/NM/ZC/ZR, D-squeezing, clipping, position */
+void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, const reg_t *reg,
+                       const uint32_t *cigar, int n_cigar, samrec_t *out);
+
+extern char bsx_rg_id[256];
+
+#endif

@@ -1,0 +1,373 @@
+/* region.c -- C5/C6/C7/R1: region de-duplication and merging, primary marking, insert-size
+ * statistics, pairing and MAPQ.  All of it is cheap, branchy and order dependent, and the
+ * floating-point parts (libm log/erfc/sqrt followed by +.499 truncation) must run on the host's
+ * glibc to match the reference bit for bit, so it stays on the CPU.
+ */
+#include <math.h>
+#include <limits.h>
+#include "align_types.h"
+
+#define PATCH_MAX_R_BW 0.05f       /* mem_alnreg.c:51-52 */
+#define PATCH_MIN_SC_RATIO 0.90f
+
+/* ------------------------------------------------------------------ sort / dedup / merge */
+static int reg_re_lt(const void *a, const void *b) { return ((const reg_t*)a)->re < ((const reg_t*)b)->re; }          /* alnreg_slt2 */
+static int reg_score_lt(const void *a_, const void *b_)                                                           /* alnreg_slt */
+{
+	const reg_t *a = (const reg_t*)a_, *b = (const reg_t*)b_;
+	return a->score > b->score || (a->score == b->score && (a->rb < b->rb || (a->rb == b->rb && a->qb < b->qb)));
+}
+
+/* mem_test_reg_concatenation, mem_alnreg.c:63-108 */
+static int try_concat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const reg_t *a, const reg_t *b, int *_w,
+                      bsx_glb_score_fn score_fn, void *ud, int *missing)
+{
+	int w, score, q_s, r_s;
+	double r;
+	if (a->rb < ref->l_pac && b->rb >= ref->l_pac) return 0;
+	if (a->qb >= b->qb || a->qe >= b->qe || a->re >= b->re) return 0;
+	w = (int)((a->re - b->rb) - (a->qe - b->qb));
+	w = w > 0 ? w : -w;
+	r = (double)(a->re - b->rb) / (b->re - a->rb) - (double)(a->qe - b->qb) / (b->qe - a->qb);
+	r = r > 0. ? r : -r;
+	if (a->re < b->rb || a->qe < b->qb) {
+		if (w > opt->w << 1 || r >= PATCH_MAX_R_BW) return 0;
+	} else if (w > opt->w << 2 || r >= PATCH_MAX_R_BW * 2) return 0;
+	w += a->w + b->w;
+	w = w < opt->w << 2 ? w : opt->w << 2;
+	if (score_fn(ud, a, b, w, &score)) { *missing = 1; return 0; }
+	q_s = (int)((double)(b->qe - a->qb) / ((b->qe - b->qb) + (a->qe - a->qb)) * (b->score + a->score) + .499);
+	r_s = (int)((double)(b->re - a->rb) / ((b->re - b->rb) + (a->re - a->rb)) * (b->score + a->score) + .499);
+	if ((double)score / (q_s > r_s ? q_s : r_s) < PATCH_MIN_SC_RATIO) return 0;
+	*_w = w;
+	return score;
+}
+
+/* mem_sort_deduplicate, mem_alnreg.c:112-202 */
+void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can_merge, reg_v *regs,
+                         bsx_glb_score_fn score_fn, void *ud, int *missing)
+{
+	int i, m;
+	if (regs->n <= 1) return;
+	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_re_lt);   /* by END, not start */
+	for (i = 0; (size_t)i < regs->n; ++i) regs->a[i].n_comp = 1;
+	for (i = 1; (size_t)i < regs->n; ++i) {
+		reg_t *p = &regs->a[i];
+		int j;
+		for (j = i - 1; j >= 0 && p->rid == regs->a[j].rid && p->rb < regs->a[j].re + opt->max_chain_gap; --j) {
+			reg_t *q = &regs->a[j];
+			int64_t or_, oq, mr, mq;
+			int score, w;
+			if (q->qe == q->qb) continue;
+			or_ = q->re - p->rb;
+			oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+			mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+			mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+			if (or_ > opt->mask_level_redun * mr && oq > opt->mask_level_redun * mq) { /* one of the two is redundant */
+				if (p->score < q->score) { p->qe = p->qb; break; }
+				else q->qe = q->qb;
+			} else if (can_merge && q->rb < p->rb && (score = try_concat(opt, ref, q, p, &w, score_fn, ud, missing)) > 0) {
+				p->n_comp += q->n_comp + 1;
+				p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+				p->sub = p->sub > q->sub ? p->sub : q->sub;
+				p->csub = p->csub > q->csub ? p->csub : q->csub;
+				p->truesc = p->score = score;
+				p->qb = q->qb; p->rb = q->rb;
+				p->w = w;
+				q->qb = q->qe;
+			}
+		}
+	}
+	for (i = 0, m = 0; (size_t)i < regs->n; ++i)
+		if (regs->a[i].qe > regs->a[i].qb) { if (m != i) regs->a[m++] = regs->a[i]; else ++m; }
+	regs->n = m;
+	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_score_lt);
+	for (i = 1; (size_t)i < regs->n; ++i)
+		if (regs->a[i].score == regs->a[i - 1].score && regs->a[i].rb == regs->a[i - 1].rb && regs->a[i].qb == regs->a[i - 1].qb)
+			regs->a[i].qe = regs->a[i].qb;
+	for (i = 1, m = 1; (size_t)i < regs->n; ++i)
+		if (regs->a[i].qe > regs->a[i].qb) { if (m != i) regs->a[m++] = regs->a[i]; else ++m; }
+	regs->n = m;
+}
+
+/* ------------------------------------------------------------------ primary marking */
+static int reg_hash_lt(const void *a_, const void *b_)   /* alnreg_hlt: score desc, is_alt, hash */
+{
+	const reg_t *a = (const reg_t*)a_, *b = (const reg_t*)b_;
+	return a->score > b->score || (a->score == b->score && (a->is_alt < b->is_alt || (a->is_alt == b->is_alt && a->hash < b->hash)));
+}
+static int reg_hash_lt2(const void *a_, const void *b_)  /* alnreg_hlt2: is_alt, score desc, hash */
+{
+	const reg_t *a = (const reg_t*)a_, *b = (const reg_t*)b_;
+	return a->is_alt < b->is_alt || (a->is_alt == b->is_alt && (a->score > b->score || (a->score == b->score && a->hash < b->hash)));
+}
+
+typedef BSX_VEC(int) int_v;
+
+/* mem_mark_primary_se_core, mem_alnreg.c:252-288 */
+static void mark_core(const bsx_opt_t *opt, int n_mark, reg_v *regs, int_v *z)
+{
+	int tmp = opt->a + opt->b, i;
+	tmp = opt->o_del + opt->e_del > tmp ? opt->o_del + opt->e_del : tmp;
+	tmp = opt->o_ins + opt->e_ins > tmp ? opt->o_ins + opt->e_ins : tmp;
+	z->n = 0;
+	bsx_vec_push(*z, 0);
+	for (i = 1; i < n_mark; ++i) {
+		reg_t *a = &regs->a[i];
+		size_t k;
+		for (k = 0; k < z->n; ++k) {
+			reg_t *b = &regs->a[z->a[k]];
+			int b_max = a->qb > b->qb ? a->qb : b->qb;
+			int e_min = a->qe < b->qe ? a->qe : b->qe;
+			if (e_min > b_max) {
+				int min_l = a->qe - a->qb < b->qe - b->qb ? a->qe - a->qb : b->qe - b->qb;
+				if (e_min - b_max >= min_l * opt->mask_level) {
+					if (b->sub == 0) b->sub = a->score;
+					if (b->score - a->score <= tmp && (b->is_alt || !a->is_alt)) ++b->sub_n;
+					break;
+				}
+			}
+		}
+		if (k == z->n) bsx_vec_push(*z, i);
+		else a->secondary = z->a[k];
+	}
+}
+
+/* mem_mark_primary_se, mem_alnreg.c:290-380 */
+void bsx_mark_primary(const bsx_opt_t *opt, reg_v *regs, int64_t id)
+{
+	int i;
+	int_v z;
+	regs->n_pri = 0;
+	if (regs->n == 0) return;
+	for (i = 0; (size_t)i < regs->n; ++i) {
+		reg_t *p = &regs->a[i];
+		p->sub = p->alt_sc = 0;
+		p->secondary = -1;
+		p->secondary_all = -1;
+		p->hash = bsx_hash64((uint64_t)(id + i));
+		if (!p->is_alt) ++regs->n_pri;
+	}
+	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_hash_lt);
+	bsx_vec_init(z);
+	mark_core(opt, (int)regs->n, regs, &z);
+	for (i = 0; (size_t)i < regs->n; ++i) {
+		reg_t *p = &regs->a[i];
+		p->secondary_all = i;
+		if (!p->is_alt && p->secondary >= 0 && regs->a[p->secondary].is_alt) p->alt_sc = regs->a[p->secondary].score;
+	}
+	if (regs->n_pri > 0 && regs->n_pri < regs->n) {
+		bsx_vec_reserve(z, regs->n);
+		bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_hash_lt2);
+		for (i = 0; (size_t)i < regs->n; ++i) z.a[regs->a[i].secondary_all] = i;
+		for (i = 0; (size_t)i < regs->n; ++i) {
+			if (regs->a[i].secondary >= 0) {
+				regs->a[i].secondary_all = z.a[regs->a[i].secondary];
+				if (regs->a[i].is_alt) regs->a[i].secondary = INT_MAX;
+			} else regs->a[i].secondary_all = -1;
+		}
+		for (i = 0; (size_t)i < regs->n_pri; ++i) { regs->a[i].sub = 0; regs->a[i].secondary = -1; }
+		mark_core(opt, (int)regs->n_pri, regs, &z);
+	} else {
+		for (i = 0; (size_t)i < regs->n; ++i) regs->a[i].secondary_all = regs->a[i].secondary;
+	}
+	bsx_vec_free(z);
+}
+
+/* ------------------------------------------------------------------ insert size */
+/* mem_infer_isize / mem_alnreg_isize, mem_alnreg.h:75-93 */
+static int infer_isize(int64_t pos1, int64_t pos2, int isrev1, int isrev2, int len1, int len2, int64_t *isize)
+{
+	if (isrev1 && !isrev2) { *isize = pos1 - pos2 + len1; return 1; }
+	else if (isrev2 && !isrev1) { *isize = pos2 - pos1 + len2; return 1; }
+	return 0;
+}
+int bsx_reg_isize(const bsx_refmeta_t *ref, const reg_t *r1, const reg_t *r2, int64_t *isize)
+{
+	int isrev1, isrev2;
+	int64_t pos1, pos2;
+	if (r1->rid != r2->rid) return 0;
+	isrev1 = r1->rb > ref->l_pac; isrev2 = r2->rb > ref->l_pac;
+	pos1 = isrev1 ? (ref->l_pac << 1) - 1 - r1->rb : r1->rb;
+	pos2 = isrev2 ? (ref->l_pac << 1) - 1 - r2->rb : r2->rb;
+	return infer_isize(pos1, pos2, isrev1, isrev2, r1->qe - r1->qb, r2->qe - r2->qb, isize);
+}
+
+#define MIN_RATIO     0.8    /* mem_pair.c:35-40 */
+#define MIN_DIR_CNT   10
+#define OUTLIER_BOUND 2.0
+#define MAPPING_BOUND 3.0
+#define MAX_STDDEV    4.0
+
+static int cal_sub(const bsx_opt_t *opt, const reg_v *regs)   /* mem_pair.c:42-57 */
+{
+	const reg_t *best = &regs->a[0], *p = 0;
+	size_t j;
+	for (j = 1; j < regs->n; ++j) {
+		int b_max, e_min;
+		p = &regs->a[j];
+		b_max = p->qb > best->qb ? p->qb : best->qb;
+		e_min = p->qe < best->qe ? p->qe : best->qe;
+		if (e_min > b_max) {
+			int min_l = p->qe - p->qb < best->qe - best->qb ? p->qe - p->qb : best->qe - best->qb;
+			if (e_min - b_max >= min_l * opt->mask_level) break;
+		}
+	}
+	return j < regs->n ? p->score : opt->min_seed_len * opt->a;
+}
+
+/* mem_pestat, mem_pair.c:60-144 (messages go to stderr at verbosity >= 3 like the reference) */
+bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, const reg_v *regs)
+{
+	BSX_VEC(int64_t) isize;
+	bsx_pestat_t pes;
+	int i, x, p25, p50, p75;
+	bsx_vec_init(isize);
+	for (i = 0; i < n >> 1; ++i) {
+		const reg_v *r0 = &regs[i << 1 | 0], *r1 = &regs[i << 1 | 1];
+		const reg_t *b0, *b1;
+		int64_t is;
+		if (r0->n == 0 || r1->n == 0) continue;
+		b0 = &r0->a[0]; b1 = &r1->a[0];
+		if (cal_sub(opt, r0) > MIN_RATIO * b0->score) continue;
+		if (cal_sub(opt, r1) > MIN_RATIO * b1->score) continue;
+		if (b0->rid != b1->rid) continue;
+		if (b0->bss != b1->bss) continue;
+		if (bsx_reg_isize(ref, b0, b1, &is))
+			if (is <= opt->max_ins && is >= -opt->max_ins) bsx_vec_push(isize, is);
+	}
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] # candidate unique pairs: %ld\n", "mem_pestat", (long)isize.n);
+	memset(&pes, 0, sizeof(pes));
+	if (isize.n < MIN_DIR_CNT) {
+		fprintf(stderr, "[M:%s] There are not enough pairs for insert size inference\n", "mem_pestat");
+		bsx_vec_free(isize);
+		pes.failed = 1;
+		return pes;
+	}
+	bsx_introsort_i64(isize.n, isize.a);
+	p25 = (int)isize.a[(int)(.25 * isize.n + .499)];
+	p50 = (int)isize.a[(int)(.50 * isize.n + .499)];
+	p75 = (int)isize.a[(int)(.75 * isize.n + .499)];
+	pes.low  = (int)(p25 - OUTLIER_BOUND * (p75 - p25) + .499);
+	pes.high = (int)(p75 + OUTLIER_BOUND * (p75 - p25) + .499);
+	if (bsx_verbose >= 3) {
+		fprintf(stderr, "[M::%s] (25, 50, 75) percentile: (%d, %d, %d)\n", "mem_pestat", p25, p50, p75);
+		fprintf(stderr, "[M::%s] low and high boundaries for computing mean and std.dev: (%d, %d)\n", "mem_pestat", pes.low, pes.high);
+	}
+	for (i = x = 0, pes.avg = 0; (size_t)i < isize.n; ++i)
+		if (isize.a[i] >= pes.low && isize.a[i] <= pes.high) { pes.avg += isize.a[i]; ++x; }
+	pes.avg /= x;
+	for (i = 0, pes.std = 0; (size_t)i < isize.n; ++i)
+		if (isize.a[i] >= pes.low && isize.a[i] <= pes.high) pes.std += (isize.a[i] - pes.avg) * (isize.a[i] - pes.avg);
+	pes.std = sqrt(pes.std / x);
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] mean and std.dev: (%.2f, %.2f)\n", "mem_pestat", pes.avg, pes.std);
+	pes.low  = (int)(p25 - MAPPING_BOUND * (p75 - p25) + .499);
+	pes.high = (int)(p75 + MAPPING_BOUND * (p75 - p25) + .499);
+	if (pes.low > pes.avg - MAX_STDDEV * pes.std) pes.low = (int)(pes.avg - MAX_STDDEV * pes.std + .499);
+	if (pes.high < pes.avg + MAX_STDDEV * pes.std) pes.high = (int)(pes.avg + MAX_STDDEV * pes.std + .499);
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] low and high boundaries for proper pairs: (%d, %d)\n", "mem_pestat", pes.low, pes.high);
+	bsx_vec_free(isize);
+	return pes;
+}
+
+/* ------------------------------------------------------------------ pairing */
+typedef struct { uint64_t x, y; } pair64_t;
+typedef struct { uint64_t x, y, z; } trio64_t;
+static int pair64_lt(const void *a_, const void *b_)   /* utils.c:46: the 192-bit sort ignores z */
+{
+	const pair64_t *a = (const pair64_t*)a_, *b = (const pair64_t*)b_;
+	return a->x < b->x || (a->x == b->x && a->y < b->y);
+}
+
+static int region_depos(const bsx_refmeta_t *ref, const reg_t *reg)   /* mem_alnreg.h:135-140 */
+{
+	int is_rev;
+	int64_t rpos = bsx_depos(ref->l_pac, reg->rb < ref->l_pac ? reg->rb : reg->re - 1, &is_rev);
+	return (int)(rpos - ref->anns[reg->rid].offset);
+}
+
+/* mem_pair, mem_pair.c:147-270 */
+void bsx_pair(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const bsx_pestat_t *pes, reg_v pair[2], int id,
+              int *score, int *sub, int *n_sub, int z[2])
+{
+	int64_t l_pac = ref->l_pac;
+	BSX_VEC(trio64_t) v;
+	BSX_VEC(pair64_t) pp;
+	int i, r, k;
+	bsx_vec_init(v); bsx_vec_init(pp);
+	for (r = 0; r < 2; ++r) {
+		for (i = 0; (size_t)i < pair[r].n_pri; ++i) {
+			trio64_t key;
+			const reg_t *p = &pair[r].a[i];
+			key.x = (uint64_t)p->bss << 63 | (uint64_t)p->rid << 32 | region_depos(ref, p);
+			key.y = (uint64_t)p->score << 32 | i << 2 | (p->rb >= l_pac) << 1 | r;
+			key.z = (uint64_t)(p->qe - p->qb);
+			bsx_vec_push(v, key);
+		}
+	}
+	bsx_introsort(v.a, v.n, sizeof(trio64_t), pair64_lt);
+	for (i = 0; (size_t)i < v.n; ++i) {
+		for (k = i - 1; k >= 0; --k) {
+			int64_t is = 0;
+			int hi = pes->low > pes->high ? pes->low : pes->high;
+			if (v.a[i].x >> 32 != v.a[k].x >> 32) break;
+			if (v.a[i].x >> 63 != v.a[k].x >> 63) break;
+			if ((int64_t)(v.a[i].x & 0xffffffffU) - (int64_t)(v.a[k].x & 0xffffffffU) > hi) break;
+			if ((v.a[i].y & 1) == (v.a[k].y & 1)) break;
+			if (infer_isize((int64_t)v.a[k].x, (int64_t)v.a[i].x, (v.a[k].y >> 1) & 1, (v.a[i].y >> 1) & 1, (int)v.a[k].z, (int)v.a[i].z, &is) &&
+			    is >= pes->low && is <= pes->high) {
+				double zscore = (is - pes->avg) / pes->std;
+				int _score = (int)((v.a[i].y >> 32) + (v.a[k].y >> 32) + .721 * log(2. * erfc(fabs(zscore) * M_SQRT1_2)) * opt->a + .499);
+				pair64_t *p;
+				if (_score < 0) _score = 0;
+				p = bsx_vec_pushp(pp);
+				p->y = (uint64_t)k << 32 | i;
+				p->x = (uint64_t)_score << 32 | (bsx_hash64(p->y ^ id << 8) & 0xffffffffU);
+			}
+		}
+	}
+	if (pp.n) {
+		int tmp;
+		bsx_introsort(pp.a, pp.n, sizeof(pair64_t), pair64_lt);
+		i = (int)(pp.a[pp.n - 1].y >> 32);
+		k = (int)(pp.a[pp.n - 1].y << 32 >> 32);
+		z[v.a[i].y & 1] = (int)(v.a[i].y << 32 >> 34);
+		z[v.a[k].y & 1] = (int)(v.a[k].y << 32 >> 34);
+		*score = (int)(pp.a[pp.n - 1].x >> 32);
+		*sub = pp.n > 1 ? (int)(pp.a[pp.n - 2].x >> 32) : 0;
+		tmp = opt->a + opt->b;
+		tmp = tmp > opt->o_del + opt->e_del ? tmp : opt->o_del + opt->e_del;
+		tmp = tmp > opt->o_ins + opt->e_ins ? tmp : opt->o_ins + opt->e_ins;
+		for (i = (int)((long)pp.n - 2), *n_sub = 0; i >= 0; --i)
+			if (*sub - (int)(pp.a[i].x >> 32) <= tmp) ++*n_sub;
+	} else { *score = 0; *sub = 0; *n_sub = 0; z[0] = -1; z[1] = -1; }
+	bsx_vec_free(v); bsx_vec_free(pp);
+}
+
+/* ------------------------------------------------------------------ MAPQ */
+#define MEM_MAPQ_COEF 30.0
+/* mem_approx_mapq_se, bwamem.c:134-157 */
+int bsx_approx_mapq_se(const bsx_opt_t *opt, const reg_t *a)
+{
+	int mapq, l, sub = a->sub ? a->sub : opt->min_seed_len * opt->a;
+	double identity;
+	sub = a->csub > sub ? a->csub : sub;
+	if (sub >= a->score) return 0;
+	l = a->qe - a->qb > a->re - a->rb ? a->qe - a->qb : (int)(a->re - a->rb);
+	identity = 1. - (double)(l * opt->a - a->score) / (opt->a + opt->b) / l;
+	if (a->score == 0) mapq = 0;
+	else if (opt->mapQ_coef_len > 0) {
+		double tmp;
+		tmp = l < opt->mapQ_coef_len ? 1. : opt->mapQ_coef_fac / log(l);
+		tmp *= identity * identity;
+		mapq = (int)(6.02 * (a->score - sub) / opt->a * tmp * tmp + .499);
+	} else {
+		mapq = (int)(MEM_MAPQ_COEF * (1. - (double)sub / a->score) * log(a->seedcov) + .499);
+		mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+	}
+	if (a->sub_n > 0) mapq -= (int)(4.343 * log(a->sub_n + 1) + .499);
+	if (mapq > 60) mapq = 60;
+	if (mapq < 0) mapq = 0;
+	mapq = (int)(mapq * (1. - a->frac_rep) + .499);
+	return mapq;
+}

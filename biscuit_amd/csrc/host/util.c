@@ -10,7 +10,7 @@
 #include <pthread.h>
 #include "bsx_core.h"
 
-int bsx_verbose = 3;
+BSX_API int bsx_verbose = 3;
 
 /* hash_64 (lib/aln/utils.h:107-117) */
 uint64_t bsx_hash64(uint64_t key)

@@ -731,3 +731,14 @@ BSX_API void oracle_extend_intv(const bsx_index_t *idx, int parent, const uint64
 	for (c = 0; c < 4; ++c) { ok[c * 4] = o[c].x[0]; ok[c * 4 + 1] = o[c].x[1]; ok[c * 4 + 2] = o[c].x[2]; ok[c * 4 + 3] = 0; }
 }
 BSX_API uint64_t oracle_sa(const bsx_index_t *idx, int parent, uint64_t k) { return fm_sa(&idx->fmi[parent], k, 0); }
+
+/* `biscuit align` on the CPU restatement: the timed CPU baseline and the SAM-level checker */
+static int port_open(int ordinal, const bsx_index_t *idx, void **ud) { (void)ordinal; *ud = oracle_port_new(idx, 1); return BSX_OK; }
+static int port_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t np, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+{
+	bsx_backend_t be;
+	((port_ctx_t*)ud)->n_threads = opt->n_threads;
+	oracle_port_backend(ud, &be);
+	return bsx_process_seqs_backend(&be, opt, idx, np, n, reads, pes0);
+}
+BSX_API int oracle_align_main(int argc, char **argv) { return bsx_align_main_with(argc, argv, port_process, 0, port_open); }
