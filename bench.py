@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- paired-end reads aligned per second through the MI355X `biscuit align` hot path.
+
+A step = one chunk (10 Mbp x threads of 2x150 bp reads, the reference's chunk size, align.c:576)
+pushed through bsx_process_seqs (== mem_process_seqs): all five HIP kernels + the host stages
+between them, ending in SAM text.  The index is resident in HBM before timing starts; reads are in
+host memory as bseq1_t records, exactly what mem_process_seqs receives.
+hg38 is not available offline: the genome is a seeded synthetic one (size --genome-mbp), and the
+JSON line says so.  N>1: one process per GPU (torchrun), chunks are the shard unit (every chunk is
+independent in the reference, so the output equals the single-GPU run); NCCL(=RCCL) carries only the
+barrier and the final reduction of counts/timings.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "128")))
+    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (-@); 0 = cores / ranks, capped at 16")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    L = B.lib()   # raises if libbiscuit_amd.so has not been built
+
+    ncores = os.cpu_count() or 1
+    threads = args.threads if args.threads > 0 else max(1, min(16, ncores // max(1, world)))
+    n_bases = int(args.genome_mbp * 1e6)
+    work = "/tmp/bsx_bench_%d" % n_bases
+    base = work + "/g"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # genome + index (rank 0 builds, the others load the files)
+    t_build = 0.0
+    if local_rank == 0 and not os.path.exists(base + ".dau.sa"):
+        os.makedirs(work, exist_ok=True)
+        t0 = time.time()
+        B.check(L.bsx_sim_genome((work + "/g.fa").encode(), C.c_int64(n_bases), C.c_uint64(2024), 8, C.c_double(0.05)), "sim_genome")
+        B.check(L.bsx_index_build((work + "/g.fa").encode(), base.encode()), "index_build")
+        t_build = time.time() - t0
+    barrier()
+    idx = Index(base)
+    dev = Device(local_rank)
+    dev.upload_index(idx)
+
+    opt = default_opt()
+    opt.n_threads = threads
+    # defaults: -b 0 (non-directional search: 4 strand searches per pair)
+    opt.flag |= 0x10 | 0x2            # MEM_F_NO_MULTI (align.c:335) | MEM_F_PE
+    pairs_per_step = (opt.chunk_size * threads) // (2 * args.read_len)   # the reference's chunk: 10 Mbp x threads
+    n_reads = pairs_per_step * 2
+
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_sam_bytes.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_sam_bytes.restype = C.c_int64
+
+    def gen(seed, n_pairs):
+        p = C.c_void_p()
+        B.check(L.bsx_sim_pairs(idx.h, n_pairs, args.read_len, seed, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
+        return p
+
+    C.c_int.in_dll(L, "bsx_verbose").value = 1   # silence per-chunk messages inside the timed region
+
+    chunks = [gen(1000 * (rank + 1) + s, pairs_per_step) for s in range(args.warmup + args.steps)]
+    n_processed = 0
+    for s in range(args.warmup):
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs(warmup)")
+        n_processed += n_reads
+    for k in range(5):
+        dev.kernel_time(k, reset=True)
+    dev.counters(reset=True)
+    phase_tot = {}
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for s in range(args.warmup, args.warmup + args.steps):
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs")
+        n_processed += n_reads
+        ps = B.PhaseStats()
+        L.bsx_last_phase_stats(C.byref(ps))
+        for f, _ in B.PhaseStats._fields_:
+            phase_tot[f] = phase_tot.get(f, 0) + getattr(ps, f)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.time() - t0
+    sam_bytes = sum(L.bsx_sim_sam_bytes(chunks[s], n_reads) for s in range(args.warmup, args.warmup + args.steps))
+
+    tmax, tot_reads = dt, n_reads * args.steps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        c = torch.tensor([tot_reads], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c)   # "gather" of per-GPU record counts over RCCL
+        tot_reads = int(c.item())
+
+    # roofline of the dominant kernel (K1+K2 FM-index seeding): algorithmic bytes = 64 B per FM block touch
+    ctr = dev.counters()
+    ktimes = [dev.kernel_time(k) for k in range(5)]
+    seed_ms, seed_launches = ktimes[0]
+    alg_bytes = 64.0 * (ctr[0] + ctr[1])
+    roof = None
+    if seed_launches:
+        ach = alg_bytes / (seed_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_seed (K1+K2 SMEM seeding)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(ach / 8000.0, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes / seed_launches, "avg_launch_ms": seed_ms / seed_launches,
+                "fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(L, B, idx, opt, args, ncores)
+
+    if rank == 0:
+        names = ["seed", "sa", "extend", "sw", "global"]
+        out = {
+            "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "2x%d bp synthetic directional bisulfite pairs vs a synthetic %.0f Mbp genome with repeat families "
+                                   "(stand-in for BASELINE configs[1]: hg38 is not available offline), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp),
+                       "reads_per_step_per_gpu": n_reads, "host_threads_per_gpu": threads, "parallelism": "chunk-sharded x%d" % world,
+                       "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(5)},
+            "host_phase_s_per_step": {k: round(v / args.steps, 4) for k, v in phase_tot.items() if k.startswith("t_")},
+            "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
+            "index_build_s": round(t_build, 1), "device": dev.name,
+        }
+        print(json.dumps(out))
+    for c in chunks:
+        L.bsx_sim_free_reads(c, n_reads)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(L, B, idx, opt, args, ncores):
+    """The CPU restatement (oracle/: same host pipeline over scalar C kernels, pthreads) on a bounded
+    sample of the same workload, all host cores.  kind = "port": the full reference cannot be built
+    offline (memchain.c & co. need un-vendored headers), see DESIGN.md."""
+    import oracle_lib
+    port = oracle_lib.Port(idx, n_threads=ncores)
+    be = port.backend()
+    o = B.Opt.from_buffer_copy(opt)
+    o.n_threads = ncores
+    n_pairs = args.cpu_sample_pairs
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, args.read_len, 999, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    t0 = time.time()
+    B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(o), idx.h, 0, n_pairs * 2, p, None), "cpu baseline")
+    dt = time.time() - t0
+    L.bsx_sim_free_reads(p, n_pairs * 2)
+    return {"value": round(n_pairs * 2 / dt, 1), "unit": "reads/s", "cores": ncores, "kind": "port",
+            "sample": "%d pairs of the same workload, one chunk, %.1f s" % (n_pairs, dt)}
+
+
+if __name__ == "__main__":
+    main()

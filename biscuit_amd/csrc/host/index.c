@@ -400,6 +400,24 @@ static int write_fmi(const char *base, const char *tag, const uint8_t *text, int
 	return BSX_OK;
 }
 
+struct build_par { const char *base; const uint8_t *fwd; int64_t l_pac; int rc[2]; };
+static void build_strand(void *data, long i, int tid)   /* i: 1 = parent (C>T), 0 = daughter (G>A) */
+{
+	struct build_par *P = (struct build_par*)data;
+	int64_t k, l_pac = P->l_pac;
+	uint8_t *text = (uint8_t*)malloc((size_t)l_pac * 2);
+	(void)tid;
+	if (!text) { P->rc[i] = BSX_E_NOMEM; return; }
+	for (k = 0; k < l_pac; ++k) {
+		uint8_t c = P->fwd[k], r = 3 - P->fwd[l_pac - 1 - k];
+		if (i) { if (c == 1) c = 3; if (r == 1) r = 3; }
+		else   { if (c == 2) c = 0; if (r == 2) r = 0; }
+		text[k] = c; text[l_pac + k] = r;
+	}
+	P->rc[i] = write_fmi(P->base, i ? "par" : "dau", text, l_pac * 2);
+	free(text);
+}
+
 BSX_API int bsx_index_build(const char *fasta, const char *base)
 {
 	fa_rec_t *recs = 0;
@@ -461,17 +479,14 @@ BSX_API int bsx_index_build(const char *fasta, const char *base)
 	fprintf(fp, "%lld %d %u\n", (long long)l_pac, n_recs, (unsigned)holes.n);
 	for (k = 0; k < (int64_t)holes.n; ++k) fprintf(fp, "%lld %d %c\n", (long long)holes.a[k].offset, holes.a[k].len, holes.a[k].amb);
 	fclose(fp);
-	/* converted texts and their FM indices */
-	text = (uint8_t*)malloc((size_t)l_pac * 2);
-	for (i = 1; i >= 0; --i) { /* 1 = parent (C>T), 0 = daughter (G>A) */
-		for (k = 0; k < l_pac; ++k) {
-			uint8_t c = fwd[k], r = 3 - fwd[l_pac - 1 - k];
-			if (i) { if (c == 1) c = 3; if (r == 1) r = 3; }
-			else   { if (c == 2) c = 0; if (r == 2) r = 0; }
-			text[k] = c; text[l_pac + k] = r;
-		}
-		if ((rc = write_fmi(base, i ? "par" : "dau", text, l_pac * 2)) != BSX_OK) break;
+	/* converted texts and their FM indices: the two strands are independent, build them side by side */
+	{
+		struct build_par bp;
+		bp.base = base; bp.fwd = fwd; bp.l_pac = l_pac; bp.rc[0] = bp.rc[1] = BSX_OK;
+		bsx_parallel_for(2, build_strand, &bp, 2);
+		rc = bp.rc[1] != BSX_OK ? bp.rc[1] : bp.rc[0];
 	}
+	text = 0;
 	free(text); free(fwd); free(n_ambs); bsx_vec_free(holes);
 	for (i = 0; i < n_recs; ++i) { free(recs[i].name); free(recs[i].comment); free(recs[i].seq); }
 	free(recs);

@@ -1,0 +1,144 @@
+/* sim.c -- seeded synthetic genome / bisulfite read generator for bench.py and the large-size tests.
+ * (hg38 and real WGBS reads are not available offline; everything generated here is labelled
+ * synthetic wherever it is reported.)  xorshift64* PRNG, so every box regenerates identical data.
+ *   genome : i.i.d. bases + planted repeat families (300-3000 bp, 2-6 copies, 0-5 % divergence,
+ *            some reverse-complemented) + short tandem repeats + one N run per contig
+ *   pairs  : directional protocol -- R1 = bisulfite-converted strand, R2 = reverse complement of
+ *            the fragment; C->T with retention 0.70 at CpG and 0.01 elsewhere; substitutions.
+ */
+#include "bsx_core.h"
+
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t rng_next(rng_t *r) { uint64_t x = r->s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; r->s = x; return x * 0x2545F4914F6CDD1DULL; }
+static inline uint64_t rng_below(rng_t *r, uint64_t n) { return rng_next(r) % n; }
+static inline double rng_unit(rng_t *r) { return (rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+BSX_API int bsx_sim_genome(const char *fasta, int64_t n, uint64_t seed, int n_contigs, double repeat_frac)
+{
+	rng_t R; uint8_t *g;
+	int64_t i, planted = 0;
+	int c;
+	FILE *fp;
+	if (n < 1000 || n_contigs < 1) return BSX_E_ARG;
+	R.s = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+	g = (uint8_t*)malloc((size_t)n);
+	if (!g) return BSX_E_NOMEM;
+	for (i = 0; i < n; i += 32) { uint64_t x = rng_next(&R); int k; for (k = 0; k < 32 && i + k < n; ++k) g[i + k] = (uint8_t)((x >> (2 * k)) & 3); }
+	while (planted < (int64_t)(n * repeat_frac)) {
+		int64_t l = 300 + (int64_t)rng_below(&R, 2700), s, d;
+		int copies = 1 + (int)rng_below(&R, 5), k;
+		if (l * 4 > n) l = n / 4;
+		s = (int64_t)rng_below(&R, (uint64_t)(n - l));
+		for (k = 0; k < copies; ++k) {
+			double div = rng_unit(&R) * 0.05;
+			int rc = rng_unit(&R) < 0.3;
+			int64_t j;
+			d = (int64_t)rng_below(&R, (uint64_t)(n - l));
+			if ((d > s ? d - s : s - d) < l) continue;
+			for (j = 0; j < l; ++j) {
+				uint8_t b = rc ? (uint8_t)(3 - g[s + l - 1 - j]) : g[s + j];
+				if (rng_unit(&R) < div) b = (uint8_t)((b + 1 + rng_below(&R, 3)) & 3);
+				g[d + j] = b;
+			}
+			planted += l;
+		}
+	}
+	for (i = 0; i < n / 200000 + 1; ++i) { /* tandem repeats */
+		int ul = 2 + (int)rng_below(&R, 28), reps = 5 + (int)rng_below(&R, 35), k;
+		int64_t d = (int64_t)rng_below(&R, (uint64_t)(n - (int64_t)ul * reps - 1));
+		for (k = ul; k < ul * reps; ++k) g[d + k] = g[d + k % ul];
+	}
+	if ((fp = fopen(fasta, "wb")) == 0) { free(g); return BSX_E_IO; }
+	for (c = 0; c < n_contigs; ++c) {
+		int64_t b = n / n_contigs * c, e = c == n_contigs - 1 ? n : n / n_contigs * (c + 1), nb, nl;
+		char line[64];
+		fprintf(fp, ">chr%d\n", c + 1);
+		nb = b + (e - b) / 3; nl = (e - b) / 200 < 1000 ? (e - b) / 200 : 1000;   /* one N run */
+		for (i = b; i < e; i += 60) {
+			int k, m = (int)(e - i < 60 ? e - i : 60);
+			for (k = 0; k < m; ++k) line[k] = (i + k >= nb && i + k < nb + nl) ? 'N' : "ACGT"[g[i + k]];
+			line[m] = '\n';
+			fwrite(line, 1, (size_t)m + 1, fp);
+		}
+	}
+	fclose(fp);
+	free(g);
+	return BSX_OK;
+}
+
+/* n_pairs read pairs as an interleaved bsx_read_t array (caller frees with bsx_sim_free_reads) */
+BSX_API int bsx_sim_pairs(const bsx_index_t *idx, int64_t n_pairs, int read_len, uint64_t seed, int frag_lo, int frag_hi,
+                          double sub_rate, double pbat_frac, bsx_read_t **out)
+{
+	rng_t R;
+	int64_t l_pac = idx->ref.l_pac, p;
+	bsx_read_t *reads;
+	uint8_t *frag;
+	if (frag_lo < read_len) frag_lo = read_len;
+	if (frag_hi < frag_lo) frag_hi = frag_lo;
+	if (l_pac <= frag_hi + 2) return BSX_E_ARG;
+	R.s = seed * 0x9E3779B97F4A7C15ULL + 0xABCDEFULL;
+	reads = (bsx_read_t*)calloc((size_t)n_pairs * 2, sizeof(bsx_read_t));
+	frag = (uint8_t*)malloc((size_t)frag_hi + 8);
+	if (!reads || !frag) { free(reads); free(frag); return BSX_E_NOMEM; }
+	for (p = 0; p < n_pairs; ++p) {
+		int fl = frag_lo + (int)rng_below(&R, (uint64_t)(frag_hi - frag_lo + 1)), i, rev, e, swap;
+		int64_t s = (int64_t)rng_below(&R, (uint64_t)(l_pac - fl));
+		int rid = bsx_pos2rid(&idx->ref, s);
+		if (bsx_pos2rid(&idx->ref, s + fl - 1) != rid) { --p; continue; }   /* fragment inside one contig */
+		rev = (int)(rng_next(&R) & 1);
+		for (i = 0; i < fl; ++i) frag[i] = rev ? (uint8_t)(3 - bsx_pac_get(idx->pac, s + fl - 1 - i)) : (uint8_t)bsx_pac_get(idx->pac, s + i);
+		for (i = 0; i < fl; ++i) { /* bisulfite conversion of the fragment's top strand */
+			if (frag[i] == 1) {
+				double keep = (i + 1 < fl && frag[i + 1] == 2) ? 0.70 : 0.01;
+				if (rng_unit(&R) >= keep) frag[i] = 3;
+			}
+		}
+		swap = rng_unit(&R) < pbat_frac;   /* PBAT-like pair: the two reads trade roles */
+		for (e = 0; e < 2; ++e) {
+			bsx_read_t *r = &reads[p * 2 + e];
+			char nm[32];
+			int from_end = (e == 1) ^ swap;
+			snprintf(nm, sizeof(nm), "p%09lld", (long long)p);
+			r->name = strdup(nm);
+			r->seq = r->seq0 = (uint8_t*)malloc((size_t)read_len + 1);
+			r->qual = (char*)malloc((size_t)read_len + 1);
+			for (i = 0; i < read_len; ++i) {
+				uint8_t b = from_end ? (uint8_t)(3 - frag[fl - 1 - i]) : frag[i];
+				if (rng_unit(&R) < sub_rate) b = (uint8_t)((b + 1 + rng_below(&R, 3)) & 3);
+				r->seq[i] = b; r->qual[i] = 'I';
+			}
+			r->qual[read_len] = 0;
+			r->l_seq = r->l_seq0 = read_len; r->id = (int)(p * 2 + e);
+		}
+	}
+	free(frag);
+	*out = reads;
+	return BSX_OK;
+}
+
+/* undo clipping and drop the SAM text so that the same array can be processed again */
+BSX_API void bsx_sim_reset_reads(bsx_read_t *reads, int64_t n)
+{
+	int64_t i;
+	for (i = 0; i < n; ++i) {
+		if (reads[i].seq0) { reads[i].seq = reads[i].seq0; reads[i].l_seq = reads[i].l_seq0; }
+		free(reads[i].sam); reads[i].sam = 0;
+		reads[i].clip5 = reads[i].clip3 = reads[i].l_adaptor = 0;
+	}
+}
+
+BSX_API int64_t bsx_sim_sam_bytes(const bsx_read_t *reads, int64_t n)
+{
+	int64_t i, tot = 0;
+	for (i = 0; i < n; ++i) if (reads[i].sam) tot += (int64_t)strlen(reads[i].sam);
+	return tot;
+}
+
+BSX_API void bsx_sim_free_reads(bsx_read_t *reads, int64_t n)
+{
+	int64_t i;
+	if (!reads) return;
+	for (i = 0; i < n; ++i) { free(reads[i].name); free(reads[i].comment); free(reads[i].barcode); free(reads[i].umi); free(reads[i].seq0); free(reads[i].qual); free(reads[i].sam); }
+	free(reads);
+}
