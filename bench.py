@@ -29,9 +29,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "128")))
-    ap.add_argument("--threads", type=int, default=0, help="host threads per rank (-@); 0 = cores / ranks, capped at 16")
+    ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
+    ap.add_argument("--host-threads", type=int, default=0, help="worker threads for the host stages; 0 = cores / ranks, capped at 64")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=20000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -50,8 +51,10 @@ def main():
     from biscuit_amd.api import Index, Device, default_opt
     L = B.lib()   # raises if libbiscuit_amd.so has not been built
 
-    ncores = os.cpu_count() or 1
-    threads = args.threads if args.threads > 0 else max(1, min(16, ncores // max(1, world)))
+    ncores = effective_cores()
+    threads = max(1, args.threads)
+    host_threads = args.host_threads if args.host_threads > 0 else max(1, min(64, ncores // max(1, world)))
+    os.environ["BSX_HOST_THREADS"] = str(host_threads)
     n_bases = int(args.genome_mbp * 1e6)
     work = "/tmp/bsx_bench_%d" % n_bases
     base = work + "/g"
@@ -151,7 +154,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%d bp synthetic directional bisulfite pairs vs a synthetic %.0f Mbp genome with repeat families "
                                    "(stand-in for BASELINE configs[1]: hg38 is not available offline), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp),
-                       "reads_per_step_per_gpu": n_reads, "host_threads_per_gpu": threads, "parallelism": "chunk-sharded x%d" % world,
+                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -167,6 +170,30 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cores():
+    """CPUs this process may actually use: min(online, affinity mask, cgroup quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, int(q / p + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(L, B, idx, opt, args, ncores):
     """The CPU restatement (oracle/: same host pipeline over scalar C kernels, pthreads) on a bounded
     sample of the same workload, all host cores.  kind = "port": the full reference cannot be built
@@ -175,7 +202,7 @@ def cpu_baseline(L, B, idx, opt, args, ncores):
     port = oracle_lib.Port(idx, n_threads=ncores)
     be = port.backend()
     o = B.Opt.from_buffer_copy(opt)
-    o.n_threads = ncores
+    os.environ["BSX_HOST_THREADS"] = str(ncores)
     n_pairs = args.cpu_sample_pairs
     p = C.c_void_p()
     B.check(L.bsx_sim_pairs(idx.h, n_pairs, args.read_len, 999, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")

@@ -84,7 +84,7 @@ class Backend(C.Structure):  # bsx_backend_t (csrc/host/bsx_core.h)
 
 class PhaseStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("t_seed", "t_sa", "t_chain", "t_extend", "t_merge", "t_pestat", "t_matesw",
-                                          "t_primary", "t_cigar", "t_sam", "t_total")] + \
+                                          "t_primary", "t_cigar", "t_sam", "t_total", "t_prep", "t_cleanup")] + \
                [(n, C.c_int64) for n in ("n_tasks", "n_intv", "n_sa", "n_ext_jobs", "n_ext_rounds", "n_sw_jobs", "n_glb_jobs")]
 
 

@@ -29,6 +29,19 @@ struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden bounce copy)
+	void *p = nullptr; size_t cap = 0;
+	int reserve(size_t n) {
+		if (n <= cap) return BSX_OK;
+		if (p) (void)hipHostFree(p);
+		size_t want = n + (n >> 2) + 4096;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return BSX_E_NOMEM; }
+		cap = want;
+		return BSX_OK;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct bsx_device {
 	int ordinal = 0;
 	char name[256];
@@ -41,6 +54,7 @@ struct bsx_device {
 	DevBuf reads; size_t n_reads = 0;
 	DevBuf jobs, res, scratch, out, aux, pool;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor
+	HostBuf hstage;        // pinned staging for bulk results
 	double k_ms[5] = {0, 0, 0, 0, 0};
 	int64_t k_launch[5] = {0, 0, 0, 0, 0};
 };
@@ -77,7 +91,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	(void)hipSetDevice(d->ordinal);
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
 	d->pac.release(); d->reads.release(); d->jobs.release(); d->res.release(); d->scratch.release();
-	d->out.release(); d->aux.release(); d->pool.release(); d->small.release();
+	d->out.release(); d->aux.release(); d->pool.release(); d->small.release(); d->hstage.release();
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	if (d->st) (void)hipStreamDestroy(d->st);
@@ -167,6 +181,24 @@ extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *to
 // ------------------------------------------------------------------------------------------
 static bool intv_info_lt(const bsx_intv_t &a, const bsx_intv_t &b) { return a.info < b.info; }
 
+struct SeedAsm {
+	const long long *off; const int *cnt; const bsx_intv_t *dense;   // round-0 results (dense, arbitrary task order)
+	const int64_t *redo_of; const std::vector<std::vector<bsx_intv_t>> *redo;
+	bsx_intv_t *out; const int64_t *out_off;
+};
+static void seed_asm_worker(void *data, long i, int tid)
+{
+	const SeedAsm *A = (const SeedAsm*)data;
+	(void)tid;
+	bsx_intv_t *dst = A->out + A->out_off[i];
+	const int64_t n = A->out_off[i + 1] - A->out_off[i];
+	if (n <= 0) return;
+	if (A->redo_of && A->redo_of[i] >= 0) std::copy((*A->redo)[A->redo_of[i]].begin(), (*A->redo)[A->redo_of[i]].end(), dst);
+	else memcpy(dst, A->dense + A->off[i], sizeof(bsx_intv_t) * (size_t)n);
+	// ks_introsort(mem_intv) (memchain.c:105): records with equal info are identical, any sort gives the reference order
+	if (n > 1) std::sort(dst, dst + n, intv_info_lt);
+}
+
 extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
                                       bsx_intv_t **out, int64_t *out_cap, int64_t *out_off)
 {
@@ -184,13 +216,14 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 
 	std::vector<long long> h_off((size_t)n);
 	std::vector<int> h_n((size_t)n);
-	std::vector<int64_t> todo;           // task indices still to run (all, then the overflowed ones)
+	std::vector<int64_t> todo;           // tasks whose interval list did not fit: redone with more room
 	std::vector<bsx_seed_task_t> sub;
 	int mem_cap = std::max(64, max_len);
 	unsigned long long dense_cap = (unsigned long long)n * 24 + 4096;
 	std::vector<std::vector<bsx_intv_t>> redo_results;
 	std::vector<int64_t> redo_index;
-	std::vector<bsx_intv_t> h_dense;
+	const bsx_intv_t *h_dense = nullptr;
+	std::vector<bsx_intv_t> dense_sub;
 
 	for (int round = 0; round < 6; ++round) {
 		const bsx_seed_task_t *cur = tasks; int64_t cn = n;
@@ -226,17 +259,19 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 		HIPCHK(hipMemcpy(r_n.data(), d_n, (size_t)cn * 4, hipMemcpyDeviceToHost));
 		HIPCHK(hipMemcpy(&used, ctr + 4, 8, hipMemcpyDeviceToHost));
 		if (used > dense_cap) used = dense_cap;
-		std::vector<bsx_intv_t> dense((size_t)used);
-		if (used) HIPCHK(hipMemcpy(dense.data(), d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
 		std::vector<int64_t> next;
 		if (round == 0) {
-			h_dense.swap(dense);
+			if ((rc = d->hstage.reserve((size_t)used * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+			if (used) HIPCHK(hipMemcpy(d->hstage.p, d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			h_dense = (const bsx_intv_t*)d->hstage.p;
 			for (int64_t i = 0; i < n; ++i) { h_off[i] = r_off[i]; h_n[i] = r_n[i]; if (r_n[i] < 0) next.push_back(i); }
 		} else {
+			dense_sub.resize((size_t)used);
+			if (used) HIPCHK(hipMemcpy(dense_sub.data(), d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
 			for (int64_t i = 0; i < cn; ++i) {
 				if (r_n[i] < 0) { next.push_back(todo[i]); continue; }
 				redo_index.push_back(todo[i]);
-				redo_results.emplace_back(dense.begin() + r_off[i], dense.begin() + r_off[i] + r_n[i]);
+				redo_results.emplace_back(dense_sub.begin() + r_off[i], dense_sub.begin() + r_off[i] + r_n[i]);
 				h_n[todo[i]] = r_n[i];
 			}
 		}
@@ -245,21 +280,17 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 	}
 	if (!todo.empty()) { fprintf(stderr, "[bsx-hip] seed_batch: %zu tasks still overflow\n", todo.size()); return BSX_E_INTERNAL; }
 
-	// assemble CSR in task order; each list ordered by info (ks_introsort(mem_intv), memchain.c:105 --
-	// records with equal info are identical, so any sort reproduces the reference order)
-	std::vector<int64_t> redo_slot((size_t)0);
+	// CSR in task order, each list ordered by info; assembled by the host worker pool
 	int64_t tot = 0;
 	for (int64_t i = 0; i < n; ++i) { out_off[i] = tot; tot += h_n[i]; }
 	out_off[n] = tot;
 	if (*out_cap < tot) { *out_cap = tot + (tot >> 2) + 16; *out = (bsx_intv_t*)realloc(*out, sizeof(bsx_intv_t) * (size_t)*out_cap); }
-	std::vector<int64_t> redo_of((size_t)0);
+	std::vector<int64_t> redo_of;
 	if (!redo_index.empty()) { redo_of.assign((size_t)n, -1); for (size_t r = 0; r < redo_index.size(); ++r) redo_of[redo_index[r]] = (int64_t)r; }
-	for (int64_t i = 0; i < n; ++i) {
-		bsx_intv_t *dst = *out + out_off[i];
-		if (!redo_of.empty() && redo_of[i] >= 0) std::copy(redo_results[redo_of[i]].begin(), redo_results[redo_of[i]].end(), dst);
-		else if (h_n[i] > 0) memcpy(dst, h_dense.data() + h_off[i], sizeof(bsx_intv_t) * (size_t)h_n[i]);
-		if (h_n[i] > 1) std::sort(dst, dst + h_n[i], intv_info_lt);
-	}
+	SeedAsm A;
+	A.off = h_off.data(); A.cnt = h_n.data(); A.dense = h_dense; A.redo_of = redo_of.empty() ? nullptr : redo_of.data(); A.redo = &redo_results;
+	A.out = *out; A.out_off = out_off;
+	bsx_parallel_for(bsx_host_threads(opt), seed_asm_worker, &A, (long)n);
 	return BSX_OK;
 }
 

@@ -108,6 +108,8 @@ BSX_API int  bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids);
 /* ---------- thread pool (kt_for equivalent; results never depend on scheduling) ---------- */
 typedef void (*bsx_for_fn)(void *data, long i, int tid);
 BSX_API void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n);
+/* worker threads for host stages: $BSX_HOST_THREADS if set, else opt->n_threads (-@ also fixes the chunk size) */
+BSX_API int bsx_host_threads(const bsx_opt_t *opt);
 
 /* ---------- device backend: the batch seams of include/bsx.h behind one vtable ---------- */
 typedef struct bsx_backend {
@@ -134,7 +136,7 @@ int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);
 
 /* per-phase wall-clock accounting of the last bsx_process_seqs* call (seconds) */
 typedef struct {
-	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total;
+	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total, t_prep, t_cleanup;
 	int64_t n_tasks, n_intv, n_sa, n_ext_jobs, n_ext_rounds, n_sw_jobs, n_glb_jobs;
 } bsx_phase_stats_t;
 BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out);

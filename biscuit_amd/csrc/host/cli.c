@@ -10,7 +10,15 @@
 #include "pipeline.h"
 
 const uint8_t *bsx_nt4_table(void);
-BSX_API char *bsx_pg_line = 0;   /* "@PG\t..." set by the program entry, printed after the header lines */
+BSX_API char *bsx_pg_line = 0;
+/* Chunk-level sharding for multi-GPU runs (one process per GPU): chunks are independent in the
+ * reference (insert-size statistics are per chunk, bwamem.c:464-467), so rank r of `world` processes
+ * chunks r, r+world, ... of the same input stream with the same n_processed offsets, and the SAM is
+ * identical to the single-process run once the chunks are written back in order.  The launcher
+ * (biscuit_amd/multi_gpu.py) installs an emit hook and gathers the text over RCCL. */
+BSX_API int bsx_shard_rank = 0, bsx_shard_world = 1;
+BSX_API void (*bsx_emit_hook)(void *ud, int64_t chunk, const char *text, size_t len) = 0;
+BSX_API void *bsx_emit_ud = 0;   /* "@PG\t..." set by the program entry, printed after the header lines */
 
 static int usage(void)
 {
@@ -320,9 +328,15 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			}
 		}
 	}
-	if (!(opt->flag & BSX_F_ALN_REG)) { char *h = bsx_sam_header(idx, hdr_line, bsx_pg_line); fputs(h, stdout); free(h); }
+	if (!(opt->flag & BSX_F_ALN_REG) && bsx_shard_rank == 0) {
+		char *h = bsx_sam_header(idx, hdr_line, bsx_pg_line);
+		if (bsx_emit_hook) bsx_emit_hook(bsx_emit_ud, -1, h, strlen(h)); else fputs(h, stdout);
+		free(h);
+	}
 	{
-		int chunk = opt->chunk_size * opt->n_threads, done_cmdline = 0;
+		/* $BSX_CHUNK_SIZE overrides the per-thread chunk size (tests only; the reference's is fixed at 10 Mbp) */
+		int chunk = (getenv("BSX_CHUNK_SIZE") ? atoi(getenv("BSX_CHUNK_SIZE")) : opt->chunk_size) * opt->n_threads, done_cmdline = 0;
+		int64_t chunk_idx = -1;
 		for (;;) {
 			int n = 0;
 			bsx_read_t *seqs = 0;
@@ -347,6 +361,13 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				if (!copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; }
 			}
 			for (i = 0; i < n; ++i) size += seqs[i].l_seq;
+			++chunk_idx;
+			if (bsx_shard_world > 1 && chunk_idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
+				n_processed += n;
+				for (i = 0; i < n; ++i) bsx_read_free(&seqs[i]);
+				free(seqs);
+				continue;
+			}
 			if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, (long)size);
 			if (opt->flag & BSX_F_SMARTPE) { /* -p: split into single and paired reads (align.c:108-146) */
 				bsx_read_t *sep[2]; int m[2];
@@ -359,7 +380,15 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			} else rc = process(ud, opt, idx, n_processed, n, seqs, pes0);
 			if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
 			n_processed += n;
-			for (i = 0; i < n; ++i) { if (rc == 0 && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
+			if (rc == 0 && bsx_emit_hook) {
+				size_t tot = 0, at = 0; char *all;
+				for (i = 0; i < n; ++i) if (seqs[i].sam) tot += strlen(seqs[i].sam);
+				all = (char*)malloc(tot + 1);
+				for (i = 0; i < n; ++i) if (seqs[i].sam) { size_t l = strlen(seqs[i].sam); memcpy(all + at, seqs[i].sam, l); at += l; }
+				bsx_emit_hook(bsx_emit_ud, chunk_idx, all, tot);
+				free(all);
+			}
+			for (i = 0; i < n; ++i) { if (rc == 0 && !bsx_emit_hook && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
 			free(seqs);
 			if (rc) break;
 		}

@@ -1,0 +1,51 @@
+/* hooks.c -- small exported entry points used by the Python plumbing (multi-GPU launcher, tests):
+ * flat wrappers over internal host functions, no logic of their own. */
+#include "align_types.h"
+#include "fastq.h"
+
+/* ---- chunked FASTQ access for the chunk-sharded multi-GPU launcher ---- */
+BSX_API void *bsx_hook_fq_open(const char *fn) { return bsx_fq_open(fn); }
+BSX_API void bsx_hook_fq_close(void *f) { bsx_fq_close((bsx_fq_t*)f); }
+BSX_API bsx_read_t *bsx_hook_fq_chunk(void *f1, void *f2, int chunk_size, int has_bc, int *n) { return bsx_fq_read_chunk((bsx_fq_t*)f1, (bsx_fq_t*)f2, chunk_size, has_bc, n); }
+BSX_API void bsx_hook_reads_free(bsx_read_t *r, int n) { int i; if (!r) return; for (i = 0; i < n; ++i) bsx_read_free(&r[i]); free(r); }
+/* concatenated SAM text of a processed chunk; returns bytes written (or needed when cap is too small) */
+BSX_API int64_t bsx_hook_chunk_sam(const bsx_read_t *r, int n, char *buf, int64_t cap)
+{
+	int64_t tot = 0; int i;
+	for (i = 0; i < n; ++i) if (r[i].sam) { size_t l = strlen(r[i].sam); if (buf && tot + (int64_t)l <= cap) memcpy(buf + tot, r[i].sam, l); tot += (int64_t)l; }
+	return tot;
+}
+
+/* ---- test hooks ---- */
+typedef struct { int64_t key, id; } kv_t;
+static int kv_lt(const void *a, const void *b) { return ((const kv_t*)a)->key < ((const kv_t*)b)->key; }
+static int kv_gt(const void *a, const void *b) { return ((const kv_t*)a)->key > ((const kv_t*)b)->key; }
+BSX_API void bsx_hook_sort_kv(int64_t n, int64_t *kv, int desc) { bsx_introsort(kv, (size_t)n, sizeof(kv_t), desc ? kv_gt : kv_lt); }
+
+BSX_API int bsx_hook_mapq(int a, int b, int min_seed_len, float coef_len, int coef_fac, int score, int sub, int csub, int sub_n,
+                          int qb, int qe, int64_t rb, int64_t re, int seedcov, float frac_rep)
+{
+	bsx_opt_t o; reg_t r;
+	bsx_opt_init(&o);
+	o.a = a; o.b = b; o.min_seed_len = min_seed_len; o.mapQ_coef_len = coef_len; o.mapQ_coef_fac = coef_fac;
+	memset(&r, 0, sizeof(r));
+	r.score = score; r.sub = sub; r.csub = csub; r.sub_n = sub_n; r.qb = qb; r.qe = qe; r.rb = rb; r.re = re; r.seedcov = seedcov; r.frac_rep = frac_rep;
+	return bsx_approx_mapq_se(&o, &r);
+}
+BSX_API uint64_t bsx_hook_hash64(uint64_t k) { return bsx_hash64(k); }
+BSX_API int bsx_hook_opt_defaults(char *buf, int cap)
+{
+	bsx_opt_t O, *o = &O;
+	bsx_opt_init(o);
+	return snprintf(buf, cap,
+		"a=%d b=%d o_del=%d e_del=%d o_ins=%d e_ins=%d pen_unpaired=%d pen_clip5=%d pen_clip3=%d w=%d zdrop=%d "
+		"max_mem_intv=%llu T=%d flag=%d min_seed_len=%d min_chain_weight=%d max_chain_extend=%u split_factor=%.9g "
+		"split_width=%d max_occ=%u max_chain_gap=%d n_threads=%d chunk_size=%d mask_level=%.9g drop_ratio=%.9g "
+		"XA_drop_ratio=%.9g mask_level_redun=%.9g mapQ_coef_len=%.9g mapQ_coef_fac=%d max_ins=%d max_matesw=%d "
+		"max_XA_hits=%d max_XA_hits_alt=%d parent=%d bsstrand=%d clip5=%d clip3=%d min_base_qual=%d has_bc=%d",
+		o->a, o->b, o->o_del, o->e_del, o->o_ins, o->e_ins, o->pen_unpaired, o->pen_clip5, o->pen_clip3, o->w, o->zdrop,
+		(unsigned long long)o->max_mem_intv, o->T, o->flag, o->min_seed_len, o->min_chain_weight, o->max_chain_extend, o->split_factor,
+		o->split_width, o->max_occ, o->max_chain_gap, o->n_threads, o->chunk_size, o->mask_level, o->drop_ratio,
+		o->XA_drop_ratio, o->mask_level_redun, o->mapQ_coef_len, o->mapQ_coef_fac, o->max_ins, o->max_matesw,
+		o->max_XA_hits, o->max_XA_hits_alt, o->parent, o->bsstrand, o->clip5, o->clip3, o->min_base_qual, o->has_bc);
+}

@@ -93,6 +93,7 @@ typedef struct {
 	bsx_btree_t **trees;         /* per thread */
 	reg_v *regs;                 /* per read */
 	bsx_pestat_t pes;
+	uint8_t *buf; bsx_seed_task_t *stasks; bsx_sa_job_t *sa_jobs;
 } chunk_t;
 
 /* ------------------------------------------------------------------ chaining */
@@ -204,41 +205,49 @@ static int filter_chained_seeds(chunk_t *C)
 }
 
 /* ------------------------------------------------------------------ extension rounds */
-static void advance_worker(void *data, long t, int tid)
-{
-	chunk_t *C = (chunk_t*)data;
-	c2r_t *T = &C->tasks[t];
-	(void)tid;
-	if (!T->done && !T->has_job) bsx_c2r_advance(C->opt, C->idx, T);
-}
+typedef struct { chunk_t *C; const int *active; const int *owner; const bsx_ext_res_t *res; } round_par_t;
 
-typedef struct { chunk_t *C; const int *owner; const bsx_ext_res_t *res; } consume_par_t;
+static void advance_worker(void *data, long i, int tid)
+{
+	round_par_t *P = (round_par_t*)data;
+	c2r_t *T = &P->C->tasks[P->active[i]];
+	(void)tid;
+	if (!T->done && !T->has_job) bsx_c2r_advance(P->C->opt, P->C->idx, T);
+}
 static void consume_worker(void *data, long i, int tid)
 {
-	consume_par_t *P = (consume_par_t*)data;
+	round_par_t *P = (round_par_t*)data;
 	(void)tid;
 	bsx_c2r_consume(P->C->opt, P->C->idx, &P->C->tasks[P->owner[i]], &P->res[i]);
 }
 
+/* All strand searches advance in lock-step: one K4 batch per round.  Only tasks that still have
+ * work stay on the active list, so the host cost of a round is proportional to its batch. */
 static int extension_rounds(chunk_t *C)
 {
 	bsx_ext_job_t *jobs = (bsx_ext_job_t*)malloc(sizeof(bsx_ext_job_t) * ((size_t)C->n_tasks + 1));
 	bsx_ext_res_t *res = (bsx_ext_res_t*)malloc(sizeof(bsx_ext_res_t) * ((size_t)C->n_tasks + 1));
 	int *owner = (int*)malloc(sizeof(int) * ((size_t)C->n_tasks + 1));
-	int rc = BSX_OK;
-	for (;;) {
-		int t, nj = 0;
-		consume_par_t P;
-		bsx_parallel_for(C->nt, advance_worker, C, C->n_tasks);
-		for (t = 0; t < C->n_tasks; ++t)
-			if (C->tasks[t].has_job) { jobs[nj] = C->tasks[t].job; owner[nj++] = t; }
+	int *active = (int*)malloc(sizeof(int) * ((size_t)C->n_tasks + 1));
+	int rc = BSX_OK, n_active = 0, t;
+	round_par_t P;
+	for (t = 0; t < C->n_tasks; ++t) if (C->tasks[t].chains.n) active[n_active++] = t; else C->tasks[t].done = 1;
+	P.C = C; P.active = active; P.owner = owner; P.res = res;
+	while (n_active > 0) {
+		int i, nj = 0, na = 0;
+		bsx_parallel_for(C->nt, advance_worker, &P, n_active);
+		for (i = 0; i < n_active; ++i) {
+			c2r_t *T = &C->tasks[active[i]];
+			if (T->has_job) { jobs[nj] = T->job; owner[nj++] = active[i]; active[na++] = active[i]; }
+			else if (!T->done) active[na++] = active[i];
+		}
+		n_active = na;
 		if (nj == 0) break;
 		if ((rc = C->be->extend_batch(C->be->ctx, nj, jobs, res)) != BSX_OK) break;
 		g_stats.n_ext_jobs += nj; ++g_stats.n_ext_rounds;
-		P.C = C; P.owner = owner; P.res = res;
 		bsx_parallel_for(C->nt, consume_worker, &P, nj);
 	}
-	free(jobs); free(res); free(owner);
+	free(jobs); free(res); free(owner); free(active);
 	return rc;
 }
 
@@ -538,6 +547,19 @@ static void out_worker(void *data, long u, int tid)
 	}
 }
 
+typedef struct {
+	chunk_t *C; samctx_t *ctx; int per; const int *todo, *jread, *jreg; const bsx_glb_job_t *sub; const bsx_glb_res_t *sres; const uint32_t *pool;
+} finish_par_t;
+static void finish_worker(void *data, long k, int tid)
+{
+	finish_par_t *F = (finish_par_t*)data;
+	int jj = F->todo[k], ri = F->jread[jj];
+	(void)tid;
+	if (F->sres[k].n_cigar < 0) return;   /* did not fit: redone with more room */
+	bsx_setsam_finish(F->C->opt, F->C->idx, &F->C->reads[ri], &F->C->regs[ri].a[F->jreg[jj]], F->pool + F->sub[k].cigar_off, F->sres[k].n_cigar,
+	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]]);
+}
+
 static int emit_sam(chunk_t *C)
 {
 	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, u, w, rc = BSX_OK, round;
@@ -576,14 +598,16 @@ static int emit_sam(chunk_t *C)
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
 		rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
 		g_stats.n_glb_jobs += (int64_t)todo.n;
-		if (rc == BSX_OK)
+		if (rc == BSX_OK) {
+			finish_par_t F;
+			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = jread.a; F.jreg = jreg.a; F.sub = sub; F.sres = sres; F.pool = pool;
+			bsx_parallel_for(C->nt, finish_worker, &F, (long)todo.n);
 			for (k = 0; k < todo.n; ++k) {
-				int jj = todo.a[k], ri = jread.a[jj];
+				int jj = todo.a[k];
 				res[jj] = sres[k];
-				if (sres[k].n_cigar < 0) { jobs.a[jj].cigar_cap = (uint32_t)(-sres[k].n_cigar) + 2; todo.a[nt++] = jj; continue; }
-				bsx_setsam_finish(C->opt, C->idx, &C->reads[ri], &C->regs[ri].a[jreg.a[jj]], pool + sub[k].cigar_off, sres[k].n_cigar,
-				                  &ctx[ri / per].table[ri % per][jreg.a[jj]]);
+				if (sres[k].n_cigar < 0) { jobs.a[jj].cigar_cap = (uint32_t)(-sres[k].n_cigar) + 2; todo.a[nt++] = jj; }
 			}
+		}
 		todo.n = nt;
 		free(sub); free(sres);
 	}
@@ -603,12 +627,65 @@ static int emit_sam(chunk_t *C)
 	return rc;
 }
 
+static void clip_worker(void *data, long i, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	const bsx_opt_t *opt = C->opt;
+	(void)tid;
+	if (C->is_pe) clip_read(&C->reads[i], (i & 1) ? opt->adaptor2 : opt->adaptor1, (i & 1) ? opt->l_adaptor2 : opt->l_adaptor1, opt);
+	else clip_read(&C->reads[i], opt->adaptor1, opt->l_adaptor1, opt);
+	C->reads[i].sam = 0;
+}
+
+static void setup_worker(void *data, long i, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	const bsx_opt_t *opt = C->opt;
+	int order[2], no = 0, k;
+	(void)tid;
+	if (C->reads[i].l_seq) memcpy(C->buf + C->roff[i], C->reads[i].seq, (size_t)C->reads[i].l_seq);
+	if (!C->is_pe) {
+		if (!(opt->parent & 1) || opt->parent >> 1) order[no++] = 0;
+		if (!(opt->parent & 1) || !(opt->parent >> 1)) order[no++] = 1;
+	} else if (!(i & 1)) { order[no++] = 1; if (!opt->parent) order[no++] = 0; }
+	else { order[no++] = 0; if (!opt->parent) order[no++] = 1; }
+	for (k = 0; k < no; ++k) {
+		int t = C->read_task0[i] + k;
+		c2r_t *T = &C->tasks[t];
+		memset(T, 0, sizeof(*T));
+		T->read_idx = (int)i; T->parent = order[k]; T->qoff = C->roff[i]; T->l_query = C->reads[i].l_seq; T->query = C->reads[i].seq;
+		C->stasks[t].qoff = T->qoff; C->stasks[t].len = T->l_query; C->stasks[t].parent = T->parent;
+	}
+}
+
+static void sa_jobs_worker(void *data, long t, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	int64_t k, c;
+	(void)tid;
+	for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k)
+		for (c = 0; c < C->ipos_off[k + 1] - C->ipos_off[k]; ++c) {
+			bsx_sa_job_t *j = &C->sa_jobs[C->ipos_off[k] + c];
+			j->k = C->intv[k].x[0] + (uint64_t)c; j->parent = C->tasks[t].parent; j->pad = 0;
+		}
+}
+
+static void release_worker(void *data, long t, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	(void)tid;
+	bsx_c2r_release(&C->tasks[t]); bsx_vec_free(C->tasks[t].regs);
+	if (C->xpos) free(C->xpos[t]);
+	if (C->xpos_off) free(C->xpos_off[t]);
+}
+static void release_regs_worker(void *data, long i, int tid) { (void)tid; free(((chunk_t*)data)->regs[i].a); }
+
 /* ------------------------------------------------------------------ the chunk */
 BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
                                      int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
 	chunk_t C;
-	int rc = BSX_OK, i, t, nt = opt->n_threads > 0 ? opt->n_threads : 1;
+	int rc = BSX_OK, i, t, nt = bsx_host_threads(opt);
 	size_t tot = 0;
 	uint8_t *buf = 0;
 	bsx_seed_task_t *stasks = 0;
@@ -622,46 +699,35 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	C.is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
 	if (C.is_pe && (n & 1)) return BSX_E_ARG;
 
-	/* clipping + chunk read buffer */
-	for (i = 0; i < n; ++i) {
-		if (C.is_pe) {
-			if (!(i & 1) && !pair_names_ok(reads[i].name, reads[i + 1].name)) {
+	/* clipping + chunk read buffer + strand searches in the reference's call order (bwamem.c:325-333,352-372) */
+	t0 = now_s();
+	if (C.is_pe)
+		for (i = 0; i < n; i += 2)
+			if (!pair_names_ok(reads[i].name, reads[i + 1].name)) {
 				fprintf(stderr, "[bsx] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name);
 				return BSX_E_FORMAT;
 			}
-			clip_read(&reads[i], (i & 1) ? opt->adaptor2 : opt->adaptor1, (i & 1) ? opt->l_adaptor2 : opt->l_adaptor1, opt);
-		} else clip_read(&reads[i], opt->adaptor1, opt->l_adaptor1, opt);
-		reads[i].sam = 0;
-	}
+	bsx_parallel_for(nt, clip_worker, &C, n);
 	C.roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	for (i = 0; i < n; ++i) { C.roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
 	C.roff[n] = (uint32_t)tot;
 	if (tot >= 0xffff0000ull) { free(C.roff); return BSX_E_ARG; }
 	buf = (uint8_t*)malloc(tot + 16);
-	for (i = 0; i < n; ++i) if (reads[i].l_seq) memcpy(buf + C.roff[i], reads[i].seq, (size_t)reads[i].l_seq);
+	C.buf = buf;
+	{
+		int per_read = C.is_pe ? (opt->parent ? 1 : 2) : ((opt->parent & 1) ? 1 : 2);
+		C.read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
+		for (i = 0; i <= n; ++i) C.read_task0[i] = i * per_read;
+		C.n_tasks = n * per_read;
+	}
+	C.tasks = (c2r_t*)malloc(sizeof(c2r_t) * ((size_t)C.n_tasks + 1));
+	stasks = (bsx_seed_task_t*)malloc(sizeof(*stasks) * ((size_t)C.n_tasks + 1));
+	C.stasks = stasks;
+	bsx_parallel_for(nt, setup_worker, &C, n);
+	g_stats.n_tasks = C.n_tasks;
 	CHECK(be->set_opt(be->ctx, opt));
 	CHECK(be->set_reads(be->ctx, buf, tot));
-
-	/* strand searches in the reference's call order (bwamem.c:325-333,352-372) */
-	C.read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
-	C.tasks = (c2r_t*)calloc((size_t)n * 2 + 1, sizeof(c2r_t));
-	for (i = 0; i < n; ++i) {
-		int order[2], no = 0, k;
-		if (!C.is_pe) {
-			if (!(opt->parent & 1) || opt->parent >> 1) order[no++] = 0;
-			if (!(opt->parent & 1) || !(opt->parent >> 1)) order[no++] = 1;
-		} else if (!(i & 1)) { order[no++] = 1; if (!opt->parent) order[no++] = 0; }
-		else { order[no++] = 0; if (!opt->parent) order[no++] = 1; }
-		C.read_task0[i] = C.n_tasks;
-		for (k = 0; k < no; ++k) {
-			c2r_t *T = &C.tasks[C.n_tasks++];
-			T->read_idx = i; T->parent = order[k]; T->qoff = C.roff[i]; T->l_query = reads[i].l_seq; T->query = reads[i].seq;
-		}
-	}
-	C.read_task0[n] = C.n_tasks;
-	g_stats.n_tasks = C.n_tasks;
-	stasks = (bsx_seed_task_t*)malloc(sizeof(*stasks) * ((size_t)C.n_tasks + 1));
-	for (t = 0; t < C.n_tasks; ++t) { stasks[t].qoff = C.tasks[t].qoff; stasks[t].len = C.tasks[t].l_query; stasks[t].parent = C.tasks[t].parent; }
+	g_stats.t_prep = now_s() - t0;
 
 	/* K1+K2 */
 	t0 = now_s();
@@ -672,18 +738,14 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	/* K3: the first min(occ, max_occ) occurrences of every interval */
 	t0 = now_s();
 	{
-		int64_t n_iv = C.intv_off[C.n_tasks], k, nj = 0, c;
+		int64_t n_iv = C.intv_off[C.n_tasks], k, nj = 0;
 		bsx_sa_job_t *sj;
 		C.ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
 		for (k = 0; k < n_iv; ++k) { C.ipos_off[k] = nj; nj += (int64_t)(C.intv[k].x[2] < opt->max_occ ? C.intv[k].x[2] : opt->max_occ); }
 		C.ipos_off[n_iv] = nj;
 		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
-		for (t = 0; t < C.n_tasks; ++t)
-			for (k = C.intv_off[t]; k < C.intv_off[t + 1]; ++k)
-				for (c = 0; c < C.ipos_off[k + 1] - C.ipos_off[k]; ++c) {
-					bsx_sa_job_t *j = &sj[C.ipos_off[k] + c];
-					j->k = C.intv[k].x[0] + (uint64_t)c; j->parent = C.tasks[t].parent; j->pad = 0;
-				}
+		C.sa_jobs = sj;
+		bsx_parallel_for(nt, sa_jobs_worker, &C, C.n_tasks);
 		C.pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
 		rc = be->sa_batch(be->ctx, nj, sj, C.pos);
 		free(sj);
@@ -701,7 +763,9 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	for (i = 0; i < nt; ++i) C.trees[i] = bsx_bt_new();
 	for (;;) {
 		int any = 0;
+		double tc0 = now_s();
 		bsx_parallel_for(nt, chain_worker, &C, C.n_tasks);
+		if (getenv("BSX_PHASES")) fprintf(stderr, "[M::chain] parallel pass %.3f s (%d threads)\n", now_s() - tc0, nt);
 		for (t = 0; t < C.n_tasks; ++t) {
 			int n_iv, k, want;
 			int64_t nj, c;
@@ -738,7 +802,7 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 		}
 		if (!any) break;
 	}
-	CHECK(filter_chained_seeds(&C));
+	{ double tf0 = now_s(); CHECK(filter_chained_seeds(&C)); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::chain] seed filter %.3f s\n", now_s() - tf0); }
 	g_stats.t_chain = now_s() - t0;
 
 	/* K4 rounds */
@@ -764,17 +828,22 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	CHECK(emit_sam(&C));
 
 done:
-	if (C.tasks) {
-		for (t = 0; t < C.n_tasks; ++t) { bsx_c2r_release(&C.tasks[t]); bsx_vec_free(C.tasks[t].regs); if (C.xpos) free(C.xpos[t]); if (C.xpos_off) free(C.xpos_off[t]); }
-		free(C.tasks);
-	}
-	if (C.regs) { for (i = 0; i < n; ++i) free(C.regs[i].a); free(C.regs); }
+	t0 = now_s();
+	if (C.tasks) { bsx_parallel_for(nt, release_worker, &C, C.n_tasks); free(C.tasks); }
+	if (C.regs) { bsx_parallel_for(nt, release_regs_worker, &C, n); free(C.regs); }
 	if (C.trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C.trees[i]); free(C.trees); }
 	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
 	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
+	g_stats.t_cleanup = now_s() - t0;
 	g_stats.t_total = now_s() - t_all;
 	if (bsx_verbose >= 3)
+	{
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", n, g_stats.t_total, be->name ? be->name : "?");
+		if (getenv("BSX_PHASES"))
+			fprintf(stderr, "[M::phases] seed %.3f sa %.3f chain %.3f extend %.3f (%ld jobs, %ld rounds) merge %.3f pestat %.3f matesw %.3f primary %.3f cigar %.3f sam %.3f | tasks %ld intv %ld sa %ld sw %ld glb %ld\n",
+				g_stats.t_seed, g_stats.t_sa, g_stats.t_chain, g_stats.t_extend, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds, g_stats.t_merge, g_stats.t_pestat,
+				g_stats.t_matesw, g_stats.t_primary, g_stats.t_cigar, g_stats.t_sam, (long)g_stats.n_tasks, (long)g_stats.n_intv, (long)g_stats.n_sa, (long)g_stats.n_sw_jobs, (long)g_stats.n_glb_jobs);
+	}
 	return rc;
 }
 

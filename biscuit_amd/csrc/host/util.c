@@ -8,6 +8,7 @@
  * permutation -- is the same.  Pinned against the reference templates in tests/test_host_primitives.py.
  */
 #include <pthread.h>
+#include <malloc.h>
 #include "bsx_core.h"
 
 BSX_API int bsx_verbose = 3;
@@ -275,20 +276,49 @@ int bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids)
 /* ------------------------------------------------------------------------------------------
  * parallel for
  * ------------------------------------------------------------------------------------------ */
+/* Persistent worker pool: the pipeline issues thousands of short parallel loops per chunk (one or
+ * two per extension round), so threads are created once and parked on a condition variable. */
 typedef struct {
-	bsx_for_fn fn; void *data; long n; long next; long grain; int tid;
-} pf_shared_t;
-typedef struct { pf_shared_t *sh; int tid; } pf_arg_t;
+	bsx_for_fn fn; void *data; long n; volatile long next; long grain; int n_part;
+} pf_job_t;
 
-static void *pf_worker(void *a_)
+static struct {
+	pthread_mutex_t call_mu;      /* one parallel loop at a time */
+	pthread_mutex_t mu;
+	pthread_cond_t cv_work, cv_done;
+	int n_workers, m_workers;
+	pthread_t *th;
+	pf_job_t *job;
+	long generation;
+	int n_done;
+	int init;
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0, 0, 0 };
+
+static void pf_run(pf_job_t *J, int tid)
 {
-	pf_arg_t *a = (pf_arg_t*)a_;
-	pf_shared_t *sh = a->sh;
 	for (;;) {
-		long b = __sync_fetch_and_add(&sh->next, sh->grain), e, i;
-		if (b >= sh->n) break;
-		e = b + sh->grain < sh->n ? b + sh->grain : sh->n;
-		for (i = b; i < e; ++i) sh->fn(sh->data, i, a->tid);
+		long b = __sync_fetch_and_add(&J->next, J->grain), e, i;
+		if (b >= J->n) break;
+		e = b + J->grain < J->n ? b + J->grain : J->n;
+		for (i = b; i < e; ++i) J->fn(J->data, i, tid);
+	}
+}
+
+static void *pf_worker(void *arg)
+{
+	int id = (int)(intptr_t)arg;   /* participates as tid id+1 */
+	long seen = 0;
+	pthread_mutex_lock(&g_pool.mu);
+	for (;;) {
+		pf_job_t *J;
+		while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
+		seen = g_pool.generation;
+		J = g_pool.job;
+		if (J == 0 || id + 1 >= J->n_part) continue;
+		pthread_mutex_unlock(&g_pool.mu);
+		pf_run(J, id + 1);
+		pthread_mutex_lock(&g_pool.mu);
+		if (++g_pool.n_done == J->n_part - 1) pthread_cond_signal(&g_pool.cv_done);
 	}
 	return 0;
 }
@@ -296,19 +326,52 @@ static void *pf_worker(void *a_)
 void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
 {
 	long i;
+	pf_job_t J;
 	if (n <= 0) return;
-	if (n_threads <= 1 || n == 1) {
-		for (i = 0; i < n; ++i) fn(data, i, 0);
-	} else {
-		pf_shared_t sh;
-		pthread_t *tid = (pthread_t*)alloca(sizeof(pthread_t) * n_threads);
-		pf_arg_t *args = (pf_arg_t*)alloca(sizeof(pf_arg_t) * n_threads);
-		int t;
-		sh.fn = fn; sh.data = data; sh.n = n; sh.next = 0;
-		sh.grain = n / (n_threads * 16L); if (sh.grain < 1) sh.grain = 1; if (sh.grain > 256) sh.grain = 256;
-		for (t = 0; t < n_threads; ++t) { args[t].sh = &sh; args[t].tid = t; pthread_create(&tid[t], 0, pf_worker, &args[t]); }
-		for (t = 0; t < n_threads; ++t) pthread_join(tid[t], 0);
+	if (n_threads > n) n_threads = (int)n;
+	if (n_threads <= 1) { for (i = 0; i < n; ++i) fn(data, i, 0); return; }
+	pthread_mutex_lock(&g_pool.call_mu);
+	pthread_mutex_lock(&g_pool.mu);
+	while (g_pool.n_workers < n_threads - 1) { /* grow the pool on demand */
+		if (g_pool.n_workers == g_pool.m_workers) {
+			g_pool.m_workers = g_pool.m_workers ? g_pool.m_workers << 1 : 16;
+			g_pool.th = (pthread_t*)realloc(g_pool.th, sizeof(pthread_t) * g_pool.m_workers);
+		}
+		if (pthread_create(&g_pool.th[g_pool.n_workers], 0, pf_worker, (void*)(intptr_t)g_pool.n_workers) != 0) break;
+		pthread_detach(g_pool.th[g_pool.n_workers]);
+		++g_pool.n_workers;
 	}
+	if (n_threads - 1 > g_pool.n_workers) n_threads = g_pool.n_workers + 1;
+	J.fn = fn; J.data = data; J.n = n; J.next = 0; J.n_part = n_threads;
+	J.grain = n / (n_threads * 8L); if (J.grain < 1) J.grain = 1; if (J.grain > 1024) J.grain = 1024;
+	g_pool.job = &J; g_pool.n_done = 0; ++g_pool.generation;
+	pthread_cond_broadcast(&g_pool.cv_work);
+	pthread_mutex_unlock(&g_pool.mu);
+	pf_run(&J, 0);
+	pthread_mutex_lock(&g_pool.mu);
+	while (g_pool.n_done < n_threads - 1) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+	g_pool.job = 0;
+	pthread_mutex_unlock(&g_pool.mu);
+	pthread_mutex_unlock(&g_pool.call_mu);
+}
+
+/* The host stages allocate millions of small records per chunk from many threads.  With glibc's
+ * defaults every arena grows and shrinks in small steps, and each step is an mprotect/munmap that
+ * takes the process-wide mmap lock against all page faults of the other workers.  Growing in large
+ * steps and never trimming keeps the memory of one chunk for the next one. */
+__attribute__((constructor)) static void bsx_tune_malloc(void)
+{
+	if (getenv("BSX_NO_MALLOC_TUNING")) return;
+	mallopt(M_TOP_PAD, 64 << 20);
+	mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+	mallopt(M_MMAP_THRESHOLD, 1 << 30);
+}
+
+int bsx_host_threads(const bsx_opt_t *opt)
+{
+	const char *e = getenv("BSX_HOST_THREADS");
+	int n = e ? atoi(e) : (opt ? opt->n_threads : 1);
+	return n > 0 ? n : 1;
 }
 
 const char *bsx_version(void) { return "biscuit_amd 0.1 (gfx950)"; }

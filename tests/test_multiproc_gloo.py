@@ -1,0 +1,41 @@
+"""CPU, world_size 2 over gloo: the chunk-sharded multi-process path (biscuit_amd/multi_gpu.py) produces
+exactly the single-process SAM.  Uses the CPU restatement of the kernels (no GPU here); the sharding,
+offset bookkeeping and ordered gather are the same code the GPU launcher runs."""
+import os
+import subprocess
+import sys
+import pytest
+import simdata
+from biscuit_amd.api import Index
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def strip_pg(b):
+    return b"\n".join(l for l in b.split(b"\n") if not l.startswith(b"@PG"))
+
+
+@pytest.mark.parametrize("pe", [True, False])
+def test_two_ranks_equal_one(tmp_path, pe):
+    d = str(tmp_path)
+    contigs = simdata.make_genome(200000, seed=5, n_contigs=2)
+    simdata.write_genome(d + "/g.fa", contigs)
+    Index.build(d + "/g.fa", d + "/g").close()
+    # ~3.6 Mbp of reads with -@ 1 and a 1 Mbp chunk => several chunks (chunk size is not a CLI option in the
+    # reference either; the test shrinks it through the environment)
+    pairs = simdata.make_pairs(contigs, 3000, 100, 3, frag=(150, 300), sub=0.01, indel=0.003)
+    simdata.write_fastq(d + "/r1.fq", [(n, a) for n, a, b in pairs])
+    simdata.write_fastq(d + "/r2.fq", [(n, b) for n, a, b in pairs])
+    files = ["r1.fq", "r2.fq"] if pe else ["r1.fq"]
+    env = dict(os.environ, BSX_CHUNK_SIZE="100000", PYTHONPATH=ROOT)
+    one = subprocess.run([os.path.join(ROOT, "oracle", "oracle_align"), "-@", "1", "g"] + files, cwd=d, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    assert one.stderr.count(b"sequences (") >= 3     # really several chunks
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29531" if pe else "29532", "-m", "biscuit_amd.multi_gpu", "--backend", "oracle", "--out", d + "/two.sam", "--", "-@", "1", "g"] + files,
+                         cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    a, b = strip_pg(one.stdout), strip_pg(open(d + "/two.sam", "rb").read())
+    assert a.count(b"\n") > 3000
+    assert a == b

@@ -1,0 +1,161 @@
+"""CPU: the oracle (oracle/port.c) and the host primitives against tests/golden/ref_vectors.npz --
+inputs and outputs recorded from the REAL reference functions (tests/golden/make_vectors.py).
+Bit-exact.  This is what pins the checker on machines without /root/reference."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import oracle_lib
+from biscuit_amd import _lib as B
+from biscuit_amd.api import Index, default_opt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+u8p, i8p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_uint64)
+
+
+def P(a, t):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def V():
+    return np.load(os.path.join(HERE, "golden", "ref_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def PL():
+    return oracle_lib.port_lib()
+
+
+def _mat(V, a, b, which):
+    key = {(1, 2): 0, (2, 3): 1, (1, 9): 2}.get((a, b))
+    if key is not None:
+        return np.ascontiguousarray(V["scmat"][key][which])
+    o = default_opt()
+    o.a, o.b = a, b
+    B.lib().bsx_opt_fill_matrices(C.byref(o))
+    return np.array([o.mat, o.ctmat, o.gamat][which], dtype=np.int8)
+
+
+def test_scoring_matrices_and_defaults(V):
+    L = B.lib()
+    for k, (a, b) in enumerate(((1, 2), (2, 3), (1, 9))):
+        o = default_opt()
+        o.a, o.b = a, b
+        L.bsx_opt_fill_matrices(C.byref(o))
+        got = np.stack([np.array(o.mat, np.int8), np.array(o.ctmat, np.int8), np.array(o.gamat, np.int8)])
+        assert (got == V["scmat"][k]).all()
+    buf = C.create_string_buffer(4096)
+    L.bsx_hook_opt_defaults(buf, 4096)
+    assert buf.value == V["opt_defaults"].tobytes()
+
+
+def test_hash_and_mapq(V):
+    L = B.lib()
+    L.bsx_hook_hash64.restype = C.c_uint64
+    L.bsx_hook_hash64.argtypes = [C.c_uint64]
+    for k, h in zip(V["hash_in"], V["hash_out"]):
+        assert L.bsx_hook_hash64(int(k)) == int(h)
+    L.bsx_hook_mapq.argtypes = [C.c_int] * 3 + [C.c_float, C.c_int] + [C.c_int] * 6 + [C.c_int64, C.c_int64, C.c_int, C.c_float]
+    for r in V["mapq"]:
+        score, sub, csub, sub_n, qb, qe, rb, re, seedcov = [int(x) for x in r[:9]]
+        q = L.bsx_hook_mapq(1, 2, 19, 50.0, 3, score, sub, csub, sub_n, qb, qe, rb, re, seedcov, float(np.float32(r[9])))
+        assert q == int(r[10]), r
+
+
+def test_introsort_permutation(V):
+    """the exact permutation of klib's unstable introsort (incl. comb-sort fallback), asc and desc"""
+    L = B.lib()
+    off = V["sort_off"]
+    for i in range(len(off) - 1):
+        keys = V["sort_keys"][off[i]:off[i + 1]]
+        n = len(keys)
+        for desc, want in ((0, V["sort_perm_asc"]), (1, V["sort_perm_desc"])):
+            kv = np.stack([keys, np.arange(n, dtype=np.int64)], 1).copy()
+            L.bsx_hook_sort_kv(C.c_int64(n), kv.ctypes.data_as(C.c_void_p), desc)
+            assert (kv[:, 1] == want[off[i]:off[i + 1]]).all(), (i, n, desc)
+
+
+def test_btree_lookup_and_order(V):
+    """kb_intervalp's `lower` and the in-order traversal, duplicates included (t = 3 nodes)"""
+    L = B.lib()
+    L.bsx_bt_new.restype = C.c_void_p
+    L.bsx_bt_put.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+    L.bsx_bt_lower.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_bt_traverse.argtypes = [C.c_void_p, C.c_void_p]
+    L.bsx_bt_free.argtypes = [C.c_void_p]
+    oo, ro = V["bt_ops_off"], V["bt_res_off"]
+    for c in range(len(oo) - 1):
+        ops = V["bt_ops"][oo[c]:oo[c + 1]].reshape(-1, 2)
+        res = V["bt_res"][ro[c]:ro[c + 1]]
+        t = C.c_void_p(L.bsx_bt_new())
+        nid = 0
+        k = 0
+        for op, x in ops:
+            if op == 0:
+                L.bsx_bt_put(t, int(x), nid); assert res[k] == nid; nid += 1; k += 1
+            elif op == 1:
+                assert L.bsx_bt_lower(t, int(x)) == int(res[k]); k += 1
+            else:
+                ids = np.zeros(nid + 1, np.int32)
+                n = L.bsx_bt_traverse(t, ids.ctypes.data_as(C.c_void_p))
+                assert n == int(x) and (ids[:n] == res[k:k + n]).all()
+        L.bsx_bt_free(t)
+
+
+def test_extend_sw_global_vs_reference_vectors(V, PL):
+    qo, to = V["ext_qoff"], V["ext_toff"]
+    for i, (par, want) in enumerate(zip(V["ext_par"], V["ext_out"])):
+        a, b, which, od, ed, oi, ei, w, eb, zd, h0 = [int(x) for x in par]
+        q = np.ascontiguousarray(V["ext_q"][qo[i]:qo[i + 1]]); t = np.ascontiguousarray(V["ext_t"][to[i]:to[i + 1]])
+        M = _mat(V, a, b, which)
+        o = (C.c_int * 6)()
+        PL.oracle_extend1(len(q), P(q, u8p), len(t), P(t, u8p), P(M, i8p), od, ed, oi, ei, w, eb, zd, h0, o)
+        assert list(o) == list(want), i
+    qo, to = V["sw_qoff"], V["sw_toff"]
+    for i, (par, want) in enumerate(zip(V["sw_par"], V["sw_out"])):
+        a, b, which, od, ed, oi, ei, xtra = [int(x) for x in par]
+        q = V["sw_q"][qo[i]:qo[i + 1]].copy(); t = V["sw_t"][to[i]:to[i + 1]].copy()
+        M = _mat(V, a, b, which)
+        o = (C.c_int * 7)()
+        PL.oracle_sw1(len(q), P(q, u8p), len(t), P(t, u8p), P(M, i8p), od, ed, oi, ei, xtra, o)
+        assert list(o) == list(want), (i, hex(xtra))
+    qo, to, co = V["gl_qoff"], V["gl_toff"], V["gl_coff"]
+    for i, par in enumerate(V["gl_par"]):
+        a, b, which, od, ed, oi, ei, w, wc = [int(x) for x in par]
+        q = np.ascontiguousarray(V["gl_q"][qo[i]:qo[i + 1]]); t = np.ascontiguousarray(V["gl_t"][to[i]:to[i + 1]])
+        M = _mat(V, a, b, which)
+        cg = (C.c_uint32 * 2048)(); n = C.c_int()
+        s = PL.oracle_global1(len(q), P(q, u8p), len(t), P(t, u8p), P(M, i8p), od, ed, oi, ei, w, wc, C.byref(n), cg, 2048)
+        assert s == int(V["gl_score"][i]) and list(cg[:n.value]) == list(V["gl_cigar"][co[i]:co[i + 1]]), i
+
+
+@pytest.fixture(scope="module")
+def g24k(tmp_path_factory):
+    d = tmp_path_factory.mktemp("g24k")
+    return Index.build(os.path.join(HERE, "golden", "g24k.fa"), str(d / "g"))
+
+
+def test_fm_index_vs_reference_vectors(V, PL, g24k):
+    """index built by the repo's builder from the committed FASTA; SMEM / LAST-like seeds / occ / SA equal
+    what the reference's bwt.c returned on it"""
+    PL.oracle_sa.restype = C.c_uint64
+    PL.oracle_sa.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    ro, so = V["fm_roff"], V["fm_soff"]
+    for i, par in enumerate(V["fm_par"]):
+        p, x, mi, n1, r1, q1 = [int(v) for v in par]
+        rd = np.ascontiguousarray(V["fm_reads"][ro[i]:ro[i + 1]])
+        out = np.zeros(4 * 512, np.uint64); ret = C.c_int()
+        n = PL.oracle_smem1(g24k.h, p, len(rd), P(rd, u8p), x, mi, P(out, u64p), 512, C.byref(ret))
+        assert n == n1 and ret.value == r1 and (out[:4 * n] == V["fm_smem"][so[i]:so[i + 1]]).all(), i
+        a = np.zeros(4, np.uint64)
+        q = PL.oracle_seed_strategy1(g24k.h, p, len(rd), P(rd, u8p), x, 19, 20, P(a, u64p))
+        assert q == q1 and (a == V["fm_ss1"][i]).all(), i
+    ks = V["fm_k"]
+    for p in (0, 1):
+        for i, k in enumerate(ks):
+            c = np.zeros(4, np.uint64)
+            PL.oracle_occ4(g24k.h, p, C.c_uint64(int(k)), P(c, u64p))
+            assert (c == V["fm_occ4_%d" % p][i]).all(), (p, k)
+        got = np.array([PL.oracle_sa(g24k.h, p, int(k)) for k in ks[ks >= 1]], dtype=np.uint64)
+        assert (got == V["fm_sa_%d" % p]).all()
