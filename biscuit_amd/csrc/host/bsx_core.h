@@ -23,6 +23,31 @@
 #define bsx_vec_push(v, x) do { if ((v).n == (v).m) bsx_vec_reserve(v, (v).n + 1); (v).a[(v).n++] = (x); } while (0)
 #define bsx_vec_pushp(v) (((v).n == (v).m ? (void)((v).m = (v).m ? (v).m << 1 : 4, (v).a = realloc((v).a, (v).m * sizeof(*(v).a))) : (void)0), &(v).a[(v).n++])
 
+/* ---------- chunk-lifetime arenas ----------
+ * Seeds, chains and regions live exactly as long as one chunk.  Each worker thread bump-allocates
+ * them from its own arena; nothing is freed individually, the arenas are rewound when the chunk is
+ * done and their pages are reused by the next chunk (no malloc lock, no page faults, no cleanup pass). */
+typedef struct bsx_arena bsx_arena_t;
+BSX_API void bsx_arenas_begin(int n_threads);   /* bind arenas to worker ids 0..n_threads-1 (0 = caller) */
+BSX_API void bsx_arenas_end(void);              /* rewind all arenas, unbind */
+void *bsx_arena_alloc(bsx_arena_t *a, size_t n);
+BSX_API extern __thread bsx_arena_t *bsx_tls_arena;
+static inline void *bsx_crealloc(void *p, size_t old_bytes, size_t new_bytes)
+{
+	if (bsx_tls_arena) {
+		void *q = bsx_arena_alloc(bsx_tls_arena, new_bytes);
+		if (p && old_bytes) memcpy(q, p, old_bytes < new_bytes ? old_bytes : new_bytes);
+		return q;
+	}
+	return realloc(p, new_bytes);
+}
+static inline void bsx_cfree(void *p) { if (!bsx_tls_arena) free(p); }
+#define bsx_cvec_free(v) (bsx_cfree((v).a), (v).a = 0, (v).n = (v).m = 0)
+#define bsx_cvec_reserve(v, cap) do { \
+		if ((v).m < (size_t)(cap)) { size_t m_ = (v).m ? (v).m : 4; while (m_ < (size_t)(cap)) m_ <<= 1; \
+			(v).a = bsx_crealloc((v).a, (v).m * sizeof(*(v).a), m_ * sizeof(*(v).a)); (v).m = m_; } } while (0)
+#define bsx_cvec_push(v, x) do { if ((v).n == (v).m) bsx_cvec_reserve(v, (v).n + 1); (v).a[(v).n++] = (x); } while (0)
+
 #define bsx_min(a, b) ((a) < (b) ? (a) : (b))
 #define bsx_max(a, b) ((a) > (b) ? (a) : (b))
 

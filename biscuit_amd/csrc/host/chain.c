@@ -19,7 +19,7 @@ static int chain_absorb(const bsx_opt_t *opt, int64_t l_pac, chain_t *c, const s
 	if (seed_rid != c->rid) return 0;
 	if (s->qbeg >= first->qbeg && s->qbeg + s->len <= last->qbeg + last->len &&
 	    s->rbeg >= first->rbeg && s->rbeg + s->len <= last->rbeg + last->len) {
-		bsx_vec_push(c->seeds_extra, *s);   /* contained on both axes: kept as a back-up seed */
+		bsx_cvec_push(c->seeds_extra, *s);   /* contained on both axes: kept as a back-up seed */
 		return 1;
 	}
 	if ((last->rbeg < l_pac || first->rbeg < l_pac) && s->rbeg >= l_pac) return 0;  /* other strand */
@@ -27,7 +27,7 @@ static int chain_absorb(const bsx_opt_t *opt, int64_t l_pac, chain_t *c, const s
 	rdist = s->rbeg - last->rbeg;
 	if (rdist >= 0 && qdist - rdist <= opt->w && rdist - qdist <= opt->w &&
 	    qdist - last->len < opt->max_chain_gap && rdist - last->len < opt->max_chain_gap) {
-		bsx_vec_push(c->seeds, *s);
+		bsx_cvec_push(c->seeds, *s);
 		return 1;
 	}
 	return 0;
@@ -36,7 +36,7 @@ static int chain_absorb(const bsx_opt_t *opt, int64_t l_pac, chain_t *c, const s
 void bsx_chain_free(chain_v *chains)
 {
 	size_t i;
-	for (i = 0; i < chains->n; ++i) { bsx_vec_free(chains->a[i].seeds); bsx_vec_free(chains->a[i].seeds_extra); }
+	for (i = 0; i < chains->n; ++i) { bsx_cvec_free(chains->a[i].seeds); bsx_cvec_free(chains->a[i].seeds_extra); }
 	chains->n = 0;
 }
 
@@ -77,8 +77,8 @@ int bsx_chain_build(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int l_seq, i
 			int rid, to_add = 0;
 			if ((int64_t)k >= avail) { /* the caller must look up more occurrences of interval i */
 				size_t u;
-				for (u = 0; u < pool.n; ++u) { bsx_vec_free(pool.a[u].seeds); bsx_vec_free(pool.a[u].seeds_extra); }
-				bsx_vec_free(pool);
+				for (u = 0; u < pool.n; ++u) { bsx_cvec_free(pool.a[u].seeds); bsx_cvec_free(pool.a[u].seeds_extra); }
+				bsx_cvec_free(pool);
 				return 1 + i;
 			}
 			s.rbeg = (int64_t)pos[pos_off[i] + (int64_t)k];
@@ -95,24 +95,24 @@ int bsx_chain_build(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int l_seq, i
 				chain_t c;
 				memset(&c, 0, sizeof(c));
 				++count;
-				bsx_vec_push(c.seeds, s);
+				bsx_cvec_push(c.seeds, s);
 				c.rid = rid;
 				c.is_alt = !!ref->anns[rid].is_alt;
 				c.pos = s.rbeg;
-				bsx_vec_push(pool, c);
+				bsx_cvec_push(pool, c);
 				bsx_bt_put(tree, c.pos, (int32_t)(pool.n - 1));
 			}
 		}
 	}
 	/* in-order traversal of the tree gives the chain order (memchain.c:372-379) */
-	ids = (int32_t*)malloc(sizeof(int32_t) * (pool.n + 1));
+	ids = (int32_t*)bsx_crealloc(0, 0, sizeof(int32_t) * (pool.n + 1));
 	n_ids = bsx_bt_traverse(tree, ids);
 	frac_rep = (float)l_rep / l_seq;
-	bsx_vec_reserve(*out, (size_t)n_ids + 1);
+	bsx_cvec_reserve(*out, (size_t)n_ids + 1);
 	for (i = 0; i < n_ids; ++i) { out->a[i] = pool.a[ids[i]]; out->a[i].frac_rep = frac_rep; }
 	out->n = (size_t)n_ids;
-	free(ids);
-	bsx_vec_free(pool);
+	bsx_cfree(ids);
+	bsx_cvec_free(pool);
 	return 0;
 }
 
@@ -154,14 +154,14 @@ void bsx_chain_filter(const bsx_opt_t *opt, chain_v *chns)
 		chain_t *c = &chns->a[i];
 		c->first = -1; c->kept = 0;
 		c->w = (uint32_t)chain_weight(c) & 0x1fffffffu;
-		if ((int)c->w < opt->min_chain_weight) { bsx_vec_free(c->seeds); bsx_vec_free(c->seeds_extra); }
+		if ((int)c->w < opt->min_chain_weight) { bsx_cvec_free(c->seeds); bsx_cvec_free(c->seeds_extra); }
 		else chns->a[k++] = *c;
 	}
 	chns->n = k;
-	if (chns->n == 0) { bsx_vec_free(keep); return; }
+	if (chns->n == 0) { bsx_cvec_free(keep); return; }
 	bsx_introsort(chns->a, chns->n, sizeof(chain_t), chain_w_desc);
 	chns->a[0].kept = 3;
-	bsx_vec_push(keep, 0);
+	bsx_cvec_push(keep, 0);
 	for (i = 1; i < chns->n; ++i) {
 		int large_overlap = 0;
 		for (k = 0; k < keep.n; ++k) {
@@ -179,7 +179,7 @@ void bsx_chain_filter(const bsx_opt_t *opt, chain_v *chns)
 			}
 		}
 		if (k == keep.n) {
-			bsx_vec_push(keep, (int)i);
+			bsx_cvec_push(keep, (int)i);
 			chns->a[i].kept = large_overlap ? 2 : 3;
 		}
 	}
@@ -187,7 +187,7 @@ void bsx_chain_filter(const bsx_opt_t *opt, chain_v *chns)
 		chain_t *c = &chns->a[keep.a[i]];
 		if (c->first >= 0) chns->a[c->first].kept = 1;
 	}
-	bsx_vec_free(keep);
+	bsx_cvec_free(keep);
 	for (i = k = 0; i < chns->n; ++i) { /* at most max_chain_extend shadowed chains survive */
 		if (chns->a[i].kept == 0 || chns->a[i].kept == 3) continue;
 		if (++k >= opt->max_chain_extend) break;
@@ -196,7 +196,7 @@ void bsx_chain_filter(const bsx_opt_t *opt, chain_v *chns)
 		if (chns->a[i].kept < 3) chns->a[i].kept = 0;
 	for (i = k = 0; i < chns->n; ++i) {
 		chain_t *c = &chns->a[i];
-		if (c->kept == 0) { bsx_vec_free(c->seeds); bsx_vec_free(c->seeds_extra); }
+		if (c->kept == 0) { bsx_cvec_free(c->seeds); bsx_cvec_free(c->seeds_extra); }
 		else chns->a[k++] = *c;
 	}
 	chns->n = k;

@@ -28,7 +28,7 @@ static int seed_violates_conversion(const bsx_index_t *idx, const uint8_t *query
 static void c2r_open_list(c2r_t *t, const seed_v *seeds)
 {
 	size_t i;
-	if (t->m_srt < (int)seeds->n) { t->m_srt = (int)seeds->n + 8; t->srt = (uint64_t*)realloc(t->srt, sizeof(uint64_t) * t->m_srt); }
+	if (t->m_srt < (int)seeds->n) { bsx_cfree(t->srt); t->m_srt = (int)seeds->n + 8; t->srt = (uint64_t*)bsx_crealloc(0, 0, sizeof(uint64_t) * t->m_srt); }
 	for (i = 0; i < seeds->n; ++i) t->srt[i] = (uint64_t)seeds->a[i].score << 32 | i;
 	t->n_srt = (int)seeds->n;
 	bsx_introsort_u64(seeds->n, t->srt);   /* ks_introsort_64, memchain.c:752 */
@@ -72,7 +72,7 @@ static void c2r_finish_region(const bsx_index_t *idx, c2r_t *t, const chain_t *c
 		r->w = t->aw[0] > t->aw[1] ? t->aw[0] : t->aw[1];
 		r->seedlen0 = s->len;
 		r->frac_rep = c->frac_rep;
-		bsx_vec_push(t->regs, *r);
+		bsx_cvec_push(t->regs, *r);
 	}
 	--t->k;
 	t->stage = 0;
@@ -212,6 +212,6 @@ void bsx_c2r_consume(const bsx_opt_t *opt, const bsx_index_t *idx, c2r_t *t, con
 void bsx_c2r_release(c2r_t *t)
 {
 	bsx_chain_free(&t->chains);
-	bsx_vec_free(t->chains);
-	free(t->srt); t->srt = 0; t->m_srt = 0;
+	bsx_cvec_free(t->chains);
+	bsx_cfree(t->srt); t->srt = 0; t->m_srt = 0;
 }

@@ -674,7 +674,7 @@ static void release_worker(void *data, long t, int tid)
 {
 	chunk_t *C = (chunk_t*)data;
 	(void)tid;
-	bsx_c2r_release(&C->tasks[t]); bsx_vec_free(C->tasks[t].regs);
+	bsx_c2r_release(&C->tasks[t]); bsx_cvec_free(C->tasks[t].regs);
 	if (C->xpos) free(C->xpos[t]);
 	if (C->xpos_off) free(C->xpos_off[t]);
 }
@@ -699,19 +699,21 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	C.is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
 	if (C.is_pe && (n & 1)) return BSX_E_ARG;
 
+	bsx_arenas_begin(nt);
 	/* clipping + chunk read buffer + strand searches in the reference's call order (bwamem.c:325-333,352-372) */
 	t0 = now_s();
 	if (C.is_pe)
 		for (i = 0; i < n; i += 2)
 			if (!pair_names_ok(reads[i].name, reads[i + 1].name)) {
 				fprintf(stderr, "[bsx] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name);
+				bsx_arenas_end();
 				return BSX_E_FORMAT;
 			}
 	bsx_parallel_for(nt, clip_worker, &C, n);
 	C.roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
 	for (i = 0; i < n; ++i) { C.roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
 	C.roff[n] = (uint32_t)tot;
-	if (tot >= 0xffff0000ull) { free(C.roff); return BSX_E_ARG; }
+	if (tot >= 0xffff0000ull) { free(C.roff); bsx_arenas_end(); return BSX_E_ARG; }
 	buf = (uint8_t*)malloc(tot + 16);
 	C.buf = buf;
 	{
@@ -834,6 +836,7 @@ done:
 	if (C.trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C.trees[i]); free(C.trees); }
 	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
 	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
+	bsx_arenas_end();
 	g_stats.t_cleanup = now_s() - t0;
 	g_stats.t_total = now_s() - t_all;
 	if (bsx_verbose >= 3)

@@ -294,8 +294,54 @@ static struct {
 	int init;
 } g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0, 0, 0 };
 
+/* ---- arenas ---- */
+#define ARENA_BLOCK ((size_t)32 << 20)
+typedef struct { char *p; size_t cap; } arena_blk_t;
+struct bsx_arena { arena_blk_t *blk; int n_blk, m_blk, cur; size_t used; };
+BSX_API __thread bsx_arena_t *bsx_tls_arena = 0;
+static bsx_arena_t **g_arenas = 0;
+static int g_n_arenas = 0, g_arenas_on = 0;
+
+void *bsx_arena_alloc(bsx_arena_t *a, size_t n)
+{
+	void *q;
+	n = (n + 15) & ~(size_t)15;
+	while (a->cur < a->n_blk && a->used + n > a->blk[a->cur].cap) { ++a->cur; a->used = 0; }
+	if (a->cur == a->n_blk) {
+		size_t cap = n > ARENA_BLOCK ? n : ARENA_BLOCK;
+		if (a->n_blk == a->m_blk) { a->m_blk = a->m_blk ? a->m_blk << 1 : 8; a->blk = (arena_blk_t*)realloc(a->blk, sizeof(arena_blk_t) * a->m_blk); }
+		a->blk[a->n_blk].p = (char*)malloc(cap); a->blk[a->n_blk].cap = cap;
+		++a->n_blk; a->used = 0;
+	}
+	q = a->blk[a->cur].p + a->used;
+	a->used += n;
+	return q;
+}
+
+void bsx_arenas_begin(int n_threads)
+{
+	int i;
+	if (getenv("BSX_NO_ARENA")) return;
+	if (n_threads > g_n_arenas) {
+		g_arenas = (bsx_arena_t**)realloc(g_arenas, sizeof(bsx_arena_t*) * n_threads);
+		for (i = g_n_arenas; i < n_threads; ++i) g_arenas[i] = (bsx_arena_t*)calloc(1, sizeof(bsx_arena_t));
+		g_n_arenas = n_threads;
+	}
+	g_arenas_on = 1;
+	bsx_tls_arena = g_arenas[0];
+}
+
+void bsx_arenas_end(void)
+{
+	int i;
+	for (i = 0; i < g_n_arenas; ++i) { g_arenas[i]->cur = 0; g_arenas[i]->used = 0; }
+	g_arenas_on = 0;
+	bsx_tls_arena = 0;
+}
+
 static void pf_run(pf_job_t *J, int tid)
 {
+	bsx_tls_arena = (g_arenas_on && tid < g_n_arenas) ? g_arenas[tid] : 0;
 	for (;;) {
 		long b = __sync_fetch_and_add(&J->next, J->grain), e, i;
 		if (b >= J->n) break;
