@@ -88,23 +88,83 @@ BSX_HD void dev_load_block(const uint32_t *bwt, uint64_t kadj, uint64_t base[4],
 
 // bwt_2occ4 (lib/aln/bwt.c:204-236): ranks of all four symbols at k and l.
 // returns 1 when the reference would take its one-block fast path (one 64-B touch), else 0 (two).
+struct DevBlock { uint4 v0, v1, v2, v3; };
+BSX_HD DevBlock dev_load_block4(const uint32_t *bwt, uint64_t kadj)
+{
+	const uint4 *p = reinterpret_cast<const uint4*>(bwt + ((kadj >> 7) << 4));
+	DevBlock b; b.v0 = p[0]; b.v1 = p[1]; b.v2 = p[2]; b.v3 = p[3];
+	return b;
+}
+// per-symbol counts among symbols 0..upto of the block: 4 x 8-bit packed (A | C<<8 | G<<16 | T<<24), max 128 each
+BSX_HD uint32_t dev_count_word(uint32_t x, int nv)
+{
+	nv = nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+	const uint32_t valid = nv == 0 ? 0u : (0x55555555u & ~(uint32_t)((1ull << ((16 - nv) << 1)) - 1));
+	const uint32_t lo = x & valid, hi = (x >> 1) & valid;
+	const uint32_t nt = (uint32_t)dev_popc(hi & lo), ng = (uint32_t)dev_popc(hi & ~lo), nc = (uint32_t)dev_popc(lo & ~hi);
+	return ((uint32_t)nv - nt - ng - nc) | nc << 8 | ng << 16 | nt << 24;
+}
+BSX_HD void dev_block_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t &c, uint32_t &g, uint32_t &t)
+{
+	// at most 128 symbols per block: the packed byte counters cannot overflow across two words, sum in 16-bit halves
+	const int n = upto + 1;
+	uint32_t s0 = dev_count_word(b.v2.x, n) + dev_count_word(b.v2.y, n - 16);
+	uint32_t s1 = dev_count_word(b.v2.z, n - 32) + dev_count_word(b.v2.w, n - 48);
+	uint32_t s2 = dev_count_word(b.v3.x, n - 64) + dev_count_word(b.v3.y, n - 80);
+	uint32_t s3 = dev_count_word(b.v3.z, n - 96) + dev_count_word(b.v3.w, n - 112);
+	// each s is a sum of two words: bytes <= 32, no carry between bytes; widen before the final adds
+	const uint32_t lo = (s0 & 0x00ff00ffu) + (s1 & 0x00ff00ffu) + (s2 & 0x00ff00ffu) + (s3 & 0x00ff00ffu);
+	const uint32_t hi = ((s0 >> 8) & 0x00ff00ffu) + ((s1 >> 8) & 0x00ff00ffu) + ((s2 >> 8) & 0x00ff00ffu) + ((s3 >> 8) & 0x00ff00ffu);
+	a = lo & 0xffff; g = lo >> 16; c = hi & 0xffff; t = hi >> 16;
+}
+
+// bwt_2occ4 (lib/aln/bwt.c:204-236): ranks of all four symbols at k and l (scalars, no indexed arrays).
+// returns 1 when the reference would take its one-block fast path (one 64-B touch), else 0 (two).
 BSX_HD int dev_2occ4(const DevFmi &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
 {
 	const uint64_t NEG1 = ~0ull;
-	uint64_t ka = k - (k >= f.primary), la = l - (l >= f.primary);
-	uint64_t base[4]; uint32_t w[8], c[4];
-	if (k == NEG1 || l == NEG1 || (ka >> 7) != (la >> 7)) {
-		if (k == NEG1) { ck[0] = ck[1] = ck[2] = ck[3] = 0; }
-		else { dev_load_block(f.bwt, ka, base, w); dev_block_count(w, (int)(ka & 127), c); for (int i = 0; i < 4; ++i) ck[i] = base[i] + c[i]; }
-		if (l == NEG1) { cl[0] = cl[1] = cl[2] = cl[3] = 0; }
-		else { dev_load_block(f.bwt, la, base, w); dev_block_count(w, (int)(la & 127), c); for (int i = 0; i < 4; ++i) cl[i] = base[i] + c[i]; }
-		return 0;
-	}
-	dev_load_block(f.bwt, ka, base, w);
-	dev_block_count(w, (int)(ka & 127), c); for (int i = 0; i < 4; ++i) ck[i] = base[i] + c[i];
-	dev_block_count(w, (int)(la & 127), c); for (int i = 0; i < 4; ++i) cl[i] = base[i] + c[i];
-	return 1;
+	const uint64_t ka = k - (k >= f.primary), la = l - (l >= f.primary);
+	const bool kv = k != NEG1, lv = l != NEG1;
+	const bool same = kv && lv && (ka >> 7) == (la >> 7);
+	// both gathers are issued before either is consumed (k == -1 reads block 0 and is discarded)
+	const DevBlock B0 = dev_load_block4(f.bwt, kv ? ka : 0);
+	DevBlock B1 = B0;
+	if (!same) B1 = dev_load_block4(f.bwt, lv ? la : 0);
+	uint32_t a, c, g, t;
+	dev_block_count4(B0, (int)(ka & 127), a, c, g, t);
+	ck[0] = kv ? ((uint64_t)B0.v0.y << 32 | B0.v0.x) + a : 0; ck[1] = kv ? ((uint64_t)B0.v0.w << 32 | B0.v0.z) + c : 0;
+	ck[2] = kv ? ((uint64_t)B0.v1.y << 32 | B0.v1.x) + g : 0; ck[3] = kv ? ((uint64_t)B0.v1.w << 32 | B0.v1.z) + t : 0;
+	dev_block_count4(B1, (int)(la & 127), a, c, g, t);
+	cl[0] = lv ? ((uint64_t)B1.v0.y << 32 | B1.v0.x) + a : 0; cl[1] = lv ? ((uint64_t)B1.v0.w << 32 | B1.v0.z) + c : 0;
+	cl[2] = lv ? ((uint64_t)B1.v1.y << 32 | B1.v1.x) + g : 0; cl[3] = lv ? ((uint64_t)B1.v1.w << 32 | B1.v1.z) + t : 0;
+	return same ? 1 : 0;
 }
+
+// One of the two resident indices picked by value with selects: indexing the kernel-argument struct with a
+// per-lane index would make the compiler copy it to scratch memory.
+BSX_HD DevFmi dev_fmi_pick(const DevIndex &ix, int which)
+{
+	DevFmi f;
+	f.primary = which ? ix.fmi[1].primary : ix.fmi[0].primary;
+	f.L2[0] = which ? ix.fmi[1].L2[0] : ix.fmi[0].L2[0]; f.L2[1] = which ? ix.fmi[1].L2[1] : ix.fmi[0].L2[1];
+	f.L2[2] = which ? ix.fmi[1].L2[2] : ix.fmi[0].L2[2]; f.L2[3] = which ? ix.fmi[1].L2[3] : ix.fmi[0].L2[3];
+	f.L2[4] = which ? ix.fmi[1].L2[4] : ix.fmi[0].L2[4];
+	f.seq_len = which ? ix.fmi[1].seq_len : ix.fmi[0].seq_len;
+	f.bwt = which ? ix.fmi[1].bwt : ix.fmi[0].bwt; f.sa = which ? ix.fmi[1].sa : ix.fmi[0].sa;
+	f.sa_mask = ix.fmi[0].sa_mask; f.sa_shift = ix.fmi[0].sa_shift;
+	return f;
+}
+// field selects straight from the (uniform) kernel argument: nothing of the index is kept in per-lane registers
+BSX_HD uint64_t dev_ix_L2(const DevIndex &ix, int which, int c)
+{
+	const uint64_t a = c == 0 ? ix.fmi[0].L2[0] : c == 1 ? ix.fmi[0].L2[1] : c == 2 ? ix.fmi[0].L2[2] : c == 3 ? ix.fmi[0].L2[3] : ix.fmi[0].L2[4];
+	const uint64_t b = c == 0 ? ix.fmi[1].L2[0] : c == 1 ? ix.fmi[1].L2[1] : c == 2 ? ix.fmi[1].L2[2] : c == 3 ? ix.fmi[1].L2[3] : ix.fmi[1].L2[4];
+	return which ? b : a;
+}
+BSX_HD uint64_t dev_ix_primary(const DevIndex &ix, int which) { return which ? ix.fmi[1].primary : ix.fmi[0].primary; }
+BSX_HD const uint32_t *dev_ix_bwt(const DevIndex &ix, int which) { return which ? ix.fmi[1].bwt : ix.fmi[0].bwt; }
+
+BSX_HD uint64_t dev_L2(const DevFmi &f, int c) { return c == 0 ? f.L2[0] : c == 1 ? f.L2[1] : c == 2 ? f.L2[2] : c == 3 ? f.L2[3] : f.L2[4]; }
 
 // bwt_extend (lib/aln/bwt.c:278-293), returning only the child interval for symbol c.
 BSX_HD DevIntv dev_extend(const DevFmi &f, const DevIntv &ik, int is_back, int c, uint32_t &n_slow, uint32_t &n_fast)
@@ -116,7 +176,8 @@ BSX_HD DevIntv dev_extend(const DevFmi &f, const DevIntv &ik, int is_back, int c
 	uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
 	uint64_t b3 = xb + ((xa <= f.primary && xa + ik.x2 - 1 >= f.primary) ? 1 : 0);
 	uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
-	uint64_t na = f.L2[c] + 1 + tk[c];
+	const uint64_t tkc = c == 3 ? tk[3] : c == 2 ? tk[2] : c == 1 ? tk[1] : tk[0];
+	uint64_t na = dev_L2(f, c) + 1 + tkc;
 	uint64_t nb = c == 3 ? b3 : c == 2 ? b2 : c == 1 ? b1 : b0;
 	uint64_t ns = c == 3 ? s3 : c == 2 ? s2 : c == 1 ? s1 : s0;
 	DevIntv o;

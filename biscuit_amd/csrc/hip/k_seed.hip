@@ -3,6 +3,8 @@
 #include "seed_core.hpp"
 #include "kernels.h"
 
+#define SEED_LDS_WORDS 32   // 256 bases per lane in LDS: 8 KB per wave
+
 // One lane = one strand search at a time; lanes pull the next task from a global cursor as soon
 // as they finish (reads differ a lot in seeding work), so a wave stays full until the queue drains.
 // Every trip of the outer loop issues the FM-block gathers of all 64 lanes together.
@@ -12,13 +14,20 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
        long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters)
 {
-	const size_t lane_id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const size_t stride = (size_t)2 * list_cap + mem_cap;
+	// per-wave slab, lane-interleaved: entry i of lane l sits at slab[i*64 + l], so the 64 lanes'
+	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
+	const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t per_lane = (size_t)2 * list_cap + mem_cap;
 	SeedLane L;
-	L.bufA = scratch + lane_id * stride;
-	L.bufB = L.bufA + list_cap;
-	L.mem = L.bufB + list_cap;
+	L.stride = 64;
+	L.bufA = scratch + wave_id * per_lane * 64 + (threadIdx.x & 63);
+	L.bufB = L.bufA + (size_t)list_cap * 64;
+	L.mem = L.bufB + (size_t)list_cap * 64;
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
+	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
+	__shared__ uint32_t s_read[4][SEED_LDS_WORDS][64];
+	uint32_t *my_read = &s_read[threadIdx.x >> 6][0][threadIdx.x & 63];
+	L.qlds = nullptr;
 	L.state = SD_DONE;
 	L.n_slow = L.n_fast = 0;
 	int task = -1, retired = 0;
@@ -34,7 +43,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						int n = L.mem_n;
 						if (n > 0 && !L.overflow) {
 							base = atomicAdd(out_cursor, (unsigned long long)n);
-							if (base + n <= out_cap) for (int k = 0; k < n; ++k) out[base + k] = L.mem[k];
+							if (base + n <= out_cap) for (int k = 0; k < n; ++k) out[base + k] = L.mem[(size_t)k * 64];
 							else L.overflow = 1;
 						}
 						task_off[task] = (long long)base;
@@ -46,6 +55,19 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 					if (t >= (unsigned int)n_tasks) { retired = 1; break; }
 					task = (int)t;
 					L.q = reads + tasks[t].qoff; L.len = tasks[t].len; L.parent = tasks[t].parent;
+					L.qlds = nullptr;
+					if (L.len <= SEED_LDS_WORDS * 8) {
+						for (int w = 0; w * 8 < L.len; ++w) {
+							uint32_t pk = 0;
+							for (int b = 0; b < 8 && w * 8 + b < L.len; ++b) {
+								int v = L.q[w * 8 + b];
+								v = L.parent ? (v == 1 ? 3 : v) : (v == 2 ? 0 : v);
+								pk |= (uint32_t)v << (b << 2);
+							}
+							my_read[w << 6] = pk;
+						}
+						L.qlds = my_read;
+					}
 					seed_lane_begin(L);
 					if (L.len < P.min_seed_len || L.len + 1 > list_cap) { // too short to seed (memchain.c:279) / cannot fit
 						if (L.len + 1 > list_cap) L.overflow = 1;
@@ -53,14 +75,16 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						continue;
 					}
 				}
-				need = seed_advance(L, ix.fmi[L.parent], ix.fmi[!L.parent], P);
+				need = seed_advance(L, ix, P);
 				if (need) break;
 			}
 		}
 		if (__all(retired)) break;
 		if (need) {
-			const DevFmi &f = L.ext_which ? ix.fmi[!L.parent] : ix.fmi[L.parent];
-			DevIntv ok = dev_extend(f, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
+			const int which = L.ext_which ? !L.parent : L.parent;
+			DevFmi fx; fx.primary = dev_ix_primary(ix, which); fx.bwt = dev_ix_bwt(ix, which);
+			fx.L2[0] = fx.L2[1] = fx.L2[2] = fx.L2[3] = fx.L2[4] = dev_ix_L2(ix, which, L.ext_c);
+			DevIntv ok = dev_extend(fx, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
 			seed_post(L, ok, P);
 		}
 	}
@@ -76,7 +100,7 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 	long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t steps = 0, calls = 0;
 	for (long long i = gid; i < n; i += (long long)gridDim.x * blockDim.x) {
-		const DevFmi &f = ix.fmi[jobs[i].parent];
+		const DevFmi f = dev_fmi_pick(ix, jobs[i].parent);
 		uint64_t k = jobs[i].k, sa = 0;
 		while (k & f.sa_mask) {
 			// bwt_invPsi (bwt.c:54-60): symbol at k and its rank come from the same 64-byte block
@@ -86,7 +110,7 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 			dev_load_block(f.bwt, x, base, w);
 			int c = (w[(x & 127) >> 4] >> ((~x & 15) << 1)) & 3;
 			dev_block_count(w, (int)(x & 127), c4);
-			k = f.L2[c] + base[c] + c4[c];
+			k = dev_L2(f, c) + (c == 0 ? base[0] + c4[0] : c == 1 ? base[1] + c4[1] : c == 2 ? base[2] + c4[2] : base[3] + c4[3]);
 			++sa; ++steps;
 		}
 		pos[i] = sa + f.sa[k >> f.sa_shift];

@@ -24,10 +24,12 @@ struct SeedParams {           // copied from bsx_opt_t
 struct SeedLane {
 	// task
 	const uint8_t *q;         // raw read (nt4); converted on the fly
+	const uint32_t *qlds;     // optional: the converted read packed 8 bases per word at qlds[(i>>3)*64] (LDS, lane-interleaved)
 	int32_t len, parent;
 	// scratch
-	DevIntv *bufA, *bufB, *mem;
+	DevIntv *bufA, *bufB, *mem;   // element i of a list lives at base[i * stride]
 	int32_t list_cap, mem_cap;
+	int32_t stride;           // 64 on the GPU: the 64 lanes' i-th entries are contiguous (one 2 KB run), 1 on the host
 	// machine
 	int32_t state, ret_state;
 	int32_t pass_x;           // pass-1 / pass-3 scan position
@@ -41,10 +43,13 @@ struct SeedLane {
 	int32_t ret;              // return value of the current smem1 call
 	int32_t mem_n;
 	int32_t overflow;
+	uint64_t last_x2;         // interval size of the last survivor pushed in this row
 	DevIntv ik;
 	// pending extend request
 	int32_t ext_back, ext_c, ext_which;   // ext_which: 0 = own index, 1 = complementary index
 	DevIntv ext_in;
+	DevIntv next_in;          // prev[j+1], requested one step ahead so that its latency overlaps the FM gathers
+	int32_t have_next;
 	uint32_t n_slow, n_fast;
 };
 
@@ -53,6 +58,7 @@ enum { SD_DONE = 0, SD_P1, SD_SMEM_BEGIN, SD_FWD, SD_FWD_POST, SD_FWD_DONE, SD_B
 
 BSX_HD int seed_qbase(const SeedLane &L, int i)
 {
+	if (L.qlds) return (int)((L.qlds[(i >> 3) << 6] >> ((i & 7) << 2)) & 15u);
 	int b = L.q[i];
 	return L.parent ? (b == 1 ? 3 : b) : (b == 2 ? 0 : b);   // bseq_bsconvert, lib/aln/bwamem.c:161-178
 }
@@ -60,7 +66,7 @@ BSX_HD int seed_qbase(const SeedLane &L, int i)
 BSX_HD void seed_emit(SeedLane &L, const DevIntv &m, int beg, int end)
 {
 	if (end - beg < 0) return;
-	if (L.mem_n < L.mem_cap) { DevIntv o = m; o.info = (uint64_t)(uint32_t)beg << 32 | (uint32_t)end; L.mem[L.mem_n] = o; }
+	if (L.mem_n < L.mem_cap) { DevIntv o = m; o.info = (uint64_t)(uint32_t)beg << 32 | (uint32_t)end; L.mem[(size_t)L.mem_n * L.stride] = o; }
 	else L.overflow = 1;
 	++L.mem_n;
 }
@@ -71,13 +77,14 @@ BSX_HD void seed_lane_begin(SeedLane &L)
 	L.state = SD_P1;
 }
 
-BSX_HD void seed_set_intv(const DevFmi &f, const DevFmi &fc, int c, DevIntv &ik)   // bwt_set_intv, lib/aln/bwt.h:105
+BSX_HD void seed_set_intv(const DevIndex &ix, int parent, int c, DevIntv &ik)   // bwt_set_intv, lib/aln/bwt.h:105
 {
-	ik.x0 = f.L2[c] + 1; ik.x2 = f.L2[c + 1] - f.L2[c]; ik.x1 = fc.L2[3 - c] + 1; ik.info = 0;
+	const uint64_t l = dev_ix_L2(ix, parent, c);
+	ik.x0 = l + 1; ik.x2 = dev_ix_L2(ix, parent, c + 1) - l; ik.x1 = dev_ix_L2(ix, !parent, 3 - c) + 1; ik.info = 0;
 }
 
 // Run the machine until it needs a bwt_extend (returns 1, request in L.ext_*) or the task is done (0).
-BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const SeedParams &P)
+BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 {
 	for (;;) {
 		switch (L.state) {
@@ -92,7 +99,7 @@ BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const Se
 			{
 				int kk = L.k2++;
 				if (kk < L.mem_cap) {
-					DevIntv p = L.mem[kk];
+					DevIntv p = L.mem[(size_t)kk * L.stride];
 					int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
 					if (end - start < P.split_len || p.x2 > (uint64_t)P.split_width) break;
 					L.x0 = (start + end) >> 1; L.min_intv = (int)(p.x2 + 1); L.ret_state = SD_P2; L.state = SD_SMEM_BEGIN;
@@ -103,7 +110,7 @@ BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const Se
 			if (L.pass_x >= L.len) { L.state = SD_DONE; break; }
 			if (seed_qbase(L, L.pass_x) < 4) {
 				L.x0 = L.pass_x;
-				seed_set_intv(f, fc, seed_qbase(L, L.x0), L.ik);
+				seed_set_intv(ix, L.parent, seed_qbase(L, L.x0), L.ik);
 				L.i = L.x0 + 1; L.state = SD_S1;
 			} else ++L.pass_x;
 			break;
@@ -119,22 +126,22 @@ BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const Se
 			L.last_beg = -1;
 			if (seed_qbase(L, L.x0) > 3) { L.ret = L.x0 + 1; L.state = SD_SMEM_END; break; }
 			if (L.min_intv < 1) L.min_intv = 1;
-			seed_set_intv(f, fc, seed_qbase(L, L.x0), L.ik);
+			seed_set_intv(ix, L.parent, seed_qbase(L, L.x0), L.ik);
 			L.ik.info = (uint64_t)(L.x0 + 1);
 			L.i = L.x0 + 1; L.ncurr = 0;          // forward list goes into bufA, top-down
 			L.state = SD_FWD;
 			break;
 		case SD_FWD: // forward extension through the complementary index (bwt.c:324-339)
-			if (L.i >= L.len) { L.bufA[L.list_cap - 1 - L.ncurr] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE; break; }
+			if (L.i >= L.len) { L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE; break; }
 			{
 				int b = seed_qbase(L, L.i);
 				if (b < 4) { L.ext_in = L.ik; L.ext_back = 0; L.ext_c = 3 - b; L.ext_which = 1; L.state = SD_FWD_POST; return 1; }
-				L.bufA[L.list_cap - 1 - L.ncurr] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE;
+				L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE;
 			}
 			break;
 		case SD_FWD_DONE: // the list is already "reversed": smallest interval first (bwt.c:341-343)
 			L.prev_is_A = 1; L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
-			L.ret = (int)(uint32_t)L.bufA[L.prev_off].info;
+			L.ret = (int)(uint32_t)L.bufA[(size_t)L.prev_off * L.stride].info;
 			L.i = L.x0 - 1;
 			L.state = SD_BWD_ROW;
 			break;
@@ -144,7 +151,7 @@ BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const Se
 				int b = L.i < 0 ? 4 : seed_qbase(L, L.i);
 				L.c = b < 4 ? b : -1;
 			}
-			L.j = 0; L.ncurr = 0;
+			L.j = 0; L.ncurr = 0; L.have_next = 0;
 			L.state = SD_BWD_ELEM;
 			break;
 		case SD_BWD_ELEM:
@@ -155,8 +162,11 @@ BSX_HD int seed_advance(SeedLane &L, const DevFmi &f, const DevFmi &fc, const Se
 				break;
 			}
 			{
-				const DevIntv *prev = (L.prev_is_A ? L.bufA : L.bufB) + L.prev_off;
-				L.ext_in = prev[L.j];
+				const DevIntv *prev = (L.prev_is_A ? L.bufA : L.bufB);
+				if (L.have_next) { L.ext_in.x0 = L.next_in.x0; L.ext_in.x1 = L.next_in.x1; L.ext_in.x2 = L.next_in.x2; L.ext_in.info = L.next_in.info; }
+				else { const DevIntv v = prev[(size_t)(L.prev_off + L.j) * L.stride]; L.ext_in.x0 = v.x0; L.ext_in.x1 = v.x1; L.ext_in.x2 = v.x2; L.ext_in.info = v.info; }
+				L.have_next = L.j + 1 < L.nprev;
+				if (L.have_next) L.next_in = prev[(size_t)(L.prev_off + L.j + 1) * L.stride];
 				if (L.c >= 0) { L.ext_back = 1; L.ext_c = L.c; L.ext_which = 0; L.state = SD_BWD_POST; return 1; }
 				// c < 0: cannot extend -> candidate SMEM (bwt.c:350-355)
 				if (L.ncurr == 0 && (L.last_beg < 0 || L.i + 1 < L.last_beg)) {
@@ -182,7 +192,7 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 	switch (L.state) {
 	case SD_FWD_POST:
 		if (ok.x2 != L.ik.x2) { // interval size changed: record the old one (bwt.c:329-333)
-			if (L.ncurr < L.list_cap) L.bufA[L.list_cap - 1 - L.ncurr] = L.ik; else L.overflow = 1;
+			if (L.ncurr < L.list_cap) L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; else L.overflow = 1;
 			++L.ncurr;
 			if (ok.x2 < (uint64_t)L.min_intv) { L.state = SD_FWD_DONE; break; }
 		}
@@ -198,9 +208,10 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 			}
 		} else { // survives: keep unless it has the size of the previous survivor (bwt.c:357-360)
 			DevIntv *curr = L.prev_is_A ? L.bufB : L.bufA;
-			if (L.ncurr == 0 || ok.x2 != curr[L.ncurr - 1].x2) {
+			if (L.ncurr == 0 || ok.x2 != L.last_x2) {
 				DevIntv o = ok; o.info = L.ext_in.info;
-				curr[L.ncurr++] = o;
+				curr[(size_t)L.ncurr * L.stride] = o; ++L.ncurr;
+				L.last_x2 = ok.x2;
 			}
 		}
 		++L.j; L.state = SD_BWD_ELEM;

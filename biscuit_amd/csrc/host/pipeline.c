@@ -233,20 +233,27 @@ static int extension_rounds(chunk_t *C)
 	round_par_t P;
 	for (t = 0; t < C->n_tasks; ++t) if (C->tasks[t].chains.n) active[n_active++] = t; else C->tasks[t].done = 1;
 	P.C = C; P.active = active; P.owner = owner; P.res = res;
+	double ta = 0, tg = 0, tb = 0, tc = 0, tx;
 	while (n_active > 0) {
 		int i, nj = 0, na = 0;
+		tx = now_s();
 		bsx_parallel_for(C->nt, advance_worker, &P, n_active);
+		ta += now_s() - tx; tx = now_s();
 		for (i = 0; i < n_active; ++i) {
 			c2r_t *T = &C->tasks[active[i]];
 			if (T->has_job) { jobs[nj] = T->job; owner[nj++] = active[i]; active[na++] = active[i]; }
 			else if (!T->done) active[na++] = active[i];
 		}
 		n_active = na;
+		tg += now_s() - tx; tx = now_s();
 		if (nj == 0) break;
 		if ((rc = C->be->extend_batch(C->be->ctx, nj, jobs, res)) != BSX_OK) break;
+		tb += now_s() - tx; tx = now_s();
 		g_stats.n_ext_jobs += nj; ++g_stats.n_ext_rounds;
 		bsx_parallel_for(C->nt, consume_worker, &P, nj);
+		tc += now_s() - tx;
 	}
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::extend] advance %.3f gather %.3f batch %.3f consume %.3f (%ld jobs, %ld rounds)\n", ta, tg, tb, tc, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds);
 	free(jobs); free(res); free(owner); free(active);
 	return rc;
 }

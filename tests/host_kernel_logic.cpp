@@ -19,7 +19,8 @@ static DevFmi mk(const bsx_fmi_t *f)
 extern "C" int hostlogic_seed(const bsx_index_t *idx, const bsx_opt_t *opt, const uint8_t *reads, int64_t n, const bsx_seed_task_t *tasks,
                               int mem_cap, uint64_t *out, int64_t out_cap, int64_t *out_off, uint64_t ctr[2])
 {
-	DevFmi F[2] = { mk(&idx->fmi[0]), mk(&idx->fmi[1]) };
+	DevIndex IX; IX.fmi[0] = mk(&idx->fmi[0]); IX.fmi[1] = mk(&idx->fmi[1]); IX.pac = idx->pac; IX.l_pac = idx->ref.l_pac;
+	DevFmi *F = IX.fmi;
 	SeedParams P;
 	P.min_seed_len = opt->min_seed_len; P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
 	P.split_width = opt->split_width; P.max_mem_intv = (int)opt->max_mem_intv; P.start_width = (opt->flag & BSX_F_SELF_OVLP) ? 2 : 1;
@@ -29,12 +30,12 @@ extern "C" int hostlogic_seed(const bsx_index_t *idx, const bsx_opt_t *opt, cons
 		int len = tasks[t].len, list_cap = len + 2;
 		std::vector<DevIntv> A(list_cap), B(list_cap), M(mem_cap);
 		SeedLane L;
-		L.bufA = A.data(); L.bufB = B.data(); L.mem = M.data(); L.list_cap = list_cap; L.mem_cap = mem_cap;
+		L.bufA = A.data(); L.bufB = B.data(); L.mem = M.data(); L.list_cap = list_cap; L.mem_cap = mem_cap; L.stride = 1; L.qlds = nullptr;
 		L.q = reads + tasks[t].qoff; L.len = len; L.parent = tasks[t].parent;
 		seed_lane_begin(L);
 		out_off[t] = tot;
 		if (len >= P.min_seed_len) {
-			while (seed_advance(L, F[L.parent], F[!L.parent], P)) {
+			while (seed_advance(L, IX, P)) {
 				const DevFmi &f = L.ext_which ? F[!L.parent] : F[L.parent];
 				DevIntv ok = dev_extend(f, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
 				seed_post(L, ok, P);
