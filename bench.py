@@ -101,7 +101,7 @@ def main():
     for s in range(args.warmup):
         B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs(warmup)")
         n_processed += n_reads
-    for k in range(5):
+    for k in range(6):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
     phase_tot = {}
@@ -131,7 +131,7 @@ def main():
 
     # roofline of the dominant kernel (K1+K2 FM-index seeding): algorithmic bytes = 64 B per FM block touch
     ctr = dev.counters()
-    ktimes = [dev.kernel_time(k) for k in range(5)]
+    ktimes = [dev.kernel_time(k) for k in range(6)]
     seed_ms, seed_launches = ktimes[0]
     alg_bytes = 64.0 * (ctr[0] + ctr[1])
     roof = None
@@ -147,7 +147,7 @@ def main():
         cpu = cpu_baseline(L, B, idx, opt, args, ncores)
 
     if rank == 0:
-        names = ["seed", "sa", "extend", "sw", "global"]
+        names = ["seed", "sa", "extend", "sw", "global", "regions"]
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
@@ -158,7 +158,8 @@ def main():
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(5)},
+            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(6)},
+            "strand_searches_per_step": phase_tot.get("n_tasks", 0) // args.steps, "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // args.steps,
             "host_phase_s_per_step": {k: round(v / args.steps, 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "index_build_s": round(t_build, 1), "device": dev.name,

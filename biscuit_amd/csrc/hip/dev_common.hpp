@@ -32,6 +32,17 @@ struct DevIndex {
 	DevFmi fmi[2];         // [1] parent, [0] daughter
 	const uint8_t *pac;
 	int64_t l_pac;
+	const int64_t *ctg_off;    // n_seqs + 1 contig offsets on the forward strand (bntann1_t.offset; [n_seqs] = l_pac)
+	const uint8_t *ctg_alt;    // n_seqs: is_alt
+	int32_t n_seqs;
+};
+
+// the options the region kernel reads (mem_opt_t fields of the same name)
+struct RegParams {
+	int32_t a, w, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3;
+	int32_t min_seed_len, min_chain_weight, max_chain_gap, max_occ, bsstrand;
+	uint32_t max_chain_extend;
+	float mask_level, drop_ratio;
 };
 
 struct DevScoring {        // set by bsx_device_set_opt

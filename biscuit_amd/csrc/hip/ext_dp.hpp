@@ -1,0 +1,141 @@
+// ext_dp.hpp -- the wavefront-wide ksw_extend2 (lib/aln/ksw.c:380-479) as a device function shared by
+// k_extend (one job per wave) and k_regions (the chain->region state machine runs it inline).
+// H/E/qb point to this wave's LDS: H,E >= qlen+2 int32 each, qb >= qlen bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_common.hpp"
+#include "wave.hpp"
+
+template <int NC>
+__device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t &J,
+                                                int32_t *H, int32_t *E, uint8_t *qb, int lane)
+{
+	const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
+	const int8_t *mat = J.parent ? sc.ctmat : sc.gamat;
+	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = sc.zdrop;
+	// query into LDS; first row (ksw.c:395-397): H[0]=h0, H[j]=max(h0-oe_ins-(j-1)e_ins,0)
+	for (int j = lane; j < qlen; j += 64) qb[j] = reads[(long long)J.qoff + (long long)j * J.qdir];
+	for (int j = lane; j <= qlen; j += 64) {
+		int v = j == 0 ? h0 : h0 - oe_ins - (j - 1) * e_ins;
+		H[j] = v > 0 ? v : 0; E[j] = 0;
+	}
+	// band clamp (ksw.c:399-407)
+	int mx = 0;
+	for (int k = 0; k < 25; ++k) mx = mx > mat[k] ? mx : mat[k];
+	int w = J.w;
+	{
+		int max_ins = (int)((double)(qlen * mx + J.end_bonus - o_ins) / e_ins + 1.);
+		max_ins = max_ins > 1 ? max_ins : 1;
+		w = w < max_ins ? w : max_ins;
+		int max_del = (int)((double)(qlen * mx + J.end_bonus - o_del) / e_del + 1.);
+		max_del = max_del > 1 ? max_del : 1;
+		w = w < max_del ? w : max_del;
+	}
+	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	int beg = 0, end = qlen;
+	int tb_reg = 4;
+	WAVE_SYNC();
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
+		const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+		const int8_t s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1_init = 0;
+		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+		int m = 0, mj = -1, h1_last = h1_init;
+		if (beg < end) {
+			const int nch = (end - beg + 63) >> 6;
+			int M[NC], Ev[NC];
+			// pass A: read the whole row's inputs
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				M[c] = 0; Ev[c] = 0;
+				if (c < nch) {
+					const int j = beg + (c << 6) + lane;
+					if (j < end) {
+						const int hp = H[j], q = qb[j];
+						const int s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : q == 3 ? s3 : s4;
+						M[c] = hp ? hp + s : 0;
+						Ev[c] = E[j];
+					}
+				}
+			}
+			WAVE_SYNC();
+			// pass B: F by prefix scan, H, E', row maximum
+			int carry = NEG_BIG, lm = -1, lj = -1;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				if (c < nch) {
+					const int j = beg + (c << 6) + lane;
+					const bool act = j < end;
+					int tins = M[c] - oe_ins; tins = tins > 0 ? tins : 0;
+					const int g = act ? tins + j * e_ins : NEG_BIG;
+					const int incl = wave_scan_max_incl(g);
+					int excl = wave_prev(incl, NEG_BIG);
+					excl = excl > carry ? excl : carry;            // prefix max over all earlier columns
+					{ const int tot = __shfl(incl, 63); carry = carry > tot ? carry : tot; }
+					int f = j == beg ? 0 : excl - (j - 1) * e_ins;
+					if (f < 0) f = 0;
+					if (act) {
+						int h = M[c] > Ev[c] ? M[c] : Ev[c];
+						h = h > f ? h : f;
+						int tdel = M[c] - oe_del; tdel = tdel > 0 ? tdel : 0;
+						int e = Ev[c] - e_del; e = e > tdel ? e : tdel;
+						E[j] = e;
+						H[j + 1] = h;
+						if (j == beg) H[beg] = h1_init;
+						if (j == end - 1) E[end] = 0;
+						if (h >= lm) { lm = h; lj = j; }
+					}
+				}
+			}
+			WAVE_SYNC();
+			m = wave_max_i32(lm);
+			mj = wave_max_i32(lm == m ? lj : -1);
+			h1_last = H[end];
+		} else { // empty row: only the boundary cell is written (ksw.c:449)
+			if (lane == 0) { H[end] = h1_init; E[end] = 0; }
+			WAVE_SYNC();
+		}
+		const int jfin = beg < end ? end : beg;
+		if (jfin == qlen) { max_ie = gscore > h1_last ? max_ie : i; gscore = gscore > h1_last ? gscore : h1_last; }
+		if (m == 0) break;
+		if (m > max) {
+			max = m; max_i = i; max_j = mj;
+			int off = mj - i; off = off < 0 ? -off : off;
+			max_off = max_off > off ? max_off : off;
+		} else if (zdrop > 0) {
+			if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+			else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+		}
+		// shrink the band to the non-zero cells (ksw.c:466-469), reading back what was written:
+		// beg' = first j in [beg,end) with (H,E) != 0 (else end); end' = last such j in [beg',end] + 2
+		{
+			const int nchk = (end - beg + 1 + 63) >> 6;   // cells beg..end inclusive
+			int nb = end, last;
+			for (int c = 0; c < nchk; ++c) {
+				const int j = beg + (c << 6) + lane;
+				const bool nz = j < end && (H[j] != 0 || E[j] != 0);
+				const unsigned long long b = __ballot(nz);
+				if (b) { nb = beg + (c << 6) + __builtin_ctzll(b); break; }
+			}
+			last = nb - 1;
+			for (int c = nchk - 1; c >= 0; --c) {
+				const int j = beg + (c << 6) + lane;
+				const bool nz = j <= end && j >= nb && (H[j] != 0 || E[j] != 0);
+				const unsigned long long b = __ballot(nz);
+				if (b) { last = beg + (c << 6) + 63 - __builtin_clzll(b); break; }
+			}
+			beg = nb;
+			end = last + 2 < qlen ? last + 2 : qlen;
+		}
+		WAVE_SYNC();
+	}
+	bsx_ext_res_t r;
+	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+	WAVE_SYNC();
+	return r;
+}

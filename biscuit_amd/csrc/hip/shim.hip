@@ -47,16 +47,16 @@ struct bsx_device {
 	char name[256];
 	int n_cu = 0;
 	hipStream_t st = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
 	DevIndex ix; bool has_index = false;
-	DevBuf bwt[2], sa[2], pac;
+	DevBuf bwt[2], sa[2], pac, ctg;
 	DevScoring sc;
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor
 	HostBuf hstage;        // pinned staging for bulk results
-	double k_ms[5] = {0, 0, 0, 0, 0};
-	int64_t k_launch[5] = {0, 0, 0, 0, 0};
+	double k_ms[6] = {0, 0, 0, 0, 0, 0};
+	int64_t k_launch[6] = {0, 0, 0, 0, 0, 0};
 };
 
 static inline unsigned long long *dev_counters(bsx_device *d) { return (unsigned long long*)d->small.p; }
@@ -77,6 +77,7 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 	HIPCHK(hipStreamCreate(&d->st));
 	HIPCHK(hipEventCreate(&d->ev0));
 	HIPCHK(hipEventCreate(&d->ev1));
+	HIPCHK(hipEventCreate(&d->ev2));
 	if (d->small.reserve(64) != BSX_OK) return BSX_E_NOMEM;
 	HIPCHK(hipMemset(d->small.p, 0, 64));
 	memset(&d->ix, 0, sizeof(d->ix));
@@ -92,8 +93,10 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
 	d->pac.release(); d->reads.release(); d->jobs.release(); d->res.release(); d->scratch.release();
 	d->out.release(); d->aux.release(); d->pool.release(); d->small.release(); d->hstage.release();
+	d->ctg.release(); d->regs.release(); d->regmeta.release();
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
+	if (d->ev2) (void)hipEventDestroy(d->ev2);
 	if (d->st) (void)hipStreamDestroy(d->st);
 	delete d;
 }
@@ -123,6 +126,17 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 	if ((rc = d->pac.reserve(npac + 16)) != BSX_OK) return rc;
 	HIPCHK(hipMemcpy(d->pac.p, idx->pac, npac, hipMemcpyHostToDevice));
 	d->ix.pac = (const uint8_t*)d->pac.p; d->ix.l_pac = idx->ref.l_pac;
+	{ // contig table: offsets (n_seqs + 1, the last one = l_pac) then the is_alt bytes
+		const int ns = idx->ref.n_seqs;
+		std::vector<int64_t> off((size_t)ns + 1);
+		std::vector<uint8_t> alt((size_t)ns + 8, 0);
+		for (int i = 0; i < ns; ++i) { off[i] = idx->ref.anns[i].offset; alt[i] = idx->ref.anns[i].is_alt ? 1 : 0; }
+		off[ns] = idx->ref.l_pac;
+		if ((rc = d->ctg.reserve(((size_t)ns + 1) * 8 + (size_t)ns + 8)) != BSX_OK) return rc;
+		HIPCHK(hipMemcpy(d->ctg.p, off.data(), ((size_t)ns + 1) * 8, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy((char*)d->ctg.p + ((size_t)ns + 1) * 8, alt.data(), (size_t)ns, hipMemcpyHostToDevice));
+		d->ix.ctg_off = (const int64_t*)d->ctg.p; d->ix.ctg_alt = (const uint8_t*)d->ctg.p + ((size_t)ns + 1) * 8; d->ix.n_seqs = ns;
+	}
 	d->has_index = true;
 	return BSX_OK;
 }
@@ -169,7 +183,7 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 
 extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
 {
-	if (!d || k < 0 || k >= 5) return BSX_E_ARG;
+	if (!d || k < 0 || k >= 6) return BSX_E_ARG;
 	if (total_ms) *total_ms = d->k_ms[k];
 	if (launches) *launches = d->k_launch[k];
 	if (reset) { d->k_ms[k] = 0; d->k_launch[k] = 0; }
@@ -291,6 +305,75 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 	A.off = h_off.data(); A.cnt = h_n.data(); A.dense = h_dense; A.redo_of = redo_of.empty() ? nullptr : redo_of.data(); A.redo = &redo_results;
 	A.out = *out; A.out_off = out_off;
 	bsx_parallel_for(bsx_host_threads(opt), seed_asm_worker, &A, (long)n);
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1+K2 -> K3 + chaining + chain filter + chain-to-region on the device; the interval lists never leave HBM
+// ------------------------------------------------------------------------------------------
+extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                                         bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (n == 0) return BSX_OK;
+	if (n > 0x7fffffff) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc, max_len = 0;
+	for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, tasks[i].len);
+	SeedParams P;
+	P.min_seed_len = opt->min_seed_len;
+	P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
+	P.split_width = opt->split_width;
+	P.max_mem_intv = (int)opt->max_mem_intv;
+	P.start_width = (opt->flag & BSX_F_SELF_OVLP) ? 2 : 1;
+	RegParams R;
+	R.a = opt->a; R.w = opt->w; R.o_del = opt->o_del; R.e_del = opt->e_del; R.o_ins = opt->o_ins; R.e_ins = opt->e_ins;
+	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
+	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
+	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
+
+	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
+	const unsigned long long dense_cap = (unsigned long long)n * 24 + 4096, regs_cap = (unsigned long long)n * 2 + 4096;
+	int waves = (int)std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * 16);
+	int grid = (waves + 3) / 4;
+	size_t lanes = (size_t)grid * 256;
+	if ((rc = d->scratch.reserve(lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv))) != BSX_OK) return rc;
+	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
+	if ((rc = d->out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
+	if ((rc = d->aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	if ((rc = d->regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
+	if ((rc = d->regmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	long long *d_off = (long long*)d->aux.p; int *d_n = (int*)((char*)d->aux.p + (size_t)n * 8);
+	long long *r_off = (long long*)d->regmeta.p; int *r_n = (int*)((char*)d->regmeta.p + (size_t)n * 8);
+	unsigned long long *ctr = dev_counters(d);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7] region task cursor
+	HIPCHK(hipMemcpyAsync(d->jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, d->st));
+	HIPCHK(hipMemsetAsync(ctr + 4, 0, 32, d->st));
+	HIPCHK(hipEventRecord(d->ev0, d->st));
+	launch_seed(d->st, grid, d->ix, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n, P,
+	            (DevIntv*)d->scratch.p, list_cap, mem_cap, (DevIntv*)d->out.p, dense_cap, ctr + 4, d_off, d_n,
+	            (unsigned int*)(ctr + 5), ctr);
+	HIPCHK(hipEventRecord(d->ev1, d->st));
+	const int rgrid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)d->n_cu * 5);
+	launch_regions(d->st, rgrid, d->ix, d->sc, R, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n,
+	               (const DevIntv*)d->out.p, d_off, d_n, (bsx_region_t*)d->regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7));
+	HIPCHK(hipEventRecord(d->ev2, d->st));
+	{
+		float ms0 = 0, ms1 = 0;
+		HIPCHK(hipEventSynchronize(d->ev2));
+		HIPCHK(hipEventElapsedTime(&ms0, d->ev0, d->ev1));
+		HIPCHK(hipEventElapsedTime(&ms1, d->ev1, d->ev2));
+		d->k_ms[0] += ms0; d->k_launch[0] += 1; d->k_ms[5] += ms1; d->k_launch[5] += 1;
+		HIPCHK(hipGetLastError());
+	}
+	unsigned long long used = 0;
+	std::vector<long long> h_off((size_t)n);
+	HIPCHK(hipMemcpy(h_off.data(), r_off, (size_t)n * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(out_n, r_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&used, ctr + 6, 8, hipMemcpyDeviceToHost));
+	if (used > regs_cap) used = regs_cap;
+	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
+	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
+	if (used) HIPCHK(hipMemcpy(*out, d->regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
 
@@ -476,6 +559,7 @@ static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t
 static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return bsx_sa_batch((bsx_device_t*)c, n, j, p); }
 static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return bsx_extend_batch((bsx_device_t*)c, n, j, r); }
 static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return bsx_sw_batch((bsx_device_t*)c, n, j, r); }
+static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return bsx_regions_batch((bsx_device_t*)c, o, n, t, out, cap, off, cnt); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return bsx_global_batch((bsx_device_t*)c, n, j, r, pool, len); }
 
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out)
@@ -484,5 +568,6 @@ extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out)
 	out->ctx = dev; out->name = "hip-gfx950";
 	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
 	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb;
+	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
 	return BSX_OK;
 }

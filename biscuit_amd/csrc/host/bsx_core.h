@@ -149,6 +149,9 @@ typedef struct bsx_backend {
 	int (*sw_batch)(void *ctx, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 	int (*global_batch)(void *ctx, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
 	                    uint32_t *cigar_pool, size_t cigar_pool_len);
+	/* optional (may be NULL): seeding through regions in one device pass, see bsx_regions_batch */
+	int (*regions_batch)(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+	                     bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
 } bsx_backend_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;
@@ -161,8 +164,8 @@ int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);
 
 /* per-phase wall-clock accounting of the last bsx_process_seqs* call (seconds) */
 typedef struct {
-	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total, t_prep, t_cleanup;
-	int64_t n_tasks, n_intv, n_sa, n_ext_jobs, n_ext_rounds, n_sw_jobs, n_glb_jobs;
+	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total, t_prep, t_cleanup, t_regions;
+	int64_t n_tasks, n_intv, n_sa, n_ext_jobs, n_ext_rounds, n_sw_jobs, n_glb_jobs, n_host_tasks;
 } bsx_phase_stats_t;
 BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out);
 

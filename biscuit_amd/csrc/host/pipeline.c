@@ -85,6 +85,9 @@ typedef struct {
 	/* tasks */
 	int n_tasks;
 	c2r_t *tasks;
+	/* strand searches the host chains itself (all of them without a device regions pass): h -> task */
+	int n_host, *hmap;
+	bsx_region_t *dregs; int64_t dregs_cap, *dreg_off; int32_t *dreg_n;
 	int *read_task0;             /* first task of each read; read_task0[n] = n_tasks */
 	bsx_intv_t *intv; int64_t intv_cap; int64_t *intv_off;
 	uint64_t *pos; int64_t *ipos_off;   /* per interval: its occurrences' positions */
@@ -97,10 +100,10 @@ typedef struct {
 } chunk_t;
 
 /* ------------------------------------------------------------------ chaining */
-static void chain_worker(void *data, long t, int tid)
+static void chain_worker(void *data, long t, int tid)   /* t indexes the host-side task list */
 {
 	chunk_t *C = (chunk_t*)data;
-	c2r_t *T = &C->tasks[t];
+	c2r_t *T = &C->tasks[C->hmap[t]];
 	const bsx_intv_t *iv = C->intv + C->intv_off[t];
 	int n_iv = (int)(C->intv_off[t + 1] - C->intv_off[t]);
 	int rc;
@@ -673,7 +676,7 @@ static void sa_jobs_worker(void *data, long t, int tid)
 	for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k)
 		for (c = 0; c < C->ipos_off[k + 1] - C->ipos_off[k]; ++c) {
 			bsx_sa_job_t *j = &C->sa_jobs[C->ipos_off[k] + c];
-			j->k = C->intv[k].x[0] + (uint64_t)c; j->parent = C->tasks[t].parent; j->pad = 0;
+			j->k = C->intv[k].x[0] + (uint64_t)c; j->parent = C->tasks[C->hmap[t]].parent; j->pad = 0;
 		}
 }
 
@@ -682,8 +685,25 @@ static void release_worker(void *data, long t, int tid)
 	chunk_t *C = (chunk_t*)data;
 	(void)tid;
 	bsx_c2r_release(&C->tasks[t]); bsx_cvec_free(C->tasks[t].regs);
-	if (C->xpos) free(C->xpos[t]);
-	if (C->xpos_off) free(C->xpos_off[t]);
+}
+
+/* regions the device produced -> the task's region list (every other mem_alnreg_t field is still zero here) */
+static void adopt_worker(void *data, long t, int tid)
+{
+	chunk_t *C = (chunk_t*)data;
+	c2r_t *T = &C->tasks[t];
+	int k, n = C->dreg_n[t];
+	(void)tid;
+	if (n < 0) return;
+	T->done = 1;
+	for (k = 0; k < n; ++k) {
+		const bsx_region_t *d = &C->dregs[C->dreg_off[t] + k];
+		reg_t r;
+		memset(&r, 0, sizeof(r));
+		r.rb = d->rb; r.re = d->re; r.qb = d->qb; r.qe = d->qe; r.rid = d->rid; r.score = d->score; r.truesc = d->truesc;
+		r.w = d->w; r.seedcov = d->seedcov; r.seedlen0 = d->seedlen0; r.frac_rep = d->frac_rep; r.bss = d->bss; r.parent = d->parent;
+		bsx_cvec_push(T->regs, r);
+	}
 }
 static void release_regs_worker(void *data, long i, int tid) { (void)tid; free(((chunk_t*)data)->regs[i].a); }
 
@@ -738,23 +758,46 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	CHECK(be->set_reads(be->ctx, buf, tot));
 	g_stats.t_prep = now_s() - t0;
 
+	/* seeding through regions in one device pass where the backend has it; what it declines (and everything,
+	 * on a backend without it) goes through the batch kernels and the host chaining below */
+	t0 = now_s();
+	C.hmap = (int*)malloc(sizeof(int) * ((size_t)C.n_tasks + 1));
+	if (be->regions_batch) {
+		C.dreg_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
+		C.dreg_n = (int32_t*)malloc(sizeof(int32_t) * ((size_t)C.n_tasks + 1));
+		CHECK(be->regions_batch(be->ctx, opt, C.n_tasks, stasks, &C.dregs, &C.dregs_cap, C.dreg_off, C.dreg_n));
+		bsx_parallel_for(nt, adopt_worker, &C, C.n_tasks);
+		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] < 0) { stasks[C.n_host] = stasks[t]; C.hmap[C.n_host++] = t; }
+		if (getenv("BSX_PHASES")) {
+			long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (t = 0; t < C.n_tasks; ++t) ++h[C.dreg_n[t] >= 0 ? 0 : (-C.dreg_n[t] < 8 ? -C.dreg_n[t] : 8)];
+			fprintf(stderr, "[M::regions] on device %ld | declined: seeds/length %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
+			        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+		}
+	} else {
+		for (t = 0; t < C.n_tasks; ++t) C.hmap[t] = t;
+		C.n_host = C.n_tasks;
+	}
+	g_stats.t_regions = now_s() - t0; g_stats.n_host_tasks = C.n_host;
+
 	/* K1+K2 */
 	t0 = now_s();
-	C.intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
-	CHECK(be->seed_batch(be->ctx, opt, C.n_tasks, stasks, &C.intv, &C.intv_cap, C.intv_off));
-	g_stats.t_seed = now_s() - t0; g_stats.n_intv = C.intv_off[C.n_tasks];
+	C.intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_host + 1));
+	C.intv_off[0] = 0;
+	CHECK(be->seed_batch(be->ctx, opt, C.n_host, stasks, &C.intv, &C.intv_cap, C.intv_off));
+	g_stats.t_seed = now_s() - t0; g_stats.n_intv = C.intv_off[C.n_host];
 
 	/* K3: the first min(occ, max_occ) occurrences of every interval */
 	t0 = now_s();
 	{
-		int64_t n_iv = C.intv_off[C.n_tasks], k, nj = 0;
+		int64_t n_iv = C.intv_off[C.n_host], k, nj = 0;
 		bsx_sa_job_t *sj;
 		C.ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
 		for (k = 0; k < n_iv; ++k) { C.ipos_off[k] = nj; nj += (int64_t)(C.intv[k].x[2] < opt->max_occ ? C.intv[k].x[2] : opt->max_occ); }
 		C.ipos_off[n_iv] = nj;
 		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
 		C.sa_jobs = sj;
-		bsx_parallel_for(nt, sa_jobs_worker, &C, C.n_tasks);
+		bsx_parallel_for(nt, sa_jobs_worker, &C, C.n_host);
 		C.pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
 		rc = be->sa_batch(be->ctx, nj, sj, C.pos);
 		free(sj);
@@ -765,17 +808,17 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 
 	/* chaining (host); intervals that must be walked past max_occ get their remaining occurrences looked up */
 	t0 = now_s();
-	C.need_more = (int*)calloc((size_t)C.n_tasks + 1, sizeof(int));
-	C.xpos = (uint64_t**)calloc((size_t)C.n_tasks + 1, sizeof(uint64_t*));
-	C.xpos_off = (int64_t**)calloc((size_t)C.n_tasks + 1, sizeof(int64_t*));
+	C.need_more = (int*)calloc((size_t)C.n_host + 1, sizeof(int));
+	C.xpos = (uint64_t**)calloc((size_t)C.n_host + 1, sizeof(uint64_t*));
+	C.xpos_off = (int64_t**)calloc((size_t)C.n_host + 1, sizeof(int64_t*));
 	C.trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
 	for (i = 0; i < nt; ++i) C.trees[i] = bsx_bt_new();
 	for (;;) {
 		int any = 0;
 		double tc0 = now_s();
-		bsx_parallel_for(nt, chain_worker, &C, C.n_tasks);
+		bsx_parallel_for(nt, chain_worker, &C, C.n_host);
 		if (getenv("BSX_PHASES")) fprintf(stderr, "[M::chain] parallel pass %.3f s (%d threads)\n", now_s() - tc0, nt);
-		for (t = 0; t < C.n_tasks; ++t) {
+		for (t = 0; t < C.n_host; ++t) {
 			int n_iv, k, want;
 			int64_t nj, c;
 			bsx_sa_job_t *sj;
@@ -799,7 +842,7 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 			for (k = 0; k < n_iv; ++k)
 				for (c = 0; c < C.xpos_off[t][k + 1] - C.xpos_off[t][k]; ++c) {
 					bsx_sa_job_t *j = &sj[C.xpos_off[t][k] + c];
-					j->k = C.intv[C.intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C.tasks[t].parent; j->pad = 0;
+					j->k = C.intv[C.intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C.tasks[C.hmap[t]].parent; j->pad = 0;
 				}
 			free(C.xpos[t]);
 			C.xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
@@ -842,7 +885,9 @@ done:
 	if (C.regs) { bsx_parallel_for(nt, release_regs_worker, &C, n); free(C.regs); }
 	if (C.trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C.trees[i]); free(C.trees); }
 	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
+	for (t = 0; t < C.n_host; ++t) { if (C.xpos) free(C.xpos[t]); if (C.xpos_off) free(C.xpos_off[t]); }
 	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
+	free(C.hmap); free(C.dregs); free(C.dreg_off); free(C.dreg_n);
 	bsx_arenas_end();
 	g_stats.t_cleanup = now_s() - t0;
 	g_stats.t_total = now_s() - t_all;
@@ -850,8 +895,8 @@ done:
 	{
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", n, g_stats.t_total, be->name ? be->name : "?");
 		if (getenv("BSX_PHASES"))
-			fprintf(stderr, "[M::phases] seed %.3f sa %.3f chain %.3f extend %.3f (%ld jobs, %ld rounds) merge %.3f pestat %.3f matesw %.3f primary %.3f cigar %.3f sam %.3f | tasks %ld intv %ld sa %ld sw %ld glb %ld\n",
-				g_stats.t_seed, g_stats.t_sa, g_stats.t_chain, g_stats.t_extend, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds, g_stats.t_merge, g_stats.t_pestat,
+			fprintf(stderr, "[M::phases] regions %.3f (host tasks %ld) seed %.3f sa %.3f chain %.3f extend %.3f (%ld jobs, %ld rounds) merge %.3f pestat %.3f matesw %.3f primary %.3f cigar %.3f sam %.3f | tasks %ld intv %ld sa %ld sw %ld glb %ld\n",
+				g_stats.t_regions, (long)g_stats.n_host_tasks, g_stats.t_seed, g_stats.t_sa, g_stats.t_chain, g_stats.t_extend, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds, g_stats.t_merge, g_stats.t_pestat,
 				g_stats.t_matesw, g_stats.t_primary, g_stats.t_cigar, g_stats.t_sam, (long)g_stats.n_tasks, (long)g_stats.n_intv, (long)g_stats.n_sa, (long)g_stats.n_sw_jobs, (long)g_stats.n_glb_jobs);
 	}
 	return rc;

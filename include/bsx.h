@@ -152,6 +152,15 @@ typedef struct bsx_ext_res {
 	int32_t score, qle, tle, gtle, gscore, max_off;
 } bsx_ext_res_t;
 
+/* One alignment region as mem_chain2region leaves it (the fields of mem_alnreg_t, lib/aln/mem_alnreg.h:34-66,
+ * that lib/aln/memchain.c:822-869 sets; everything else is zero at that point). */
+typedef struct bsx_region {
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0;
+	float   frac_rep;
+	uint8_t bss, parent, pad[2];
+} bsx_region_t;
+
 /* local SW with 2nd-best + start recovery: ksw_align2 (lib/aln/ksw.c:343-365) */
 typedef struct bsx_sw_job {
 	int64_t  tpos;
@@ -230,6 +239,13 @@ int bsx_seed_batch(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n, const bsx
 int bsx_sa_batch(bsx_device_t *dev, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos);
 /* K4 */
 int bsx_extend_batch(bsx_device_t *dev, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res);
+/* K1+K2+K3 and the chaining/extension logic between them in one pass (mem_chain + mem_chain_flt +
+ * mem_chain2region, lib/aln/memchain.c:268-488,742-904; called per strand search from lib/aln/bwamem.c:352-372):
+ * regions of task i = (*out)[out_off[i] .. out_off[i] + out_n[i]).  out_n[i] < 0 means the device declined the task
+ * (more occurrences/chains/regions than its on-chip tables hold, a long read, or tied chain positions): the caller
+ * runs that task through bsx_seed_batch/bsx_sa_batch/bsx_extend_batch and its own chaining instead. */
+int bsx_regions_batch(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                      bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
 /* K5 */
 int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 /* K6 */
@@ -241,7 +257,7 @@ int bsx_global_batch(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bs
  * c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
 /* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since
- * the last reset: k = 0 seed, 1 sa, 2 extend, 3 sw, 4 global */
+ * the last reset: k = 0 seed, 1 sa, 2 extend, 3 sw, 4 global, 5 regions */
 int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *launches, int reset);
 
 /* ------------------------------------------------------------------------------------------

@@ -662,6 +662,7 @@ BSX_API void *oracle_port_new(const bsx_index_t *idx, int n_threads)
 BSX_API void oracle_port_free(void *c) { free(c); }
 BSX_API void oracle_port_backend(void *c, bsx_backend_t *be)
 {
+	memset(be, 0, sizeof(*be));   /* no regions_batch: the CPU checker always runs the host chaining path */
 	be->ctx = c; be->name = "oracle-port-cpu";
 	be->set_opt = port_set_opt; be->set_reads = port_set_reads;
 	be->seed_batch = port_seed_batch; be->sa_batch = port_sa_batch; be->extend_batch = port_extend_batch;
