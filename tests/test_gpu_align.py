@@ -13,10 +13,13 @@ HIP = os.path.join(ROOT, "biscuit_amd", "biscuit_align")
 CPU = os.path.join(ROOT, "oracle", "oracle_align")
 
 
-def run(exe, args, cwd):
-    p = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+def run(exe, args, cwd, env=None, want_stderr=False):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=e)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    return b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
+    sam = b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
+    return (sam, p.stderr.decode()) if want_stderr else sam
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +51,9 @@ CASES = [
     ("se150_clip", ["-@", "4", "-J", "AGATCGGAAGAGC", "-z", "10", "-5", "2", "-3", "1", "g", "b1.fq"]),
     ("se150_scoring", ["-@", "4", "-A", "2", "-B", "3", "-O", "5,7", "-E", "2,1", "-L", "4,6", "-T", "40", "-k", "17", "-w", "60", "g", "b1.fq"]),
     ("long_1kb", ["-@", "4", "g", "long.fq"]),
+    # options the device chaining/extension pass reads: occurrence cap, chain filter knobs, strand restriction, band, clip penalties
+    ("pe150_chain_knobs", ["-@", "4", "-c", "12", "-D", "0.3", "-W", "25", "-m", "30", "-G", "4000", "g", "b1.fq", "b2.fq"]),
+    ("se150_bsstrand_band", ["-@", "4", "-f", "1", "-w", "12", "-L", "0,9", "-r", "1.2", "-y", "30", "g", "b1.fq"]),
 ]
 
 
@@ -61,3 +67,77 @@ def test_sam_identical(data, name, args):
         for i, (a, b) in enumerate(zip(gl, wl)):
             assert a == b, "first difference at line %d:\nHIP: %s\nCPU: %s" % (i, a[:600], b[:600])
         assert len(gl) == len(wl)
+
+
+def _on_device(stderr):
+    import re
+    m = re.findall(r"\[M::regions\] on device (\d+) \| declined: (.*)", stderr)
+    assert m, stderr[-1500:]
+    on = sum(int(a) for a, _ in m)
+    off = sum(int(x) for _, rest in m for x in re.findall(r" (\d+)", rest))
+    return on, off
+
+
+@pytest.mark.parametrize("name,args", [CASES[1], CASES[3], CASES[9], CASES[11], CASES[12]], ids=lambda c: c if isinstance(c, str) else "")
+def test_device_regions_equal_host_chaining(data, name, args):
+    """k_regions (SA lookup + chaining + chain filter + chain-to-region on the device) against the same
+    strand searches chained on the host through the batch kernels: identical SAM, and the device pass
+    really took the bulk of the work."""
+    dev, err = run(HIP, args, data, env={"BSX_PHASES": "1"}, want_stderr=True)
+    host = run(HIP, args, data, env={"BSX_HOST_CHAIN": "1"})
+    assert dev == host
+    on, off = _on_device(err)
+    assert on > off, (on, off)
+
+
+def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
+    """Same A/B at the bench's workload shape (synthetic genome with repeat families, 2x150 pairs, -b 0):
+    60k pairs through bsx_process_seqs with the device regions pass and with host chaining; every read's
+    SAM text must be identical.  This is the data where chains per strand search run into the dozens."""
+    import ctypes as C
+    import zlib
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    L = B.lib()
+    d = str(tmp_path)
+    B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(8000000), C.c_uint64(77), 5, C.c_double(0.08)), "sim_genome")
+    B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "index_build")
+    idx = Index(d + "/g")
+    dev = Device(0)
+    dev.upload_index(idx)
+    opt = default_opt()
+    opt.n_threads = 4
+    opt.flag |= 0x10 | 0x2
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    n_pairs = 60000
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 5, 200, 500, 0.01, 0.2, C.byref(p)), "sim_pairs")
+    reads = C.cast(p, C.POINTER(B.Read))
+
+    def crc():
+        c = 0
+        for i in range(2 * n_pairs):
+            c = zlib.crc32(C.string_at(reads[i].sam), c)
+        return c
+
+    try:
+        os.environ.pop("BSX_HOST_CHAIN", None)
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
+        ps = B.PhaseStats()
+        L.bsx_last_phase_stats(C.byref(ps))
+        assert ps.n_host_tasks * 5 < ps.n_tasks, (ps.n_host_tasks, ps.n_tasks)
+        a = crc()
+        L.bsx_sim_reset_reads(p, 2 * n_pairs)
+        os.environ["BSX_HOST_CHAIN"] = "1"
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
+        L.bsx_last_phase_stats(C.byref(ps))
+        assert ps.n_host_tasks == ps.n_tasks
+        assert crc() == a
+    finally:
+        os.environ.pop("BSX_HOST_CHAIN", None)
+        L.bsx_sim_free_reads(p, 2 * n_pairs)
+        dev.close()
+        idx.close()
