@@ -15,8 +15,10 @@ void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const u
                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc);
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                    long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb);
-// K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions
-void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+// K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
+// Two launches: LDS-resident tables, then the strand searches that did not fit over HBM slabs (big_grid * 4 of regions_big_slab_bytes()).
+size_t regions_big_slab_bytes();
+void launch_regions(hipStream_t st, int grid, int big_grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *task_cursor);
+                    unsigned int *cursors, int *retry_list, void *slabs);

@@ -52,7 +52,7 @@ struct bsx_device {
 	DevBuf bwt[2], sa[2], pac, ctg;
 	DevScoring sc;
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor
 	HostBuf hstage;        // pinned staging for bulk results
 	double k_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -78,8 +78,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 	HIPCHK(hipEventCreate(&d->ev0));
 	HIPCHK(hipEventCreate(&d->ev1));
 	HIPCHK(hipEventCreate(&d->ev2));
-	if (d->small.reserve(64) != BSX_OK) return BSX_E_NOMEM;
-	HIPCHK(hipMemset(d->small.p, 0, 64));
+	if (d->small.reserve(128) != BSX_OK) return BSX_E_NOMEM;
+	HIPCHK(hipMemset(d->small.p, 0, 128));
 	memset(&d->ix, 0, sizeof(d->ix));
 	memset(&d->sc, 0, sizeof(d->sc));
 	*out = d;
@@ -93,7 +93,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
 	d->pac.release(); d->reads.release(); d->jobs.release(); d->res.release(); d->scratch.release();
 	d->out.release(); d->aux.release(); d->pool.release(); d->small.release(); d->hstage.release();
-	d->ctg.release(); d->regs.release(); d->regmeta.release();
+	d->ctg.release(); d->regs.release(); d->regmeta.release(); d->slabs.release();
 	if (d->ev0) (void)hipEventDestroy(d->ev0);
 	if (d->ev1) (void)hipEventDestroy(d->ev1);
 	if (d->ev2) (void)hipEventDestroy(d->ev2);
@@ -312,7 +312,8 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 // K1+K2 -> K3 + chaining + chain filter + chain-to-region on the device; the interval lists never leave HBM
 // ------------------------------------------------------------------------------------------
 extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
-                                         bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n)
+                                         bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
+                                         bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
 	if (n == 0) return BSX_OK;
@@ -342,20 +343,23 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 	if ((rc = d->out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = d->aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = d->regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = d->regmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	if ((rc = d->regmeta.reserve((size_t)n * 16 + 64)) != BSX_OK) return rc;
+	const int big_grid = d->n_cu * 2;
+	if ((rc = d->slabs.reserve((size_t)big_grid * 4 * regions_big_slab_bytes())) != BSX_OK) return rc;
 	long long *d_off = (long long*)d->aux.p; int *d_n = (int*)((char*)d->aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)d->regmeta.p; int *r_n = (int*)((char*)d->regmeta.p + (size_t)n * 8);
-	unsigned long long *ctr = dev_counters(d);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7] region task cursor
+	int *retry = (int*)((char*)d->regmeta.p + (size_t)n * 12);
+	unsigned long long *ctr = dev_counters(d);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7..8] region task/retry cursors (3 x u32)
 	HIPCHK(hipMemcpyAsync(d->jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, d->st));
-	HIPCHK(hipMemsetAsync(ctr + 4, 0, 32, d->st));
+	HIPCHK(hipMemsetAsync(ctr + 4, 0, 48, d->st));
 	HIPCHK(hipEventRecord(d->ev0, d->st));
 	launch_seed(d->st, grid, d->ix, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n, P,
 	            (DevIntv*)d->scratch.p, list_cap, mem_cap, (DevIntv*)d->out.p, dense_cap, ctr + 4, d_off, d_n,
 	            (unsigned int*)(ctr + 5), ctr);
 	HIPCHK(hipEventRecord(d->ev1, d->st));
-	const int rgrid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)d->n_cu * 5);
-	launch_regions(d->st, rgrid, d->ix, d->sc, R, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n,
-	               (const DevIntv*)d->out.p, d_off, d_n, (bsx_region_t*)d->regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7));
+	const int rgrid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)d->n_cu * 3);
+	launch_regions(d->st, rgrid, big_grid, d->ix, d->sc, R, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n,
+	               (const DevIntv*)d->out.p, d_off, d_n, (bsx_region_t*)d->regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7), retry, d->slabs.p);
 	HIPCHK(hipEventRecord(d->ev2, d->st));
 	{
 		float ms0 = 0, ms1 = 0;
@@ -374,6 +378,37 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
 	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	if (used) HIPCHK(hipMemcpy(*out, d->regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
+
+	// declined tasks: hand their interval lists back (ordered by info, as bsx_seed_batch returns them)
+	std::vector<int64_t> decl;
+	for (int64_t i = 0; i < n; ++i) if (out_n[i] < -1) decl.push_back(i);
+	decl_off[0] = 0;
+	if (!decl.empty()) {
+		std::vector<long long> s_off((size_t)n); std::vector<int> s_n((size_t)n);
+		HIPCHK(hipMemcpy(s_off.data(), d_off, (size_t)n * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(s_n.data(), d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+		int64_t tot = 0;
+		for (size_t j = 0; j < decl.size(); ++j) { decl_off[j] = tot; tot += s_n[decl[j]]; }
+		decl_off[decl.size()] = tot;
+		if (*decl_cap < tot) { *decl_cap = tot + (tot >> 2) + 16; *decl_intv = (bsx_intv_t*)realloc(*decl_intv, sizeof(bsx_intv_t) * (size_t)*decl_cap); }
+		const bsx_intv_t *dense = nullptr;
+		if (decl.size() > 2048) { // many: one bulk copy of the dense lists, gathered on the host
+			unsigned long long sused = 0;
+			HIPCHK(hipMemcpy(&sused, ctr + 4, 8, hipMemcpyDeviceToHost));
+			if (sused > dense_cap) sused = dense_cap;
+			if ((rc = d->hstage.reserve((size_t)sused * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+			if (sused) HIPCHK(hipMemcpy(d->hstage.p, d->out.p, (size_t)sused * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			dense = (const bsx_intv_t*)d->hstage.p;
+		}
+		for (size_t j = 0; j < decl.size(); ++j) {
+			const int64_t i = decl[j]; const int cnt = s_n[i];
+			bsx_intv_t *dst = *decl_intv + decl_off[j];
+			if (cnt <= 0) continue;
+			if (dense) memcpy(dst, dense + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
+			else HIPCHK(hipMemcpy(dst, (const bsx_intv_t*)d->out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
+		}
+	}
 	return BSX_OK;
 }
 
@@ -559,7 +594,8 @@ static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t
 static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return bsx_sa_batch((bsx_device_t*)c, n, j, p); }
 static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return bsx_extend_batch((bsx_device_t*)c, n, j, r); }
 static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return bsx_sw_batch((bsx_device_t*)c, n, j, r); }
-static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return bsx_regions_batch((bsx_device_t*)c, o, n, t, out, cap, off, cnt); }
+static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt,
+                      bsx_intv_t **di, int64_t *dc, int64_t *doff) { return bsx_regions_batch((bsx_device_t*)c, o, n, t, out, cap, off, cnt, di, dc, doff); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return bsx_global_batch((bsx_device_t*)c, n, j, r, pool, len); }
 
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out)

@@ -151,7 +151,8 @@ typedef struct bsx_backend {
 	                    uint32_t *cigar_pool, size_t cigar_pool_len);
 	/* optional (may be NULL): seeding through regions in one device pass, see bsx_regions_batch */
 	int (*regions_batch)(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
-	                     bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
+	                     bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
+	                     bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off);
 } bsx_backend_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;

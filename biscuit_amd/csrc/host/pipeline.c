@@ -712,7 +712,8 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
                                      int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
 	chunk_t C;
-	int rc = BSX_OK, i, t, nt = bsx_host_threads(opt);
+	int rc = BSX_OK, i, t, nt = bsx_host_threads(opt), n_reseed = 0;
+	bsx_intv_t *decl_intv = 0; int64_t decl_cap = 0, *decl_off = 0;
 	size_t tot = 0;
 	uint8_t *buf = 0;
 	bsx_seed_task_t *stasks = 0;
@@ -765,18 +766,22 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	if (be->regions_batch) {
 		C.dreg_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
 		C.dreg_n = (int32_t*)malloc(sizeof(int32_t) * ((size_t)C.n_tasks + 1));
-		CHECK(be->regions_batch(be->ctx, opt, C.n_tasks, stasks, &C.dregs, &C.dregs_cap, C.dreg_off, C.dreg_n));
+		decl_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
+		CHECK(be->regions_batch(be->ctx, opt, C.n_tasks, stasks, &C.dregs, &C.dregs_cap, C.dreg_off, C.dreg_n, &decl_intv, &decl_cap, decl_off));
 		bsx_parallel_for(nt, adopt_worker, &C, C.n_tasks);
-		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] < 0) { stasks[C.n_host] = stasks[t]; C.hmap[C.n_host++] = t; }
+		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
+		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] == -1) { stasks[C.n_host] = stasks[t]; C.hmap[C.n_host++] = t; }
+		n_reseed = C.n_host;
+		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] < -1) C.hmap[C.n_host++] = t;
 		if (getenv("BSX_PHASES")) {
-			long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-			for (t = 0; t < C.n_tasks; ++t) ++h[C.dreg_n[t] >= 0 ? 0 : (-C.dreg_n[t] < 8 ? -C.dreg_n[t] : 8)];
-			fprintf(stderr, "[M::regions] on device %ld | declined: seeds/length %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
-			        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+			long h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+			for (t = 0; t < C.n_tasks; ++t) ++h[C.dreg_n[t] >= 0 ? 0 : (-C.dreg_n[t] < 9 ? -C.dreg_n[t] : 9)];
+			fprintf(stderr, "[M::regions] on device %ld | declined: seeding overflow %ld, read length %ld, intervals %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
+			        h[0], h[1], h[9], h[8], h[2], h[3], h[4], h[5], h[6], h[7]);
 		}
 	} else {
 		for (t = 0; t < C.n_tasks; ++t) C.hmap[t] = t;
-		C.n_host = C.n_tasks;
+		C.n_host = n_reseed = C.n_tasks;
 	}
 	g_stats.t_regions = now_s() - t0; g_stats.n_host_tasks = C.n_host;
 
@@ -784,7 +789,13 @@ BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *o
 	t0 = now_s();
 	C.intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_host + 1));
 	C.intv_off[0] = 0;
-	CHECK(be->seed_batch(be->ctx, opt, C.n_host, stasks, &C.intv, &C.intv_cap, C.intv_off));
+	CHECK(be->seed_batch(be->ctx, opt, n_reseed, stasks, &C.intv, &C.intv_cap, C.intv_off));
+	if (C.n_host > n_reseed) { /* append the interval lists the device handed back */
+		int64_t base = C.intv_off[n_reseed], add = decl_off[C.n_host - n_reseed];
+		if (C.intv_cap < base + add) { C.intv_cap = base + add + 16; C.intv = (bsx_intv_t*)realloc(C.intv, sizeof(bsx_intv_t) * (size_t)C.intv_cap); }
+		if (add) memcpy(C.intv + base, decl_intv, sizeof(bsx_intv_t) * (size_t)add);
+		for (t = n_reseed; t <= C.n_host; ++t) C.intv_off[t] = base + decl_off[t - n_reseed];
+	}
 	g_stats.t_seed = now_s() - t0; g_stats.n_intv = C.intv_off[C.n_host];
 
 	/* K3: the first min(occ, max_occ) occurrences of every interval */
@@ -887,7 +898,7 @@ done:
 	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
 	for (t = 0; t < C.n_host; ++t) { if (C.xpos) free(C.xpos[t]); if (C.xpos_off) free(C.xpos_off[t]); }
 	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
-	free(C.hmap); free(C.dregs); free(C.dreg_off); free(C.dreg_n);
+	free(C.hmap); free(C.dregs); free(C.dreg_off); free(C.dreg_n); free(decl_intv); free(decl_off);
 	bsx_arenas_end();
 	g_stats.t_cleanup = now_s() - t0;
 	g_stats.t_total = now_s() - t_all;
