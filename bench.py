@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-sample-pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one chunk at a time through bsx_process_seqs (no overlap of consecutive chunks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,10 +98,25 @@ def main():
     C.c_int.in_dll(L, "bsx_verbose").value = 1   # silence per-chunk messages inside the timed region
 
     chunks = [gen(1000 * (rank + 1) + s, pairs_per_step) for s in range(args.warmup + args.steps)]
+    # chunks go through the two-deep pipeline of include/bsx.h (front half of chunk k+1 on the device while the host
+    # finishes chunk k); --no-pipeline runs them one at a time through bsx_process_seqs instead
+    L.bsx_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bsx_stream_push.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bsx_stream_flush.argtypes = [C.c_void_p]
+    L.bsx_stream_close.argtypes = [C.c_void_p]
+    L.bsx_stream_close.restype = None
+    stream = C.c_void_p()
+    if not args.no_pipeline:
+        B.check(L.bsx_stream_open(dev.h, C.byref(opt), idx.h, None, C.byref(stream)), "stream_open")
     n_processed = 0
     for s in range(args.warmup):
-        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs(warmup)")
+        if args.no_pipeline:
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs(warmup)")
+        else:
+            B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push(warmup)")
         n_processed += n_reads
+    if not args.no_pipeline:
+        B.check(L.bsx_stream_flush(stream), "stream_flush(warmup)")
     for k in range(6):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
@@ -108,13 +124,24 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for s in range(args.warmup, args.warmup + args.steps):
-        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs")
-        n_processed += n_reads
+    def account():
         ps = B.PhaseStats()
         L.bsx_last_phase_stats(C.byref(ps))
         for f, _ in B.PhaseStats._fields_:
             phase_tot[f] = phase_tot.get(f, 0) + getattr(ps, f)
+
+    for s in range(args.warmup, args.warmup + args.steps):
+        if args.no_pipeline:
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs")
+            account()
+        else:
+            B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push")
+            if s > args.warmup:
+                account()       # the push completed the previous chunk
+        n_processed += n_reads
+    if not args.no_pipeline:
+        B.check(L.bsx_stream_flush(stream), "stream_flush")   # the last chunk completes inside the timed region
+        account()
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
@@ -154,7 +181,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%d bp synthetic directional bisulfite pairs vs a synthetic %.0f Mbp genome with repeat families "
                                    "(stand-in for BASELINE configs[1]: hg38 is not available offline), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp),
-                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world,
+                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world, "chunk_pipeline_depth": 1 if args.no_pipeline else 2,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -165,6 +192,8 @@ def main():
             "index_build_s": round(t_build, 1), "device": dev.name,
         }
         print(json.dumps(out))
+    if not args.no_pipeline:
+        L.bsx_stream_close(stream)
     for c in chunks:
         L.bsx_sim_free_reads(c, n_reads)
     if dist is not None:

@@ -643,14 +643,15 @@ __global__ void __launch_bounds__(256, 3)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count)
+          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota)
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
 	RgDp &D = dp[threadIdx.x >> 6];
-	for (;;) {
+	// each wave takes `quota` tasks and leaves (bounded workgroup life, see k_seed); the launch covers all tasks
+	for (int taken = 0; taken < quota; ++taken) {
 		int t = 0;
 		if (lane == 0) t = (int)atomicAdd(task_cursor, 1u);
 		t = uni(__shfl(t, 0));
@@ -693,11 +694,11 @@ size_t regions_big_slab_bytes() { return sizeof(RgBig); }
 void launch_regions(hipStream_t st, int grid, int big_grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *cursors, int *retry_list, void *slabs)
+                    unsigned int *cursors, int *retry_list, void *slabs, int quota)
 {
 	// cursors: [0] task cursor, [1] retry count, [2] retry cursor
 	hipLaunchKernelGGL(k_regions, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, cursors, retry_list, cursors + 1);
+	                   out, out_cap, out_cursor, reg_off, reg_n, cursors, retry_list, cursors + 1, quota);
 	hipLaunchKernelGGL(k_regions_big, dim3(big_grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 	                   out, out_cap, out_cursor, reg_off, reg_n, retry_list, cursors + 1, cursors + 2, (RgBig*)slabs);
 }

@@ -8,15 +8,27 @@
 // One lane = one strand search at a time; lanes pull the next task from a global cursor as soon
 // as they finish (reads differ a lot in seeding work), so a wave stays full until the queue drains.
 // Every trip of the outer loop issues the FM-block gathers of all 64 lanes together.
+// A lane retires after `quota` tasks (0 = never): workgroups then have a bounded life and the launch is
+// many more workgroups than fit on the chip, which lets kernels of a higher-priority stream (the back half of
+// the previous chunk) get compute units while this one is running.  Scratch slabs are therefore not tied to
+// the workgroup index: each wave takes a free slab and gives it back when it exits.
 __global__ void __launch_bounds__(256)
 k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
-       long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters)
+       long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
+       int quota, unsigned int *slab_busy, int n_slabs)
 {
 	// per-wave slab, lane-interleaved: entry i of lane l sits at slab[i*64 + l], so the 64 lanes'
 	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
-	const size_t wave_id = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	int slab = 0;
+	if ((threadIdx.x & 63) == 0) {
+		unsigned int h = (unsigned int)((blockIdx.x * 4u + (threadIdx.x >> 6)) % (unsigned int)n_slabs);
+		while (atomicCAS(&slab_busy[h], 0u, 1u) != 0u) h = h + 1 == (unsigned int)n_slabs ? 0 : h + 1;
+		slab = (int)h;
+	}
+	slab = __shfl(slab, 0);
+	const size_t wave_id = (size_t)slab;
 	const size_t per_lane = (size_t)2 * list_cap + mem_cap;
 	SeedLane L;
 	L.stride = 64;
@@ -30,7 +42,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.qlds = nullptr;
 	L.state = SD_DONE;
 	L.n_slow = L.n_fast = 0;
-	int task = -1, retired = 0;
+	int task = -1, retired = 0, taken = 0;
 	uint32_t tot_slow = 0, tot_fast = 0;
 
 	for (;;) {
@@ -51,8 +63,10 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						tot_slow += L.n_slow; tot_fast += L.n_fast;
 						task = -1;
 					}
+					if (quota && taken >= quota) { retired = 1; break; }
 					unsigned int t = atomicAdd(task_cursor, 1u);
 					if (t >= (unsigned int)n_tasks) { retired = 1; break; }
+					++taken;
 					task = (int)t;
 					L.q = reads + tasks[t].qoff; L.len = tasks[t].len; L.parent = tasks[t].parent;
 					L.qlds = nullptr;
@@ -90,7 +104,11 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	}
 	// work counters for the algorithmic-bytes model: slow path = two 64-B blocks, fast = one
 	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); }
-	if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast); }
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast);
+		__threadfence();
+		atomicExch(&slab_busy[slab], 0u);
+	}
 }
 
 // K3: bwt_sa (lib/aln/bwt.c:87-97) -- LF-walk to the next sampled rank; one lane per lookup.
@@ -122,10 +140,11 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
-                 long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters)
+                 long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
+                 int quota, unsigned int *slab_busy, int n_slabs)
 {
 	hipLaunchKernelGGL(k_seed, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-	                   task_off, task_n, task_cursor, counters);
+	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

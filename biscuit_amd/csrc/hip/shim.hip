@@ -42,24 +42,33 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-struct bsx_device {
-	int ordinal = 0;
-	char name[256];
-	int n_cu = 0;
-	hipStream_t st = nullptr;
+// One lane = one HIP stream with its own staging: a chunk is bound to a lane for its whole life, so the front half
+// (seeding .. regions) of one chunk and the back half (merge .. SAM) of the previous one can be in flight together.
+#define BSX_LANES 2
+struct Lane {
+	hipStream_t st = nullptr;      // front-half kernels (low priority)
+	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-	DevIndex ix; bool has_index = false;
-	DevBuf bwt[2], sa[2], pac, ctg;
-	DevScoring sc;
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs;
-	DevBuf small;          // counters[4] | out_cursor | task_cursor
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabflags;
+	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	double k_ms[6] = {0, 0, 0, 0, 0, 0};
 	int64_t k_launch[6] = {0, 0, 0, 0, 0, 0};
 };
 
-static inline unsigned long long *dev_counters(bsx_device *d) { return (unsigned long long*)d->small.p; }
+struct bsx_device {
+	int ordinal = 0;
+	char name[256];
+	int n_cu = 0;
+	DevIndex ix; bool has_index = false;
+	DevBuf bwt[2], sa[2], pac, ctg;
+	DevScoring sc;
+	Lane lane[BSX_LANES];
+};
+struct LaneRef { bsx_device *d; int lane; };   // what the backend vtable carries as ctx
+
+static inline unsigned long long *dev_counters(Lane &L) { return (unsigned long long*)L.small.p; }
 
 extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 {
@@ -74,12 +83,20 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 	HIPCHK(hipGetDeviceProperties(&prop, ordinal));
 	snprintf(d->name, sizeof(d->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
 	d->n_cu = prop.multiProcessorCount;
-	HIPCHK(hipStreamCreate(&d->st));
-	HIPCHK(hipEventCreate(&d->ev0));
-	HIPCHK(hipEventCreate(&d->ev1));
-	HIPCHK(hipEventCreate(&d->ev2));
-	if (d->small.reserve(128) != BSX_OK) return BSX_E_NOMEM;
-	HIPCHK(hipMemset(d->small.p, 0, 128));
+	for (int l = 0; l < BSX_LANES; ++l) {
+		Lane &L = d->lane[l];
+		int lo = 0, hi = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest priority (numerically lower)
+		HIPCHK(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
+		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
+		if (L.slabflags.reserve((size_t)d->n_cu * 16 * 4) != BSX_OK) return BSX_E_NOMEM;
+		HIPCHK(hipMemset(L.slabflags.p, 0, (size_t)d->n_cu * 16 * 4));
+		HIPCHK(hipEventCreate(&L.ev0));
+		HIPCHK(hipEventCreate(&L.ev1));
+		HIPCHK(hipEventCreate(&L.ev2));
+		if (L.small.reserve(128) != BSX_OK) return BSX_E_NOMEM;
+		HIPCHK(hipMemset(L.small.p, 0, 128));
+	}
 	memset(&d->ix, 0, sizeof(d->ix));
 	memset(&d->sc, 0, sizeof(d->sc));
 	*out = d;
@@ -91,13 +108,17 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	if (!d) return;
 	(void)hipSetDevice(d->ordinal);
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
-	d->pac.release(); d->reads.release(); d->jobs.release(); d->res.release(); d->scratch.release();
-	d->out.release(); d->aux.release(); d->pool.release(); d->small.release(); d->hstage.release();
-	d->ctg.release(); d->regs.release(); d->regmeta.release(); d->slabs.release();
-	if (d->ev0) (void)hipEventDestroy(d->ev0);
-	if (d->ev1) (void)hipEventDestroy(d->ev1);
-	if (d->ev2) (void)hipEventDestroy(d->ev2);
-	if (d->st) (void)hipStreamDestroy(d->st);
+	d->pac.release(); d->ctg.release();
+	for (int l = 0; l < BSX_LANES; ++l) {
+		Lane &L = d->lane[l];
+		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release();
+		if (L.ev0) (void)hipEventDestroy(L.ev0);
+		if (L.ev1) (void)hipEventDestroy(L.ev1);
+		if (L.ev2) (void)hipEventDestroy(L.ev2);
+		if (L.st) (void)hipStreamDestroy(L.st);
+		if (L.st_hi) (void)hipStreamDestroy(L.st_hi);
+	}
 	delete d;
 }
 
@@ -149,25 +170,28 @@ extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o)
 	return BSX_OK;
 }
 
-extern "C" BSX_API int bsx_device_set_reads(bsx_device_t *d, const uint8_t *buf, size_t n)
+static int lane_set_reads(bsx_device_t *d, int lane, const uint8_t *buf, size_t n)
 {
 	if (!d) return BSX_E_ARG;
+	Lane &L = d->lane[lane];
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc;
-	if ((rc = d->reads.reserve(n + 64)) != BSX_OK) return rc;
-	if (n) HIPCHK(hipMemcpyAsync(d->reads.p, buf, n, hipMemcpyHostToDevice, d->st));
-	HIPCHK(hipStreamSynchronize(d->st));
-	d->n_reads = n;
+	if ((rc = L.reads.reserve(n + 64)) != BSX_OK) return rc;
+	if (n) HIPCHK(hipMemcpyAsync(L.reads.p, buf, n, hipMemcpyHostToDevice, L.st));
+	HIPCHK(hipStreamSynchronize(L.st));
+	L.n_reads = n;
 	return BSX_OK;
 }
 
-// time one kernel (already enqueued between ev0/ev1 on d->st)
-static int finish_timed(bsx_device *d, int k)
+extern "C" BSX_API int bsx_device_set_reads(bsx_device_t *d, const uint8_t *buf, size_t n) { return lane_set_reads(d, 0, buf, n); }
+
+// time one kernel (already enqueued between ev0/ev1 on the lane's stream)
+static int finish_timed(Lane &L, int k)
 {
 	float ms = 0;
-	HIPCHK(hipEventSynchronize(d->ev1));
-	HIPCHK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
-	d->k_ms[k] += ms; d->k_launch[k] += 1;
+	HIPCHK(hipEventSynchronize(L.ev1));
+	HIPCHK(hipEventElapsedTime(&ms, L.ev0, L.ev1));
+	L.k_ms[k] += ms; L.k_launch[k] += 1;
 	HIPCHK(hipGetLastError());
 	return BSX_OK;
 }
@@ -176,17 +200,26 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 {
 	if (!d) return BSX_E_ARG;
 	HIPCHK(hipSetDevice(d->ordinal));
-	HIPCHK(hipMemcpy(c, d->small.p, 32, hipMemcpyDeviceToHost));
-	if (reset) HIPCHK(hipMemset(d->small.p, 0, 32));
+	c[0] = c[1] = c[2] = c[3] = 0;
+	for (int l = 0; l < BSX_LANES; ++l) {
+		uint64_t t[4];
+		HIPCHK(hipMemcpy(t, d->lane[l].small.p, 32, hipMemcpyDeviceToHost));
+		for (int k = 0; k < 4; ++k) c[k] += t[k];
+		if (reset) HIPCHK(hipMemset(d->lane[l].small.p, 0, 32));
+	}
 	return BSX_OK;
 }
 
 extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
 {
 	if (!d || k < 0 || k >= 6) return BSX_E_ARG;
-	if (total_ms) *total_ms = d->k_ms[k];
-	if (launches) *launches = d->k_launch[k];
-	if (reset) { d->k_ms[k] = 0; d->k_launch[k] = 0; }
+	double ms = 0; int64_t n = 0;
+	for (int l = 0; l < BSX_LANES; ++l) {
+		ms += d->lane[l].k_ms[k]; n += d->lane[l].k_launch[k];
+		if (reset) { d->lane[l].k_ms[k] = 0; d->lane[l].k_launch[k] = 0; }
+	}
+	if (total_ms) *total_ms = ms;
+	if (launches) *launches = n;
 	return BSX_OK;
 }
 
@@ -213,10 +246,11 @@ static void seed_asm_worker(void *data, long i, int tid)
 	if (n > 1) std::sort(dst, dst + n, intv_info_lt);
 }
 
-extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
-                                      bsx_intv_t **out, int64_t *out_cap, int64_t *out_off)
+static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                           bsx_intv_t **out, int64_t *out_cap, int64_t *out_off)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) { out_off[0] = 0; return BSX_OK; }
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc, max_len = 0;
@@ -253,20 +287,20 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 		int grid = (waves + 3) / 4;
 		size_t lanes = (size_t)grid * 256;
 		size_t scratch_bytes = lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv);
-		if ((rc = d->scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
-		if ((rc = d->jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
-		if ((rc = d->out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
-		if ((rc = d->aux.reserve((size_t)cn * 12 + 64)) != BSX_OK) return rc;
-		long long *d_off = (long long*)d->aux.p; int *d_n = (int*)((char*)d->aux.p + (size_t)cn * 8);
-		unsigned long long *ctr = dev_counters(d);
-		HIPCHK(hipMemcpyAsync(d->jobs.p, cur, (size_t)cn * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, d->st));
-		HIPCHK(hipMemsetAsync(ctr + 4, 0, 16, d->st));   // out_cursor (u64) + task_cursor (u32)
-		HIPCHK(hipEventRecord(d->ev0, d->st));
-		launch_seed(d->st, grid, d->ix, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)cn, P,
-		            (DevIntv*)d->scratch.p, list_cap, mem_cap, (DevIntv*)d->out.p, dense_cap, ctr + 4, d_off, d_n,
-		            (unsigned int*)(ctr + 5), ctr);
-		HIPCHK(hipEventRecord(d->ev1, d->st));
-		if ((rc = finish_timed(d, 0)) != BSX_OK) return rc;
+		if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
+		if ((rc = L.jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
+		if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
+		if ((rc = L.aux.reserve((size_t)cn * 12 + 64)) != BSX_OK) return rc;
+		long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)cn * 8);
+		unsigned long long *ctr = dev_counters(L);
+		HIPCHK(hipMemcpyAsync(L.jobs.p, cur, (size_t)cn * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st));
+		HIPCHK(hipMemsetAsync(ctr + 4, 0, 16, L.st));   // out_cursor (u64) + task_cursor (u32)
+		HIPCHK(hipEventRecord(L.ev0, L.st));
+		launch_seed(L.st, grid, d->ix, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)cn, P,
+		            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
+		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4);
+		HIPCHK(hipEventRecord(L.ev1, L.st));
+		if ((rc = finish_timed(L, 0)) != BSX_OK) return rc;
 		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
 		unsigned long long used = 0;
 		HIPCHK(hipMemcpy(r_off.data(), d_off, (size_t)cn * 8, hipMemcpyDeviceToHost));
@@ -275,13 +309,13 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 		if (used > dense_cap) used = dense_cap;
 		std::vector<int64_t> next;
 		if (round == 0) {
-			if ((rc = d->hstage.reserve((size_t)used * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
-			if (used) HIPCHK(hipMemcpy(d->hstage.p, d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
-			h_dense = (const bsx_intv_t*)d->hstage.p;
+			if ((rc = L.hstage.reserve((size_t)used * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+			if (used) HIPCHK(hipMemcpy(L.hstage.p, L.out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			h_dense = (const bsx_intv_t*)L.hstage.p;
 			for (int64_t i = 0; i < n; ++i) { h_off[i] = r_off[i]; h_n[i] = r_n[i]; if (r_n[i] < 0) next.push_back(i); }
 		} else {
 			dense_sub.resize((size_t)used);
-			if (used) HIPCHK(hipMemcpy(dense_sub.data(), d->out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			if (used) HIPCHK(hipMemcpy(dense_sub.data(), L.out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
 			for (int64_t i = 0; i < cn; ++i) {
 				if (r_n[i] < 0) { next.push_back(todo[i]); continue; }
 				redo_index.push_back(todo[i]);
@@ -311,11 +345,12 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 // ------------------------------------------------------------------------------------------
 // K1+K2 -> K3 + chaining + chain filter + chain-to-region on the device; the interval lists never leave HBM
 // ------------------------------------------------------------------------------------------
-extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
-                                         bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
-                                         bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off)
+static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
+                              bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
+                              bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	if (n > 0x7fffffff) return BSX_E_ARG;
 	HIPCHK(hipSetDevice(d->ordinal));
@@ -335,38 +370,41 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 
 	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
 	const unsigned long long dense_cap = (unsigned long long)n * 24 + 4096, regs_cap = (unsigned long long)n * 2 + 4096;
-	int waves = (int)std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * 16);
-	int grid = (waves + 3) / 4;
-	size_t lanes = (size_t)grid * 256;
-	if ((rc = d->scratch.reserve(lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv))) != BSX_OK) return rc;
-	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
-	if ((rc = d->out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
-	if ((rc = d->aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
-	if ((rc = d->regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = d->regmeta.reserve((size_t)n * 16 + 64)) != BSX_OK) return rc;
+	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
+	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
+	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
+	const int n_slabs = d->n_cu * 16;
+	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota)) : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)n_slabs) + 3) / 4);
+	size_t lanes = (size_t)n_slabs * 64;
+	if ((rc = L.scratch.reserve(lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv))) != BSX_OK) return rc;
+	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
+	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
+	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 16 + 64)) != BSX_OK) return rc;
 	const int big_grid = d->n_cu * 2;
-	if ((rc = d->slabs.reserve((size_t)big_grid * 4 * regions_big_slab_bytes())) != BSX_OK) return rc;
-	long long *d_off = (long long*)d->aux.p; int *d_n = (int*)((char*)d->aux.p + (size_t)n * 8);
-	long long *r_off = (long long*)d->regmeta.p; int *r_n = (int*)((char*)d->regmeta.p + (size_t)n * 8);
-	int *retry = (int*)((char*)d->regmeta.p + (size_t)n * 12);
-	unsigned long long *ctr = dev_counters(d);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7..8] region task/retry cursors (3 x u32)
-	HIPCHK(hipMemcpyAsync(d->jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, d->st));
-	HIPCHK(hipMemsetAsync(ctr + 4, 0, 48, d->st));
-	HIPCHK(hipEventRecord(d->ev0, d->st));
-	launch_seed(d->st, grid, d->ix, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n, P,
-	            (DevIntv*)d->scratch.p, list_cap, mem_cap, (DevIntv*)d->out.p, dense_cap, ctr + 4, d_off, d_n,
-	            (unsigned int*)(ctr + 5), ctr);
-	HIPCHK(hipEventRecord(d->ev1, d->st));
-	const int rgrid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)d->n_cu * 3);
-	launch_regions(d->st, rgrid, big_grid, d->ix, d->sc, R, (const uint8_t*)d->reads.p, (const bsx_seed_task_t*)d->jobs.p, (int)n,
-	               (const DevIntv*)d->out.p, d_off, d_n, (bsx_region_t*)d->regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7), retry, d->slabs.p);
-	HIPCHK(hipEventRecord(d->ev2, d->st));
+	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_big_slab_bytes())) != BSX_OK) return rc;
+	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
+	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
+	int *retry = (int*)((char*)L.regmeta.p + (size_t)n * 12);
+	unsigned long long *ctr = dev_counters(L);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7..8] region task/retry cursors (3 x u32)
+	HIPCHK(hipMemcpyAsync(L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st));
+	HIPCHK(hipMemsetAsync(ctr + 4, 0, 48, L.st));
+	HIPCHK(hipEventRecord(L.ev0, L.st));
+	launch_seed(L.st, grid, d->ix, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)n, P,
+	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
+	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs);
+	HIPCHK(hipEventRecord(L.ev1, L.st));
+	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
+	launch_regions(L.st, rgrid, big_grid, d->ix, d->sc, R, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)n,
+	               (const DevIntv*)L.out.p, d_off, d_n, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7), retry, L.slabs.p, reg_quota);
+	HIPCHK(hipEventRecord(L.ev2, L.st));
 	{
 		float ms0 = 0, ms1 = 0;
-		HIPCHK(hipEventSynchronize(d->ev2));
-		HIPCHK(hipEventElapsedTime(&ms0, d->ev0, d->ev1));
-		HIPCHK(hipEventElapsedTime(&ms1, d->ev1, d->ev2));
-		d->k_ms[0] += ms0; d->k_launch[0] += 1; d->k_ms[5] += ms1; d->k_launch[5] += 1;
+		HIPCHK(hipEventSynchronize(L.ev2));
+		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
+		HIPCHK(hipEventElapsedTime(&ms1, L.ev1, L.ev2));
+		L.k_ms[0] += ms0; L.k_launch[0] += 1; L.k_ms[5] += ms1; L.k_launch[5] += 1;
 		HIPCHK(hipGetLastError());
 	}
 	unsigned long long used = 0;
@@ -377,7 +415,7 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
 	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
-	if (used) HIPCHK(hipMemcpy(*out, d->regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
+	if (used) HIPCHK(hipMemcpy(*out, L.regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
 
 	// declined tasks: hand their interval lists back (ordered by info, as bsx_seed_batch returns them)
 	std::vector<int64_t> decl;
@@ -396,16 +434,16 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 			unsigned long long sused = 0;
 			HIPCHK(hipMemcpy(&sused, ctr + 4, 8, hipMemcpyDeviceToHost));
 			if (sused > dense_cap) sused = dense_cap;
-			if ((rc = d->hstage.reserve((size_t)sused * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
-			if (sused) HIPCHK(hipMemcpy(d->hstage.p, d->out.p, (size_t)sused * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
-			dense = (const bsx_intv_t*)d->hstage.p;
+			if ((rc = L.hstage.reserve((size_t)sused * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+			if (sused) HIPCHK(hipMemcpy(L.hstage.p, L.out.p, (size_t)sused * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			dense = (const bsx_intv_t*)L.hstage.p;
 		}
 		for (size_t j = 0; j < decl.size(); ++j) {
 			const int64_t i = decl[j]; const int cnt = s_n[i];
 			bsx_intv_t *dst = *decl_intv + decl_off[j];
 			if (cnt <= 0) continue;
 			if (dense) memcpy(dst, dense + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
-			else HIPCHK(hipMemcpy(dst, (const bsx_intv_t*)d->out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+			else HIPCHK(hipMemcpy(dst, (const bsx_intv_t*)L.out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt, hipMemcpyDeviceToHost));
 			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
 		}
 	}
@@ -415,30 +453,32 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 // ------------------------------------------------------------------------------------------
 // K3
 // ------------------------------------------------------------------------------------------
-extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos)
+static int lane_sa_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc;
-	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_sa_job_t))) != BSX_OK) return rc;
-	if ((rc = d->res.reserve((size_t)n * 8)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_sa_job_t), hipMemcpyHostToDevice, d->st));
+	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_sa_job_t))) != BSX_OK) return rc;
+	if ((rc = L.res.reserve((size_t)n * 8)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_sa_job_t), hipMemcpyHostToDevice, L.st));
 	int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)d->n_cu * 8);
-	HIPCHK(hipEventRecord(d->ev0, d->st));
-	launch_sa(d->st, grid, d->ix, (const bsx_sa_job_t*)d->jobs.p, (long long)n, (uint64_t*)d->res.p, dev_counters(d));
-	HIPCHK(hipEventRecord(d->ev1, d->st));
-	if ((rc = finish_timed(d, 1)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(pos, d->res.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipEventRecord(L.ev0, L.st));
+	launch_sa(L.st, grid, d->ix, (const bsx_sa_job_t*)L.jobs.p, (long long)n, (uint64_t*)L.res.p, dev_counters(L));
+	HIPCHK(hipEventRecord(L.ev1, L.st));
+	if ((rc = finish_timed(L, 1)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(pos, L.res.p, (size_t)n * 8, hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // K4
 // ------------------------------------------------------------------------------------------
-extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res)
+static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
 	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}
@@ -454,34 +494,35 @@ extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ex
 		order[c].push_back((int)i);
 	}
 	int rc;
-	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
-	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
-	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, d->st));
+	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
+	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
+	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 	size_t off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st));
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev0, d->st));
+	HIPCHK(hipEventRecord(L.ev0, L.st));
 	off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		launch_extend(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_ext_job_t*)d->jobs.p, (const int*)d->aux.p + off,
-		              (long long)order[c].size(), (bsx_ext_res_t*)d->res.p, QCAP[c], NCS[c], d->n_cu);
+		launch_extend(L.st, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+		              (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, QCAP[c], NCS[c], d->n_cu);
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev1, d->st));
-	if ((rc = finish_timed(d, 2)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_ext_res_t), hipMemcpyDeviceToHost));
+	HIPCHK(hipEventRecord(L.ev1, L.st));
+	if ((rc = finish_timed(L, 2)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t), hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // K5
 // ------------------------------------------------------------------------------------------
-extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res)
+static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
 	std::vector<int> order[2];
@@ -496,38 +537,39 @@ extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job
 	}
 	int rc;
 	const int blocks_cap = d->n_cu * 8;
-	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_sw_job_t))) != BSX_OK) return rc;
-	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
-	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	if ((rc = d->scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t), hipMemcpyHostToDevice, d->st));
+	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_sw_job_t))) != BSX_OK) return rc;
+	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
+	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t), hipMemcpyHostToDevice, L.st_hi));
 	size_t off = 0;
 	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st_hi));
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev0, d->st));
+	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
 	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
 		const long long m = (long long)order[c].size();
 		const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
-		launch_sw(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_sw_job_t*)d->jobs.p, (const int*)d->aux.p + off, m,
-		          (bsx_sw_res_t*)d->res.p, (unsigned long long*)d->scratch.p, max_tlen, blocks, c == 0 ? 4 : 16);
+		launch_sw(L.st_hi, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
+		          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : 16);
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev1, d->st));
-	if ((rc = finish_timed(d, 3)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_sw_res_t), hipMemcpyDeviceToHost));
+	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
+	if ((rc = finish_timed(L, 3)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_sw_res_t), hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // K6
 // ------------------------------------------------------------------------------------------
-extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
-                                        uint32_t *cigar_pool, size_t cigar_pool_len)
+static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+                             uint32_t *cigar_pool, size_t cigar_pool_len)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
 	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 1024, 2048}, NCS[3] = {4, 16, 32}, WPB[3] = {4, 4, 1};
@@ -561,49 +603,69 @@ extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_gl
 		zmax[c] = (zmax[c] + 255) & ~(size_t)255;
 		ztot = std::max(ztot, (size_t)blocks[c] * WPB[c] * zmax[c]);
 	}
-	if ((rc = d->jobs.reserve((size_t)n * sizeof(bsx_glb_job_t))) != BSX_OK) return rc;
-	if ((rc = d->res.reserve((size_t)n * sizeof(bsx_glb_res_t))) != BSX_OK) return rc;
-	if ((rc = d->aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	if ((rc = d->scratch.reserve(ztot + 256)) != BSX_OK) return rc;
-	if ((rc = d->pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(d->jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t), hipMemcpyHostToDevice, d->st));
+	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_glb_job_t))) != BSX_OK) return rc;
+	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_glb_res_t))) != BSX_OK) return rc;
+	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+	if ((rc = L.scratch.reserve(ztot + 256)) != BSX_OK) return rc;
+	if ((rc = L.pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t), hipMemcpyHostToDevice, L.st_hi));
 	size_t off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)d->aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, d->st));
+		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st_hi));
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev0, d->st));
+	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		launch_global(d->st, d->ix, d->sc, (const uint8_t*)d->reads.p, (const bsx_glb_job_t*)d->jobs.p, (const int*)d->aux.p + off,
-		              (long long)order[c].size(), (bsx_glb_res_t*)d->res.p, (uint32_t*)d->pool.p, (uint8_t*)d->scratch.p, zmax[c],
+		launch_global(L.st_hi, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+		              (long long)order[c].size(), (bsx_glb_res_t*)L.res.p, (uint32_t*)L.pool.p, (uint8_t*)L.scratch.p, zmax[c],
 		              QCAP[c], NCS[c], blocks[c], WPB[c]);
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(d->ev1, d->st));
-	if ((rc = finish_timed(d, 4)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, d->res.p, (size_t)n * sizeof(bsx_glb_res_t), hipMemcpyDeviceToHost));
-	if (cigar_pool_len) HIPCHK(hipMemcpy(cigar_pool, d->pool.p, cigar_pool_len * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
+	if ((rc = finish_timed(L, 4)) != BSX_OK) return rc;
+	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_glb_res_t), hipMemcpyDeviceToHost));
+	if (cigar_pool_len) HIPCHK(hipMemcpy(cigar_pool, L.pool.p, cigar_pool_len * 4, hipMemcpyDeviceToHost));
 	return BSX_OK;
 }
 
-// the five seams as one vtable for the host pipeline
-static int be_set_opt(void *c, const bsx_opt_t *o) { return bsx_device_set_opt((bsx_device_t*)c, o); }
-static int be_set_reads(void *c, const uint8_t *b, size_t n) { return bsx_device_set_reads((bsx_device_t*)c, b, n); }
-static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_intv_t **out, int64_t *cap, int64_t *off) { return bsx_seed_batch((bsx_device_t*)c, o, n, t, out, cap, off); }
-static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return bsx_sa_batch((bsx_device_t*)c, n, j, p); }
-static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return bsx_extend_batch((bsx_device_t*)c, n, j, r); }
-static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return bsx_sw_batch((bsx_device_t*)c, n, j, r); }
-static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt,
-                      bsx_intv_t **di, int64_t *dc, int64_t *doff) { return bsx_regions_batch((bsx_device_t*)c, o, n, t, out, cap, off, cnt, di, dc, doff); }
-static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return bsx_global_batch((bsx_device_t*)c, n, j, r, pool, len); }
+// the C ABI of include/bsx.h: lane 0
+extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks, bsx_intv_t **out, int64_t *out_cap, int64_t *out_off)
+{ return lane_seed_batch(d, 0, opt, n, tasks, out, out_cap, out_off); }
+extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks, bsx_region_t **out, int64_t *out_cap,
+                                         int64_t *out_off, int32_t *out_n, bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off)
+{ return lane_regions_batch(d, 0, opt, n, tasks, out, out_cap, out_off, out_n, decl_intv, decl_cap, decl_off); }
+extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos) { return lane_sa_batch(d, 0, n, jobs, pos); }
+extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res) { return lane_extend_batch(d, 0, n, jobs, res); }
+extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res) { return lane_sw_batch(d, 0, n, jobs, res); }
+extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_len)
+{ return lane_global_batch(d, 0, n, jobs, res, cigar_pool, cigar_pool_len); }
 
-extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out)
+// the seams as one vtable for the host pipeline; ctx = (device, lane)
+#define LR(c) ((LaneRef*)(c))->d, ((LaneRef*)(c))->lane
+static int be_set_opt(void *c, const bsx_opt_t *o) { return bsx_device_set_opt(((LaneRef*)c)->d, o); }
+static int be_set_reads(void *c, const uint8_t *b, size_t n) { return lane_set_reads(LR(c), b, n); }
+static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_intv_t **out, int64_t *cap, int64_t *off) { return lane_seed_batch(LR(c), o, n, t, out, cap, off); }
+static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return lane_sa_batch(LR(c), n, j, p); }
+static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return lane_extend_batch(LR(c), n, j, r); }
+static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return lane_sw_batch(LR(c), n, j, r); }
+static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt,
+                      bsx_intv_t **di, int64_t *dc, int64_t *doff) { return lane_regions_batch(LR(c), o, n, t, out, cap, off, cnt, di, dc, doff); }
+static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
+
+static LaneRef g_lane_ref[8][BSX_LANES];   // ctx storage for the vtables (by device ordinal)
+
+extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *out)
 {
 	if (!dev) return BSX_E_NODEVICE;
-	out->ctx = dev; out->name = "hip-gfx950";
+	if (lane < 0 || lane >= BSX_LANES || dev->ordinal < 0 || dev->ordinal >= 8) return BSX_E_ARG;
+	LaneRef *r = &g_lane_ref[dev->ordinal][lane];
+	r->d = dev; r->lane = lane;
+	memset(out, 0, sizeof(*out));
+	out->ctx = r; out->name = "hip-gfx950";
 	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
 	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb;
 	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
 	return BSX_OK;
 }
+extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out) { return bsx_hip_backend_lane(dev, 0, out); }

@@ -28,8 +28,10 @@
  * them from its own arena; nothing is freed individually, the arenas are rewound when the chunk is
  * done and their pages are reused by the next chunk (no malloc lock, no page faults, no cleanup pass). */
 typedef struct bsx_arena bsx_arena_t;
-BSX_API void bsx_arenas_begin(int n_threads);   /* bind arenas to worker ids 0..n_threads-1 (0 = caller) */
-BSX_API void bsx_arenas_end(void);              /* rewind all arenas, unbind */
+/* Two chunks can be in flight (front half of one, back half of the previous): there are two arena sets. */
+BSX_API int  bsx_arenas_begin(int n_threads);   /* take a free set (-1: arenas off), bind it to the caller and to its parallel loops */
+BSX_API void bsx_arenas_bind(int set);          /* another thread continues work on the chunk that owns `set` */
+BSX_API void bsx_arenas_end(int set);           /* rewind the set, release it, unbind the caller */
 void *bsx_arena_alloc(bsx_arena_t *a, size_t n);
 BSX_API extern __thread bsx_arena_t *bsx_tls_arena;
 static inline void *bsx_crealloc(void *p, size_t old_bytes, size_t new_bytes)
@@ -160,8 +162,12 @@ typedef struct bsx_backend {
 BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
                                      int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
-/* HIP backend constructor (csrc/hip/shim.hip) */
-int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);
+/* HIP backend constructors (csrc/hip/shim.hip): lane = one of the device's two independent streams + staging sets */
+int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);          /* lane 0 */
+int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *out);
+/* the chunk pipeline over two arbitrary backends (tests run it over two CPU-restatement contexts) */
+BSX_API int bsx_stream_open_backends(const bsx_backend_t *be0, const bsx_backend_t *be1, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     const bsx_pestat_t *pes0, bsx_stream_t **out);
 
 /* per-phase wall-clock accounting of the last bsx_process_seqs* call (seconds) */
 typedef struct {

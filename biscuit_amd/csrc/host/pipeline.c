@@ -4,8 +4,10 @@
  * The reference maps reads one at a time inside kt_for workers.  Here a chunk moves through the
  * stages as whole batches so that every kernel launch carries the work of all reads:
  *
- *   clip -> [K1+K2 seed] -> [K3 SA] -> chain/filter (host) -> [K5 seed SW, long reads only]
- *        -> rounds of [K4 extend] driven by the per-task state machines (extend.c)
+ *   clip -> [K1+K2 seed -> K3 SA + chaining + chain filter + extension, fused on the device (k_regions)]
+ *        -> for the strand searches the device declined, and on backends without the fused pass:
+ *             [K1+K2 seed] -> [K3 SA] -> chain/filter (host) -> [K5 seed SW, long reads only]
+ *             -> rounds of [K4 extend] driven by the per-task state machines (extend.c)
  *        -> merge/dedup (host, [K6 score-only] for concatenation tests)
  *        -> insert-size statistics (host reduction over the chunk)
  *        -> [K5 mate rescue] -> primary marking, pairing, MAPQ (host)
@@ -15,16 +17,16 @@
  * Host stages are parallelised over reads with bsx_parallel_for; no result depends on scheduling.
  */
 #include <math.h>
+#include <pthread.h>
 #include <sys/time.h>
 #include "align_types.h"
 #include "pipeline.h"
 
 static double now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
 
-static bsx_phase_stats_t g_stats;
-BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out) { *out = g_stats; }
+static bsx_phase_stats_t g_last_stats;   /* of the last chunk that completed */
+BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out) { *out = g_last_stats; }
 
-#define CHECK(x) do { int rc_ = (x); if (rc_ != BSX_OK) { rc = rc_; goto done; } } while (0)
 
 /* ------------------------------------------------------------------ read clipping (bwamem.c:218-303) */
 static const uint8_t *find_bytes(const uint8_t *hay, size_t hlen, const uint8_t *needle, size_t nlen)
@@ -97,6 +99,12 @@ typedef struct {
 	reg_v *regs;                 /* per read */
 	bsx_pestat_t pes;
 	uint8_t *buf; bsx_seed_task_t *stasks; bsx_sa_job_t *sa_jobs;
+	/* life cycle: front half (seeding .. regions per strand search), back half (merge .. SAM) */
+	bsx_backend_t be_copy;
+	const bsx_pestat_t *pes0; bsx_pestat_t pes0_copy;
+	int arena_set, rc;
+	double t_begin;
+	bsx_phase_stats_t st;
 } chunk_t;
 
 /* ------------------------------------------------------------------ chaining */
@@ -182,7 +190,7 @@ static int filter_chained_seeds(chunk_t *C)
 	if (jobs.n) {
 		res = (bsx_sw_res_t*)malloc(sizeof(*res) * jobs.n);
 		rc = C->be->sw_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res);
-		g_stats.n_sw_jobs += (int64_t)jobs.n;
+		C->st.n_sw_jobs += (int64_t)jobs.n;
 	}
 	if (rc == BSX_OK) {
 		for (t = 0; t < C->n_tasks; ++t) {
@@ -240,7 +248,9 @@ static int extension_rounds(chunk_t *C)
 	while (n_active > 0) {
 		int i, nj = 0, na = 0;
 		tx = now_s();
-		bsx_parallel_for(C->nt, advance_worker, &P, n_active);
+		/* a handful of strand searches: not worth the worker pool (which the other chunk's half may be using) */
+		if (n_active < 64) for (i = 0; i < n_active; ++i) advance_worker(&P, i, 0);
+		else bsx_parallel_for(C->nt, advance_worker, &P, n_active);
 		ta += now_s() - tx; tx = now_s();
 		for (i = 0; i < n_active; ++i) {
 			c2r_t *T = &C->tasks[active[i]];
@@ -252,11 +262,12 @@ static int extension_rounds(chunk_t *C)
 		if (nj == 0) break;
 		if ((rc = C->be->extend_batch(C->be->ctx, nj, jobs, res)) != BSX_OK) break;
 		tb += now_s() - tx; tx = now_s();
-		g_stats.n_ext_jobs += nj; ++g_stats.n_ext_rounds;
-		bsx_parallel_for(C->nt, consume_worker, &P, nj);
+		C->st.n_ext_jobs += nj; ++C->st.n_ext_rounds;
+		if (nj < 64) for (i = 0; i < nj; ++i) consume_worker(&P, i, 0);
+		else bsx_parallel_for(C->nt, consume_worker, &P, nj);
 		tc += now_s() - tx;
 	}
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::extend] advance %.3f gather %.3f batch %.3f consume %.3f (%ld jobs, %ld rounds)\n", ta, tg, tb, tc, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds);
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::extend] advance %.3f gather %.3f batch %.3f consume %.3f (%ld jobs, %ld rounds)\n", ta, tg, tb, tc, (long)C->st.n_ext_jobs, (long)C->st.n_ext_rounds);
 	free(jobs); free(res); free(owner); free(active);
 	return rc;
 }
@@ -364,7 +375,7 @@ static int merge_regions(chunk_t *C)
 		if (jobs.n == 0) break;
 		res = (bsx_glb_res_t*)malloc(sizeof(*res) * jobs.n);
 		rc = C->be->global_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res, 0, 0);
-		g_stats.n_glb_jobs += (int64_t)jobs.n;
+		C->st.n_glb_jobs += (int64_t)jobs.n;
 		if (rc == BSX_OK) {
 			size_t cur = 0;
 			for (i = 0; i < n; ++i) {
@@ -496,7 +507,7 @@ static int mate_rescue(chunk_t *C)
 		if (jobs.n == 0) break;
 		res = (bsx_sw_res_t*)malloc(sizeof(*res) * jobs.n);
 		rc = C->be->sw_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res);
-		g_stats.n_sw_jobs += (int64_t)jobs.n;
+		C->st.n_sw_jobs += (int64_t)jobs.n;
 		if (rc == BSX_OK)
 			for (pi = 0, cur = 0; pi < np; ++pi)
 				if (M[pi].pending) for (k = 0; k < M[pi].slots.n; ++k) if (!M[pi].slots.a[k].have) { M[pi].slots.a[k].res = res[cur++]; M[pi].slots.a[k].have = 1; }
@@ -584,7 +595,7 @@ static int emit_sam(chunk_t *C)
 	bsx_vec_init(jobs); bsx_vec_init(jread); bsx_vec_init(jreg); bsx_vec_init(todo);
 	P.C = C; P.ctx = ctx; P.final_pass = 0;
 	bsx_parallel_for(C->nt, out_worker, &P, n_units);
-	g_stats.t_primary += now_s() - t0; t0 = now_s();
+	C->st.t_primary += now_s() - t0; t0 = now_s();
 	for (u = 0; u < n_units; ++u)
 		for (w = 0; w < per; ++w) {
 			int ri = u * per + w;
@@ -607,7 +618,7 @@ static int emit_sam(chunk_t *C)
 		for (k = 0; k < todo.n; ++k) { sub[k] = jobs.a[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
 		rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
-		g_stats.n_glb_jobs += (int64_t)todo.n;
+		C->st.n_glb_jobs += (int64_t)todo.n;
 		if (rc == BSX_OK) {
 			finish_par_t F;
 			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = jread.a; F.jreg = jreg.a; F.sub = sub; F.sres = sres; F.pool = pool;
@@ -622,7 +633,7 @@ static int emit_sam(chunk_t *C)
 		free(sub); free(sres);
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
-	g_stats.t_cigar += now_s() - t0; t0 = now_s();
+	C->st.t_cigar += now_s() - t0; t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
 	for (u = 0; u < n_units; ++u)
@@ -631,7 +642,7 @@ static int emit_sam(chunk_t *C)
 			for (k = 0; k < regs->n; ++k) free(ctx[u].table[w][k].cigar);
 			free(ctx[u].table[w]); bsx_vec_free(ctx[u].want[w]);
 		}
-	g_stats.t_sam += now_s() - t0;
+	C->st.t_sam += now_s() - t0;
 	free(ctx); free(res); free(pool);
 	bsx_vec_free(jobs); bsx_vec_free(jread); bsx_vec_free(jreg); bsx_vec_free(todo);
 	return rc;
@@ -708,208 +719,245 @@ static void adopt_worker(void *data, long t, int tid)
 static void release_regs_worker(void *data, long i, int tid) { (void)tid; free(((chunk_t*)data)->regs[i].a); }
 
 /* ------------------------------------------------------------------ the chunk */
-BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
-                                     int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+#define FCHECK(x) do { rc = (x); if (rc != BSX_OK) return rc; } while (0)
+
+static chunk_t *chunk_new(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n,
+                          bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
-	chunk_t C;
-	int rc = BSX_OK, i, t, nt = bsx_host_threads(opt), n_reseed = 0;
+	chunk_t *C = (chunk_t*)calloc(1, sizeof(chunk_t));
+	C->be_copy = *be; C->be = &C->be_copy;
+	C->opt = opt; C->idx = idx; C->n = n; C->reads = reads; C->n_processed = n_processed; C->nt = bsx_host_threads(opt);
+	C->is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
+	if (pes0) { C->pes0_copy = *pes0; C->pes0 = &C->pes0_copy; }
+	C->arena_set = -1;
+	C->t_begin = now_s();
+	return C;
+}
+
+/* front half: clipping, strand searches, seeding .. regions of every strand search (mem_align1_core's first part,
+ * lib/aln/bwamem.c:183-208, for the whole chunk) */
+static int chunk_front(chunk_t *C)
+{
+	const bsx_backend_t *be = C->be;
+	const bsx_opt_t *opt = C->opt;
+	bsx_read_t *reads = C->reads;
+	int rc = BSX_OK, i, t, n = C->n, nt = C->nt, n_reseed = 0;
 	bsx_intv_t *decl_intv = 0; int64_t decl_cap = 0, *decl_off = 0;
 	size_t tot = 0;
-	uint8_t *buf = 0;
-	bsx_seed_task_t *stasks = 0;
-	double t0, t_all = now_s();
+	double t0;
 
-	memset(&C, 0, sizeof(C));
-	memset(&g_stats, 0, sizeof(g_stats));
-	if (!be || !opt || !idx || n < 0) return BSX_E_ARG;
-	if (n == 0) return BSX_OK;
-	C.be = be; C.opt = opt; C.idx = idx; C.n = n; C.reads = reads; C.n_processed = n_processed; C.nt = nt;
-	C.is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
-	if (C.is_pe && (n & 1)) return BSX_E_ARG;
-
-	bsx_arenas_begin(nt);
+	C->arena_set = bsx_arenas_begin(nt);
 	/* clipping + chunk read buffer + strand searches in the reference's call order (bwamem.c:325-333,352-372) */
 	t0 = now_s();
-	if (C.is_pe)
+	if (C->is_pe)
 		for (i = 0; i < n; i += 2)
 			if (!pair_names_ok(reads[i].name, reads[i + 1].name)) {
 				fprintf(stderr, "[bsx] paired reads have different names: \"%s\", \"%s\"\n", reads[i].name, reads[i + 1].name);
-				bsx_arenas_end();
 				return BSX_E_FORMAT;
 			}
-	bsx_parallel_for(nt, clip_worker, &C, n);
-	C.roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
-	for (i = 0; i < n; ++i) { C.roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
-	C.roff[n] = (uint32_t)tot;
-	if (tot >= 0xffff0000ull) { free(C.roff); bsx_arenas_end(); return BSX_E_ARG; }
-	buf = (uint8_t*)malloc(tot + 16);
-	C.buf = buf;
+	bsx_parallel_for(nt, clip_worker, C, n);
+	C->roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	for (i = 0; i < n; ++i) { C->roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
+	C->roff[n] = (uint32_t)tot;
+	if (tot >= 0xffff0000ull) return BSX_E_ARG;
+	C->buf = (uint8_t*)malloc(tot + 16);
 	{
-		int per_read = C.is_pe ? (opt->parent ? 1 : 2) : ((opt->parent & 1) ? 1 : 2);
-		C.read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
-		for (i = 0; i <= n; ++i) C.read_task0[i] = i * per_read;
-		C.n_tasks = n * per_read;
+		int per_read = C->is_pe ? (opt->parent ? 1 : 2) : ((opt->parent & 1) ? 1 : 2);
+		C->read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
+		for (i = 0; i <= n; ++i) C->read_task0[i] = i * per_read;
+		C->n_tasks = n * per_read;
 	}
-	C.tasks = (c2r_t*)malloc(sizeof(c2r_t) * ((size_t)C.n_tasks + 1));
-	stasks = (bsx_seed_task_t*)malloc(sizeof(*stasks) * ((size_t)C.n_tasks + 1));
-	C.stasks = stasks;
-	bsx_parallel_for(nt, setup_worker, &C, n);
-	g_stats.n_tasks = C.n_tasks;
-	CHECK(be->set_opt(be->ctx, opt));
-	CHECK(be->set_reads(be->ctx, buf, tot));
-	g_stats.t_prep = now_s() - t0;
+	C->tasks = (c2r_t*)malloc(sizeof(c2r_t) * ((size_t)C->n_tasks + 1));
+	C->stasks = (bsx_seed_task_t*)malloc(sizeof(bsx_seed_task_t) * ((size_t)C->n_tasks + 1));
+	bsx_parallel_for(nt, setup_worker, C, n);
+	C->st.n_tasks = C->n_tasks;
+	FCHECK(be->set_opt(be->ctx, opt));
+	FCHECK(be->set_reads(be->ctx, C->buf, tot));
+	C->st.t_prep = now_s() - t0;
 
 	/* seeding through regions in one device pass where the backend has it; what it declines (and everything,
 	 * on a backend without it) goes through the batch kernels and the host chaining below */
 	t0 = now_s();
-	C.hmap = (int*)malloc(sizeof(int) * ((size_t)C.n_tasks + 1));
+	C->hmap = (int*)malloc(sizeof(int) * ((size_t)C->n_tasks + 1));
 	if (be->regions_batch) {
-		C.dreg_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
-		C.dreg_n = (int32_t*)malloc(sizeof(int32_t) * ((size_t)C.n_tasks + 1));
-		decl_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_tasks + 1));
-		CHECK(be->regions_batch(be->ctx, opt, C.n_tasks, stasks, &C.dregs, &C.dregs_cap, C.dreg_off, C.dreg_n, &decl_intv, &decl_cap, decl_off));
-		bsx_parallel_for(nt, adopt_worker, &C, C.n_tasks);
+		C->dreg_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_tasks + 1));
+		C->dreg_n = (int32_t*)malloc(sizeof(int32_t) * ((size_t)C->n_tasks + 1));
+		decl_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_tasks + 1));
+		rc = be->regions_batch(be->ctx, opt, C->n_tasks, C->stasks, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n, &decl_intv, &decl_cap, decl_off);
+		if (rc != BSX_OK) goto out;
+		bsx_parallel_for(nt, adopt_worker, C, C->n_tasks);
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
-		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] == -1) { stasks[C.n_host] = stasks[t]; C.hmap[C.n_host++] = t; }
-		n_reseed = C.n_host;
-		for (t = 0; t < C.n_tasks; ++t) if (C.dreg_n[t] < -1) C.hmap[C.n_host++] = t;
+		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) { C->stasks[C->n_host] = C->stasks[t]; C->hmap[C->n_host++] = t; }
+		n_reseed = C->n_host;
+		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] < -1) C->hmap[C->n_host++] = t;
 		if (getenv("BSX_PHASES")) {
 			long h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-			for (t = 0; t < C.n_tasks; ++t) ++h[C.dreg_n[t] >= 0 ? 0 : (-C.dreg_n[t] < 9 ? -C.dreg_n[t] : 9)];
+			for (t = 0; t < C->n_tasks; ++t) ++h[C->dreg_n[t] >= 0 ? 0 : (-C->dreg_n[t] < 9 ? -C->dreg_n[t] : 9)];
 			fprintf(stderr, "[M::regions] on device %ld | declined: seeding overflow %ld, read length %ld, intervals %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
 			        h[0], h[1], h[9], h[8], h[2], h[3], h[4], h[5], h[6], h[7]);
 		}
 	} else {
-		for (t = 0; t < C.n_tasks; ++t) C.hmap[t] = t;
-		C.n_host = n_reseed = C.n_tasks;
+		for (t = 0; t < C->n_tasks; ++t) C->hmap[t] = t;
+		C->n_host = n_reseed = C->n_tasks;
 	}
-	g_stats.t_regions = now_s() - t0; g_stats.n_host_tasks = C.n_host;
+	C->st.t_regions = now_s() - t0; C->st.n_host_tasks = C->n_host;
 
 	/* K1+K2 */
 	t0 = now_s();
-	C.intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C.n_host + 1));
-	C.intv_off[0] = 0;
-	CHECK(be->seed_batch(be->ctx, opt, n_reseed, stasks, &C.intv, &C.intv_cap, C.intv_off));
-	if (C.n_host > n_reseed) { /* append the interval lists the device handed back */
-		int64_t base = C.intv_off[n_reseed], add = decl_off[C.n_host - n_reseed];
-		if (C.intv_cap < base + add) { C.intv_cap = base + add + 16; C.intv = (bsx_intv_t*)realloc(C.intv, sizeof(bsx_intv_t) * (size_t)C.intv_cap); }
-		if (add) memcpy(C.intv + base, decl_intv, sizeof(bsx_intv_t) * (size_t)add);
-		for (t = n_reseed; t <= C.n_host; ++t) C.intv_off[t] = base + decl_off[t - n_reseed];
+	C->intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_host + 1));
+	C->intv_off[0] = 0;
+	rc = be->seed_batch(be->ctx, opt, n_reseed, C->stasks, &C->intv, &C->intv_cap, C->intv_off);
+	if (rc != BSX_OK) goto out;
+	if (C->n_host > n_reseed) { /* append the interval lists the device handed back */
+		int64_t base = C->intv_off[n_reseed], add = decl_off[C->n_host - n_reseed];
+		if (C->intv_cap < base + add) { C->intv_cap = base + add + 16; C->intv = (bsx_intv_t*)realloc(C->intv, sizeof(bsx_intv_t) * (size_t)C->intv_cap); }
+		if (add) memcpy(C->intv + base, decl_intv, sizeof(bsx_intv_t) * (size_t)add);
+		for (t = n_reseed; t <= C->n_host; ++t) C->intv_off[t] = base + decl_off[t - n_reseed];
 	}
-	g_stats.t_seed = now_s() - t0; g_stats.n_intv = C.intv_off[C.n_host];
+	C->st.t_seed = now_s() - t0; C->st.n_intv = C->intv_off[C->n_host];
 
 	/* K3: the first min(occ, max_occ) occurrences of every interval */
 	t0 = now_s();
 	{
-		int64_t n_iv = C.intv_off[C.n_host], k, nj = 0;
+		int64_t n_iv = C->intv_off[C->n_host], k, nj = 0;
 		bsx_sa_job_t *sj;
-		C.ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
-		for (k = 0; k < n_iv; ++k) { C.ipos_off[k] = nj; nj += (int64_t)(C.intv[k].x[2] < opt->max_occ ? C.intv[k].x[2] : opt->max_occ); }
-		C.ipos_off[n_iv] = nj;
+		C->ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+		for (k = 0; k < n_iv; ++k) { C->ipos_off[k] = nj; nj += (int64_t)(C->intv[k].x[2] < opt->max_occ ? C->intv[k].x[2] : opt->max_occ); }
+		C->ipos_off[n_iv] = nj;
 		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
-		C.sa_jobs = sj;
-		bsx_parallel_for(nt, sa_jobs_worker, &C, C.n_host);
-		C.pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
-		rc = be->sa_batch(be->ctx, nj, sj, C.pos);
+		C->sa_jobs = sj;
+		bsx_parallel_for(nt, sa_jobs_worker, C, C->n_host);
+		C->pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+		rc = be->sa_batch(be->ctx, nj, sj, C->pos);
 		free(sj);
-		g_stats.n_sa = nj;
-		if (rc != BSX_OK) goto done;
+		C->st.n_sa = nj;
+		if (rc != BSX_OK) goto out;
 	}
-	g_stats.t_sa = now_s() - t0;
+	C->st.t_sa = now_s() - t0;
 
 	/* chaining (host); intervals that must be walked past max_occ get their remaining occurrences looked up */
 	t0 = now_s();
-	C.need_more = (int*)calloc((size_t)C.n_host + 1, sizeof(int));
-	C.xpos = (uint64_t**)calloc((size_t)C.n_host + 1, sizeof(uint64_t*));
-	C.xpos_off = (int64_t**)calloc((size_t)C.n_host + 1, sizeof(int64_t*));
-	C.trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
-	for (i = 0; i < nt; ++i) C.trees[i] = bsx_bt_new();
+	C->need_more = (int*)calloc((size_t)C->n_host + 1, sizeof(int));
+	C->xpos = (uint64_t**)calloc((size_t)C->n_host + 1, sizeof(uint64_t*));
+	C->xpos_off = (int64_t**)calloc((size_t)C->n_host + 1, sizeof(int64_t*));
+	C->trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
+	for (i = 0; i < nt; ++i) C->trees[i] = bsx_bt_new();
 	for (;;) {
 		int any = 0;
-		double tc0 = now_s();
-		bsx_parallel_for(nt, chain_worker, &C, C.n_host);
-		if (getenv("BSX_PHASES")) fprintf(stderr, "[M::chain] parallel pass %.3f s (%d threads)\n", now_s() - tc0, nt);
-		for (t = 0; t < C.n_host; ++t) {
+		bsx_parallel_for(nt, chain_worker, C, C->n_host);
+		for (t = 0; t < C->n_host; ++t) {
 			int n_iv, k, want;
 			int64_t nj, c;
 			bsx_sa_job_t *sj;
-			if (C.need_more[t] <= 0) continue;
+			if (C->need_more[t] <= 0) continue;
 			any = 1;
-			n_iv = (int)(C.intv_off[t + 1] - C.intv_off[t]);
-			want = C.need_more[t] - 1;
-			if (!C.xpos_off[t]) {
-				C.xpos_off[t] = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
-				for (k = 0; k <= n_iv; ++k) C.xpos_off[t][k] = C.ipos_off[C.intv_off[t] + k] - C.ipos_off[C.intv_off[t]];
+			n_iv = (int)(C->intv_off[t + 1] - C->intv_off[t]);
+			want = C->need_more[t] - 1;
+			if (!C->xpos_off[t]) {
+				C->xpos_off[t] = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+				for (k = 0; k <= n_iv; ++k) C->xpos_off[t][k] = C->ipos_off[C->intv_off[t] + k] - C->ipos_off[C->intv_off[t]];
 			}
 			{ /* give interval `want` all of its occurrences, keep the others */
 				int64_t *cnt = (int64_t*)malloc(sizeof(int64_t) * (size_t)n_iv);
-				for (k = 0; k < n_iv; ++k) cnt[k] = C.xpos_off[t][k + 1] - C.xpos_off[t][k];
-				cnt[want] = (int64_t)C.intv[C.intv_off[t] + want].x[2];
-				for (k = 0, nj = 0; k < n_iv; ++k) { C.xpos_off[t][k] = nj; nj += cnt[k]; }
-				C.xpos_off[t][n_iv] = nj;
+				for (k = 0; k < n_iv; ++k) cnt[k] = C->xpos_off[t][k + 1] - C->xpos_off[t][k];
+				cnt[want] = (int64_t)C->intv[C->intv_off[t] + want].x[2];
+				for (k = 0, nj = 0; k < n_iv; ++k) { C->xpos_off[t][k] = nj; nj += cnt[k]; }
+				C->xpos_off[t][n_iv] = nj;
 				free(cnt);
 			}
 			sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
 			for (k = 0; k < n_iv; ++k)
-				for (c = 0; c < C.xpos_off[t][k + 1] - C.xpos_off[t][k]; ++c) {
-					bsx_sa_job_t *j = &sj[C.xpos_off[t][k] + c];
-					j->k = C.intv[C.intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C.tasks[C.hmap[t]].parent; j->pad = 0;
+				for (c = 0; c < C->xpos_off[t][k + 1] - C->xpos_off[t][k]; ++c) {
+					bsx_sa_job_t *j = &sj[C->xpos_off[t][k] + c];
+					j->k = C->intv[C->intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C->tasks[C->hmap[t]].parent; j->pad = 0;
 				}
-			free(C.xpos[t]);
-			C.xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
-			rc = be->sa_batch(be->ctx, nj, sj, C.xpos[t]);
+			free(C->xpos[t]);
+			C->xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+			rc = be->sa_batch(be->ctx, nj, sj, C->xpos[t]);
 			free(sj);
-			g_stats.n_sa += nj;
-			if (rc != BSX_OK) goto done;
-			C.need_more[t] = 0;
+			C->st.n_sa += nj;
+			if (rc != BSX_OK) goto out;
+			C->need_more[t] = 0;
 		}
 		if (!any) break;
 	}
-	{ double tf0 = now_s(); CHECK(filter_chained_seeds(&C)); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::chain] seed filter %.3f s\n", now_s() - tf0); }
-	g_stats.t_chain = now_s() - t0;
+	rc = filter_chained_seeds(C);
+	if (rc != BSX_OK) goto out;
+	C->st.t_chain = now_s() - t0;
 
 	/* K4 rounds */
 	t0 = now_s();
-	CHECK(extension_rounds(&C));
-	g_stats.t_extend = now_s() - t0;
+	rc = extension_rounds(C);
+	C->st.t_extend = now_s() - t0;
+out:
+	free(decl_intv); free(decl_off);
+	return rc;
+}
 
-	/* merge */
+/* back half: per-read merge, insert-size statistics, mate rescue, pairing, CIGARs, SAM text (the rest of
+ * mem_process_seqs, lib/aln/bwamem.c:374-412) */
+static int chunk_back(chunk_t *C)
+{
+	const bsx_opt_t *opt = C->opt;
+	int rc = BSX_OK;
+	double t0;
+	bsx_arenas_bind(C->arena_set);
 	t0 = now_s();
-	C.regs = (reg_v*)calloc((size_t)n + 1, sizeof(reg_v));
-	CHECK(merge_regions(&C));
-	g_stats.t_merge = now_s() - t0;
-
-	if (C.is_pe) {
+	C->regs = (reg_v*)calloc((size_t)C->n + 1, sizeof(reg_v));
+	FCHECK(merge_regions(C));
+	C->st.t_merge = now_s() - t0;
+	if (C->is_pe) {
 		t0 = now_s();
-		if (pes0) C.pes = *pes0;
-		else C.pes = bsx_pestat(opt, &idx->ref, n, C.regs);
-		g_stats.t_pestat = now_s() - t0;
+		if (C->pes0) C->pes = *C->pes0;
+		else C->pes = bsx_pestat(opt, &C->idx->ref, C->n, C->regs);
+		C->st.t_pestat = now_s() - t0;
 		t0 = now_s();
-		if (!(opt->flag & BSX_F_NO_RESCUE)) CHECK(mate_rescue(&C));
-		g_stats.t_matesw = now_s() - t0;
+		if (!(opt->flag & BSX_F_NO_RESCUE)) FCHECK(mate_rescue(C));
+		C->st.t_matesw = now_s() - t0;
 	}
-	CHECK(emit_sam(&C));
+	return emit_sam(C);
+}
 
-done:
-	t0 = now_s();
-	if (C.tasks) { bsx_parallel_for(nt, release_worker, &C, C.n_tasks); free(C.tasks); }
-	if (C.regs) { bsx_parallel_for(nt, release_regs_worker, &C, n); free(C.regs); }
-	if (C.trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C.trees[i]); free(C.trees); }
-	free(C.roff); free(C.read_task0); free(C.intv); free(C.intv_off); free(C.pos); free(C.ipos_off);
-	for (t = 0; t < C.n_host; ++t) { if (C.xpos) free(C.xpos[t]); if (C.xpos_off) free(C.xpos_off[t]); }
-	free(C.need_more); free(C.xpos); free(C.xpos_off); free(stasks); free(buf);
-	free(C.hmap); free(C.dregs); free(C.dreg_off); free(C.dreg_n); free(decl_intv); free(decl_off);
-	bsx_arenas_end();
-	g_stats.t_cleanup = now_s() - t0;
-	g_stats.t_total = now_s() - t_all;
-	if (bsx_verbose >= 3)
-	{
-		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", n, g_stats.t_total, be->name ? be->name : "?");
+static void chunk_free(chunk_t *C)
+{
+	int i, t, nt = C->nt;
+	double t0 = now_s();
+	bsx_arenas_bind(C->arena_set);
+	if (C->tasks) { bsx_parallel_for(nt, release_worker, C, C->n_tasks); free(C->tasks); }
+	if (C->regs) { bsx_parallel_for(nt, release_regs_worker, C, C->n); free(C->regs); }
+	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); }
+	free(C->roff); free(C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
+	for (t = 0; t < C->n_host; ++t) { if (C->xpos) free(C->xpos[t]); if (C->xpos_off) free(C->xpos_off[t]); }
+	free(C->need_more); free(C->xpos); free(C->xpos_off); free(C->stasks); free(C->buf);
+	free(C->hmap); free(C->dregs); free(C->dreg_off); free(C->dreg_n);
+	bsx_arenas_end(C->arena_set);
+	C->st.t_cleanup = now_s() - t0;
+	C->st.t_total = now_s() - C->t_begin;
+	g_last_stats = C->st;
+	if (bsx_verbose >= 3) {
+		const bsx_phase_stats_t *S = &C->st;
+		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", C->n, S->t_total, C->be->name ? C->be->name : "?");
 		if (getenv("BSX_PHASES"))
 			fprintf(stderr, "[M::phases] regions %.3f (host tasks %ld) seed %.3f sa %.3f chain %.3f extend %.3f (%ld jobs, %ld rounds) merge %.3f pestat %.3f matesw %.3f primary %.3f cigar %.3f sam %.3f | tasks %ld intv %ld sa %ld sw %ld glb %ld\n",
-				g_stats.t_regions, (long)g_stats.n_host_tasks, g_stats.t_seed, g_stats.t_sa, g_stats.t_chain, g_stats.t_extend, (long)g_stats.n_ext_jobs, (long)g_stats.n_ext_rounds, g_stats.t_merge, g_stats.t_pestat,
-				g_stats.t_matesw, g_stats.t_primary, g_stats.t_cigar, g_stats.t_sam, (long)g_stats.n_tasks, (long)g_stats.n_intv, (long)g_stats.n_sa, (long)g_stats.n_sw_jobs, (long)g_stats.n_glb_jobs);
+				S->t_regions, (long)S->n_host_tasks, S->t_seed, S->t_sa, S->t_chain, S->t_extend, (long)S->n_ext_jobs, (long)S->n_ext_rounds, S->t_merge, S->t_pestat,
+				S->t_matesw, S->t_primary, S->t_cigar, S->t_sam, (long)S->n_tasks, (long)S->n_intv, (long)S->n_sa, (long)S->n_sw_jobs, (long)S->n_glb_jobs);
 	}
+	free(C);
+}
+
+/* ------------------------------------------------------------------ the chunk, synchronously (mem_process_seqs) */
+BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
+{
+	chunk_t *C;
+	int rc;
+	if (!be || !opt || !idx || n < 0) return BSX_E_ARG;
+	if (n == 0) return BSX_OK;
+	if ((opt->flag & BSX_F_PE) && (n & 1)) return BSX_E_ARG;
+	C = chunk_new(be, opt, idx, n_processed, n, reads, pes0);
+	rc = chunk_front(C);
+	if (rc == BSX_OK) rc = chunk_back(C);
+	chunk_free(C);
 	return rc;
 }
 
@@ -920,4 +968,96 @@ BSX_API int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_
 	int rc = bsx_hip_backend(dev, &be);   /* the HIP kernels are the only product backend */
 	if (rc != BSX_OK) return rc;
 	return bsx_process_seqs_backend(&be, opt, idx, n_processed, n, reads, pes0);
+}
+
+/* ------------------------------------------------------------------ chunks as a two-deep pipeline
+ * The reference overlaps reading, aligning and writing of consecutive chunks (kt_pipeline, lib/aln/align.c:100-170).
+ * Here the overlap that matters is inside the aligning step: the front half of a chunk is device-bound, the back
+ * half host-bound, so chunk k+1's front half runs (on its own device lane, from its own thread) while chunk k's
+ * back half runs on the caller's thread.  Chunks stay independent: each has its own insert-size statistics. */
+struct bsx_stream {
+	bsx_backend_t be[2];
+	const bsx_opt_t *opt; const bsx_index_t *idx;
+	bsx_pestat_t pes0; int has_pes0;
+	chunk_t *inflight;        /* front half running or done */
+	pthread_t th; int th_live;
+	int64_t n_pushed;
+};
+
+static void *front_thread(void *arg)
+{
+	chunk_t *C = (chunk_t*)arg;
+	C->rc = chunk_front(C);
+	bsx_arenas_bind(-1);
+	return 0;
+}
+
+BSX_API int bsx_stream_open_backends(const bsx_backend_t *be0, const bsx_backend_t *be1, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     const bsx_pestat_t *pes0, bsx_stream_t **out)
+{
+	bsx_stream_t *s;
+	if (!be0 || !be1 || !opt || !idx || !out) return BSX_E_ARG;
+	s = (bsx_stream_t*)calloc(1, sizeof(*s));
+	s->be[0] = *be0; s->be[1] = *be1; s->opt = opt; s->idx = idx;
+	if (pes0) { s->pes0 = *pes0; s->has_pes0 = 1; }
+	*out = s;
+	return BSX_OK;
+}
+
+BSX_API int bsx_stream_open(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes0, bsx_stream_t **out)
+{
+	bsx_backend_t b0, b1;
+	int rc;
+	if ((rc = bsx_hip_backend_lane(dev, 0, &b0)) != BSX_OK) return rc;
+	if ((rc = bsx_hip_backend_lane(dev, 1, &b1)) != BSX_OK) return rc;
+	return bsx_stream_open_backends(&b0, &b1, opt, idx, pes0, out);
+}
+
+/* finish the chunk in flight (its reads get their SAM text) */
+static int stream_drain(bsx_stream_t *s)
+{
+	chunk_t *C = s->inflight;
+	int rc;
+	if (!C) return BSX_OK;
+	if (s->th_live) { pthread_join(s->th, 0); s->th_live = 0; }
+	s->inflight = 0;
+	rc = C->rc;
+	if (rc == BSX_OK) rc = chunk_back(C);
+	chunk_free(C);
+	return rc;
+}
+
+BSX_API int bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_read_t *reads)
+{
+	chunk_t *prev, *C = 0;
+	int rc = BSX_OK, rc2;
+	if (!s || n < 0) return BSX_E_ARG;
+	if ((s->opt->flag & BSX_F_PE) && (n & 1)) return BSX_E_ARG;
+	/* the previous chunk's front half must be over before a new front half may start (one front thread) */
+	prev = s->inflight;
+	if (prev && s->th_live) { pthread_join(s->th, 0); s->th_live = 0; }
+	s->inflight = 0;
+	if (n > 0) {
+		C = chunk_new(&s->be[s->n_pushed & 1], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
+		++s->n_pushed;
+		if (pthread_create(&s->th, 0, front_thread, C) == 0) s->th_live = 1;
+		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); }
+	}
+	if (prev) {
+		rc = prev->rc;
+		if (rc == BSX_OK) rc = chunk_back(prev);
+		chunk_free(prev);
+	}
+	s->inflight = C;
+	if (rc != BSX_OK) { rc2 = stream_drain(s); (void)rc2; }
+	return rc;
+}
+
+BSX_API int bsx_stream_flush(bsx_stream_t *s) { return s ? stream_drain(s) : BSX_E_ARG; }
+
+BSX_API void bsx_stream_close(bsx_stream_t *s)
+{
+	if (!s) return;
+	(void)stream_drain(s);
+	free(s);
 }

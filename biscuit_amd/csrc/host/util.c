@@ -280,6 +280,7 @@ int bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids)
  * two per extension round), so threads are created once and parked on a condition variable. */
 typedef struct {
 	bsx_for_fn fn; void *data; long n; volatile long next; long grain; int n_part;
+	int arena_set;   /* of the calling thread: the workers allocate from the same chunk's arenas */
 } pf_job_t;
 
 static struct {
@@ -299,8 +300,12 @@ static struct {
 typedef struct { char *p; size_t cap; } arena_blk_t;
 struct bsx_arena { arena_blk_t *blk; int n_blk, m_blk, cur; size_t used; };
 BSX_API __thread bsx_arena_t *bsx_tls_arena = 0;
-static bsx_arena_t **g_arenas = 0;
-static int g_n_arenas = 0, g_arenas_on = 0;
+#define ARENA_SETS 2
+static bsx_arena_t **g_arenas[ARENA_SETS] = {0, 0};
+static int g_n_arenas[ARENA_SETS] = {0, 0}, g_set_busy[ARENA_SETS] = {0, 0};
+static pthread_mutex_t g_arena_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_arena_cv = PTHREAD_COND_INITIALIZER;
+static __thread int tls_arena_set = -1;
 
 void *bsx_arena_alloc(bsx_arena_t *a, size_t n)
 {
@@ -318,30 +323,48 @@ void *bsx_arena_alloc(bsx_arena_t *a, size_t n)
 	return q;
 }
 
-void bsx_arenas_begin(int n_threads)
+int bsx_arenas_begin(int n_threads)
 {
-	int i;
-	if (getenv("BSX_NO_ARENA")) return;
-	if (n_threads > g_n_arenas) {
-		g_arenas = (bsx_arena_t**)realloc(g_arenas, sizeof(bsx_arena_t*) * n_threads);
-		for (i = g_n_arenas; i < n_threads; ++i) g_arenas[i] = (bsx_arena_t*)calloc(1, sizeof(bsx_arena_t));
-		g_n_arenas = n_threads;
+	int i, set;
+	if (getenv("BSX_NO_ARENA")) return -1;
+	pthread_mutex_lock(&g_arena_mu);
+	for (;;) {
+		for (set = 0; set < ARENA_SETS; ++set) if (!g_set_busy[set]) break;
+		if (set < ARENA_SETS) break;
+		pthread_cond_wait(&g_arena_cv, &g_arena_mu);
 	}
-	g_arenas_on = 1;
-	bsx_tls_arena = g_arenas[0];
+	g_set_busy[set] = 1;
+	if (n_threads > g_n_arenas[set]) {
+		g_arenas[set] = (bsx_arena_t**)realloc(g_arenas[set], sizeof(bsx_arena_t*) * n_threads);
+		for (i = g_n_arenas[set]; i < n_threads; ++i) g_arenas[set][i] = (bsx_arena_t*)calloc(1, sizeof(bsx_arena_t));
+		g_n_arenas[set] = n_threads;
+	}
+	pthread_mutex_unlock(&g_arena_mu);
+	bsx_arenas_bind(set);
+	return set;
 }
 
-void bsx_arenas_end(void)
+void bsx_arenas_bind(int set)
+{
+	tls_arena_set = set;
+	bsx_tls_arena = set >= 0 ? g_arenas[set][0] : 0;
+}
+
+void bsx_arenas_end(int set)
 {
 	int i;
-	for (i = 0; i < g_n_arenas; ++i) { g_arenas[i]->cur = 0; g_arenas[i]->used = 0; }
-	g_arenas_on = 0;
-	bsx_tls_arena = 0;
+	bsx_arenas_bind(-1);
+	if (set < 0) return;
+	pthread_mutex_lock(&g_arena_mu);
+	for (i = 0; i < g_n_arenas[set]; ++i) { g_arenas[set][i]->cur = 0; g_arenas[set][i]->used = 0; }
+	g_set_busy[set] = 0;
+	pthread_cond_signal(&g_arena_cv);
+	pthread_mutex_unlock(&g_arena_mu);
 }
 
 static void pf_run(pf_job_t *J, int tid)
 {
-	bsx_tls_arena = (g_arenas_on && tid < g_n_arenas) ? g_arenas[tid] : 0;
+	bsx_tls_arena = (J->arena_set >= 0 && tid < g_n_arenas[J->arena_set]) ? g_arenas[J->arena_set][tid] : 0;
 	for (;;) {
 		long b = __sync_fetch_and_add(&J->next, J->grain), e, i;
 		if (b >= J->n) break;
@@ -388,7 +411,7 @@ void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
 		++g_pool.n_workers;
 	}
 	if (n_threads - 1 > g_pool.n_workers) n_threads = g_pool.n_workers + 1;
-	J.fn = fn; J.data = data; J.n = n; J.next = 0; J.n_part = n_threads;
+	J.fn = fn; J.data = data; J.n = n; J.next = 0; J.n_part = n_threads; J.arena_set = tls_arena_set;
 	J.grain = n / (n_threads * 8L); if (J.grain < 1) J.grain = 1; if (J.grain > 1024) J.grain = 1024;
 	g_pool.job = &J; g_pool.n_done = 0; ++g_pool.generation;
 	pthread_cond_broadcast(&g_pool.cv_work);
