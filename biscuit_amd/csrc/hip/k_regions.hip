@@ -56,7 +56,8 @@ struct RgStore {
 	int n_nodes, root;
 };
 typedef RgStore<64, 96, 96, 12, 0, unsigned char, signed char> RgSmall;
-typedef RgStore<512, 1024, 1024, 64, 1024, unsigned short, short> RgBig;
+typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
+typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 struct RgDp { int32_t H[RG_QCAP + 2], E[RG_QCAP + 2]; uint8_t qb[RG_QCAP + 4]; };   // ext_dp's rows, always LDS
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
@@ -638,7 +639,7 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 	return status;
 }
 
-// first tier: tables in LDS.  Tasks declined for table size go on retry_list for the second tier.
+// first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
 __global__ void __launch_bounds__(256, 3)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -664,41 +665,54 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 	}
 }
 
-// second tier: the same code over per-wave tables in HBM, for the strand searches of repeat-rich reads
+// second and third tier: the same code over per-wave tables in HBM, for the strand searches of repeat-rich reads.
+// `list` names the tasks (null: 0..*count-1); what this tier declines for table size goes on next_list.
+template <typename Store>
 __global__ void __launch_bounds__(256, 2)
-k_regions_big(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
-              const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
-              bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-              const int *retry_list, const unsigned int *retry_count, unsigned int *retry_cursor, RgBig *slabs)
+k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+               bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+               const int *list, const unsigned int *count, unsigned int *cursor, Store *slabs, int *next_list, unsigned int *next_count)
 {
 	__shared__ RgDp dp[4];
 	const int lane = wave_lane();
-	RgBig &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
+	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
 	RgDp &D = dp[threadIdx.x >> 6];
-	const int n = (int)*retry_count;
+	const int n = (int)*count;
 	for (;;) {
 		int i = 0;
-		if (lane == 0) i = (int)atomicAdd(retry_cursor, 1u);
+		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
 		i = uni(__shfl(i, 0));
 		if (i >= n) break;
-		const int t = uni(retry_list[i]);
+		const int t = list ? uni(list[i]) : i;
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
-		const int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane);
-		rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane);
+		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
+		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
 }
 
-size_t regions_big_slab_bytes() { return sizeof(RgBig); }
+size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
 
-void launch_regions(hipStream_t st, int grid, int big_grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *cursors, int *retry_list, void *slabs, int quota)
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota)
 {
-	// cursors: [0] task cursor, [1] retry count, [2] retry cursor
 	hipLaunchKernelGGL(k_regions, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, cursors, retry_list, cursors + 1, quota);
-	hipLaunchKernelGGL(k_regions_big, dim3(big_grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, retry_list, cursors + 1, cursors + 2, (RgBig*)slabs);
+	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota);
+}
+
+void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count)
+{
+	if (tier == 2)
+		hipLaunchKernelGGL(k_regions_slab<RgBig>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count);
+	else
+		hipLaunchKernelGGL(k_regions_slab<RgHuge>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count);
 }

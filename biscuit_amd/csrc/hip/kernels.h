@@ -17,9 +17,14 @@ void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const u
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                    long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
-// Two launches: LDS-resident tables, then the strand searches that did not fit over HBM slabs (big_grid * 4 of regions_big_slab_bytes()).
-size_t regions_big_slab_bytes();
-void launch_regions(hipStream_t st, int grid, int big_grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+// Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
+// regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.
+size_t regions_slab_bytes(int tier);
+void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *cursors, int *retry_list, void *slabs, int quota);
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota);
+void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count);

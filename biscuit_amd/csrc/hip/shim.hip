@@ -48,9 +48,10 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabflags;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	double k_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -89,6 +90,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest priority (numerically lower)
 		HIPCHK(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
+		HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
+		HIPCHK(hipEventCreate(&L.ev3));
 		if (L.slabflags.reserve((size_t)d->n_cu * 16 * 4) != BSX_OK) return BSX_E_NOMEM;
 		HIPCHK(hipMemset(L.slabflags.p, 0, (size_t)d->n_cu * 16 * 4));
 		HIPCHK(hipEventCreate(&L.ev0));
@@ -112,12 +115,14 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release();
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
 		if (L.ev1) (void)hipEventDestroy(L.ev1);
 		if (L.ev2) (void)hipEventDestroy(L.ev2);
 		if (L.st) (void)hipStreamDestroy(L.st);
 		if (L.st_hi) (void)hipStreamDestroy(L.st_hi);
+		if (L.st2) (void)hipStreamDestroy(L.st2);
+		if (L.ev3) (void)hipEventDestroy(L.ev3);
 	}
 	delete d;
 }
@@ -369,35 +374,100 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
 
 	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
-	const unsigned long long dense_cap = (unsigned long long)n * 24 + 4096, regs_cap = (unsigned long long)n * 2 + 4096;
+	const unsigned long long dense_cap = (unsigned long long)n * 24 + (1u << 20), regs_cap = (unsigned long long)n * 2 + 65536;
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota)) : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)n_slabs) + 3) / 4);
-	size_t lanes = (size_t)n_slabs * 64;
-	if ((rc = L.scratch.reserve(lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv))) != BSX_OK) return rc;
+	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv);
+	const int big_grid = d->n_cu * 2, huge_grid = 16;
+	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 16 + 64)) != BSX_OK) return rc;
-	const int big_grid = d->n_cu * 2;
-	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_big_slab_bytes())) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 20 + 64)) != BSX_OK) return rc;
+	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
+	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
-	int *retry = (int*)((char*)L.regmeta.p + (size_t)n * 12);
-	unsigned long long *ctr = dev_counters(L);   // [4] seed out cursor, [5] seed task cursor, [6] region out cursor, [7..8] region task/retry cursors (3 x u32)
+	int *retry_a = (int*)((char*)L.regmeta.p + (size_t)n * 12), *retry_b = (int*)((char*)L.regmeta.p + (size_t)n * 16);
+	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
+	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
+	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor
+	unsigned long long *ctr = dev_counters(L);
+	unsigned int *c32 = (unsigned int*)(ctr + 7);
+	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
+	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
 	HIPCHK(hipMemcpyAsync(L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st));
-	HIPCHK(hipMemsetAsync(ctr + 4, 0, 48, L.st));
+	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipEventRecord(L.ev0, L.st));
-	launch_seed(L.st, grid, d->ix, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)n, P,
+	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
 	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
-	launch_regions(L.st, rgrid, big_grid, d->ix, d->sc, R, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)n,
-	               (const DevIntv*)L.out.p, d_off, d_n, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, (unsigned int*)(ctr + 7), retry, L.slabs.p, reg_quota);
+	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
+	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota);
+	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3);
+	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr);
+
+	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats) are seeded again
+	// on the side stream with much longer lists, then go through the third tier as well.
+	std::vector<int64_t> redo;            // task indices
+	std::vector<long long> redo_off; std::vector<int> redo_n, redo_rn; std::vector<long long> redo_roff;
+	{
+		std::vector<int> s_n((size_t)n);
+		HIPCHK(hipEventSynchronize(L.ev1));
+		HIPCHK(hipMemcpy(s_n.data(), d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i);
+		if (redo.size() > 4096) redo.clear();   // not the rare case this is for: leave them to the caller
+	}
+	if (!redo.empty()) {
+		const size_t n2 = redo.size();
+		std::vector<bsx_seed_task_t> sub(n2);
+		for (size_t j = 0; j < n2; ++j) sub[j] = tasks[redo[j]];
+		redo_off.assign(n2, 0); redo_n.assign(n2, -1);
+		// device side: tasks2 | off2 | n2 | roff2 | rn2
+		if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 4 + 8 + 4) + 256)) != BSX_OK) return rc;
+		bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
+		long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; int *cnt2 = (int*)(roff2 + n2); int *rn2 = cnt2 + n2;
+		std::vector<size_t> cur(n2);
+		for (size_t j = 0; j < n2; ++j) cur[j] = j;
+		int cap2 = mem_cap * 64;
+		for (int round = 0; round < 3 && !cur.empty(); ++round, cap2 *= 8) {
+			const size_t m = cur.size(), per_lane = ((size_t)2 * list_cap + cap2) * sizeof(DevIntv);
+			const int g2 = (int)((m + 255) / 256);
+			if ((size_t)g2 * 256 * per_lane > scratch_bytes || g2 * 4 > n_slabs) break;   // would not fit the scratch we already hold
+			std::vector<bsx_seed_task_t> ss(m);
+			for (size_t j = 0; j < m; ++j) ss[j] = sub[cur[j]];
+			HIPCHK(hipMemcpyAsync(t2, ss.data(), m * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
+			HIPCHK(hipMemsetAsync(c32 + 7, 0, 4, L.st2));
+			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)m, P, (DevIntv*)L.scratch.p, list_cap, cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
+			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4);
+			std::vector<long long> ho(m); std::vector<int> hn(m);
+			HIPCHK(hipMemcpyAsync(ho.data(), off2, m * 8, hipMemcpyDeviceToHost, L.st2));
+			HIPCHK(hipMemcpyAsync(hn.data(), cnt2, m * 4, hipMemcpyDeviceToHost, L.st2));
+			HIPCHK(hipStreamSynchronize(L.st2));
+			std::vector<size_t> next;
+			for (size_t j = 0; j < m; ++j) { if (hn[j] < 0) next.push_back(cur[j]); else { redo_off[cur[j]] = ho[j]; redo_n[cur[j]] = hn[j]; } }
+			cur.swap(next);
+		}
+		const unsigned int n2u = (unsigned int)n2;
+		HIPCHK(hipMemcpyAsync(t2, sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
+		HIPCHK(hipMemcpyAsync(off2, redo_off.data(), n2 * 8, hipMemcpyHostToDevice, L.st2));
+		HIPCHK(hipMemcpyAsync(cnt2, redo_n.data(), n2 * 4, hipMemcpyHostToDevice, L.st2));
+		HIPCHK(hipMemcpyAsync(c32 + 5, &n2u, 4, hipMemcpyHostToDevice, L.st2));
+		HIPCHK(hipStreamSynchronize(L.st2));   // the host vectors above go out of scope; the region kernels keep running on L.st
+		launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr);
+		redo_roff.resize(n2); redo_rn.resize(n2);
+		HIPCHK(hipMemcpyAsync(redo_roff.data(), roff2, n2 * 8, hipMemcpyDeviceToHost, L.st));
+		HIPCHK(hipMemcpyAsync(redo_rn.data(), rn2, n2 * 4, hipMemcpyDeviceToHost, L.st));
+	}
 	HIPCHK(hipEventRecord(L.ev2, L.st));
 	{
 		float ms0 = 0, ms1 = 0;
@@ -414,6 +484,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipMemcpy(&used, ctr + 6, 8, hipMemcpyDeviceToHost));
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
+	for (size_t j = 0; j < redo.size(); ++j) { // what the redone strand searches produced; -1 = the caller seeds and chains it
+		out_off[redo[j]] = redo_roff[j];
+		out_n[redo[j]] = redo_rn[j] >= 0 ? redo_rn[j] : -1;
+	}
 	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	if (used) HIPCHK(hipMemcpy(*out, L.regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
 

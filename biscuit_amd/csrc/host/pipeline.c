@@ -328,66 +328,102 @@ static void merge_worker(void *data, long i, int tid)
 	}
 }
 
+/* exclusive prefix sum of per-item counts: off[0..n], returns the total */
+static int64_t prefix_counts(long n, const int *cnt, int64_t *off)
+{
+	long i; int64_t tot = 0;
+	for (i = 0; i < n; ++i) { off[i] = tot; tot += cnt[i]; }
+	off[n] = tot;
+	return tot;
+}
+
+typedef struct { merge_par_t *P; int *cnt; int64_t *off; bsx_glb_job_t *jobs; const bsx_glb_res_t *res; } merge_aux_t;
+
+static void merge_init_worker(void *data, long i, int tid)   /* concatenate the regions of the read's strand searches in call order */
+{
+	merge_par_t *P = (merge_par_t*)data;
+	chunk_t *C = P->C;
+	reg_v *r = &P->saved[i];
+	int t;
+	size_t tot = 0;
+	(void)tid;
+	P->ud[i].C = C; P->ud[i].read = (int)i;
+	for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
+	if (tot) { r->m = tot; r->a = (reg_t*)malloc(sizeof(reg_t) * r->m); }
+	for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
+		c2r_t *T = &C->tasks[t];
+		if (T->regs.n) { memcpy(r->a + r->n, T->regs.a, sizeof(reg_t) * T->regs.n); r->n += T->regs.n; }
+	}
+	P->pending[i] = 1;
+}
+static void merge_count_worker(void *data, long i, int tid)
+{
+	merge_aux_t *A = (merge_aux_t*)data;
+	(void)tid;
+	A->cnt[i] = A->P->pending[i] ? (int)A->P->ud[i].wanted.n : 0;
+}
+static void merge_jobs_worker(void *data, long i, int tid)
+{
+	merge_aux_t *A = (merge_aux_t*)data;
+	chunk_t *C = A->P->C;
+	int k;
+	(void)tid;
+	for (k = 0; k < A->cnt[i]; ++k) {
+		const gcache_t *g = &A->P->ud[i].wanted.a[k];
+		bsx_glb_job_t j;
+		int rev = g->rb >= C->idx->ref.l_pac;
+		memset(&j, 0, sizeof(j));
+		j.qlen = g->qe - g->qb; j.tlen = (int32_t)(g->re - g->rb);
+		j.qoff = C->roff[i] + (uint32_t)(rev ? g->qe - 1 : g->qb); j.qdir = rev ? -1 : 1;
+		j.tpos = rev ? g->re - 1 : g->rb; j.tdir = rev ? -1 : 1;
+		j.w0 = g->w; j.w_max = g->w > C->opt->w << 2 ? g->w : C->opt->w << 2; j.n_try = 1; j.use_ct = (uint8_t)g->parent; j.want_cigar = 0;
+		A->jobs[A->off[i] + k] = j;
+	}
+}
+static void merge_scores_worker(void *data, long i, int tid)
+{
+	merge_aux_t *A = (merge_aux_t*)data;
+	int k;
+	(void)tid;
+	for (k = 0; k < A->cnt[i]; ++k) { gcache_t g = A->P->ud[i].wanted.a[k]; g.score = A->res[A->off[i] + k].score; bsx_vec_push(A->P->ud[i].cache, g); }
+}
+static void merge_free_worker(void *data, long i, int tid)
+{
+	merge_par_t *P = (merge_par_t*)data;
+	(void)tid;
+	bsx_vec_free(P->ud[i].cache); bsx_vec_free(P->ud[i].wanted); free(P->saved[i].a);
+}
+
 static int merge_regions(chunk_t *C)
 {
-	int n = C->n, i, rc = BSX_OK, round;
+	int n = C->n, rc = BSX_OK, round;
 	merge_par_t P;
-	BSX_VEC(bsx_glb_job_t) jobs;
-	BSX_VEC(int) jowner;
+	merge_aux_t A;
 	P.C = C;
 	P.ud = (merge_ud_t*)calloc(n ? n : 1, sizeof(merge_ud_t));
 	P.saved = (reg_v*)calloc(n ? n : 1, sizeof(reg_v));
 	P.pending = (int*)malloc(sizeof(int) * (n ? n : 1));
-	bsx_vec_init(jobs); bsx_vec_init(jowner);
-	for (i = 0; i < n; ++i) { /* concatenate the regions of the read's strand searches in call order */
-		int t;
-		reg_v *r = &P.saved[i];
-		P.ud[i].C = C; P.ud[i].read = i;
-		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
-			c2r_t *T = &C->tasks[t];
-			if (T->regs.n) {
-				if (r->m < r->n + T->regs.n) { r->m = (r->n + T->regs.n) * 2; r->a = (reg_t*)realloc(r->a, sizeof(reg_t) * r->m); }
-				memcpy(r->a + r->n, T->regs.a, sizeof(reg_t) * T->regs.n);
-				r->n += T->regs.n;
-			}
-		}
-		P.pending[i] = 1;
-	}
+	A.P = &P; A.cnt = (int*)malloc(sizeof(int) * ((size_t)n + 1)); A.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n + 1));
+	bsx_parallel_for(C->nt, merge_init_worker, &P, n);
 	for (round = 0; round < 64; ++round) {
 		bsx_glb_res_t *res;
-		size_t k;
+		int64_t nj;
 		bsx_parallel_for(C->nt, merge_worker, &P, n);
-		jobs.n = 0; jowner.n = 0;
-		for (i = 0; i < n; ++i) {
-			if (!P.pending[i]) continue;
-			for (k = 0; k < P.ud[i].wanted.n; ++k) {
-				const gcache_t *g = &P.ud[i].wanted.a[k];
-				bsx_glb_job_t j;
-				int rev = g->rb >= C->idx->ref.l_pac;
-				memset(&j, 0, sizeof(j));
-				j.qlen = g->qe - g->qb; j.tlen = (int32_t)(g->re - g->rb);
-				j.qoff = C->roff[i] + (uint32_t)(rev ? g->qe - 1 : g->qb); j.qdir = rev ? -1 : 1;
-				j.tpos = rev ? g->re - 1 : g->rb; j.tdir = rev ? -1 : 1;
-				j.w0 = g->w; j.w_max = g->w > C->opt->w << 2 ? g->w : C->opt->w << 2; j.n_try = 1; j.use_ct = (uint8_t)g->parent; j.want_cigar = 0;
-				bsx_vec_push(jobs, j); bsx_vec_push(jowner, i);
-			}
-		}
-		if (jobs.n == 0) break;
-		res = (bsx_glb_res_t*)malloc(sizeof(*res) * jobs.n);
-		rc = C->be->global_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res, 0, 0);
-		C->st.n_glb_jobs += (int64_t)jobs.n;
-		if (rc == BSX_OK) {
-			size_t cur = 0;
-			for (i = 0; i < n; ++i) {
-				if (!P.pending[i]) continue;
-				for (k = 0; k < P.ud[i].wanted.n; ++k) { gcache_t g = P.ud[i].wanted.a[k]; g.score = res[cur++].score; bsx_vec_push(P.ud[i].cache, g); }
-			}
-		}
-		free(res);
+		bsx_parallel_for(C->nt, merge_count_worker, &A, n);
+		nj = prefix_counts(n, A.cnt, A.off);
+		if (nj == 0) break;
+		A.jobs = (bsx_glb_job_t*)malloc(sizeof(bsx_glb_job_t) * (size_t)nj);
+		res = (bsx_glb_res_t*)malloc(sizeof(*res) * (size_t)nj);
+		bsx_parallel_for(C->nt, merge_jobs_worker, &A, n);
+		rc = C->be->global_batch(C->be->ctx, nj, A.jobs, res, 0, 0);
+		C->st.n_glb_jobs += nj;
+		A.res = res;
+		if (rc == BSX_OK) bsx_parallel_for(C->nt, merge_scores_worker, &A, n);
+		free(res); free(A.jobs);
 		if (rc != BSX_OK) break;
 	}
-	for (i = 0; i < n; ++i) { bsx_vec_free(P.ud[i].cache); bsx_vec_free(P.ud[i].wanted); free(P.saved[i].a); }
-	free(P.ud); free(P.saved); free(P.pending); bsx_vec_free(jobs); bsx_vec_free(jowner);
+	bsx_parallel_for(C->nt, merge_free_worker, &P, n);
+	free(P.ud); free(P.saved); free(P.pending); free(A.cnt); free(A.off);
 	return rc;
 }
 
@@ -480,42 +516,75 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 	return missing;
 }
 
-typedef struct { chunk_t *C; msw_pair_t *M; } msw_par_t;
+typedef struct { chunk_t *C; msw_pair_t *M; int *cnt; int64_t *off; bsx_sw_job_t *jobs; const bsx_sw_res_t *res; } msw_par_t;
 static void msw_worker(void *data, long pi, int tid)
 {
 	msw_par_t *P = (msw_par_t*)data;
 	(void)tid;
 	if (P->M[pi].pending) P->M[pi].pending = matesw_replay(P->C, &P->M[pi], (int)pi);
 }
+static void msw_init_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	(void)tid;
+	regs_copy(&P->M[pi].saved[0], &P->C->regs[pi << 1]); regs_copy(&P->M[pi].saved[1], &P->C->regs[pi << 1 | 1]); P->M[pi].pending = 1;
+}
+static void msw_count_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	size_t k; int c = 0;
+	(void)tid;
+	if (P->M[pi].pending) for (k = 0; k < P->M[pi].slots.n; ++k) c += !P->M[pi].slots.a[k].have;
+	P->cnt[pi] = c;
+}
+static void msw_jobs_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	size_t k; int64_t at = P->off[pi];
+	(void)tid;
+	if (P->cnt[pi]) for (k = 0; k < P->M[pi].slots.n; ++k) if (!P->M[pi].slots.a[k].have) P->jobs[at++] = P->M[pi].slots.a[k].job;
+}
+static void msw_results_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	size_t k; int64_t at = P->off[pi];
+	(void)tid;
+	if (P->cnt[pi]) for (k = 0; k < P->M[pi].slots.n; ++k) if (!P->M[pi].slots.a[k].have) { P->M[pi].slots.a[k].res = P->res[at++]; P->M[pi].slots.a[k].have = 1; }
+}
+static void msw_free_worker(void *data, long pi, int tid)
+{
+	msw_par_t *P = (msw_par_t*)data;
+	(void)tid;
+	free(P->M[pi].saved[0].a); free(P->M[pi].saved[1].a); bsx_vec_free(P->M[pi].slots);
+}
 
 static int mate_rescue(chunk_t *C)
 {
-	int np = C->n >> 1, pi, rc = BSX_OK, round;
+	int np = C->n >> 1, rc = BSX_OK, round;
 	msw_pair_t *M = (msw_pair_t*)calloc(np ? np : 1, sizeof(msw_pair_t));
 	msw_par_t P;
-	BSX_VEC(bsx_sw_job_t) jobs;
-	bsx_vec_init(jobs);
-	for (pi = 0; pi < np; ++pi) { regs_copy(&M[pi].saved[0], &C->regs[pi << 1]); regs_copy(&M[pi].saved[1], &C->regs[pi << 1 | 1]); M[pi].pending = 1; }
 	P.C = C; P.M = M;
+	P.cnt = (int*)malloc(sizeof(int) * ((size_t)np + 1)); P.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)np + 1));
+	bsx_parallel_for(C->nt, msw_init_worker, &P, np);
 	for (round = 0; round < 256; ++round) {
 		bsx_sw_res_t *res;
-		size_t k, cur;
+		int64_t nj;
 		bsx_parallel_for(C->nt, msw_worker, &P, np);
-		jobs.n = 0;
-		for (pi = 0; pi < np; ++pi)
-			if (M[pi].pending) for (k = 0; k < M[pi].slots.n; ++k) if (!M[pi].slots.a[k].have) bsx_vec_push(jobs, M[pi].slots.a[k].job);
-		if (jobs.n == 0) break;
-		res = (bsx_sw_res_t*)malloc(sizeof(*res) * jobs.n);
-		rc = C->be->sw_batch(C->be->ctx, (int64_t)jobs.n, jobs.a, res);
-		C->st.n_sw_jobs += (int64_t)jobs.n;
-		if (rc == BSX_OK)
-			for (pi = 0, cur = 0; pi < np; ++pi)
-				if (M[pi].pending) for (k = 0; k < M[pi].slots.n; ++k) if (!M[pi].slots.a[k].have) { M[pi].slots.a[k].res = res[cur++]; M[pi].slots.a[k].have = 1; }
-		free(res);
+		bsx_parallel_for(C->nt, msw_count_worker, &P, np);
+		nj = prefix_counts(np, P.cnt, P.off);
+		if (nj == 0) break;
+		P.jobs = (bsx_sw_job_t*)malloc(sizeof(bsx_sw_job_t) * (size_t)nj);
+		res = (bsx_sw_res_t*)malloc(sizeof(*res) * (size_t)nj);
+		bsx_parallel_for(C->nt, msw_jobs_worker, &P, np);
+		rc = C->be->sw_batch(C->be->ctx, nj, P.jobs, res);
+		C->st.n_sw_jobs += nj;
+		P.res = res;
+		if (rc == BSX_OK) bsx_parallel_for(C->nt, msw_results_worker, &P, np);
+		free(res); free(P.jobs);
 		if (rc != BSX_OK) break;
 	}
-	for (pi = 0; pi < np; ++pi) { free(M[pi].saved[0].a); free(M[pi].saved[1].a); bsx_vec_free(M[pi].slots); }
-	free(M); bsx_vec_free(jobs);
+	bsx_parallel_for(C->nt, msw_free_worker, &P, np);
+	free(M); free(P.cnt); free(P.off);
 	return rc;
 }
 
@@ -581,52 +650,85 @@ static void finish_worker(void *data, long k, int tid)
 	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]]);
 }
 
+typedef struct { chunk_t *C; samctx_t *ctx; int per; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg; } plan_par_t;
+static void plan_count_worker(void *data, long u, int tid)
+{
+	plan_par_t *Q = (plan_par_t*)data;
+	int w, c = 0;
+	(void)tid;
+	for (w = 0; w < Q->per; ++w) c += (int)Q->ctx[u].want[w].n;
+	Q->cnt[u] = c;
+}
+static void plan_jobs_worker(void *data, long u, int tid)
+{
+	plan_par_t *Q = (plan_par_t*)data;
+	chunk_t *C = Q->C;
+	int w; size_t k; int64_t at = Q->off[u];
+	(void)tid;
+	for (w = 0; w < Q->per; ++w) {
+		int ri = (int)u * Q->per + w;
+		reg_v *regs = &C->regs[ri];
+		Q->ctx[u].table[w] = (samrec_t*)calloc(regs->n ? regs->n : 1, sizeof(samrec_t));
+		for (k = 0; k < Q->ctx[u].want[w].n; ++k, ++at) {
+			int gi = Q->ctx[u].want[w].a[k];
+			bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &Q->jobs[at]);
+			Q->jobs[at].cigar_cap = 24;
+			Q->jread[at] = ri; Q->jreg[at] = gi;
+		}
+	}
+}
+static void plan_free_worker(void *data, long u, int tid)
+{
+	plan_par_t *Q = (plan_par_t*)data;
+	int w; size_t k;
+	(void)tid;
+	for (w = 0; w < Q->per; ++w) {
+		reg_v *regs = &Q->C->regs[u * Q->per + w];
+		if (Q->ctx[u].table[w]) for (k = 0; k < regs->n; ++k) free(Q->ctx[u].table[w][k].cigar);
+		free(Q->ctx[u].table[w]); bsx_vec_free(Q->ctx[u].want[w]);
+	}
+}
+
 static int emit_sam(chunk_t *C)
 {
-	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, u, w, rc = BSX_OK, round;
+	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, rc = BSX_OK, round;
 	samctx_t *ctx = (samctx_t*)calloc(n_units ? n_units : 1, sizeof(samctx_t));
 	out_par_t P;
-	BSX_VEC(bsx_glb_job_t) jobs;
-	BSX_VEC(int) jread, jreg, todo;
-	bsx_glb_res_t *res = 0;
+	plan_par_t Q;
+	BSX_VEC(int) todo;
 	uint32_t *pool = 0;
 	size_t k, pool_len = 0;
+	int64_t n_jobs;
 	double t0 = now_s();
-	bsx_vec_init(jobs); bsx_vec_init(jread); bsx_vec_init(jreg); bsx_vec_init(todo);
+	bsx_vec_init(todo);
 	P.C = C; P.ctx = ctx; P.final_pass = 0;
 	bsx_parallel_for(C->nt, out_worker, &P, n_units);
 	C->st.t_primary += now_s() - t0; t0 = now_s();
-	for (u = 0; u < n_units; ++u)
-		for (w = 0; w < per; ++w) {
-			int ri = u * per + w;
-			reg_v *regs = &C->regs[ri];
-			ctx[u].table[w] = (samrec_t*)calloc(regs->n ? regs->n : 1, sizeof(samrec_t));
-			for (k = 0; k < ctx[u].want[w].n; ++k) {
-				bsx_glb_job_t j;
-				int gi = ctx[u].want[w].a[k];
-				bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &j);
-				j.cigar_cap = 24;
-				bsx_vec_push(jobs, j); bsx_vec_push(jread, ri); bsx_vec_push(jreg, gi);
-			}
-		}
-	res = (bsx_glb_res_t*)malloc(sizeof(*res) * (jobs.n ? jobs.n : 1));
-	for (k = 0; k < jobs.n; ++k) bsx_vec_push(todo, (int)k);
+	Q.C = C; Q.ctx = ctx; Q.per = per;
+	Q.cnt = (int*)malloc(sizeof(int) * ((size_t)n_units + 1)); Q.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_units + 1));
+	bsx_parallel_for(C->nt, plan_count_worker, &Q, n_units);
+	n_jobs = prefix_counts(n_units, Q.cnt, Q.off);
+	Q.jobs = (bsx_glb_job_t*)malloc(sizeof(bsx_glb_job_t) * (size_t)(n_jobs ? n_jobs : 1));
+	Q.jread = (int*)malloc(sizeof(int) * (size_t)(n_jobs ? n_jobs : 1)); Q.jreg = (int*)malloc(sizeof(int) * (size_t)(n_jobs ? n_jobs : 1));
+	bsx_parallel_for(C->nt, plan_jobs_worker, &Q, n_units);
+	bsx_vec_reserve(todo, (size_t)n_jobs + 1);
+	for (k = 0; k < (size_t)n_jobs; ++k) todo.a[k] = (int)k;
+	todo.n = (size_t)n_jobs;
 	for (round = 0; round < 8 && todo.n && rc == BSX_OK; ++round) { /* a CIGAR that does not fit is redone with the room it asked for */
 		bsx_glb_job_t *sub = (bsx_glb_job_t*)malloc(sizeof(*sub) * todo.n);
 		bsx_glb_res_t *sres = (bsx_glb_res_t*)malloc(sizeof(*sres) * todo.n);
 		size_t off = 0, nt = 0;
-		for (k = 0; k < todo.n; ++k) { sub[k] = jobs.a[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
+		for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
 		rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
 		C->st.n_glb_jobs += (int64_t)todo.n;
 		if (rc == BSX_OK) {
 			finish_par_t F;
-			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = jread.a; F.jreg = jreg.a; F.sub = sub; F.sres = sres; F.pool = pool;
+			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = Q.jread; F.jreg = Q.jreg; F.sub = sub; F.sres = sres; F.pool = pool;
 			bsx_parallel_for(C->nt, finish_worker, &F, (long)todo.n);
 			for (k = 0; k < todo.n; ++k) {
 				int jj = todo.a[k];
-				res[jj] = sres[k];
-				if (sres[k].n_cigar < 0) { jobs.a[jj].cigar_cap = (uint32_t)(-sres[k].n_cigar) + 2; todo.a[nt++] = jj; }
+				if (sres[k].n_cigar < 0) { Q.jobs[jj].cigar_cap = (uint32_t)(-sres[k].n_cigar) + 2; todo.a[nt++] = jj; }
 			}
 		}
 		todo.n = nt;
@@ -636,15 +738,10 @@ static int emit_sam(chunk_t *C)
 	C->st.t_cigar += now_s() - t0; t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
-	for (u = 0; u < n_units; ++u)
-		for (w = 0; w < per; ++w) {
-			reg_v *regs = &C->regs[u * per + w];
-			for (k = 0; k < regs->n; ++k) free(ctx[u].table[w][k].cigar);
-			free(ctx[u].table[w]); bsx_vec_free(ctx[u].want[w]);
-		}
+	bsx_parallel_for(C->nt, plan_free_worker, &Q, n_units);
 	C->st.t_sam += now_s() - t0;
-	free(ctx); free(res); free(pool);
-	bsx_vec_free(jobs); bsx_vec_free(jread); bsx_vec_free(jreg); bsx_vec_free(todo);
+	free(ctx); free(pool); free(Q.cnt); free(Q.off); free(Q.jobs); free(Q.jread); free(Q.jreg);
+	bsx_vec_free(todo);
 	return rc;
 }
 
@@ -815,6 +912,13 @@ static int chunk_front(chunk_t *C)
 		for (t = n_reseed; t <= C->n_host; ++t) C->intv_off[t] = base + decl_off[t - n_reseed];
 	}
 	C->st.t_seed = now_s() - t0; C->st.n_intv = C->intv_off[C->n_host];
+	if (getenv("BSX_PHASES") && be->regions_batch)
+		for (t = 0; t < C->n_host && t < 80; ++t) {
+			int64_t k, occ = 0, big = 0;
+			for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k) { occ += (int64_t)(C->intv[k].x[2] < (uint64_t)opt->max_occ ? C->intv[k].x[2] : (uint64_t)opt->max_occ); big += C->intv[k].x[2] > (uint64_t)opt->max_occ; }
+			fprintf(stderr, "[M::declined] task %d status %d len %d: %ld intervals, %ld occurrences (capped), %ld intervals beyond max_occ\n", C->hmap[t], C->dreg_n[C->hmap[t]],
+			        C->tasks[C->hmap[t]].l_query, (long)(C->intv_off[t + 1] - C->intv_off[t]), (long)occ, (long)big);
+		}
 
 	/* K3: the first min(occ, max_occ) occurrences of every interval */
 	t0 = now_s();
