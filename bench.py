@@ -123,6 +123,8 @@ def main():
     phase_tot = {}
     barrier()
     torch.cuda.synchronize()
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
     def account():
         ps = B.PhaseStats()
@@ -145,6 +147,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
     sam_bytes = sum(L.bsx_sim_sam_bytes(chunks[s], n_reads) for s in range(args.warmup, args.warmup + args.steps))
 
     tmax, tot_reads = dt, n_reads * args.steps
@@ -188,6 +191,7 @@ def main():
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(6)},
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // args.steps, "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // args.steps,
             "host_phase_s_per_step": {k: round(v / args.steps, 4) for k, v in phase_tot.items() if k.startswith("t_")},
+            "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "index_build_s": round(t_build, 1), "device": dev.name,
         }

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <vector>
 extern "C" {
@@ -54,6 +55,8 @@ struct Lane {
 	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
+	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
+	hipEvent_t pev[2] = {nullptr, nullptr};
 	double k_ms[6] = {0, 0, 0, 0, 0, 0};
 	int64_t k_launch[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -92,6 +95,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
 		HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
 		HIPCHK(hipEventCreate(&L.ev3));
+		HIPCHK(hipEventCreateWithFlags(&L.pev[0], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&L.pev[1], hipEventDisableTiming));
 		if (L.slabflags.reserve((size_t)d->n_cu * 16 * 4) != BSX_OK) return BSX_E_NOMEM;
 		HIPCHK(hipMemset(L.slabflags.p, 0, (size_t)d->n_cu * 16 * 4));
 		HIPCHK(hipEventCreate(&L.ev0));
@@ -115,7 +120,9 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release();
+		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
+		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
 		if (L.ev1) (void)hipEventDestroy(L.ev1);
 		if (L.ev2) (void)hipEventDestroy(L.ev2);
@@ -175,6 +182,48 @@ extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o)
 	return BSX_OK;
 }
 
+// Large copies between pageable host memory and the device go through two pinned halves, copy and DMA overlapped:
+// handing pageable memory to hipMemcpy makes the runtime pin and unpin the user pages on every call, which costs
+// more system time per chunk than the copies themselves.  Synchronous: complete on return.
+#define XFER_CHUNK ((size_t)8 << 20)
+static int xfer(Lane &L, hipStream_t st, void *dst, const void *src, size_t n, bool h2d)
+{
+	if (n == 0) return BSX_OK;
+	if (n < ((size_t)256 << 10)) {
+		HIPCHK(hipMemcpyAsync(dst, src, n, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		return BSX_OK;
+	}
+	int rc;
+	if ((rc = L.pin.reserve(2 * XFER_CHUNK)) != BSX_OK) return rc;
+	char *pin = (char*)L.pin.p;
+	size_t off = 0, prev_off = 0, prev_m = 0;
+	int i = 0;
+	for (; off < n; off += XFER_CHUNK, ++i) {
+		const size_t m = std::min(XFER_CHUNK, n - off);
+		char *p = pin + (size_t)(i & 1) * XFER_CHUNK;
+		if (h2d) {
+			if (i >= 2) HIPCHK(hipEventSynchronize(L.pev[i & 1]));   // the DMA that last read this half is done
+			memcpy(p, (const char*)src + off, m);
+			HIPCHK(hipMemcpyAsync((char*)dst + off, p, m, hipMemcpyHostToDevice, st));
+			HIPCHK(hipEventRecord(L.pev[i & 1], st));
+		} else {
+			HIPCHK(hipMemcpyAsync(p, (const char*)src + off, m, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipEventRecord(L.pev[i & 1], st));
+			if (i >= 1) { // drain the previous half while this one is in flight
+				HIPCHK(hipEventSynchronize(L.pev[(i - 1) & 1]));
+				memcpy((char*)dst + prev_off, pin + (size_t)((i - 1) & 1) * XFER_CHUNK, prev_m);
+			}
+			prev_off = off; prev_m = m;
+		}
+	}
+	HIPCHK(hipStreamSynchronize(st));
+	if (!h2d) memcpy((char*)dst + prev_off, pin + (size_t)((i - 1) & 1) * XFER_CHUNK, prev_m);
+	return BSX_OK;
+}
+#define H2D(st, dst, src, n) do { int rc_ = xfer(L, st, dst, src, n, true); if (rc_ != BSX_OK) return rc_; } while (0)
+#define D2H(st, dst, src, n) do { int rc_ = xfer(L, st, dst, src, n, false); if (rc_ != BSX_OK) return rc_; } while (0)
+
 static int lane_set_reads(bsx_device_t *d, int lane, const uint8_t *buf, size_t n)
 {
 	if (!d) return BSX_E_ARG;
@@ -182,8 +231,7 @@ static int lane_set_reads(bsx_device_t *d, int lane, const uint8_t *buf, size_t 
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc;
 	if ((rc = L.reads.reserve(n + 64)) != BSX_OK) return rc;
-	if (n) HIPCHK(hipMemcpyAsync(L.reads.p, buf, n, hipMemcpyHostToDevice, L.st));
-	HIPCHK(hipStreamSynchronize(L.st));
+	H2D(L.st, L.reads.p, buf, n);
 	L.n_reads = n;
 	return BSX_OK;
 }
@@ -400,7 +448,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	unsigned int *c32 = (unsigned int*)(ctr + 7);
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
 	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
-	HIPCHK(hipMemcpyAsync(L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st));
+	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
@@ -417,15 +465,19 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 
 	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats) are seeded again
 	// on the side stream with much longer lists, then go through the third tier as well.
+	const bool trace = getenv("BSX_PHASES") != nullptr;
+	struct timespec ts0, ts1, ts2, ts3;
+	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	std::vector<int64_t> redo;            // task indices
 	std::vector<long long> redo_off; std::vector<int> redo_n, redo_rn; std::vector<long long> redo_roff;
 	{
 		std::vector<int> s_n((size_t)n);
 		HIPCHK(hipEventSynchronize(L.ev1));
-		HIPCHK(hipMemcpy(s_n.data(), d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+		D2H(L.st2, s_n.data(), d_n, (size_t)n * 4);
 		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i);
 		if (redo.size() > 4096) redo.clear();   // not the rare case this is for: leave them to the caller
 	}
+	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	if (!redo.empty()) {
 		const size_t n2 = redo.size();
 		std::vector<bsx_seed_task_t> sub(n2);
@@ -468,10 +520,15 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipMemcpyAsync(redo_roff.data(), roff2, n2 * 8, hipMemcpyDeviceToHost, L.st));
 		HIPCHK(hipMemcpyAsync(redo_rn.data(), rn2, n2 * 4, hipMemcpyDeviceToHost, L.st));
 	}
+	clock_gettime(CLOCK_MONOTONIC, &ts2);
 	HIPCHK(hipEventRecord(L.ev2, L.st));
 	{
 		float ms0 = 0, ms1 = 0;
 		HIPCHK(hipEventSynchronize(L.ev2));
+		clock_gettime(CLOCK_MONOTONIC, &ts3);
+		if (trace) fprintf(stderr, "[M::regions_batch] seed kernel done +%.0f ms | redo of %zu strand searches enqueued +%.0f ms | all region tiers done +%.0f ms\n",
+		                   (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, redo.size(), (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6,
+		                   (ts3.tv_sec - ts0.tv_sec) * 1e3 + (ts3.tv_nsec - ts0.tv_nsec) * 1e-6);
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
 		HIPCHK(hipEventElapsedTime(&ms1, L.ev1, L.ev2));
 		L.k_ms[0] += ms0; L.k_launch[0] += 1; L.k_ms[5] += ms1; L.k_launch[5] += 1;
@@ -479,8 +536,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	}
 	unsigned long long used = 0;
 	std::vector<long long> h_off((size_t)n);
-	HIPCHK(hipMemcpy(h_off.data(), r_off, (size_t)n * 8, hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(out_n, r_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+	D2H(L.st, h_off.data(), r_off, (size_t)n * 8);
+	D2H(L.st, out_n, r_n, (size_t)n * 4);
 	HIPCHK(hipMemcpy(&used, ctr + 6, 8, hipMemcpyDeviceToHost));
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
@@ -489,7 +546,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		out_n[redo[j]] = redo_rn[j] >= 0 ? redo_rn[j] : -1;
 	}
 	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
-	if (used) HIPCHK(hipMemcpy(*out, L.regs.p, (size_t)used * sizeof(bsx_region_t), hipMemcpyDeviceToHost));
+	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
 	// declined tasks: hand their interval lists back (ordered by info, as bsx_seed_batch returns them)
 	std::vector<int64_t> decl;
@@ -497,8 +554,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	decl_off[0] = 0;
 	if (!decl.empty()) {
 		std::vector<long long> s_off((size_t)n); std::vector<int> s_n((size_t)n);
-		HIPCHK(hipMemcpy(s_off.data(), d_off, (size_t)n * 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(s_n.data(), d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+		D2H(L.st, s_off.data(), d_off, (size_t)n * 8);
+		D2H(L.st, s_n.data(), d_n, (size_t)n * 4);
 		int64_t tot = 0;
 		for (size_t j = 0; j < decl.size(); ++j) { decl_off[j] = tot; tot += s_n[decl[j]]; }
 		decl_off[decl.size()] = tot;
@@ -615,10 +672,10 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t), hipMemcpyHostToDevice, L.st_hi));
+	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t));
 	size_t off = 0;
 	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st_hi));
+		H2D(L.st_hi, (int*)L.aux.p + off, order[c].data(), order[c].size() * 4);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
@@ -632,7 +689,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
 	if ((rc = finish_timed(L, 3)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_sw_res_t), hipMemcpyDeviceToHost));
+	D2H(L.st_hi, res, L.res.p, (size_t)n * sizeof(bsx_sw_res_t));
 	return BSX_OK;
 }
 
@@ -682,10 +739,10 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	if ((rc = L.scratch.reserve(ztot + 256)) != BSX_OK) return rc;
 	if ((rc = L.pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t), hipMemcpyHostToDevice, L.st_hi));
+	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t));
 	size_t off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st_hi));
+		H2D(L.st_hi, (int*)L.aux.p + off, order[c].data(), order[c].size() * 4);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
@@ -698,8 +755,8 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
 	if ((rc = finish_timed(L, 4)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_glb_res_t), hipMemcpyDeviceToHost));
-	if (cigar_pool_len) HIPCHK(hipMemcpy(cigar_pool, L.pool.p, cigar_pool_len * 4, hipMemcpyDeviceToHost));
+	D2H(L.st_hi, res, L.res.p, (size_t)n * sizeof(bsx_glb_res_t));
+	D2H(L.st_hi, cigar_pool, L.pool.p, cigar_pool_len * 4);
 	return BSX_OK;
 }
 

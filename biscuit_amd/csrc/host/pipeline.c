@@ -103,6 +103,7 @@ typedef struct {
 	bsx_backend_t be_copy;
 	const bsx_pestat_t *pes0; bsx_pestat_t pes0_copy;
 	int arena_set, rc;
+	pthread_t th; int th_live;   /* the thread running the front half (stream mode) */
 	double t_begin;
 	bsx_phase_stats_t st;
 } chunk_t;
@@ -770,7 +771,7 @@ static void setup_worker(void *data, long i, int tid)
 	for (k = 0; k < no; ++k) {
 		int t = C->read_task0[i] + k;
 		c2r_t *T = &C->tasks[t];
-		memset(T, 0, sizeof(*T));
+		memset(T, 0, C2R_HEADER_BYTES);
 		T->read_idx = (int)i; T->parent = order[k]; T->qoff = C->roff[i]; T->l_query = C->reads[i].l_seq; T->query = C->reads[i].seq;
 		C->stasks[t].qoff = T->qoff; C->stasks[t].len = T->l_query; C->stasks[t].parent = T->parent;
 	}
@@ -792,8 +793,10 @@ static void release_worker(void *data, long t, int tid)
 {
 	chunk_t *C = (chunk_t*)data;
 	(void)tid;
-	bsx_c2r_release(&C->tasks[t]); bsx_cvec_free(C->tasks[t].regs);
+	bsx_cvec_free(C->tasks[t].regs);
 }
+static void release_host_worker(void *data, long h, int tid) { chunk_t *C = (chunk_t*)data; (void)tid; bsx_c2r_release(&C->tasks[C->hmap[h]]); }
+static void init_host_worker(void *data, long h, int tid) { chunk_t *C = (chunk_t*)data; (void)tid; bsx_c2r_init(&C->tasks[C->hmap[h]]); }
 
 /* regions the device produced -> the task's region list (every other mem_alnreg_t field is still zero here) */
 static void adopt_worker(void *data, long t, int tid)
@@ -898,6 +901,7 @@ static int chunk_front(chunk_t *C)
 		C->n_host = n_reseed = C->n_tasks;
 	}
 	C->st.t_regions = now_s() - t0; C->st.n_host_tasks = C->n_host;
+	bsx_parallel_for(nt, init_host_worker, C, C->n_host);
 
 	/* K1+K2 */
 	t0 = now_s();
@@ -1027,7 +1031,11 @@ static void chunk_free(chunk_t *C)
 	int i, t, nt = C->nt;
 	double t0 = now_s();
 	bsx_arenas_bind(C->arena_set);
-	if (C->tasks) { bsx_parallel_for(nt, release_worker, C, C->n_tasks); free(C->tasks); }
+	if (C->tasks) {
+		if (C->hmap) bsx_parallel_for(nt, release_host_worker, C, C->n_host);
+		if (C->arena_set < 0) bsx_parallel_for(nt, release_worker, C, C->n_tasks);   /* arena memory is rewound, not freed */
+		free(C->tasks);
+	}
 	if (C->regs) { bsx_parallel_for(nt, release_regs_worker, C, C->n); free(C->regs); }
 	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); }
 	free(C->roff); free(C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
@@ -1084,7 +1092,6 @@ struct bsx_stream {
 	const bsx_opt_t *opt; const bsx_index_t *idx;
 	bsx_pestat_t pes0; int has_pes0;
 	chunk_t *inflight;        /* front half running or done */
-	pthread_t th; int th_live;
 	int64_t n_pushed;
 };
 
@@ -1117,14 +1124,11 @@ BSX_API int bsx_stream_open(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_i
 	return bsx_stream_open_backends(&b0, &b1, opt, idx, pes0, out);
 }
 
-/* finish the chunk in flight (its reads get their SAM text) */
-static int stream_drain(bsx_stream_t *s)
+/* wait for the chunk's front half, run its back half (its reads get their SAM text), release it */
+static int chunk_finish(chunk_t *C)
 {
-	chunk_t *C = s->inflight;
 	int rc;
-	if (!C) return BSX_OK;
-	if (s->th_live) { pthread_join(s->th, 0); s->th_live = 0; }
-	s->inflight = 0;
+	if (C->th_live) { pthread_join(C->th, 0); C->th_live = 0; }
 	rc = C->rc;
 	if (rc == BSX_OK) rc = chunk_back(C);
 	chunk_free(C);
@@ -1134,27 +1138,30 @@ static int stream_drain(bsx_stream_t *s)
 BSX_API int bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_read_t *reads)
 {
 	chunk_t *prev, *C = 0;
-	int rc = BSX_OK, rc2;
+	int rc = BSX_OK;
 	if (!s || n < 0) return BSX_E_ARG;
 	if ((s->opt->flag & BSX_F_PE) && (n & 1)) return BSX_E_ARG;
-	/* the previous chunk's front half must be over before a new front half may start (one front thread) */
 	prev = s->inflight;
-	if (prev && s->th_live) { pthread_join(s->th, 0); s->th_live = 0; }
 	s->inflight = 0;
+	/* the new chunk's front half starts right away, on the other device lane: the tail of the previous front half
+	 * (a few straggling strand searches being seeded again) leaves the device almost idle */
 	if (n > 0) {
 		C = chunk_new(&s->be[s->n_pushed & 1], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
 		++s->n_pushed;
-		if (pthread_create(&s->th, 0, front_thread, C) == 0) s->th_live = 1;
+		if (pthread_create(&C->th, 0, front_thread, C) == 0) C->th_live = 1;
 		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); }
 	}
-	if (prev) {
-		rc = prev->rc;
-		if (rc == BSX_OK) rc = chunk_back(prev);
-		chunk_free(prev);
-	}
+	if (prev) rc = chunk_finish(prev);
 	s->inflight = C;
-	if (rc != BSX_OK) { rc2 = stream_drain(s); (void)rc2; }
+	if (rc != BSX_OK && C) { s->inflight = 0; (void)chunk_finish(C); }
 	return rc;
+}
+
+static int stream_drain(bsx_stream_t *s)
+{
+	chunk_t *C = s->inflight;
+	s->inflight = 0;
+	return C ? chunk_finish(C) : BSX_OK;
 }
 
 BSX_API int bsx_stream_flush(bsx_stream_t *s) { return s ? stream_drain(s) : BSX_E_ARG; }

@@ -6,20 +6,24 @@
 
 /* one strand search (mem_align1_core call, lib/aln/bwamem.c:183-208) being turned into regions */
 typedef struct {
+	/* header: every strand search */
 	int read_idx, parent;
 	uint32_t qoff;            /* of the clipped read in the chunk read buffer */
 	int l_query;
 	const uint8_t *query;     /* clipped raw read on the host */
 	chain_v chains;
 	BSX_VEC(reg_t) regs;
-	/* state machine (extend.c) */
+	int has_job, done;
+	/* state machine (extend.c): only touched for the strand searches the host chains itself (bsx_c2r_init) */
 	int ci, chain_open, pass, n0;
 	uint64_t *srt; int n_srt, m_srt, k;
 	int stage, tryi;
 	int64_t rmax[2]; int rid;
 	reg_t cur; int aw[2]; int sc0;
-	bsx_ext_job_t job; int has_job, done;
+	bsx_ext_job_t job;
 } c2r_t;
+#define C2R_HEADER_BYTES offsetof(c2r_t, ci)
+static inline void bsx_c2r_init(c2r_t *t) { memset((char*)t + C2R_HEADER_BYTES, 0, sizeof(c2r_t) - C2R_HEADER_BYTES); }
 
 int  bsx_c2r_advance(const bsx_opt_t *opt, const bsx_index_t *idx, c2r_t *t);
 void bsx_c2r_consume(const bsx_opt_t *opt, const bsx_index_t *idx, c2r_t *t, const bsx_ext_res_t *res);

@@ -217,48 +217,71 @@ static int cal_sub(const bsx_opt_t *opt, const reg_v *regs)   /* mem_pair.c:42-5
 }
 
 /* mem_pestat, mem_pair.c:60-144 (messages go to stderr at verbosity >= 3 like the reference) */
+typedef struct { const bsx_opt_t *opt; const bsx_refmeta_t *ref; const reg_v *regs; int32_t *is; } pes_par_t;
+#define PES_NONE INT32_MIN
+static void pes_worker(void *data, long i, int tid)   /* the pair's insert size if both ends are unique enough (mem_pair.c:68-84) */
+{
+	pes_par_t *P = (pes_par_t*)data;
+	const reg_v *r0 = &P->regs[i << 1 | 0], *r1 = &P->regs[i << 1 | 1];
+	const reg_t *b0, *b1;
+	int64_t is;
+	(void)tid;
+	P->is[i] = PES_NONE;
+	if (r0->n == 0 || r1->n == 0) return;
+	b0 = &r0->a[0]; b1 = &r1->a[0];
+	if (cal_sub(P->opt, r0) > MIN_RATIO * b0->score) return;
+	if (cal_sub(P->opt, r1) > MIN_RATIO * b1->score) return;
+	if (b0->rid != b1->rid) return;
+	if (b0->bss != b1->bss) return;
+	if (bsx_reg_isize(P->ref, b0, b1, &is))
+		if (is <= P->opt->max_ins && is >= -P->opt->max_ins) P->is[i] = (int32_t)is;
+}
+
+/* mem_pestat.  The reference sorts the insert sizes and walks the sorted array; they are integers in
+ * [-max_ins, max_ins], so a histogram gives the same sorted sequence, and the sums below are taken over it
+ * value by value in ascending order exactly as the reference's loops do. */
 bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, const reg_v *regs)
 {
-	BSX_VEC(int64_t) isize;
 	bsx_pestat_t pes;
-	int i, x, p25, p50, p75;
-	bsx_vec_init(isize);
-	for (i = 0; i < n >> 1; ++i) {
-		const reg_v *r0 = &regs[i << 1 | 0], *r1 = &regs[i << 1 | 1];
-		const reg_t *b0, *b1;
-		int64_t is;
-		if (r0->n == 0 || r1->n == 0) continue;
-		b0 = &r0->a[0]; b1 = &r1->a[0];
-		if (cal_sub(opt, r0) > MIN_RATIO * b0->score) continue;
-		if (cal_sub(opt, r1) > MIN_RATIO * b1->score) continue;
-		if (b0->rid != b1->rid) continue;
-		if (b0->bss != b1->bss) continue;
-		if (bsx_reg_isize(ref, b0, b1, &is))
-			if (is <= opt->max_ins && is >= -opt->max_ins) bsx_vec_push(isize, is);
-	}
-	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] # candidate unique pairs: %ld\n", "mem_pestat", (long)isize.n);
+	pes_par_t P;
+	int64_t *hist, tot = 0, c, want[3], cum;
+	int i, x, p25 = 0, p50 = 0, p75 = 0, np = n >> 1, nb = 2 * opt->max_ins + 1, q;
+	long j;
 	memset(&pes, 0, sizeof(pes));
-	if (isize.n < MIN_DIR_CNT) {
+	if (opt->max_ins < 0) { pes.failed = 1; return pes; }
+	P.opt = opt; P.ref = ref; P.regs = regs; P.is = (int32_t*)malloc(sizeof(int32_t) * (size_t)(np ? np : 1));
+	bsx_parallel_for(bsx_host_threads(opt), pes_worker, &P, np);
+	hist = (int64_t*)calloc((size_t)nb, sizeof(int64_t));
+	for (i = 0; i < np; ++i) if (P.is[i] != PES_NONE) { ++hist[P.is[i] + opt->max_ins]; ++tot; }
+	free(P.is);
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] # candidate unique pairs: %ld\n", "mem_pestat", (long)tot);
+	if (tot < MIN_DIR_CNT) {
 		fprintf(stderr, "[M:%s] There are not enough pairs for insert size inference\n", "mem_pestat");
-		bsx_vec_free(isize);
+		free(hist);
 		pes.failed = 1;
 		return pes;
 	}
-	bsx_introsort_i64(isize.n, isize.a);
-	p25 = (int)isize.a[(int)(.25 * isize.n + .499)];
-	p50 = (int)isize.a[(int)(.50 * isize.n + .499)];
-	p75 = (int)isize.a[(int)(.75 * isize.n + .499)];
+	/* element k of the sorted array, for the three percentile positions */
+	want[0] = (int)(.25 * tot + .499); want[1] = (int)(.50 * tot + .499); want[2] = (int)(.75 * tot + .499);
+	for (i = 0, cum = 0, q = 0; i < nb && q < 3; ++i) {
+		cum += hist[i];
+		while (q < 3 && want[q] < cum) { int v = i - opt->max_ins; if (q == 0) p25 = v; else if (q == 1) p50 = v; else p75 = v; ++q; }
+	}
 	pes.low  = (int)(p25 - OUTLIER_BOUND * (p75 - p25) + .499);
 	pes.high = (int)(p75 + OUTLIER_BOUND * (p75 - p25) + .499);
 	if (bsx_verbose >= 3) {
 		fprintf(stderr, "[M::%s] (25, 50, 75) percentile: (%d, %d, %d)\n", "mem_pestat", p25, p50, p75);
 		fprintf(stderr, "[M::%s] low and high boundaries for computing mean and std.dev: (%d, %d)\n", "mem_pestat", pes.low, pes.high);
 	}
-	for (i = x = 0, pes.avg = 0; (size_t)i < isize.n; ++i)
-		if (isize.a[i] >= pes.low && isize.a[i] <= pes.high) { pes.avg += isize.a[i]; ++x; }
+	for (i = 0, x = 0, pes.avg = 0; i < nb; ++i) {
+		int v = i - opt->max_ins;
+		if (v >= pes.low && v <= pes.high) for (c = 0; c < hist[i]; ++c) { pes.avg += v; ++x; }
+	}
 	pes.avg /= x;
-	for (i = 0, pes.std = 0; (size_t)i < isize.n; ++i)
-		if (isize.a[i] >= pes.low && isize.a[i] <= pes.high) pes.std += (isize.a[i] - pes.avg) * (isize.a[i] - pes.avg);
+	for (i = 0, pes.std = 0; i < nb; ++i) {
+		int v = i - opt->max_ins;
+		if (v >= pes.low && v <= pes.high) for (j = 0; j < hist[i]; ++j) pes.std += (v - pes.avg) * (v - pes.avg);
+	}
 	pes.std = sqrt(pes.std / x);
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] mean and std.dev: (%.2f, %.2f)\n", "mem_pestat", pes.avg, pes.std);
 	pes.low  = (int)(p25 - MAPPING_BOUND * (p75 - p25) + .499);
@@ -266,7 +289,7 @@ bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, c
 	if (pes.low > pes.avg - MAX_STDDEV * pes.std) pes.low = (int)(pes.avg - MAX_STDDEV * pes.std + .499);
 	if (pes.high < pes.avg + MAX_STDDEV * pes.std) pes.high = (int)(pes.avg + MAX_STDDEV * pes.std + .499);
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] low and high boundaries for proper pairs: (%d, %d)\n", "mem_pestat", pes.low, pes.high);
-	bsx_vec_free(isize);
+	free(hist);
 	return pes;
 }
 

@@ -8,6 +8,9 @@
  * permutation -- is the same.  Pinned against the reference templates in tests/test_host_primitives.py.
  */
 #include <pthread.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <malloc.h>
 #include "bsx_core.h"
 
@@ -377,6 +380,9 @@ static void *pf_worker(void *arg)
 {
 	int id = (int)(intptr_t)arg;   /* participates as tid id+1 */
 	long seen = 0;
+	/* the workers yield to the threads that feed the device (the front half of the next chunk, the HIP runtime's
+	 * own threads) when there are fewer cores than runnable threads */
+	{ const char *e = getenv("BSX_WORKER_NICE"); int nv = e ? atoi(e) : 5; if (nv > 0) setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nv); }
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
 		pf_job_t *J;
