@@ -106,8 +106,11 @@ def main():
     L.bsx_stream_close.argtypes = [C.c_void_p]
     L.bsx_stream_close.restype = None
     stream = C.c_void_p()
+    depth = 1
     if not args.no_pipeline:
         B.check(L.bsx_stream_open(dev.h, C.byref(opt), idx.h, None, C.byref(stream)), "stream_open")
+        L.bsx_stream_depth.argtypes = [C.c_void_p]
+        depth = L.bsx_stream_depth(stream)
     n_processed = 0
     for s in range(args.warmup):
         if args.no_pipeline:
@@ -131,6 +134,7 @@ def main():
         L.bsx_last_phase_stats(C.byref(ps))
         for f, _ in B.PhaseStats._fields_:
             phase_tot[f] = phase_tot.get(f, 0) + getattr(ps, f)
+        phase_tot["_chunks"] = phase_tot.get("_chunks", 0) + 1
 
     for s in range(args.warmup, args.warmup + args.steps):
         if args.no_pipeline:
@@ -138,12 +142,12 @@ def main():
             account()
         else:
             B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push")
-            if s > args.warmup:
-                account()       # the push completed the previous chunk
+            if s - args.warmup >= depth - 1:
+                account()       # the push completed the chunk pushed depth-1 pushes ago
         n_processed += n_reads
     if not args.no_pipeline:
-        B.check(L.bsx_stream_flush(stream), "stream_flush")   # the last chunk completes inside the timed region
-        account()
+        B.check(L.bsx_stream_flush(stream), "stream_flush")   # the chunks still in flight complete inside the timed region
+        account()               # (the statistics of the last one stand in for the others drained with it)
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
@@ -184,13 +188,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "2x%d bp synthetic directional bisulfite pairs vs a synthetic %.0f Mbp genome with repeat families "
                                    "(stand-in for BASELINE configs[1]: hg38 is not available offline), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp),
-                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world, "chunk_pipeline_depth": 1 if args.no_pipeline else 2,
+                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world, "chunk_pipeline_depth": depth,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(6)},
-            "strand_searches_per_step": phase_tot.get("n_tasks", 0) // args.steps, "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // args.steps,
-            "host_phase_s_per_step": {k: round(v / args.steps, 4) for k, v in phase_tot.items() if k.startswith("t_")},
+            "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
+            "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "index_build_s": round(t_build, 1), "device": dev.name,

@@ -45,7 +45,7 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 
 // One lane = one HIP stream with its own staging: a chunk is bound to a lane for its whole life, so the front half
 // (seeding .. regions) of one chunk and the back half (merge .. SAM) of the previous one can be in flight together.
-#define BSX_LANES 2
+#define BSX_LANES 4
 struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs

@@ -162,12 +162,12 @@ typedef struct bsx_backend {
 BSX_API int bsx_process_seqs_backend(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
                                      int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
-/* HIP backend constructors (csrc/hip/shim.hip): lane = one of the device's two independent streams + staging sets */
+/* HIP backend constructors (csrc/hip/shim.hip): lane = one of the device's independent stream + staging sets */
 int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out);          /* lane 0 */
 int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *out);
 /* the chunk pipeline over two arbitrary backends (tests run it over two CPU-restatement contexts) */
-BSX_API int bsx_stream_open_backends(const bsx_backend_t *be0, const bsx_backend_t *be1, const bsx_opt_t *opt, const bsx_index_t *idx,
-                                     const bsx_pestat_t *pes0, bsx_stream_t **out);
+BSX_API int bsx_stream_open_backends(int depth, const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
+                                     const bsx_pestat_t *pes0, bsx_stream_t **out);   /* be[depth]: one backend context per chunk in flight */
 
 /* per-phase wall-clock accounting of the last bsx_process_seqs* call (seconds) */
 typedef struct {

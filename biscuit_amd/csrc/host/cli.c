@@ -159,9 +159,28 @@ static void classify(int n, bsx_read_t *seqs, int m[2], bsx_read_t *sep[2])
 	if (bsx_verbose >= 3) fprintf(stderr, "[%s] %d SE sequences; %d PE sequences\n", "bseq_classify", m[0], m[1]);
 }
 
+/* set by the product entry: chunks go through bsx_stream_* on the device `ud` names instead of one at a time */
+static int g_use_stream = 0;
+
 typedef int (*process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
 /* shared by the product entry (HIP) and the test-only entry that injects another backend */
+/* write out (or hand to the hook) the SAM text of a finished chunk and release its reads */
+static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok)
+{
+	int i;
+	if (ok && bsx_emit_hook) {
+		size_t tot = 0, at = 0; char *all;
+		for (i = 0; i < n; ++i) if (seqs[i].sam) tot += strlen(seqs[i].sam);
+		all = (char*)malloc(tot + 1);
+		for (i = 0; i < n; ++i) if (seqs[i].sam) { size_t l = strlen(seqs[i].sam); memcpy(all + at, seqs[i].sam, l); at += l; }
+		bsx_emit_hook(bsx_emit_ud, chunk_idx, all, tot);
+		free(all);
+	}
+	for (i = 0; i < n; ++i) { if (ok && !bsx_emit_hook && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
+	free(seqs);
+}
+
 BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void *ud, int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud))
 {
 	bsx_opt_t opt_, opt0, *opt = &opt_;
@@ -337,6 +356,15 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 		/* $BSX_CHUNK_SIZE overrides the per-thread chunk size (tests only; the reference's is fixed at 10 Mbp) */
 		int chunk = (getenv("BSX_CHUNK_SIZE") ? atoi(getenv("BSX_CHUNK_SIZE")) : opt->chunk_size) * opt->n_threads, done_cmdline = 0;
 		int64_t chunk_idx = -1;
+		/* pipelined mode: chunks in flight, oldest first (the reference's kt_pipeline keeps reading/aligning/writing
+		 * of consecutive chunks in flight the same way, align.c:165-170) */
+		struct { bsx_read_t *seqs; int n; int64_t idx; } pend[8];
+		int n_pend = 0, depth = 1;
+		bsx_stream_t *stream = 0;
+		if (g_use_stream && !(opt->flag & BSX_F_SMARTPE)) {
+			if ((rc = bsx_stream_open((bsx_device_t*)ud, opt, idx, pes0, &stream)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); return 1; }
+			depth = bsx_stream_depth(stream);
+		}
 		for (;;) {
 			int n = 0;
 			bsx_read_t *seqs = 0;
@@ -377,20 +405,28 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				if (m[0]) { tmp.flag &= ~BSX_F_PE; rc = process(ud, &tmp, idx, n_processed, m[0], sep[0], 0); for (i = 0; i < m[0] && rc == 0; ++i) seqs[sep[0][i].id] = sep[0][i]; }
 				if (m[1] && rc == 0) { tmp.flag |= BSX_F_PE; rc = process(ud, &tmp, idx, n_processed + m[0], m[1], sep[1], pes0); for (i = 0; i < m[1] && rc == 0; ++i) seqs[sep[1][i].id] = sep[1][i]; }
 				free(sep[0]); free(sep[1]);
+			} else if (stream) {
+				rc = bsx_stream_push(stream, n_processed, n, seqs);
+				pend[n_pend].seqs = seqs; pend[n_pend].n = n; pend[n_pend].idx = chunk_idx; ++n_pend;
+				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+				n_processed += n;
+				while (rc == 0 && n_pend > depth - 1) { /* the push completed the oldest chunk in flight */
+					emit_chunk(pend[0].seqs, pend[0].n, pend[0].idx, 1);
+					for (i = 1; i < n_pend; ++i) pend[i - 1] = pend[i];
+					--n_pend;
+				}
+				if (rc) break;
+				continue;
 			} else rc = process(ud, opt, idx, n_processed, n, seqs, pes0);
 			if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
 			n_processed += n;
-			if (rc == 0 && bsx_emit_hook) {
-				size_t tot = 0, at = 0; char *all;
-				for (i = 0; i < n; ++i) if (seqs[i].sam) tot += strlen(seqs[i].sam);
-				all = (char*)malloc(tot + 1);
-				for (i = 0; i < n; ++i) if (seqs[i].sam) { size_t l = strlen(seqs[i].sam); memcpy(all + at, seqs[i].sam, l); at += l; }
-				bsx_emit_hook(bsx_emit_ud, chunk_idx, all, tot);
-				free(all);
-			}
-			for (i = 0; i < n; ++i) { if (rc == 0 && !bsx_emit_hook && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
-			free(seqs);
+			emit_chunk(seqs, n, chunk_idx, rc == 0);
 			if (rc) break;
+		}
+		if (stream) {
+			if (rc == 0 && (rc = bsx_stream_flush(stream)) != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+			for (i = 0; i < n_pend; ++i) emit_chunk(pend[i].seqs, pend[i].n, pend[i].idx, rc == 0);
+			bsx_stream_close(stream);
 		}
 	}
 	fflush(stdout);
@@ -418,5 +454,6 @@ static int hip_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, i
 
 BSX_API int bsx_align_main(int argc, char **argv)
 {
+	g_use_stream = getenv("BSX_NO_STREAM") ? 0 : 1;
 	return bsx_align_main_with(argc, argv, hip_process, 0, hip_open);
 }

@@ -1087,11 +1087,13 @@ BSX_API int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_
  * Here the overlap that matters is inside the aligning step: the front half of a chunk is device-bound, the back
  * half host-bound, so chunk k+1's front half runs (on its own device lane, from its own thread) while chunk k's
  * back half runs on the caller's thread.  Chunks stay independent: each has its own insert-size statistics. */
+#define STREAM_MAX_DEPTH 4
 struct bsx_stream {
-	bsx_backend_t be[2];
+	bsx_backend_t be[STREAM_MAX_DEPTH];
+	int depth;                /* chunks in flight: depth-1 front halves ahead of the back half being run */
 	const bsx_opt_t *opt; const bsx_index_t *idx;
 	bsx_pestat_t pes0; int has_pes0;
-	chunk_t *inflight;        /* front half running or done */
+	chunk_t *q[STREAM_MAX_DEPTH]; int n_q;   /* in flight, oldest first */
 	int64_t n_pushed;
 };
 
@@ -1103,13 +1105,15 @@ static void *front_thread(void *arg)
 	return 0;
 }
 
-BSX_API int bsx_stream_open_backends(const bsx_backend_t *be0, const bsx_backend_t *be1, const bsx_opt_t *opt, const bsx_index_t *idx,
+BSX_API int bsx_stream_open_backends(int depth, const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx,
                                      const bsx_pestat_t *pes0, bsx_stream_t **out)
 {
 	bsx_stream_t *s;
-	if (!be0 || !be1 || !opt || !idx || !out) return BSX_E_ARG;
+	int i;
+	if (!be || !opt || !idx || !out || depth < 1 || depth > STREAM_MAX_DEPTH) return BSX_E_ARG;
 	s = (bsx_stream_t*)calloc(1, sizeof(*s));
-	s->be[0] = *be0; s->be[1] = *be1; s->opt = opt; s->idx = idx;
+	for (i = 0; i < depth; ++i) s->be[i] = be[i];
+	s->depth = depth; s->opt = opt; s->idx = idx;
 	if (pes0) { s->pes0 = *pes0; s->has_pes0 = 1; }
 	*out = s;
 	return BSX_OK;
@@ -1117,12 +1121,15 @@ BSX_API int bsx_stream_open_backends(const bsx_backend_t *be0, const bsx_backend
 
 BSX_API int bsx_stream_open(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes0, bsx_stream_t **out)
 {
-	bsx_backend_t b0, b1;
-	int rc;
-	if ((rc = bsx_hip_backend_lane(dev, 0, &b0)) != BSX_OK) return rc;
-	if ((rc = bsx_hip_backend_lane(dev, 1, &b1)) != BSX_OK) return rc;
-	return bsx_stream_open_backends(&b0, &b1, opt, idx, pes0, out);
+	bsx_backend_t b[STREAM_MAX_DEPTH];
+	const char *e = getenv("BSX_STREAM_DEPTH");
+	int rc, i, depth = e ? atoi(e) : 3;
+	if (depth < 1) depth = 1;
+	if (depth > STREAM_MAX_DEPTH) depth = STREAM_MAX_DEPTH;
+	for (i = 0; i < depth; ++i) if ((rc = bsx_hip_backend_lane(dev, i, &b[i])) != BSX_OK) return rc;
+	return bsx_stream_open_backends(depth, b, opt, idx, pes0, out);
 }
+BSX_API int bsx_stream_depth(const bsx_stream_t *s) { return s ? s->depth : 0; }
 
 /* wait for the chunk's front half, run its back half (its reads get their SAM text), release it */
 static int chunk_finish(chunk_t *C)
@@ -1137,31 +1144,37 @@ static int chunk_finish(chunk_t *C)
 
 BSX_API int bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_read_t *reads)
 {
-	chunk_t *prev, *C = 0;
-	int rc = BSX_OK;
+	int rc = BSX_OK, i;
 	if (!s || n < 0) return BSX_E_ARG;
 	if ((s->opt->flag & BSX_F_PE) && (n & 1)) return BSX_E_ARG;
-	prev = s->inflight;
-	s->inflight = 0;
-	/* the new chunk's front half starts right away, on the other device lane: the tail of the previous front half
-	 * (a few straggling strand searches being seeded again) leaves the device almost idle */
+	/* the new chunk's front half starts right away on a free device lane: the tail of a front half (a few straggling
+	 * strand searches being seeded again) leaves the device almost idle, and the host is busy with an older chunk */
 	if (n > 0) {
-		C = chunk_new(&s->be[s->n_pushed & 1], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
+		chunk_t *C = chunk_new(&s->be[s->n_pushed % s->depth], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
 		++s->n_pushed;
 		if (pthread_create(&C->th, 0, front_thread, C) == 0) C->th_live = 1;
 		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); }
+		s->q[s->n_q++] = C;
 	}
-	if (prev) rc = chunk_finish(prev);
-	s->inflight = C;
-	if (rc != BSX_OK && C) { s->inflight = 0; (void)chunk_finish(C); }
+	while (s->n_q > (n > 0 ? s->depth - 1 : 0) && rc == BSX_OK) { /* complete the oldest: its lane is the next push's */
+		rc = chunk_finish(s->q[0]);
+		for (i = 1; i < s->n_q; ++i) s->q[i - 1] = s->q[i];
+		--s->n_q;
+	}
+	if (rc != BSX_OK) { while (s->n_q) (void)chunk_finish(s->q[--s->n_q]); }
 	return rc;
 }
 
 static int stream_drain(bsx_stream_t *s)
 {
-	chunk_t *C = s->inflight;
-	s->inflight = 0;
-	return C ? chunk_finish(C) : BSX_OK;
+	int rc = BSX_OK, rc2, i;
+	while (s->n_q) {
+		rc2 = chunk_finish(s->q[0]);
+		if (rc == BSX_OK) rc = rc2;
+		for (i = 1; i < s->n_q; ++i) s->q[i - 1] = s->q[i];
+		--s->n_q;
+	}
+	return rc;
 }
 
 BSX_API int bsx_stream_flush(bsx_stream_t *s) { return s ? stream_drain(s) : BSX_E_ARG; }

@@ -303,9 +303,9 @@ static struct {
 typedef struct { char *p; size_t cap; } arena_blk_t;
 struct bsx_arena { arena_blk_t *blk; int n_blk, m_blk, cur; size_t used; };
 BSX_API __thread bsx_arena_t *bsx_tls_arena = 0;
-#define ARENA_SETS 2
-static bsx_arena_t **g_arenas[ARENA_SETS] = {0, 0};
-static int g_n_arenas[ARENA_SETS] = {0, 0}, g_set_busy[ARENA_SETS] = {0, 0};
+#define ARENA_SETS 4
+static bsx_arena_t **g_arenas[ARENA_SETS];
+static int g_n_arenas[ARENA_SETS], g_set_busy[ARENA_SETS];
 static pthread_mutex_t g_arena_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_arena_cv = PTHREAD_COND_INITIALIZER;
 static __thread int tls_arena_set = -1;

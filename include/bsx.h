@@ -272,16 +272,18 @@ int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *
 int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx,
                      int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
-/* The same, for a sequence of chunks, as a two-deep pipeline: what lib/aln/align.c:100-170 (kt_pipeline over
+/* The same, for a sequence of chunks, as a pipeline: what lib/aln/align.c:100-170 (kt_pipeline over
  * read / mem_process_seqs / write) does for I/O, done here for the two halves of the aligning step itself.  The
- * device-bound front half of chunk k+1 (seeding .. regions) runs on its own device lane and thread while the
- * host-bound back half of chunk k (merge, pairing, CIGAR, SAM text) runs on the caller's thread.
- *   bsx_stream_push(chunk k) returns once chunk k-1 is complete (its reads[i].sam are set);
- *   bsx_stream_flush completes the last chunk.  Every chunk is independent, exactly as with bsx_process_seqs
- *   (own insert-size statistics unless pes0 is given), so the output does not depend on the pipelining.
+ * device-bound front half of a chunk (seeding .. regions) runs on its own device lane and thread while the
+ * host-bound back half of an older chunk (merge, pairing, CIGAR, SAM text) runs on the caller's thread; up to
+ * depth-1 front halves are in flight ahead of it (depth 3 unless $BSX_STREAM_DEPTH says otherwise, at most 4).
+ *   bsx_stream_push(chunk k) returns once chunk k-(depth-1) is complete (its reads[i].sam are set);
+ *   bsx_stream_flush completes the chunks still in flight, in order.  Every chunk is independent, exactly as with
+ *   bsx_process_seqs (own insert-size statistics unless pes0 is given): the output does not depend on the depth.
  * opt and idx must outlive the stream; a chunk's reads must stay valid until it is complete. */
 typedef struct bsx_stream bsx_stream_t;
 int  bsx_stream_open(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes0, bsx_stream_t **out);
+int  bsx_stream_depth(const bsx_stream_t *s);
 int  bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_read_t *reads);
 int  bsx_stream_flush(bsx_stream_t *s);
 void bsx_stream_close(bsx_stream_t *s);

@@ -141,3 +141,83 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
         L.bsx_sim_free_reads(p, 2 * n_pairs)
         dev.close()
         idx.close()
+
+
+def test_chunk_stream_equals_chunk_by_chunk_on_device(tmp_path):
+    """bsx_stream_* (device lanes, priority streams, front halves of later chunks overlapping an older chunk's back
+    half) against bsx_process_seqs chunk by chunk: identical SAM text for every chunk at depths 2 and 3."""
+    import ctypes as C
+    import zlib
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    L = B.lib()
+    d = str(tmp_path)
+    B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(4000000), C.c_uint64(78), 4, C.c_double(0.08)), "sim_genome")
+    B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "index_build")
+    idx = Index(d + "/g")
+    dev = Device(0)
+    dev.upload_index(idx)
+    opt = default_opt()
+    opt.n_threads = 4
+    opt.flag |= 0x10 | 0x2
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bsx_stream_push.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bsx_stream_flush.argtypes = [C.c_void_p]
+    L.bsx_stream_close.argtypes = [C.c_void_p]
+    L.bsx_stream_close.restype = None
+    n_pairs, n_chunks = 20000, 5
+    chunks = []
+    for k in range(n_chunks):
+        p = C.c_void_p()
+        B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 300 + k, 200, 500, 0.01, 0.2, C.byref(p)), "sim_pairs")
+        chunks.append(p)
+
+    def crc(k):
+        r = C.cast(chunks[k], C.POINTER(B.Read))
+        c = 0
+        for i in range(2 * n_pairs):
+            c = zlib.crc32(C.string_at(r[i].sam), c)
+        return c
+
+    try:
+        want = []
+        for k in range(n_chunks):
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 2 * n_pairs * k, 2 * n_pairs, chunks[k], None), "process_seqs")
+            want.append(crc(k))
+            L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+        assert len(set(want)) == n_chunks
+        for depth in ("2", "3"):
+            os.environ["BSX_STREAM_DEPTH"] = depth
+            s = C.c_void_p()
+            B.check(L.bsx_stream_open(dev.h, C.byref(opt), idx.h, None, C.byref(s)), "stream_open")
+            for k in range(n_chunks):
+                B.check(L.bsx_stream_push(s, 2 * n_pairs * k, 2 * n_pairs, chunks[k]), "push")
+            B.check(L.bsx_stream_flush(s), "flush")
+            L.bsx_stream_close(s)
+            for k in range(n_chunks):
+                assert crc(k) == want[k], (depth, k)
+                L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+    finally:
+        os.environ.pop("BSX_STREAM_DEPTH", None)
+        for c in chunks:
+            L.bsx_sim_free_reads(c, 2 * n_pairs)
+        dev.close()
+        idx.close()
+
+
+def test_cli_many_chunks_through_the_stream(data):
+    """The CLI drives chunks through bsx_stream_*: with a small chunk size the run is dozens of chunks, several in
+    flight at once; the SAM must still equal the CPU driver's (same chunking, so the same per-chunk insert-size
+    statistics) and the one-chunk-at-a-time product path's."""
+    env = {"BSX_CHUNK_SIZE": "30000"}
+    args = ["-@", "4", "g", "b1.fq", "b2.fq"]
+    want = run(CPU, args, data, env=env)
+    got = run(HIP, args, data, env=env)
+    sync = run(HIP, args, data, env=dict(env, BSX_NO_STREAM="1"))
+    assert got.count(b"\n") > 8000
+    assert got == want
+    assert sync == want

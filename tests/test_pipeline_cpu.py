@@ -95,3 +95,67 @@ def test_regression_fixture():
     got = run(["-@", "2", d + "/g", os.path.join(GOLD, "pe_small_1.fq"), os.path.join(GOLD, "pe_small_2.fq")], d)
     want = open(os.path.join(GOLD, "pe_small.sam")).read()
     assert got.strip() == want.strip()
+
+
+def _load_pairs(L, B, C, idx, n_pairs, seed):
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 100, seed, 150, 400, 0.01, 0.2, C.byref(p)), "sim_pairs")
+    return p
+
+
+def test_chunk_stream_equals_chunk_by_chunk(data):
+    """The chunk pipeline (front halves of later chunks in flight while an older chunk's back half runs) over
+    CPU-restatement contexts: every chunk's SAM text equals what the synchronous bsx_process_seqs path gives,
+    at every depth."""
+    import ctypes as C
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import default_opt
+    from oracle_lib import Port
+    L = B.lib()
+    idx = Index(data + "/g")
+    opt = default_opt()
+    opt.n_threads = 2
+    opt.flag |= 0x10 | 0x2
+    n_pairs, n_chunks = 300, 5
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_stream_open_backends.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bsx_stream_push.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bsx_stream_flush.argtypes = [C.c_void_p]
+    L.bsx_stream_close.argtypes = [C.c_void_p]
+    L.bsx_stream_close.restype = None
+    chunks = [_load_pairs(L, B, C, idx, n_pairs, 50 + k) for k in range(n_chunks)]
+    ports = [Port(idx, 2) for _ in range(4)]
+
+    def sam_of(k):
+        r = C.cast(chunks[k], C.POINTER(B.Read))
+        return b"".join(C.string_at(r[i].sam) for i in range(2 * n_pairs))
+
+    try:
+        be0 = ports[0].backend()
+        want = []
+        for k in range(n_chunks):
+            B.check(L.bsx_process_seqs_backend(C.byref(be0), C.byref(opt), idx.h, 2 * n_pairs * k, 2 * n_pairs, chunks[k], None), "process")
+            want.append(sam_of(k))
+            L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+        assert len(set(want)) == n_chunks and all(w.count(b"\n") >= 2 * n_pairs for w in want)
+        for depth in (1, 2, 3, 4):
+            bes = (B.Backend * depth)(*[ports[i].backend() for i in range(depth)])
+            s = C.c_void_p()
+            B.check(L.bsx_stream_open_backends(depth, bes, C.byref(opt), idx.h, None, C.byref(s)), "open")
+            for k in range(n_chunks):
+                B.check(L.bsx_stream_push(s, 2 * n_pairs * k, 2 * n_pairs, chunks[k]), "push")
+                done = k - (depth - 1)
+                if done >= 0:
+                    assert sam_of(done) == want[done], (depth, done)
+            B.check(L.bsx_stream_flush(s), "flush")
+            for k in range(n_chunks):
+                assert sam_of(k) == want[k], (depth, k)
+                L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+            L.bsx_stream_close(s)
+    finally:
+        for c in chunks:
+            L.bsx_sim_free_reads(c, 2 * n_pairs)
+        idx.close()
