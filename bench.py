@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "128")))
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
@@ -120,7 +120,7 @@ def main():
         n_processed += n_reads
     if not args.no_pipeline:
         B.check(L.bsx_stream_flush(stream), "stream_flush(warmup)")
-    for k in range(6):
+    for k in range(7):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
     phase_tot = {}
@@ -163,25 +163,37 @@ def main():
         dist.all_reduce(c)   # "gather" of per-GPU record counts over RCCL
         tot_reads = int(c.item())
 
-    # roofline of the dominant kernel (K1+K2 FM-index seeding): algorithmic bytes = 64 B per FM block touch
+    # rooflines of the two kernels that carry the run, both HBM-bound gathers over the FM index:
+    #   k_seed (K1+K2): 64 B per FM block touched by bwt_extend (two blocks unless k and l share one)
+    #   k_regions (K3 + chaining + extension, first tier): 64 B per LF step of bwt_sa + 8 B per SA sample read
+    # (durations are HIP-event times on the launch stream; the redo launches of k_seed on a handful of strand
+    #  searches and the slab tiers of k_regions are counted in the bytes but are a fraction of a percent)
     ctr = dev.counters()
-    ktimes = [dev.kernel_time(k) for k in range(6)]
+    ktimes = [dev.kernel_time(k) for k in range(7)]
     seed_ms, seed_launches = ktimes[0]
-    alg_bytes = 64.0 * (ctr[0] + ctr[1])
-    roof = None
-    if seed_launches:
-        ach = alg_bytes / (seed_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_seed (K1+K2 SMEM seeding)", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(ach / 8000.0, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes / seed_launches, "avg_launch_ms": seed_ms / seed_launches,
-                "fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)}
+    reg_ms, reg_launches = ktimes[5]
+
+    def roof_of(name, alg_bytes, ms, launches, extra):
+        if not launches or ms <= 0:
+            return None
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
+             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches}
+        r.update(extra)
+        return r
+
+    roof_seed = roof_of("k_seed (K1+K2 SMEM seeding)", 64.0 * (ctr[0] + ctr[1]), seed_ms, seed_launches,
+                        {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)})
+    roof_reg = roof_of("k_regions (K3 SA lookup + chaining + banded extension, LDS tier)", 64.0 * ctr[2] + 8.0 * ctr[3], reg_ms, reg_launches,
+                       {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)})
+    roof, roof_other = (roof_reg, roof_seed) if (roof_reg and reg_ms >= seed_ms) else (roof_seed, roof_reg)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L, B, idx, opt, args, ncores)
 
     if rank == 0:
-        names = ["seed", "sa", "extend", "sw", "global", "regions"]
+        names = ["seed", "sa", "extend", "sw", "global", "regions_tier1", "regions_tiers23_and_reseed_wait"]
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
@@ -191,8 +203,9 @@ def main():
                        "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world, "chunk_pipeline_depth": depth,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 32 * 8) + n_bases / 4)},
             "roofline": roof,
+            "roofline_second_kernel": roof_other,
             "cpu_baseline": cpu,
-            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(6)},
+            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(7)},
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},

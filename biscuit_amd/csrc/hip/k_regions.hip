@@ -261,7 +261,7 @@ __device__ int rg_bt_traverse(Store &S, int *stk)
 }
 
 // bwt_sa (bwt.c:87-97) on one strand's own index
-__device__ __forceinline__ long long rg_sa(const DevIndex &ix, int parent, unsigned long long k)
+__device__ __forceinline__ long long rg_sa(const DevIndex &ix, int parent, unsigned long long k, uint32_t &n_steps)
 {
 	const unsigned long long prim = dev_ix_primary(ix, parent);
 	const uint32_t *bw = dev_ix_bwt(ix, parent);
@@ -283,6 +283,7 @@ __device__ __forceinline__ long long rg_sa(const DevIndex &ix, int parent, unsig
 		k = dev_ix_L2(ix, parent, c) + base + (c == 0 ? ca : c == 1 ? cc : c == 2 ? cg : ct);
 		++steps;
 	}
+	n_steps += (uint32_t)steps;
 	return (long long)(steps + sa[k >> sa_shift]);
 }
 
@@ -306,7 +307,7 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 //   6 regions > RCAP
 template <typename Store>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
-                       int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, int lane)
+                       int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, int lane, unsigned long long *counters)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -341,14 +342,18 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	if (over || tot > Store::SCAP) return 2;
 	{
 		int i = 0, acc = 0;   // occurrences are visited in increasing order by each lane: the interval cursor only moves forward
+		uint32_t lf = 0;
 		for (int o = lane; o < tot; o += 64) {
 			while (acc + S.iv_n[i] <= o) { acc += S.iv_n[i]; ++i; }
-			const long long pos = rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc));
+			const long long pos = rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
 			S.s_rid[o] = rg_intv2rid(ix, pos, pos + slen);
 			S.s_chain[o] = -1; S.s_extra[o] = 0;
 		}
+		// work counters of the algorithmic-bytes model: FM blocks touched by the LF walks, SA samples read
+		lf = (uint32_t)wave_sum_i32((int)lf);
+		if (lane == 0) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)tot); }
 	}
 	WAVE_SYNC();
 	// ---- C. chaining in arrival order (mem_chain's loop over occurrences, memchain.c:313-366)
@@ -644,7 +649,7 @@ __global__ void __launch_bounds__(256, 3)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota)
+          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters)
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
@@ -659,7 +664,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		if (t >= n_tasks) break;
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane, counters);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
 	}
@@ -672,7 +677,8 @@ __global__ void __launch_bounds__(256, 2)
 k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-               const int *list, const unsigned int *count, unsigned int *cursor, Store *slabs, int *next_list, unsigned int *next_count)
+               const int *list, const unsigned int *count, unsigned int *cursor, Store *slabs, int *next_list, unsigned int *next_count,
+               unsigned long long *counters)
 {
 	__shared__ RgDp dp[4];
 	const int lane = wave_lane();
@@ -687,7 +693,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int t = list ? uni(list[i]) : i;
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane, counters);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
@@ -698,21 +704,22 @@ size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota)
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters)
 {
 	hipLaunchKernelGGL(k_regions, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota);
+	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters);
 }
 
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count)
+                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
+                         unsigned long long *counters)
 {
 	if (tier == 2)
 		hipLaunchKernelGGL(k_regions_slab<RgBig>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count);
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters);
 	else
 		hipLaunchKernelGGL(k_regions_slab<RgHuge>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count);
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters);
 }

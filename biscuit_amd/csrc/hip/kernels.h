@@ -23,8 +23,9 @@ size_t regions_slab_bytes(int tier);
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota);
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count);
+                         const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
+                         unsigned long long *counters);

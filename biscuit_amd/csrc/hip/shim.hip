@@ -57,8 +57,8 @@ struct Lane {
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
 	hipEvent_t pev[2] = {nullptr, nullptr};
-	double k_ms[6] = {0, 0, 0, 0, 0, 0};
-	int64_t k_launch[6] = {0, 0, 0, 0, 0, 0};
+	double k_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+	int64_t k_launch[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 struct bsx_device {
@@ -265,7 +265,7 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 
 extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
 {
-	if (!d || k < 0 || k >= 6) return BSX_E_ARG;
+	if (!d || k < 0 || k >= 7) return BSX_E_ARG;
 	double ms = 0; int64_t n = 0;
 	for (int l = 0; l < BSX_LANES; ++l) {
 		ms += d->lane[l].k_ms[k]; n += d->lane[l].k_launch[k];
@@ -422,7 +422,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
 
 	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
-	const unsigned long long dense_cap = (unsigned long long)n * 24 + (1u << 20), regs_cap = (unsigned long long)n * 2 + 65536;
+	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
+	// dozens of intervals per strand search, and HBM is not the scarce resource here
+	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 6 + 65536;
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
@@ -457,11 +459,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
 	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
-	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota);
+	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr);
+	HIPCHK(hipEventRecord(L.ev3, L.st));
 	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3);
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr);
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr);
 
 	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats) are seeded again
 	// on the side stream with much longer lists, then go through the third tier as well.
@@ -515,7 +518,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipMemcpyAsync(c32 + 5, &n2u, 4, hipMemcpyHostToDevice, L.st2));
 		HIPCHK(hipStreamSynchronize(L.st2));   // the host vectors above go out of scope; the region kernels keep running on L.st
 		launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr);
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr);
 		redo_roff.resize(n2); redo_rn.resize(n2);
 		HIPCHK(hipMemcpyAsync(redo_roff.data(), roff2, n2 * 8, hipMemcpyDeviceToHost, L.st));
 		HIPCHK(hipMemcpyAsync(redo_rn.data(), rn2, n2 * 4, hipMemcpyDeviceToHost, L.st));
@@ -523,15 +526,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	clock_gettime(CLOCK_MONOTONIC, &ts2);
 	HIPCHK(hipEventRecord(L.ev2, L.st));
 	{
-		float ms0 = 0, ms1 = 0;
+		float ms0 = 0, ms1 = 0, ms2 = 0;
 		HIPCHK(hipEventSynchronize(L.ev2));
 		clock_gettime(CLOCK_MONOTONIC, &ts3);
 		if (trace) fprintf(stderr, "[M::regions_batch] seed kernel done +%.0f ms | redo of %zu strand searches enqueued +%.0f ms | all region tiers done +%.0f ms\n",
 		                   (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, redo.size(), (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6,
 		                   (ts3.tv_sec - ts0.tv_sec) * 1e3 + (ts3.tv_nsec - ts0.tv_nsec) * 1e-6);
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
-		HIPCHK(hipEventElapsedTime(&ms1, L.ev1, L.ev2));
-		L.k_ms[0] += ms0; L.k_launch[0] += 1; L.k_ms[5] += ms1; L.k_launch[5] += 1;
+		HIPCHK(hipEventElapsedTime(&ms1, L.ev1, L.ev3));   // the first region tier alone
+		HIPCHK(hipEventElapsedTime(&ms2, L.ev3, L.ev2));   // tiers 2 and 3 and the wait for re-seeded strand searches
+		L.k_ms[0] += ms0; L.k_launch[0] += 1; L.k_ms[5] += ms1; L.k_launch[5] += 1; L.k_ms[6] += ms2; L.k_launch[6] += 1;
 		HIPCHK(hipGetLastError());
 	}
 	unsigned long long used = 0;

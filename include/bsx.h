@@ -257,11 +257,11 @@ int bsx_global_batch(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bs
                      uint32_t *cigar_pool, size_t cigar_pool_len);
 
 /* device-side work counters of the last seed/sa batch (algorithmic-bytes model):
- * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa),
- * c[3]=bwt_sa calls */
+ * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and
+ * from the region kernels), c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
 /* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since
- * the last reset: k = 0 seed, 1 sa, 2 extend, 3 sw, 4 global, 5 regions */
+ * the last reset: k = 0 seed, 1 sa, 2 extend, 3 sw, 4 global, 5 regions (first tier), 6 regions (tiers 2-3 + re-seeding wait) */
 int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *launches, int reset);
 
 /* ------------------------------------------------------------------------------------------

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence committed under profiles/: one kernel-trace run of the default bench command and
+# separate --pmc passes (never combined with sys/hip traces).  Run on the GPU box from the repo root:
+#   tools/profile_round.sh r02
+set -u
+TAG=${1:-rXX}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline"
+cd /tmp
+python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1   # builds the index once
+$BENCH > "$OUT/bench_untraced.json" 2> "$OUT/bench_untraced.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum"; do
+	name=$(echo $grp | tr ' ' '_')
+	rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o bench -- python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc group $grp failed" >> "$OUT/errors.txt"
+done
+find "$OUT" -name "*.csv" | head -50 > "$OUT/files.txt"
