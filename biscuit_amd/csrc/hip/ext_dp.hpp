@@ -38,7 +38,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevSco
 	WAVE_SYNC();
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
-		const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+		const int t = wave_bcast(tb_reg, i & 63);
 		const int8_t s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;
@@ -76,7 +76,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevSco
 					const int incl = wave_scan_max_incl(g);
 					int excl = wave_prev(incl, NEG_BIG);
 					excl = excl > carry ? excl : carry;            // prefix max over all earlier columns
-					{ const int tot = __shfl(incl, 63); carry = carry > tot ? carry : tot; }
+					{ const int tot = __builtin_amdgcn_readlane(incl, 63); carry = carry > tot ? carry : tot; }
 					int f = j == beg ? 0 : excl - (j - 1) * e_ins;
 					if (f < 0) f = 0;
 					if (act) {
@@ -137,5 +137,156 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevSco
 	bsx_ext_res_t r;
 	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	WAVE_SYNC();
+	return r;
+}
+
+// The same recurrence with the two DP rows held in registers: lane l owns entries l, l+64, ... of the reference's
+// eh[] array (H = the value ksw.c keeps in eh[j].h, i.e. the diagonal predecessor; E = eh[j].e), so a row costs no
+// LDS traffic and no barriers: the right-shift of H by one column is a lane shift, F is the same max-plus prefix
+// scan, and entries outside the band simply keep their old contents, exactly like the array they mirror.
+// Needs qlen + 1 <= 64 * NC entries.
+template <int NC>
+__device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t &J, int lane)
+{
+	const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
+	// the 5x5 matrix of this strand as 25 scalars (constant indices: scalar loads, hoisted); indexing the kernel
+	// argument with a run-time index instead would be five vector loads from memory in every row
+	int mt[25];
+#pragma unroll
+	for (int k = 0; k < 25; ++k) mt[k] = J.parent ? sc.ctmat[k] : sc.gamat[k];
+	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = sc.zdrop;
+	int Hr[NC], Er[NC], sq[NC][5];   // sq[c][t]: score of this lane's query base of chunk c against target base t
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int a = (c << 6) + lane;
+		const int q = a < qlen ? reads[(long long)J.qoff + (long long)a * J.qdir] : 4;
+#pragma unroll
+		for (int t = 0; t < 5; ++t) sq[c][t] = q == 0 ? mt[t * 5] : q == 1 ? mt[t * 5 + 1] : q == 2 ? mt[t * 5 + 2] : q == 3 ? mt[t * 5 + 3] : mt[t * 5 + 4];
+		const int v = a == 0 ? h0 : h0 - oe_ins - (a - 1) * e_ins;   // first row (ksw.c:395-397)
+		Hr[c] = (a <= qlen && v > 0) ? v : 0;
+		Er[c] = 0;
+	}
+	int mx = 0;
+#pragma unroll
+	for (int k = 0; k < 25; ++k) mx = mx > mt[k] ? mx : mt[k];
+	int w = J.w;
+	{ // band clamp (ksw.c:399-407)
+		int max_ins = (int)((double)(qlen * mx + J.end_bonus - o_ins) / e_ins + 1.);
+		max_ins = max_ins > 1 ? max_ins : 1;
+		w = w < max_ins ? w : max_ins;
+		int max_del = (int)((double)(qlen * mx + J.end_bonus - o_del) / e_del + 1.);
+		max_del = max_del > 1 ? max_del : 1;
+		w = w < max_del ? w : max_del;
+	}
+	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	int beg = 0, end = qlen;
+	int tb_reg = 4;
+	for (int i = 0; i < tlen; ++i) {
+		if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
+		const int t = wave_bcast(tb_reg, i & 63);
+		if (beg < i - w) beg = i - w;
+		if (end > i + w + 1) end = i + w + 1;
+		if (end > qlen) end = qlen;
+		int h1_init = 0;
+		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+		int m = 0, mj = -1, h1_last = h1_init;
+		if (beg < end) {
+			const int c0 = beg >> 6, c1 = (end - 1) >> 6;
+			int hn[NC];
+			int carry = NEG_BIG, lm = -1, lj = -1;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				hn[c] = 0;
+				if (c >= c0 && c <= c1) {
+					const int a = (c << 6) + lane;
+					const bool act = a >= beg && a < end;
+					const int s = t == 0 ? sq[c][0] : t == 1 ? sq[c][1] : t == 2 ? sq[c][2] : t == 3 ? sq[c][3] : sq[c][4];
+					const int M = (act && Hr[c]) ? Hr[c] + s : 0;
+					int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
+					const int g = act ? tins + a * e_ins : NEG_BIG;
+					const int incl = wave_scan_max_incl(g);
+					int excl = wave_prev(incl, NEG_BIG);
+					excl = excl > carry ? excl : carry;
+					{ const int tot = __builtin_amdgcn_readlane(incl, 63); carry = carry > tot ? carry : tot; }
+					int f = a == beg ? 0 : excl - (a - 1) * e_ins;
+					if (f < 0) f = 0;
+					if (act) {
+						int h = M > Er[c] ? M : Er[c];
+						h = h > f ? h : f;
+						int tdel = M - oe_del; tdel = tdel > 0 ? tdel : 0;
+						int e = Er[c] - e_del; e = e > tdel ? e : tdel;
+						Er[c] = e;
+						hn[c] = h;
+						if (h >= lm) { lm = h; lj = a; }
+					} else if (a == end) Er[c] = 0;
+				}
+			}
+			// eh[end].e = 0 when `end` opens a chunk the loop above did not visit
+			if ((end & 63) == 0 && (end >> 6) < NC && (end >> 6) > c1) {
+#pragma unroll
+				for (int c = 0; c < NC; ++c) if (c == (end >> 6) && lane == 0) Er[c] = 0;
+			}
+			// H: entry a takes h(i, a-1) for a-1 in the band, entry beg takes the first-column value
+#pragma unroll
+			for (int c = NC - 1; c >= 0; --c) {
+				if (c >= c0 && c <= c1 + 1) {
+					const int a = (c << 6) + lane;
+					int up = wave_prev(hn[c], 0);
+					const int edge = c > 0 ? __builtin_amdgcn_readlane(hn[c > 0 ? c - 1 : 0], 63) : 0;
+					if (lane == 0) up = edge;
+					if (a == beg) Hr[c] = h1_init;
+					else if (a - 1 >= beg && a - 1 < end) Hr[c] = up;
+				}
+			}
+			m = wave_max_i32(lm);
+			mj = wave_max_i32(lm == m ? lj : -1);
+			if (end == qlen) { // h(i, end-1), only read for the to-the-end score
+				int v = 0;
+#pragma unroll
+				for (int c = 0; c < NC; ++c) if (c == c1) v = hn[c];
+				h1_last = wave_bcast(v, (end - 1) & 63);
+			}
+		} else { // empty row: only the boundary cell is written (ksw.c:449)
+#pragma unroll
+			for (int c = 0; c < NC; ++c) if ((c << 6) + lane == end) { Hr[c] = h1_init; Er[c] = 0; }
+		}
+		const int jfin = beg < end ? end : beg;
+		if (jfin == qlen) { max_ie = gscore > h1_last ? max_ie : i; gscore = gscore > h1_last ? gscore : h1_last; }
+		if (m == 0) break;
+		if (m > max) {
+			max = m; max_i = i; max_j = mj;
+			int off = mj - i; off = off < 0 ? -off : off;
+			max_off = max_off > off ? max_off : off;
+		} else if (zdrop > 0) {
+			if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+			else { if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+		}
+		// shrink the band to the non-zero cells (ksw.c:466-469)
+		{
+			int nb = end, last;
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				if (nb == end && c >= (beg >> 6) && c <= ((end - 1) >> 6)) {
+					const int a = (c << 6) + lane;
+					const unsigned long long b = __ballot(a >= beg && a < end && (Hr[c] != 0 || Er[c] != 0));
+					if (b) nb = (c << 6) + __builtin_ctzll(b);
+				}
+			}
+			last = nb - 1;
+#pragma unroll
+			for (int c = NC - 1; c >= 0; --c) {
+				if (last == nb - 1 && c <= (end >> 6) && c >= (nb >> 6)) {
+					const int a = (c << 6) + lane;
+					const unsigned long long b = __ballot(a <= end && a >= nb && (Hr[c] != 0 || Er[c] != 0));
+					if (b) last = (c << 6) + 63 - __builtin_clzll(b);
+				}
+			}
+			beg = nb;
+			end = last + 2 < qlen ? last + 2 : qlen;
+		}
+	}
+	bsx_ext_res_t r;
+	r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
 	return r;
 }

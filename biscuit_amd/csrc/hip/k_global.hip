@@ -72,7 +72,7 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 				int tb_reg = 4;
 				for (int i = 0; i < tlen; ++i) {
 					if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
-					const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+					const int t = wave_bcast(tb_reg, i & 63);
 					const int s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
 					const int beg = i > w ? i - w : 0;
 					const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
@@ -104,7 +104,7 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 								const int incl = wave_scan_max_incl(g);
 								int excl = wave_prev(incl, G_INACTIVE);
 								excl = excl > carry ? excl : carry;
-								{ const int tot = __shfl(incl, 63); carry = carry > tot ? carry : tot; }
+								{ const int tot = __builtin_amdgcn_readlane(incl, 63); carry = carry > tot ? carry : tot; }
 								const int f = j == beg ? G_MINUS_INF : excl - (j - 1) * e_ins;
 								if (act) {
 									const int m = M[c], e0 = Ev[c];
@@ -156,7 +156,7 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 						if (n <= cap) for (int a = 0; a < n >> 1; ++a) { const uint32_t tmp = cig[a]; cig[a] = cig[n - 1 - a]; cig[n - 1 - a] = tmp; }
 						else n = -n;
 					}
-					n_cigar = __shfl(n, 0);
+					n_cigar = __builtin_amdgcn_readlane(n, 0);
 				}
 			}
 			if (J.n_try == 1) break;

@@ -18,7 +18,7 @@
 #include "ext_dp.hpp"
 
 #define RG_QCAP 256
-#define RG_NC 4          // band <= min(qlen, 2w+1) <= 256 columns
+#define RG_NC 4          // extension rows live in registers: 64 * RG_NC entries >= qlen + 1
 
 struct RgChain {         // mem_chain_t reduced to what chaining and the filter read: first seed = (pos, first_q), last seed
 	long long pos, last_r;
@@ -58,7 +58,7 @@ struct RgStore {
 typedef RgStore<64, 96, 96, 12, 0, unsigned char, signed char> RgSmall;
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
-struct RgDp { int32_t H[RG_QCAP + 2], E[RG_QCAP + 2]; uint8_t qb[RG_QCAP + 4]; };   // ext_dp's rows, always LDS
+struct RgDp { int32_t H[64], E[64]; };   // per-wave LDS scratch of the one-lane passes (introsort stack, tree traversal stack)
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -307,7 +307,8 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 //   6 regions > RCAP
 template <typename Store>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
-                       int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, int lane, unsigned long long *counters)
+                       int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
+                       unsigned long long *counters)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -327,13 +328,28 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	if (n_iv == 0 || l_query < P.min_seed_len) return 0;
 
 	// ---- A. intervals, ordered by info (ks_introsort(mem_intv), memchain.c:105; equal keys are identical records)
-	for (int i = lane; i < n_iv; i += 64) {
-		const DevIntv mine = src[i];
-		int rank = 0;
-		for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
-		S.iv_x0[rank] = mine.x0;
-		S.iv_n[rank] = mine.x2 > 0x7fffffffull ? 0x7fffffff : (int)mine.x2;
-		S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
+	// With positions looked up beforehand (k_occ), posl holds them interval by interval in the order the seeding kernel
+	// left the list: iv_x0 then carries each interval's offset into posl instead of its first SA rank.
+	long long run = 0;
+	for (int base = 0; base < n_iv; base += 64) {
+		const int i = base + lane;
+		DevIntv mine; mine.x0 = mine.x1 = mine.x2 = 0; mine.info = 0;
+		if (i < n_iv) mine = src[i];
+		const int cnt = mine.x2 > 0x7fffffffull ? 0x7fffffff : (int)mine.x2;
+		long long incl = cnt;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
+			if (lane >= off) incl += o;
+		}
+		if (i < n_iv) {
+			int rank = 0;
+			for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
+			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - cnt) : mine.x0;
+			S.iv_n[rank] = cnt;
+			S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
+		}
+		run += uni64((long long)((unsigned long long)(unsigned)__shfl((int)(incl >> 32), 63) << 32 | (unsigned)__shfl((int)incl, 63)));
 	}
 	WAVE_SYNC();
 	// ---- B. occurrences: every k < x[2] of every interval (the caps of memchain.c:325-326 cannot bind while x[2] <= max_occ)
@@ -345,7 +361,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		uint32_t lf = 0;
 		for (int o = lane; o < tot; o += 64) {
 			while (acc + S.iv_n[i] <= o) { acc += S.iv_n[i]; ++i; }
-			const long long pos = rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
+			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
 			S.s_rid[o] = rg_intv2rid(ix, pos, pos + slen);
@@ -353,9 +369,10 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 		// work counters of the algorithmic-bytes model: FM blocks touched by the LF walks, SA samples read
 		lf = (uint32_t)wave_sum_i32((int)lf);
-		if (lane == 0) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)tot); }
+		if (lane == 0 && !posl) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)tot); }
 	}
 	WAVE_SYNC();
+	if (P.dbg & 1) return 0;
 	// ---- C. chaining in arrival order (mem_chain's loop over occurrences, memchain.c:313-366)
 	int nc = 0;
 	for (int o = 0; o < tot; ++o) {
@@ -408,6 +425,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 		WAVE_SYNC();
 	}
+	if (P.dbg & 2) return 0;
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
 		for (int c = lane; c < nc; c += 64) { // mem_chain_weight, memchain.c:158-180, one lane per chain
@@ -480,6 +498,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			WAVE_SYNC();
 		}
 	}
+	if (P.dbg & 4) return 0;
 	// ---- E. chains -> regions (mem_chain2region, memchain.c:873-904)
 	const int nk = uni(S.n_chains), ns = tot;
 	for (int ci = 0; ci < nk; ++ci) {
@@ -585,7 +604,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						const int prev = R.score;
 						aw = P.w << i;
 						J.w = aw;
-						res = ext_dp<RG_NC>(ix, sc, reads, J, D.H, D.E, D.qb, lane);
+						if (P.dbg & 8) { res.score = J.h0 + 10; res.qle = J.qlen; res.tle = J.qlen; res.gtle = J.qlen; res.gscore = J.h0 + 10; res.max_off = 0; }
+						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
@@ -649,7 +669,8 @@ __global__ void __launch_bounds__(256, 3)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters)
+          unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
+          const long long *pos_off, const unsigned long long *pos)
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
@@ -664,7 +685,8 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		if (t >= n_tasks) break;
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane, counters);
+		const long long po = pos ? uni64(pos_off[t]) : -1;
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
 	}
@@ -678,7 +700,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
                const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                const int *list, const unsigned int *count, unsigned int *cursor, Store *slabs, int *next_list, unsigned int *next_count,
-               unsigned long long *counters)
+               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
 {
 	__shared__ RgDp dp[4];
 	const int lane = wave_lane();
@@ -693,10 +715,64 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int t = list ? uni(list[i]) : i;
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, lane, counters);
+		const long long po = pos ? uni64(pos_off[t]) : -1;
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
+}
+
+// ---- K3 for the whole chunk ahead of the region kernels: the LF walks are pure pointer chasing, and run an order of
+// magnitude faster with one walk per lane and thousands of waves in flight than inside the wave-per-task kernels.
+// k_occ_expand lists the SA ranks of every occurrence each strand search will visit (lane per strand search),
+// k_occ turns each rank into its reference position in place (lane per occurrence, bwt_sa, bwt.c:87-97).
+#define OCC_MAX_PER_TASK 8192   // = RgHuge::SCAP: nothing on the device visits more
+__global__ void __launch_bounds__(256)
+k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ,
+             unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off)
+{
+	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (t >= n_tasks) return;
+	const int n_iv = task_n[t];
+	long long off = -1;
+	if (n_iv > 0) {
+		const DevIntv *src = seeds_dense + task_off[t];
+		unsigned long long tot = 0; int over = 0;
+		for (int i = 0; i < n_iv; ++i) { const unsigned long long x2 = src[i].x2; if (x2 > (unsigned long long)max_occ) over = 1; tot += x2; }
+		if (!over && tot > 0 && tot <= OCC_MAX_PER_TASK) {
+			const unsigned long long base = atomicAdd(cursor, tot);
+			if (base + tot <= desc_cap) {
+				const unsigned long long par = (unsigned long long)(tasks[t].parent & 1) << 63;
+				unsigned long long j = base;
+				for (int i = 0; i < n_iv; ++i) { const unsigned long long x0 = src[i].x0, x2 = src[i].x2; for (unsigned long long k = 0; k < x2; ++k) desc[j++] = (x0 + k) | par; }
+				off = (long long)base;
+			}
+		}
+	}
+	pos_off[t] = off;
+}
+
+__global__ void __launch_bounds__(256)
+k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const unsigned long long *cursor, unsigned long long *counters)
+{
+	unsigned long long n = *cursor;
+	if (n > desc_cap) n = desc_cap;
+	uint32_t lf = 0, calls = 0;
+	for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * blockDim.x) {
+		const unsigned long long v = desc[j];
+		desc[j] = (unsigned long long)rg_sa(ix, (int)(v >> 63), v & 0x7fffffffffffffffull, lf);
+		++calls;
+	}
+	for (int off = 32; off > 0; off >>= 1) { lf += __shfl_down(lf, off); calls += __shfl_down(calls, off); }
+	if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)calls); }
+}
+
+void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
+                const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
+                unsigned long long *counters)
+{
+	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off);
+	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters);
 }
 
 size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
@@ -704,22 +780,23 @@ size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters)
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
+                    const long long *pos_off, const unsigned long long *pos)
 {
 	hipLaunchKernelGGL(k_regions, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters);
+	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
 }
 
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
-                         unsigned long long *counters)
+                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
 {
 	if (tier == 2)
 		hipLaunchKernelGGL(k_regions_slab<RgBig>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters);
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos);
 	else
 		hipLaunchKernelGGL(k_regions_slab<RgHuge>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters);
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters, pos_off, pos);
 }

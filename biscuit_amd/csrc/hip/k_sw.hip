@@ -44,7 +44,7 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 			const long long src = (ii <= te_rev) ? (long long)(te_rev - ii) : (long long)ii;  // reversed prefix in pass 2
 			tb_reg = ii < tlen ? dev_ref_base(ix.pac, ix.l_pac, tpos + src * tdir) : 4;
 		}
-		const int t = __builtin_amdgcn_readfirstlane(__shfl(tb_reg, i & 63));
+		const int t = wave_bcast(tb_reg, i & 63);
 		const int s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
 		int rowmax = 0, pm_full = NEG_BIG, carry_seg = NEG_BIG;
 #pragma unroll
@@ -52,9 +52,9 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 			if (c < nch) {
 				const int j = (c << 6) + lane;
 				const bool act = j < Q;
-				int d = __shfl_up(Hp[c], 1);
+				int d = wave_prev(Hp[c], 0);
 				if (lane == 0) d = 0;
-				if (c > 0) { const int pv = __shfl(Hp[c > 0 ? c - 1 : 0], 63); if (lane == 0) d = pv; }
+				if (c > 0) { const int pv = __builtin_amdgcn_readlane(Hp[c > 0 ? c - 1 : 0], 63); if (lane == 0) d = pv; }
 				const int q = qv[c];
 				const int s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : q == 3 ? s3 : q == 4 ? s4 : 0;
 				int h;
@@ -67,7 +67,7 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 				const int incl = wave_scan_max_incl(g);
 				int excl = wave_prev(incl, NEG_BIG);
 				excl = excl > pm_full ? excl : pm_full;
-				{ const int tot = __shfl(incl, 63); pm_full = pm_full > tot ? pm_full : tot; }
+				{ const int tot = __builtin_amdgcn_readlane(incl, 63); pm_full = pm_full > tot ? pm_full : tot; }
 				int ff = j == 0 ? 0 : excl - (j - 1) * e_ins;
 				ff = ff > 0 ? ff : 0;
 				// stripe-restricted F (restarts at every multiple of slen)
@@ -76,7 +76,7 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 				int sincl = wave_segscan_max_incl(g, hflag);
 				if (!hflag) sincl = sincl > carry_seg ? sincl : carry_seg;
 				const int sexcl = wave_prev(sincl, carry_seg);
-				carry_seg = __shfl(sincl, 63);
+				carry_seg = __builtin_amdgcn_readlane(sincl, 63);
 				int fs = head ? 0 : sexcl - (j - 1) * e_ins;
 				fs = fs > 0 ? fs : 0;
 				const int hpre = h > fs ? h : fs;

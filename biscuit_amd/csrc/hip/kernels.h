@@ -23,9 +23,15 @@ size_t regions_slab_bytes(int tier);
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters);
+                    unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
+                    const long long *pos_off, const unsigned long long *pos);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
-                         unsigned long long *counters);
+                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos);
+// K3 ahead of the region kernels: SA ranks of all occurrences of all strand searches listed into desc (pos_off[t] = where task
+// t's start, -1 = none listed), then turned into reference positions in place.  pos_off/pos feed launch_regions*.
+void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
+                const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
+                unsigned long long *counters);

@@ -49,10 +49,10 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -95,6 +95,7 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
 		HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
 		HIPCHK(hipEventCreate(&L.ev3));
+		HIPCHK(hipEventCreate(&L.ev4));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[0], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[1], hipEventDisableTiming));
 		if (L.slabflags.reserve((size_t)d->n_cu * 16 * 4) != BSX_OK) return BSX_E_NOMEM;
@@ -120,7 +121,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -130,6 +131,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.st_hi) (void)hipStreamDestroy(L.st_hi);
 		if (L.st2) (void)hipStreamDestroy(L.st2);
 		if (L.ev3) (void)hipEventDestroy(L.ev3);
+		if (L.ev4) (void)hipEventDestroy(L.ev4);
 	}
 	delete d;
 }
@@ -420,6 +422,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
+	R.dbg = getenv("BSX_RG_DBG") ? atoi(getenv("BSX_RG_DBG")) : 0;
 
 	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
@@ -440,6 +443,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.regmeta.reserve((size_t)n * 20 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
+	const unsigned long long pos_cap = (unsigned long long)n * 128 + (1u << 20);   // one u64 per seed occurrence of the chunk
+	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
+	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
+	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
 	int *retry_a = (int*)((char*)L.regmeta.p + (size_t)n * 12), *retry_b = (int*)((char*)L.regmeta.p + (size_t)n * 16);
@@ -457,14 +464,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
 	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
+	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr);
+	HIPCHK(hipEventRecord(L.ev4, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
 	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
-	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr);
+	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos);
 	HIPCHK(hipEventRecord(L.ev3, L.st));
 	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr);
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr);
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 
 	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats) are seeded again
 	// on the side stream with much longer lists, then go through the third tier as well.
@@ -518,7 +527,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipMemcpyAsync(c32 + 5, &n2u, 4, hipMemcpyHostToDevice, L.st2));
 		HIPCHK(hipStreamSynchronize(L.st2));   // the host vectors above go out of scope; the region kernels keep running on L.st
 		launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr);
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
 		redo_roff.resize(n2); redo_rn.resize(n2);
 		HIPCHK(hipMemcpyAsync(redo_roff.data(), roff2, n2 * 8, hipMemcpyDeviceToHost, L.st));
 		HIPCHK(hipMemcpyAsync(redo_rn.data(), rn2, n2 * 4, hipMemcpyDeviceToHost, L.st));
@@ -533,7 +542,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		                   (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, redo.size(), (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6,
 		                   (ts3.tv_sec - ts0.tv_sec) * 1e3 + (ts3.tv_nsec - ts0.tv_nsec) * 1e-6);
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
-		HIPCHK(hipEventElapsedTime(&ms1, L.ev1, L.ev3));   // the first region tier alone
+		float ms3 = 0;
+		HIPCHK(hipEventElapsedTime(&ms3, L.ev1, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
+		L.k_ms[1] += ms3; L.k_launch[1] += 1;
+		HIPCHK(hipEventElapsedTime(&ms1, L.ev4, L.ev3));   // the first region tier alone
 		HIPCHK(hipEventElapsedTime(&ms2, L.ev3, L.ev2));   // tiers 2 and 3 and the wait for re-seeded strand searches
 		L.k_ms[0] += ms0; L.k_launch[0] += 1; L.k_ms[5] += ms1; L.k_launch[5] += 1; L.k_ms[6] += ms2; L.k_launch[6] += 1;
 		HIPCHK(hipGetLastError());

@@ -10,32 +10,54 @@
 
 __device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
 
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(v, off); v = v > o ? v : o; }
-	return v;
-}
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(v, off); v = v < o ? v : o; }
-	return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-	return v;
-}
+// Cross-lane data movement goes through DPP (one VALU instruction, no LDS round trip) wherever the pattern allows:
+// shifts inside a row of 16 lanes, the row broadcasts that stitch rows together, the whole-wave shift by one lane.
+// __shfl_* compile to ds_bpermute, whose latency dominated the DP rows (a scan is six dependent steps).
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+// value of lane `src` (uniform src)
+__device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+
 // inclusive max-scan across the wave
 __device__ __forceinline__ int wave_scan_max_incl(int v)
 {
-	const int lane = wave_lane();
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(v, off); if (lane >= off) v = v > o ? v : o; }
+	int t;
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;   // rows 1,3 take lane 15 of the row before
+	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;   // rows 2,3 take lane 31
 	return v;
 }
+__device__ __forceinline__ int wave_scan_min_incl(int v)
+{
+	const int BIG = 0x7fffffff;
+	int t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v < t ? v : t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v < t ? v : t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v < t ? v : t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v < t ? v : t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v < t ? v : t;
+	t = __builtin_amdgcn_update_dpp(BIG, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v < t ? v : t;
+	return v;
+}
+__device__ __forceinline__ int wave_scan_sum_incl(int v)
+{
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(2), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(4), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR(8), 0xf, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xa, 0xf, false);
+	v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xc, 0xf, false);
+	return v;
+}
+// reductions: the last lane of the inclusive scan holds the result; every lane gets it back as a scalar
+__device__ __forceinline__ int wave_max_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_max_incl(v), 63); }
+__device__ __forceinline__ int wave_min_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_min_incl(v), 63); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_sum_incl(v), 63); }
 // segmented inclusive max-scan: `head` marks the first element of a segment.  On return `head`
 // holds "a segment head occurred at or before this lane within the wave".
 __device__ __forceinline__ int wave_segscan_max_incl(int v, int &head)
@@ -48,11 +70,5 @@ __device__ __forceinline__ int wave_segscan_max_incl(int v, int &head)
 	}
 	return v;
 }
-// value of lane `src` (uniform src)
-__device__ __forceinline__ int wave_bcast(int v, int src) { return __shfl(v, src); }
 // previous lane's value; lane 0 gets `first`
-__device__ __forceinline__ int wave_prev(int v, int first)
-{
-	int o = __shfl_up(v, 1);
-	return wave_lane() == 0 ? first : o;
-}
+__device__ __forceinline__ int wave_prev(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
