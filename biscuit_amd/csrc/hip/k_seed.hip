@@ -1,5 +1,6 @@
 // k_seed.hip -- K1+K2 (FM-index SMEM seeding) and K3 (suffix-array lookup) kernels, gfx950.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "seed_core.hpp"
 #include "kernels.h"
 
@@ -12,7 +13,8 @@
 // many more workgroups than fit on the chip, which lets kernels of a higher-priority stream (the back half of
 // the previous chunk) get compute units while this one is running.  Scratch slabs are therefore not tied to
 // the workgroup index: each wave takes a free slab and gives it back when it exits.
-__global__ void __launch_bounds__(256)
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC)
 k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
@@ -143,8 +145,16 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
                  int quota, unsigned int *slab_busy, int n_slabs)
 {
-	hipLaunchKernelGGL(k_seed, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+	static const int occ = getenv("BSX_SEED_OCC") ? atoi(getenv("BSX_SEED_OCC")) : 3;   // waves per SIMD the register allocation targets
+	if (occ <= 3)
+		hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+	else if (occ == 4)
+		hipLaunchKernelGGL(k_seed<4>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+	else
+		hipLaunchKernelGGL(k_seed<5>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

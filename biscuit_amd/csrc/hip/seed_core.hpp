@@ -53,7 +53,7 @@ struct SeedLane {
 	uint32_t n_slow, n_fast;
 };
 
-enum { SD_DONE = 0, SD_P1, SD_SMEM_BEGIN, SD_FWD, SD_FWD_POST, SD_FWD_DONE, SD_BWD_ROW, SD_BWD_ELEM, SD_BWD_POST,
+enum { SD_DONE = 0, SD_P1, SD_SMEM_BEGIN, SD_FWD, SD_FWD_POST, SD_FWD_DONE, SD_BWD_ELEM, SD_BWD_POST,
        SD_SMEM_END, SD_P2, SD_P3, SD_S1, SD_S1_POST };
 
 BSX_HD int seed_qbase(const SeedLane &L, int i)
@@ -143,10 +143,7 @@ BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			L.prev_is_A = 1; L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
 			L.ret = (int)(uint32_t)L.bufA[(size_t)L.prev_off * L.stride].info;
 			L.i = L.x0 - 1;
-			L.state = SD_BWD_ROW;
-			break;
-		case SD_BWD_ROW: // one backward position (bwt.c:345-346)
-			if (L.i < -1) { L.state = SD_SMEM_END; break; }
+			// first backward row set up here (x0 >= 0, so i >= -1): one trip through the switch less per SMEM
 			{
 				int b = L.i < 0 ? 4 : seed_qbase(L, L.i);
 				L.c = b < 4 ? b : -1;
@@ -155,11 +152,16 @@ BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			L.state = SD_BWD_ELEM;
 			break;
 		case SD_BWD_ELEM:
-			if (L.j >= L.nprev) { // end of the row (bwt.c:362-363)
+			if (L.j >= L.nprev) { // end of the row (bwt.c:362-363): roll over to the next one and go on with its first element
 				if (L.ncurr == 0) { L.state = SD_SMEM_END; break; }
 				L.prev_is_A = !L.prev_is_A; L.prev_off = 0; L.nprev = L.ncurr;
-				--L.i; L.state = SD_BWD_ROW;
-				break;
+				--L.i;
+					if (L.i < -1) { L.state = SD_SMEM_END; break; }
+				{
+					int b = L.i < 0 ? 4 : seed_qbase(L, L.i);
+					L.c = b < 4 ? b : -1;
+				}
+				L.j = 0; L.ncurr = 0; L.have_next = 0;   // nprev = the survivors of the row just finished: at least one
 			}
 			{
 				const DevIntv *prev = (L.prev_is_A ? L.bufA : L.bufB);
