@@ -163,37 +163,47 @@ def main():
         dist.all_reduce(c)   # "gather" of per-GPU record counts over RCCL
         tot_reads = int(c.item())
 
-    # rooflines of the two kernels that carry the run, both HBM-bound gathers over the FM index:
+    # rooflines of the two HBM-bound kernels, both random 64-byte gathers over the FM index:
     #   k_seed (K1+K2): 64 B per FM block touched by bwt_extend (two blocks unless k and l share one)
-    #   k_regions (K3 + chaining + extension, first tier): 64 B per LF step of bwt_sa + 8 B per SA sample read
-    # (durations are HIP-event times on the launch stream; the redo launches of k_seed on a handful of strand
-    #  searches and the slab tiers of k_regions are counted in the bytes but are a fraction of a percent)
+    #   k_occ  (K3):    64 B per LF step of bwt_sa + 8 B per SA sample + 16 B per occurrence (rank in, position out)
+    # Durations are HIP-event times on the launch stream over the timed region.  With chunks pipelined, kernels of
+    # different chunks share the device, so a launch lasts longer than it would alone; one extra chunk is therefore
+    # run unpipelined after the timed region and its event times are reported next to the live ones.
     ctr = dev.counters()
     ktimes = [dev.kernel_time(k) for k in range(7)]
-    seed_ms, seed_launches = ktimes[0]
-    reg_ms, reg_launches = ktimes[5]
+    alone = None
+    if not args.no_pipeline:
+        for k in range(7):
+            dev.kernel_time(k, reset=True)
+        extra = gen(777, pairs_per_step)
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(standalone)")
+        L.bsx_sim_free_reads(extra, n_reads)
+        alone = [dev.kernel_time(k) for k in range(7)]
 
-    def roof_of(name, alg_bytes, ms, launches, extra):
+    def roof_of(name, k, alg_bytes, extra):
+        ms, launches = ktimes[k]
         if not launches or ms <= 0:
             return None
         ach = alg_bytes / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
-             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": ms / launches}
+             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3)}
+        if alone and alone[k][1]:
+            r["avg_launch_ms_standalone"] = round(alone[k][0] / alone[k][1], 3)
+            r["achieved_standalone"] = round(alg_bytes / launches / (alone[k][0] / alone[k][1] * 1e-3) / 1e9, 2)
         r.update(extra)
         return r
 
-    roof_seed = roof_of("k_seed (K1+K2 SMEM seeding)", 64.0 * (ctr[0] + ctr[1]), seed_ms, seed_launches,
-                        {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)})
-    roof_reg = roof_of("k_regions (K3 SA lookup + chaining + banded extension, LDS tier)", 64.0 * ctr[2] + 8.0 * ctr[3], reg_ms, reg_launches,
-                       {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)})
-    roof, roof_other = (roof_reg, roof_seed) if (roof_reg and reg_ms >= seed_ms) else (roof_seed, roof_reg)
+    roof = roof_of("k_seed (K1+K2 SMEM seeding)", 0, 64.0 * (ctr[0] + ctr[1]),
+                   {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)})
+    roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
+                         {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L, B, idx, opt, args, ncores)
 
     if rank == 0:
-        names = ["seed", "sa", "extend", "sw", "global", "regions_tier1", "regions_tiers23_and_reseed_wait"]
+        names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23_and_reseed_wait"]
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
@@ -206,6 +216,7 @@ def main():
             "roofline_second_kernel": roof_other,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(7)},
+            "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(7)} if alone else None),
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
