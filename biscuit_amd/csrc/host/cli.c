@@ -5,6 +5,7 @@
 #include <ctype.h>
 #include <math.h>
 #include <getopt.h>
+#include <pthread.h>
 #include "bsx_core.h"
 #include "fastq.h"
 #include "pipeline.h"
@@ -165,6 +166,59 @@ static int g_use_stream = 0;
 typedef int (*process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
 /* shared by the product entry (HIP) and the test-only entry that injects another backend */
+/* ---- step 0 and step 2 of the reference's kt_pipeline (align.c:100-170) as two helper threads: one parses the next
+ * chunks of FASTQ ahead of the aligner, one writes finished chunks out, so that neither sits on the thread that runs
+ * the back half of the alignment.  Bounded queues of chunk records between them. */
+typedef struct { bsx_read_t *seqs; int n; int64_t idx; int ok; } chunk_rec_t;
+typedef struct {
+	pthread_mutex_t mu; pthread_cond_t cv;
+	chunk_rec_t q[4]; int head, count, closed;
+} chunk_q_t;
+static void cq_init(chunk_q_t *Q) { memset(Q, 0, sizeof(*Q)); pthread_mutex_init(&Q->mu, 0); pthread_cond_init(&Q->cv, 0); }
+static void cq_put(chunk_q_t *Q, chunk_rec_t r)
+{
+	pthread_mutex_lock(&Q->mu);
+	while (Q->count == 4) pthread_cond_wait(&Q->cv, &Q->mu);
+	Q->q[(Q->head + Q->count++) & 3] = r;
+	pthread_cond_broadcast(&Q->cv);
+	pthread_mutex_unlock(&Q->mu);
+}
+static void cq_close(chunk_q_t *Q) { pthread_mutex_lock(&Q->mu); Q->closed = 1; pthread_cond_broadcast(&Q->cv); pthread_mutex_unlock(&Q->mu); }
+static int cq_get(chunk_q_t *Q, chunk_rec_t *r)   /* 0 when the queue is closed and empty */
+{
+	int got = 0;
+	pthread_mutex_lock(&Q->mu);
+	while (Q->count == 0 && !Q->closed) pthread_cond_wait(&Q->cv, &Q->mu);
+	if (Q->count) { *r = Q->q[Q->head]; Q->head = (Q->head + 1) & 3; --Q->count; got = 1; pthread_cond_broadcast(&Q->cv); }
+	pthread_mutex_unlock(&Q->mu);
+	return got;
+}
+static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok);
+typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; int chunk, has_bc, copy_comment; volatile int stop; } reader_t;
+static void *reader_main(void *arg)
+{
+	reader_t *R = (reader_t*)arg;
+	int64_t idx = 0;
+	while (!R->stop) {
+		chunk_rec_t r;
+		int i;
+		r.seqs = bsx_fq_read_chunk(R->f1, R->f2, R->chunk, R->has_bc, &r.n);
+		if (r.seqs == 0 || r.n == 0) { free(r.seqs); break; }
+		if (!R->copy_comment) for (i = 0; i < r.n; ++i) { free(r.seqs[i].comment); r.seqs[i].comment = 0; }
+		r.idx = idx++; r.ok = 1;
+		cq_put(R->Q, r);
+	}
+	cq_close(R->Q);
+	return 0;
+}
+static void *writer_main(void *arg)
+{
+	chunk_q_t *Q = (chunk_q_t*)arg;
+	chunk_rec_t r;
+	while (cq_get(Q, &r)) emit_chunk(r.seqs, r.n, r.idx, r.ok);
+	return 0;
+}
+
 /* write out (or hand to the hook) the SAM text of a finished chunk and release its reads */
 static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok)
 {
@@ -365,6 +419,45 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			if ((rc = bsx_stream_open((bsx_device_t*)ud, opt, idx, pes0, &stream)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); return 1; }
 			depth = bsx_stream_depth(stream);
 		}
+		if (stream && !seq1) { /* reader thread -> this thread (stream push / back halves) -> writer thread */
+			chunk_q_t in_q, out_q;
+			reader_t R;
+			pthread_t th_r, th_w;
+			chunk_rec_t r;
+			cq_init(&in_q); cq_init(&out_q);
+			R.Q = &in_q; R.f1 = f1; R.f2 = f2; R.chunk = chunk; R.has_bc = opt->has_bc; R.copy_comment = copy_comment; R.stop = 0;
+			pthread_create(&th_r, 0, reader_main, &R);
+			pthread_create(&th_w, 0, writer_main, &out_q);
+			while (cq_get(&in_q, &r)) {
+				int64_t size = 0;
+				for (i = 0; i < r.n; ++i) size += r.seqs[i].l_seq;
+				if (bsx_shard_world > 1 && r.idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
+					n_processed += r.n;
+					for (i = 0; i < r.n; ++i) bsx_read_free(&r.seqs[i]);
+					free(r.seqs);
+					continue;
+				}
+				if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", r.n, (long)size);
+				rc = bsx_stream_push(stream, n_processed, r.n, r.seqs);
+				pend[n_pend].seqs = r.seqs; pend[n_pend].n = r.n; pend[n_pend].idx = r.idx; ++n_pend;
+				n_processed += r.n;
+				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; R.stop = 1; break; }
+				while (n_pend > depth - 1) { /* the push completed the oldest chunk in flight */
+					chunk_rec_t d; d.seqs = pend[0].seqs; d.n = pend[0].n; d.idx = pend[0].idx; d.ok = 1;
+					cq_put(&out_q, d);
+					for (i = 1; i < n_pend; ++i) pend[i - 1] = pend[i];
+					--n_pend;
+				}
+			}
+			if (rc) { chunk_rec_t d; while (cq_get(&in_q, &d)) { for (i = 0; i < d.n; ++i) bsx_read_free(&d.seqs[i]); free(d.seqs); } }   /* let the reader finish */
+			if (rc == 0 && (rc = bsx_stream_flush(stream)) != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+			for (i = 0; i < n_pend; ++i) { chunk_rec_t d; d.seqs = pend[i].seqs; d.n = pend[i].n; d.idx = pend[i].idx; d.ok = rc == 0; cq_put(&out_q, d); }
+			n_pend = 0;
+			cq_close(&out_q);
+			pthread_join(th_r, 0); pthread_join(th_w, 0);
+			bsx_stream_close(stream); stream = 0;
+			goto loop_done;
+		}
 		for (;;) {
 			int n = 0;
 			bsx_read_t *seqs = 0;
@@ -428,6 +521,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			for (i = 0; i < n_pend; ++i) emit_chunk(pend[i].seqs, pend[i].n, pend[i].idx, rc == 0);
 			bsx_stream_close(stream);
 		}
+loop_done: ;
 	}
 	fflush(stdout);
 	free(hdr_line); free(opt->adaptor1); free(opt->adaptor2); free(pes0); free(seq1); free(seq2);

@@ -52,25 +52,56 @@ static inline int fq_getc(bsx_fq_t *f)
 	return (int)f->buf[f->begin++];
 }
 
-/* read up to a delimiter: 0 = any white space, 2 = end of line; returns the delimiter or -1 */
 #define vec_putc(v, c) do { if ((v).n + 1 >= (v).m) bsx_vec_reserve(v, (v).n + 2); (v).a[(v).n++] = (char)(c); } while (0)
+/* refill the buffer if it is exhausted; 0 at end of file */
+static inline int fq_fill(bsx_fq_t *f)
+{
+	if (f->begin < f->end) return 1;
+	if (f->is_eof) return 0;
+	f->begin = 0;
+	f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
+	if (f->end <= 0) { f->is_eof = 1; f->end = 0; return 0; }
+	return 1;
+}
+
+/* read up to a delimiter: 0 = any white space, 1 = end of line; returns the delimiter or -1.  Whole runs are taken
+ * from the buffer at once (memchr / a tight scan) instead of a call per character. */
 static int fq_until(bsx_fq_t *f, int line_only, void *v_, int append)
 {
 	BSX_VEC(char) *v = v_;
-	int c, got = 0;
+	int c = -1, got = 0;
 	if (!append) v->n = 0;
 	for (;;) {
-		c = fq_getc(f);
-		if (c < 0) break;
+		const unsigned char *p, *q, *e;
+		size_t len;
+		if (!fq_fill(f)) { c = -1; break; }
 		got = 1;
-		if (line_only ? c == '\n' : isspace(c)) break;
-		vec_putc(*v, c);
+		p = f->buf + f->begin; e = f->buf + f->end;
+		if (line_only) q = (const unsigned char*)memchr(p, '\n', (size_t)(e - p));
+		else { for (q = p; q < e && !isspace(*q); ++q); if (q == e) q = 0; }
+		len = (size_t)((q ? q : e) - p);
+		if (len) { bsx_vec_reserve(*v, v->n + len + 2); memcpy(v->a + v->n, p, len); v->n += len; }
+		f->begin += (int)len + (q ? 1 : 0);
+		if (q) { c = *q; break; }
 	}
 	if (!got && c < 0) return -1;
 	if (line_only && v->n > 0 && v->a[v->n - 1] == '\r') --v->n;
 	bsx_vec_reserve(*v, v->n + 1);
 	v->a[v->n] = 0;
-	return c < 0 ? -1 : c; /* -1 at EOF */
+	return c; /* -1 at EOF */
+}
+
+/* skip the rest of the current line; -1 if the file ends first */
+static int fq_skip_line(bsx_fq_t *f)
+{
+	for (;;) {
+		const unsigned char *p, *q;
+		if (!fq_fill(f)) return -1;
+		p = f->buf + f->begin;
+		q = (const unsigned char*)memchr(p, '\n', (size_t)(f->end - f->begin));
+		if (q) { f->begin += (int)(q - p) + 1; return '\n'; }
+		f->begin = f->end;
+	}
 }
 
 /* returns sequence length, -1 at end of file, -2 on a truncated quality string */
@@ -96,8 +127,7 @@ static int fq_read(bsx_fq_t *f)
 	f->seq.a[f->seq.n] = 0;
 	if (c != '+') { if (c == -1) f->last_char = 0; return (int)f->seq.n; }
 	bsx_vec_reserve(f->qual, f->seq.n + 2);
-	while ((c = fq_getc(f)) != -1 && c != '\n');   /* rest of the '+' line */
-	if (c == -1) return -2;
+	if (fq_skip_line(f) < 0) return -2;   /* rest of the '+' line */
 	while (f->qual.n < f->seq.n) { if (fq_until(f, 1, &f->qual, 1) < 0) break; }
 	f->last_char = 0;
 	if (f->seq.n != f->qual.n) return -2;

@@ -295,7 +295,7 @@ static int merge_score_fn(void *ud_, const reg_t *a, const reg_t *b, int w, int 
 	return 1;
 }
 
-typedef struct { chunk_t *C; merge_ud_t *ud; reg_v *saved; int *pending; } merge_par_t;
+typedef struct { chunk_t *C; merge_ud_t *ud; int *pending; } merge_par_t;
 
 static void regs_copy(reg_v *dst, const reg_v *src)
 {
@@ -313,7 +313,16 @@ static void merge_worker(void *data, long i, int tid)
 	size_t k;
 	(void)tid;
 	if (!P->pending[i]) return;
-	regs_copy(regs, &P->saved[i]);
+	{ /* (re)start from the regions of the read's strand searches, concatenated in call order */
+		int t; size_t tot = 0;
+		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
+		if (regs->m < tot) { regs->m = tot + 2; regs->a = (reg_t*)realloc(regs->a, sizeof(reg_t) * regs->m); }
+		regs->n = 0; regs->n_pri = 0;
+		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
+			const c2r_t *T = &C->tasks[t];
+			if (T->regs.n) { memcpy(regs->a + regs->n, T->regs.a, sizeof(reg_t) * T->regs.n); regs->n += T->regs.n; }
+		}
+	}
 	P->ud[i].wanted.n = 0;
 	bsx_regs_sort_dedup(C->opt, &C->idx->ref, 1, regs, merge_score_fn, &P->ud[i], &missing);
 	if (missing) return; /* retried once the scores have been computed */
@@ -340,21 +349,11 @@ static int64_t prefix_counts(long n, const int *cnt, int64_t *off)
 
 typedef struct { merge_par_t *P; int *cnt; int64_t *off; bsx_glb_job_t *jobs; const bsx_glb_res_t *res; } merge_aux_t;
 
-static void merge_init_worker(void *data, long i, int tid)   /* concatenate the regions of the read's strand searches in call order */
+static void merge_init_worker(void *data, long i, int tid)
 {
 	merge_par_t *P = (merge_par_t*)data;
-	chunk_t *C = P->C;
-	reg_v *r = &P->saved[i];
-	int t;
-	size_t tot = 0;
 	(void)tid;
-	P->ud[i].C = C; P->ud[i].read = (int)i;
-	for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
-	if (tot) { r->m = tot; r->a = (reg_t*)malloc(sizeof(reg_t) * r->m); }
-	for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
-		c2r_t *T = &C->tasks[t];
-		if (T->regs.n) { memcpy(r->a + r->n, T->regs.a, sizeof(reg_t) * T->regs.n); r->n += T->regs.n; }
-	}
+	P->ud[i].C = P->C; P->ud[i].read = (int)i;
 	P->pending[i] = 1;
 }
 static void merge_count_worker(void *data, long i, int tid)
@@ -392,7 +391,7 @@ static void merge_free_worker(void *data, long i, int tid)
 {
 	merge_par_t *P = (merge_par_t*)data;
 	(void)tid;
-	bsx_vec_free(P->ud[i].cache); bsx_vec_free(P->ud[i].wanted); free(P->saved[i].a);
+	bsx_vec_free(P->ud[i].cache); bsx_vec_free(P->ud[i].wanted);
 }
 
 static int merge_regions(chunk_t *C)
@@ -402,7 +401,6 @@ static int merge_regions(chunk_t *C)
 	merge_aux_t A;
 	P.C = C;
 	P.ud = (merge_ud_t*)calloc(n ? n : 1, sizeof(merge_ud_t));
-	P.saved = (reg_v*)calloc(n ? n : 1, sizeof(reg_v));
 	P.pending = (int*)malloc(sizeof(int) * (n ? n : 1));
 	A.P = &P; A.cnt = (int*)malloc(sizeof(int) * ((size_t)n + 1)); A.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n + 1));
 	bsx_parallel_for(C->nt, merge_init_worker, &P, n);
@@ -424,14 +422,14 @@ static int merge_regions(chunk_t *C)
 		if (rc != BSX_OK) break;
 	}
 	bsx_parallel_for(C->nt, merge_free_worker, &P, n);
-	free(P.ud); free(P.saved); free(P.pending); free(A.cnt); free(A.off);
+	free(P.ud); free(P.pending); free(A.cnt); free(A.off);
 	return rc;
 }
 
 /* ------------------------------------------------------------------ mate rescue (mem_alnreg.c:395-513) */
 typedef struct { int i, j; bsx_sw_job_t job; bsx_sw_res_t res; int have; } msw_slot_t;
 typedef struct {
-	reg_v saved[2];
+	reg_v saved[2]; int have_saved;
 	BSX_VEC(msw_slot_t) slots;
 	int pending;
 } msw_pair_t;
@@ -499,21 +497,36 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 	const bsx_opt_t *opt = C->opt;
 	reg_v *pair = &C->regs[pi << 1];
 	reg_v good[2];
+	reg_t small[2][8];
 	int i, missing = 0;
 	size_t j;
-	regs_copy(&pair[0], &M->saved[0]); regs_copy(&pair[1], &M->saved[1]);
+	/* The first pass only collects SW requests: a request returns before anything is applied, so the lists are still
+	 * the originals.  They are saved when the first results are about to be applied, and every later pass (a rescued
+	 * hit can change what the following candidates see) restarts from that copy. */
+	if (M->slots.n) {
+		if (!M->have_saved) { regs_copy(&M->saved[0], &pair[0]); regs_copy(&M->saved[1], &pair[1]); M->have_saved = 1; }
+		else { regs_copy(&pair[0], &M->saved[0]); regs_copy(&pair[1], &M->saved[1]); }
+	}
 	memset(good, 0, sizeof(good));
-	for (i = 0; i < 2; ++i)
+	for (i = 0; i < 2; ++i) {
+		good[i].a = small[i]; good[i].m = 8;
 		for (j = 0; j < pair[i].n; ++j)
 			if (pair[i].a[j].score >= pair[i].a[0].score - opt->pen_unpaired) {
-				if (good[i].n == good[i].m) { good[i].m = good[i].m ? good[i].m << 1 : 4; good[i].a = (reg_t*)realloc(good[i].a, sizeof(reg_t) * good[i].m); }
+				if (good[i].n == good[i].m) {
+					reg_t *na = (reg_t*)malloc(sizeof(reg_t) * (good[i].m << 1));
+					memcpy(na, good[i].a, sizeof(reg_t) * good[i].n);
+					if (good[i].a != small[i]) free(good[i].a);
+					good[i].a = na; good[i].m <<= 1;
+				}
 				good[i].a[good[i].n++] = pair[i].a[j];
 			}
+	}
 	for (i = 0; i < 2; ++i)
 		for (j = 0; j < good[i].n && (int)j < opt->max_matesw; ++j)
 			/* once a result is missing, keep walking (without applying) only to collect further requests */
 			missing |= matesw_core(C, M, pi, i, (int)j, &good[i].a[j], (pi << 1) | !i, &pair[!i], !missing);
-	free(good[0].a); free(good[1].a);
+	if (good[0].a != small[0]) free(good[0].a);
+	if (good[1].a != small[1]) free(good[1].a);
 	return missing;
 }
 
@@ -528,7 +541,7 @@ static void msw_init_worker(void *data, long pi, int tid)
 {
 	msw_par_t *P = (msw_par_t*)data;
 	(void)tid;
-	regs_copy(&P->M[pi].saved[0], &P->C->regs[pi << 1]); regs_copy(&P->M[pi].saved[1], &P->C->regs[pi << 1 | 1]); P->M[pi].pending = 1;
+	P->M[pi].pending = 1;
 }
 static void msw_count_worker(void *data, long pi, int tid)
 {

@@ -142,3 +142,22 @@ BSX_API void bsx_sim_free_reads(bsx_read_t *reads, int64_t n)
 	for (i = 0; i < n; ++i) { free(reads[i].name); free(reads[i].comment); free(reads[i].barcode); free(reads[i].umi); free(reads[i].seq0); free(reads[i].qual); free(reads[i].sam); }
 	free(reads);
 }
+
+/* the pairs of bsx_sim_pairs as two FASTQ files (end-to-end runs of the command line) */
+BSX_API int bsx_sim_write_fastq(const bsx_read_t *reads, int64_t n, const char *fq1, const char *fq2, int append)
+{
+	FILE *f[2];
+	int64_t i;
+	int k;
+	f[0] = fopen(fq1, append ? "a" : "w"); f[1] = fopen(fq2, append ? "a" : "w");
+	if (!f[0] || !f[1]) { if (f[0]) fclose(f[0]); if (f[1]) fclose(f[1]); return BSX_E_IO; }
+	for (i = 0; i < n; ++i) {
+		const bsx_read_t *r = &reads[i];
+		FILE *o = f[i & 1];
+		fputc('@', o); fputs(r->name, o); fputc('\n', o);
+		for (k = 0; k < r->l_seq; ++k) fputc("ACGTN"[r->seq[k] < 4 ? r->seq[k] : 4], o);
+		fputs("\n+\n", o); fputs(r->qual, o); fputc('\n', o);
+	}
+	fclose(f[0]); fclose(f[1]);
+	return BSX_OK;
+}

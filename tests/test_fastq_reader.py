@@ -1,0 +1,142 @@
+"""CPU: the FASTA/FASTQ reader (csrc/host/fastq.c) against a direct Python statement of klib's kseq_read grammar
+(lib/aln/kseq.h:182-222) and of bis_bseq_read's chunk rule (lib/aln/bwa.c:817-850)."""
+import ctypes as C
+import gzip
+import random
+from biscuit_amd import _lib as B
+
+
+def kseq_records(text):
+    """kseq_read: header '>' or '@', name to the first white space, comment = rest of line, sequence lines until a line
+    starting with '>', '@' or '+', then quality lines until as many characters as bases."""
+    recs, i, n = [], 0, len(text)
+    while True:
+        while i < n and text[i] not in ">@":
+            i += 1
+        if i >= n:
+            break
+        i += 1
+        j = i
+        while j < n and not text[j].isspace():
+            j += 1
+        name = text[i:j]
+        comment = ""
+        if j < n and text[j] != "\n":
+            k = text.find("\n", j + 1)
+            k = n if k < 0 else k
+            comment = text[j + 1:k].rstrip("\r")
+            j = k
+        i = j + 1
+        seq = []
+        while i < n and text[i] not in ">+@":
+            k = text.find("\n", i)
+            k = n if k < 0 else k
+            seq.append(text[i:k].rstrip("\r"))
+            i = k + 1
+        seq = "".join(seq)
+        qual = None
+        if i < n and text[i] == "+":
+            k = text.find("\n", i)
+            i = (n if k < 0 else k) + 1
+            q = []
+            while sum(map(len, q)) < len(seq) and i < n:
+                k = text.find("\n", i)
+                k = n if k < 0 else k
+                q.append(text[i:k].rstrip("\r"))
+                i = k + 1
+            qual = "".join(q)
+            if len(qual) != len(seq):
+                break   # truncated quality: the reader stops here
+        recs.append((name, comment, seq, qual))
+    return recs
+
+
+def read_all(path1, path2, chunk_size):
+    L = B.lib()
+    L.bsx_hook_fq_open.restype = C.c_void_p
+    L.bsx_hook_fq_open.argtypes = [C.c_char_p]
+    L.bsx_hook_fq_close.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_chunk.restype = C.POINTER(B.Read)
+    L.bsx_hook_fq_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    f1 = L.bsx_hook_fq_open(path1.encode())
+    f2 = L.bsx_hook_fq_open(path2.encode()) if path2 else None
+    chunks = []
+    while True:
+        n = C.c_int()
+        r = L.bsx_hook_fq_chunk(f1, f2, chunk_size, 0, C.byref(n))
+        if not r or n.value == 0:
+            break
+        out = []
+        for i in range(n.value):
+            x = r[i]
+            out.append((x.name.decode(), (x.comment or b"").decode(), "".join("ACGTN"[x.seq[k]] for k in range(x.l_seq)), x.qual.decode() if x.qual else None))
+        chunks.append(out)
+        L.bsx_sim_free_reads(r, n.value)
+    L.bsx_hook_fq_close(f1)
+    if f2:
+        L.bsx_hook_fq_close(f2)
+    return chunks
+
+
+def make_text(rng, n, fastq=True, crlf=False, multiline=False):
+    eol = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(n):
+        l = rng.choice([0, 1, 7, 60, 61, 150, 300]) if i % 11 == 0 else rng.randint(20, 200)
+        seq = "".join(rng.choice("ACGTN") for _ in range(l))
+        name = "r%d" % i + ("/1" if i % 3 == 0 else "")
+        com = " some comment %d" % i if i % 4 == 0 else ""
+        width = 60 if multiline else max(1, l)
+        lines = [seq[k:k + width] for k in range(0, l, width)] or [""]
+        if fastq:
+            qual = "".join(rng.choice("!#5I@>+") for _ in range(l))   # '@', '>' and '+' may start a quality line
+            qlines = [qual[k:k + width] for k in range(0, l, width)] or [""]
+            out.append("@" + name + com + eol + eol.join(lines) + eol + "+" + (name if i % 5 == 0 else "") + eol + eol.join(qlines) + eol)
+        else:
+            out.append(">" + name + com + eol + eol.join(lines) + eol)
+    return "".join(out)
+
+
+def check(tmp_path, text, gz=False, chunk_size=2000):
+    p = str(tmp_path / ("x.fq.gz" if gz else "x.fq"))
+    (gzip.open(p, "wt", newline="") if gz else open(p, "w", newline="")).write(text)
+    want = [(n[:-2] if len(n) > 2 and n[-2] == "/" and n[-1].isdigit() else n, c, s.upper().translate(str.maketrans("BDEFHIJKLMOPQRSUVWXYZ", "N" * 21)), q or None)
+            for n, c, s, q in kseq_records(text)]
+    chunks = read_all(p, None, chunk_size)
+    got = [r for ch in chunks for r in ch]
+    assert got == want
+    # chunk rule: a chunk ends at the first even record count once it holds >= chunk_size bases
+    for ch in chunks[:-1]:
+        tot = 0
+        for k, r in enumerate(ch):
+            tot += len(r[2])
+            if tot >= chunk_size and (k + 1) % 2 == 0:
+                assert k + 1 == len(ch)
+                break
+        else:
+            raise AssertionError("chunk ended early")
+
+
+def test_fastq_grammar_variants(tmp_path):
+    rng = random.Random(5)
+    check(tmp_path, make_text(rng, 400))
+    check(tmp_path, make_text(rng, 300, crlf=True))
+    check(tmp_path, make_text(rng, 300, multiline=True))
+    check(tmp_path, make_text(rng, 300, fastq=False, multiline=True))
+    check(tmp_path, make_text(rng, 300, multiline=True), gz=True)
+    check(tmp_path, make_text(rng, 50).rstrip("\n"))                       # no newline at the end of the file
+    check(tmp_path, "garbage before\n" + make_text(rng, 20))
+    check(tmp_path, make_text(rng, 5000), chunk_size=100000)               # records straddling the 256 KB buffer
+
+
+def test_paired_files_interleave(tmp_path):
+    rng = random.Random(6)
+    a, b = make_text(rng, 200), make_text(rng, 200)
+    p1, p2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    open(p1, "w").write(a)
+    open(p2, "w").write(b)
+    got = [r for ch in read_all(p1, p2, 3000) for r in ch]
+    ra, rb = kseq_records(a), kseq_records(b)
+    assert len(got) == 400
+    assert [g[2] for g in got[0::2]] == [r[2] for r in ra] and [g[2] for g in got[1::2]] == [r[2] for r in rb]
