@@ -193,10 +193,26 @@ def main():
         r.update(extra)
         return r
 
+    # HBM traffic per launch from the committed counter passes (rocprofv3 --pmc cannot run inside this process; the
+    # passes profile this same command, one chunk per launch), only quoted when the workload is the profiled one
+    traffic = {}
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and abs(args.genome_mbp - 128) < 1e-9 and args.read_len == 150 and threads == 16:
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("_reads_per_chunk") == n_reads:
+            for kname in ("k_seed", "k_occ"):
+                if tj.get(kname, {}).get("FETCH_SIZE_KiB") is not None and tj[kname].get("WRITE_SIZE_KiB") is not None:
+                    traffic[kname] = 1024.0 * (tj[kname]["FETCH_SIZE_KiB"] + tj[kname]["WRITE_SIZE_KiB"])
+
     roof = roof_of("k_seed (K1+K2 SMEM seeding)", 0, 64.0 * (ctr[0] + ctr[1]),
                    {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)})
     roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
                          {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)})
+    for r, kname in ((roof, "k_seed"), (roof_other, "k_occ")):
+        if r and kname in traffic:
+            r["traffic"] = traffic[kname]
+            r["traffic_source"] = "FETCH_SIZE+WRITE_SIZE of profiles/r01_traffic.json: separate rocprofv3 --pmc passes of this command, calibrated on k_occ's known 64-byte gathers"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
