@@ -300,7 +300,7 @@ typedef struct { chunk_t *C; merge_ud_t *ud; int *pending; } merge_par_t;
 static void regs_copy(reg_v *dst, const reg_v *src)
 {
 	dst->n = src->n; dst->n_pri = src->n_pri;
-	if (dst->m < src->n) { dst->m = src->n + 4; dst->a = (reg_t*)realloc(dst->a, sizeof(reg_t) * dst->m); }
+	if (dst->m < src->n) { dst->a = (reg_t*)bsx_crealloc(dst->a, 0, sizeof(reg_t) * (src->n + 4)); dst->m = src->n + 4; }
 	if (src->n) memcpy(dst->a, src->a, sizeof(reg_t) * src->n);
 }
 
@@ -316,7 +316,7 @@ static void merge_worker(void *data, long i, int tid)
 	{ /* (re)start from the regions of the read's strand searches, concatenated in call order */
 		int t; size_t tot = 0;
 		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
-		if (regs->m < tot) { regs->m = tot + 2; regs->a = (reg_t*)realloc(regs->a, sizeof(reg_t) * regs->m); }
+		if (regs->m < tot) { regs->a = (reg_t*)bsx_crealloc(regs->a, 0, sizeof(reg_t) * (tot + 2)); regs->m = tot + 2; }
 		regs->n = 0; regs->n_pri = 0;
 		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) {
 			const c2r_t *T = &C->tasks[t];
@@ -481,7 +481,7 @@ static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const re
 		b.seedcov = (int)((d1 < d2 ? d1 : d2) >> 1);
 		b.bss = reg->bss; b.parent = (uint8_t)(1 - parent);
 		/* keep the mate list ordered by score, then de-duplicate without merging (mem_alnreg.c:478-488) */
-		if (mregs->n == mregs->m) { mregs->m = mregs->m ? mregs->m << 1 : 4; mregs->a = (reg_t*)realloc(mregs->a, sizeof(reg_t) * mregs->m); }
+		if (mregs->n == mregs->m) { size_t m2 = mregs->m ? mregs->m << 1 : 4; mregs->a = (reg_t*)bsx_crealloc(mregs->a, sizeof(reg_t) * mregs->n, sizeof(reg_t) * m2); mregs->m = m2; }
 		++mregs->n;
 		for (ins = 0; (size_t)ins < mregs->n - 1; ++ins) if (mregs->a[ins].score < b.score) break;
 		for (pos = (int)mregs->n - 1; pos > ins; --pos) mregs->a[pos] = mregs->a[pos - 1];
@@ -569,7 +569,7 @@ static void msw_free_worker(void *data, long pi, int tid)
 {
 	msw_par_t *P = (msw_par_t*)data;
 	(void)tid;
-	free(P->M[pi].saved[0].a); free(P->M[pi].saved[1].a); bsx_vec_free(P->M[pi].slots);
+	bsx_cfree(P->M[pi].saved[0].a); bsx_cfree(P->M[pi].saved[1].a); bsx_vec_free(P->M[pi].slots);
 }
 
 static int mate_rescue(chunk_t *C)
@@ -628,7 +628,7 @@ static void out_worker(void *data, long u, int tid)
 			regs_copy(&tmp[0], &pair[0]); regs_copy(&tmp[1], &pair[1]);
 			ctx->plan = 1;
 			bsx_reg2sam_pe(C->opt, C->idx, (uint64_t)((C->n_processed >> 1) + u), &C->reads[u << 1], tmp, &C->pes, ctx, bsx_rg_id);
-			free(tmp[0].a); free(tmp[1].a);
+			bsx_cfree(tmp[0].a); bsx_cfree(tmp[1].a);
 		} else {
 			ctx->plan = 0;
 			bsx_reg2sam_pe(C->opt, C->idx, (uint64_t)((C->n_processed >> 1) + u), &C->reads[u << 1], pair, &C->pes, ctx, bsx_rg_id);
@@ -643,7 +643,7 @@ static void out_worker(void *data, long u, int tid)
 			regs_copy(&tmp, regs);
 			ctx->plan = 1;
 			bsx_reg2sam_se(C->opt, C->idx, &C->reads[u], &tmp, ctx, bsx_rg_id);
-			free(tmp.a);
+			bsx_cfree(tmp.a);
 		} else {
 			ctx->plan = 0;
 			bsx_reg2sam_se(C->opt, C->idx, &C->reads[u], regs, ctx, bsx_rg_id);
@@ -682,7 +682,8 @@ static void plan_jobs_worker(void *data, long u, int tid)
 	for (w = 0; w < Q->per; ++w) {
 		int ri = (int)u * Q->per + w;
 		reg_v *regs = &C->regs[ri];
-		Q->ctx[u].table[w] = (samrec_t*)calloc(regs->n ? regs->n : 1, sizeof(samrec_t));
+		Q->ctx[u].table[w] = (samrec_t*)bsx_crealloc(0, 0, sizeof(samrec_t) * (regs->n ? regs->n : 1));
+		memset(Q->ctx[u].table[w], 0, sizeof(samrec_t) * (regs->n ? regs->n : 1));
 		for (k = 0; k < Q->ctx[u].want[w].n; ++k, ++at) {
 			int gi = Q->ctx[u].want[w].a[k];
 			bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &Q->jobs[at]);
@@ -698,8 +699,8 @@ static void plan_free_worker(void *data, long u, int tid)
 	(void)tid;
 	for (w = 0; w < Q->per; ++w) {
 		reg_v *regs = &Q->C->regs[u * Q->per + w];
-		if (Q->ctx[u].table[w]) for (k = 0; k < regs->n; ++k) free(Q->ctx[u].table[w][k].cigar);
-		free(Q->ctx[u].table[w]); bsx_vec_free(Q->ctx[u].want[w]);
+		if (Q->ctx[u].table[w]) for (k = 0; k < regs->n; ++k) bsx_cfree(Q->ctx[u].table[w][k].cigar);
+		bsx_cfree(Q->ctx[u].table[w]); bsx_cvec_free(Q->ctx[u].want[w]);
 	}
 }
 
@@ -752,7 +753,7 @@ static int emit_sam(chunk_t *C)
 	C->st.t_cigar += now_s() - t0; t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
-	bsx_parallel_for(C->nt, plan_free_worker, &Q, n_units);
+	if (C->arena_set < 0) bsx_parallel_for(C->nt, plan_free_worker, &Q, n_units);   /* arena memory is rewound with the chunk */
 	C->st.t_sam += now_s() - t0;
 	free(ctx); free(pool); free(Q.cnt); free(Q.off); free(Q.jobs); free(Q.jread); free(Q.jreg);
 	bsx_vec_free(todo);
@@ -829,7 +830,7 @@ static void adopt_worker(void *data, long t, int tid)
 		bsx_cvec_push(T->regs, r);
 	}
 }
-static void release_regs_worker(void *data, long i, int tid) { (void)tid; free(((chunk_t*)data)->regs[i].a); }
+static void release_regs_worker(void *data, long i, int tid) { (void)tid; bsx_cfree(((chunk_t*)data)->regs[i].a); }
 
 /* ------------------------------------------------------------------ the chunk */
 #define FCHECK(x) do { rc = (x); if (rc != BSX_OK) return rc; } while (0)
@@ -1049,7 +1050,7 @@ static void chunk_free(chunk_t *C)
 		if (C->arena_set < 0) bsx_parallel_for(nt, release_worker, C, C->n_tasks);   /* arena memory is rewound, not freed */
 		free(C->tasks);
 	}
-	if (C->regs) { bsx_parallel_for(nt, release_regs_worker, C, C->n); free(C->regs); }
+	if (C->regs) { if (C->arena_set < 0) bsx_parallel_for(nt, release_regs_worker, C, C->n); free(C->regs); }
 	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); }
 	free(C->roff); free(C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
 	for (t = 0; t < C->n_host; ++t) { if (C->xpos) free(C->xpos[t]); if (C->xpos_off) free(C->xpos_off[t]); }

@@ -113,7 +113,7 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 	out->ZR = parent ? n_ret_c : n_ret_g;
 	out->bss_u = (n_conv_ct == 0 && n_conv_ga == 0) ? 1 : 0;
 	/* position, strand, D squeezing and clipping (mem_alnreg_format.c:79-120) */
-	cigar = (uint32_t*)malloc(4 * ((size_t)n_cigar + 2) + l_MD + 4);
+	cigar = (uint32_t*)bsx_crealloc(0, 0, 4 * ((size_t)n_cigar + 2) + l_MD + 4);   /* chunk lifetime: from the worker's arena */
 	memcpy(cigar, cg, 4 * (size_t)n_cigar);
 	rpos = bsx_depos(l_pac, reg->rb < l_pac ? reg->rb : reg->re - 1, &is_rev);
 	out->is_rev = (uint32_t)is_rev;
@@ -146,7 +146,7 @@ static void set_sam(drv_t *D, int which, reg_v *regs, reg_t *reg)
 	int ri = (int)(reg - regs->a);
 	if (reg->n_cigar > 0) return;   /* mem_alnreg_format.c:42 */
 	if (D->ctx->plan) {
-		bsx_vec_push(D->ctx->want[which], ri);
+		bsx_cvec_push(D->ctx->want[which], ri);
 		reg->n_cigar = 1;  /* stands for "will have a CIGAR" during planning */
 		return;
 	}

@@ -284,19 +284,19 @@ int bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids)
 typedef struct {
 	bsx_for_fn fn; void *data; long n; volatile long next; long grain; int n_part;
 	int arena_set;   /* of the calling thread: the workers allocate from the same chunk's arenas */
+	int n_inside;    /* workers currently running this loop */
 } pf_job_t;
 
+/* Several loops can be open at once (the front half of one chunk and the back half of another each run theirs):
+ * idle workers join whichever open loop still has iterations left, so a short loop never queues behind a long one. */
+#define PF_MAX_JOBS 4
 static struct {
-	pthread_mutex_t call_mu;      /* one parallel loop at a time */
 	pthread_mutex_t mu;
 	pthread_cond_t cv_work, cv_done;
 	int n_workers, m_workers;
 	pthread_t *th;
-	pf_job_t *job;
-	long generation;
-	int n_done;
-	int init;
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0, 0, 0 };
+	pf_job_t *jobs[PF_MAX_JOBS];
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, {0, 0, 0, 0} };
 
 /* ---- arenas ---- */
 #define ARENA_BLOCK ((size_t)32 << 20)
@@ -379,21 +379,23 @@ static void pf_run(pf_job_t *J, int tid)
 static void *pf_worker(void *arg)
 {
 	int id = (int)(intptr_t)arg;   /* participates as tid id+1 */
-	long seen = 0;
 	/* the workers yield to the threads that feed the device (the front half of the next chunk, the HIP runtime's
 	 * own threads) when there are fewer cores than runnable threads */
 	{ const char *e = getenv("BSX_WORKER_NICE"); int nv = e ? atoi(e) : 5; if (nv > 0) setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nv); }
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
-		pf_job_t *J;
-		while (g_pool.generation == seen) pthread_cond_wait(&g_pool.cv_work, &g_pool.mu);
-		seen = g_pool.generation;
-		J = g_pool.job;
-		if (J == 0 || id + 1 >= J->n_part) continue;
+		pf_job_t *J = 0;
+		int k;
+		for (k = 0; k < PF_MAX_JOBS; ++k) {
+			pf_job_t *c = g_pool.jobs[k];
+			if (c && id + 1 < c->n_part && c->next < c->n) { J = c; break; }
+		}
+		if (!J) { pthread_cond_wait(&g_pool.cv_work, &g_pool.mu); continue; }
+		++J->n_inside;
 		pthread_mutex_unlock(&g_pool.mu);
 		pf_run(J, id + 1);
 		pthread_mutex_lock(&g_pool.mu);
-		if (++g_pool.n_done == J->n_part - 1) pthread_cond_signal(&g_pool.cv_done);
+		if (--J->n_inside == 0) pthread_cond_broadcast(&g_pool.cv_done);
 	}
 	return 0;
 }
@@ -401,11 +403,11 @@ static void *pf_worker(void *arg)
 void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
 {
 	long i;
+	int slot;
 	pf_job_t J;
 	if (n <= 0) return;
 	if (n_threads > n) n_threads = (int)n;
 	if (n_threads <= 1) { for (i = 0; i < n; ++i) fn(data, i, 0); return; }
-	pthread_mutex_lock(&g_pool.call_mu);
 	pthread_mutex_lock(&g_pool.mu);
 	while (g_pool.n_workers < n_threads - 1) { /* grow the pool on demand */
 		if (g_pool.n_workers == g_pool.m_workers) {
@@ -417,17 +419,22 @@ void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
 		++g_pool.n_workers;
 	}
 	if (n_threads - 1 > g_pool.n_workers) n_threads = g_pool.n_workers + 1;
-	J.fn = fn; J.data = data; J.n = n; J.next = 0; J.n_part = n_threads; J.arena_set = tls_arena_set;
+	J.fn = fn; J.data = data; J.n = n; J.next = 0; J.n_part = n_threads; J.arena_set = tls_arena_set; J.n_inside = 0;
 	J.grain = n / (n_threads * 8L); if (J.grain < 1) J.grain = 1; if (J.grain > 1024) J.grain = 1024;
-	g_pool.job = &J; g_pool.n_done = 0; ++g_pool.generation;
+	for (;;) { /* a free slot (more than PF_MAX_JOBS callers at once: wait for one to finish) */
+		for (slot = 0; slot < PF_MAX_JOBS; ++slot) if (!g_pool.jobs[slot]) break;
+		if (slot < PF_MAX_JOBS) break;
+		pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+	}
+	g_pool.jobs[slot] = &J;
 	pthread_cond_broadcast(&g_pool.cv_work);
 	pthread_mutex_unlock(&g_pool.mu);
 	pf_run(&J, 0);
 	pthread_mutex_lock(&g_pool.mu);
-	while (g_pool.n_done < n_threads - 1) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
-	g_pool.job = 0;
+	g_pool.jobs[slot] = 0;                 /* nobody new joins; wait for the workers still inside */
+	while (J.n_inside > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+	pthread_cond_broadcast(&g_pool.cv_done);   /* a caller may be waiting for the slot */
 	pthread_mutex_unlock(&g_pool.mu);
-	pthread_mutex_unlock(&g_pool.call_mu);
 }
 
 /* The host stages allocate millions of small records per chunk from many threads.  With glibc's
