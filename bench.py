@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "128")))
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
@@ -120,6 +120,9 @@ def main():
         n_processed += n_reads
     if not args.no_pipeline:
         B.check(L.bsx_stream_flush(stream), "stream_flush(warmup)")
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    for s_ in range(args.warmup):
+        L.bsx_sim_reset_reads(chunks[s_], n_reads)   # drop the warm-up chunks' SAM text
     for k in range(7):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
@@ -129,6 +132,14 @@ def main():
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.time()
+    sam_bytes_box = [0]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+
+    def retire(k):
+        # a completed chunk: count its SAM text, then drop it (13 chunks of SAM would be several GB per rank)
+        sam_bytes_box[0] += L.bsx_sim_sam_bytes(chunks[k], n_reads)
+        L.bsx_sim_reset_reads(chunks[k], n_reads)
+
     def account():
         ps = B.PhaseStats()
         L.bsx_last_phase_stats(C.byref(ps))
@@ -140,19 +151,23 @@ def main():
         if args.no_pipeline:
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs")
             account()
+            retire(s)
         else:
             B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push")
             if s - args.warmup >= depth - 1:
                 account()       # the push completed the chunk pushed depth-1 pushes ago
+                retire(s - (depth - 1))
         n_processed += n_reads
     if not args.no_pipeline:
         B.check(L.bsx_stream_flush(stream), "stream_flush")   # the chunks still in flight complete inside the timed region
         account()               # (the statistics of the last one stand in for the others drained with it)
+        for k in range(max(args.warmup, args.warmup + args.steps - (depth - 1)), args.warmup + args.steps):
+            retire(k)
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
-    sam_bytes = sum(L.bsx_sim_sam_bytes(chunks[s], n_reads) for s in range(args.warmup, args.warmup + args.steps))
+    sam_bytes = sam_bytes_box[0]
 
     tmax, tot_reads = dt, n_reads * args.steps
     if dist is not None:
