@@ -107,15 +107,18 @@ __device__ __forceinline__ int rg_cal_max_gap(const RegParams &P, int qlen)   //
 	l = l > 1 ? l : 1;
 	return l < P.w << 1 ? l : P.w << 1;
 }
+// cal_max_gap for every length a read of this kernel can ask about, tabulated once per workgroup (two double divisions each)
+__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (unsigned)qlen <= (unsigned)RG_QCAP ? tab[qlen] : rg_cal_max_gap(P, qlen); }
 #define RG_BSS(parent, l_pac, rb) ((((rb) > (l_pac)) == (parent)) ? 1 : 0)
 
-// klib introsort (ksort.h:184-236) on chain indices ord[0..n) with "a before b" = w[a] > w[b].
-// Same control flow as csrc/host/util.c:bsx_introsort so that equal weights end in the reference's order.
-template <typename Idx>
-__device__ void rg_introsort_w(Idx *a, int n, const RgChain *ch, int *stk)
+// klib introsort (ksort.h:184-236) of the chains by weight, descending, with the control flow of
+// csrc/host/util.c:bsx_introsort so that equal weights end in the reference's order.  One lane runs it; the elements are
+// packed keys (weight << RG_KEY_BITS | chain index) so that a comparison is two independent LDS reads and a swap two stores.
+#define RG_KEY_BITS 13   // chain indices < 8192 (RgHuge::CCAP)
+__device__ void rg_introsort_keys(unsigned int *a, int n, int *stk)
 {
-#define LT(x, y) (ch[(x)].w > ch[(y)].w)
-#define SWP(i, j) do { Idx t_ = a[i]; a[i] = a[j]; a[j] = t_; } while (0)
+#define LT(x, y) (((x) >> RG_KEY_BITS) > ((y) >> RG_KEY_BITS))
+#define SWP(i, j) do { const unsigned int t_ = a[i]; a[i] = a[j]; a[j] = t_; } while (0)
 	if (n < 2) return;
 	if (n == 2) { if (LT(a[1], a[0])) SWP(0, 1); return; }
 	int d, s = 0, t = n - 1, i, j, k, top = 0;
@@ -139,7 +142,7 @@ __device__ void rg_introsort_w(Idx *a, int n, const RgChain *ch, int *stk)
 			i = s; j = t; k = i + ((j - i) >> 1) + 1;
 			if (LT(a[k], a[i])) { if (LT(a[k], a[j])) k = j; }
 			else k = LT(a[j], a[i]) ? i : j;
-			const unsigned char rp = a[k];
+			const unsigned int rp = a[k];
 			if (k != t) SWP(k, t);
 			for (;;) {
 				do ++i; while (LT(a[i], rp));
@@ -288,17 +291,19 @@ __device__ __forceinline__ long long rg_sa(const DevIndex &ix, int parent, unsig
 }
 
 // overlap test of mem_chain_flt (memchain.c:436-452) for chain ci against kept chain ck: bit 0 = large overlap, bit 1 = ci is dropped
-__device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci, const RgChain &ck)
+__device__ __forceinline__ int rg_flt_vals(const RegParams &P, int ci_beg, int ci_end, int ci_w, int ci_alt, int ck_beg, int ck_end, int ck_w, int ck_alt)
 {
-	const int ci_beg = ci.first_q, ci_end = ci.last_q + ci.last_len;
-	const int ck_beg = ck.first_q, ck_end = ck.last_q + ck.last_len;
 	const int b_max = ck_beg > ci_beg ? ck_beg : ci_beg, e_min = ck_end < ci_end ? ck_end : ci_end;
-	if (e_min > b_max && (!ck.is_alt || ci.is_alt)) {
+	if (e_min > b_max && (!ck_alt || ci_alt)) {
 		const int li = ci_end - ci_beg, lj = ck_end - ck_beg, min_l = li < lj ? li : lj;
 		if ((float)(e_min - b_max) >= (float)min_l * P.mask_level && min_l < P.max_chain_gap)
-			return 1 | (((float)ci.w < (float)ck.w * P.drop_ratio && ck.w - ci.w >= P.min_seed_len << 1) ? 2 : 0);
+			return 1 | (((float)ci_w < (float)ck_w * P.drop_ratio && ck_w - ci_w >= P.min_seed_len << 1) ? 2 : 0);
 	}
 	return 0;
+}
+__device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci, const RgChain &ck)
+{
+	return rg_flt_vals(P, ci.first_q, ci.last_q + ci.last_len, ci.w, ci.is_alt, ck.first_q, ck.last_q + ck.last_len, ck.w, ck.is_alt);
 }
 
 // One strand search, SA intervals -> regions, by one wavefront.  Returns 0 or the reason the task is declined:
@@ -308,7 +313,7 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 template <typename Store>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
-                       unsigned long long *counters)
+                       unsigned long long *counters, const int *gap)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -451,25 +456,79 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			}
 		}
 		WAVE_SYNC();
-		int n = 0;
-		if (lane == 0) {
-			if (Store::NODES) rg_bt_traverse(S, D.E);
-			for (int i = 0; i < nc; ++i) { const int c = S.ord[i]; if (S.ch[c].w >= P.min_chain_weight) S.ord[n++] = (idx_t)c; }
-			rg_introsort_w(S.ord, n, S.ch, D.H);
-		}
-		n = uni(n);
+		if (P.dbg & 16) return 0;
+		if (Store::NODES && lane == 0) rg_bt_traverse(S, D.E);
 		WAVE_SYNC();
-		if (n > 0) {
+		// chains heavy enough, in that order, as sort keys; srt[] is free until stage E: first half keys, second half the kept list
+		unsigned int *keys = (unsigned int*)S.srt, *keepc = keys + Store::SCAP;
+		int n = 0;
+		const unsigned long long lt_mask = (1ull << lane) - 1;
+		for (int base = 0; base < nc; base += 64) {
+			const int i = base + lane;
+			const int c = i < nc ? (int)S.ord[i] : 0;
+			const int w = i < nc ? S.ch[c].w : -1;
+			const bool ok = i < nc && w >= P.min_chain_weight;
+			const unsigned long long b = __ballot(ok);
+			if (ok) keys[n + __popcll(b & lt_mask)] = (unsigned int)w << RG_KEY_BITS | (unsigned int)c;
+			n += __popcll(b);
+		}
+		WAVE_SYNC();
+		if (lane == 0) rg_introsort_keys(keys, n, D.H);
+		WAVE_SYNC();
+		for (int i = lane; i < n; i += 64) S.ord[i] = (idx_t)(keys[i] & ((1u << RG_KEY_BITS) - 1));
+		WAVE_SYNC();
+		if (P.dbg & 32) return 0;
+		if (n > 0 && Store::CCAP <= 128) {
+			// The overlap filter with every chain's four numbers in registers: lane l holds the chains at sorted positions l and
+			// l + 64.  The kept list grows in sorted order, so "the first kept chain that drops chain i" is the lowest lane that says so.
+			int cb[2], ce[2], cw[2], ca[2], kp[2] = {0, 0}, fi[2] = {-1, -1};
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int j = lane + 64 * h;
+				cb[h] = ce[h] = cw[h] = ca[h] = 0;
+				if (j < n) { const RgChain c = S.ch[S.ord[j]]; cb[h] = c.first_q; ce[h] = c.last_q + c.last_len; cw[h] = c.w; ca[h] = c.is_alt; }
+			}
+			if (lane == 0) kp[0] = 3;
+			for (int i = 1; i < n; ++i) {
+				const int sl = i & 63, hi = i >> 6;
+				const int ib = __builtin_amdgcn_readlane(hi ? cb[1] : cb[0], sl), ie = __builtin_amdgcn_readlane(hi ? ce[1] : ce[0], sl);
+				const int iw = __builtin_amdgcn_readlane(hi ? cw[1] : cw[0], sl), ia = __builtin_amdgcn_readlane(hi ? ca[1] : ca[0], sl);
+				int r[2];
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int j = lane + 64 * h;
+					r[h] = (j < i && kp[h]) ? rg_flt_vals(P, ib, ie, iw, ia, cb[h], ce[h], cw[h], ca[h]) : 0;
+				}
+				const unsigned long long d0 = __ballot(r[0] & 2), d1 = __ballot(r[1] & 2);
+				const int stop = d0 ? __ffsll((long long)d0) - 1 : d1 ? 64 + __ffsll((long long)d1) - 1 : 0x7fffffff;
+				int large = 0;
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int j = lane + 64 * h;
+					const int hit = (r[h] & 1) && j <= stop;
+					if (hit && fi[h] < 0) fi[h] = i;
+					if (__ballot(hit)) large = 1;
+				}
+				if (stop == 0x7fffffff && lane == sl) { if (hi) kp[1] = large ? 2 : 3; else kp[0] = large ? 2 : 3; }
+			}
+#pragma unroll
+			for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < n) S.ch[S.ord[j]].kept = (signed char)kp[h]; }
+			WAVE_SYNC();
+#pragma unroll
+			for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) S.ch[S.ord[fi[h]]].kept = 1; }
+			WAVE_SYNC();
+		} else if (n > 0) {
 			int nk = 1;
-			if (lane == 0) { S.ch[S.ord[0]].kept = 3; S.keep[0] = 0; }
+			if (lane == 0) { S.ch[S.ord[0]].kept = 3; S.keep[0] = 0; keepc[0] = S.ord[0]; }
 			WAVE_SYNC();
 			for (int i = 1; i < n; ++i) {
 				// chain i against the kept chains, 64 at a time; the reference's loop stops at the first kept chain that drops it
-				const RgChain ci = S.ch[S.ord[i]];
+				const int cidx = uni(S.ord[i]);
+				const RgChain ci = S.ch[cidx];
 				int stop = nk;
 				for (int base = 0; base < nk && stop == nk; base += 64) {
 					const int k = base + lane;
-					const int r = k < nk ? rg_flt_test(P, ci, S.ch[S.ord[S.keep[k]]]) : 0;
+					const int r = k < nk ? rg_flt_test(P, ci, S.ch[keepc[k]]) : 0;
 					const unsigned long long d = __ballot(r & 2);
 					if (d) stop = base + __ffsll((long long)d) - 1;
 				}
@@ -477,24 +536,39 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 				for (int base = 0; base < nk && base <= stop; base += 64) {
 					const int k = base + lane;
 					int hit = 0;
-					if (k < nk && k <= stop) { RgChain &ck = S.ch[S.ord[S.keep[k]]]; hit = rg_flt_test(P, ci, ck) & 1; if (hit && ck.first < 0) ck.first = (short)i; }
+					if (k < nk && k <= stop) { RgChain &ck = S.ch[keepc[k]]; hit = rg_flt_test(P, ci, ck) & 1; if (hit && ck.first < 0) ck.first = (short)i; }
 					if (__ballot(hit)) large = 1;
 				}
 				if (stop == nk) {
-					if (lane == 0) { S.keep[nk] = (idx_t)i; S.ch[S.ord[i]].kept = large ? 2 : 3; }
+					if (lane == 0) { S.keep[nk] = (idx_t)i; keepc[nk] = (unsigned int)cidx; S.ch[cidx].kept = large ? 2 : 3; }
 					++nk;
 				}
 				WAVE_SYNC();
 			}
-			if (lane == 0) {
-				for (int i = 0; i < nk; ++i) { const RgChain &c = S.ch[S.ord[S.keep[i]]]; if (c.first >= 0) S.ch[S.ord[c.first]].kept = 1; }
-				int i; unsigned int k = 0;
-				for (i = 0; i < n; ++i) { const int kp = S.ch[S.ord[i]].kept; if (kp == 0 || kp == 3) continue; if (++k >= P.max_chain_extend) break; }
-				for (; i < n; ++i) if (S.ch[S.ord[i]].kept < 3) S.ch[S.ord[i]].kept = 0;
-				int m = 0;
-				for (i = 0; i < n; ++i) if (S.ch[S.ord[i]].kept) S.ord[m++] = S.ord[i];
-				S.n_chains = m;   // ord[0..m) = surviving chains in processing order
+			for (int k = lane; k < nk; k += 64) { const int f = S.ch[keepc[k]].first; if (f >= 0) S.ch[S.ord[f]].kept = 1; }
+			WAVE_SYNC();
+		}
+		if (n > 0) {
+			if (P.max_chain_extend < (unsigned int)n) { // at most max_chain_extend shadowed chains survive (memchain.c:474-482); off by default
+				if (lane == 0) {
+					int i; unsigned int k = 0;
+					for (i = 0; i < n; ++i) { const int kp = S.ch[S.ord[i]].kept; if (kp == 0 || kp == 3) continue; if (++k >= P.max_chain_extend) break; }
+					for (; i < n; ++i) if (S.ch[S.ord[i]].kept < 3) S.ch[S.ord[i]].kept = 0;
+				}
+				WAVE_SYNC();
 			}
+			int m = 0;   // surviving chains, in processing order, compacted in place (targets never pass the sources)
+			for (int base = 0; base < n; base += 64) {
+				const int i = base + lane;
+				const int c = i < n ? (int)S.ord[i] : 0;
+				const bool ok = i < n && S.ch[c].kept != 0;
+				const unsigned long long b = __ballot(ok);
+				WAVE_SYNC();
+				if (ok) S.ord[m + __popcll(b & lt_mask)] = (idx_t)c;
+				m += __popcll(b);
+				WAVE_SYNC();
+			}
+			if (lane == 0) S.n_chains = m;
 			WAVE_SYNC();
 		}
 	}
@@ -509,8 +583,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		long long rmax0 = l_pac << 1, rmax1 = 0;
 		for (int o = lane; o < ns; o += 64) if (S.s_chain[o] == c && !S.s_extra[o]) {
 			const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
-			const long long b = rb - (qb + rg_cal_max_gap(P, qb));
-			const long long e = rb + ln + ((l_query - qb - ln) + rg_cal_max_gap(P, l_query - qb - ln));
+			const long long b = rb - (qb + rg_gap(gap, P, qb));
+			const long long e = rb + ln + ((l_query - qb - ln) + rg_gap(gap, P, l_query - qb - ln));
 			rmax0 = rmax0 < b ? rmax0 : b; rmax1 = rmax1 > e ? rmax1 : e;
 		}
 		rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1));
@@ -564,11 +638,11 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 					if (s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) continue;
 					if (s_len - rg.seedlen0 > .1 * l_query) continue;
 					int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
-					int max_gap = rg_cal_max_gap(P, (int)(qd < rd ? qd : rd));
+					int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
 					int w = max_gap < rg.w ? max_gap : rg.w;
 					if (qd - rd < w && rd - qd < w) break;
 					qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
-					max_gap = rg_cal_max_gap(P, (int)(qd < rd ? qd : rd));
+					max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
 					w = max_gap < rg.w ? max_gap : rg.w;
 					if (qd - rd < w && rd - qd < w) break;
 				}
@@ -674,6 +748,9 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
+	__shared__ int gap_tab[RG_QCAP + 1];
+	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	__syncthreads();
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
 	RgDp &D = dp[threadIdx.x >> 6];
@@ -686,7 +763,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
 	}
@@ -703,6 +780,9 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
                unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
 {
 	__shared__ RgDp dp[4];
+	__shared__ int gap_tab[RG_QCAP + 1];
+	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	__syncthreads();
 	const int lane = wave_lane();
 	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
 	RgDp &D = dp[threadIdx.x >> 6];
@@ -716,7 +796,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
