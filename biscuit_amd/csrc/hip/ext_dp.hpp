@@ -146,8 +146,9 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevSco
 // scan, and entries outside the band simply keep their old contents, exactly like the array they mirror.
 // Needs qlen + 1 <= 64 * NC entries.
 template <int NC>
-__device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t &J, int lane)
-{
+__device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t &J, int lane,
+                                                    const uint8_t *win = nullptr, long long win_beg = 0)
+{   // win: the reference bases [win_beg, ...) already in LDS, one byte each, covering every row of this job (else HBM)
 	const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
 	// the 5x5 matrix of this strand as 25 scalars (constant indices: scalar loads, hoisted); indexing the kernel
 	// argument with a run-time index instead would be five vector loads from memory in every row
@@ -183,7 +184,10 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 	int beg = 0, end = qlen;
 	int tb_reg = 4;
 	for (int i = 0; i < tlen; ++i) {
-		if ((i & 63) == 0) tb_reg = (i + lane < tlen) ? dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(i + lane) * J.tdir) : 4;
+		if ((i & 63) == 0) {
+			const long long tp = J.tpos + (long long)(i + lane) * J.tdir;
+			tb_reg = (i + lane < tlen) ? (win ? (int)win[tp - win_beg] : dev_ref_base(ix.pac, ix.l_pac, tp)) : 4;
+		}
 		const int t = wave_bcast(tb_reg, i & 63);
 		if (beg < i - w) beg = i - w;
 		if (end > i + w + 1) end = i + w + 1;

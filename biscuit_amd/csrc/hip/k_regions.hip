@@ -77,26 +77,27 @@ __device__ __forceinline__ long long wave_max_i64(long long v)
 	return v;
 }
 
-__device__ __forceinline__ int rg_pos2rid(const DevIndex &ix, long long pos_f)   // bns_pos2rid, bntseq.c:356-369
+#define RG_CTG_LDS 256   // contig offset tables up to this many entries are copied to LDS once per workgroup
+__device__ __forceinline__ int rg_pos2rid(const DevIndex &ix, const long long *ctg, long long pos_f)   // bns_pos2rid, bntseq.c:356-369
 {
 	int left = 0, mid = 0, right = ix.n_seqs;
 	if (pos_f >= ix.l_pac) return -1;
 	while (left < right) {
 		mid = (left + right) >> 1;
-		if (pos_f >= ix.ctg_off[mid]) {
+		if (pos_f >= ctg[mid]) {
 			if (mid == ix.n_seqs - 1) break;
-			if (pos_f < ix.ctg_off[mid + 1]) break;
+			if (pos_f < ctg[mid + 1]) break;
 			left = mid + 1;
 		} else right = mid;
 	}
 	return mid;
 }
 __device__ __forceinline__ long long rg_depos(long long l_pac, long long p) { return p >= l_pac ? (l_pac << 1) - 1 - p : p; }
-__device__ __forceinline__ int rg_intv2rid(const DevIndex &ix, long long rb, long long re)   // bns_intv2rid, bntseq.c:371-379
+__device__ __forceinline__ int rg_intv2rid(const DevIndex &ix, const long long *ctg, long long rb, long long re)   // bns_intv2rid, bntseq.c:371-379
 {
 	if (rb < ix.l_pac && re > ix.l_pac) return -2;
-	const int a = rg_pos2rid(ix, rg_depos(ix.l_pac, rb));
-	const int b = rb < re ? rg_pos2rid(ix, rg_depos(ix.l_pac, re - 1)) : a;
+	const int a = rg_pos2rid(ix, ctg, rg_depos(ix.l_pac, rb));
+	const int b = rb < re ? rg_pos2rid(ix, ctg, rg_depos(ix.l_pac, re - 1)) : a;
 	return a == b ? a : -1;
 }
 __device__ __forceinline__ int rg_cal_max_gap(const RegParams &P, int qlen)   // memchain.c:576-582
@@ -313,7 +314,7 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 template <typename Store>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
-                       unsigned long long *counters, const int *gap)
+                       unsigned long long *counters, const int *gap, const long long *ctg)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -369,7 +370,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
-			S.s_rid[o] = rg_intv2rid(ix, pos, pos + slen);
+			S.s_rid[o] = rg_intv2rid(ix, ctg, pos, pos + slen);
 			S.s_chain[o] = -1; S.s_extra[o] = 0;
 		}
 		// work counters of the algorithmic-bytes model: FM blocks touched by the LF walks, SA samples read
@@ -593,8 +594,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		int rid;
 		{
 			const int is_rev = ch_pos >= l_pac;
-			rid = uni(rg_pos2rid(ix, rg_depos(l_pac, ch_pos)));
-			long long far_beg = uni64(ix.ctg_off[rid]), far_end = uni64(ix.ctg_off[rid + 1]);
+			rid = uni(rg_pos2rid(ix, ctg, rg_depos(l_pac, ch_pos)));
+			long long far_beg = uni64(ctg[rid]), far_end = uni64(ctg[rid + 1]);
 			if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
 			rmax0 = rmax0 > far_beg ? rmax0 : far_beg; rmax1 = rmax1 < far_end ? rmax1 : far_end;
 		}
@@ -749,7 +750,10 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
 	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
+	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
@@ -763,7 +767,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
 	}
@@ -781,7 +785,10 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 {
 	__shared__ RgDp dp[4];
 	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
+	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
 	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
@@ -796,7 +803,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab);
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
