@@ -12,6 +12,7 @@
 // RG_RCAP regions, reads longer than RG_QCAP or long enough for the seed-SW filter (memchain.c:544),
 // and two chains starting at the same reference position (there the reference's B-tree shape decides).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "dev_common.hpp"
 #include "wave.hpp"
 #include "kernels.h"
@@ -740,7 +741,8 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 }
 
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
-__global__ void __launch_bounds__(256, 3)
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
@@ -870,8 +872,13 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
                     const long long *pos_off, const unsigned long long *pos)
 {
-	hipLaunchKernelGGL(k_regions, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
+	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets
+	if (occ >= 4)
+		hipLaunchKernelGGL(k_regions<4>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
+	else
+		hipLaunchKernelGGL(k_regions<3>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
 }
 
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
