@@ -864,6 +864,21 @@ void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_tas
 	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters);
 }
 
+// The index files sample the suffix array every 32nd rank (bwtindex.c:328,340), which makes bwt_sa a walk of 31 LF steps
+// on average.  HBM has room for a much denser sample: at upload time every `intv`-th rank's position is computed once from
+// the sparse samples (the value of SA[k] does not depend on the sampling), and all later lookups walk ~intv - 1 steps.
+__global__ void __launch_bounds__(256)
+k_sa_dense(DevIndex ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out)
+{
+	uint32_t lf = 0;
+	for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * blockDim.x)
+		out[j] = (unsigned long long)rg_sa(ix, parent, j * intv, lf);
+}
+void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out)
+{
+	hipLaunchKernelGGL(k_sa_dense, dim3(n_cu * 32), dim3(256), 0, st, ix, parent, intv, n, out);
+}
+
 size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
 
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,

@@ -35,3 +35,5 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
                 unsigned long long *counters);
+// out[j] = SA[j * intv] for j < n, from the (sparser) samples ix currently holds: the denser suffix-array sample kept in HBM
+void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out);

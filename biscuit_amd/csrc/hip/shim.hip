@@ -172,6 +172,29 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 		HIPCHK(hipMemcpy((char*)d->ctg.p + ((size_t)ns + 1) * 8, alt.data(), (size_t)ns, hipMemcpyHostToDevice));
 		d->ix.ctg_off = (const int64_t*)d->ctg.p; d->ix.ctg_alt = (const uint8_t*)d->ctg.p + ((size_t)ns + 1) * 8; d->ix.n_seqs = ns;
 	}
+	{ // denser suffix-array sample for the device (the files' 1-in-32 stays what the loader and the host see)
+		const char *e = getenv("BSX_DEVICE_SA_INTV");
+		int want = e ? atoi(e) : 4;
+		const int file_intv = (int)d->ix.fmi[0].sa_mask + 1;
+		if (want >= 1 && want < file_intv && (want & (want - 1)) == 0 && d->ix.fmi[1].sa_mask == d->ix.fmi[0].sa_mask) {
+			DevBuf dense[2];
+			Lane &L = d->lane[0];
+			for (int i = 0; i < 2; ++i) {
+				const unsigned long long nd = d->ix.fmi[i].seq_len / (unsigned)want + 1;
+				if ((rc = dense[i].reserve((size_t)nd * 8)) != BSX_OK) { dense[0].release(); dense[1].release(); return rc; }
+				launch_sa_dense(L.st, d->n_cu, d->ix, i, (unsigned)want, nd, (unsigned long long*)dense[i].p);
+			}
+			HIPCHK(hipStreamSynchronize(L.st));
+			HIPCHK(hipGetLastError());
+			int shift = 0;
+			while ((1 << shift) < want) ++shift;
+			for (int i = 0; i < 2; ++i) {
+				d->sa[i].release();
+				d->sa[i] = dense[i];
+				d->ix.fmi[i].sa = (const uint64_t*)d->sa[i].p; d->ix.fmi[i].sa_mask = (uint32_t)want - 1; d->ix.fmi[i].sa_shift = (uint32_t)shift;
+			}
+		}
+	}
 	d->has_index = true;
 	return BSX_OK;
 }
