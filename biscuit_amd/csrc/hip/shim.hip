@@ -91,9 +91,23 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		Lane &L = d->lane[l];
 		int lo = 0, hi = 0;
 		HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least, hi = greatest priority (numerically lower)
-		HIPCHK(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
+		// The front-half streams leave a few compute units alone (one in every `reserve`): workgroups of k_seed live for tens of
+		// milliseconds and are not preempted, so without free CUs the short high-priority batches of the back half (K5, K6)
+		// would queue behind them no matter their priority.
+		static const int reserve = getenv("BSX_RESERVE_CU_EVERY") ? atoi(getenv("BSX_RESERVE_CU_EVERY")) : 8;
+		bool masked = false;
+		if (reserve >= 2 && d->n_cu >= 16) {
+			std::vector<uint32_t> mask((size_t)(d->n_cu + 31) / 32, 0u);
+			for (int cu = 0; cu < d->n_cu; ++cu) if (cu % reserve != reserve - 1) mask[cu >> 5] |= 1u << (cu & 31);
+			masked = hipExtStreamCreateWithCUMask(&L.st, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+			         hipExtStreamCreateWithCUMask(&L.st2, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+			if (!masked) { (void)hipGetLastError(); if (L.st) { (void)hipStreamDestroy(L.st); L.st = nullptr; } if (L.st2) { (void)hipStreamDestroy(L.st2); L.st2 = nullptr; } }
+		}
+		if (!masked) {
+			HIPCHK(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
+			HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
+		}
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
-		HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
 		HIPCHK(hipEventCreate(&L.ev3));
 		HIPCHK(hipEventCreate(&L.ev4));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[0], hipEventDisableTiming));
@@ -381,19 +395,19 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		if ((rc = finish_timed(L, 0)) != BSX_OK) return rc;
 		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
 		unsigned long long used = 0;
-		HIPCHK(hipMemcpy(r_off.data(), d_off, (size_t)cn * 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(r_n.data(), d_n, (size_t)cn * 4, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(&used, ctr + 4, 8, hipMemcpyDeviceToHost));
+		D2H(L.st, r_off.data(), d_off, (size_t)cn * 8);
+		D2H(L.st, r_n.data(), d_n, (size_t)cn * 4);
+		D2H(L.st, &used, ctr + 4, 8);
 		if (used > dense_cap) used = dense_cap;
 		std::vector<int64_t> next;
 		if (round == 0) {
 			if ((rc = L.hstage.reserve((size_t)used * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
-			if (used) HIPCHK(hipMemcpy(L.hstage.p, L.out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			if (used) D2H(L.st, L.hstage.p, L.out.p, (size_t)used * sizeof(bsx_intv_t));
 			h_dense = (const bsx_intv_t*)L.hstage.p;
 			for (int64_t i = 0; i < n; ++i) { h_off[i] = r_off[i]; h_n[i] = r_n[i]; if (r_n[i] < 0) next.push_back(i); }
 		} else {
 			dense_sub.resize((size_t)used);
-			if (used) HIPCHK(hipMemcpy(dense_sub.data(), L.out.p, (size_t)used * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			if (used) D2H(L.st, dense_sub.data(), L.out.p, (size_t)used * sizeof(bsx_intv_t));
 			for (int64_t i = 0; i < cn; ++i) {
 				if (r_n[i] < 0) { next.push_back(todo[i]); continue; }
 				redo_index.push_back(todo[i]);
@@ -577,7 +591,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	std::vector<long long> h_off((size_t)n);
 	D2H(L.st, h_off.data(), r_off, (size_t)n * 8);
 	D2H(L.st, out_n, r_n, (size_t)n * 4);
-	HIPCHK(hipMemcpy(&used, ctr + 6, 8, hipMemcpyDeviceToHost));
+	D2H(L.st, &used, ctr + 6, 8);
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
 	for (size_t j = 0; j < redo.size(); ++j) { // what the redone strand searches produced; -1 = the caller seeds and chains it
@@ -602,10 +616,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		const bsx_intv_t *dense = nullptr;
 		if (decl.size() > 2048) { // many: one bulk copy of the dense lists, gathered on the host
 			unsigned long long sused = 0;
-			HIPCHK(hipMemcpy(&sused, ctr + 4, 8, hipMemcpyDeviceToHost));
+			D2H(L.st, &sused, ctr + 4, 8);
 			if (sused > dense_cap) sused = dense_cap;
 			if ((rc = L.hstage.reserve((size_t)sused * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
-			if (sused) HIPCHK(hipMemcpy(L.hstage.p, L.out.p, (size_t)sused * sizeof(bsx_intv_t), hipMemcpyDeviceToHost));
+			if (sused) D2H(L.st, L.hstage.p, L.out.p, (size_t)sused * sizeof(bsx_intv_t));
 			dense = (const bsx_intv_t*)L.hstage.p;
 		}
 		for (size_t j = 0; j < decl.size(); ++j) {
@@ -613,7 +627,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			bsx_intv_t *dst = *decl_intv + decl_off[j];
 			if (cnt <= 0) continue;
 			if (dense) memcpy(dst, dense + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
-			else HIPCHK(hipMemcpy(dst, (const bsx_intv_t*)L.out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+			else D2H(L.st, dst, (const bsx_intv_t*)L.out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
 			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
 		}
 	}
@@ -638,7 +652,7 @@ static int lane_sa_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sa_job_
 	launch_sa(L.st, grid, d->ix, (const bsx_sa_job_t*)L.jobs.p, (long long)n, (uint64_t*)L.res.p, dev_counters(L));
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	if ((rc = finish_timed(L, 1)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(pos, L.res.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+	D2H(L.st, pos, L.res.p, (size_t)n * 8);
 	return BSX_OK;
 }
 
@@ -682,7 +696,7 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	if ((rc = finish_timed(L, 2)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpy(res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t), hipMemcpyDeviceToHost));
+	D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
 	return BSX_OK;
 }
 
