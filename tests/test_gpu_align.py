@@ -221,3 +221,20 @@ def test_cli_many_chunks_through_the_stream(data):
     assert got.count(b"\n") > 8000
     assert got == want
     assert sync == want
+
+
+@pytest.mark.parametrize("env", [
+    {"BSX_DEVICE_SA_INTV": "32"},                                   # the files' suffix-array sample instead of the denser device one
+    {"BSX_DEVICE_SA_INTV": "1"},                                    # every rank sampled: K3 is a plain load
+    {"BSX_REGIONS_OCC": "3", "BSX_SEED_OCC": "4"},                  # other register-allocation targets
+    {"BSX_RESERVE_CU_EVERY": "0", "BSX_STREAM_DEPTH": "1"},         # no reserved CUs, no overlap of chunks
+    {"BSX_SEED_QUOTA": "0", "BSX_REGIONS_QUOTA": "1", "BSX_STREAM_DEPTH": "4"},   # persistent seeding waves, one task per region wave
+], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4"])
+def test_device_tuning_knobs_do_not_change_the_output(data, env):
+    """Launch shapes, occupancy targets, the device-side suffix-array sample and the pipeline depth are performance knobs:
+    the SAM must be byte-identical whatever they are set to."""
+    base_env = {"BSX_CHUNK_SIZE": "60000"}
+    args = ["-@", "4", "g", "b1.fq", "b2.fq"]
+    want = run(HIP, args, data, env=base_env)
+    got = run(HIP, args, data, env=dict(base_env, **env))
+    assert got == want and got.count(b"\n") > 8000
