@@ -33,6 +33,10 @@ BSX_API int  bsx_arenas_begin(int n_threads);   /* take a free set (-1: arenas o
 BSX_API void bsx_arenas_bind(int set);          /* another thread continues work on the chunk that owns `set` */
 BSX_API void bsx_arenas_end(int set);           /* rewind the set, release it, unbind the caller */
 void *bsx_arena_alloc(bsx_arena_t *a, size_t n);
+/* large arrays that live as long as the arena set (chunk after chunk): slot = a small fixed index per array */
+void *bsx_big_get(int set, int slot, size_t bytes);
+void  bsx_big_put(int set, int slot, void *p);                     /* frees only when the set is off (-1) */
+void  bsx_big_update(int set, int slot, void *p, size_t cap);      /* the user realloc'd the block */
 BSX_API extern __thread bsx_arena_t *bsx_tls_arena;
 static inline void *bsx_crealloc(void *p, size_t old_bytes, size_t new_bytes)
 {

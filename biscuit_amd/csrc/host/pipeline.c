@@ -870,19 +870,19 @@ static int chunk_front(chunk_t *C)
 				return BSX_E_FORMAT;
 			}
 	bsx_parallel_for(nt, clip_worker, C, n);
-	C->roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+	C->roff = (uint32_t*)bsx_big_get(C->arena_set, 0, sizeof(uint32_t) * ((size_t)n + 1));
 	for (i = 0; i < n; ++i) { C->roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
 	C->roff[n] = (uint32_t)tot;
 	if (tot >= 0xffff0000ull) return BSX_E_ARG;
-	C->buf = (uint8_t*)malloc(tot + 16);
+	C->buf = (uint8_t*)bsx_big_get(C->arena_set, 1, tot + 16);
 	{
 		int per_read = C->is_pe ? (opt->parent ? 1 : 2) : ((opt->parent & 1) ? 1 : 2);
-		C->read_task0 = (int*)malloc(sizeof(int) * ((size_t)n + 1));
+		C->read_task0 = (int*)bsx_big_get(C->arena_set, 2, sizeof(int) * ((size_t)n + 1));
 		for (i = 0; i <= n; ++i) C->read_task0[i] = i * per_read;
 		C->n_tasks = n * per_read;
 	}
-	C->tasks = (c2r_t*)malloc(sizeof(c2r_t) * ((size_t)C->n_tasks + 1));
-	C->stasks = (bsx_seed_task_t*)malloc(sizeof(bsx_seed_task_t) * ((size_t)C->n_tasks + 1));
+	C->tasks = (c2r_t*)bsx_big_get(C->arena_set, 3, sizeof(c2r_t) * ((size_t)C->n_tasks + 1));
+	C->stasks = (bsx_seed_task_t*)bsx_big_get(C->arena_set, 4, sizeof(bsx_seed_task_t) * ((size_t)C->n_tasks + 1));
 	bsx_parallel_for(nt, setup_worker, C, n);
 	C->st.n_tasks = C->n_tasks;
 	FCHECK(be->set_opt(be->ctx, opt));
@@ -892,12 +892,16 @@ static int chunk_front(chunk_t *C)
 	/* seeding through regions in one device pass where the backend has it; what it declines (and everything,
 	 * on a backend without it) goes through the batch kernels and the host chaining below */
 	t0 = now_s();
-	C->hmap = (int*)malloc(sizeof(int) * ((size_t)C->n_tasks + 1));
+	C->hmap = (int*)bsx_big_get(C->arena_set, 5, sizeof(int) * ((size_t)C->n_tasks + 1));
 	if (be->regions_batch) {
-		C->dreg_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_tasks + 1));
-		C->dreg_n = (int32_t*)malloc(sizeof(int32_t) * ((size_t)C->n_tasks + 1));
+		C->dreg_off = (int64_t*)bsx_big_get(C->arena_set, 6, sizeof(int64_t) * ((size_t)C->n_tasks + 1));
+		C->dreg_n = (int32_t*)bsx_big_get(C->arena_set, 7, sizeof(int32_t) * ((size_t)C->n_tasks + 1));
+		/* the regions array is grown by the backend: start from the block kept from the last chunk of this set */
+		C->dregs_cap = (int64_t)(2 * (size_t)C->n_tasks + 4096);
+		C->dregs = (bsx_region_t*)bsx_big_get(C->arena_set, 8, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		decl_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_tasks + 1));
 		rc = be->regions_batch(be->ctx, opt, C->n_tasks, C->stasks, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n, &decl_intv, &decl_cap, decl_off);
+		bsx_big_update(C->arena_set, 8, C->dregs, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		if (rc != BSX_OK) goto out;
 		bsx_parallel_for(nt, adopt_worker, C, C->n_tasks);
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
@@ -1025,7 +1029,8 @@ static int chunk_back(chunk_t *C)
 	double t0;
 	bsx_arenas_bind(C->arena_set);
 	t0 = now_s();
-	C->regs = (reg_v*)calloc((size_t)C->n + 1, sizeof(reg_v));
+	C->regs = (reg_v*)bsx_big_get(C->arena_set, 9, sizeof(reg_v) * ((size_t)C->n + 1));
+	memset(C->regs, 0, sizeof(reg_v) * ((size_t)C->n + 1));
 	FCHECK(merge_regions(C));
 	C->st.t_merge = now_s() - t0;
 	if (C->is_pe) {
@@ -1048,14 +1053,14 @@ static void chunk_free(chunk_t *C)
 	if (C->tasks) {
 		if (C->hmap) bsx_parallel_for(nt, release_host_worker, C, C->n_host);
 		if (C->arena_set < 0) bsx_parallel_for(nt, release_worker, C, C->n_tasks);   /* arena memory is rewound, not freed */
-		free(C->tasks);
+		bsx_big_put(C->arena_set, 3, C->tasks);
 	}
-	if (C->regs) { if (C->arena_set < 0) bsx_parallel_for(nt, release_regs_worker, C, C->n); free(C->regs); }
+	if (C->regs) { if (C->arena_set < 0) bsx_parallel_for(nt, release_regs_worker, C, C->n); bsx_big_put(C->arena_set, 9, C->regs); }
 	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); }
-	free(C->roff); free(C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
+	bsx_big_put(C->arena_set, 0, C->roff); bsx_big_put(C->arena_set, 2, C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
 	for (t = 0; t < C->n_host; ++t) { if (C->xpos) free(C->xpos[t]); if (C->xpos_off) free(C->xpos_off[t]); }
-	free(C->need_more); free(C->xpos); free(C->xpos_off); free(C->stasks); free(C->buf);
-	free(C->hmap); free(C->dregs); free(C->dreg_off); free(C->dreg_n);
+	free(C->need_more); free(C->xpos); free(C->xpos_off); bsx_big_put(C->arena_set, 4, C->stasks); bsx_big_put(C->arena_set, 1, C->buf);
+	bsx_big_put(C->arena_set, 5, C->hmap); bsx_big_put(C->arena_set, 8, C->dregs); bsx_big_put(C->arena_set, 6, C->dreg_off); bsx_big_put(C->arena_set, 7, C->dreg_n);
 	bsx_arenas_end(C->arena_set);
 	C->st.t_cleanup = now_s() - t0;
 	C->st.t_total = now_s() - C->t_begin;

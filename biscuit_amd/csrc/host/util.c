@@ -310,6 +310,24 @@ static pthread_mutex_t g_arena_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_arena_cv = PTHREAD_COND_INITIALIZER;
 static __thread int tls_arena_set = -1;
 
+/* Large per-chunk arrays (tasks, read buffer, regions...) are kept from chunk to chunk with the arena set: each is hundreds
+ * of MB, and taking them from malloc in a worker thread means an mmap, a page fault per 4 KB and a munmap every chunk. */
+#define BIG_SLOTS 16
+static struct { void *p; size_t cap; } g_big[ARENA_SETS][BIG_SLOTS];
+void *bsx_big_get(int set, int slot, size_t bytes)
+{
+	if (set < 0 || slot < 0 || slot >= BIG_SLOTS) return malloc(bytes);
+	if (g_big[set][slot].cap < bytes) {
+		free(g_big[set][slot].p);
+		g_big[set][slot].cap = bytes + (bytes >> 3) + 4096;
+		g_big[set][slot].p = malloc(g_big[set][slot].cap);
+	}
+	return g_big[set][slot].p;
+}
+void bsx_big_put(int set, int slot, void *p) { if (set < 0 || slot < 0 || slot >= BIG_SLOTS) free(p); }
+/* a realloc'd buffer handed out by bsx_big_get may have been grown by its user: remember the new block */
+void bsx_big_update(int set, int slot, void *p, size_t cap) { if (set >= 0 && slot >= 0 && slot < BIG_SLOTS) { g_big[set][slot].p = p; g_big[set][slot].cap = cap; } }
+
 void *bsx_arena_alloc(bsx_arena_t *a, size_t n)
 {
 	void *q;
