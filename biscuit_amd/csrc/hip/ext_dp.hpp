@@ -183,6 +183,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
 	int tb_reg = 4;
+	const bool packed_max = (long long)h0 + (long long)qlen * mx < (1 << 21);   // every H of this job fits 22 bits
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) {
 			const long long tp = J.tpos + (long long)(i + lane) * J.tdir;
@@ -243,8 +244,13 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 					else if (a - 1 >= beg && a - 1 < end) Hr[c] = up;
 				}
 			}
-			m = wave_max_i32(lm);
-			mj = wave_max_i32(lm == m ? lj : -1);
+			if (packed_max) { // row maximum and the last column that attains it in one reduction: (h << 9 | column), columns < 512
+				const int key = wave_max_i32(lm < 0 ? -1 : (lm << 9 | lj));
+				m = key >> 9; mj = key < 0 ? -1 : (key & 511);
+			} else {
+				m = wave_max_i32(lm);
+				mj = wave_max_i32(lm == m ? lj : -1);
+			}
 			if (end == qlen) { // h(i, end-1), only read for the to-the-end score
 				int v = 0;
 #pragma unroll

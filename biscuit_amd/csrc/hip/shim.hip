@@ -469,7 +469,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
-	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota)) : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)n_slabs) + 3) / 4);
+	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
+	// gathers in flight on a given box
+	static const int seed_wpc = getenv("BSX_SEED_WAVES_PER_CU") ? std::max(1, std::min(16, atoi(getenv("BSX_SEED_WAVES_PER_CU")))) : 16;
+	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
+	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
 	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)2 * list_cap + mem_cap) * sizeof(DevIntv);
 	const int big_grid = d->n_cu * 2, huge_grid = 16;
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
