@@ -311,7 +311,7 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 // One strand search, SA intervals -> regions, by one wavefront.  Returns 0 or the reason the task is declined:
 //   1 seeding overflowed   9 read longer than RG_QCAP or long enough for the seed-SW filter (memchain.c:544)   8 intervals > ICAP
 //   2 occurrences > SCAP or an interval beyond max_occ      3 chains > CCAP      4 two chains start at the same position
-//   6 regions > RCAP
+//   6 regions > RCAP      10 an over-represented interval has to be walked past max_occ (memchain.c:325-326)
 template <typename Store>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
@@ -342,7 +342,9 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		const int i = base + lane;
 		DevIntv mine; mine.x0 = mine.x1 = mine.x2 = 0; mine.info = 0;
 		if (i < n_iv) mine = src[i];
-		const int cnt = mine.x2 > 0x7fffffffull ? 0x7fffffff : (int)mine.x2;
+		// occurrences this strand search will visit: all of them, or the first max_occ of an over-represented interval (memchain.c:325-326)
+		const int big = mine.x2 > (unsigned long long)P.max_occ;
+		const int cnt = big ? P.max_occ : (int)mine.x2;
 		long long incl = cnt;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
@@ -353,21 +355,32 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			int rank = 0;
 			for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
 			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - cnt) : mine.x0;
-			S.iv_n[rank] = cnt;
+			S.iv_n[rank] = cnt | big << 30;
 			S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
 		}
 		run += uni64((long long)((unsigned long long)(unsigned)__shfl((int)(incl >> 32), 63) << 32 | (unsigned)__shfl((int)incl, 63)));
 	}
 	WAVE_SYNC();
 	// ---- B. occurrences: every k < x[2] of every interval (the caps of memchain.c:325-326 cannot bind while x[2] <= max_occ)
-	int tot = 0, over = 0;
-	for (int i = 0; i < n_iv; ++i) { const int c = uni(S.iv_n[i]); if (c > Store::SCAP || c > P.max_occ) over = 1; tot += c > Store::SCAP ? Store::SCAP : c; }
+	int tot = 0, over = 0, any_big = 0;
+	for (int i = 0; i < n_iv; ++i) { const int c = uni(S.iv_n[i]) & 0x3fffffff; any_big |= uni(S.iv_n[i]) >> 30; if (c > Store::SCAP) over = 1; tot += c > Store::SCAP ? Store::SCAP : c; }
 	if (over || tot > Store::SCAP) return 2;
+	float frac_rep = 0.f;
+	if (any_big) { // read length covered by over-represented seeds (memchain.c:294-301)
+		int b = 0, e = 0, l_rep = 0;
+		for (int i = 0; i < n_iv; ++i) {
+			if (!(uni(S.iv_n[i]) >> 30)) continue;
+			const int sb = uni(S.iv_beg[i]), se = uni(S.iv_end[i]);
+			if (sb > e) { l_rep += e - b; b = sb; e = se; } else e = e > se ? e : se;
+		}
+		l_rep += e - b;
+		frac_rep = (float)l_rep / l_query;
+	}
 	{
 		int i = 0, acc = 0;   // occurrences are visited in increasing order by each lane: the interval cursor only moves forward
 		uint32_t lf = 0;
 		for (int o = lane; o < tot; o += 64) {
-			while (acc + S.iv_n[i] <= o) { acc += S.iv_n[i]; ++i; }
+			while (acc + (S.iv_n[i] & 0x3fffffff) <= o) { acc += S.iv_n[i] & 0x3fffffff; ++i; }
 			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
@@ -382,7 +395,16 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	if (P.dbg & 1) return 0;
 	// ---- C. chaining in arrival order (mem_chain's loop over occurrences, memchain.c:313-366)
 	int nc = 0;
+	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
 	for (int o = 0; o < tot; ++o) {
+		while (o >= iv_stop) { // next interval with occurrences
+			// an over-represented interval is walked past its first max_occ occurrences while it has started at most 5 chains
+			// (memchain.c:325-326): those further occurrences were not looked up, the host takes the strand search
+			if (iv_big && count < P.max_occ && count <= 5) return 10;
+			++cur_iv;
+			const int v = uni(S.iv_n[cur_iv]);
+			iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
+		}
 		const int rid = uni(S.s_rid[o]);
 		const long long rbeg = uni64(S.s_rbeg[o]);
 		const int qbeg = uni(S.s_qbeg[o]), len = uni(S.s_len[o]);
@@ -428,11 +450,12 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 				S.s_chain[o] = (decltype(S.s_chain[0] + 0))nc;
 				if (Store::NODES) rg_bt_put(S, rbeg, nc);
 			}
-			++nc;
+			++nc; ++count;
 		}
 		WAVE_SYNC();
 	}
 	if (P.dbg & 2) return 0;
+	if (iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
 		for (int c = lane; c < nc; c += 64) { // mem_chain_weight, memchain.c:158-180, one lane per chain
@@ -707,7 +730,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 					if (t_qbeg >= R.qb && t_qbeg + t_len <= R.qe && t_rbeg >= R.rb && t_rbeg + t_len <= R.re) cov += t_len;
 				}
 				R.seedcov = uni(wave_sum_i32(cov));
-				R.w = aw0 > aw1 ? aw0 : aw1; R.seedlen0 = s_len; R.frac_rep = 0.f;   // no over-represented seed reaches this kernel
+				R.w = aw0 > aw1 ? aw0 : aw1; R.seedlen0 = s_len; R.frac_rep = frac_rep;
 				if (uni(S.n_regs) == Store::RCAP) return 6;
 				WAVE_SYNC();
 				if (lane == 0) { S.regs[S.n_regs] = R; ++S.n_regs; }
@@ -827,13 +850,16 @@ k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_den
 	if (n_iv > 0) {
 		const DevIntv *src = seeds_dense + task_off[t];
 		unsigned long long tot = 0; int over = 0;
-		for (int i = 0; i < n_iv; ++i) { const unsigned long long x2 = src[i].x2; if (x2 > (unsigned long long)max_occ) over = 1; tot += x2; }
+		for (int i = 0; i < n_iv; ++i) { const unsigned long long x2 = src[i].x2; tot += x2 > (unsigned long long)max_occ ? (unsigned long long)max_occ : x2; }   // the first max_occ of an over-represented interval
 		if (!over && tot > 0 && tot <= OCC_MAX_PER_TASK) {
 			const unsigned long long base = atomicAdd(cursor, tot);
 			if (base + tot <= desc_cap) {
 				const unsigned long long par = (unsigned long long)(tasks[t].parent & 1) << 63;
 				unsigned long long j = base;
-				for (int i = 0; i < n_iv; ++i) { const unsigned long long x0 = src[i].x0, x2 = src[i].x2; for (unsigned long long k = 0; k < x2; ++k) desc[j++] = (x0 + k) | par; }
+				for (int i = 0; i < n_iv; ++i) {
+					const unsigned long long x0 = src[i].x0, x2 = src[i].x2 > (unsigned long long)max_occ ? (unsigned long long)max_occ : src[i].x2;
+					for (unsigned long long k = 0; k < x2; ++k) desc[j++] = (x0 + k) | par;
+				}
 				off = (long long)base;
 			}
 		}

@@ -242,8 +242,8 @@ int bsx_extend_batch(bsx_device_t *dev, int64_t n, const bsx_ext_job_t *jobs, bs
 /* K1+K2+K3 and the chaining/extension logic between them in one pass (mem_chain + mem_chain_flt +
  * mem_chain2region, lib/aln/memchain.c:268-488,742-904; called per strand search from lib/aln/bwamem.c:352-372):
  * regions of task i = (*out)[out_off[i] .. out_off[i] + out_n[i]).  out_n[i] < 0 means the device declined the task
- * (a read too long for its on-chip rows, an interval beyond max_occ, more occurrences/chains/regions than its tables
- * hold): the caller runs that task through bsx_sa_batch/bsx_extend_batch and its own chaining instead.  For those
+ * (a read too long for its on-chip rows, an over-represented interval that has to be walked past max_occ, more
+ * occurrences/chains/regions than its tables hold): the caller runs that task through bsx_sa_batch/bsx_extend_batch and its own chaining instead.  For those
  * tasks the sorted SA intervals are handed back so that they need not be seeded again: the j-th declined task with
  * out_n != -1 (in task order) has (*decl_intv)[decl_off[j] .. decl_off[j+1]); out_n == -1 means its interval list
  * overflowed as well and bsx_seed_batch has to redo it.  decl_off must have room for n + 1 entries. */
