@@ -23,13 +23,16 @@ __device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amd
 // inclusive max-scan across the wave
 __device__ __forceinline__ int wave_scan_max_incl(int v)
 {
+	// lanes without a source take INT_MIN, the identity of max: with it the compiler folds each step into one v_max_i32 with a
+	// DPP operand instead of a DPP move followed by the max
+	const int ID = (int)0x80000000;
 	int t;
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;   // rows 1,3 take lane 15 of the row before
-	t = __builtin_amdgcn_update_dpp(NEG_BIG, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;   // rows 2,3 take lane 31
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_SHR(1), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_SHR(2), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_SHR(4), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_BCAST15, 0xa, 0xf, false); v = v > t ? v : t;   // rows 1,3 take lane 15 of the row before
+	t = __builtin_amdgcn_update_dpp(ID, v, DPP_ROW_BCAST31, 0xc, 0xf, false); v = v > t ? v : t;   // rows 2,3 take lane 31
 	return v;
 }
 __device__ __forceinline__ int wave_scan_min_incl(int v)
