@@ -199,16 +199,18 @@ static void *reader_main(void *arg)
 {
 	reader_t *R = (reader_t*)arg;
 	int64_t idx = 0;
+	bsx_fq_pair_t *P = bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
 	while (!R->stop) {
 		chunk_rec_t r;
 		int i;
-		r.seqs = bsx_fq_read_chunk(R->f1, R->f2, R->chunk, R->has_bc, &r.n);
+		r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
 		if (r.seqs == 0 || r.n == 0) { free(r.seqs); break; }
 		if (!R->copy_comment) for (i = 0; i < r.n; ++i) { free(r.seqs[i].comment); r.seqs[i].comment = 0; }
 		r.idx = idx++; r.ok = 1;
 		cq_put(R->Q, r);
 	}
 	cq_close(R->Q);
+	bsx_fq_pair_close(P);
 	return 0;
 }
 static void *writer_main(void *arg)

@@ -7,6 +7,7 @@
  */
 #include <zlib.h>
 #include <ctype.h>
+#include <pthread.h>
 #include "bsx_core.h"
 #include "fastq.h"
 
@@ -169,6 +170,102 @@ bsx_read_t *bsx_fq_read_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size, int ha
 		if (size >= chunk_size && (n & 1) == 0) break;
 	}
 	if (size == 0 && f2 && fq_read(f2) >= 0) fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", __func__);
+	*n_ = n;
+	return seqs;
+}
+
+/* ---- the same chunks with one parser thread per file: each turns its file into blocks of records ahead of the
+ * consumer, which pairs them up under the chunk rule above.  Inflating and parsing two gzipped files is the slowest host
+ * step of the command line once the aligner is fast; this halves it. */
+#define FEED_BLOCK 2048
+#define FEED_RING 8
+typedef struct { bsx_read_t *r; int n, eof; } feed_block_t;
+typedef struct {
+	bsx_fq_t *f; int has_bc;
+	pthread_t th;
+	pthread_mutex_t mu; pthread_cond_t cv;
+	feed_block_t ring[FEED_RING]; int head, count, stop;
+	feed_block_t cur; int cur_i, done;
+} feed_t;
+struct bsx_fq_pair { feed_t a, b; int has_b; };
+
+static void *feed_main(void *arg)
+{
+	feed_t *F = (feed_t*)arg;
+	for (;;) {
+		feed_block_t blk;
+		blk.r = (bsx_read_t*)malloc(sizeof(bsx_read_t) * FEED_BLOCK); blk.n = 0; blk.eof = 0;
+		while (blk.n < FEED_BLOCK) {
+			if (fq_read(F->f) < 0) { blk.eof = 1; break; }
+			to_read(F->f, &blk.r[blk.n++], F->has_bc);
+		}
+		pthread_mutex_lock(&F->mu);
+		while (F->count == FEED_RING && !F->stop) pthread_cond_wait(&F->cv, &F->mu);
+		if (F->stop) { int i; pthread_mutex_unlock(&F->mu); for (i = 0; i < blk.n; ++i) bsx_read_free(&blk.r[i]); free(blk.r); return 0; }
+		F->ring[(F->head + F->count++) % FEED_RING] = blk;
+		pthread_cond_broadcast(&F->cv);
+		pthread_mutex_unlock(&F->mu);
+		if (blk.eof) return 0;
+	}
+}
+static void feed_start(feed_t *F, bsx_fq_t *f, int has_bc)
+{
+	memset(F, 0, sizeof(*F));
+	F->f = f; F->has_bc = has_bc;
+	pthread_mutex_init(&F->mu, 0); pthread_cond_init(&F->cv, 0);
+	pthread_create(&F->th, 0, feed_main, F);
+}
+/* next record of the file, 0 at its end */
+static int feed_next(feed_t *F, bsx_read_t *out)
+{
+	for (;;) {
+		if (F->cur_i < F->cur.n) { *out = F->cur.r[F->cur_i++]; return 1; }
+		free(F->cur.r); F->cur.r = 0; F->cur.n = F->cur_i = 0;
+		if (F->done) return 0;
+		pthread_mutex_lock(&F->mu);
+		while (F->count == 0) pthread_cond_wait(&F->cv, &F->mu);
+		F->cur = F->ring[F->head]; F->head = (F->head + 1) % FEED_RING; --F->count;
+		pthread_cond_broadcast(&F->cv);
+		pthread_mutex_unlock(&F->mu);
+		if (F->cur.eof) F->done = 1;
+	}
+}
+static void feed_stop(feed_t *F)
+{
+	int i;
+	pthread_mutex_lock(&F->mu); F->stop = 1; pthread_cond_broadcast(&F->cv); pthread_mutex_unlock(&F->mu);
+	pthread_join(F->th, 0);
+	for (; F->cur_i < F->cur.n; ++F->cur_i) bsx_read_free(&F->cur.r[F->cur_i]);
+	free(F->cur.r);
+	while (F->count) { feed_block_t *b = &F->ring[F->head]; for (i = 0; i < b->n; ++i) bsx_read_free(&b->r[i]); free(b->r); F->head = (F->head + 1) % FEED_RING; --F->count; }
+}
+
+bsx_fq_pair_t *bsx_fq_pair_open(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc)
+{
+	bsx_fq_pair_t *P = (bsx_fq_pair_t*)calloc(1, sizeof(*P));
+	feed_start(&P->a, f1, has_bc);
+	if (f2) { feed_start(&P->b, f2, has_bc); P->has_b = 1; }
+	return P;
+}
+void bsx_fq_pair_close(bsx_fq_pair_t *P)
+{
+	if (!P) return;
+	feed_stop(&P->a);
+	if (P->has_b) feed_stop(&P->b);
+	free(P);
+}
+bsx_read_t *bsx_fq_pair_read_chunk(bsx_fq_pair_t *P, int chunk_size, int *n_)
+{
+	int size = 0, m = 0, n = 0;
+	bsx_read_t *seqs = 0, ra, rb;
+	while (feed_next(&P->a, &ra)) {
+		if (P->has_b && !feed_next(&P->b, &rb)) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bsx_fq_read_chunk"); bsx_read_free(&ra); break; }
+		if (n + 2 > m) { m = m ? m << 1 : 256; seqs = (bsx_read_t*)realloc(seqs, (size_t)m * sizeof(bsx_read_t)); }
+		seqs[n] = ra; seqs[n].id = n; size += seqs[n++].l_seq;
+		if (P->has_b) { seqs[n] = rb; seqs[n].id = n; size += seqs[n++].l_seq; }
+		if (size >= chunk_size && (n & 1) == 0) break;
+	}
+	if (size == 0 && P->has_b && feed_next(&P->b, &rb)) { fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", "bsx_fq_read_chunk"); bsx_read_free(&rb); }
 	*n_ = n;
 	return seqs;
 }

@@ -49,3 +49,6 @@ BSX_API int bsx_hook_opt_defaults(char *buf, int cap)
 		o->XA_drop_ratio, o->mask_level_redun, o->mapQ_coef_len, o->mapQ_coef_fac, o->max_ins, o->max_matesw,
 		o->max_XA_hits, o->max_XA_hits_alt, o->parent, o->bsstrand, o->clip5, o->clip3, o->min_base_qual, o->has_bc);
 }
+BSX_API void *bsx_hook_fq_pair_open(void *f1, void *f2, int has_bc) { return bsx_fq_pair_open((bsx_fq_t*)f1, (bsx_fq_t*)f2, has_bc); }
+BSX_API void bsx_hook_fq_pair_close(void *p) { bsx_fq_pair_close((bsx_fq_pair_t*)p); }
+BSX_API bsx_read_t *bsx_hook_fq_pair_chunk(void *p, int chunk_size, int *n) { return bsx_fq_pair_read_chunk((bsx_fq_pair_t*)p, chunk_size, n); }

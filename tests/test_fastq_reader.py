@@ -140,3 +140,59 @@ def test_paired_files_interleave(tmp_path):
     ra, rb = kseq_records(a), kseq_records(b)
     assert len(got) == 400
     assert [g[2] for g in got[0::2]] == [r[2] for r in ra] and [g[2] for g in got[1::2]] == [r[2] for r in rb]
+
+
+def read_all_threaded(path1, path2, chunk_size):
+    L = B.lib()
+    L.bsx_hook_fq_open.restype = C.c_void_p
+    L.bsx_hook_fq_open.argtypes = [C.c_char_p]
+    L.bsx_hook_fq_close.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_pair_open.restype = C.c_void_p
+    L.bsx_hook_fq_pair_open.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bsx_hook_fq_pair_close.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_pair_chunk.restype = C.POINTER(B.Read)
+    L.bsx_hook_fq_pair_chunk.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    f1 = L.bsx_hook_fq_open(path1.encode())
+    f2 = L.bsx_hook_fq_open(path2.encode()) if path2 else None
+    p = L.bsx_hook_fq_pair_open(f1, f2, 0)
+    chunks = []
+    while True:
+        n = C.c_int()
+        r = L.bsx_hook_fq_pair_chunk(p, chunk_size, C.byref(n))
+        if not r or n.value == 0:
+            break
+        chunks.append([(r[i].name.decode(), (r[i].comment or b"").decode(), "".join("ACGTN"[r[i].seq[k]] for k in range(r[i].l_seq)),
+                        r[i].qual.decode() if r[i].qual else None, r[i].id) for i in range(n.value)])
+        L.bsx_sim_free_reads(r, n.value)
+    L.bsx_hook_fq_pair_close(p)
+    L.bsx_hook_fq_close(f1)
+    if f2:
+        L.bsx_hook_fq_close(f2)
+    return chunks
+
+
+def test_parser_threads_give_the_same_chunks(tmp_path):
+    """One parser thread per file (what the command line uses) against the in-line reader: same chunks, same records, same ids;
+    also with files of unequal length and with the consumer stopping early."""
+    rng = random.Random(7)
+    a, b = make_text(rng, 9000), make_text(rng, 9000, multiline=True)
+    p1, p2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq.gz")
+    open(p1, "w").write(a)
+    gzip.open(p2, "wt").write(b)
+    for chunk in (3000, 50000, 10 ** 7):
+        want = [[r + (i,) for i, r in enumerate(ch)] for ch in read_all(p1, p2, chunk)]
+        assert read_all_threaded(p1, p2, chunk) == want
+        assert read_all_threaded(p1, None, chunk) == [[r + (i,) for i, r in enumerate(ch)] for ch in read_all(p1, None, chunk)]
+    short = str(tmp_path / "short.fq")
+    open(short, "w").write(make_text(random.Random(8), 100))
+    assert sum(len(c) for c in read_all_threaded(p1, short, 4000)) == sum(len(c) for c in read_all(p1, short, 4000)) == 200
+    # early close with blocks still queued must not hang or leak into the next reader
+    L = B.lib()
+    f1 = L.bsx_hook_fq_open(p1.encode())
+    p = L.bsx_hook_fq_pair_open(f1, None, 0)
+    n = C.c_int()
+    r = L.bsx_hook_fq_pair_chunk(p, 100, C.byref(n))
+    L.bsx_sim_free_reads(r, n.value)
+    L.bsx_hook_fq_pair_close(p)
+    L.bsx_hook_fq_close(f1)

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--genome-mbp", type=float, default=128)
 ap.add_argument("--chunks", type=int, default=6)
 ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--out", default=None, help="where the SAM goes (default: a file in the work directory; /dev/null isolates the aligner from the write)")
 a = ap.parse_args()
 from biscuit_amd import _lib as B
 from biscuit_amd.api import Index
@@ -39,10 +40,11 @@ for k in range(a.chunks):
 idx.close()
 env = dict(os.environ, BSX_HOST_THREADS=str(a.threads))
 t0 = time.time()
-with open(work + "/e2e.sam", "wb") as out:
+outp = a.out or (work + "/e2e.sam")
+with open(outp, "wb") as out:
     p = subprocess.run([os.path.join(ROOT, "biscuit_amd", "biscuit_align"), "-@", str(a.threads), base, fq1, fq2], stdout=out, stderr=subprocess.PIPE, env=env)
 dt = time.time() - t0
 assert p.returncode == 0, p.stderr.decode()[-2000:]
 n = 2 * pairs * a.chunks
-print({"cli_end_to_end_reads_per_s": round(n / dt, 1), "reads": n, "seconds": round(dt, 2), "sam_bytes": os.path.getsize(work + "/e2e.sam"),
+print({"cli_end_to_end_reads_per_s": round(n / dt, 1), "reads": n, "seconds": round(dt, 2), "sam_bytes": os.path.getsize(outp), "out": outp,
        "includes": "index load + upload, FASTQ parse, alignment, SAM text to a file"})
