@@ -43,7 +43,6 @@ struct RegParams {
 	int32_t min_seed_len, min_chain_weight, max_chain_gap, max_occ, bsstrand;
 	uint32_t max_chain_extend;
 	float mask_level, drop_ratio;
-	int32_t dbg;   // timing experiments only (BSX_RG_DBG): 1 stop after seeds are placed, 2 after chaining, 4 after the chain filter, 8 skip the DP calls
 };
 
 struct DevScoring {        // set by bsx_device_set_opt

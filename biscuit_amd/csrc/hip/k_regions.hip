@@ -392,7 +392,6 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		if (lane == 0 && !posl) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)tot); }
 	}
 	WAVE_SYNC();
-	if (P.dbg & 1) return 0;
 	// ---- C. chaining in arrival order (mem_chain's loop over occurrences, memchain.c:313-366)
 	int nc = 0;
 	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
@@ -454,7 +453,6 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 		WAVE_SYNC();
 	}
-	if (P.dbg & 2) return 0;
 	if (iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
@@ -481,7 +479,6 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			}
 		}
 		WAVE_SYNC();
-		if (P.dbg & 16) return 0;
 		if (Store::NODES && lane == 0) rg_bt_traverse(S, D.E);
 		WAVE_SYNC();
 		// chains heavy enough, in that order, as sort keys; srt[] is free until stage E: first half keys, second half the kept list
@@ -502,7 +499,6 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		WAVE_SYNC();
 		for (int i = lane; i < n; i += 64) S.ord[i] = (idx_t)(keys[i] & ((1u << RG_KEY_BITS) - 1));
 		WAVE_SYNC();
-		if (P.dbg & 32) return 0;
 		if (n > 0 && Store::CCAP <= 128) {
 			// The overlap filter with every chain's four numbers in registers: lane l holds the chains at sorted positions l and
 			// l + 64.  The kept list grows in sorted order, so "the first kept chain that drops chain i" is the lowest lane that says so.
@@ -597,7 +593,6 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			WAVE_SYNC();
 		}
 	}
-	if (P.dbg & 4) return 0;
 	// ---- E. chains -> regions (mem_chain2region, memchain.c:873-904)
 	const int nk = uni(S.n_chains), ns = tot;
 	for (int ci = 0; ci < nk; ++ci) {
@@ -703,8 +698,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						const int prev = R.score;
 						aw = P.w << i;
 						J.w = aw;
-						if (P.dbg & 8) { res.score = J.h0 + 10; res.qle = J.qlen; res.tle = J.qlen; res.gtle = J.qlen; res.gscore = J.h0 + 10; res.max_off = 0; }
-						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
+						res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;

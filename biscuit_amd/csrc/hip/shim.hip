@@ -459,7 +459,6 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
-	R.dbg = getenv("BSX_RG_DBG") ? atoi(getenv("BSX_RG_DBG")) : 0;
 
 	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average

@@ -104,6 +104,7 @@ typedef struct {
 	const bsx_pestat_t *pes0; bsx_pestat_t pes0_copy;
 	int arena_set, rc;
 	pthread_t th; int th_live;   /* the thread running the front half (stream mode) */
+	int back_done;               /* ... which ran the back half too */
 	double t_begin;
 	bsx_phase_stats_t st;
 } chunk_t;
@@ -1116,10 +1117,16 @@ struct bsx_stream {
 	int64_t n_pushed;
 };
 
+static int g_whole_chunk_threads = -1;   /* $BSX_STREAM_WHOLE_CHUNK: the chunk's thread runs its back half too */
+
 static void *front_thread(void *arg)
 {
 	chunk_t *C = (chunk_t*)arg;
 	C->rc = chunk_front(C);
+	/* With the back half on the chunk's own thread as well, back halves of consecutive chunks overlap each other: one
+	 * chunk's serial stretches and waits for its K5/K6 batches are filled with the other's parallel loops (the worker
+	 * pool serves several loops at once).  Chunks still complete in order: the stream joins the threads in order. */
+	if (g_whole_chunk_threads && C->rc == BSX_OK) { C->rc = chunk_back(C); C->back_done = 1; }
 	bsx_arenas_bind(-1);
 	return 0;
 }
@@ -1130,6 +1137,7 @@ BSX_API int bsx_stream_open_backends(int depth, const bsx_backend_t *be, const b
 	bsx_stream_t *s;
 	int i;
 	if (!be || !opt || !idx || !out || depth < 1 || depth > STREAM_MAX_DEPTH) return BSX_E_ARG;
+	if (g_whole_chunk_threads < 0) { const char *e = getenv("BSX_STREAM_WHOLE_CHUNK"); g_whole_chunk_threads = e ? atoi(e) : 0; }
 	s = (bsx_stream_t*)calloc(1, sizeof(*s));
 	for (i = 0; i < depth; ++i) s->be[i] = be[i];
 	s->depth = depth; s->opt = opt; s->idx = idx;
@@ -1156,7 +1164,7 @@ static int chunk_finish(chunk_t *C)
 	int rc;
 	if (C->th_live) { pthread_join(C->th, 0); C->th_live = 0; }
 	rc = C->rc;
-	if (rc == BSX_OK) rc = chunk_back(C);
+	if (rc == BSX_OK && !C->back_done) rc = chunk_back(C);
 	chunk_free(C);
 	return rc;
 }
