@@ -688,7 +688,7 @@ static void plan_jobs_worker(void *data, long u, int tid)
 		for (k = 0; k < Q->ctx[u].want[w].n; ++k, ++at) {
 			int gi = Q->ctx[u].want[w].a[k];
 			bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &Q->jobs[at]);
-			Q->jobs[at].cigar_cap = 24;
+			Q->jobs[at].cigar_cap = 8;   /* most CIGARs are 1-3 operations; one that does not fit is redone with the room it asks for */
 			Q->jread[at] = ri; Q->jreg[at] = gi;
 		}
 	}
