@@ -244,3 +244,60 @@ def test_device_tuning_knobs_do_not_change_the_output(data, env):
     want = run(HIP, args, data, env=base_env)
     got = run(HIP, args, data, env=dict(base_env, **env))
     assert got == want and got.count(b"\n") > 8000
+
+
+def test_sim_chunk_equals_cpu_restatement(tmp_path):
+    """A repeat-rich simulated chunk (the bench's generator: repeat families, tandem repeats) through the product
+    (device seeding, K3, chaining, extension in all three region tiers) and through the CPU restatement of the kernels with
+    the host's own chaining (oracle/): every read's SAM text must be identical.  Two settings of max_occ, so that the
+    over-represented-seed rule is compared against the host implementation as well."""
+    import ctypes as C
+    import zlib
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    from oracle_lib import Port
+    L = B.lib()
+    d = str(tmp_path)
+    B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(6000000), C.c_uint64(91), 6, C.c_double(0.10)), "sim_genome")
+    B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "index_build")
+    idx = Index(d + "/g")
+    dev = Device(0)
+    dev.upload_index(idx)
+    port = Port(idx, 16)
+    be = port.backend()
+    opt = default_opt()
+    opt.n_threads = 4
+    opt.flag |= 0x10 | 0x2
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    n_pairs = 40000
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 17, 200, 500, 0.01, 0.2, C.byref(p)), "sim_pairs")
+    reads = C.cast(p, C.POINTER(B.Read))
+
+    def sams():
+        return [C.string_at(reads[i].sam) for i in range(2 * n_pairs)]
+
+    os.environ["BSX_HOST_THREADS"] = "16"
+    try:
+        for max_occ in (500, 10):
+            opt.max_occ = max_occ
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
+            ps = B.PhaseStats()
+            L.bsx_last_phase_stats(C.byref(ps))
+            assert ps.n_host_tasks * 10 < ps.n_tasks, (max_occ, ps.n_host_tasks, ps.n_tasks)
+            got = sams()
+            L.bsx_sim_reset_reads(p, 2 * n_pairs)
+            B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "cpu restatement")
+            want = sams()
+            L.bsx_sim_reset_reads(p, 2 * n_pairs)
+            bad = [i for i in range(2 * n_pairs) if got[i] != want[i]]
+            assert not bad, "max_occ %d: %d reads differ, first:\nHIP: %s\nCPU: %s" % (max_occ, len(bad), got[bad[0]][:400], want[bad[0]][:400])
+    finally:
+        os.environ.pop("BSX_HOST_THREADS", None)
+        L.bsx_sim_free_reads(p, 2 * n_pairs)
+        dev.close()
+        idx.close()
