@@ -97,7 +97,12 @@ def main():
 
     C.c_int.in_dll(L, "bsx_verbose").value = 1   # silence per-chunk messages inside the timed region
 
-    chunks = [gen(1000 * (rank + 1) + s, pairs_per_step) for s in range(args.warmup + args.steps)]
+    # a bounded set of distinct chunks, reused round-robin (a chunk is only pushed again long after it has completed and its
+    # SAM text has been dropped): keeps the host memory of a rank at a few GB whatever --steps is
+    class Ring(list):
+        def __getitem__(self, i):
+            return list.__getitem__(self, i % len(self))
+    chunks = Ring(gen(1000 * (rank + 1) + s, pairs_per_step) for s in range(min(args.warmup + args.steps, 8)))
     # chunks go through the two-deep pipeline of include/bsx.h (front half of chunk k+1 on the device while the host
     # finishes chunk k); --no-pipeline runs them one at a time through bsx_process_seqs instead
     L.bsx_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -257,7 +262,7 @@ def main():
         print(json.dumps(out))
     if not args.no_pipeline:
         L.bsx_stream_close(stream)
-    for c in chunks:
+    for c in list.__iter__(chunks):
         L.bsx_sim_free_reads(c, n_reads)
     if dist is not None:
         dist.destroy_process_group()
