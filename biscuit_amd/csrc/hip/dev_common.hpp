@@ -115,18 +115,25 @@ BSX_HD uint32_t dev_count_word(uint32_t x, int nv)
 	const uint32_t nt = (uint32_t)dev_popc(hi & lo), ng = (uint32_t)dev_popc(hi & ~lo), nc = (uint32_t)dev_popc(lo & ~hi);
 	return ((uint32_t)nv - nt - ng - nc) | nc << 8 | ng << 16 | nt << 24;
 }
+// T, G and C are counted word by word straight into three accumulators (popcount-and-add is one instruction); A is what is
+// left of the upto+1 symbols.  nv = how many symbols of the word lie at or before `upto` (the first symbol sits in the top bits).
+BSX_HD void dev_count_tgc(uint32_t x, int nv, uint32_t &nt, uint32_t &ng, uint32_t &nc)
+{
+	nv = nv < 0 ? 0 : nv;
+	const uint32_t below = 0xffffffffu >> ((nv << 1) & 31);                          // bits under the nv leading symbols (nv < 16)
+	const uint32_t valid = nv >= 16 ? 0x55555555u : (0x55555555u & ~below);
+	const uint32_t lo = x & valid, hi = (x >> 1) & valid;
+	nt += (uint32_t)dev_popc(hi & lo); ng += (uint32_t)dev_popc(hi & ~lo); nc += (uint32_t)dev_popc(lo & ~hi);
+}
 BSX_HD void dev_block_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t &c, uint32_t &g, uint32_t &t)
 {
-	// at most 128 symbols per block: the packed byte counters cannot overflow across two words, sum in 16-bit halves
 	const int n = upto + 1;
-	uint32_t s0 = dev_count_word(b.v2.x, n) + dev_count_word(b.v2.y, n - 16);
-	uint32_t s1 = dev_count_word(b.v2.z, n - 32) + dev_count_word(b.v2.w, n - 48);
-	uint32_t s2 = dev_count_word(b.v3.x, n - 64) + dev_count_word(b.v3.y, n - 80);
-	uint32_t s3 = dev_count_word(b.v3.z, n - 96) + dev_count_word(b.v3.w, n - 112);
-	// each s is a sum of two words: bytes <= 32, no carry between bytes; widen before the final adds
-	const uint32_t lo = (s0 & 0x00ff00ffu) + (s1 & 0x00ff00ffu) + (s2 & 0x00ff00ffu) + (s3 & 0x00ff00ffu);
-	const uint32_t hi = ((s0 >> 8) & 0x00ff00ffu) + ((s1 >> 8) & 0x00ff00ffu) + ((s2 >> 8) & 0x00ff00ffu) + ((s3 >> 8) & 0x00ff00ffu);
-	a = lo & 0xffff; g = lo >> 16; c = hi & 0xffff; t = hi >> 16;
+	uint32_t nt = 0, ng = 0, nc = 0;
+	dev_count_tgc(b.v2.x, n, nt, ng, nc);       dev_count_tgc(b.v2.y, n - 16, nt, ng, nc);
+	dev_count_tgc(b.v2.z, n - 32, nt, ng, nc);  dev_count_tgc(b.v2.w, n - 48, nt, ng, nc);
+	dev_count_tgc(b.v3.x, n - 64, nt, ng, nc);  dev_count_tgc(b.v3.y, n - 80, nt, ng, nc);
+	dev_count_tgc(b.v3.z, n - 96, nt, ng, nc);  dev_count_tgc(b.v3.w, n - 112, nt, ng, nc);
+	a = (uint32_t)n - nt - ng - nc; c = nc; g = ng; t = nt;
 }
 
 // bwt_2occ4 (lib/aln/bwt.c:204-236): ranks of all four symbols at k and l (scalars, no indexed arrays).
