@@ -102,6 +102,9 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 			fx.L2[0] = fx.L2[1] = fx.L2[2] = fx.L2[3] = fx.L2[4] = dev_ix_L2(ix, which, L.ext_c);
 			DevIntv ok = dev_extend(fx, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
 			seed_post(L, ok, P);
+			// a strand search whose lists no longer fit is abandoned at once: its result is discarded and it is seeded again with
+			// longer lists, so finishing it here would only keep this wave (and the kernel's tail) alive for nothing
+			if (L.overflow) L.state = SD_DONE;
 		}
 	}
 	// work counters for the algorithmic-bytes model: slow path = two 64-B blocks, fast = one
