@@ -79,13 +79,13 @@ class GlbRes(C.Structure):
 
 class Backend(C.Structure):  # bsx_backend_t (csrc/host/bsx_core.h)
     _fields_ = [("ctx", C.c_void_p), ("name", C.c_char_p)] + [(n, C.c_void_p) for n in
-                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "regions_batch")]
+                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "regions_batch", "regions_finish")]
 
 
 class PhaseStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("t_seed", "t_sa", "t_chain", "t_extend", "t_merge", "t_pestat", "t_matesw",
                                           "t_primary", "t_cigar", "t_sam", "t_total", "t_prep", "t_cleanup", "t_regions")] + \
-               [(n, C.c_int64) for n in ("n_tasks", "n_intv", "n_sa", "n_ext_jobs", "n_ext_rounds", "n_sw_jobs", "n_glb_jobs", "n_host_tasks")]
+               [(n, C.c_int64) for n in ("n_tasks", "n_intv", "n_sa", "n_ext_jobs", "n_ext_rounds", "n_sw_jobs", "n_glb_jobs", "n_host_tasks", "n_redo_tasks")]
 
 
 _lib = None

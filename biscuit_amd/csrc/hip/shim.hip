@@ -57,6 +57,16 @@ struct Lane {
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
 	hipEvent_t pev[2] = {nullptr, nullptr};
+	// strand searches being seeded again on the side stream while the caller goes on (lane_regions_finish collects them)
+	struct {
+		bool active = false;
+		std::vector<int64_t> tasks;            // their indices in the chunk
+		std::vector<bsx_seed_task_t> sub;      // kept alive for the asynchronous upload
+		unsigned int n2u = 0;
+		HostBuf hres;                          // pinned: region offsets (8 B each) then counts (4 B each)
+		hipEvent_t ev = nullptr, ev_tiers = nullptr;
+		unsigned long long used_main = 0;      // regions the caller already holds
+	} rs;
 	double k_ms[7] = {0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[7] = {0, 0, 0, 0, 0, 0, 0};
 };
@@ -110,6 +120,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
 		HIPCHK(hipEventCreate(&L.ev3));
 		HIPCHK(hipEventCreate(&L.ev4));
+		HIPCHK(hipEventCreateWithFlags(&L.rs.ev, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&L.rs.ev_tiers, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[0], hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[1], hipEventDisableTiming));
 		if (L.slabflags.reserve((size_t)d->n_cu * 16 * 4) != BSX_OK) return BSX_E_NOMEM;
@@ -146,6 +158,9 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.st2) (void)hipStreamDestroy(L.st2);
 		if (L.ev3) (void)hipEventDestroy(L.ev3);
 		if (L.ev4) (void)hipEventDestroy(L.ev4);
+		if (L.rs.ev) (void)hipEventDestroy(L.rs.ev);
+		if (L.rs.ev_tiers) (void)hipEventDestroy(L.rs.ev_tiers);
+		L.rs.hres.release();
 	}
 	delete d;
 }
@@ -460,7 +475,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
 
-	const int mem_cap = std::max(64, max_len), list_cap = max_len + 2;
+	// $BSX_SEED_MEM_CAP (tests): a short first-pass list, so that ordinary reads take the seeded-again path too
+	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
 	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 6 + 65536;
@@ -515,13 +531,15 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 
-	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats) are seeded again
-	// on the side stream with much longer lists, then go through the third tier as well.
+	HIPCHK(hipEventRecord(L.rs.ev_tiers, L.st));
+	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats: ~300 k dependent FM steps
+	// on one lane) are seeded again on the side stream with much longer lists and go through the third tier as well.  None of
+	// that is waited for here: everything is enqueued, and lane_regions_finish collects the result when the caller gets to the
+	// chunk's back half.
 	const bool trace = getenv("BSX_PHASES") != nullptr;
 	struct timespec ts0, ts1, ts2, ts3;
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	std::vector<int64_t> redo;            // task indices
-	std::vector<long long> redo_off; std::vector<int> redo_n, redo_rn; std::vector<long long> redo_roff;
 	{
 		std::vector<int> s_n((size_t)n);
 		HIPCHK(hipEventSynchronize(L.ev1));
@@ -530,47 +548,34 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (redo.size() > 4096) redo.clear();   // not the rare case this is for: leave them to the caller
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
+	L.rs.active = false;
 	if (!redo.empty()) {
 		const size_t n2 = redo.size();
-		std::vector<bsx_seed_task_t> sub(n2);
-		for (size_t j = 0; j < n2; ++j) sub[j] = tasks[redo[j]];
-		redo_off.assign(n2, 0); redo_n.assign(n2, -1);
-		// device side: tasks2 | off2 | n2 | roff2 | rn2
-		if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 4 + 8 + 4) + 256)) != BSX_OK) return rc;
-		bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
-		long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; int *cnt2 = (int*)(roff2 + n2); int *rn2 = cnt2 + n2;
-		std::vector<size_t> cur(n2);
-		for (size_t j = 0; j < n2; ++j) cur[j] = j;
-		int cap2 = mem_cap * 64;
-		for (int round = 0; round < 3 && !cur.empty(); ++round, cap2 *= 8) {
-			const size_t m = cur.size(), per_lane = ((size_t)2 * list_cap + cap2) * sizeof(DevIntv);
-			const int g2 = (int)((m + 255) / 256);
-			if ((size_t)g2 * 256 * per_lane > scratch_bytes || g2 * 4 > n_slabs) break;   // would not fit the scratch we already hold
-			std::vector<bsx_seed_task_t> ss(m);
-			for (size_t j = 0; j < m; ++j) ss[j] = sub[cur[j]];
-			HIPCHK(hipMemcpyAsync(t2, ss.data(), m * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
+		const int g2 = (int)((n2 + 255) / 256);
+		// one pass with the longest lists the scratch we already hold allows (up to 512x the first pass)
+		long long cap2 = (long long)(scratch_bytes / ((size_t)g2 * 256) / sizeof(DevIntv)) - 2LL * list_cap;
+		if (cap2 > (long long)mem_cap * 512) cap2 = (long long)mem_cap * 512;
+		if (cap2 >= (long long)mem_cap * 8 && g2 * 4 <= n_slabs) {
+			L.rs.tasks = redo; L.rs.sub.resize(n2); L.rs.n2u = (unsigned int)n2;
+			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[redo[j]];
+			// device side: tasks2 | off2 | roff2 | cnt2 | rn2
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 4 + 4) + 256)) != BSX_OK) return rc;
+			if ((rc = L.rs.hres.reserve(n2 * 12 + 64)) != BSX_OK) return rc;
+			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
+			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; int *cnt2 = (int*)(roff2 + n2); int *rn2 = cnt2 + n2;
+			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
+			HIPCHK(hipMemcpyAsync(c32 + 5, &L.rs.n2u, 4, hipMemcpyHostToDevice, L.st2));
 			HIPCHK(hipMemsetAsync(c32 + 7, 0, 4, L.st2));
-			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)m, P, (DevIntv*)L.scratch.p, list_cap, cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
+			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4);
-			std::vector<long long> ho(m); std::vector<int> hn(m);
-			HIPCHK(hipMemcpyAsync(ho.data(), off2, m * 8, hipMemcpyDeviceToHost, L.st2));
-			HIPCHK(hipMemcpyAsync(hn.data(), cnt2, m * 4, hipMemcpyDeviceToHost, L.st2));
-			HIPCHK(hipStreamSynchronize(L.st2));
-			std::vector<size_t> next;
-			for (size_t j = 0; j < m; ++j) { if (hn[j] < 0) next.push_back(cur[j]); else { redo_off[cur[j]] = ho[j]; redo_n[cur[j]] = hn[j]; } }
-			cur.swap(next);
-		}
-		const unsigned int n2u = (unsigned int)n2;
-		HIPCHK(hipMemcpyAsync(t2, sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-		HIPCHK(hipMemcpyAsync(off2, redo_off.data(), n2 * 8, hipMemcpyHostToDevice, L.st2));
-		HIPCHK(hipMemcpyAsync(cnt2, redo_n.data(), n2 * 4, hipMemcpyHostToDevice, L.st2));
-		HIPCHK(hipMemcpyAsync(c32 + 5, &n2u, 4, hipMemcpyHostToDevice, L.st2));
-		HIPCHK(hipStreamSynchronize(L.st2));   // the host vectors above go out of scope; the region kernels keep running on L.st
-		launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
-		redo_roff.resize(n2); redo_rn.resize(n2);
-		HIPCHK(hipMemcpyAsync(redo_roff.data(), roff2, n2 * 8, hipMemcpyDeviceToHost, L.st));
-		HIPCHK(hipMemcpyAsync(redo_rn.data(), rn2, n2 * 4, hipMemcpyDeviceToHost, L.st));
+			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the third tier's slabs are shared with the main launch sequence
+			launch_regions_slab(L.st2, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
+			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
+			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
+			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
+			L.rs.active = true;
+		} else redo.clear();
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts2);
 	HIPCHK(hipEventRecord(L.ev2, L.st));
@@ -597,16 +602,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	D2H(L.st, &used, ctr + 6, 8);
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
-	for (size_t j = 0; j < redo.size(); ++j) { // what the redone strand searches produced; -1 = the caller seeds and chains it
-		out_off[redo[j]] = redo_roff[j];
-		out_n[redo[j]] = redo_rn[j] >= 0 ? redo_rn[j] : -1;
-	}
-	if (*out_cap < (int64_t)used) { *out_cap = (int64_t)used + 16; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
+	L.rs.used_main = used;
+	for (size_t j = 0; j < redo.size(); ++j) out_n[redo[j]] = BSX_REGIONS_PENDING;   // lane_regions_finish fills these in
+	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
 	// declined tasks: hand their interval lists back (ordered by info, as bsx_seed_batch returns them)
 	std::vector<int64_t> decl;
-	for (int64_t i = 0; i < n; ++i) if (out_n[i] < -1) decl.push_back(i);
+	for (int64_t i = 0; i < n; ++i) if (out_n[i] < -1 && out_n[i] != BSX_REGIONS_PENDING) decl.push_back(i);
 	decl_off[0] = 0;
 	if (!decl.empty()) {
 		std::vector<long long> s_off((size_t)n); std::vector<int> s_n((size_t)n);
@@ -634,6 +637,36 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
 		}
 	}
+	return BSX_OK;
+}
+
+// the strand searches lane_regions_batch left pending: their regions are appended to *out, out_off/out_n filled in
+// (out_n = -1: even the longest lists or the largest tier did not hold them, the caller seeds and chains them itself)
+static int lane_regions_finish(bsx_device_t *d, int lane, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
+	if (!L.rs.active) return BSX_OK;
+	HIPCHK(hipSetDevice(d->ordinal));
+	struct timespec ta, tb;
+	clock_gettime(CLOCK_MONOTONIC, &ta);
+	HIPCHK(hipEventSynchronize(L.rs.ev));
+	clock_gettime(CLOCK_MONOTONIC, &tb);
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_finish] waited %.0f ms for %zu strand searches seeded again\n", (tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6, L.rs.tasks.size());
+	HIPCHK(hipGetLastError());
+	const size_t n2 = L.rs.tasks.size();
+	const long long *roff = (const long long*)L.rs.hres.p;
+	const int *rn = (const int*)((const char*)L.rs.hres.p + n2 * 8);
+	int64_t used = (int64_t)L.rs.used_main;
+	for (size_t j = 0; j < n2; ++j) {
+		const int64_t i = L.rs.tasks[j];
+		if (rn[j] < 0) { out_n[i] = -1; out_off[i] = 0; continue; }
+		if (*out_cap < used + rn[j]) { *out_cap = used + rn[j] + 1024; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
+		D2H(L.st2, *out + used, (const bsx_region_t*)L.regs.p + roff[j], sizeof(bsx_region_t) * (size_t)rn[j]);
+		out_off[i] = used; out_n[i] = rn[j];
+		used += rn[j];
+	}
+	L.rs.active = false;
 	return BSX_OK;
 }
 
@@ -822,6 +855,8 @@ extern "C" BSX_API int bsx_seed_batch(bsx_device_t *d, const bsx_opt_t *opt, int
 extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks, bsx_region_t **out, int64_t *out_cap,
                                          int64_t *out_off, int32_t *out_n, bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off)
 { return lane_regions_batch(d, 0, opt, n, tasks, out, out_cap, out_off, out_n, decl_intv, decl_cap, decl_off); }
+extern "C" BSX_API int bsx_regions_finish(bsx_device_t *d, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n)
+{ return lane_regions_finish(d, 0, out, out_cap, out_off, out_n); }
 extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos) { return lane_sa_batch(d, 0, n, jobs, pos); }
 extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res) { return lane_extend_batch(d, 0, n, jobs, res); }
 extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res) { return lane_sw_batch(d, 0, n, jobs, res); }
@@ -837,7 +872,16 @@ static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { retur
 static int be_ext(void *c, int64_t n, const bsx_ext_job_t *j, bsx_ext_res_t *r) { return lane_extend_batch(LR(c), n, j, r); }
 static int be_sw(void *c, int64_t n, const bsx_sw_job_t *j, bsx_sw_res_t *r) { return lane_sw_batch(LR(c), n, j, r); }
 static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt,
-                      bsx_intv_t **di, int64_t *dc, int64_t *doff) { return lane_regions_batch(LR(c), o, n, t, out, cap, off, cnt, di, dc, doff); }
+                      bsx_intv_t **di, int64_t *dc, int64_t *doff)
+{
+	// The handful of strand searches seeded again (tandem repeats) are done by the time the region tiers are, so by default they are
+	// collected before returning; $BSX_ASYNC_REDO=1 leaves them pending for regions_finish at the start of the chunk's back half.
+	const int async_redo = getenv("BSX_ASYNC_REDO") ? atoi(getenv("BSX_ASYNC_REDO")) : 0;
+	int rc = lane_regions_batch(LR(c), o, n, t, out, cap, off, cnt, di, dc, doff);
+	if (rc == BSX_OK && !async_redo) rc = lane_regions_finish(LR(c), out, cap, off, cnt);
+	return rc;
+}
+static int be_regions_finish(void *c, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return lane_regions_finish(LR(c), out, cap, off, cnt); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
 
 static LaneRef g_lane_ref[8][BSX_LANES];   // ctx storage for the vtables (by device ordinal)
@@ -852,7 +896,8 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	out->ctx = r; out->name = "hip-gfx950";
 	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
 	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb;
-	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
+	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;
+	out->regions_finish = out->regions_batch ? be_regions_finish : nullptr;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
 	return BSX_OK;
 }
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out) { return bsx_hip_backend_lane(dev, 0, out); }

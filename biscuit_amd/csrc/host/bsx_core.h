@@ -159,6 +159,8 @@ typedef struct bsx_backend {
 	int (*regions_batch)(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
 	                     bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
 	                     bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off);
+	/* optional, with regions_batch: collect the strand searches it reported as BSX_REGIONS_PENDING */
+	int (*regions_finish)(void *ctx, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
 } bsx_backend_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;
@@ -177,6 +179,7 @@ BSX_API int bsx_stream_open_backends(int depth, const bsx_backend_t *be, const b
 typedef struct {
 	double t_seed, t_sa, t_chain, t_extend, t_merge, t_pestat, t_matesw, t_primary, t_cigar, t_sam, t_total, t_prep, t_cleanup, t_regions;
 	int64_t n_tasks, n_intv, n_sa, n_ext_jobs, n_ext_rounds, n_sw_jobs, n_glb_jobs, n_host_tasks;
+	int64_t n_redo_tasks;   /* strand searches the device seeded a second time with longer lists */
 } bsx_phase_stats_t;
 BSX_API void bsx_last_phase_stats(bsx_phase_stats_t *out);
 

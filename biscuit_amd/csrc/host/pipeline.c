@@ -88,7 +88,7 @@ typedef struct {
 	int n_tasks;
 	c2r_t *tasks;
 	/* strand searches the host chains itself (all of them without a device regions pass): h -> task */
-	int n_host, *hmap;
+	int n_host, *hmap, n_pending;
 	bsx_region_t *dregs; int64_t dregs_cap, *dreg_off; int32_t *dreg_n;
 	int *read_task0;             /* first task of each read; read_task0[n] = n_tasks */
 	bsx_intv_t *intv; int64_t intv_cap; int64_t *intv_off;
@@ -811,7 +811,7 @@ static void release_worker(void *data, long t, int tid)
 	bsx_cvec_free(C->tasks[t].regs);
 }
 static void release_host_worker(void *data, long h, int tid) { chunk_t *C = (chunk_t*)data; (void)tid; bsx_c2r_release(&C->tasks[C->hmap[h]]); }
-static void init_host_worker(void *data, long h, int tid) { chunk_t *C = (chunk_t*)data; (void)tid; bsx_c2r_init(&C->tasks[C->hmap[h]]); }
+static void init_host_worker(void *data, long h, int tid) { chunk_t *C = (chunk_t*)data; c2r_t *T = &C->tasks[C->hmap[h]]; (void)tid; bsx_c2r_init(T); T->done = T->has_job = 0; }
 
 /* regions the device produced -> the task's region list (every other mem_alnreg_t field is still zero here) */
 static void adopt_worker(void *data, long t, int tid)
@@ -847,6 +847,129 @@ static chunk_t *chunk_new(const bsx_backend_t *be, const bsx_opt_t *opt, const b
 	C->arena_set = -1;
 	C->t_begin = now_s();
 	return C;
+}
+
+/* Strand searches the host chains itself: C->hmap[0..n_host), the first n_reseed of them seeded here (K1+K2 batch), the
+ * others with the interval lists the device handed back.  K3, chaining, chain filter, extension rounds; afterwards their
+ * regions are in place like the adopted ones and everything else is released. */
+static int host_path(chunk_t *C, int n_reseed, const bsx_intv_t *decl_intv, const int64_t *decl_off)
+{
+	const bsx_backend_t *be = C->be;
+	const bsx_opt_t *opt = C->opt;
+	int rc = BSX_OK, i, t, nt = C->nt;
+	double t0;
+	if (C->n_host == 0) return BSX_OK;
+	bsx_parallel_for(nt, init_host_worker, C, C->n_host);
+
+	/* K1+K2 */
+	t0 = now_s();
+	C->intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_host + 1));
+	C->intv_off[0] = 0;
+	if (n_reseed == C->n_tasks) rc = be->seed_batch(be->ctx, opt, n_reseed, C->stasks, &C->intv, &C->intv_cap, C->intv_off);   /* hmap is the identity */
+	else {
+		bsx_seed_task_t *sub = (bsx_seed_task_t*)malloc(sizeof(*sub) * ((size_t)n_reseed + 1));
+		for (t = 0; t < n_reseed; ++t) sub[t] = C->stasks[C->hmap[t]];
+		rc = be->seed_batch(be->ctx, opt, n_reseed, sub, &C->intv, &C->intv_cap, C->intv_off);
+		free(sub);
+	}
+	if (rc != BSX_OK) goto out;
+	if (C->n_host > n_reseed) { /* append the interval lists the device handed back */
+		int64_t base = C->intv_off[n_reseed], add = decl_off[C->n_host - n_reseed];
+		if (C->intv_cap < base + add) { C->intv_cap = base + add + 16; C->intv = (bsx_intv_t*)realloc(C->intv, sizeof(bsx_intv_t) * (size_t)C->intv_cap); }
+		if (add) memcpy(C->intv + base, decl_intv, sizeof(bsx_intv_t) * (size_t)add);
+		for (t = n_reseed; t <= C->n_host; ++t) C->intv_off[t] = base + decl_off[t - n_reseed];
+	}
+	C->st.t_seed += now_s() - t0; C->st.n_intv += C->intv_off[C->n_host];
+	if (getenv("BSX_PHASES") && be->regions_batch)
+		for (t = 0; t < C->n_host && t < 80; ++t) {
+			int64_t k, occ = 0, big = 0;
+			for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k) { occ += (int64_t)(C->intv[k].x[2] < (uint64_t)opt->max_occ ? C->intv[k].x[2] : (uint64_t)opt->max_occ); big += C->intv[k].x[2] > (uint64_t)opt->max_occ; }
+			fprintf(stderr, "[M::declined] task %d status %d len %d: %ld intervals, %ld occurrences (capped), %ld intervals beyond max_occ\n", C->hmap[t], C->dreg_n[C->hmap[t]],
+			        C->tasks[C->hmap[t]].l_query, (long)(C->intv_off[t + 1] - C->intv_off[t]), (long)occ, (long)big);
+		}
+
+	/* K3: the first min(occ, max_occ) occurrences of every interval */
+	t0 = now_s();
+	{
+		int64_t n_iv = C->intv_off[C->n_host], k, nj = 0;
+		bsx_sa_job_t *sj;
+		C->ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+		for (k = 0; k < n_iv; ++k) { C->ipos_off[k] = nj; nj += (int64_t)(C->intv[k].x[2] < opt->max_occ ? C->intv[k].x[2] : opt->max_occ); }
+		C->ipos_off[n_iv] = nj;
+		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
+		C->sa_jobs = sj;
+		bsx_parallel_for(nt, sa_jobs_worker, C, C->n_host);
+		C->pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+		rc = be->sa_batch(be->ctx, nj, sj, C->pos);
+		free(sj);
+		C->st.n_sa += nj;
+		if (rc != BSX_OK) goto out;
+	}
+	C->st.t_sa += now_s() - t0;
+
+	/* chaining (host); intervals that must be walked past max_occ get their remaining occurrences looked up */
+	t0 = now_s();
+	C->need_more = (int*)calloc((size_t)C->n_host + 1, sizeof(int));
+	C->xpos = (uint64_t**)calloc((size_t)C->n_host + 1, sizeof(uint64_t*));
+	C->xpos_off = (int64_t**)calloc((size_t)C->n_host + 1, sizeof(int64_t*));
+	C->trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
+	for (i = 0; i < nt; ++i) C->trees[i] = bsx_bt_new();
+	for (;;) {
+		int any = 0;
+		bsx_parallel_for(nt, chain_worker, C, C->n_host);
+		for (t = 0; t < C->n_host; ++t) {
+			int n_iv, k, want;
+			int64_t nj, c;
+			bsx_sa_job_t *sj;
+			if (C->need_more[t] <= 0) continue;
+			any = 1;
+			n_iv = (int)(C->intv_off[t + 1] - C->intv_off[t]);
+			want = C->need_more[t] - 1;
+			if (!C->xpos_off[t]) {
+				C->xpos_off[t] = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
+				for (k = 0; k <= n_iv; ++k) C->xpos_off[t][k] = C->ipos_off[C->intv_off[t] + k] - C->ipos_off[C->intv_off[t]];
+			}
+			{ /* give interval `want` all of its occurrences, keep the others */
+				int64_t *cnt = (int64_t*)malloc(sizeof(int64_t) * (size_t)n_iv);
+				for (k = 0; k < n_iv; ++k) cnt[k] = C->xpos_off[t][k + 1] - C->xpos_off[t][k];
+				cnt[want] = (int64_t)C->intv[C->intv_off[t] + want].x[2];
+				for (k = 0, nj = 0; k < n_iv; ++k) { C->xpos_off[t][k] = nj; nj += cnt[k]; }
+				C->xpos_off[t][n_iv] = nj;
+				free(cnt);
+			}
+			sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
+			for (k = 0; k < n_iv; ++k)
+				for (c = 0; c < C->xpos_off[t][k + 1] - C->xpos_off[t][k]; ++c) {
+					bsx_sa_job_t *j = &sj[C->xpos_off[t][k] + c];
+					j->k = C->intv[C->intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C->tasks[C->hmap[t]].parent; j->pad = 0;
+				}
+			free(C->xpos[t]);
+			C->xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
+			rc = be->sa_batch(be->ctx, nj, sj, C->xpos[t]);
+			free(sj);
+			C->st.n_sa += nj;
+			if (rc != BSX_OK) goto out;
+			C->need_more[t] = 0;
+		}
+		if (!any) break;
+	}
+	rc = filter_chained_seeds(C);
+	if (rc != BSX_OK) goto out;
+	C->st.t_chain += now_s() - t0;
+
+	/* K4 rounds */
+	t0 = now_s();
+	rc = extension_rounds(C);
+	C->st.t_extend += now_s() - t0;
+out:
+	bsx_parallel_for(nt, release_host_worker, C, C->n_host);
+	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); C->trees = 0; }
+	free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
+	for (t = 0; t < C->n_host; ++t) { if (C->xpos) free(C->xpos[t]); if (C->xpos_off) free(C->xpos_off[t]); }
+	free(C->need_more); free(C->xpos); free(C->xpos_off);
+	C->intv = 0; C->intv_cap = 0; C->intv_off = 0; C->pos = 0; C->ipos_off = 0; C->need_more = 0; C->xpos = 0; C->xpos_off = 0;
+	C->n_host = 0;
+	return rc;
 }
 
 /* front half: clipping, strand searches, seeding .. regions of every strand search (mem_align1_core's first part,
@@ -906,12 +1029,13 @@ static int chunk_front(chunk_t *C)
 		if (rc != BSX_OK) goto out;
 		bsx_parallel_for(nt, adopt_worker, C, C->n_tasks);
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
-		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) { C->stasks[C->n_host] = C->stasks[t]; C->hmap[C->n_host++] = t; }
+		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
 		n_reseed = C->n_host;
-		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] < -1) C->hmap[C->n_host++] = t;
+		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] < -1 && C->dreg_n[t] != BSX_REGIONS_PENDING) C->hmap[C->n_host++] = t;
+		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == BSX_REGIONS_PENDING) ++C->n_pending;
 		if (getenv("BSX_PHASES")) {
 			long h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-			for (t = 0; t < C->n_tasks; ++t) ++h[C->dreg_n[t] >= 0 ? 0 : (-C->dreg_n[t] < 9 ? -C->dreg_n[t] : 9)];
+			for (t = 0; t < C->n_tasks; ++t) ++h[C->dreg_n[t] >= 0 ? 0 : C->dreg_n[t] == BSX_REGIONS_PENDING ? 1 : (-C->dreg_n[t] < 9 ? -C->dreg_n[t] : 9)];
 			fprintf(stderr, "[M::regions] on device %ld | declined: seeding overflow %ld, read length %ld, intervals %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
 			        h[0], h[1], h[9], h[8], h[2], h[3], h[4], h[5], h[6], h[7]);
 		}
@@ -920,104 +1044,36 @@ static int chunk_front(chunk_t *C)
 		C->n_host = n_reseed = C->n_tasks;
 	}
 	C->st.t_regions = now_s() - t0; C->st.n_host_tasks = C->n_host;
-	bsx_parallel_for(nt, init_host_worker, C, C->n_host);
-
-	/* K1+K2 */
-	t0 = now_s();
-	C->intv_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_host + 1));
-	C->intv_off[0] = 0;
-	rc = be->seed_batch(be->ctx, opt, n_reseed, C->stasks, &C->intv, &C->intv_cap, C->intv_off);
-	if (rc != BSX_OK) goto out;
-	if (C->n_host > n_reseed) { /* append the interval lists the device handed back */
-		int64_t base = C->intv_off[n_reseed], add = decl_off[C->n_host - n_reseed];
-		if (C->intv_cap < base + add) { C->intv_cap = base + add + 16; C->intv = (bsx_intv_t*)realloc(C->intv, sizeof(bsx_intv_t) * (size_t)C->intv_cap); }
-		if (add) memcpy(C->intv + base, decl_intv, sizeof(bsx_intv_t) * (size_t)add);
-		for (t = n_reseed; t <= C->n_host; ++t) C->intv_off[t] = base + decl_off[t - n_reseed];
-	}
-	C->st.t_seed = now_s() - t0; C->st.n_intv = C->intv_off[C->n_host];
-	if (getenv("BSX_PHASES") && be->regions_batch)
-		for (t = 0; t < C->n_host && t < 80; ++t) {
-			int64_t k, occ = 0, big = 0;
-			for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k) { occ += (int64_t)(C->intv[k].x[2] < (uint64_t)opt->max_occ ? C->intv[k].x[2] : (uint64_t)opt->max_occ); big += C->intv[k].x[2] > (uint64_t)opt->max_occ; }
-			fprintf(stderr, "[M::declined] task %d status %d len %d: %ld intervals, %ld occurrences (capped), %ld intervals beyond max_occ\n", C->hmap[t], C->dreg_n[C->hmap[t]],
-			        C->tasks[C->hmap[t]].l_query, (long)(C->intv_off[t + 1] - C->intv_off[t]), (long)occ, (long)big);
-		}
-
-	/* K3: the first min(occ, max_occ) occurrences of every interval */
-	t0 = now_s();
-	{
-		int64_t n_iv = C->intv_off[C->n_host], k, nj = 0;
-		bsx_sa_job_t *sj;
-		C->ipos_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
-		for (k = 0; k < n_iv; ++k) { C->ipos_off[k] = nj; nj += (int64_t)(C->intv[k].x[2] < opt->max_occ ? C->intv[k].x[2] : opt->max_occ); }
-		C->ipos_off[n_iv] = nj;
-		sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
-		C->sa_jobs = sj;
-		bsx_parallel_for(nt, sa_jobs_worker, C, C->n_host);
-		C->pos = (uint64_t*)malloc(8 * ((size_t)nj + 1));
-		rc = be->sa_batch(be->ctx, nj, sj, C->pos);
-		free(sj);
-		C->st.n_sa = nj;
-		if (rc != BSX_OK) goto out;
-	}
-	C->st.t_sa = now_s() - t0;
-
-	/* chaining (host); intervals that must be walked past max_occ get their remaining occurrences looked up */
-	t0 = now_s();
-	C->need_more = (int*)calloc((size_t)C->n_host + 1, sizeof(int));
-	C->xpos = (uint64_t**)calloc((size_t)C->n_host + 1, sizeof(uint64_t*));
-	C->xpos_off = (int64_t**)calloc((size_t)C->n_host + 1, sizeof(int64_t*));
-	C->trees = (bsx_btree_t**)malloc(sizeof(bsx_btree_t*) * nt);
-	for (i = 0; i < nt; ++i) C->trees[i] = bsx_bt_new();
-	for (;;) {
-		int any = 0;
-		bsx_parallel_for(nt, chain_worker, C, C->n_host);
-		for (t = 0; t < C->n_host; ++t) {
-			int n_iv, k, want;
-			int64_t nj, c;
-			bsx_sa_job_t *sj;
-			if (C->need_more[t] <= 0) continue;
-			any = 1;
-			n_iv = (int)(C->intv_off[t + 1] - C->intv_off[t]);
-			want = C->need_more[t] - 1;
-			if (!C->xpos_off[t]) {
-				C->xpos_off[t] = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_iv + 1));
-				for (k = 0; k <= n_iv; ++k) C->xpos_off[t][k] = C->ipos_off[C->intv_off[t] + k] - C->ipos_off[C->intv_off[t]];
-			}
-			{ /* give interval `want` all of its occurrences, keep the others */
-				int64_t *cnt = (int64_t*)malloc(sizeof(int64_t) * (size_t)n_iv);
-				for (k = 0; k < n_iv; ++k) cnt[k] = C->xpos_off[t][k + 1] - C->xpos_off[t][k];
-				cnt[want] = (int64_t)C->intv[C->intv_off[t] + want].x[2];
-				for (k = 0, nj = 0; k < n_iv; ++k) { C->xpos_off[t][k] = nj; nj += cnt[k]; }
-				C->xpos_off[t][n_iv] = nj;
-				free(cnt);
-			}
-			sj = (bsx_sa_job_t*)malloc(sizeof(*sj) * ((size_t)nj + 1));
-			for (k = 0; k < n_iv; ++k)
-				for (c = 0; c < C->xpos_off[t][k + 1] - C->xpos_off[t][k]; ++c) {
-					bsx_sa_job_t *j = &sj[C->xpos_off[t][k] + c];
-					j->k = C->intv[C->intv_off[t] + k].x[0] + (uint64_t)c; j->parent = C->tasks[C->hmap[t]].parent; j->pad = 0;
-				}
-			free(C->xpos[t]);
-			C->xpos[t] = (uint64_t*)malloc(8 * ((size_t)nj + 1));
-			rc = be->sa_batch(be->ctx, nj, sj, C->xpos[t]);
-			free(sj);
-			C->st.n_sa += nj;
-			if (rc != BSX_OK) goto out;
-			C->need_more[t] = 0;
-		}
-		if (!any) break;
-	}
-	rc = filter_chained_seeds(C);
-	if (rc != BSX_OK) goto out;
-	C->st.t_chain = now_s() - t0;
-
-	/* K4 rounds */
-	t0 = now_s();
-	rc = extension_rounds(C);
-	C->st.t_extend = now_s() - t0;
+	rc = host_path(C, n_reseed, decl_intv, decl_off);
 out:
 	free(decl_intv); free(decl_off);
+	return rc;
+}
+
+/* The strand searches the device was still seeding again when the front half returned (reads inside tandem repeats):
+ * collect their regions now; what even that pass could not hold goes through the host path. */
+static int finish_pending(chunk_t *C)
+{
+	const bsx_backend_t *be = C->be;
+	int rc, t, n_list = 0, *list = (int*)malloc(sizeof(int) * (size_t)C->n_pending);
+	for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == BSX_REGIONS_PENDING) list[n_list++] = t;
+	rc = be->regions_finish ? be->regions_finish(be->ctx, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n) : BSX_E_ARG;
+	bsx_big_update(C->arena_set, 8, C->dregs, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
+	C->st.n_redo_tasks += n_list;
+	C->n_pending = 0; C->n_host = 0;
+	if (rc == BSX_OK) {
+		int i;
+		for (i = 0; i < n_list; ++i) {
+			t = list[i];
+			if (C->dreg_n[t] >= 0) adopt_worker(C, t, 0);
+			else if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
+			else rc = BSX_E_ARG;
+		}
+		if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] seeded again on the device: %d strand searches, %d of them left to the host\n", n_list, C->n_host);
+		C->st.n_host_tasks += C->n_host;
+		if (rc == BSX_OK) rc = host_path(C, C->n_host, 0, 0);
+	}
+	free(list);
 	return rc;
 }
 
@@ -1030,6 +1086,7 @@ static int chunk_back(chunk_t *C)
 	double t0;
 	bsx_arenas_bind(C->arena_set);
 	t0 = now_s();
+	if (C->n_pending) FCHECK(finish_pending(C));
 	C->regs = (reg_v*)bsx_big_get(C->arena_set, 9, sizeof(reg_v) * ((size_t)C->n + 1));
 	memset(C->regs, 0, sizeof(reg_v) * ((size_t)C->n + 1));
 	FCHECK(merge_regions(C));
@@ -1048,19 +1105,16 @@ static int chunk_back(chunk_t *C)
 
 static void chunk_free(chunk_t *C)
 {
-	int i, t, nt = C->nt;
+	int nt = C->nt;
 	double t0 = now_s();
 	bsx_arenas_bind(C->arena_set);
 	if (C->tasks) {
-		if (C->hmap) bsx_parallel_for(nt, release_host_worker, C, C->n_host);
 		if (C->arena_set < 0) bsx_parallel_for(nt, release_worker, C, C->n_tasks);   /* arena memory is rewound, not freed */
 		bsx_big_put(C->arena_set, 3, C->tasks);
 	}
 	if (C->regs) { if (C->arena_set < 0) bsx_parallel_for(nt, release_regs_worker, C, C->n); bsx_big_put(C->arena_set, 9, C->regs); }
-	if (C->trees) { for (i = 0; i < nt; ++i) bsx_bt_free(C->trees[i]); free(C->trees); }
-	bsx_big_put(C->arena_set, 0, C->roff); bsx_big_put(C->arena_set, 2, C->read_task0); free(C->intv); free(C->intv_off); free(C->pos); free(C->ipos_off);
-	for (t = 0; t < C->n_host; ++t) { if (C->xpos) free(C->xpos[t]); if (C->xpos_off) free(C->xpos_off[t]); }
-	free(C->need_more); free(C->xpos); free(C->xpos_off); bsx_big_put(C->arena_set, 4, C->stasks); bsx_big_put(C->arena_set, 1, C->buf);
+	bsx_big_put(C->arena_set, 0, C->roff); bsx_big_put(C->arena_set, 2, C->read_task0);
+	bsx_big_put(C->arena_set, 4, C->stasks); bsx_big_put(C->arena_set, 1, C->buf);
 	bsx_big_put(C->arena_set, 5, C->hmap); bsx_big_put(C->arena_set, 8, C->dregs); bsx_big_put(C->arena_set, 6, C->dreg_off); bsx_big_put(C->arena_set, 7, C->dreg_n);
 	bsx_arenas_end(C->arena_set);
 	C->st.t_cleanup = now_s() - t0;

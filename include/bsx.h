@@ -250,6 +250,11 @@ int bsx_extend_batch(bsx_device_t *dev, int64_t n, const bsx_ext_job_t *jobs, bs
 int bsx_regions_batch(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
                       bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,
                       bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off);
+/* out_n[i] == BSX_REGIONS_PENDING: the strand search overflowed the seeding lists (a read inside a tandem repeat) and is
+ * being seeded again with much longer lists while the call returns; bsx_regions_finish waits for those, appends their
+ * regions to *out and fills out_off/out_n in (-1: seed and chain it on the host).  Same arrays as the batch call. */
+#define BSX_REGIONS_PENDING (-100)
+int bsx_regions_finish(bsx_device_t *dev, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
 /* K5 */
 int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 /* K6 */

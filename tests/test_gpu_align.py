@@ -140,10 +140,27 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
             assert ps.n_host_tasks == ps.n_tasks
             assert crc() == a, max_occ
             L.bsx_sim_reset_reads(p, 2 * n_pairs)
+            os.environ.pop("BSX_HOST_CHAIN", None)
+            # strand searches whose interval lists overflow are seeded again on a side stream with longer lists; a short
+            # first-pass list sends ordinary reads down that path, collected before the front half returns or (async) by
+            # regions_finish at the start of the back half
+            os.environ["BSX_SEED_MEM_CAP"] = "28"
+            for asy in ("0", "1"):
+                os.environ["BSX_ASYNC_REDO"] = asy
+                B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
+                L.bsx_last_phase_stats(C.byref(ps))
+                assert crc() == a, (max_occ, asy)
+                assert ps.n_host_tasks * 5 < ps.n_tasks
+                if asy == "1":
+                    assert ps.n_redo_tasks > 0
+                L.bsx_sim_reset_reads(p, 2 * n_pairs)
+            os.environ.pop("BSX_SEED_MEM_CAP", None)
+            os.environ.pop("BSX_ASYNC_REDO", None)
             seen.add(a)
         assert len(seen) == 2   # the cap does change the alignments
     finally:
-        os.environ.pop("BSX_HOST_CHAIN", None)
+        for k in ("BSX_HOST_CHAIN", "BSX_SEED_MEM_CAP", "BSX_ASYNC_REDO"):
+            os.environ.pop(k, None)
         L.bsx_sim_free_reads(p, 2 * n_pairs)
         dev.close()
         idx.close()
