@@ -140,10 +140,30 @@ def main():
     sam_bytes_box = [0]
     L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
 
+    # A completed chunk's SAM text is counted and dropped (13 chunks of SAM would be several GB per rank) by a consumer
+    # thread, as the command line's writer thread does (cli.c): the stream runs a chunk's back half on the thread that
+    # pushes, so consuming the output there would stall the pipeline.  The consumer is joined inside the timed region.
+    import queue
+    import threading
+    retire_q = queue.Queue()
+    retire_s = [0.0]
+    retired = set()
+
+    def consumer():
+        while True:
+            k = retire_q.get()
+            if k is None:
+                return
+            tr = time.time()
+            sam_bytes_box[0] += L.bsx_sim_sam_bytes(chunks[k], n_reads)
+            L.bsx_sim_reset_reads(chunks[k], n_reads)
+            retire_s[0] += time.time() - tr
+            retired.add(k)
+    consumer_th = threading.Thread(target=consumer)
+    consumer_th.start()
+
     def retire(k):
-        # a completed chunk: count its SAM text, then drop it (13 chunks of SAM would be several GB per rank)
-        sam_bytes_box[0] += L.bsx_sim_sam_bytes(chunks[k], n_reads)
-        L.bsx_sim_reset_reads(chunks[k], n_reads)
+        retire_q.put(k)
 
     def account():
         ps = B.PhaseStats()
@@ -158,6 +178,8 @@ def main():
             account()
             retire(s)
         else:
+            while s - len(chunks) >= args.warmup and (s - len(chunks)) not in retired:
+                time.sleep(0.001)   # the ring slot's previous use must have been consumed (it has, several steps ago)
             B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push")
             if s - args.warmup >= depth - 1:
                 account()       # the push completed the chunk pushed depth-1 pushes ago
@@ -168,6 +190,8 @@ def main():
         account()               # (the statistics of the last one stand in for the others drained with it)
         for k in range(max(args.warmup, args.warmup + args.steps - (depth - 1)), args.warmup + args.steps):
             retire(k)
+    retire_q.put(None)
+    consumer_th.join()
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
@@ -255,6 +279,7 @@ def main():
             "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(7)} if alone else None),
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
+            "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "index_build_s": round(t_build, 1), "device": dev.name,

@@ -698,7 +698,10 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						const int prev = R.score;
 						aw = P.w << i;
 						J.w = aw;
-						res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
+						// most extensions of a 150 bp read are shorter than a wavefront is wide: one register entry per lane then,
+						// and none of the per-chunk band tests and carries of the wider form
+						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane);
+						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;

@@ -67,3 +67,78 @@ for d in dirs:
     lines.append("")
 open(os.path.join(out, "%s_pmc_summary.md" % tag), "w").write("\n".join(lines))
 print("wrote profiles/%s_*" % tag)
+
+# --- HBM traffic per kernel (feeds bench.py's roofline.traffic) and the device's busy time under the pipelined run
+import json
+
+
+def pmc_dir(name):
+    f = glob.glob(os.path.join(src, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True)
+    return table(f[0])[0] if f else None
+
+
+def pick(agg, kernel):
+    tot = collections.defaultdict(float)
+    for k, v in agg.items():
+        if k.startswith(kernel + "<") or k == kernel:
+            for c, x in v.items():
+                tot[c] += x
+    return tot
+
+
+fs, ws, hm = pmc_dir("FETCH_SIZE"), pmc_dir("WRITE_SIZE"), pmc_dir("TCC_HIT_sum_TCC_MISS_sum")
+if fs and ws:
+    traffic = {}
+    for kern in ("k_seed", "k_occ", "k_regions"):
+        traffic[kern] = {"FETCH_SIZE_KiB": pick(fs, kern).get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": pick(ws, kern).get("WRITE_SIZE", 0.0)}
+        if hm:
+            traffic[kern]["TCC_HIT"] = pick(hm, kern).get("TCC_HIT_sum", 0.0)
+            traffic[kern]["TCC_MISS"] = pick(hm, kern).get("TCC_MISS_sum", 0.0)
+    traffic["_note"] = ("rocprofv3 --pmc passes of `python bench.py --genome-mbp 128 --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline` "
+                        "(one chunk of 1,066,666 read pairs; tools/profile_round.sh), summed over the dispatches of each kernel.  Calibration on this "
+                        "access pattern: k_occ reads exactly one 64-byte FM block per LF step (4 x 16 B loads per lane) plus 8 B per lookup and 16 B per "
+                        "occurrence; with the files' 1-in-32 suffix-array sample (an earlier pass of this round) its FETCH_SIZE was 0.88 x that byte count "
+                        "at a 7 % L2 hit rate, i.e. FETCH_SIZE is within a few percent of the bytes that miss L2 for 64-byte gathers (not the 1/2 the "
+                        "guide measured for wide coalesced streams).")
+    traffic["_pairs_per_chunk"] = 1066666
+    json.dump(traffic, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
+
+kt = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if kt:
+    iv = []
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(kt[0])):
+        a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        iv.append((a, b))
+        per[short(r["Kernel_Name"])] += (b - a) * 1e-6
+    iv.sort()
+    # the trace covers index upload, warm-up, the timed steps and the stand-alone chunk: split it at idle gaps > 0.5 s
+    # (host-only stretches: synthetic reads being generated) and report every stretch; the longest is the timed region
+    merged = []
+    for a, b in iv:
+        if merged and a <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], b)
+        else:
+            merged.append([a, b])
+    phases = [[merged[0]]]
+    for m in merged[1:]:
+        if m[0] - phases[-1][-1][1] > 500e6:
+            phases.append([m])
+        else:
+            phases[-1].append(m)
+    with open(os.path.join(out, "%s_gpu_busy.md" % tag), "w") as g:
+        g.write("# Device busy time under the pipelined bench (%s)\n\n" % tag)
+        g.write("From the rocprofv3 kernel trace of `bench.py --steps 4 --warmup 1` (tools/profile_round.sh): stretches of device activity\n"
+                "separated by idle gaps > 0.5 s.  The longest stretch is the timed region (4 chunks through the depth-3 stream, the\n"
+                "first and last of them without a neighbour to overlap with); `busy` = at least one kernel executing.\n\n")
+        g.write("| stretch | start, ms | length, ms | busy, ms | busy % | kernels |\n|---|---|---|---|---|---|\n")
+        t0 = iv[0][0]
+        for i, ph in enumerate(phases):
+            a, b = ph[0][0], ph[-1][1]
+            busy = sum(y - x for x, y in ph)
+            nk = sum(1 for x, y in iv if a <= x <= b)
+            g.write("| %d | %.0f | %.1f | %.1f | %.1f | %d |\n" % (i, (a - t0) * 1e-6, (b - a) * 1e-6, busy * 1e-6, 100.0 * busy / max(1, b - a), nk))
+        g.write("\n| kernel | summed duration over the whole trace, ms |\n|---|---|\n")
+        for k in sorted(per, key=lambda k: -per[k]):
+            if per[k] >= 1.0:
+                g.write("| %s | %.1f |\n" % (k, per[k]))
