@@ -19,7 +19,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
        long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-       int quota, unsigned int *slab_busy, int n_slabs)
+       int quota, unsigned int *slab_busy, int n_slabs, int trip_budget)
 {
 	// per-wave slab, lane-interleaved: entry i of lane l sits at slab[i*64 + l], so the 64 lanes'
 	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
@@ -44,7 +44,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.qlds = nullptr;
 	L.state = SD_DONE;
 	L.n_slow = L.n_fast = 0;
-	int task = -1, retired = 0, taken = 0;
+	int task = -1, retired = 0, taken = 0, trips = 0;
 	uint32_t tot_slow = 0, tot_fast = 0;
 
 	for (;;) {
@@ -61,7 +61,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 							else L.overflow = 1;
 						}
 						task_off[task] = (long long)base;
-						task_n[task] = L.overflow ? -n : n;
+						task_n[task] = L.overflow ? -n - 1 : n;   // any negative count: seed this strand search again
 						tot_slow += L.n_slow; tot_fast += L.n_fast;
 						task = -1;
 					}
@@ -85,6 +85,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						L.qlds = my_read;
 					}
 					seed_lane_begin(L);
+					trips = 0;
 					if (L.len < P.min_seed_len || L.len + 1 > list_cap) { // too short to seed (memchain.c:279) / cannot fit
 						if (L.len + 1 > list_cap) L.overflow = 1;
 						L.state = SD_DONE;
@@ -104,6 +105,11 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 			seed_post(L, ok, P);
 			// a strand search whose lists no longer fit is abandoned at once: its result is discarded and it is seeded again with
 			// longer lists, so finishing it here would only keep this wave (and the kernel's tail) alive for nothing
+			// The same goes for a strand search that has taken `trip_budget` extensions (a few in a hundred thousand do: low-complexity
+			// reads whose lists stay just inside their bounds).  The kernel lasts at least as long as its longest dependent chain, and
+			// one lane's chain of 20 k extensions is a third of the time the whole chunk needs; the second pass has the region tiers'
+			// run time to finish them in.
+			if (trip_budget && ++trips > trip_budget) L.overflow = 1;
 			if (L.overflow) L.state = SD_DONE;
 		}
 	}
@@ -146,18 +152,18 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-                 int quota, unsigned int *slab_busy, int n_slabs)
+                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget)
 {
 	static const int occ = getenv("BSX_SEED_OCC") ? atoi(getenv("BSX_SEED_OCC")) : 3;   // waves per SIMD the register allocation targets
 	if (occ <= 3)
 		hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
 	else if (occ == 4)
 		hipLaunchKernelGGL(k_seed<4>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
 	else
 		hipLaunchKernelGGL(k_seed<5>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

@@ -405,7 +405,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		HIPCHK(hipEventRecord(L.ev0, L.st));
 		launch_seed(L.st, grid, d->ix, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)cn, P,
 		            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4);
+		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4, 0);
 		HIPCHK(hipEventRecord(L.ev1, L.st));
 		if ((rc = finish_timed(L, 0)) != BSX_OK) return rc;
 		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
@@ -482,6 +482,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 6 + 65536;
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
+	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
+	static const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
 	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
@@ -518,7 +520,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs);
+	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
@@ -567,7 +569,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			HIPCHK(hipMemcpyAsync(c32 + 5, &L.rs.n2u, 4, hipMemcpyHostToDevice, L.st2));
 			HIPCHK(hipMemsetAsync(c32 + 7, 0, 4, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4);
+			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the third tier's slabs are shared with the main launch sequence
 			launch_regions_slab(L.st2, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
