@@ -461,6 +461,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (n == 0) return BSX_OK;
 	if (n > 0x7fffffff) return BSX_E_ARG;
 	HIPCHK(hipSetDevice(d->ordinal));
+	struct timespec ts_in, ts_out;
+	clock_gettime(CLOCK_MONOTONIC, &ts_in);
 	int rc, max_len = 0;
 	for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, tasks[i].len);
 	SeedParams P;
@@ -609,6 +611,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
+	clock_gettime(CLOCK_MONOTONIC, &ts_out);
+	if (trace) fprintf(stderr, "[M::regions_batch] entry to kernels enqueued %.0f ms | tiers done to regions downloaded %.0f ms (%llu regions)\n",
+	                   (ts0.tv_sec - ts_in.tv_sec) * 1e3 + (ts0.tv_nsec - ts_in.tv_nsec) * 1e-6, (ts_out.tv_sec - ts3.tv_sec) * 1e3 + (ts_out.tv_nsec - ts3.tv_nsec) * 1e-6, used);
 	// declined tasks: hand their interval lists back (ordered by info, as bsx_seed_batch returns them)
 	std::vector<int64_t> decl;
 	for (int64_t i = 0; i < n; ++i) if (out_n[i] < -1 && out_n[i] != BSX_REGIONS_PENDING) decl.push_back(i);

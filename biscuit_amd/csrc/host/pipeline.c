@@ -1027,7 +1027,7 @@ static int chunk_front(chunk_t *C)
 		rc = be->regions_batch(be->ctx, opt, C->n_tasks, C->stasks, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n, &decl_intv, &decl_cap, decl_off);
 		bsx_big_update(C->arena_set, 8, C->dregs, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		if (rc != BSX_OK) goto out;
-		bsx_parallel_for(nt, adopt_worker, C, C->n_tasks);
+		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, adopting the regions %.3f s\n", ta - t0, now_s() - ta); }
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
 		n_reseed = C->n_host;
