@@ -49,6 +49,9 @@ struct SeedLane {
 	int32_t ext_back, ext_c, ext_which;   // ext_which: 0 = own index, 1 = complementary index
 	DevIntv ext_in;
 	DevIntv next_in;          // prev[j+1], requested one step ahead so that its latency overlaps the FM gathers
+	DevIntv head;             // entry 0 of the list being built (the forward list's latest push, a backward row's first survivor).
+	                          // It is never stored: the next row reads it from here.  Most backward rows have a single survivor,
+	                          // so most extensions write nothing at all to the lists in scratch
 	int32_t have_next;
 	uint32_t n_slow, n_fast;
 };
@@ -81,6 +84,15 @@ BSX_HD void seed_set_intv(const DevIndex &ix, int parent, int c, DevIntv &ik)   
 {
 	const uint64_t l = dev_ix_L2(ix, parent, c);
 	ik.x0 = l + 1; ik.x2 = dev_ix_L2(ix, parent, c + 1) - l; ik.x1 = dev_ix_L2(ix, !parent, 3 - c) + 1; ik.info = 0;
+}
+
+// push L.ik on the forward list (written downwards from the top of bufA): the entry pushed last is entry 0 of the backward
+// sweep's first row and stays in `head`; the one that was there moves to its slot in memory
+BSX_HD void seed_fwd_push(SeedLane &L)
+{
+	if (L.ncurr > 0) L.bufA[(size_t)(L.list_cap - L.ncurr) * L.stride] = L.head;
+	L.head = L.ik;
+	++L.ncurr;
 }
 
 // Run the machine until it needs a bwt_extend (returns 1, request in L.ext_*) or the task is done (0).
@@ -132,16 +144,16 @@ BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			L.state = SD_FWD;
 			break;
 		case SD_FWD: // forward extension through the complementary index (bwt.c:324-339)
-			if (L.i >= L.len) { L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE; break; }
+			if (L.i >= L.len) { seed_fwd_push(L); L.state = SD_FWD_DONE; break; }
 			{
 				int b = seed_qbase(L, L.i);
 				if (b < 4) { L.ext_in = L.ik; L.ext_back = 0; L.ext_c = 3 - b; L.ext_which = 1; L.state = SD_FWD_POST; return 1; }
-				L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; ++L.ncurr; L.state = SD_FWD_DONE;
+				seed_fwd_push(L); L.state = SD_FWD_DONE;
 			}
 			break;
 		case SD_FWD_DONE: // the list is already "reversed": smallest interval first (bwt.c:341-343)
 			L.prev_is_A = 1; L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
-			L.ret = (int)(uint32_t)L.bufA[(size_t)L.prev_off * L.stride].info;
+			L.ret = (int)(uint32_t)L.head.info;
 			L.i = L.x0 - 1;
 			// first backward row set up here (x0 >= 0, so i >= -1): one trip through the switch less per SMEM
 			{
@@ -166,7 +178,7 @@ BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			{
 				const DevIntv *prev = (L.prev_is_A ? L.bufA : L.bufB);
 				if (L.have_next) { L.ext_in.x0 = L.next_in.x0; L.ext_in.x1 = L.next_in.x1; L.ext_in.x2 = L.next_in.x2; L.ext_in.info = L.next_in.info; }
-				else { const DevIntv v = prev[(size_t)(L.prev_off + L.j) * L.stride]; L.ext_in.x0 = v.x0; L.ext_in.x1 = v.x1; L.ext_in.x2 = v.x2; L.ext_in.info = v.info; }
+				else { L.ext_in.x0 = L.head.x0; L.ext_in.x1 = L.head.x1; L.ext_in.x2 = L.head.x2; L.ext_in.info = L.head.info; }   // j == 0: entry 0 lives in `head`
 				L.have_next = L.j + 1 < L.nprev;
 				if (L.have_next) L.next_in = prev[(size_t)(L.prev_off + L.j + 1) * L.stride];
 				if (L.c >= 0) { L.ext_back = 1; L.ext_c = L.c; L.ext_which = 0; L.state = SD_BWD_POST; return 1; }
@@ -194,8 +206,7 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 	switch (L.state) {
 	case SD_FWD_POST:
 		if (ok.x2 != L.ik.x2) { // interval size changed: record the old one (bwt.c:329-333)
-			if (L.ncurr < L.list_cap) L.bufA[(size_t)(L.list_cap - 1 - L.ncurr) * L.stride] = L.ik; else L.overflow = 1;
-			++L.ncurr;
+			if (L.ncurr < L.list_cap) seed_fwd_push(L); else { L.overflow = 1; ++L.ncurr; }
 			if (ok.x2 < (uint64_t)L.min_intv) { L.state = SD_FWD_DONE; break; }
 		}
 		L.ik = ok; L.ik.info = (uint64_t)(L.i + 1);
@@ -212,7 +223,8 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 			DevIntv *curr = L.prev_is_A ? L.bufB : L.bufA;
 			if (L.ncurr == 0 || ok.x2 != L.last_x2) {
 				DevIntv o = ok; o.info = L.ext_in.info;
-				curr[(size_t)L.ncurr * L.stride] = o; ++L.ncurr;
+				if (L.ncurr == 0) L.head = o; else curr[(size_t)L.ncurr * L.stride] = o;
+				++L.ncurr;
 				L.last_x2 = ok.x2;
 			}
 		}
