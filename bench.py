@@ -128,7 +128,7 @@ def main():
     L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
     for s_ in range(args.warmup):
         L.bsx_sim_reset_reads(chunks[s_], n_reads)   # drop the warm-up chunks' SAM text
-    for k in range(7):
+    for k in range(8):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
     phase_tot = {}
@@ -214,15 +214,15 @@ def main():
     # different chunks share the device, so a launch lasts longer than it would alone; one extra chunk is therefore
     # run unpipelined after the timed region and its event times are reported next to the live ones.
     ctr = dev.counters()
-    ktimes = [dev.kernel_time(k) for k in range(7)]
+    ktimes = [dev.kernel_time(k) for k in range(8)]
     alone = None
     if not args.no_pipeline:
-        for k in range(7):
+        for k in range(8):
             dev.kernel_time(k, reset=True)
         extra = gen(777, pairs_per_step)
         B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(standalone)")
         L.bsx_sim_free_reads(extra, n_reads)
-        alone = [dev.kernel_time(k) for k in range(7)]
+        alone = [dev.kernel_time(k) for k in range(8)]
 
     def roof_of(name, k, alg_bytes, extra):
         ms, launches = ktimes[k]
@@ -244,7 +244,7 @@ def main():
     if os.path.exists(tpath) and abs(args.genome_mbp - 128) < 1e-9 and args.read_len == 150 and threads == 16:
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("_reads_per_chunk") == n_reads:
+        if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
             for kname in ("k_seed", "k_occ"):
                 if tj.get(kname, {}).get("FETCH_SIZE_KiB") is not None and tj[kname].get("WRITE_SIZE_KiB") is not None:
                     traffic[kname] = 1024.0 * (tj[kname]["FETCH_SIZE_KiB"] + tj[kname]["WRITE_SIZE_KiB"])
@@ -263,7 +263,7 @@ def main():
         cpu = cpu_baseline(L, B, idx, opt, args, ncores)
 
     if rank == 0:
-        names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23_and_reseed_wait"]
+        names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_host_path_batches"]
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
@@ -275,8 +275,8 @@ def main():
             "roofline": roof,
             "roofline_second_kernel": roof_other,
             "cpu_baseline": cpu,
-            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(7)},
-            "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(7)} if alone else None),
+            "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(8)},
+            "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(8)} if alone else None),
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),

@@ -67,8 +67,8 @@ struct Lane {
 		hipEvent_t ev = nullptr, ev_tiers = nullptr;
 		unsigned long long used_main = 0;      // regions the caller already holds
 	} rs;
-	double k_ms[7] = {0, 0, 0, 0, 0, 0, 0};
-	int64_t k_launch[7] = {0, 0, 0, 0, 0, 0, 0};
+	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct bsx_device {
@@ -319,7 +319,7 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 
 extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
 {
-	if (!d || k < 0 || k >= 7) return BSX_E_ARG;
+	if (!d || k < 0 || k >= 8) return BSX_E_ARG;
 	double ms = 0; int64_t n = 0;
 	for (int l = 0; l < BSX_LANES; ++l) {
 		ms += d->lane[l].k_ms[k]; n += d->lane[l].k_launch[k];
@@ -407,7 +407,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
 		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4, 0);
 		HIPCHK(hipEventRecord(L.ev1, L.st));
-		if ((rc = finish_timed(L, 0)) != BSX_OK) return rc;
+		if ((rc = finish_timed(L, 7)) != BSX_OK) return rc;   // the batch form, for what the host chains: not the chunk-wide launch of slot 0
 		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
 		unsigned long long used = 0;
 		D2H(L.st, r_off.data(), d_off, (size_t)cn * 8);

@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps ${STEPS:-16} --warmup 1 --no-cpu-baseline"
 cd /tmp
 python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1   # builds the index once
 $BENCH > "$OUT/bench_untraced.json" 2> "$OUT/bench_untraced.err"

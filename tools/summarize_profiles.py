@@ -95,12 +95,12 @@ if fs and ws:
             traffic[kern]["TCC_HIT"] = pick(hm, kern).get("TCC_HIT_sum", 0.0)
             traffic[kern]["TCC_MISS"] = pick(hm, kern).get("TCC_MISS_sum", 0.0)
     traffic["_note"] = ("rocprofv3 --pmc passes of `python bench.py --genome-mbp 128 --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline` "
-                        "(one chunk of 1,066,666 read pairs; tools/profile_round.sh), summed over the dispatches of each kernel.  Calibration on this "
+                        "(one chunk of 1,066,666 reads; tools/profile_round.sh), summed over the dispatches of each kernel.  Calibration on this "
                         "access pattern: k_occ reads exactly one 64-byte FM block per LF step (4 x 16 B loads per lane) plus 8 B per lookup and 16 B per "
                         "occurrence; with the files' 1-in-32 suffix-array sample (an earlier pass of this round) its FETCH_SIZE was 0.88 x that byte count "
                         "at a 7 % L2 hit rate, i.e. FETCH_SIZE is within a few percent of the bytes that miss L2 for 64-byte gathers (not the 1/2 the "
                         "guide measured for wide coalesced streams).")
-    traffic["_pairs_per_chunk"] = 1066666
+    traffic["_reads_per_chunk"] = 1066666
     json.dump(traffic, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
 
 kt = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
@@ -128,9 +128,10 @@ if kt:
             phases[-1].append(m)
     with open(os.path.join(out, "%s_gpu_busy.md" % tag), "w") as g:
         g.write("# Device busy time under the pipelined bench (%s)\n\n" % tag)
-        g.write("From the rocprofv3 kernel trace of `bench.py --steps 4 --warmup 1` (tools/profile_round.sh): stretches of device activity\n"
-                "separated by idle gaps > 0.5 s.  The longest stretch is the timed region (4 chunks through the depth-3 stream, the\n"
-                "first and last of them without a neighbour to overlap with); `busy` = at least one kernel executing.\n\n")
+        g.write("From the rocprofv3 kernel trace of the default `bench.py` run (tools/profile_round.sh): stretches of device activity\n"
+                "separated by idle gaps > 0.5 s.  The longest stretch is warm-up + timed region (chunks through the depth-3 stream);\n"
+                "`busy` = at least one kernel executing, which includes single-wave launches (the second seeding pass), so it says\n"
+                "when the device had nothing at all to do, not how full it was.\n\n")
         g.write("| stretch | start, ms | length, ms | busy, ms | busy % | kernels |\n|---|---|---|---|---|---|\n")
         t0 = iv[0][0]
         for i, ph in enumerate(phases):
