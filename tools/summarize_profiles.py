@@ -143,3 +143,20 @@ if kt:
         for k in sorted(per, key=lambda k: -per[k]):
             if per[k] >= 1.0:
                 g.write("| %s | %.1f |\n" % (k, per[k]))
+
+# --- the dominant kernel's launches by kind: rocprofv3's per-kernel average mixes the chunk-wide launch (what bench.py's
+# `roofline` times with HIP events) with the single-workgroup launches of the second seeding pass and of the host path
+if kt:
+    cls = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt[0])):
+        if short(r["Kernel_Name"]).startswith("k_seed"):
+            wgs = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+            cls["chunk-wide (>= 1000 workgroups)" if wgs >= 1000 else "second pass / host path (<= 16 workgroups)"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    with open(os.path.join(out, "%s_kseed_launches.md" % tag), "w") as g:
+        g.write("# k_seed launches in the kernel trace (%s), by kind\n\n" % tag)
+        g.write("`%s_kernel_stats.csv` averages every launch of a kernel; bench.py's `roofline.avg_launch_ms` is the chunk-wide launch only\n"
+                "(HIP events on its stream), so compare it with the first row.  The trace covers warm-up chunk + timed chunks (pipelined:\n"
+                "kernels of two or three chunks share the device) + one stand-alone chunk (`avg_launch_ms_standalone`).\n\n" % tag)
+        g.write("| kind | launches | average ms | min ms | max ms |\n|---|---|---|---|---|\n")
+        for k, v in sorted(cls.items()):
+            g.write("| %s | %d | %.1f | %.1f | %.1f |\n" % (k, len(v), sum(v) / len(v), min(v), max(v)))
