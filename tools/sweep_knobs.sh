@@ -1,12 +1,5 @@
+#!/bin/bash
+# pipelined default bench under a list of environment settings, one line each (A/B on one box): tools/sweep_knobs.sh A=1 BSX_X=2 ...
 run() { env "$@" timeout 300 python bench.py --steps 12 --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$*',d['value'],d['ms_per_step'])"; }
-run A=1
-run BSX_SEED_OCC=4
-run BSX_REGIONS_OCC=3
-run BSX_REGIONS_OCC=5
-run BSX_SEED_QUOTA=4
-run BSX_SEED_QUOTA=1
-run BSX_REGIONS_QUOTA=32
-run BSX_REGIONS_QUOTA=8
-run BSX_RESERVE_CU_EVERY=16
-run A=2
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);k=d['kernel_ms_per_step_standalone'];print('$*',d['value'],d['ms_per_step'],k['regions_tiers23'],d['kernel_ms_per_step']['regions_tiers23'])"; }
+for v in "$@"; do run $v; done
