@@ -57,6 +57,7 @@ struct RgStore {
 	int n_nodes, root;
 };
 typedef RgStore<64, 96, 96, 12, 0, unsigned char, signed char> RgSmall;
+typedef RgStore<96, 192, 192, 16, 0, unsigned char, short> RgMid;               // still LDS: 16 KB per wave, two waves per workgroup
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 struct RgDp { int32_t H[64], E[64]; };   // per-wave LDS scratch of the one-lane passes (introsort stack, tree traversal stack)
@@ -351,9 +352,24 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
 			if (lane >= off) incl += o;
 		}
+		// the HBM tiers hold thousands of intervals (reads inside tandem repeats): there the other keys come 64 at a time with one
+		// coalesced load and are handed round with v_readlane, instead of n_iv uniform loads per group of 64
+		int big_rank = 0;
+		if (Store::SCAP > 128) {
+			for (int cb = 0; cb < n_iv; cb += 64) {
+				const int kk = cb + lane;
+				const unsigned long long oinfo = kk < n_iv ? src[kk].info : ~0ull;
+				const int lim = n_iv - cb < 64 ? n_iv - cb : 64;
+				for (int j = 0; j < lim; ++j) {
+					const unsigned long long oi = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(oinfo >> 32), j) << 32 | (unsigned)__builtin_amdgcn_readlane((int)oinfo, j);
+					big_rank += (oi < mine.info) || (oi == mine.info && cb + j < i);
+				}
+			}
+		}
 		if (i < n_iv) {
 			int rank = 0;
-			for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
+			if (Store::SCAP <= 128) for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
+			else rank = big_rank;
 			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - cnt) : mine.x0;
 			S.iv_n[rank] = cnt | big << 30;
 			S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
@@ -379,6 +395,27 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	{
 		int i = 0, acc = 0;   // occurrences are visited in increasing order by each lane: the interval cursor only moves forward
 		uint32_t lf = 0;
+		if (Store::SCAP > 128 && n_iv > 256) { // thousands of intervals with a few occurrences each: a lane per interval, 64 intervals at a time
+			int run_o = 0;
+			for (int base = 0; base < n_iv; base += 64) {
+				const int ii = base + lane;
+				const int cnt = ii < n_iv ? (S.iv_n[ii] & 0x3fffffff) : 0;
+				const int incl = wave_scan_sum_incl(cnt);
+				const int o0 = run_o + incl - cnt;
+				if (cnt) {
+					const unsigned long long x0 = S.iv_x0[ii];
+					const int qb = S.iv_beg[ii], slen = S.iv_end[ii] - qb;
+					for (int c = 0; c < cnt; ++c) {
+						const long long pos = posl ? (long long)posl[x0 + (unsigned long long)c] : rg_sa(ix, parent, x0 + (unsigned long long)c, lf);
+						const int o = o0 + c;
+						S.s_rbeg[o] = pos; S.s_qbeg[o] = (short)qb; S.s_len[o] = (short)slen;
+						S.s_rid[o] = rg_intv2rid(ix, ctg, pos, pos + slen);
+						S.s_chain[o] = -1; S.s_extra[o] = 0;
+					}
+				}
+				run_o += uni(__builtin_amdgcn_readlane(incl, 63));
+			}
+		} else
 		for (int o = lane; o < tot; o += 64) {
 			while (acc + (S.iv_n[i] & 0x3fffffff) <= o) { acc += S.iv_n[i] & 0x3fffffff; ++i; }
 			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
@@ -831,6 +868,43 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 	}
 }
 
+// Between the first tier and the HBM tiers: the same tables four times larger, still in LDS (two waves per workgroup, three
+// workgroups per CU).  On a larger genome a repeat family has more copies, and a quarter of the strand searches outgrow the
+// first tier's 96 seeds; in HBM slabs every table access is a memory round trip.  Same list protocol as k_regions_slab.
+__global__ void __launch_bounds__(128, 2)
+k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+              const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+              bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+              const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
+              unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+{
+	__shared__ RgMid lds[2];
+	__shared__ RgDp dp[2];
+	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
+	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
+	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
+	__syncthreads();
+	const int lane = wave_lane();
+	RgMid &S = lds[threadIdx.x >> 6];
+	RgDp &D = dp[threadIdx.x >> 6];
+	const int n = (int)*count;
+	for (;;) {
+		int i = 0;
+		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
+		i = uni(__shfl(i, 0));
+		if (i >= n) break;
+		const int t = uni(list[i]);
+		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
+		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
+		const long long po = pos ? uni64(pos_off[t]) : -1;
+		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
+		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
+		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
+	}
+}
+
 // ---- K3 for the whole chunk ahead of the region kernels: the LF walks are pure pointer chasing, and run an order of
 // magnitude faster with one walk per lane and thousands of waves in flight than inside the wave-per-task kernels.
 // k_occ_expand lists the SA ranks of every occurrence each strand search will visit (lane per strand search),
@@ -919,6 +993,15 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
 }
 
+void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+                        const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+                        bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                        const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+{
+	hipLaunchKernelGGL(k_regions_mid, dim3(grid), dim3(128), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos);
+}
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

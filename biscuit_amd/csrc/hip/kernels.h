@@ -25,6 +25,12 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
                     const long long *pos_off, const unsigned long long *pos);
+// the tier in between: LDS tables four times the first tier's; consumes the first tier's list, appends to the second tier's
+void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+                        const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
+                        bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                        const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

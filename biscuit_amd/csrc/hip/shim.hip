@@ -500,7 +500,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 20 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 24 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	const unsigned long long pos_cap = (unsigned long long)n * 128 + (1u << 20);   // one u64 per seed occurrence of the chunk
@@ -510,9 +510,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
 	int *retry_a = (int*)((char*)L.regmeta.p + (size_t)n * 12), *retry_b = (int*)((char*)L.regmeta.p + (size_t)n * 16);
+	int *retry_m = (int*)((char*)L.regmeta.p + (size_t)n * 20);
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
-	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor
+	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
+	//                       [10] count of what the LDS tier in between hands to tier 2  [11] that tier's cursor
 	unsigned long long *ctr = dev_counters(L);
 	unsigned int *c32 = (unsigned int*)(ctr + 7);
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
@@ -530,8 +532,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
 	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos);
 	HIPCHK(hipEventRecord(L.ev3, L.st));
+	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
+	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
+	if (use_mid)
+		launch_regions_mid(L.st, d->n_cu * 4, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
+	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 

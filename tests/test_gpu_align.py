@@ -252,7 +252,8 @@ def test_cli_many_chunks_through_the_stream(data):
     {"BSX_REGIONS_OCC": "3", "BSX_SEED_OCC": "4"},                  # other register-allocation targets
     {"BSX_RESERVE_CU_EVERY": "0", "BSX_STREAM_DEPTH": "1"},         # no reserved CUs, no overlap of chunks
     {"BSX_SEED_QUOTA": "0", "BSX_REGIONS_QUOTA": "1", "BSX_STREAM_DEPTH": "4"},   # persistent seeding waves, one task per region wave
-], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4"])
+    {"BSX_REGIONS_MID": "0", "BSX_SEED_TRIP_BUDGET": "200"},        # no LDS tier between the first and the HBM tiers; most strand searches handed to the second seeding pass
+], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget"])
 def test_device_tuning_knobs_do_not_change_the_output(data, env):
     """Launch shapes, occupancy targets, the device-side suffix-array sample and the pipeline depth are performance knobs:
     the SAM must be byte-identical whatever they are set to."""
