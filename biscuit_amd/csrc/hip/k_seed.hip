@@ -47,9 +47,19 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	int task = -1, retired = 0, taken = 0, trips = 0;
 	uint32_t tot_slow = 0, tot_fast = 0;
 
+	unsigned int trip = 0;
 	for (;;) {
+		// Every trip: the short machine (forward walk, backward sweep, LAST-like walk).  A lane that reaches any other state
+		// waits for the full machine, which the wave runs every fourth trip, or at once when 25 lanes wait or no lane has an
+		// extension to do: its code (pass control, SMEM prologue/epilogue, publishing, fetching and packing the next read) is
+		// several times longer than a trip's, and a wave pays for every state any of its lanes is in.  (Measured: 180 -> 174 ms,
+		// and the same with the full machine on every trip: what helps is that the common states leave through the short copy.)
 		int need = 0;
-		if (!retired) {
+		if (!retired) need = seed_advance_t<true>(L, ix, P) == 1;
+		const bool cold = !retired && !need;
+		const unsigned long long cm = __ballot(cold);
+		++trip;
+		if (cold && ((trip & 3u) == 0 || __popcll(cm) > 24 || __ballot(need) == 0)) {
 			for (;;) {
 				if (L.state == SD_DONE) {
 					if (task >= 0) { // publish the finished task

@@ -96,9 +96,15 @@ BSX_HD void seed_fwd_push(SeedLane &L)
 }
 
 // Run the machine until it needs a bwt_extend (returns 1, request in L.ext_*) or the task is done (0).
-BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
+// HOT_ONLY: only the states a lane is in on almost every trip (forward walk, backward sweep, LAST-like walk) are compiled in; on
+// reaching any other state the function returns 2 and leaves it to the full machine.  The lanes of a wave are in different
+// states and the wave executes the code of every state some lane is in, so the rare transitions (pass control, SMEM
+// prologue and epilogue) are kept out of the per-trip path.
+template <bool HOT_ONLY>
+BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 {
 	for (;;) {
+		if (HOT_ONLY && L.state != SD_FWD && L.state != SD_BWD_ELEM && L.state != SD_S1 && L.state != SD_FWD_DONE) return L.state == SD_DONE ? 0 : 2;
 		switch (L.state) {
 		case SD_DONE: return 0;
 		case SD_P1:  // pass 1: SMEMs from every position (memchain.c:65-73)
@@ -199,6 +205,8 @@ BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 		}
 	}
 }
+
+BSX_HD int seed_advance(SeedLane &L, const DevIndex &ix, const SeedParams &P) { return seed_advance_t<false>(L, ix, P); }
 
 // Consume the result of the requested extend.
 BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
