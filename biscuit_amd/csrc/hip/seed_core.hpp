@@ -104,7 +104,7 @@ template <bool HOT_ONLY>
 BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 {
 	for (;;) {
-		if (HOT_ONLY && L.state != SD_FWD && L.state != SD_BWD_ELEM && L.state != SD_S1 && L.state != SD_FWD_DONE) return L.state == SD_DONE ? 0 : 2;
+		if (HOT_ONLY && L.state != SD_FWD && L.state != SD_BWD_ELEM && L.state != SD_S1 && L.state != SD_FWD_DONE && L.state != SD_P3) return L.state == SD_DONE ? 0 : 2;
 		switch (L.state) {
 		case SD_DONE: return 0;
 		case SD_P1:  // pass 1: SMEMs from every position (memchain.c:65-73)
