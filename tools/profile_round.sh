@@ -17,6 +17,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INS
 	name=$(echo $grp | tr ' ' '_')
 	rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o bench -- python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-128} --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err"
 	# (the profiler may crash while the process exits, after the counters have been written: judge by the output)
-	ls "$OUT/pmc_$name"/*/*counter_collection.csv "$OUT/pmc_$name"/*counter_collection.csv > /dev/null 2>&1 || echo "pmc group $grp: no counter file" >> "$OUT/errors.txt"
+	[ -n "$(find "$OUT/pmc_$name" -name "*counter_collection.csv" 2>/dev/null | head -1)" ] || echo "pmc group $grp: no counter file" >> "$OUT/errors.txt"
 done
 find "$OUT" -name "*.csv" | head -50 > "$OUT/files.txt"
