@@ -1216,9 +1216,13 @@ BSX_API int bsx_stream_depth(const bsx_stream_t *s) { return s ? s->depth : 0; }
 static int chunk_finish(chunk_t *C)
 {
 	int rc;
+	double t0 = now_s(), t1, t2;
 	if (C->th_live) { pthread_join(C->th, 0); C->th_live = 0; }
+	t1 = now_s();
 	rc = C->rc;
 	if (rc == BSX_OK && !C->back_done) rc = chunk_back(C);
+	t2 = now_s();
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::stream] waited %.3f s for the front half, back half %.3f s\n", t1 - t0, t2 - t1);
 	chunk_free(C);
 	return rc;
 }
