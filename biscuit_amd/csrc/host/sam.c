@@ -22,6 +22,8 @@ static inline void sb_need(sbuf_t *b, size_t extra)
 {
 	if (b->l + extra + 1 > b->m) { b->m = (b->l + extra + 1) * 2 + 64; b->s = (char*)realloc(b->s, b->m); }
 }
+/* room for the usual record (two copies of the read, the tags) in one allocation instead of a doubling series */
+static inline void sb_reserve(sbuf_t *b, size_t m) { if (m > b->m) { b->m = m; b->s = (char*)realloc(b->s, b->m); if (b->l == 0) b->s[0] = 0; } }
 static inline void sb_putc(sbuf_t *b, int c) { sb_need(b, 1); b->s[b->l++] = (char)c; b->s[b->l] = 0; }
 static inline void sb_putsn(sbuf_t *b, const char *p, size_t n) { sb_need(b, n); memcpy(b->s + b->l, p, n); b->l += n; b->s[b->l] = 0; }
 static inline void sb_puts(sbuf_t *b, const char *p) { sb_putsn(b, p, strlen(p)); }
@@ -390,6 +392,7 @@ void bsx_reg2sam_se(const bsx_opt_t *opt, const bsx_index_t *idx, bsx_read_t *s,
 {
 	drv_t D = { opt, idx, ctx, rg_id };
 	sbuf_t str = {0, 0, 0};
+	if (!ctx->plan) sb_reserve(&str, (size_t)s->l_seq0 * 3 + 200);
 	int_v sel = select_format(&D, 0, regs);
 	if (sel.n > 0) {
 		size_t i;
@@ -415,6 +418,7 @@ static void pe_nopairing(drv_t *D, bsx_read_t s[2], reg_v regs[2], const bsx_pes
 	}
 	for (i = 0; i < 2; ++i) {
 		sbuf_t str = {0, 0, 0};
+		if (!D->ctx->plan) sb_reserve(&str, (size_t)s[i].l_seq0 * 3 + 200);
 		if (sel[i].n) {
 			size_t j;
 			for (j = 0; j < sel[i].n; ++j) {
@@ -486,6 +490,7 @@ void bsx_reg2sam_pe(const bsx_opt_t *opt, const bsx_index_t *idx, uint64_t id, b
 	for (i = 0; i < 2; ++i) set_sam(&D, i, &regs[i], &regs[i].a[z[i]]);
 	for (i = 0; i < 2; ++i) {
 		sbuf_t str = {0, 0, 0};
+		if (!ctx->plan) sb_reserve(&str, (size_t)s[i].l_seq0 * 3 + 200);
 		reg_v *r = &regs[i];
 		format_sam(&D, i, &str, &s[i], &r->a[z[i]], &regs[!i].a[z[!i]], r, 1, pes);
 		if (r->n_pri < r->n) { /* best ALT hit as an extra supplementary record */
