@@ -40,6 +40,15 @@ static inline void sb_putl(sbuf_t *b, long c)   /* kputl/kputw: decimal, '-' for
 }
 #define sb_putw(b, c) sb_putl(b, (long)(int)(c))
 
+/* a builder that starts in a caller's stack buffer: moved to the heap the first time it has to grow */
+static inline void sb_room_from_stack(sbuf_t *b, const char *stack, size_t extra)
+{
+	if (b->l + extra + 1 <= b->m) return;
+	b->m = (b->l + extra + 1) * 2 + 64;
+	if (b->s == stack) { char *h = (char*)malloc(b->m); memcpy(h, stack, b->l + 1); b->s = h; }
+	else b->s = (char*)realloc(b->s, b->m);
+}
+
 /* ------------------------------------------------------------------ K6 job + finish */
 static int infer_bw(int l1, int l2, int score, int a, int q, int r)   /* bwamem.h:192-198 */
 {
@@ -76,21 +85,37 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 	const char *int2base = reg->rb < l_pac ? "ACGTN" : "TGCAN";
 	const uint8_t *query = s->seq;
 	int parent = reg->parent, l_MD;
-	sbuf_t md = {0, 0, 0};
+	/* MD (at most two characters per reference base, plus the last count) in a stack buffer unless the alignment is unusually
+	 * long (one heap block per record otherwise: a million per chunk); the reference bases of the alignment, decoded once in
+	 * alignment order: a forward walk over pac on either strand */
+	char md_stack[1024];
+	uint8_t rb_stack[480], *rbase = rb_stack;
+	sbuf_t md = {md_stack, 0, sizeof(md_stack)};   /* grows through sb_room_from_stack only */
 	uint32_t *cigar;
 	(void)opt;
+	md_stack[0] = 0;
+	{
+		const int64_t rl = reg->re - reg->rb, f0 = rev ? (l_pac << 1) - reg->re : reg->rb;   /* forward coordinate of the first base */
+		int64_t j;
+		if (rl > (int64_t)sizeof(rb_stack)) {
+			rbase = (uint8_t*)malloc((size_t)rl);
+		}
+		if (rev) for (j = 0; j < rl; ++j) rbase[j] = (uint8_t)(3 - bsx_pac_get(idx->pac, f0 + j));
+		else for (j = 0; j < rl; ++j) rbase[j] = (uint8_t)bsx_pac_get(idx->pac, f0 + j);
+	}
 	/* MD / NM / ZC / ZR over the alignment (bwa.c:342-418); conversions are MD mismatches but not NM */
 	for (k = 0, x = y = u = 0; k < n_cigar; ++k) {
 		int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
 		if (op == 0) {
 			for (i = 0; i < len; ++i) {
 				int q = rev ? query[reg->qe - 1 - (x + i)] : query[reg->qb + x + i];
-				int r = bsx_ref_base(l_pac, idx->pac, rev ? reg->re - 1 - (y + i) : reg->rb + y + i);
+				int r = rbase[y + i];
 				if (q == r) {
 					if (q == 1) ++n_ret_c;
 					if (q == 2) ++n_ret_g;
 					++u;
 				} else {
+					sb_room_from_stack(&md, md_stack, 16);
 					sb_putw(&md, u); sb_putc(&md, int2base[r]); u = 0;
 					if (parent && q == 3 && r == 1) ++n_conv_ct;
 					else if (!parent && q == 0 && r == 2) ++n_conv_ga;
@@ -100,13 +125,15 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 			x += len; y += len;
 		} else if (op == 2) {
 			if (k > 0 && k < n_cigar - 1) {
+				sb_room_from_stack(&md, md_stack, 16 + (size_t)len);
 				sb_putw(&md, u); sb_putc(&md, '^');
-				for (i = 0; i < len; ++i) sb_putc(&md, int2base[bsx_ref_base(l_pac, idx->pac, rev ? reg->re - 1 - (y + i) : reg->rb + y + i)]);
+				for (i = 0; i < len; ++i) sb_putc(&md, int2base[rbase[y + i]]);
 				u = 0; n_gap += len;
 			}
 			y += len;
 		} else if (op == 1) { x += len; n_gap += len; }
 	}
+	sb_room_from_stack(&md, md_stack, 16);
 	sb_putw(&md, u);
 	l_MD = (int)md.l + 1;
 	memset(out, 0, sizeof(*out));
@@ -129,8 +156,9 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 		if (clip5) { memmove(cigar + 1, cigar, (size_t)n_cigar * 4); cigar[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
 		if (clip3) cigar[n_cigar++] = (uint32_t)clip3 << 4 | 3;
 	}
-	memcpy(cigar + n_cigar, md.s ? md.s : "", md.s ? md.l + 1 : 1);
-	free(md.s);
+	memcpy(cigar + n_cigar, md.s, md.l + 1);
+	if (md.s != md_stack) free(md.s);
+	if (rbase != rb_stack) free(rbase);
 	out->n_cigar = n_cigar;
 	out->cigar = cigar;
 	out->pos = (int)(rpos - idx->ref.anns[reg->rid].offset);
