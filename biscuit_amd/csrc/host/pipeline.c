@@ -576,6 +576,7 @@ static void msw_free_worker(void *data, long pi, int tid)
 static int mate_rescue(chunk_t *C)
 {
 	int np = C->n >> 1, rc = BSX_OK, round;
+	double t_batch = 0, t_all = now_s();
 	msw_pair_t *M = (msw_pair_t*)calloc(np ? np : 1, sizeof(msw_pair_t));
 	msw_par_t P;
 	P.C = C; P.M = M;
@@ -591,7 +592,7 @@ static int mate_rescue(chunk_t *C)
 		P.jobs = (bsx_sw_job_t*)malloc(sizeof(bsx_sw_job_t) * (size_t)nj);
 		res = (bsx_sw_res_t*)malloc(sizeof(*res) * (size_t)nj);
 		bsx_parallel_for(C->nt, msw_jobs_worker, &P, np);
-		rc = C->be->sw_batch(C->be->ctx, nj, P.jobs, res);
+		{ double tb = now_s(); rc = C->be->sw_batch(C->be->ctx, nj, P.jobs, res); t_batch += now_s() - tb; }
 		C->st.n_sw_jobs += nj;
 		P.res = res;
 		if (rc == BSX_OK) bsx_parallel_for(C->nt, msw_results_worker, &P, np);
@@ -599,6 +600,7 @@ static int mate_rescue(chunk_t *C)
 		if (rc != BSX_OK) break;
 	}
 	bsx_parallel_for(C->nt, msw_free_worker, &P, np);
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host\n", round, t_batch, now_s() - t_all - t_batch);
 	free(M); free(P.cnt); free(P.off);
 	return rc;
 }
@@ -715,7 +717,7 @@ static int emit_sam(chunk_t *C)
 	uint32_t *pool = 0;
 	size_t k, pool_len = 0;
 	int64_t n_jobs;
-	double t0 = now_s();
+	double t0 = now_s(), t_batch = 0;
 	bsx_vec_init(todo);
 	P.C = C; P.ctx = ctx; P.final_pass = 0;
 	bsx_parallel_for(C->nt, out_worker, &P, n_units);
@@ -736,7 +738,7 @@ static int emit_sam(chunk_t *C)
 		size_t off = 0, nt = 0;
 		for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
-		rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
+		{ double tb = now_s(); rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off); t_batch += now_s() - tb; }
 		C->st.n_glb_jobs += (int64_t)todo.n;
 		if (rc == BSX_OK) {
 			finish_par_t F;
@@ -751,6 +753,7 @@ static int emit_sam(chunk_t *C)
 		free(sub); free(sres);
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
 	C->st.t_cigar += now_s() - t0; t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
