@@ -733,10 +733,12 @@ static int emit_sam(chunk_t *C)
 	for (k = 0; k < (size_t)n_jobs; ++k) todo.a[k] = (int)k;
 	todo.n = (size_t)n_jobs;
 	for (round = 0; round < 8 && todo.n && rc == BSX_OK; ++round) { /* a CIGAR that does not fit is redone with the room it asked for */
-		bsx_glb_job_t *sub = (bsx_glb_job_t*)malloc(sizeof(*sub) * todo.n);
+		/* the first round is every job, in place (a million 48-byte records are not copied); a later one the few whose CIGAR did not fit */
+		bsx_glb_job_t *sub = round == 0 ? Q.jobs : (bsx_glb_job_t*)malloc(sizeof(*sub) * todo.n);
 		bsx_glb_res_t *sres = (bsx_glb_res_t*)malloc(sizeof(*sres) * todo.n);
 		size_t off = 0, nt = 0;
-		for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
+		if (round == 0) for (k = 0; k < todo.n; ++k) { sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
+		else for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
 		{ double tb = now_s(); rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off); t_batch += now_s() - tb; }
 		C->st.n_glb_jobs += (int64_t)todo.n;
@@ -750,7 +752,8 @@ static int emit_sam(chunk_t *C)
 			}
 		}
 		todo.n = nt;
-		free(sub); free(sres);
+		if (round) free(sub);
+		free(sres);
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
 	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
