@@ -159,3 +159,91 @@ def test_chunk_stream_equals_chunk_by_chunk(data):
         for c in chunks:
             L.bsx_sim_free_reads(c, 2 * n_pairs)
         idx.close()
+
+
+def test_pending_and_declined_strand_searches_take_the_host_path(data):
+    """The device regions pass may decline a strand search (-1: seed and chain it on the host) or leave it pending
+    (BSX_REGIONS_PENDING: still being seeded again on a side stream; regions_finish settles it at the start of the chunk's
+    back half).  A stand-in regions pass that computes nothing — every fifth strand search pending, the others declined,
+    the pending ones declined by regions_finish — must therefore give the SAM of the plain host path: the strand searches
+    go through host chaining in two instalments, one in the front half and one in the back half."""
+    import ctypes as C
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import default_opt
+    from oracle_lib import Port
+    L = B.lib()
+    idx = Index(data + "/g")
+    opt = default_opt()
+    opt.n_threads = 2
+    opt.flag |= 0x10 | 0x2
+    n_pairs, n_chunks = 300, 3
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_stream_open_backends.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.bsx_stream_push.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bsx_stream_flush.argtypes = [C.c_void_p]
+    L.bsx_stream_close.argtypes = [C.c_void_p]
+    L.bsx_stream_close.restype = None
+    chunks = [_load_pairs(L, B, C, idx, n_pairs, 70 + k) for k in range(n_chunks)]
+    ports = [Port(idx, 2) for _ in range(2)]
+    PENDING = -100
+    p64, p32, pp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)
+    BATCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, pp, p64, p64, p32, pp, p64, p64)
+    FINISH = C.CFUNCTYPE(C.c_int, C.c_void_p, pp, p64, p64, p32)
+    n_of, calls = {}, {"batch": 0, "finish": 0, "pending": 0}
+
+    def batch(ctx, o, n, tasks, out, cap, off, cnt, di, dc, doff):
+        n_of[ctx] = n
+        calls["batch"] += 1
+        for i in range(n):
+            off[i] = 0
+            cnt[i] = PENDING if i % 5 == 0 else -1
+        doff[0] = 0
+        return 0
+
+    def finish(ctx, out, cap, off, cnt):
+        calls["finish"] += 1
+        for i in range(n_of[ctx]):
+            if cnt[i] == PENDING:
+                cnt[i] = -1
+                calls["pending"] += 1
+        return 0
+
+    cb = (BATCH(batch), FINISH(finish))   # kept alive for the duration of the test
+
+    def sam_of(k):
+        r = C.cast(chunks[k], C.POINTER(B.Read))
+        return b"".join(C.string_at(r[i].sam) for i in range(2 * n_pairs))
+
+    def standin(port):
+        be = port.backend()
+        be.regions_batch = C.cast(cb[0], C.c_void_p).value
+        be.regions_finish = C.cast(cb[1], C.c_void_p).value
+        return be
+
+    try:
+        be0 = ports[0].backend()
+        want = []
+        for k in range(n_chunks):
+            B.check(L.bsx_process_seqs_backend(C.byref(be0), C.byref(opt), idx.h, 2 * n_pairs * k, 2 * n_pairs, chunks[k], None), "process")
+            want.append(sam_of(k))
+            L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+        be1 = standin(ports[0])
+        for k in range(n_chunks):
+            B.check(L.bsx_process_seqs_backend(C.byref(be1), C.byref(opt), idx.h, 2 * n_pairs * k, 2 * n_pairs, chunks[k], None), "process")
+            assert sam_of(k) == want[k], k
+            L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
+        assert calls["batch"] == n_chunks and calls["finish"] == n_chunks and calls["pending"] > 0
+        bes = (B.Backend * 2)(standin(ports[0]), standin(ports[1]))
+        s = C.c_void_p()
+        B.check(L.bsx_stream_open_backends(2, bes, C.byref(opt), idx.h, None, C.byref(s)), "open")
+        for k in range(n_chunks):
+            B.check(L.bsx_stream_push(s, 2 * n_pairs * k, 2 * n_pairs, chunks[k]), "push")
+        B.check(L.bsx_stream_flush(s), "flush")
+        for k in range(n_chunks):
+            assert sam_of(k) == want[k], ("stream", k)
+        L.bsx_stream_close(s)
+    finally:
+        for c in chunks:
+            L.bsx_sim_free_reads(c, 2 * n_pairs)
