@@ -164,9 +164,11 @@ def test_chunk_stream_equals_chunk_by_chunk(data):
 def test_pending_and_declined_strand_searches_take_the_host_path(data):
     """The device regions pass may decline a strand search (-1: seed and chain it on the host) or leave it pending
     (BSX_REGIONS_PENDING: still being seeded again on a side stream; regions_finish settles it at the start of the chunk's
-    back half).  A stand-in regions pass that computes nothing — every fifth strand search pending, the others declined,
-    the pending ones declined by regions_finish — must therefore give the SAM of the plain host path: the strand searches
-    go through host chaining in two instalments, one in the front half and one in the back half."""
+    back half), or hand its interval list back (< -1: chain it on the host from these).  A stand-in regions pass that
+    computes no regions — a fifth of the strand searches pending, a fifth handed back with their intervals (seeded by the
+    CPU restatement inside the stand-in), the others declined, the pending ones declined by regions_finish — must
+    therefore give the SAM of the plain host path: the strand searches go through host chaining in two instalments, one
+    in the front half and one in the back half."""
     import ctypes as C
     from biscuit_amd import _lib as B
     from biscuit_amd.api import default_opt
@@ -191,16 +193,23 @@ def test_pending_and_declined_strand_searches_take_the_host_path(data):
     p64, p32, pp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)
     BATCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, pp, p64, p64, p32, pp, p64, p64)
     FINISH = C.CFUNCTYPE(C.c_int, C.c_void_p, pp, p64, p64, p32)
-    n_of, calls = {}, {"batch": 0, "finish": 0, "pending": 0}
+    n_of, calls = {}, {"batch": 0, "finish": 0, "pending": 0, "handed_back": 0}
+    PL = ports[0].L   # the oracle library (test infrastructure), not the product library
+    PL.oracle_port_seed_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, pp, p64, p64]
 
     def batch(ctx, o, n, tasks, out, cap, off, cnt, di, dc, doff):
         n_of[ctx] = n
         calls["batch"] += 1
         for i in range(n):
             off[i] = 0
-            cnt[i] = PENDING if i % 5 == 0 else -1
-        doff[0] = 0
-        return 0
+            cnt[i] = PENDING if i % 5 == 0 else (-10 if i % 5 == 1 else -1)
+        sel = [i for i in range(n) if i % 5 == 1]   # these come back with their interval lists, in task order
+        src = C.cast(tasks, C.POINTER(C.c_int32))   # bsx_seed_task_t = 3 x 32 bits
+        sub = (C.c_int32 * (3 * len(sel) + 3))()
+        for j, i in enumerate(sel):
+            sub[3 * j], sub[3 * j + 1], sub[3 * j + 2] = src[3 * i], src[3 * i + 1], src[3 * i + 2]
+        calls["handed_back"] += len(sel)
+        return PL.oracle_port_seed_batch(ctx, o, len(sel), sub, di, dc, doff)
 
     def finish(ctx, out, cap, off, cnt):
         calls["finish"] += 1
@@ -234,7 +243,7 @@ def test_pending_and_declined_strand_searches_take_the_host_path(data):
             B.check(L.bsx_process_seqs_backend(C.byref(be1), C.byref(opt), idx.h, 2 * n_pairs * k, 2 * n_pairs, chunks[k], None), "process")
             assert sam_of(k) == want[k], k
             L.bsx_sim_reset_reads(chunks[k], 2 * n_pairs)
-        assert calls["batch"] == n_chunks and calls["finish"] == n_chunks and calls["pending"] > 0
+        assert calls["batch"] == n_chunks and calls["finish"] == n_chunks and calls["pending"] > 0 and calls["handed_back"] > 0
         bes = (B.Backend * 2)(standin(ports[0]), standin(ports[1]))
         s = C.c_void_p()
         B.check(L.bsx_stream_open_backends(2, bes, C.byref(opt), idx.h, None, C.byref(s)), "open")
