@@ -44,7 +44,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.qlds = nullptr;
 	L.state = SD_DONE;
 	L.n_slow = L.n_fast = 0;
-	int task = -1, retired = 0, taken = 0, trips = 0;
+	int task = -1, retired = 0, taken = 0, trips = 0, budget = 0;
 	uint32_t tot_slow = 0, tot_fast = 0;
 
 	unsigned int trip = 0;
@@ -96,6 +96,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 					}
 					seed_lane_begin(L);
 					trips = 0;
+					budget = trip_budget * ((L.len + 255) >> 8);   // per 256 bases: a long read is not a runaway
 					if (L.len < P.min_seed_len || L.len + 1 > list_cap) { // too short to seed (memchain.c:279) / cannot fit
 						if (L.len + 1 > list_cap) L.overflow = 1;
 						L.state = SD_DONE;
@@ -119,7 +120,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 			// reads whose lists stay just inside their bounds).  The kernel lasts at least as long as its longest dependent chain, and
 			// one lane's chain of 20 k extensions is a third of the time the whole chunk needs; the second pass has the region tiers'
 			// run time to finish them in.
-			if (trip_budget && ++trips > trip_budget) L.overflow = 1;
+			if (budget && ++trips > budget) L.overflow = 1;
 			if (L.overflow) L.state = SD_DONE;
 		}
 	}
