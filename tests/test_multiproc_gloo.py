@@ -33,7 +33,7 @@ def test_two_ranks_equal_one(tmp_path, pe):
     assert one.returncode == 0, one.stderr.decode()[-2000:]
     assert one.stderr.count(b"sequences (") >= 3     # really several chunks
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29531" if pe else "29532", "-m", "biscuit_amd.multi_gpu", "--backend", "oracle", "--out", d + "/two.sam", "--", "-@", "1", "g"] + files,
+                          "--master-port", "29531" if pe else "29532", os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/two.sam", "--", "-@", "1", "g"] + files,
                          cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert two.returncode == 0, two.stderr.decode()[-3000:]
     a, b = strip_pg(one.stdout), strip_pg(open(d + "/two.sam", "rb").read())
