@@ -38,6 +38,36 @@ class Index:
         B.check(B.lib().bsx_index_build(fasta.encode(), base.encode()), "bsx_index_build")
         return Index(base)
 
+    @classmethod
+    def _wrap(cls, h):
+        self = cls.__new__(cls)
+        self.base = None
+        self.h = h
+        self.l_pac = B.lib().bsx_index_l_pac(h)
+        return self
+
+    @classmethod
+    def from_fasta(cls, fasta):
+        """pac + annotation only (bis_bns_fasta2bntseq); the FM indices come from build_host() or Device.build_index()"""
+        h = C.c_void_p()
+        B.check(B.lib().bsx_index_from_fasta(fasta.encode(), C.byref(h)), "bsx_index_from_fasta")
+        return cls._wrap(h)
+
+    @classmethod
+    def synthetic(cls, n_bases, seed, n_contigs=8, repeat_frac=0.05):
+        """seeded synthetic genome (csrc/host/sim.c) straight into an index without FM indices"""
+        L = B.lib()
+        L.bsx_sim_genome_index.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        B.check(L.bsx_sim_genome_index(n_bases, seed, n_contigs, repeat_frac, C.byref(h)), "bsx_sim_genome_index")
+        return cls._wrap(h)
+
+    def build_host(self):
+        B.check(B.lib().bsx_index_build_host(self.h), "bsx_index_build_host")
+
+    def save(self, base):
+        B.check(B.lib().bsx_index_save(self.h, base.encode()), "bsx_index_save")
+
     def close(self):
         if self.h:
             B.lib().bsx_index_free(self.h)
@@ -127,6 +157,10 @@ class Device(Batches):
 
     def upload_index(self, index):
         B.check(B.lib().bsx_device_upload_index(self.h, index.h), "bsx_device_upload_index")
+
+    def build_index(self, index, fill_host=False):
+        """both FM indices built on the device from index's pac and left resident (csrc/hip/k_index.hip)"""
+        B.check(B.lib().bsx_device_build_index(self.h, index.h, int(fill_host)), "bsx_device_build_index")
 
     def counters(self, reset=False):
         c = (C.c_uint64 * 4)()

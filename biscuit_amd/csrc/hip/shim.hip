@@ -10,38 +10,11 @@
 #include <time.h>
 #include <algorithm>
 #include <vector>
-extern "C" {
-#include "bsx_core.h"
-}
+#include "devbuf.hpp"
 #include "kernels.h"
+#include "index_build.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[bsx-hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return BSX_E_NODEVICE; } } while (0)
-
-struct DevBuf {
-	void *p = nullptr; size_t cap = 0;
-	int reserve(size_t n) {
-		if (n <= cap) return BSX_OK;
-		if (p) (void)hipFree(p);
-		size_t want = n + (n >> 2) + 4096;
-		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed\n", want); return BSX_E_NOMEM; }
-		cap = want;
-		return BSX_OK;
-	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden bounce copy)
-	void *p = nullptr; size_t cap = 0;
-	int reserve(size_t n) {
-		if (n <= cap) return BSX_OK;
-		if (p) (void)hipHostFree(p);
-		size_t want = n + (n >> 2) + 4096;
-		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return BSX_E_NOMEM; }
-		cap = want;
-		return BSX_OK;
-	}
-	void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
 
 // One lane = one HIP stream with its own staging: a chunk is bound to a lane for its whole life, so the front half
 // (seeding .. regions) of one chunk and the back half (merge .. SAM) of the previous one can be in flight together.
@@ -167,24 +140,9 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 
 extern "C" BSX_API const char *bsx_device_name(const bsx_device_t *d) { return d ? d->name : ""; }
 
-extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_t *idx)
+// pac and the contig table: what the kernels need of the reference besides the FM indices
+static int upload_ref(bsx_device_t *d, const bsx_index_t *idx)
 {
-	if (!d || !idx) return BSX_E_ARG;
-	HIPCHK(hipSetDevice(d->ordinal));
-	for (int i = 0; i < 2; ++i) {
-		const bsx_fmi_t *f = &idx->fmi[i];
-		int rc;
-		if ((rc = d->bwt[i].reserve((size_t)f->bwt_size * 4 + 64)) != BSX_OK) return rc;
-		if ((rc = d->sa[i].reserve((size_t)f->n_sa * 8)) != BSX_OK) return rc;
-		HIPCHK(hipMemcpy(d->bwt[i].p, f->bwt, (size_t)f->bwt_size * 4, hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(d->sa[i].p, f->sa, (size_t)f->n_sa * 8, hipMemcpyHostToDevice));
-		DevFmi &g = d->ix.fmi[i];
-		g.primary = f->primary; for (int k = 0; k < 5; ++k) g.L2[k] = f->L2[k];
-		g.seq_len = f->seq_len; g.bwt = (const uint32_t*)d->bwt[i].p; g.sa = (const uint64_t*)d->sa[i].p;
-		g.sa_mask = (uint32_t)f->sa_intv - 1; g.sa_shift = 0;
-		while ((1 << g.sa_shift) < f->sa_intv) ++g.sa_shift;
-		if ((1 << g.sa_shift) != f->sa_intv) return BSX_E_FORMAT;
-	}
 	size_t npac = (size_t)(idx->ref.l_pac / 4 + 1);
 	int rc;
 	if ((rc = d->pac.reserve(npac + 16)) != BSX_OK) return rc;
@@ -201,6 +159,30 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 		HIPCHK(hipMemcpy((char*)d->ctg.p + ((size_t)ns + 1) * 8, alt.data(), (size_t)ns, hipMemcpyHostToDevice));
 		d->ix.ctg_off = (const int64_t*)d->ctg.p; d->ix.ctg_alt = (const uint8_t*)d->ctg.p + ((size_t)ns + 1) * 8; d->ix.n_seqs = ns;
 	}
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_t *idx)
+{
+	if (!d || !idx) return BSX_E_ARG;
+	if (!idx->fmi[0].bwt || !idx->fmi[1].bwt || !idx->fmi[0].sa || !idx->fmi[1].sa) return BSX_E_ARG;   // no FM indices on the host side: bsx_device_build_index makes them in place
+	HIPCHK(hipSetDevice(d->ordinal));
+	for (int i = 0; i < 2; ++i) {
+		const bsx_fmi_t *f = &idx->fmi[i];
+		int rc;
+		if ((rc = d->bwt[i].reserve((size_t)f->bwt_size * 4 + 64)) != BSX_OK) return rc;
+		if ((rc = d->sa[i].reserve((size_t)f->n_sa * 8)) != BSX_OK) return rc;
+		HIPCHK(hipMemcpy(d->bwt[i].p, f->bwt, (size_t)f->bwt_size * 4, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d->sa[i].p, f->sa, (size_t)f->n_sa * 8, hipMemcpyHostToDevice));
+		DevFmi &g = d->ix.fmi[i];
+		g.primary = f->primary; for (int k = 0; k < 5; ++k) g.L2[k] = f->L2[k];
+		g.seq_len = f->seq_len; g.bwt = (const uint32_t*)d->bwt[i].p; g.sa = (const uint64_t*)d->sa[i].p;
+		g.sa_mask = (uint32_t)f->sa_intv - 1; g.sa_shift = 0;
+		while ((1 << g.sa_shift) < f->sa_intv) ++g.sa_shift;
+		if ((1 << g.sa_shift) != f->sa_intv) return BSX_E_FORMAT;
+	}
+	int rc;
+	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
 	{ // denser suffix-array sample for the device (the files' 1-in-32 stays what the loader and the host see)
 		const char *e = getenv("BSX_DEVICE_SA_INTV");
 		int want = e ? atoi(e) : 4;
@@ -223,6 +205,42 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 				d->ix.fmi[i].sa = (const uint64_t*)d->sa[i].p; d->ix.fmi[i].sa_mask = (uint32_t)want - 1; d->ix.fmi[i].sa_shift = (uint32_t)shift;
 			}
 		}
+	}
+	d->has_index = true;
+	return BSX_OK;
+}
+
+// (f)1 on the device: both FM indices built in HBM from the genome's pac (k_index.hip) and left resident
+extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx, int fill_host)
+{
+	if (!d || !idx || !idx->pac || idx->ref.l_pac <= 0) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc;
+	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
+	const char *e = getenv("BSX_DEVICE_SA_INTV");
+	int dense = e ? atoi(e) : 4;
+	if (dense < 1 || dense > 32 || (dense & (dense - 1))) dense = 4;
+	Lane &L = d->lane[0];
+	for (int i = 1; i >= 0; --i) {
+		bsx_fmi_t *f = &idx->fmi[i], meta;
+		memset(&meta, 0, sizeof(meta));
+		free(f->bwt); free(f->sa); f->bwt = nullptr; f->sa = nullptr;
+		d->bwt[i].release(); d->sa[i].release();
+		const uint64_t n = (uint64_t)idx->ref.l_pac * 2;
+		uint32_t *h_bwt = nullptr; uint64_t *h_sa = nullptr;
+		if (fill_host) {
+			const uint64_t n_occ = (n + 127) / 128 + 1, words = ((n + 15) >> 4) + n_occ * 8, n_sa = (n + 32) / 32;
+			h_bwt = (uint32_t*)calloc(words + 16, 4); h_sa = (uint64_t*)calloc(n_sa, 8);
+			if (!h_bwt || !h_sa) { free(h_bwt); free(h_sa); return BSX_E_NOMEM; }
+		}
+		rc = bsx_ix_build_fmi(L.st, d->n_cu, (const uint8_t*)d->pac.p, idx->ref.l_pac, i, dense, 32, &d->bwt[i], &d->sa[i], &meta, h_bwt, h_sa);
+		if (rc != BSX_OK) { free(h_bwt); free(h_sa); return rc; }
+		*f = meta; f->bwt = h_bwt; f->sa = h_sa;   // bwt == NULL: the FM index lives on the device only
+		DevFmi &g = d->ix.fmi[i];
+		g.primary = meta.primary; for (int k = 0; k < 5; ++k) g.L2[k] = meta.L2[k];
+		g.seq_len = meta.seq_len; g.bwt = (const uint32_t*)d->bwt[i].p; g.sa = (const uint64_t*)d->sa[i].p;
+		g.sa_mask = (uint32_t)dense - 1; g.sa_shift = 0;
+		while ((1 << g.sa_shift) < dense) ++g.sa_shift;
 	}
 	d->has_index = true;
 	return BSX_OK;

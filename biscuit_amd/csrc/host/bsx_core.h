@@ -100,6 +100,13 @@ struct bsx_index {
 
 #define bsx_pac_get(pac, l) ((pac)[(l) >> 2] >> ((~(l) & 3) << 1) & 3)
 
+/* genome sink (index.c): contigs and bases streamed in, an index holding pac + annotation (no FM indices yet) out */
+typedef struct bsx_gsink bsx_gsink_t;
+bsx_gsink_t *bsx_gsink_new(void);
+void bsx_gsink_contig(bsx_gsink_t *g, const char *name, const char *comment);
+int  bsx_gsink_bases(bsx_gsink_t *g, const char *chars, int64_t n);   /* FASTA characters of the current contig */
+bsx_index_t *bsx_gsink_finish(bsx_gsink_t *g);
+
 /* coordinate helpers (bntseq.c:356-452, bntseq.h:91-93) */
 static inline int64_t bsx_depos(int64_t l_pac, int64_t pos, int *is_rev)
 {

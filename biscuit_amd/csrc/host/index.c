@@ -298,21 +298,105 @@ static const uint8_t nt4_of_char[256] = {
 };
 const uint8_t *bsx_nt4_table(void) { return nt4_of_char; }
 
-typedef struct { char *name, *comment; char *seq; int64_t l; } fa_rec_t;
+/* ------------------------------------------------------------------------------------------
+ * genome sink: contigs and bases streamed in, <base>.bis.{pac,ann,amb} content out (bis_bns_fasta2bntseq,
+ * lib/aln/bntseq.c:542-633).  N -> random base with the reference's generator and seed (bntseq.c:558-559,495).
+ * Both the FASTA reader and the synthetic-genome generator (sim.c) feed it, so a genome never has to exist as
+ * text or as one byte per base.
+ * ------------------------------------------------------------------------------------------ */
+struct bsx_gsink {
+	bsx_index_t *idx;
+	int64_t cap;             /* bases the pac array has room for */
+	BSX_VEC(bsx_amb_t) holes;
+	int n_anns, m_anns;
+	int lasts;               /* last character of the current contig (runs of one ambiguity code form one hole) */
+};
 
-/* minimal FASTA reader (plain or gzip) */
-static int read_fasta(const char *fn, fa_rec_t **recs_, int *n_)
+bsx_gsink_t *bsx_gsink_new(void)
+{
+	bsx_gsink_t *g = (bsx_gsink_t*)calloc(1, sizeof(*g));
+	g->idx = (bsx_index_t*)calloc(1, sizeof(bsx_index_t));
+	g->idx->ref.seed = 11;
+	bsx_vec_init(g->holes);
+	srand48(11);
+	return g;
+}
+
+void bsx_gsink_contig(bsx_gsink_t *g, const char *name, const char *comment)
+{
+	bsx_refmeta_t *r = &g->idx->ref;
+	bsx_ann_t *p;
+	if (g->n_anns == g->m_anns) { g->m_anns = g->m_anns ? g->m_anns << 1 : 16; r->anns = (bsx_ann_t*)realloc(r->anns, sizeof(bsx_ann_t) * (size_t)g->m_anns); }
+	p = &r->anns[g->n_anns++];
+	memset(p, 0, sizeof(*p));
+	p->name = strdup(name); p->anno = strdup(comment ? comment : "");
+	p->offset = r->l_pac;
+	r->n_seqs = g->n_anns;
+	g->lasts = 0;
+}
+
+int bsx_gsink_bases(bsx_gsink_t *g, const char *chars, int64_t n)
+{
+	bsx_refmeta_t *r = &g->idx->ref;
+	bsx_ann_t *p;
+	int64_t k, l = r->l_pac;
+	uint8_t *pac;
+	if (g->n_anns == 0) return BSX_E_FORMAT;
+	p = &r->anns[g->n_anns - 1];
+	if ((int64_t)p->len + n > 0x7fffffffLL) { fprintf(stderr, "[bsx] contig %s is longer than 2^31 bases\n", p->name); return BSX_E_FORMAT; }
+	if (l + n + 64 > g->cap) {
+		int64_t nc = g->cap ? g->cap : (1 << 20);
+		while (nc < l + n + 64) nc <<= 1;
+		g->idx->pac = (uint8_t*)realloc(g->idx->pac, (size_t)(nc / 4 + 32));
+		if (!g->idx->pac) return BSX_E_NOMEM;
+		memset(g->idx->pac + g->cap / 4, 0, (size_t)(nc / 4 + 32 - g->cap / 4));
+		g->cap = nc;
+	}
+	pac = g->idx->pac;
+	for (k = 0; k < n; ++k, ++l) {
+		int ch = (unsigned char)chars[k], c = nt4_of_char[ch];
+		if (c >= 4) {
+			if (g->lasts == ch) ++g->holes.a[g->holes.n - 1].len;
+			else {
+				bsx_amb_t h; h.offset = l; h.len = 1; h.amb = (char)ch;
+				bsx_vec_push(g->holes, h);
+				++p->n_ambs;
+			}
+			c = (int)(lrand48() & 3);
+		}
+		g->lasts = ch;
+		pac[l >> 2] |= (uint8_t)(c << ((~l & 3) << 1));
+	}
+	p->len += (int32_t)n;
+	r->l_pac = l;
+	return BSX_OK;
+}
+
+bsx_index_t *bsx_gsink_finish(bsx_gsink_t *g)
+{
+	bsx_index_t *idx = g->idx;
+	idx->ref.n_holes = (int32_t)g->holes.n;
+	idx->ref.ambs = g->holes.a;
+	if (!idx->pac) idx->pac = (uint8_t*)calloc(32, 1);
+	free(g);
+	return idx;
+}
+
+/* minimal FASTA reader (plain or gzip), streamed into the sink */
+BSX_API int bsx_index_from_fasta(const char *fn, bsx_index_t **out)
 {
 	gzFile fp = gzopen(fn, "r");
 	char *line;
 	size_t cap = 1 << 16;
-	fa_rec_t *recs = 0; int n = 0, m = 0;
-	int64_t mseq = 0;
+	bsx_gsink_t *g;
+	int rc = BSX_OK, n = 0;
+	*out = 0;
 	if (!fp) return BSX_E_IO;
 	gzbuffer(fp, 1 << 20);
 	line = (char*)malloc(cap);
-	while (gzgets(fp, line, (int)cap)) {
-		size_t l = strlen(line);
+	g = bsx_gsink_new();
+	while (rc == BSX_OK && gzgets(fp, line, (int)cap)) {
+		size_t l = strlen(line), i, m;
 		while (l == cap - 1 && line[l - 1] != '\n') { /* long line */
 			cap <<= 1; line = (char*)realloc(line, cap);
 			if (!gzgets(fp, line + l, (int)(cap - l))) break;
@@ -320,30 +404,27 @@ static int read_fasta(const char *fn, fa_rec_t **recs_, int *n_)
 		}
 		while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
 		if (line[0] == '>') {
-			char *p = line + 1, *q;
-			if (n == m) { m = m ? m << 1 : 16; recs = (fa_rec_t*)realloc(recs, sizeof(fa_rec_t) * m); }
+			char *p = line + 1, *q, *comment = 0;
 			for (q = p; *q && !isspace((unsigned char)*q); ++q);
-			recs[n].comment = 0;
-			if (*q) { *q++ = 0; while (*q && isspace((unsigned char)*q)) ++q; if (*q) recs[n].comment = strdup(q); }
-			recs[n].name = strdup(p);
-			recs[n].seq = 0; recs[n].l = 0; mseq = 0;
+			if (*q) { *q++ = 0; while (*q && isspace((unsigned char)*q)) ++q; if (*q) comment = q; }
+			bsx_gsink_contig(g, p, comment);
 			++n;
 		} else if (n > 0) {
-			fa_rec_t *r = &recs[n - 1];
-			size_t i;
-			if (r->l + (int64_t)l + 1 > mseq) { mseq = (r->l + l + 1) * 2; r->seq = (char*)realloc(r->seq, mseq); }
-			for (i = 0; i < l; ++i) if (!isspace((unsigned char)line[i])) r->seq[r->l++] = line[i];
+			for (i = 0, m = 0; i < l; ++i) if (!isspace((unsigned char)line[i])) line[m++] = line[i];
+			rc = bsx_gsink_bases(g, line, (int64_t)m);
 		}
 	}
 	free(line);
 	gzclose(fp);
-	*recs_ = recs; *n_ = n;
-	return n > 0 ? BSX_OK : BSX_E_FORMAT;
+	*out = bsx_gsink_finish(g);
+	if (rc == BSX_OK && (n == 0 || (*out)->ref.l_pac <= 0)) rc = BSX_E_FORMAT;
+	if (rc != BSX_OK) { bsx_index_free(*out); *out = 0; }
+	return rc;
 }
 
-static int write_fmi(const char *base, const char *tag, const uint8_t *text, int64_t n)
+/* FM index of one converted text on the host: suffix-sort text+sentinel (SA-IS, 32-bit), derive BWT, occ blocks, SA samples */
+static int host_build_fmi(const uint8_t *text, int64_t n, bsx_fmi_t *f)
 {
-	/* text: n symbols 0..3.  Suffix-sort text+sentinel, derive BWT, occ blocks and SA samples. */
 	uint8_t *s = (uint8_t*)malloc((size_t)n + 1);
 	int32_t *SA = (int32_t*)malloc(sizeof(int32_t) * ((size_t)n + 1));
 	uint64_t L2[5] = {0, 0, 0, 0, 0}, primary = 0, c[4] = {0, 0, 0, 0};
@@ -351,8 +432,6 @@ static int write_fmi(const char *base, const char *tag, const uint8_t *text, int
 	uint32_t *out;
 	uint8_t *bw;
 	int64_t i;
-	char fn[4096];
-	FILE *fp;
 
 	if (!s || !SA) { free(s); free(SA); return BSX_E_NOMEM; }
 	for (i = 0; i < n; ++i) { s[i] = text[i] + 1; ++L2[1 + text[i]]; }
@@ -377,7 +456,7 @@ static int write_fmi(const char *base, const char *tag, const uint8_t *text, int
 	/* interleave: every 128 symbols 4 x u64 counts then 8 words; one trailing count block */
 	n_occ = (seq_len + 127) / 128 + 1;
 	bwt_words = ((seq_len + 15) >> 4) + n_occ * 8;
-	out = (uint32_t*)calloc(bwt_words, 4);
+	out = (uint32_t*)calloc(bwt_words + 16, 4);
 	for (i = 0, k = 0; i < n; ++i) {
 		if ((i & 127) == 0) { memcpy(out + k, c, 32); k += 8; }
 		if ((i & 15) == 0) ++k;
@@ -387,108 +466,105 @@ static int write_fmi(const char *base, const char *tag, const uint8_t *text, int
 	memcpy(out + k, c, 32); k += 8;
 	free(bw);
 	if (k != bwt_words) { free(out); free(sa_s); return BSX_E_INTERNAL; }
-
-	snprintf(fn, sizeof(fn), "%s.%s.bwt", base, tag);
-	if ((fp = fopen(fn, "wb")) == 0) { free(out); free(sa_s); return BSX_E_IO; }
-	fwrite(&primary, 8, 1, fp); fwrite(L2 + 1, 8, 4, fp); fwrite(out, 4, bwt_words, fp);
-	fclose(fp); free(out);
-	snprintf(fn, sizeof(fn), "%s.%s.sa", base, tag);
-	if ((fp = fopen(fn, "wb")) == 0) { free(sa_s); return BSX_E_IO; }
-	fwrite(&primary, 8, 1, fp); fwrite(L2 + 1, 8, 4, fp); fwrite(&sa_intv, 8, 1, fp); fwrite(&seq_len, 8, 1, fp);
-	fwrite(sa_s + 1, 8, n_sa - 1, fp);
-	fclose(fp); free(sa_s);
+	memset(f, 0, sizeof(*f));
+	f->primary = primary; memcpy(f->L2, L2, sizeof(L2)); f->seq_len = seq_len;
+	f->bwt_size = bwt_words; f->bwt = out;
+	f->sa_intv = (int)sa_intv; f->n_sa = n_sa; f->sa = sa_s;
+	f->sa[0] = (uint64_t)-1;   /* as the loader leaves it (lib/aln/bwt.c:448-452) */
 	return BSX_OK;
 }
 
-struct build_par { const char *base; const uint8_t *fwd; int64_t l_pac; int rc[2]; };
+static int save_fmi(const char *base, const char *tag, const bsx_fmi_t *f)
+{
+	char fn[4096];
+	FILE *fp;
+	uint64_t sa_intv = (uint64_t)f->sa_intv;
+	int ok;
+	if (!f->bwt || !f->sa) return BSX_E_ARG;
+	snprintf(fn, sizeof(fn), "%s.%s.bwt", base, tag);
+	if ((fp = fopen(fn, "wb")) == 0) return BSX_E_IO;
+	ok = fwrite(&f->primary, 8, 1, fp) == 1 && fwrite(f->L2 + 1, 8, 4, fp) == 4 && fwrite(f->bwt, 4, f->bwt_size, fp) == f->bwt_size;
+	if (fclose(fp) != 0 || !ok) return BSX_E_IO;
+	snprintf(fn, sizeof(fn), "%s.%s.sa", base, tag);
+	if ((fp = fopen(fn, "wb")) == 0) return BSX_E_IO;
+	ok = fwrite(&f->primary, 8, 1, fp) == 1 && fwrite(f->L2 + 1, 8, 4, fp) == 4 && fwrite(&sa_intv, 8, 1, fp) == 1 &&
+	     fwrite(&f->seq_len, 8, 1, fp) == 1 && fwrite(f->sa + 1, 8, f->n_sa - 1, fp) == f->n_sa - 1;
+	if (fclose(fp) != 0 || !ok) return BSX_E_IO;
+	return BSX_OK;
+}
+
+struct build_par { bsx_index_t *idx; int rc[2]; };
 static void build_strand(void *data, long i, int tid)   /* i: 1 = parent (C>T), 0 = daughter (G>A) */
 {
 	struct build_par *P = (struct build_par*)data;
-	int64_t k, l_pac = P->l_pac;
+	const uint8_t *pac = P->idx->pac;
+	int64_t k, l_pac = P->idx->ref.l_pac;
 	uint8_t *text = (uint8_t*)malloc((size_t)l_pac * 2);
 	(void)tid;
 	if (!text) { P->rc[i] = BSX_E_NOMEM; return; }
 	for (k = 0; k < l_pac; ++k) {
-		uint8_t c = P->fwd[k], r = 3 - P->fwd[l_pac - 1 - k];
+		uint8_t c = (uint8_t)bsx_pac_get(pac, k), r = (uint8_t)(3 - bsx_pac_get(pac, l_pac - 1 - k));
 		if (i) { if (c == 1) c = 3; if (r == 1) r = 3; }
 		else   { if (c == 2) c = 0; if (r == 2) r = 0; }
 		text[k] = c; text[l_pac + k] = r;
 	}
-	P->rc[i] = write_fmi(P->base, i ? "par" : "dau", text, l_pac * 2);
+	P->rc[i] = host_build_fmi(text, l_pac * 2, &P->idx->fmi[i]);
 	free(text);
+}
+
+/* both FM indices of idx (pac + annotation present) on the host; texts of at most 2^31 - 2 symbols.  Larger genomes
+ * are indexed on the device (bsx_device_build_index). */
+BSX_API int bsx_index_build_host(bsx_index_t *idx)
+{
+	struct build_par bp;
+	int i;
+	if (!idx || !idx->pac) return BSX_E_ARG;
+	if (idx->ref.l_pac <= 0 || idx->ref.l_pac * 2 + 1 >= 0x7fffffffLL) { fprintf(stderr, "[bsx] genome too large for the host's 32-bit suffix sorter: build the index on the device\n"); return BSX_E_ARG; }
+	for (i = 0; i < 2; ++i) { free(idx->fmi[i].bwt); free(idx->fmi[i].sa); memset(&idx->fmi[i], 0, sizeof(bsx_fmi_t)); }
+	bp.idx = idx; bp.rc[0] = bp.rc[1] = BSX_OK;
+	bsx_parallel_for(2, build_strand, &bp, 2);   /* the two strands are independent: side by side */
+	return bp.rc[1] != BSX_OK ? bp.rc[1] : bp.rc[0];
+}
+
+/* the seven files of `biscuit index` (lib/aln/bwtindex.c:206-347): <base>.bis.{pac,ann,amb}, <base>.{par,dau}.{bwt,sa} */
+BSX_API int bsx_index_save(const bsx_index_t *idx, const char *base)
+{
+	char fn[4096];
+	FILE *fp;
+	int64_t l_pac, k;
+	int i, rc;
+	if (!idx || !idx->pac) return BSX_E_ARG;
+	l_pac = idx->ref.l_pac;
+	snprintf(fn, sizeof(fn), "%s.bis.pac", base);
+	if ((fp = fopen(fn, "wb")) == 0) return BSX_E_IO;
+	fwrite(idx->pac, 1, (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1)), fp);
+	{ uint8_t ct = 0; if (l_pac % 4 == 0) fwrite(&ct, 1, 1, fp); ct = (uint8_t)(l_pac % 4); fwrite(&ct, 1, 1, fp); }
+	if (fclose(fp) != 0) return BSX_E_IO;
+	snprintf(fn, sizeof(fn), "%s.bis.ann", base);
+	if ((fp = fopen(fn, "w")) == 0) return BSX_E_IO;
+	fprintf(fp, "%lld %d %u\n", (long long)l_pac, idx->ref.n_seqs, idx->ref.seed);
+	for (i = 0; i < idx->ref.n_seqs; ++i) {
+		const bsx_ann_t *p = &idx->ref.anns[i];
+		fprintf(fp, "%d %s", (int)p->gi, p->name);
+		fprintf(fp, " %s\n", p->anno && p->anno[0] ? p->anno : "(null)");
+		fprintf(fp, "%lld %d %d\n", (long long)p->offset, p->len, p->n_ambs);
+	}
+	if (fclose(fp) != 0) return BSX_E_IO;
+	snprintf(fn, sizeof(fn), "%s.bis.amb", base);
+	if ((fp = fopen(fn, "w")) == 0) return BSX_E_IO;
+	fprintf(fp, "%lld %d %u\n", (long long)l_pac, idx->ref.n_seqs, (unsigned)idx->ref.n_holes);
+	for (k = 0; k < idx->ref.n_holes; ++k) fprintf(fp, "%lld %d %c\n", (long long)idx->ref.ambs[k].offset, idx->ref.ambs[k].len, idx->ref.ambs[k].amb);
+	if (fclose(fp) != 0) return BSX_E_IO;
+	if ((rc = save_fmi(base, "par", &idx->fmi[1])) != BSX_OK) return rc;
+	return save_fmi(base, "dau", &idx->fmi[0]);
 }
 
 BSX_API int bsx_index_build(const char *fasta, const char *base)
 {
-	fa_rec_t *recs = 0;
-	int n_recs = 0, i, rc;
-	int64_t l_pac = 0, k, off;
-	uint8_t *fwd, *pac, *text;
-	char fn[4096];
-	FILE *fp;
-	BSX_VEC(bsx_amb_t) holes;
-	int32_t *n_ambs;
-
-	if ((rc = read_fasta(fasta, &recs, &n_recs)) != BSX_OK) return rc;
-	for (i = 0; i < n_recs; ++i) l_pac += recs[i].l;
-	if (l_pac <= 0 || l_pac * 2 + 1 >= 0x7fffffffLL) { fprintf(stderr, "[bsx] genome too large for the 32-bit suffix sorter\n"); return BSX_E_ARG; }
-	fwd = (uint8_t*)malloc((size_t)l_pac);
-	bsx_vec_init(holes);
-	n_ambs = (int32_t*)calloc(n_recs, sizeof(int32_t));
-	/* N -> random base: same generator and seed as the reference (bntseq.c:558-559,495) */
-	srand48(11);
-	for (i = 0, off = 0; i < n_recs; ++i) {
-		int lasts = 0;
-		for (k = 0; k < recs[i].l; ++k) {
-			int ch = (unsigned char)recs[i].seq[k], c = nt4_of_char[ch];
-			if (c >= 4) {
-				if (lasts == ch) ++holes.a[holes.n - 1].len;
-				else {
-					bsx_amb_t h; h.offset = off + k; h.len = 1; h.amb = (char)ch;
-					bsx_vec_push(holes, h);
-					++n_ambs[i];
-				}
-				c = (int)(lrand48() & 3);
-			}
-			lasts = ch;
-			fwd[off + k] = (uint8_t)c;
-		}
-		off += recs[i].l;
-	}
-	/* <base>.bis.pac */
-	pac = (uint8_t*)calloc((size_t)(l_pac / 4 + 2), 1);
-	for (k = 0; k < l_pac; ++k) pac[k >> 2] |= fwd[k] << ((~k & 3) << 1);
-	snprintf(fn, sizeof(fn), "%s.bis.pac", base);
-	if ((fp = fopen(fn, "wb")) == 0) return BSX_E_IO;
-	fwrite(pac, 1, (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1)), fp);
-	{ uint8_t ct = 0; if (l_pac % 4 == 0) fwrite(&ct, 1, 1, fp); ct = (uint8_t)(l_pac % 4); fwrite(&ct, 1, 1, fp); }
-	fclose(fp); free(pac);
-	/* <base>.bis.ann / .amb */
-	snprintf(fn, sizeof(fn), "%s.bis.ann", base);
-	if ((fp = fopen(fn, "w")) == 0) return BSX_E_IO;
-	fprintf(fp, "%lld %d %u\n", (long long)l_pac, n_recs, 11u);
-	for (i = 0, off = 0; i < n_recs; ++i) {
-		fprintf(fp, "%d %s", 0, recs[i].name);
-		fprintf(fp, " %s\n", recs[i].comment ? recs[i].comment : "(null)");
-		fprintf(fp, "%lld %d %d\n", (long long)off, (int)recs[i].l, n_ambs[i]);
-		off += recs[i].l;
-	}
-	fclose(fp);
-	snprintf(fn, sizeof(fn), "%s.bis.amb", base);
-	if ((fp = fopen(fn, "w")) == 0) return BSX_E_IO;
-	fprintf(fp, "%lld %d %u\n", (long long)l_pac, n_recs, (unsigned)holes.n);
-	for (k = 0; k < (int64_t)holes.n; ++k) fprintf(fp, "%lld %d %c\n", (long long)holes.a[k].offset, holes.a[k].len, holes.a[k].amb);
-	fclose(fp);
-	/* converted texts and their FM indices: the two strands are independent, build them side by side */
-	{
-		struct build_par bp;
-		bp.base = base; bp.fwd = fwd; bp.l_pac = l_pac; bp.rc[0] = bp.rc[1] = BSX_OK;
-		bsx_parallel_for(2, build_strand, &bp, 2);
-		rc = bp.rc[1] != BSX_OK ? bp.rc[1] : bp.rc[0];
-	}
-	text = 0;
-	free(text); free(fwd); free(n_ambs); bsx_vec_free(holes);
-	for (i = 0; i < n_recs; ++i) { free(recs[i].name); free(recs[i].comment); free(recs[i].seq); }
-	free(recs);
+	bsx_index_t *idx = 0;
+	int rc = bsx_index_from_fasta(fasta, &idx);
+	if (rc != BSX_OK) return rc;
+	if ((rc = bsx_index_build_host(idx)) == BSX_OK) rc = bsx_index_save(idx, base);
+	bsx_index_free(idx);
 	return rc;
 }

@@ -13,16 +13,14 @@ static inline uint64_t rng_next(rng_t *r) { uint64_t x = r->s; x ^= x >> 12; x ^
 static inline uint64_t rng_below(rng_t *r, uint64_t n) { return rng_next(r) % n; }
 static inline double rng_unit(rng_t *r) { return (rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
 
-BSX_API int bsx_sim_genome(const char *fasta, int64_t n, uint64_t seed, int n_contigs, double repeat_frac)
+/* the genome as one byte per base (0..3); N runs are decided by the writers below */
+static uint8_t *gen_genome(int64_t n, uint64_t seed, double repeat_frac)
 {
 	rng_t R; uint8_t *g;
 	int64_t i, planted = 0;
-	int c;
-	FILE *fp;
-	if (n < 1000 || n_contigs < 1) return BSX_E_ARG;
 	R.s = seed * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
 	g = (uint8_t*)malloc((size_t)n);
-	if (!g) return BSX_E_NOMEM;
+	if (!g) return 0;
 	for (i = 0; i < n; i += 32) { uint64_t x = rng_next(&R); int k; for (k = 0; k < 32 && i + k < n; ++k) g[i + k] = (uint8_t)((x >> (2 * k)) & 3); }
 	while (planted < (int64_t)(n * repeat_frac)) {
 		int64_t l = 300 + (int64_t)rng_below(&R, 2700), s, d;
@@ -48,12 +46,29 @@ BSX_API int bsx_sim_genome(const char *fasta, int64_t n, uint64_t seed, int n_co
 		int64_t d = (int64_t)rng_below(&R, (uint64_t)(n - (int64_t)ul * reps - 1));
 		for (k = ul; k < ul * reps; ++k) g[d + k] = g[d + k % ul];
 	}
+	return g;
+}
+/* contig c of n_contigs: [*b, *e), with one N run [*nb, *nb + *nl) */
+static void contig_span(int64_t n, int n_contigs, int c, int64_t *b, int64_t *e, int64_t *nb, int64_t *nl)
+{
+	*b = n / n_contigs * c; *e = c == n_contigs - 1 ? n : n / n_contigs * (c + 1);
+	*nb = *b + (*e - *b) / 3; *nl = (*e - *b) / 200 < 1000 ? (*e - *b) / 200 : 1000;
+}
+
+BSX_API int bsx_sim_genome(const char *fasta, int64_t n, uint64_t seed, int n_contigs, double repeat_frac)
+{
+	uint8_t *g;
+	int64_t i;
+	int c;
+	FILE *fp;
+	if (n < 1000 || n_contigs < 1) return BSX_E_ARG;
+	if ((g = gen_genome(n, seed, repeat_frac)) == 0) return BSX_E_NOMEM;
 	if ((fp = fopen(fasta, "wb")) == 0) { free(g); return BSX_E_IO; }
 	for (c = 0; c < n_contigs; ++c) {
-		int64_t b = n / n_contigs * c, e = c == n_contigs - 1 ? n : n / n_contigs * (c + 1), nb, nl;
+		int64_t b, e, nb, nl;
 		char line[64];
+		contig_span(n, n_contigs, c, &b, &e, &nb, &nl);
 		fprintf(fp, ">chr%d\n", c + 1);
-		nb = b + (e - b) / 3; nl = (e - b) / 200 < 1000 ? (e - b) / 200 : 1000;   /* one N run */
 		for (i = b; i < e; i += 60) {
 			int k, m = (int)(e - i < 60 ? e - i : 60);
 			for (k = 0; k < m; ++k) line[k] = (i + k >= nb && i + k < nb + nl) ? 'N' : "ACGT"[g[i + k]];
@@ -64,6 +79,39 @@ BSX_API int bsx_sim_genome(const char *fasta, int64_t n, uint64_t seed, int n_co
 	fclose(fp);
 	free(g);
 	return BSX_OK;
+}
+
+/* the same genome handed straight to the index builder's sink: an index with pac + annotation and no FM indices yet
+ * (bsx_index_build_host / bsx_device_build_index make those).  What bsx_sim_genome + bsx_index_from_fasta give, without
+ * the FASTA text: a 3.1 Gbp genome is 0.78 GB this way. */
+BSX_API int bsx_sim_genome_index(int64_t n, uint64_t seed, int n_contigs, double repeat_frac, bsx_index_t **out)
+{
+	uint8_t *g;
+	bsx_gsink_t *S;
+	int64_t i;
+	int c, rc = BSX_OK;
+	char *buf;
+	*out = 0;
+	if (n < 1000 || n_contigs < 1) return BSX_E_ARG;
+	if ((g = gen_genome(n, seed, repeat_frac)) == 0) return BSX_E_NOMEM;
+	buf = (char*)malloc(1 << 20);
+	S = bsx_gsink_new();
+	for (c = 0; c < n_contigs && rc == BSX_OK; ++c) {
+		int64_t b, e, nb, nl;
+		char nm[32];
+		contig_span(n, n_contigs, c, &b, &e, &nb, &nl);
+		snprintf(nm, sizeof(nm), "chr%d", c + 1);
+		bsx_gsink_contig(S, nm, 0);
+		for (i = b; i < e && rc == BSX_OK; i += 1 << 20) {
+			int64_t k, m = e - i < (1 << 20) ? e - i : (1 << 20);
+			for (k = 0; k < m; ++k) buf[k] = (i + k >= nb && i + k < nb + nl) ? 'N' : "ACGT"[g[i + k]];
+			rc = bsx_gsink_bases(S, buf, m);
+		}
+	}
+	free(buf); free(g);
+	*out = bsx_gsink_finish(S);
+	if (rc != BSX_OK) { bsx_index_free(*out); *out = 0; }
+	return rc;
 }
 
 /* n_pairs read pairs as an interleaved bsx_read_t array (caller frees with bsx_sim_free_reads) */

@@ -207,8 +207,14 @@ typedef struct bsx_glb_res {
 typedef struct bsx_index bsx_index_t;
 int  bsx_index_load(const char *base, bsx_index_t **out);
 void bsx_index_free(bsx_index_t *idx);
-/* builds all seven files from a FASTA: main_biscuit_index (lib/aln/bwtindex.c:206-347) */
+/* builds all seven files from a FASTA: main_biscuit_index (lib/aln/bwtindex.c:206-347); host suffix sorter, genomes up
+ * to 1.07 Gbp (2 x l_pac < 2^31).  In steps: bsx_index_from_fasta (bis_bns_fasta2bntseq, lib/aln/bntseq.c:542-633: pac +
+ * annotation), then the two FM indices on the host (bsx_index_build_host) or, for genomes of any size, on the device
+ * (bsx_device_build_index below: what bwt_bwtgen, lib/aln/bwt_gen.c:1595-1607, is for in the reference), then bsx_index_save. */
 int  bsx_index_build(const char *fasta, const char *base);
+int  bsx_index_from_fasta(const char *fasta, bsx_index_t **out);
+int  bsx_index_build_host(bsx_index_t *idx);
+int  bsx_index_save(const bsx_index_t *idx, const char *base);
 int64_t bsx_index_l_pac(const bsx_index_t *idx);
 int  bsx_index_n_seqs(const bsx_index_t *idx);
 
@@ -225,6 +231,12 @@ int  bsx_device_open(int ordinal, bsx_device_t **out);
 void bsx_device_close(bsx_device_t *dev);
 /* copy both FM indices, SA samples and pac into HBM (resident for the life of dev) */
 int  bsx_device_upload_index(bsx_device_t *dev, const bsx_index_t *idx);
+/* Build both FM indices (BWT with occurrence blocks + suffix-array samples) of idx's genome on the device, from its pac,
+ * and leave them resident exactly as bsx_device_upload_index would: 64-bit suffix sorting in HBM, hg38-sized genomes
+ * included (bwt_bwtgen + bwt_bwtupdate_core + bwt_cal_sa, lib/aln/bwtindex.c:258-340).  fill_host != 0 also copies the
+ * file-format arrays into idx (for bsx_index_save and for host-side consumers); they are byte-identical to the host
+ * builder's and the reference's. */
+int  bsx_device_build_index(bsx_device_t *dev, bsx_index_t *idx, int fill_host);
 /* copy scoring matrices / penalties used by the DP kernels */
 int  bsx_device_set_opt(bsx_device_t *dev, const bsx_opt_t *opt);
 /* upload the chunk read buffer (nt4 codes of all clipped reads, concatenated) */
