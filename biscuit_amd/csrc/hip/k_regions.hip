@@ -932,6 +932,11 @@ k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_den
 					for (unsigned long long k = 0; k < x2; ++k) desc[j++] = (x0 + k) | par;
 				}
 				off = (long long)base;
+			} else {
+				// no room: the strand search is chained with inline LF walks instead (pos_off = -1).  k_occ still visits every slot up to
+				// min(cursor, cap): what this task reserved of them is given rank 0, where a walk ends at once, instead of whatever an earlier
+				// chunk left there
+				for (unsigned long long j = base; j < desc_cap && j < base + tot; ++j) desc[j] = 0;
 			}
 		}
 	}

@@ -521,7 +521,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.regmeta.reserve((size_t)n * 24 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
-	const unsigned long long pos_cap = (unsigned long long)n * 128 + (1u << 20);   // one u64 per seed occurrence of the chunk
+	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
+	// copies there), a few dozen against small ones.  $BSX_POS_CAP (tests): a cap small enough for strand searches to find no room.
+	const unsigned long long pos_cap = getenv("BSX_POS_CAP") ? strtoull(getenv("BSX_POS_CAP"), 0, 10) : (unsigned long long)n * 384 + (1u << 20);
 	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
 	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;

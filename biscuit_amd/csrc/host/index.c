@@ -214,6 +214,13 @@ BSX_API void bsx_index_free(bsx_index_t *idx)
 
 BSX_API int64_t bsx_index_l_pac(const bsx_index_t *idx) { return idx->ref.l_pac; }
 BSX_API int bsx_index_n_seqs(const bsx_index_t *idx) { return idx->ref.n_seqs; }
+BSX_API const uint8_t *bsx_index_pac(const bsx_index_t *idx) { return idx->pac; }
+BSX_API int bsx_index_contig(const bsx_index_t *idx, int i, const char **name, int64_t *offset, int64_t *len)
+{
+	if (!idx || i < 0 || i >= idx->ref.n_seqs) return BSX_E_ARG;
+	*name = idx->ref.anns[i].name; *offset = idx->ref.anns[i].offset; *len = idx->ref.anns[i].len;
+	return BSX_OK;
+}
 
 /* ------------------------------------------------------------------------------------------
  * SA-IS (induced sorting).  s has n symbols, s[n-1] is a unique smallest sentinel.

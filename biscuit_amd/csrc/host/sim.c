@@ -115,8 +115,16 @@ BSX_API int bsx_sim_genome_index(int64_t n, uint64_t seed, int n_contigs, double
 }
 
 /* n_pairs read pairs as an interleaved bsx_read_t array (caller frees with bsx_sim_free_reads) */
+BSX_API int bsx_sim_pairs_truth(const bsx_index_t *idx, int64_t n_pairs, int read_len, uint64_t seed, int frag_lo, int frag_hi,
+                                double sub_rate, double pbat_frac, bsx_read_t **out, int64_t *truth);
 BSX_API int bsx_sim_pairs(const bsx_index_t *idx, int64_t n_pairs, int read_len, uint64_t seed, int frag_lo, int frag_hi,
                           double sub_rate, double pbat_frac, bsx_read_t **out)
+{
+	return bsx_sim_pairs_truth(idx, n_pairs, read_len, seed, frag_lo, frag_hi, sub_rate, pbat_frac, out, 0);
+}
+/* truth (optional, 2 per pair): forward-strand start of the fragment, fragment length << 1 | taken from the reverse strand */
+BSX_API int bsx_sim_pairs_truth(const bsx_index_t *idx, int64_t n_pairs, int read_len, uint64_t seed, int frag_lo, int frag_hi,
+                                double sub_rate, double pbat_frac, bsx_read_t **out, int64_t *truth)
 {
 	rng_t R;
 	int64_t l_pac = idx->ref.l_pac, p;
@@ -135,6 +143,7 @@ BSX_API int bsx_sim_pairs(const bsx_index_t *idx, int64_t n_pairs, int read_len,
 		int rid = bsx_pos2rid(&idx->ref, s);
 		if (bsx_pos2rid(&idx->ref, s + fl - 1) != rid) { --p; continue; }   /* fragment inside one contig */
 		rev = (int)(rng_next(&R) & 1);
+		if (truth) { truth[p * 2] = s; truth[p * 2 + 1] = (int64_t)fl << 1 | rev; }
 		for (i = 0; i < fl; ++i) frag[i] = rev ? (uint8_t)(3 - bsx_pac_get(idx->pac, s + fl - 1 - i)) : (uint8_t)bsx_pac_get(idx->pac, s + i);
 		for (i = 0; i < fl; ++i) { /* bisulfite conversion of the fragment's top strand */
 			if (frag[i] == 1) {

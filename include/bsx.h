@@ -217,6 +217,8 @@ int  bsx_index_build_host(bsx_index_t *idx);
 int  bsx_index_save(const bsx_index_t *idx, const char *base);
 int64_t bsx_index_l_pac(const bsx_index_t *idx);
 int  bsx_index_n_seqs(const bsx_index_t *idx);
+const uint8_t *bsx_index_pac(const bsx_index_t *idx);    /* 2 bits per base, the .bis.pac layout */
+int  bsx_index_contig(const bsx_index_t *idx, int i, const char **name, int64_t *offset, int64_t *len);
 
 /* options: mem_opt_init (lib/aln/bwamem.c:77-128) + the three matrices (lib/aln/bwa.c:146-182) */
 void bsx_opt_init(bsx_opt_t *opt);

@@ -69,6 +69,15 @@ def test_sam_identical(data, name, args):
         assert len(gl) == len(wl)
 
 
+def test_occurrence_table_overflow(data):
+    """strand searches that find no room in the chunk-wide occurrence table (k_occ_expand) walk the suffix array inline
+    instead; the slots they reserved must not be read as ranks.  Same SAM as with room for everything."""
+    args = CASES[1][1]
+    want = run(HIP, args, data)
+    for cap in ("0", "5000", "60000"):
+        assert run(HIP, args, data, env={"BSX_POS_CAP": cap}) == want, cap
+
+
 def _on_device(stderr):
     import re
     m = re.findall(r"\[M::regions\] on device (\d+) \| declined: (.*)", stderr)

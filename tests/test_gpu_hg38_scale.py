@@ -1,0 +1,199 @@
+"""-m gpu: BASELINE configs[1] at its real size -- an hg38-sized genome (3.1 Gbp, SYNTHETIC: hg38 is not available
+offline; SURVEY 8(d) config 2 fallback) whose two FM indices (6.2 G symbols each) are built on the device.  Suffix-array
+ranks and forward-reverse coordinates exceed 2^32 here, which no smaller genome exercises:
+  * the index itself: adjacent suffixes are in lexicographic order (checked on the text, independently of any FM code),
+    LF steps agree with the suffix array, counts add up;
+  * K1-K3 on the device == the CPU restatement at ranks/positions > 2^32;
+  * the whole path: SAM of the HIP pipeline == SAM of the CPU restatement byte for byte on a sample of pairs, records
+    valid against the genome, reads found where they were simulated from (including reverse-strand hits whose
+    forward-reverse coordinates are > 2^32).
+Set BSX_TEST_GENOME_MBP to run the same checks on a smaller genome."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import samcheck
+import simdata
+from biscuit_amd import _lib as B
+from biscuit_amd.api import Index, Device, default_opt, SEED_DT, SA_DT
+
+pytestmark = pytest.mark.gpu
+MBP = float(os.environ.get("BSX_TEST_GENOME_MBP", "3100"))
+
+
+class PacContig:
+    """str-like view of one contig of the packed genome (what samcheck indexes and slices)"""
+
+    def __init__(self, pac, off, n):
+        self.pac, self.off, self.n = pac, off, n
+
+    def __len__(self):
+        return self.n
+
+    def _codes(self, a, b):
+        i = np.arange(self.off + a, self.off + b, dtype=np.int64)
+        return (self.pac[i >> 2] >> ((~i & 3) << 1)) & 3
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            a, b, _ = k.indices(self.n)
+            return simdata.BASES[self._codes(a, b)].tobytes().decode()
+        return "ACGT"[int(self._codes(k, k + 1)[0])]
+
+
+@pytest.fixture(scope="module")
+def big():
+    L = B.lib()
+    n = int(MBP * 1e6)
+    idx = Index.synthetic(n, seed=2024, n_contigs=24 if n >= 1_000_000_000 else 8)
+    dev = Device(0)
+    dev.build_index(idx, fill_host=True)
+    L.bsx_index_pac.restype = C.POINTER(C.c_uint8)
+    L.bsx_index_pac.argtypes = [C.c_void_p]
+    pac = np.ctypeslib.as_array(L.bsx_index_pac(idx.h), shape=(idx.l_pac // 4 + 1,))
+    L.bsx_index_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.bsx_index_n_seqs.argtypes = [C.c_void_p]
+    contigs = []
+    for i in range(L.bsx_index_n_seqs(idx.h)):
+        nm, off, ln = C.c_char_p(), C.c_int64(), C.c_int64()
+        B.check(L.bsx_index_contig(idx.h, i, C.byref(nm), C.byref(off), C.byref(ln)), "contig")
+        contigs.append((nm.value.decode(), off.value, ln.value))
+    import oracle_lib
+    port = oracle_lib.Port(idx, n_threads=16)
+    yield dict(idx=idx, dev=dev, pac=pac, contigs=contigs, port=port, l_pac=idx.l_pac)
+    dev.close()
+    idx.close()
+
+
+def _text(pac, l_pac, parent, pos, n):
+    """n symbols of the converted text [fwd ; revcomp(fwd)] from pos"""
+    i = np.arange(pos, min(pos + n, 2 * l_pac), dtype=np.int64)
+    f = np.where(i < l_pac, i, 2 * l_pac - 1 - i)
+    b = (pac[f >> 2] >> ((~f & 3) << 1)) & 3
+    b = np.where(i < l_pac, b, 3 - b)
+    return np.where(b == 1, 3, b) if parent else np.where(b == 2, 0, b)
+
+
+def test_index_sorted_and_consistent(big):
+    dev, port, pac, l_pac = big["dev"], big["port"], big["pac"], big["l_pac"]
+    n = 2 * l_pac
+    rng = np.random.default_rng(1)
+    for parent in (1, 0):
+        k = rng.integers(1, n, 3000).astype(np.uint64)   # ranks up to 6.2e9 (> 2^32 when the genome is hg38-sized)
+        if n > 1 << 32:
+            k[:1000] = rng.integers(1 << 32, n, 1000).astype(np.uint64)
+        jobs = np.zeros(2 * len(k), dtype=SA_DT)
+        jobs["k"] = np.concatenate([k, k + 1]); jobs["parent"] = parent
+        pos = dev.sa(jobs)
+        assert (pos == port.sa(jobs)).all()                # device LF walk + dense sample == host walk over the file-format arrays
+        assert (pos < n).all()
+        a, b = pos[:len(k)], pos[len(k):]
+        for x, y in zip(a, b):                             # suffix of rank k < suffix of rank k+1, compared on the text itself
+            tx, ty = _text(pac, l_pac, parent, int(x), 4000), _text(pac, l_pac, parent, int(y), 4000)
+            m = min(len(tx), len(ty))
+            d = np.nonzero(tx[:m] != ty[:m])[0]
+            if len(d):
+                assert tx[d[0]] < ty[d[0]], (parent, int(x), int(y))
+            else:
+                assert len(tx) < len(ty) or m == 4000
+
+
+def _reads_at(big, starts, rev, read_len=150):
+    """bisulfite reads (directional R1-like) from given forward starts / strands: exercises chosen coordinates"""
+    pac, l_pac = big["pac"], big["l_pac"]
+    rng = np.random.default_rng(7)
+    seqs = []
+    for s, r in zip(starts, rev):
+        i = np.arange(s, s + read_len, dtype=np.int64)
+        g = ((pac[i >> 2] >> ((~i & 3) << 1)) & 3).astype(np.uint8)
+        if r:
+            g = (3 - g[::-1]).astype(np.uint8)
+        c = g == 1
+        g[c & (rng.random(read_len) > 0.2)] = 3
+        seqs.append(g)
+    return seqs
+
+
+def test_seed_and_sa_beyond_2_32(big):
+    dev, port, l_pac = big["dev"], big["port"], big["l_pac"]
+    opt = default_opt()
+    rng = np.random.default_rng(3)
+    # reads from the first tenth of the genome on the reverse strand: forward-reverse coordinates near 2*l_pac (> 2^32)
+    starts = rng.integers(1000, l_pac // 10, 600)
+    seqs = _reads_at(big, starts, [True] * 300 + [False] * 300)
+    buf, offs = simdata.read_buffer(seqs)
+    tasks = np.zeros(2 * len(seqs), dtype=SEED_DT)
+    for i, s in enumerate(seqs):
+        for p in (0, 1):
+            tasks[2 * i + p] = (offs[i], len(s), p)
+    for be in (port, dev):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    pi, po = port.seed(opt, tasks)
+    di, do = dev.seed(opt, tasks)
+    assert (po == do).all() and pi.shape == di.shape and (pi == di).all()
+    assert int(po[-1]) > len(tasks)
+    if 2 * l_pac > 1 << 32:
+        assert (pi[:, 0] > (1 << 32)).any() and (pi[:, 1] > (1 << 32)).any()   # ranks beyond 32 bits were really used
+    jobs = []
+    for t in range(len(tasks)):
+        for k in range(po[t], po[t + 1]):
+            x0, _, x2, _ = [int(v) for v in pi[k]]
+            for j in range(min(x2, 20)):
+                jobs.append((x0 + j, int(tasks[t]["parent"]), 0))
+    jobs = np.array(jobs, dtype=SA_DT)
+    pp, dp = port.sa(jobs), dev.sa(jobs)
+    assert (pp == dp).all()
+    if 2 * l_pac > 1 << 32:
+        assert (pp > (1 << 32)).any()
+
+
+def test_sam_identical_and_where_simulated(big):
+    L = B.lib()
+    idx, dev, port = big["idx"], big["dev"], big["port"]
+    n_pairs = 20000
+    opt = default_opt()
+    opt.n_threads = 16
+    opt.flag |= 0x10 | 0x2
+    L.bsx_sim_pairs_truth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p), C.c_void_p]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    truth = np.zeros(2 * n_pairs, dtype=np.int64)
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs_truth(idx.h, n_pairs, 150, 4242, 200, 500, 0.005, 0.1, C.byref(p), truth.ctypes.data_as(C.c_void_p)), "sim_pairs")
+    n = 2 * n_pairs
+    r = C.cast(p, C.POINTER(B.Read))
+    try:
+        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, n, p, None), "process_seqs")
+        hip = [C.string_at(r[i].sam) for i in range(n)]
+        L.bsx_sim_reset_reads(p, n)
+        be = port.backend()
+        os.environ["BSX_HOST_THREADS"] = "16"
+        B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(opt), idx.h, 0, n, p, None), "process_seqs(cpu restatement)")
+        cpu = [C.string_at(r[i].sam) for i in range(n)]
+        bad = [i for i in range(n) if hip[i] != cpu[i]]
+        assert not bad, "SAM differs for %d reads, first: %r vs %r" % (len(bad), hip[bad[0]], cpu[bad[0]])
+        genome = {nm: PacContig(big["pac"], off, ln) for nm, off, ln in big["contigs"]}
+        ctg_off = {nm: off for nm, off, ln in big["contigs"]}
+        hdr, recs = samcheck.parse_sam(b"".join(hip[:8000]).decode())
+        for rec in recs:
+            samcheck.check_record(rec, genome, 150)
+        samcheck.check_pairs(recs)
+        prim = [x for x in recs if not x["flag"] & 0x900]
+        assert len(prim) == 8000
+        assert np.mean([not x["flag"] & 4 for x in prim]) > 0.97
+        # where they were simulated from: primary records of confidently mapped reads lie inside their fragment
+        ok = tot = 0
+        for x in prim:
+            if x["flag"] & 4 or x["mapq"] < 30:
+                continue
+            pi = int(x["qname"][1:])
+            s, fl = int(truth[2 * pi]), int(truth[2 * pi + 1]) >> 1
+            g = ctg_off[x["rname"]] + x["pos"] - 1
+            tot += 1
+            ok += s - 10 <= g <= s + fl + 10
+        assert tot > 6000 and ok / tot > 0.995, (ok, tot)
+    finally:
+        L.bsx_sim_free_reads(p, n)
