@@ -43,6 +43,7 @@ struct RegParams {
 	int32_t min_seed_len, min_chain_weight, max_chain_gap, max_occ, bsstrand;
 	uint32_t max_chain_extend;
 	float mask_level, drop_ratio;
+	int32_t prof;          // count wave cycles per stage (tracing only: the counters are contended atomics)
 };
 
 struct DevScoring {        // set by bsx_device_set_opt

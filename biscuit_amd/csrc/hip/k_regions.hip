@@ -21,10 +21,12 @@
 #define RG_QCAP 256
 #define RG_NC 4          // extension rows live in registers: 64 * RG_NC entries >= qlen + 1
 
-struct RgChain {         // mem_chain_t reduced to what chaining and the filter read: first seed = (pos, first_q), last seed
+struct RgChain {         // mem_chain_t reduced to what chaining, the filter and the region loop read: first seed = (pos, first_q), last seed,
+                         // and mem_chain_weight's two running sums (query and reference coverage) with their high-water marks
 	long long pos, last_r;
-	int rid, w;
-	short first_q, last_q, last_len, first;
+	int rid, endr_off;                                        // endr_off: end of the reference coverage so far, relative to pos
+	short first_q, last_q, last_len, wq, wr, endq, first, w;  // w = min(wq, wr) once chaining is over; first: mem_chain_flt's
+	unsigned short n_seeds, seed0;                            // seeds on the main list (not seeds_extra), and the first of them
 	signed char kept; unsigned char is_alt, has_extra, pad;
 };
 
@@ -56,8 +58,9 @@ struct RgStore {
 	RgNode node[NODES_ ? NODES_ : 1];
 	int n_nodes, root;
 };
-typedef RgStore<64, 96, 96, 12, 0, unsigned char, signed char> RgSmall;
-typedef RgStore<96, 192, 192, 16, 0, unsigned char, short> RgMid;               // still LDS: 16 KB per wave, two waves per workgroup
+typedef RgStore<64, 96, 96, 16, 0, unsigned char, signed char> RgSmall;
+typedef RgStore<128, 256, 256, 24, 0, unsigned char, short> RgMid;              // still LDS: 24 KB per wave, two waves per workgroup: the
+                                                                                // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 struct RgDp { int32_t H[64], E[64]; };   // per-wave LDS scratch of the one-lane passes (introsort stack, tree traversal stack)
@@ -321,6 +324,10 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
 	const uint8_t *query = reads + qoff;
+	// per-stage wave cycles into counters[32 + stage] (P.prof, set under $BSX_PHASES): where a strand search's time goes
+	long long pf_t = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+	unsigned int pf_ext = 0, pf_rows = 0;
+#define RG_STAGE(k) do { if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + (k)], (unsigned long long)(now_ - pf_t)); pf_t = now_; } } while (0)
 	if (lane == 0) {
 		S.n_chains = 0; S.n_regs = 0;
 		if (Store::NODES) { S.n_nodes = 0; S.root = rg_bt_alloc(S, 0); }
@@ -352,24 +359,18 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
 			if (lane >= off) incl += o;
 		}
-		// the HBM tiers hold thousands of intervals (reads inside tandem repeats): there the other keys come 64 at a time with one
-		// coalesced load and are handed round with v_readlane, instead of n_iv uniform loads per group of 64
-		int big_rank = 0;
-		if (Store::SCAP > 128) {
-			for (int cb = 0; cb < n_iv; cb += 64) {
-				const int kk = cb + lane;
-				const unsigned long long oinfo = kk < n_iv ? src[kk].info : ~0ull;
-				const int lim = n_iv - cb < 64 ? n_iv - cb : 64;
-				for (int j = 0; j < lim; ++j) {
-					const unsigned long long oi = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(oinfo >> 32), j) << 32 | (unsigned)__builtin_amdgcn_readlane((int)oinfo, j);
-					big_rank += (oi < mine.info) || (oi == mine.info && cb + j < i);
-				}
+		// the other keys come 64 at a time with one coalesced load and are handed round with v_readlane
+		int rank = 0;
+		for (int cb = 0; cb < n_iv; cb += 64) {
+			const int kk = cb + lane;
+			const unsigned long long oinfo = kk < n_iv ? src[kk].info : ~0ull;
+			const int lim = n_iv - cb < 64 ? n_iv - cb : 64;
+			for (int j = 0; j < lim; ++j) {
+				const unsigned long long oi = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(oinfo >> 32), j) << 32 | (unsigned)__builtin_amdgcn_readlane((int)oinfo, j);
+				rank += (oi < mine.info) || (oi == mine.info && cb + j < i);
 			}
 		}
 		if (i < n_iv) {
-			int rank = 0;
-			if (Store::SCAP <= 128) for (int k = 0; k < n_iv; ++k) { const unsigned long long oi = src[k].info; rank += (oi < mine.info) || (oi == mine.info && k < i); }
-			else rank = big_rank;
 			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - cnt) : mine.x0;
 			S.iv_n[rank] = cnt | big << 30;
 			S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
@@ -377,9 +378,18 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		run += uni64((long long)((unsigned long long)(unsigned)__shfl((int)(incl >> 32), 63) << 32 | (unsigned)__shfl((int)incl, 63)));
 	}
 	WAVE_SYNC();
+	RG_STAGE(0);
 	// ---- B. occurrences: every k < x[2] of every interval (the caps of memchain.c:325-326 cannot bind while x[2] <= max_occ)
 	int tot = 0, over = 0, any_big = 0;
-	for (int i = 0; i < n_iv; ++i) { const int c = uni(S.iv_n[i]) & 0x3fffffff; any_big |= uni(S.iv_n[i]) >> 30; if (c > Store::SCAP) over = 1; tot += c > Store::SCAP ? Store::SCAP : c; }
+	for (int base = 0; base < n_iv; base += 64) { // totals with one pass over the table, 64 intervals at a time
+		const int i = base + lane;
+		const int v = i < n_iv ? S.iv_n[i] : 0;
+		const int c = v & 0x3fffffff;
+		if (__ballot(c > Store::SCAP)) over = 1;
+		if (__ballot(v >> 30)) any_big = 1;
+		tot += wave_sum_i32(c > Store::SCAP ? Store::SCAP : c);
+		if (tot > Store::SCAP) { over = 1; break; }
+	}
 	if (over || tot > Store::SCAP) return 2;
 	float frac_rep = 0.f;
 	if (any_big) { // read length covered by over-represented seeds (memchain.c:294-301)
@@ -395,7 +405,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	{
 		int i = 0, acc = 0;   // occurrences are visited in increasing order by each lane: the interval cursor only moves forward
 		uint32_t lf = 0;
-		if (Store::SCAP > 128 && n_iv > 256) { // thousands of intervals with a few occurrences each: a lane per interval, 64 intervals at a time
+		if (Store::SCAP > 256 && n_iv > 256) { // thousands of intervals with a few occurrences each: a lane per interval, 64 intervals at a time
 			int run_o = 0;
 			for (int base = 0; base < n_iv; base += 64) {
 				const int ii = base + lane;
@@ -429,7 +439,26 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		if (lane == 0 && !posl) { atomicAdd(&counters[2], (unsigned long long)lf); atomicAdd(&counters[3], (unsigned long long)tot); }
 	}
 	WAVE_SYNC();
+	// asymmetric_flt_seed (memchain.c:138-149) for every seed at once, a lane per seed: a reference T under a read C or a reference A
+	// under a read G.  Bit 1 of s_extra; the seed loop of stage E only tests the bit (one dependent trip to HBM per seed there
+	// was a quarter of this kernel's time on a genome where most seeds are chance matches).
+	for (int o = lane; o < tot; o += 64) {
+		if (S.s_rid[o] < 0) continue;
+		const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
+		int bad = 0;
+		for (int i = 0; i < ln; ++i) { const int r = dev_ref_base(ix.pac, l_pac, rb + i), q = query[qb + i]; bad |= (r == 3 && q == 1) || (r == 0 && q == 2); }
+		if (bad) S.s_extra[o] = 2;
+	}
+	WAVE_SYNC();
+	RG_STAGE(1);
 	// ---- C. chaining in arrival order (mem_chain's loop over occurrences, memchain.c:313-366)
+	// Without the B-tree (LDS tiers): the chain starts live sorted across the wave's registers, entry e in lane e & 63 of register set
+	// e >> 6.  kb_intervalp's `lower` (the largest start <= rbeg) is a compare, a ballot and a population count per register set; a
+	// new chain shifts the entries above it up one lane (DPP).  Unique starts make the sorted order the tree's in-order traversal.
+	constexpr int NR = Store::NODES ? 1 : (Store::CCAP + 63) / 64;
+	unsigned int st_lo[NR], st_hi[NR]; int st_id[NR];
+#pragma unroll
+	for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
 	int nc = 0;
 	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
 	for (int o = 0; o < tot; ++o) {
@@ -442,33 +471,53 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
 		}
 		const int rid = uni(S.s_rid[o]);
+		if (rid < 0) continue;
 		const long long rbeg = uni64(S.s_rbeg[o]);
 		const int qbeg = uni(S.s_qbeg[o]), len = uni(S.s_len[o]);
-		if (rid < 0) continue;
 		if ((P.bsstrand & 1) && RG_BSS(parent, l_pac, rbeg) != P.bsstrand >> 1) continue;
-		// kb_intervalp's `lower`: the chain with the largest start <= rbeg (starts are unique here); lanes scan the chain table
-		long long best = -1;
-		int lower = -1;
+		int lower = -1, at = 0;   // at: sorted index the new chain would take
+		bool tied = false;
 		if (Store::NODES) {
 			if (lane == 0 && nc > 0) lower = rg_bt_lower(S, rbeg);
 			lower = uni(__shfl(lower, 0));
 		} else {
-			long long mybest = -1; int myc = -1;
-			for (int c = lane; c < nc; c += 64) { const long long p = S.ch[c].pos; if (p <= rbeg && p > mybest) { mybest = p; myc = c; } }
-			best = uni64(wave_max_i64(mybest));
-			if (best >= 0) { const unsigned long long b = __ballot(mybest == best); lower = uni(__shfl(myc, __ffsll((long long)b) - 1)); }
+			const unsigned int rlo = (unsigned int)rbeg, rhi = (unsigned int)((unsigned long long)rbeg >> 32);
+#pragma unroll
+			for (int r = 0; r < NR; ++r)
+				if (r * 64 < nc) at += __popcll(__ballot(st_hi[r] < rhi || (st_hi[r] == rhi && st_lo[r] <= rlo)));
+			if (at > 0) {
+				const int e = at - 1, el = e & 63;
+				unsigned int plo = 0, phi = 0;
+#pragma unroll
+				for (int r = 0; r < NR; ++r)
+					if (r == e >> 6) { lower = __builtin_amdgcn_readlane(st_id[r], el); plo = (unsigned int)__builtin_amdgcn_readlane((int)st_lo[r], el); phi = (unsigned int)__builtin_amdgcn_readlane((int)st_hi[r], el); }
+				tied = plo == rlo && phi == rhi;
+			}
 		}
 		int merged = 0;
 		if (lower >= 0) { // merge_seed_to_chain, memchain.c:227-256
 			const RgChain c = S.ch[lower];
 			if (rid == c.rid) {
 				if (qbeg >= c.first_q && qbeg + len <= c.last_q + c.last_len && rbeg >= c.pos && rbeg + len <= c.last_r + c.last_len) {
-					if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.s_extra[o] = 1; S.ch[lower].has_extra = 1; }
+					if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.s_extra[o] |= 1; S.ch[lower].has_extra = 1; }
 					merged = 1;
 				} else if (!((c.last_r < l_pac || c.pos < l_pac) && rbeg >= l_pac)) {
 					const long long qdist = qbeg - c.last_q, rdist = rbeg - c.last_r;
 					if (rdist >= 0 && qdist - rdist <= P.w && rdist - qdist <= P.w && qdist - c.last_len < P.max_chain_gap && rdist - c.last_len < P.max_chain_gap) {
-						if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.ch[lower].last_q = (short)qbeg; S.ch[lower].last_r = rbeg; S.ch[lower].last_len = (short)len; }
+						if (lane == 0) {
+							RgChain &d = S.ch[lower];
+							S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower;
+							d.last_q = (short)qbeg; d.last_r = rbeg; d.last_len = (short)len;
+							// mem_chain_weight (memchain.c:158-180) as a running sum: seeds join a chain in the order that loop visits them
+							int wq = c.wq, wr = c.wr;
+							if (qbeg >= c.endq) wq += len; else if (qbeg + len > c.endq) wq += qbeg + len - c.endq;
+							const long long endr = c.pos + c.endr_off;
+							if (rbeg >= endr) wr += len; else if (rbeg + len > endr) wr += (int)(rbeg + len - endr);
+							d.wq = (short)wq; d.wr = (short)(wr < 32767 ? wr : 32767);   // only min(wq, wr) is read, and wq <= read length
+							if (qbeg + len > c.endq) d.endq = (short)(qbeg + len);
+							if (rbeg + len > endr) d.endr_off = (int)(rbeg + len - c.pos);
+							d.n_seeds = (unsigned short)(c.n_seeds + 1);
+						}
 						merged = 1;
 					}
 				}
@@ -477,47 +526,50 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 		if (!merged) {
 			if (nc == Store::CCAP) return 3;
-			if (!Store::NODES && best == rbeg) return 4;   // duplicate key: the B-tree shape matters, the second tier keeps one
+			if (!Store::NODES && tied) return 4;   // duplicate key: the B-tree shape matters, the HBM tiers keep one
 			if (lane == 0) {
 				RgChain c;
-				c.pos = c.last_r = rbeg; c.rid = rid; c.w = 0; c.first_q = c.last_q = (short)qbeg; c.last_len = (short)len; c.first = -1;
+				c.pos = c.last_r = rbeg; c.rid = rid; c.endr_off = len; c.first_q = c.last_q = (short)qbeg; c.last_len = (short)len;
+				c.wq = c.wr = (short)len; c.endq = (short)(qbeg + len); c.first = -1; c.w = 0; c.n_seeds = 1; c.seed0 = (unsigned short)o;
 				c.kept = 0; c.is_alt = ix.ctg_alt[rid] ? 1 : 0; c.has_extra = 0; c.pad = 0;
 				S.ch[nc] = c;
 				S.s_chain[o] = (decltype(S.s_chain[0] + 0))nc;
 				if (Store::NODES) rg_bt_put(S, rbeg, nc);
+			}
+			if (!Store::NODES) { // open slot `at` of the sorted table
+				const int ar = at >> 6, al = at & 63;
+#pragma unroll
+				for (int r = NR - 1; r >= 0; --r) {
+					if (r >= ar && r * 64 <= nc) {
+						const unsigned int e_lo = r > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)st_lo[r > 0 ? r - 1 : 0], 63) : 0u;
+						const unsigned int e_hi = r > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)st_hi[r > 0 ? r - 1 : 0], 63) : 0u;
+						const int e_id = r > 0 ? __builtin_amdgcn_readlane(st_id[r > 0 ? r - 1 : 0], 63) : 0;
+						const unsigned int s_lo = (unsigned int)wave_prev((int)st_lo[r], (int)e_lo), s_hi = (unsigned int)wave_prev((int)st_hi[r], (int)e_hi);
+						const int s_id = wave_prev(st_id[r], e_id);
+						const bool keep = r == ar && lane < al, put = r == ar && lane == al;
+						st_lo[r] = keep ? st_lo[r] : put ? (unsigned int)rbeg : s_lo;
+						st_hi[r] = keep ? st_hi[r] : put ? (unsigned int)((unsigned long long)rbeg >> 32) : s_hi;
+						st_id[r] = keep ? st_id[r] : put ? nc : s_id;
+					}
+				}
 			}
 			++nc; ++count;
 		}
 		WAVE_SYNC();
 	}
 	if (iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
+	RG_STAGE(2);
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
-		for (int c = lane; c < nc; c += 64) { // mem_chain_weight, memchain.c:158-180, one lane per chain
-			long long end = 0; int w = 0, tmp;
-			for (int o = 0; o < tot; ++o) if (S.s_chain[o] == c && !S.s_extra[o]) {
-				const int qb = S.s_qbeg[o], ln = S.s_len[o];
-				if (qb >= end) w += ln; else if (qb + ln > end) w += (int)(qb + ln - end);
-				end = end > qb + ln ? end : qb + ln;
-			}
-			tmp = w; w = 0; end = 0;
-			for (int o = 0; o < tot; ++o) if (S.s_chain[o] == c && !S.s_extra[o]) {
-				const long long rb = S.s_rbeg[o]; const int ln = S.s_len[o];
-				if (rb >= end) w += ln; else if (rb + ln > end) w += (int)(rb + ln - end);
-				end = end > rb + ln ? end : rb + ln;
-			}
-			w = w < tmp ? w : tmp;
-			S.ch[c].w = w < 1 << 30 ? w : (1 << 30) - 1;
-			if (!Store::NODES) {   // unique starts: the in-order traversal of the tree (memchain.c:372-379) is the order by start
-				int r = 0;
-				const long long mypos = S.ch[c].pos;
-				for (int k = 0; k < nc; ++k) r += S.ch[k].pos < mypos;
-				S.ord[r] = (idx_t)c;
-			}
+		for (int c = lane; c < nc; c += 64) { RgChain &d = S.ch[c]; const int w = d.wq < d.wr ? d.wq : d.wr; d.w = (short)w; }
+		if (!Store::NODES) { // the sorted table is the in-order traversal of the tree (memchain.c:372-379)
+#pragma unroll
+			for (int r = 0; r < NR; ++r) if (r * 64 + lane < nc) S.ord[r * 64 + lane] = (idx_t)st_id[r];
 		}
 		WAVE_SYNC();
 		if (Store::NODES && lane == 0) rg_bt_traverse(S, D.E);
 		WAVE_SYNC();
+		RG_STAGE(3);
 		// chains heavy enough, in that order, as sort keys; srt[] is free until stage E: first half keys, second half the kept list
 		unsigned int *keys = (unsigned int*)S.srt, *keepc = keys + Store::SCAP;
 		int n = 0;
@@ -536,44 +588,59 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		WAVE_SYNC();
 		for (int i = lane; i < n; i += 64) S.ord[i] = (idx_t)(keys[i] & ((1u << RG_KEY_BITS) - 1));
 		WAVE_SYNC();
-		if (n > 0 && Store::CCAP <= 128) {
-			// The overlap filter with every chain's four numbers in registers: lane l holds the chains at sorted positions l and
-			// l + 64.  The kept list grows in sorted order, so "the first kept chain that drops chain i" is the lowest lane that says so.
-			int cb[2], ce[2], cw[2], ca[2], kp[2] = {0, 0}, fi[2] = {-1, -1};
+		RG_STAGE(4);
+		if (n > 0 && !Store::NODES) {
+			// The overlap filter with every chain's four numbers in registers: lane l holds the chains at sorted positions l + 64 h.
+			// The kept list grows in sorted order, so "the first kept chain that drops chain i" is the lowest position that says so.
+			constexpr int NH = (Store::CCAP + 63) / 64;
+			int cb[NH], ce[NH], cw[NH], ca[NH], kp[NH], fi[NH];
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
+			for (int h = 0; h < NH; ++h) {
 				const int j = lane + 64 * h;
-				cb[h] = ce[h] = cw[h] = ca[h] = 0;
+				cb[h] = ce[h] = cw[h] = ca[h] = 0; kp[h] = 0; fi[h] = -1;
 				if (j < n) { const RgChain c = S.ch[S.ord[j]]; cb[h] = c.first_q; ce[h] = c.last_q + c.last_len; cw[h] = c.w; ca[h] = c.is_alt; }
 			}
 			if (lane == 0) kp[0] = 3;
 			for (int i = 1; i < n; ++i) {
 				const int sl = i & 63, hi = i >> 6;
-				const int ib = __builtin_amdgcn_readlane(hi ? cb[1] : cb[0], sl), ie = __builtin_amdgcn_readlane(hi ? ce[1] : ce[0], sl);
-				const int iw = __builtin_amdgcn_readlane(hi ? cw[1] : cw[0], sl), ia = __builtin_amdgcn_readlane(hi ? ca[1] : ca[0], sl);
-				int r[2];
+				int ib = 0, ie = 0, iw = 0, ia = 0;
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int j = lane + 64 * h;
-					r[h] = (j < i && kp[h]) ? rg_flt_vals(P, ib, ie, iw, ia, cb[h], ce[h], cw[h], ca[h]) : 0;
+				for (int h = 0; h < NH; ++h) if (h == hi) {
+					ib = __builtin_amdgcn_readlane(cb[h], sl); ie = __builtin_amdgcn_readlane(ce[h], sl);
+					iw = __builtin_amdgcn_readlane(cw[h], sl); ia = __builtin_amdgcn_readlane(ca[h], sl);
 				}
-				const unsigned long long d0 = __ballot(r[0] & 2), d1 = __ballot(r[1] & 2);
-				const int stop = d0 ? __ffsll((long long)d0) - 1 : d1 ? 64 + __ffsll((long long)d1) - 1 : 0x7fffffff;
+				int r[NH];
+				int stop = 0x7fffffff;
+#pragma unroll
+				for (int h = 0; h < NH; ++h) {
+					r[h] = 0;
+					if (h <= hi) { // kept chains sit at positions < i only
+						const int j = lane + 64 * h;
+						r[h] = (j < i && kp[h]) ? rg_flt_vals(P, ib, ie, iw, ia, cb[h], ce[h], cw[h], ca[h]) : 0;
+						const unsigned long long d = __ballot(r[h] & 2);
+						if (d && stop == 0x7fffffff) stop = 64 * h + __ffsll((long long)d) - 1;
+					}
+				}
 				int large = 0;
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int j = lane + 64 * h;
-					const int hit = (r[h] & 1) && j <= stop;
-					if (hit && fi[h] < 0) fi[h] = i;
-					if (__ballot(hit)) large = 1;
+				for (int h = 0; h < NH; ++h) {
+					if (h <= hi) {
+						const int j = lane + 64 * h;
+						const int hit = (r[h] & 1) && j <= stop;
+						if (hit && fi[h] < 0) fi[h] = i;
+						if (__ballot(hit)) large = 1;
+					}
 				}
-				if (stop == 0x7fffffff && lane == sl) { if (hi) kp[1] = large ? 2 : 3; else kp[0] = large ? 2 : 3; }
+				if (stop == 0x7fffffff) {
+#pragma unroll
+					for (int h = 0; h < NH; ++h) if (h == hi && lane == sl) kp[h] = large ? 2 : 3;
+				}
 			}
 #pragma unroll
-			for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < n) S.ch[S.ord[j]].kept = (signed char)kp[h]; }
+			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n) S.ch[S.ord[j]].kept = (signed char)kp[h]; }
 			WAVE_SYNC();
 #pragma unroll
-			for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) S.ch[S.ord[fi[h]]].kept = 1; }
+			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) S.ch[S.ord[fi[h]]].kept = 1; }
 			WAVE_SYNC();
 		} else if (n > 0) {
 			int nk = 1;
@@ -630,27 +697,40 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			WAVE_SYNC();
 		}
 	}
+	RG_STAGE(5);
 	// ---- E. chains -> regions (mem_chain2region, memchain.c:873-904)
 	const int nk = uni(S.n_chains), ns = tot;
 	for (int ci = 0; ci < nk; ++ci) {
 		const int c = uni(S.ord[ci]);
-		const long long ch_pos = uni64(S.ch[c].pos);
-		const int ch_has_extra = uni(S.ch[c].has_extra);
+		const RgChain chn = S.ch[c];
+		const long long ch_pos = uni64(chn.pos);
+		const int ch_has_extra = uni(chn.has_extra);
+		const int single = uni(chn.n_seeds) == 1;
+		const int seed0 = uni(chn.seed0);
+		// a chain of one seed that fails asymmetric_flt_seed, with no contained seeds to fall back to, comes and goes without a trace:
+		// most chains of a strand search against the wrong conversion are such
+		if (single && !ch_has_extra && (uni(S.s_extra[seed0]) & 2)) continue;
 		// mem_chain_reference_span (memchain.c:585-605) + bns_fetch_seq's contig clamp; one lane per seed
 		long long rmax0 = l_pac << 1, rmax1 = 0;
-		for (int o = lane; o < ns; o += 64) if (S.s_chain[o] == c && !S.s_extra[o]) {
-			const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
-			const long long b = rb - (qb + rg_gap(gap, P, qb));
-			const long long e = rb + ln + ((l_query - qb - ln) + rg_gap(gap, P, l_query - qb - ln));
-			rmax0 = rmax0 < b ? rmax0 : b; rmax1 = rmax1 > e ? rmax1 : e;
+		if (single) {
+			const long long rb = uni64(S.s_rbeg[seed0]); const int qb = uni(S.s_qbeg[seed0]), ln = uni(S.s_len[seed0]);
+			rmax0 = rb - (qb + rg_gap(gap, P, qb));
+			rmax1 = rb + ln + ((l_query - qb - ln) + rg_gap(gap, P, l_query - qb - ln));
+		} else {
+			for (int o = lane; o < ns; o += 64) if (S.s_chain[o] == c && !(S.s_extra[o] & 1)) {
+				const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
+				const long long b = rb - (qb + rg_gap(gap, P, qb));
+				const long long e = rb + ln + ((l_query - qb - ln) + rg_gap(gap, P, l_query - qb - ln));
+				rmax0 = rmax0 < b ? rmax0 : b; rmax1 = rmax1 > e ? rmax1 : e;
+			}
+			rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1));
 		}
-		rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1));
 		rmax0 = rmax0 > 0 ? rmax0 : 0; rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
 		if (rmax0 < l_pac && l_pac < rmax1) { if (ch_pos < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
 		int rid;
 		{
 			const int is_rev = ch_pos >= l_pac;
-			rid = uni(rg_pos2rid(ix, ctg, rg_depos(l_pac, ch_pos)));
+			rid = uni(chn.rid);   // a chain's seeds share the contig of its first one (memchain.c:232)
 			long long far_beg = uni64(ctg[rid]), far_end = uni64(ctg[rid + 1]);
 			if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
 			rmax0 = rmax0 > far_beg ? rmax0 : far_beg; rmax1 = rmax1 < far_end ? rmax1 : far_end;
@@ -660,33 +740,32 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			if (pass == 1 && !(uni(S.n_regs) == n0 && ch_has_extra)) break;
 			// the list (seeds or seeds_extra) in arrival order, and its best-first order
 			int nl = 0;
-			for (int base = 0; base < ns; base += 64) {
-				const int o = base + lane;
-				const bool in = o < ns && S.s_chain[o] == c && (int)S.s_extra[o] == pass;
-				const unsigned long long b = __ballot(in);
-				if (in) S.lst[nl + __popcll(b & ((1ull << lane) - 1))] = (idx_t)o;
-				nl += __popcll(b);
+			if (single && pass == 0) {
+				if (lane == 0) { S.lst[0] = (idx_t)seed0; S.srt[0] = (unsigned long long)(unsigned)S.s_len[seed0] << 32; }
+				nl = 1;
+				WAVE_SYNC();
+			} else {
+				for (int base = 0; base < ns; base += 64) {
+					const int o = base + lane;
+					const bool in = o < ns && S.s_chain[o] == c && (int)(S.s_extra[o] & 1) == pass;
+					const unsigned long long b = __ballot(in);
+					if (in) S.lst[nl + __popcll(b & ((1ull << lane) - 1))] = (idx_t)o;
+					nl += __popcll(b);
+				}
+				WAVE_SYNC();
+				for (int i = lane; i < nl; i += 64) { // keys score<<32|i are unique: rank by counting
+					const unsigned long long key = (unsigned long long)(unsigned)S.s_len[S.lst[i]] << 32 | (unsigned)i;
+					int r = 0;
+					for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)S.s_len[S.lst[k]] << 32 | (unsigned)k) < key;
+					S.srt[r] = key;
+				}
+				WAVE_SYNC();
 			}
-			WAVE_SYNC();
-			for (int i = lane; i < nl; i += 64) { // keys score<<32|i are unique: rank by counting
-				const unsigned long long key = (unsigned long long)(unsigned)S.s_len[S.lst[i]] << 32 | (unsigned)i;
-				int r = 0;
-				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)S.s_len[S.lst[k]] << 32 | (unsigned)k) < key;
-				S.srt[r] = key;
-			}
-			WAVE_SYNC();
 			for (int k = nl - 1; k >= 0; --k) {
 				const int si = uni((int)(uint32_t)S.srt[k]);
 				const int o = uni(S.lst[si]);
+				if (uni(S.s_extra[o]) & 2) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested for every seed after stage B
 				const long long s_rbeg = uni64(S.s_rbeg[o]); const int s_qbeg = uni(S.s_qbeg[o]), s_len = uni(S.s_len[o]);
-				// asymmetric_flt_seed (memchain.c:138-149)
-				int bad = 0;
-				for (int base = 0; base < s_len; base += 64) {
-					const int i = base + lane; int v = 0;
-					if (i < s_len) { const int r = dev_ref_base(ix.pac, l_pac, s_rbeg + i), q = query[s_qbeg + i]; v = (r == 3 && q == 1) || (r == 0 && q == 2); }
-					if (__ballot(v)) bad = 1;
-				}
-				if (bad) continue;
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(S.n_regs);
@@ -735,6 +814,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						const int prev = R.score;
 						aw = P.w << i;
 						J.w = aw;
+						RG_STAGE(6);
 						// most extensions of a 150 bp read are shorter than a wavefront is wide: one register entry per lane then,
 						// and none of the per-chunk band tests and carries of the wider form
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane);
@@ -742,6 +822,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
+						RG_STAGE(7);
+						++pf_ext; pf_rows += (unsigned int)(res.tle > res.gtle ? res.tle : res.gtle);
 						if (R.score == prev || res.max_off < (aw >> 1) + (aw >> 2)) break;
 					}
 					const int local = res.gscore <= 0 || res.gscore <= R.score - clip;
@@ -772,6 +854,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			}
 		}
 	}
+	RG_STAGE(6);
+	if (P.prof && lane == 0) { atomicAdd(&counters[40], (unsigned long long)pf_ext); atomicAdd(&counters[41], (unsigned long long)pf_rows); }
 	return 0;
 }
 
@@ -804,7 +888,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
           unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-          const long long *pos_off, const unsigned long long *pos)
+          const long long *pos_off, const unsigned long long *pos, const unsigned char *cls)
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
@@ -823,6 +907,11 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		if (lane == 0) t = (int)atomicAdd(task_cursor, 1u);
 		t = uni(__shfl(t, 0));
 		if (t >= n_tasks) break;
+		if (cls && uni(cls[t]) != 0) { // larger than this tier's tables: straight to the next one
+			if (lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
+			--taken;   // costs nothing: the quota counts strand searches done here
+			continue;
+		}
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
@@ -912,16 +1001,20 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 #define OCC_MAX_PER_TASK 8192   // = RgHuge::SCAP: nothing on the device visits more
 __global__ void __launch_bounds__(256)
 k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ,
-             unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off)
+             unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off, unsigned char *cls)
 {
 	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (t >= n_tasks) return;
 	const int n_iv = task_n[t];
 	long long off = -1;
+	unsigned char tier = 0;
 	if (n_iv > 0) {
 		const DevIntv *src = seeds_dense + task_off[t];
 		unsigned long long tot = 0; int over = 0;
 		for (int i = 0; i < n_iv; ++i) { const unsigned long long x2 = src[i].x2; tot += x2 > (unsigned long long)max_occ ? (unsigned long long)max_occ : x2; }   // the first max_occ of an over-represented interval
+		// which tier's tables hold this strand search: decided here, where the sizes are known, so that the first tier does not start
+		// what it would have to give up (chains and regions can still outgrow a tier: that is found out along the way)
+		tier = (n_iv <= RgSmall::ICAP && tot <= (unsigned long long)RgSmall::SCAP) ? 0 : (n_iv <= RgMid::ICAP && tot <= (unsigned long long)RgMid::SCAP) ? 1 : 2;
 		if (!over && tot > 0 && tot <= OCC_MAX_PER_TASK) {
 			const unsigned long long base = atomicAdd(cursor, tot);
 			if (base + tot <= desc_cap) {
@@ -941,6 +1034,7 @@ k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_den
 		}
 	}
 	pos_off[t] = off;
+	if (cls) cls[t] = tier;
 }
 
 __global__ void __launch_bounds__(256)
@@ -960,9 +1054,9 @@ k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const 
 
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters)
+                unsigned long long *counters, unsigned char *cls)
 {
-	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off);
+	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off, cls);
 	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters);
 }
 
@@ -987,15 +1081,15 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos)
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls)
 {
-	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets
+	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 3;   // waves per SIMD the register allocation targets (the tables in LDS allow three workgroups per CU)
 	if (occ >= 4)
 		hipLaunchKernelGGL(k_regions<4>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls);
 	else
 		hipLaunchKernelGGL(k_regions<3>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos);
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls);
 }
 
 void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,

@@ -24,7 +24,7 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos);
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls);   // cls[t] != 0: not for this tier (launch_occ)
 // the tier in between: LDS tables four times the first tier's; consumes the first tier's list, appends to the second tier's
 void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -40,6 +40,6 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 // t's start, -1 = none listed), then turned into reference positions in place.  pos_off/pos feed launch_regions*.
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters);
+                unsigned long long *counters, unsigned char *cls);   // cls[t]: the first tier whose interval/occurrence tables hold task t
 // out[j] = SA[j * intv] for j < n, from the (sparser) samples ix currently holds: the denser suffix-array sample kept in HBM
 void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out);

@@ -102,8 +102,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipEventCreate(&L.ev0));
 		HIPCHK(hipEventCreate(&L.ev1));
 		HIPCHK(hipEventCreate(&L.ev2));
-		if (L.small.reserve(128) != BSX_OK) return BSX_E_NOMEM;
-		HIPCHK(hipMemset(L.small.p, 0, 128));
+		if (L.small.reserve(1024) != BSX_OK) return BSX_E_NOMEM;   // u64 slots 32..47: per-stage cycle counts of the region kernels ($BSX_PHASES)
+		HIPCHK(hipMemset(L.small.p, 0, 1024));
 	}
 	memset(&d->ix, 0, sizeof(d->ix));
 	memset(&d->sc, 0, sizeof(d->sc));
@@ -493,7 +493,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.a = opt->a; R.w = opt->w; R.o_del = opt->o_del; R.e_del = opt->e_del; R.o_ins = opt->o_ins; R.e_ins = opt->e_ins;
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
-	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio;
+	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
 
 	// $BSX_SEED_MEM_CAP (tests): a short first-pass list, so that ordinary reads take the seeded-again path too
 	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
@@ -518,7 +518,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 24 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 25 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
@@ -531,6 +531,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
 	int *retry_a = (int*)((char*)L.regmeta.p + (size_t)n * 12), *retry_b = (int*)((char*)L.regmeta.p + (size_t)n * 16);
 	int *retry_m = (int*)((char*)L.regmeta.p + (size_t)n * 20);
+	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 24;
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
 	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
@@ -546,11 +547,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
 	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
-	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr);
+	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
 	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
-	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos);
+	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls);
 	HIPCHK(hipEventRecord(L.ev3, L.st));
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
 	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
@@ -638,6 +639,19 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
+	if (trace) {
+		unsigned int hc[12]; unsigned long long hu[12];
+		D2H(L.st, hc, c32, sizeof(hc));
+		D2H(L.st, hu, ctr, sizeof(hu));
+		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, left tier 2: %u\n",
+		        (long long)n, hu[4], hu[11], hc[1], hc[10], hc[3]);
+		unsigned long long pf[16];
+		D2H(L.st, pf, ctr + 32, sizeof(pf));
+		HIPCHK(hipMemsetAsync(ctr + 32, 0, sizeof(pf), L.st));
+		double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)pf[k];
+		if (tot > 0) fprintf(stderr, "[M::regions_batch] wave cycles by stage (all tiers): intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% chain prologues+seed tests %.1f%% extension %.1f%% | %.0f M cycles, %llu extensions, %llu rows\n",
+		        100 * pf[0] / tot, 100 * pf[1] / tot, 100 * pf[2] / tot, 100 * pf[3] / tot, 100 * pf[4] / tot, 100 * pf[5] / tot, 100 * pf[6] / tot, 100 * pf[7] / tot, tot * 1e-6, pf[8], pf[9]);
+	}
 	clock_gettime(CLOCK_MONOTONIC, &ts_out);
 	if (trace) fprintf(stderr, "[M::regions_batch] entry to kernels enqueued %.0f ms | tiers done to regions downloaded %.0f ms (%llu regions)\n",
 	                   (ts0.tv_sec - ts_in.tv_sec) * 1e3 + (ts0.tv_nsec - ts_in.tv_nsec) * 1e-6, (ts_out.tv_sec - ts3.tv_sec) * 1e3 + (ts_out.tv_nsec - ts3.tv_nsec) * 1e-6, used);

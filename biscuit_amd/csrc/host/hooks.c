@@ -52,3 +52,5 @@ BSX_API int bsx_hook_opt_defaults(char *buf, int cap)
 BSX_API void *bsx_hook_fq_pair_open(void *f1, void *f2, int has_bc) { return bsx_fq_pair_open((bsx_fq_t*)f1, (bsx_fq_t*)f2, has_bc); }
 BSX_API void bsx_hook_fq_pair_close(void *p) { bsx_fq_pair_close((bsx_fq_pair_t*)p); }
 BSX_API bsx_read_t *bsx_hook_fq_pair_chunk(void *p, int chunk_size, int *n) { return bsx_fq_pair_read_chunk((bsx_fq_pair_t*)p, chunk_size, n); }
+const uint8_t *bsx_nt4_table(void);
+BSX_API const uint8_t *bsx_hook_nt4_table(void) { return bsx_nt4_table(); }

@@ -244,3 +244,59 @@ API int64_t ref_bt_traverse(void *t, int64_t *ids, int64_t cap)
 }
 /* change the payload of the key found by interval lookup (mem_chain mutates chains in place through
  * the pointer kb_intervalp returns; positions never change) -- not needed for structure tests. */
+
+/* ---------------- FASTQ chunk reader and SAM header (bwa.c) ---------------- */
+#include <unistd.h>
+#include "kseq.h"
+KSEQ_DECLARE(gzFile)   /* instantiated by the reference itself in utils.c:53 */
+
+API void *ref_kseq_open(const char *fn) { gzFile fp = gzopen(fn, "r"); return fp ? kseq_init(fp) : 0; }
+API void ref_kseq_close(void *ks_) { kseq_t *ks = (kseq_t*)ks_; gzFile fp = ks->f->f; kseq_destroy(ks); gzclose(fp); }
+
+/* kseq_read (kseq.h:182-222, the grammar under bis_bseq_read, bwa.c:817-850): next record flattened as
+ *   name \t comment|* \t sequence \t qual|* \n        returns kseq_read's value (>= 0 length, -1 end of file, -2 truncated quality)
+ * bis_bseq_read itself cannot be linked: bseq1_code_nt4 needs nst_nt4_table, defined in bntseq.c, which does not build
+ * here (encode.h is not vendored).  The table is pinned separately as data (tests/golden/make_vectors.py reads it from the
+ * reference source); the chunk rule and trim_readno around kseq_read stay restated. */
+API int ref_kseq_next(void *ks_, char *out, size_t cap)
+{
+	kseq_t *ks = (kseq_t*)ks_;
+	int l = kseq_read(ks);
+	out[0] = 0;
+	if (l < 0) return l;
+	if (ks->name.l + ks->comment.l + ks->seq.l + ks->qual.l + 16 > cap) return -3;
+	sprintf(out, "%s\t%s\t%s\t%s\n", ks->name.s, ks->comment.l ? ks->comment.s : "*", ks->seq.s, ks->qual.l ? ks->qual.s : "*");
+	return l;
+}
+
+/* bwa_print_sam_hdr (bwa.c:654-684) prints to stdout: captured through a temporary file */
+extern char *bwa_pg;
+API int ref_sam_hdr(int n_seqs, const char **names, const int *lens, const char *hdr_line, const char *pg, char *out, size_t cap)
+{
+	bntseq_t bns;
+	FILE *tmp = tmpfile();
+	int saved, i;
+	long sz;
+	if (!tmp) return -1;
+	memset(&bns, 0, sizeof(bns));
+	bns.n_seqs = n_seqs;
+	bns.anns = (bntann1_t*)calloc((size_t)n_seqs + 1, sizeof(bntann1_t));
+	for (i = 0; i < n_seqs; ++i) { bns.anns[i].name = (char*)names[i]; bns.anns[i].len = lens[i]; }
+	bwa_pg = (char*)pg;
+	fflush(stdout);
+	saved = dup(1);
+	dup2(fileno(tmp), 1);
+	bwa_print_sam_hdr(&bns, hdr_line && hdr_line[0] ? hdr_line : 0);
+	fflush(stdout);
+	dup2(saved, 1); close(saved);
+	bwa_pg = 0;
+	free(bns.anns);
+	sz = ftell(tmp);
+	if (sz < 0) { fseek(tmp, 0, SEEK_END); sz = ftell(tmp); }
+	fseek(tmp, 0, SEEK_END); sz = ftell(tmp); rewind(tmp);
+	if ((size_t)sz + 1 > cap) { fclose(tmp); return -1; }
+	if (fread(out, 1, (size_t)sz, tmp) != (size_t)sz) { fclose(tmp); return -1; }
+	out[sz] = 0;
+	fclose(tmp);
+	return (int)sz;
+}

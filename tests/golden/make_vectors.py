@@ -247,5 +247,113 @@ for par in (0, 1):
     out["fm_sa_%d" % par] = np.array([R.ref_bwt_sa(H[par], C.c_uint64(int(k))) for k in ks[ks >= 1]], dtype=np.uint64)
 out["fm_k"] = ks
 
+# ---- K1+K2 as a whole: mem_collect_intv (memchain.c:50-106) is static in a file that does not build here, so its 20-line
+# driver is restated below over the REAL bwt_smem1a / bwt_seed_strategy1 (all FM work is the reference's); the result is
+# what the seeding kernel must return for the read, interval for interval.  Default options (mem_opt_init).
+def collect_intv(par, conv, min_seed_len=19, split_factor=1.5, split_width=10, max_mem_intv=20, start_width=1):
+    L_ = len(conv)
+    split_len = int(min_seed_len * split_factor + .499)
+    mem = []
+    o1 = np.zeros(4 * 1024, np.uint64); r1 = C.c_int()
+
+    def smem1(x, mi):
+        n1 = R.ref_bwt_smem1a(H[par], H[1 - par], L_, P(conv, u8p), x, mi, C.c_uint64(0), P(o1, u64p), 1024, C.byref(r1))
+        assert n1 <= 1024
+        return [tuple(int(v) for v in o1[4 * i:4 * i + 4]) for i in range(n1)], r1.value
+    x = 0
+    while x < L_:                                    # pass 1 (memchain.c:65-73)
+        if conv[x] < 4:
+            got, x = smem1(x, start_width)
+            mem += [m for m in got if (m[3] & 0xffffffff) - (m[3] >> 32) >= min_seed_len]
+        else:
+            x += 1
+    for k in range(len(mem)):                        # pass 2 (memchain.c:76-85)
+        st, en = mem[k][3] >> 32, mem[k][3] & 0xffffffff
+        if en - st < split_len or mem[k][2] > split_width:
+            continue
+        got, _ = smem1((st + en) >> 1, mem[k][2] + 1)
+        mem += [m for m in got if (m[3] & 0xffffffff) - (m[3] >> 32) >= min_seed_len]
+    x = 0
+    a1 = np.zeros(4, np.uint64)
+    while x < L_:                                    # pass 3 (memchain.c:88-103)
+        if conv[x] < 4:
+            x = R.ref_bwt_seed_strategy1(H[par], H[1 - par], L_, P(conv, u8p), x, min_seed_len, max_mem_intv, P(a1, u64p))
+            if int(a1[2]) > 0:
+                mem.append(tuple(int(v) for v in a1))
+        else:
+            x += 1
+    mem.sort(key=lambda m: m[3])                     # ks_introsort(mem_intv): records with equal info are identical
+    return np.array(mem, np.uint64).reshape(-1, 4)
+
+
+fm_all = [collect_intv(int(fm_par[i][0]), fm_reads[i]) for i in range(len(fm_reads))]
+out["fm_collect"], out["fm_coff"] = ragged([a.reshape(-1) for a in fm_all], np.uint64)
+
+# ---- I1: the record grammar (kseq_read, kseq.h:182-222, as instantiated by the reference in utils.c:53) on awkward inputs, the
+# base-to-code table (bntseq.c:49-66, read from the source as data: bntseq.c does not build here), the SAM header
+# (bwa_print_sam_hdr, bwa.c:654-684)
+import re  # noqa: E402
+import tempfile  # noqa: E402
+FQ_CASES = [
+    "@r1 first comment\nACGTNacgtn\n+\nIIIIIIIIII\n@r2/1\nAC\nGT\n+r2\nII\nII\n",
+    ">fa1 desc here\nACGT\nTTGA\n>fa2\nA\n\n>fa3\n",
+    "@q1\nACGT\n+\n@III\n@q2\tc\nGGCC\n+\n+@+@\n",
+    "junk before\n@r\r\nACGT\r\n+\r\nIIII\r\n",
+    "@trunc\nACGTACGT\n+\nIII",
+    "@a\nAC\n+\nII\n@b\nGT\n+\nII",
+    "@noseq\n+\n\n@x y z\nA\n+\nI\n",
+    "@long " + "c" * 5000 + "\n" + "ACGT" * 3000 + "\n+\n" + "I" * 12000 + "\n",
+    "",
+]
+fq_out = []
+with tempfile.TemporaryDirectory() as td:
+    for i, text in enumerate(FQ_CASES):
+        fn = os.path.join(td, "c%d.fq" % i)
+        open(fn, "w").write(text)
+        R.ref_kseq_open.restype = C.c_void_p
+        R.ref_kseq_open.argtypes = [C.c_char_p]
+        R.ref_kseq_close.argtypes = [C.c_void_p]
+        R.ref_kseq_next.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        ks = R.ref_kseq_open(fn.encode())
+        buf = C.create_string_buffer(1 << 20)
+        recs = []
+        while True:
+            l = R.ref_kseq_next(ks, buf, len(buf))
+            if l < 0:
+                recs.append("END %d\n" % l)
+                break
+            recs.append(buf.value.decode())
+        R.ref_kseq_close(ks)
+        fq_out.append("".join(recs))
+out["fq_case"], out["fq_case_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in FQ_CASES], np.uint8)
+out["fq_recs"], out["fq_recs_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in fq_out], np.uint8)
+
+src = open("/root/reference/lib/aln/bntseq.c").read()
+body = src[src.index("nst_nt4_table[256]"):]
+body = body[body.index("{") + 1:body.index("};")]
+nt4 = np.array([int(v) for v in re.findall(r"\d+", body)], np.uint8)
+assert len(nt4) == 256
+out["nt4_table"] = nt4
+
+HDR_CASES = [
+    (["chr1", "chr10", "chr2", "chrM", "Chr3", "1", "chr1_alt"], [1000, 20, 300, 16569, 5, 7, 9], "", "@PG\tID:biscuit\tPN:biscuit\tVN:x\tCL:biscuit align a b"),
+    (["b", "a"], [10, 20], "@RG\tID:g\tSM:s", ""),
+    (["b", "a"], [10, 20], "@SQ\tSN:b\tLN:10\n@SQ\tSN:a\tLN:20\n@CO\tx", "@PG\tID:p"),
+    (["b", "a"], [10, 20], "@CO\thas @SQ\tin the middle of a line", ""),
+    (["z%03d" % (i * 37 % 101) for i in range(101)], list(range(1, 102)), "", ""),
+]
+R.ref_sam_hdr.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+hdr_in, hdr_out = [], []
+for names, lens, hl, pg in HDR_CASES:
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    la = (C.c_int * len(lens))(*lens)
+    buf = C.create_string_buffer(1 << 16)
+    n = R.ref_sam_hdr(len(names), arr, la, hl.encode() if hl else None, pg.encode() if pg else None, buf, len(buf))
+    assert n >= 0
+    hdr_in.append("\x1e".join(["\x1f".join(names), "\x1f".join(str(x) for x in lens), hl, pg]))
+    hdr_out.append(buf.value.decode())
+out["hdr_in"], out["hdr_in_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in hdr_in], np.uint8)
+out["hdr_out"], out["hdr_out_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in hdr_out], np.uint8)
+
 np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
 print("wrote", os.path.join(HERE, "ref_vectors.npz"), os.path.getsize(os.path.join(HERE, "ref_vectors.npz")), "bytes")

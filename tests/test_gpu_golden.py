@@ -99,10 +99,37 @@ def test_sw_kernel_vs_reference_vectors(V, tmp_path):
 
 
 def test_fm_kernels_vs_reference_vectors(V, tmp_path):
-    """K1-K3 on the committed 24 kb genome: every SMEM the reference's bwt_smem1a reports for a read must
-    be among the intervals the seed kernel returns (pass 1 covers all start positions), and bwt_sa agrees."""
+    """K1-K3 on the committed 24 kb genome against vectors recorded from the real reference: the seeding kernel's interval
+    lists == the lists the reference's bwt_smem1a / bwt_seed_strategy1 give when driven as mem_collect_intv drives them
+    (memchain.c:50-106; tests/golden/make_vectors.py), interval for interval; every SMEM recorded for a single bwt_smem1a
+    call with min_intv 1 is among them; bwt_sa agrees."""
     idx = Index.build(os.path.join(HERE, "golden", "g24k.fa"), str(tmp_path / "g"))
     dev = Device(0); dev.upload_index(idx)
+    ro = V["fm_roff"]
+    reads = [V["fm_reads"][ro[i]:ro[i + 1]] for i in range(len(ro) - 1)]
+    buf, offs = simdata.read_buffer(reads)
+    tasks = np.zeros(len(reads), dtype=SEED_DT)
+    for i, r in enumerate(reads):
+        tasks[i] = (offs[i], len(r), int(V["fm_par"][i][0]))
+    opt = default_opt()
+    dev.set_opt(opt)
+    dev.set_reads(buf)
+    iv, off = dev.seed(opt, tasks)
+    co = V["fm_coff"] // 4
+    assert (np.asarray(off) == co).all()
+    assert (iv.reshape(-1) == V["fm_collect"]).all()
+    assert int(co[-1]) > 1000
+    so, n_in = V["fm_soff"], 0
+    for i, par in enumerate(V["fm_par"]):
+        if int(par[2]) != 1:      # min_intv of the recorded call: pass 1 runs with 1
+            continue
+        mine = {tuple(int(v) for v in row) for row in iv[off[i]:off[i + 1]]}
+        sm = V["fm_smem"][so[i]:so[i + 1]].reshape(-1, 4)
+        for row in sm:
+            if (int(row[3]) & 0xffffffff) - (int(row[3]) >> 32) >= 19:
+                assert tuple(int(v) for v in row) in mine, (i, row)
+                n_in += 1
+    assert n_in > 100
     ks = V["fm_k"][V["fm_k"] >= 1]
     for p in (0, 1):
         jobs = np.zeros(len(ks), dtype=SA_DT)

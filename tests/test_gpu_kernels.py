@@ -117,11 +117,6 @@ def _rand_ext_jobs(small_index, seqs, offs, rng, n, long_band=False):
     return jobs
 
 
-def _true_ext_jobs(small_index, pairs_seqs, offs, rng):
-    """extension jobs shaped like the real ones: a read against its true locus (found by seeding)"""
-    return None
-
-
 def test_extend_matches_oracle(small_index, port, device):
     opt = default_opt()
     rng = np.random.default_rng(11)

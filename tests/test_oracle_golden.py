@@ -159,3 +159,85 @@ def test_fm_index_vs_reference_vectors(V, PL, g24k):
             assert (c == V["fm_occ4_%d" % p][i]).all(), (p, k)
         got = np.array([PL.oracle_sa(g24k.h, p, int(k)) for k in ks[ks >= 1]], dtype=np.uint64)
         assert (got == V["fm_sa_%d" % p]).all()
+
+
+def _ragged(V, key, off):
+    o = V[off]
+    return [V[key][o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
+def test_three_pass_seeding_vs_reference_vectors(V, g24k):
+    """K1+K2 as mem_collect_intv composes them (memchain.c:50-106): the CPU restatement's interval lists == the lists
+    obtained by driving the real bwt_smem1a / bwt_seed_strategy1 (tests/golden/make_vectors.py), read by read."""
+    import simdata
+    from biscuit_amd.api import SEED_DT
+    port = oracle_lib.Port(g24k, n_threads=2)
+    reads = _ragged(V, "fm_reads", "fm_roff")
+    buf, offs = simdata.read_buffer(reads)
+    tasks = np.zeros(len(reads), dtype=SEED_DT)
+    for i, r in enumerate(reads):
+        tasks[i] = (offs[i], len(r), int(V["fm_par"][i][0]))
+    opt = default_opt()
+    port.set_opt(opt)
+    port.set_reads(buf)
+    iv, off = port.seed(opt, tasks)
+    co = V["fm_coff"] // 4
+    assert (np.asarray(off) == co).all()
+    assert (iv.reshape(-1) == V["fm_collect"]).all()
+    assert int(co[-1]) > 1000
+
+
+def test_nt4_table_vs_reference(V):
+    L = B.lib()
+    L.bsx_hook_nt4_table.restype = C.POINTER(C.c_uint8)
+    t = np.ctypeslib.as_array(L.bsx_hook_nt4_table(), shape=(256,))
+    assert (t == V["nt4_table"]).all()   # nst_nt4_table, bntseq.c:49-66, recorded as data
+
+
+def test_fastq_grammar_vs_reference_kseq(V, tmp_path):
+    """csrc/host/fastq.c against records the reference's own kseq_read (utils.c:53 instantiation of kseq.h:182-222) produced
+    for the same bytes: name / comment / sequence / quality, including where reading stops."""
+    import test_fastq_reader as T
+    nt4 = V["nt4_table"]
+    cases = [bytes(x).decode() for x in _ragged(V, "fq_case", "fq_case_off")]
+    wants = [bytes(x).decode() for x in _ragged(V, "fq_recs", "fq_recs_off")]
+    assert len(cases) >= 8
+    for i, (text, want) in enumerate(zip(cases, wants)):
+        fn = str(tmp_path / ("c%d.fq" % i))
+        open(fn, "w").write(text)
+        got = [r for ch in T.read_all(fn, None, 1 << 30) for r in ch]
+        exp = []
+        for line in want.split("\n"):
+            if not line or line.startswith("END"):
+                break
+            name, comment, seq, qual = line.split("\t")
+            if len(name) > 2 and name[-2] == "/" and name[-1].isdigit():
+                name = name[:-2]                       # trim_readno (bwa.c:58-63)
+            codes = "".join("ACGTN"[min(int(nt4[ord(c)]), 4)] for c in seq)
+            exp.append((name, "" if comment == "*" else comment, codes, None if qual == "*" else qual))
+        assert got == exp, (i, got[:3], exp[:3])
+
+
+def test_sam_header_vs_reference(V, tmp_path):
+    """bsx_sam_header against text printed by the real bwa_print_sam_hdr (bwa.c:654-684): @SQ lines sorted by name unless the
+    -H text brings its own, then the -H text, then @PG."""
+    L = B.lib()
+    L.bsx_sam_header.restype = C.c_void_p
+    L.bsx_sam_header.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    ins = [bytes(x).decode() for x in _ragged(V, "hdr_in", "hdr_in_off")]
+    outs = [bytes(x).decode() for x in _ragged(V, "hdr_out", "hdr_out_off")]
+    assert len(ins) >= 5
+    for k, (spec, want) in enumerate(zip(ins, outs)):
+        names, lens, hl, pg = spec.split("\x1e")
+        names, lens = names.split("\x1f"), [int(x) for x in lens.split("\x1f")]
+        fa = str(tmp_path / ("h%d.fa" % k))
+        with open(fa, "w") as f:
+            for n, l in zip(names, lens):
+                f.write(">%s\n%s\n" % (n, "ACGT" * (l // 4) + "ACGT"[:l % 4]))
+        idx = Index.from_fasta(fa)
+        p = L.bsx_sam_header(idx.h, hl.encode() if hl else None, pg.encode() if pg else None)
+        got = C.string_at(p).decode()
+        from biscuit_amd.api import _libc_free
+        _libc_free(p)
+        idx.close()
+        assert got == want, (k, got[:200], want[:200])
