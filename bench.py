@@ -143,22 +143,48 @@ def main():
     # pushes, so consuming the output there would stall the pipeline.  The consumer is joined inside the timed region.
     import queue
     import threading
+    import numpy as np
+    from biscuit_amd.gather import ChunkGather
     retire_q = queue.Queue()
     retire_s = [0.0]
     retired = set()
+    # the per-chunk alignment records (SAM text) of every rank stream to rank 0 while the following chunks are
+    # aligned (biscuit_amd/gather.py: sizes, then exactly the payload, rank -> rank 0 over RCCL); rank 0 takes them in chunk
+    # order and drops them (a real run writes them).  Chunk s of rank r is global chunk s * world + r.  All of it is inside
+    # the timed region.  With one GPU the gather degenerates to handing the text over in this process.
+    gathered = [0, 0]
+
+    def sink(k, buf):
+        gathered[0] += 1
+        gathered[1] += len(buf)
+    gdev = torch.device("cuda", local_rank) if world > 1 else torch.device("cpu")
+    G = ChunkGather(rank, world, gdev, sink, max_pending=3)
+    L.bsx_hook_chunk_sam.restype = C.c_int64
+    L.bsx_hook_chunk_sam.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
 
     def consumer():
         while True:
             k = retire_q.get()
             if k is None:
+                G.close()
                 return
             tr = time.time()
-            sam_bytes_box[0] += L.bsx_sim_sam_bytes(chunks[k], n_reads)
+            nb = L.bsx_hook_chunk_sam(chunks[k], n_reads, None, 0)
+            text = np.empty(nb, dtype=np.uint8)
+            L.bsx_hook_chunk_sam(chunks[k], n_reads, text.ctypes.data_as(C.c_void_p), nb)
+            sam_bytes_box[0] += nb
             L.bsx_sim_reset_reads(chunks[k], n_reads)
             retire_s[0] += time.time() - tr
             retired.add(k)
+            G.submit((k - args.warmup) * world + rank, text)
     consumer_th = threading.Thread(target=consumer)
     consumer_th.start()
+    def gather_main():
+        if world > 1:
+            torch.cuda.set_device(local_rank)   # the current device is per thread
+        G.run()
+    gather_th = threading.Thread(target=gather_main)
+    gather_th.start()
 
     def retire(k):
         retire_q.put(k)
@@ -190,6 +216,7 @@ def main():
             retire(k)
     retire_q.put(None)
     consumer_th.join()
+    gather_th.join()
     torch.cuda.synchronize()
     barrier()
     dt = time.time() - t0
@@ -222,39 +249,69 @@ def main():
         L.bsx_sim_free_reads(extra, n_reads)
         alone = [dev.kernel_time(k) for k in range(8)]
 
-    def roof_of(name, k, alg_bytes, extra):
+    # Counter passes cannot run inside this process (rocprofv3 --pmc wraps a command): HBM traffic and instruction counts per
+    # launch come from the committed passes of THIS command at THIS genome size (profiles/*_pmc_<Mbp>mbp.json, written by
+    # tools/profile_round.sh + tools/summarize_profiles.py), and are only quoted when the workload is the profiled one.
+    pmc = {}
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%dmbp.json" % int(round(args.genome_mbp)))))
+    if cand and args.read_len == 150 and threads == 16:
+        with open(cand[-1]) as f:
+            tj = json.load(f)
+        if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
+            pmc = tj
+            pmc["_file"] = os.path.relpath(cand[-1], ROOT)
+    PEAK_HBM = 8000.0       # GB/s, spec (MI355X_MICROARCH.md); a streaming copy reaches 6.3 TB/s
+    GATHER_CEILING = 3500.0   # GB/s: dependent random 64-B block reads over a 3.1 GB table, four lanes per block, measured on this GPU
+                              # with tools/ubench/gather64.hip (profiles/r02_gather64.txt); one lane per block: 2.7 TB/s
+
+    def roof_of(name, k, alg_bytes, extra, pmc_key=None):
         ms, launches = ktimes[k]
         if not launches or ms <= 0:
             return None
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 5),
-             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3)}
+        r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(ach / PEAK_HBM, 5),
+             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3),
+             "random_64B_gather_ceiling": GATHER_CEILING, "frac_of_gather_ceiling": round(ach / GATHER_CEILING, 4)}
         if alone and alone[k][1]:
             r["avg_launch_ms_standalone"] = round(alone[k][0] / alone[k][1], 3)
             r["achieved_standalone"] = round(alg_bytes / launches / (alone[k][0] / alone[k][1] * 1e-3) / 1e9, 2)
+            r["frac_standalone"] = round(r["achieved_standalone"] / PEAK_HBM, 5)
+        p = pmc.get(pmc_key or "", {})
+        if p.get("FETCH_SIZE_KiB") is not None and p.get("WRITE_SIZE_KiB") is not None:
+            r["traffic"] = 1024.0 * (p["FETCH_SIZE_KiB"] + p["WRITE_SIZE_KiB"])
+            r["traffic_source"] = "FETCH_SIZE + WRITE_SIZE of %s (separate rocprofv3 --pmc passes of this command at this genome size)" % pmc["_file"]
         r.update(extra)
         return r
 
-    # HBM traffic per launch from the committed counter passes (rocprofv3 --pmc cannot run inside this process; the
-    # passes profile this same command, one chunk per launch), only quoted when the workload is the profiled one
-    traffic = {}
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and abs(args.genome_mbp - 128) < 1e-9 and args.read_len == 150 and threads == 16:
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
-            for kname in ("k_seed", "k_occ"):
-                if tj.get(kname, {}).get("FETCH_SIZE_KiB") is not None and tj[kname].get("WRITE_SIZE_KiB") is not None:
-                    traffic[kname] = 1024.0 * (tj[kname]["FETCH_SIZE_KiB"] + tj[kname]["WRITE_SIZE_KiB"])
-
-    roof = roof_of("k_seed (K1+K2 SMEM seeding)", 0, 64.0 * (ctr[0] + ctr[1]),
-                   {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps)})
+    roof = roof_of("k_seed (K1+K2 SMEM seeding: dependent random 64-B FM-block gathers)", 0, 64.0 * (ctr[0] + ctr[1]),
+                   {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps),
+                    "what_bounds_it": "not HBM: the per-lane seeding state machine between two gathers (instruction issue, divergence); see DESIGN.md"}, "k_seed")
     roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
-                         {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)})
-    for r, kname in ((roof, "k_seed"), (roof_other, "k_occ")):
-        if r and kname in traffic:
-            r["traffic"] = traffic[kname]
-            r["traffic_source"] = "FETCH_SIZE+WRITE_SIZE of profiles/r01_traffic.json: separate rocprofv3 --pmc passes of this command, calibrated on k_occ's known 64-byte gathers"
+                         {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)}, "k_occ")
+
+    # The region kernels (C1+C2+K4+C4: chaining, chain filter, extension) take the most device time and touch ~1.5 KB per strand
+    # search: they are bound by instruction issue.  Roofline against the issue rates: one scalar instruction per CU per cycle,
+    # one wave64 VALU instruction per SIMD per two cycles (256 CUs x 4 SIMDs, 2.4 GHz).
+    def issue_roof():
+        ms = ktimes[5][0] + ktimes[6][0]
+        launches = ktimes[5][1]
+        if not launches or ms <= 0:
+            return None
+        r = {"bound": "issue", "kernel": "k_regions, all tiers (C1+C2+K4+C4)", "avg_ms_per_chunk": round(ms / launches, 3),
+             "peak_salu_ginst_per_s": 256 * 2.4, "peak_valu_ginst_per_s": 1024 * 2.4 / 2, "salu_inst_per_chunk": None, "valu_inst_per_chunk": None,
+             "frac_salu": None, "frac_valu": None}
+        if alone and alone[5][1]:
+            r["avg_ms_per_chunk_standalone"] = round((alone[5][0] + alone[6][0]) / alone[5][1], 3)
+        p = pmc.get("k_regions", {})
+        if p.get("SQ_INSTS_SALU") is not None and p.get("SQ_INSTS_VALU") is not None:
+            t = (r.get("avg_ms_per_chunk_standalone") or r["avg_ms_per_chunk"]) * 1e-3
+            r["salu_inst_per_chunk"], r["valu_inst_per_chunk"] = p["SQ_INSTS_SALU"], p["SQ_INSTS_VALU"]
+            r["frac_salu"] = round(p["SQ_INSTS_SALU"] / t / (256 * 2.4e9), 4)
+            r["frac_valu"] = round(p["SQ_INSTS_VALU"] * 2 / t / (1024 * 2.4e9), 4)
+            r["counter_source"] = pmc["_file"]
+        return r
+    roof_regions = issue_roof()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -273,6 +330,8 @@ def main():
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 4 * 8) + n_bases / 4)},
             "roofline": roof,
             "roofline_second_kernel": roof_other,
+            "roofline_regions": roof_regions,
+            "record_gather": {"chunks_received_by_rank0": gathered[0], "bytes_received_by_rank0": gathered[1], "in_timed_region": True},
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(8)},
             "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(8)} if alone else None),

@@ -147,8 +147,9 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp(const DevIndex &ix, const DevSco
 // Needs qlen + 1 <= 64 * NC entries.
 template <int NC>
 __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t &J, int lane,
-                                                    const uint8_t *win = nullptr, long long win_beg = 0)
+                                                    const uint8_t *win = nullptr, long long win_beg = 0, const uint8_t *qlds = nullptr, uint32_t qlds_off = 0)
 {   // win: the reference bases [win_beg, ...) already in LDS, one byte each, covering every row of this job (else HBM)
+    // qlds: the read already in LDS, qlds[k] = reads[qlds_off + k] (else the chunk's read buffer in HBM)
 	const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
 	// the 5x5 matrix of this strand as 25 scalars (constant indices: scalar loads, hoisted); indexing the kernel
 	// argument with a run-time index instead would be five vector loads from memory in every row
@@ -161,7 +162,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		const int a = (c << 6) + lane;
-		const int q = a < qlen ? reads[(long long)J.qoff + (long long)a * J.qdir] : 4;
+		const int q = a < qlen ? (qlds ? (int)qlds[(int)(J.qoff - qlds_off) + a * J.qdir] : (int)reads[(long long)J.qoff + (long long)a * J.qdir]) : 4;
 #pragma unroll
 		for (int t = 0; t < 5; ++t) sq[c][t] = q == 0 ? mt[t * 5] : q == 1 ? mt[t * 5 + 1] : q == 2 ? mt[t * 5 + 2] : q == 3 ? mt[t * 5 + 3] : mt[t * 5 + 4];
 		const int v = a == 0 ? h0 : h0 - oe_ins - (a - 1) * e_ins;   // first row (ksw.c:395-397)

@@ -27,7 +27,7 @@ struct RgChain {         // mem_chain_t reduced to what chaining, the filter and
 	int rid, endr_off;                                        // endr_off: end of the reference coverage so far, relative to pos
 	short first_q, last_q, last_len, wq, wr, endq, first, w;  // w = min(wq, wr) once chaining is over; first: mem_chain_flt's
 	unsigned short n_seeds, seed0;                            // seeds on the main list (not seeds_extra), and the first of them
-	signed char kept; unsigned char is_alt, has_extra, pad;
+	signed char kept; unsigned char is_alt; unsigned short n_extra;   // n_extra: seeds on seeds_extra (contained in the chain on both axes)
 };
 
 // Working set of one strand search.  Two sizes: the common case lives in LDS; what does not fit there is
@@ -63,7 +63,12 @@ typedef RgStore<128, 256, 256, 24, 0, unsigned char, short> RgMid;              
                                                                                 // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
-struct RgDp { int32_t H[64], E[64]; };   // per-wave LDS scratch of the one-lane passes (introsort stack, tree traversal stack)
+#define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
+struct RgDp {            // per-wave LDS scratch
+	int32_t H[64], E[64];        // the one-lane passes (introsort stack, tree traversal stack)
+	uint8_t q[RG_QCAP];          // the read
+	uint8_t win[RG_WIN];         // reference bases [rmax0, rmax1) of the chain being extended, one byte each
+};
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -82,7 +87,7 @@ __device__ __forceinline__ long long wave_max_i64(long long v)
 	return v;
 }
 
-#define RG_CTG_LDS 256   // contig offset tables up to this many entries are copied to LDS once per workgroup
+#define RG_CTG_LDS 128   // contig offset tables up to this many entries are copied to LDS once per workgroup
 __device__ __forceinline__ int rg_pos2rid(const DevIndex &ix, const long long *ctg, long long pos_f)   // bns_pos2rid, bntseq.c:356-369
 {
 	int left = 0, mid = 0, right = ix.n_seqs;
@@ -312,14 +317,85 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 	return rg_flt_vals(P, ci.first_q, ci.last_q + ci.last_len, ci.w, ci.is_alt, ck.first_q, ck.last_q + ck.last_len, ck.w, ck.is_alt);
 }
 
+// ---- The LDS tiers stop after the chain filter and hand the surviving chains to k_c2r: chaining needs its tables (24 KB of LDS per
+// wave at the larger size, six waves per CU), the chain-to-region loop needs registers and latency hiding (extension rows are
+// dependent DPP chains) but almost no tables.  One launch each, with the occupancy each can have.  What is exported per strand
+// search: the kept chains in processing order, each with its seeds (main list, then seeds_extra) in arrival order.
+struct RgXHdr { int n_chains, n_seeds; float frac_rep; int pad; };
+struct RgXChain { long long pos; int rid, seed_off; unsigned short n_main, n_extra; int pad; };
+struct RgXSeed { long long rbeg; short qbeg, len; unsigned char bad, pad[3]; };
+struct RgXPool { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
+
+// returns 11 (exported), 0 (nothing left to extend: the strand search has no regions) or 6 (no room: the next tier takes it)
+template <typename Store>
+__device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool &X, int lane)
+{
+	typedef typename Store::idx_t idx_t;
+	const int nk = uni(S.n_chains);
+	const unsigned long long lt_mask = (1ull << lane) - 1;
+	// a chain of one seed that fails asymmetric_flt_seed, with no contained seeds to fall back to, comes and goes without a trace
+	int n_surv = 0, n_sd = 0;
+	for (int base = 0; base < nk; base += 64) {
+		const int ci = base + lane;
+		bool surv = false; int cnt = 0;
+		if (ci < nk) {
+			const RgChain c = S.ch[S.ord[ci]];
+			surv = !(c.n_seeds == 1 && c.n_extra == 0 && (S.s_extra[c.seed0] & 2));
+			cnt = surv ? c.n_seeds + c.n_extra : 0;
+		}
+		const unsigned long long b = __ballot(surv);
+		WAVE_SYNC();
+		if (surv) S.ord[n_surv + __popcll(b & lt_mask)] = S.ord[ci];   // compacted in place, order kept (targets never pass the sources)
+		n_surv += __popcll(b);
+		n_sd += wave_sum_i32(cnt);
+		WAVE_SYNC();
+	}
+	if (n_surv == 0) return 0;
+	const unsigned long long bytes = sizeof(RgXHdr) + (unsigned long long)n_surv * sizeof(RgXChain) + (unsigned long long)n_sd * sizeof(RgXSeed);
+	unsigned long long at = 0;
+	if (lane == 0) at = atomicAdd(X.cursor, bytes);
+	at = (unsigned long long)uni64((long long)at);
+	if (at + bytes > X.cap) return 6;
+	RgXHdr *H = (RgXHdr*)(X.base + at);
+	RgXChain *XC = (RgXChain*)(H + 1);
+	RgXSeed *XS = (RgXSeed*)(XC + n_surv);
+	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->pad = 0; }
+	int so = 0;
+	for (int ci = 0; ci < n_surv; ++ci) {
+		const int c = uni(S.ord[ci]);
+		const RgChain chn = S.ch[c];
+		const int n_main = uni(chn.n_seeds), n_extra = uni(chn.n_extra);
+		if (lane == 0) { RgXChain x; x.pos = chn.pos; x.rid = chn.rid; x.seed_off = so; x.n_main = (unsigned short)n_main; x.n_extra = (unsigned short)n_extra; x.pad = 0; XC[ci] = x; }
+		if (n_main == 1 && n_extra == 0) {
+			if (lane == 0) { const int o = chn.seed0; RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.bad = (unsigned char)((S.s_extra[o] >> 1) & 1); x.pad[0] = x.pad[1] = x.pad[2] = 0; XS[so] = x; }
+			so += 1;
+			continue;
+		}
+		for (int pass = 0; pass < 2; ++pass) {
+			if (pass == 1 && n_extra == 0) break;
+			int nl = 0;
+			for (int base = 0; base < tot; base += 64) {
+				const int o = base + lane;
+				const bool in = o < tot && S.s_chain[o] == c && (int)(S.s_extra[o] & 1) == pass;
+				const unsigned long long b = __ballot(in);
+				if (in) { RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.bad = (unsigned char)((S.s_extra[o] >> 1) & 1); x.pad[0] = x.pad[1] = x.pad[2] = 0; XS[so + nl + __popcll(b & lt_mask)] = x; }
+				nl += __popcll(b);
+			}
+			so += nl;
+		}
+	}
+	if (lane == 0) { X.xoff[t] = (long long)at; X.xlist[atomicAdd(X.xcount, 1u)] = t; }
+	return 11;
+}
+
 // One strand search, SA intervals -> regions, by one wavefront.  Returns 0 or the reason the task is declined:
 //   1 seeding overflowed   9 read longer than RG_QCAP or long enough for the seed-SW filter (memchain.c:544)   8 intervals > ICAP
 //   2 occurrences > SCAP or an interval beyond max_occ      3 chains > CCAP      4 two chains start at the same position
 //   6 regions > RCAP      10 an over-represented interval has to be walked past max_occ (memchain.c:325-326)
-template <typename Store>
+template <typename Store, bool SPLIT = false>
 __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
-                       unsigned long long *counters, const int *gap, const long long *ctg)
+                       unsigned long long *counters, const int *gap, const long long *ctg, const RgXPool *X = nullptr, int task_id = 0)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -341,6 +417,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		if (l_query >= 1 && !(min_l > 0.05f * l_query)) return 9;
 	}
 	if (n_iv == 0 || l_query < P.min_seed_len) return 0;
+	for (int i = lane; i < l_query; i += 64) D.q[i] = query[i];   // the read, for the seed tests and the extensions (ordered by the stage barriers below)
 
 	// ---- A. intervals, ordered by info (ks_introsort(mem_intv), memchain.c:105; equal keys are identical records)
 	// With positions looked up beforehand (k_occ), posl holds them interval by interval in the order the seeding kernel
@@ -446,7 +523,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		if (S.s_rid[o] < 0) continue;
 		const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
 		int bad = 0;
-		for (int i = 0; i < ln; ++i) { const int r = dev_ref_base(ix.pac, l_pac, rb + i), q = query[qb + i]; bad |= (r == 3 && q == 1) || (r == 0 && q == 2); }
+		for (int i = 0; i < ln; ++i) { const int r = dev_ref_base(ix.pac, l_pac, rb + i), q = D.q[qb + i]; bad |= (r == 3 && q == 1) || (r == 0 && q == 2); }
 		if (bad) S.s_extra[o] = 2;
 	}
 	WAVE_SYNC();
@@ -499,7 +576,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			const RgChain c = S.ch[lower];
 			if (rid == c.rid) {
 				if (qbeg >= c.first_q && qbeg + len <= c.last_q + c.last_len && rbeg >= c.pos && rbeg + len <= c.last_r + c.last_len) {
-					if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.s_extra[o] |= 1; S.ch[lower].has_extra = 1; }
+					if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.s_extra[o] |= 1; S.ch[lower].n_extra = (unsigned short)(c.n_extra + 1); }
 					merged = 1;
 				} else if (!((c.last_r < l_pac || c.pos < l_pac) && rbeg >= l_pac)) {
 					const long long qdist = qbeg - c.last_q, rdist = rbeg - c.last_r;
@@ -531,7 +608,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 				RgChain c;
 				c.pos = c.last_r = rbeg; c.rid = rid; c.endr_off = len; c.first_q = c.last_q = (short)qbeg; c.last_len = (short)len;
 				c.wq = c.wr = (short)len; c.endq = (short)(qbeg + len); c.first = -1; c.w = 0; c.n_seeds = 1; c.seed0 = (unsigned short)o;
-				c.kept = 0; c.is_alt = ix.ctg_alt[rid] ? 1 : 0; c.has_extra = 0; c.pad = 0;
+				c.kept = 0; c.is_alt = ix.ctg_alt[rid] ? 1 : 0; c.n_extra = 0;
 				S.ch[nc] = c;
 				S.s_chain[o] = (decltype(S.s_chain[0] + 0))nc;
 				if (Store::NODES) rg_bt_put(S, rbeg, nc);
@@ -698,13 +775,18 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 	}
 	RG_STAGE(5);
+	if (SPLIT) { // the chain-to-region loop runs in k_c2r
+		const int st = rg_export(S, task_id, tot, frac_rep, *X, lane);
+		RG_STAGE(6);
+		return st;
+	}
 	// ---- E. chains -> regions (mem_chain2region, memchain.c:873-904)
 	const int nk = uni(S.n_chains), ns = tot;
 	for (int ci = 0; ci < nk; ++ci) {
 		const int c = uni(S.ord[ci]);
 		const RgChain chn = S.ch[c];
 		const long long ch_pos = uni64(chn.pos);
-		const int ch_has_extra = uni(chn.has_extra);
+		const int ch_has_extra = uni(chn.n_extra) != 0;
 		const int single = uni(chn.n_seeds) == 1;
 		const int seed0 = uni(chn.seed0);
 		// a chain of one seed that fails asymmetric_flt_seed, with no contained seeds to fall back to, comes and goes without a trace:
@@ -736,6 +818,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			rmax0 = rmax0 > far_beg ? rmax0 : far_beg; rmax1 = rmax1 < far_end ? rmax1 : far_end;
 		}
 		const int n0 = uni(S.n_regs);
+		int win_ok = 0;   // 0: not loaded yet, 1: in LDS, -1: too long for it
 		for (int pass = 0; pass < 2; ++pass) {
 			if (pass == 1 && !(uni(S.n_regs) == n0 && ch_has_extra)) break;
 			// the list (seeds or seeds_extra) in arrival order, and its best-first order
@@ -796,6 +879,14 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 					if (uni(i) == nl) { WAVE_SYNC(); if (lane == 0) S.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
+				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
+					const int span = (int)(rmax1 - rmax0);
+					if (span > 0 && span <= RG_WIN) {
+						for (int i = lane; i < span; i += 64) D.win[i] = (uint8_t)dev_ref_base(ix.pac, l_pac, rmax0 + i);
+						win_ok = 1;
+						WAVE_SYNC();
+					} else win_ok = -1;
+				}
 				bsx_region_t R; memset(&R, 0, sizeof(R));
 				int aw0 = P.w, aw1 = P.w;
 				const int qe = s_qbeg + s_len;
@@ -817,8 +908,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						RG_STAGE(6);
 						// most extensions of a 150 bp read are shorter than a wavefront is wide: one register entry per lane then,
 						// and none of the per-chunk band tests and carries of the wider form
-						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane);
-						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
+						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? D.win : nullptr, rmax0, D.q, qoff);
+						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? D.win : nullptr, rmax0, D.q, qoff);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
@@ -881,6 +972,215 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 	return status;
 }
 
+// ---- chains -> regions for the strand searches the LDS tiers exported (mem_chain2region + mem_chain2region1, memchain.c:742-904):
+// the same seed loop as stage E of rg_task, over the exported lists.  One wavefront per strand search; nothing but the regions made
+// so far, the read, the current chain's seeds and its reference window live in LDS (5.5 KB per wave), so the launch runs at the
+// occupancy the registers allow.
+#define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
+#define RG_XREGS 24
+struct RgC2r {
+	bsx_region_t regs[RG_XREGS];
+	RgXSeed sd[RG_XSEEDS];
+	unsigned long long srt[RG_XSEEDS];
+	uint8_t q[RG_QCAP];
+	uint8_t win[RG_WIN];
+	int n_regs;
+};
+
+__device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, int l_query, int parent, uint32_t qoff,
+                      const RgXHdr *H, int lane, unsigned long long *counters, const int *gap, const long long *ctg)
+{
+	const long long l_pac = ix.l_pac;
+	long long pf_t = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+	unsigned int pf_ext = 0, pf_rows = 0;
+	const int nk = uni(H->n_chains);
+	const float frac_rep = H->frac_rep;
+	const RgXChain *XC = (const RgXChain*)(H + 1);
+	const RgXSeed *XS = (const RgXSeed*)(XC + nk);
+	if (lane == 0) W.n_regs = 0;
+	for (int i = lane; i < l_query; i += 64) W.q[i] = reads[qoff + i];
+	WAVE_SYNC();
+	for (int ci = 0; ci < nk; ++ci) {
+		const long long ch_pos = uni64(XC[ci].pos);
+		const int rid = uni(XC[ci].rid), seed_off = uni(XC[ci].seed_off), n_main = uni((int)XC[ci].n_main), n_extra = uni((int)XC[ci].n_extra);
+		if (n_main > RG_XSEEDS || n_extra > RG_XSEEDS) return 2;
+		// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp
+		long long rmax0 = l_pac << 1, rmax1 = 0;
+		for (int o = lane; o < n_main; o += 64) {
+			const RgXSeed sd = XS[seed_off + o];
+			const long long b = sd.rbeg - (sd.qbeg + rg_gap(gap, P, sd.qbeg));
+			const long long e = sd.rbeg + sd.len + ((l_query - sd.qbeg - sd.len) + rg_gap(gap, P, l_query - sd.qbeg - sd.len));
+			rmax0 = rmax0 < b ? rmax0 : b; rmax1 = rmax1 > e ? rmax1 : e;
+		}
+		rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1));
+		rmax0 = rmax0 > 0 ? rmax0 : 0; rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
+		if (rmax0 < l_pac && l_pac < rmax1) { if (ch_pos < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+		{
+			const int is_rev = ch_pos >= l_pac;
+			long long far_beg = uni64(ctg[rid]), far_end = uni64(ctg[rid + 1]);
+			if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+			rmax0 = rmax0 > far_beg ? rmax0 : far_beg; rmax1 = rmax1 < far_end ? rmax1 : far_end;
+		}
+		const int n0 = uni(W.n_regs);
+		int win_ok = 0;
+		for (int pass = 0; pass < 2; ++pass) {
+			if (pass == 1 && !(uni(W.n_regs) == n0 && n_extra > 0)) break;
+			const int nl = pass ? n_extra : n_main;
+			const RgXSeed *src = XS + seed_off + (pass ? n_main : 0);
+			WAVE_SYNC();
+			for (int i = lane; i < nl; i += 64) W.sd[i] = src[i];
+			WAVE_SYNC();
+			for (int i = lane; i < nl; i += 64) { // keys score<<32|i are unique: rank by counting (ks_introsort_64, memchain.c:752)
+				const unsigned long long key = (unsigned long long)(unsigned)W.sd[i].len << 32 | (unsigned)i;
+				int r = 0;
+				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)W.sd[k].len << 32 | (unsigned)k) < key;
+				W.srt[r] = key;
+			}
+			WAVE_SYNC();
+			for (int k = nl - 1; k >= 0; --k) {
+				const int si = uni((int)(uint32_t)W.srt[k]);
+				const RgXSeed sd = W.sd[si];
+				if (uni((int)sd.bad)) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
+				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
+				// contained in a region of this strand search? (memchain.c:761-819)
+				int u;
+				const int nr = uni(W.n_regs);
+				for (u = 0; u < nr; ++u) {
+					const bsx_region_t &rg = W.regs[u];
+					if (s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) continue;
+					if (s_len - rg.seedlen0 > .1 * l_query) continue;
+					int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
+					int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+					int w = max_gap < rg.w ? max_gap : rg.w;
+					if (qd - rd < w && rd - qd < w) break;
+					qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
+					max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+					w = max_gap < rg.w ? max_gap : rg.w;
+					if (qd - rd < w && rd - qd < w) break;
+				}
+				u = uni(u);
+				if (u < nr) {
+					int i;
+					for (i = k + 1; i < nl; ++i) {
+						if (W.srt[i] == 0) continue;
+						const RgXSeed td = W.sd[(int)(uint32_t)W.srt[i]];
+						const long long t_rbeg = td.rbeg; const int t_qbeg = td.qbeg, t_len = td.len;
+						if (t_len < s_len * .95) continue;
+						if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
+						if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) break;
+					}
+					if (uni(i) == nl) { WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
+				}
+				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
+				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
+					const int span = (int)(rmax1 - rmax0);
+					if (span > 0 && span <= RG_WIN) {
+						for (int i = lane; i < span; i += 64) W.win[i] = (uint8_t)dev_ref_base(ix.pac, l_pac, rmax0 + i);
+						win_ok = 1;
+						WAVE_SYNC();
+					} else win_ok = -1;
+				}
+				bsx_region_t R; memset(&R, 0, sizeof(R));
+				int aw0 = P.w, aw1 = P.w;
+				const int qe = s_qbeg + s_len;
+				R.score = R.truesc = -1; R.rid = rid;
+				for (int side = 0; side < 2; ++side) {
+					if (side == 0 && s_qbeg == 0) { R.score = R.truesc = s_len * P.a; R.qb = 0; R.rb = s_rbeg; continue; }
+					if (side == 1 && qe == l_query) { R.qe = l_query; R.re = s_rbeg + s_len; continue; }
+					const int sc0 = R.score, clip = side ? P.pen_clip3 : P.pen_clip5;
+					int aw = P.w;
+					bsx_ext_res_t res; res.score = -1; res.qle = res.tle = res.gtle = 0; res.gscore = -1; res.max_off = 0;
+					bsx_ext_job_t J;
+					J.parent = (uint8_t)parent; J.pad = 0; J.end_bonus = clip;
+					if (side == 0) { J.qoff = qoff + (uint32_t)s_qbeg - 1; J.qdir = -1; J.qlen = s_qbeg; J.tpos = s_rbeg - 1; J.tdir = -1; J.tlen = (int)(s_rbeg - rmax0); J.h0 = s_len * P.a; }
+					else { J.qoff = qoff + (uint32_t)qe; J.qdir = 1; J.qlen = l_query - qe; J.tpos = s_rbeg + s_len; J.tdir = 1; J.tlen = (int)(rmax1 - (s_rbeg + s_len)); J.h0 = sc0; }
+					for (int i = 0; i < 2; ++i) {
+						const int prev = R.score;
+						aw = P.w << i;
+						J.w = aw;
+						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + 6], (unsigned long long)(now_ - pf_t)); pf_t = now_; }
+						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
+						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
+						R.score = res.score;
+						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + 7], (unsigned long long)(now_ - pf_t)); pf_t = now_; }
+						++pf_ext; pf_rows += (unsigned int)(res.tle > res.gtle ? res.tle : res.gtle);
+						if (R.score == prev || res.max_off < (aw >> 1) + (aw >> 2)) break;
+					}
+					const int local = res.gscore <= 0 || res.gscore <= R.score - clip;
+					if (side == 0) {
+						aw0 = aw;
+						if (local) { R.qb = s_qbeg - res.qle; R.rb = s_rbeg - res.tle; R.truesc = R.score; }
+						else { R.qb = 0; R.rb = s_rbeg - res.gtle; R.truesc = res.gscore; }
+					} else {
+						aw1 = aw;
+						if (local) { R.qe = qe + res.qle; R.re = s_rbeg + s_len + res.tle; R.truesc += R.score - sc0; }
+						else { R.qe = l_query; R.re = s_rbeg + s_len + res.gtle; R.truesc += res.gscore - sc0; }
+					}
+				}
+				R.bss = (uint8_t)RG_BSS(parent, l_pac, R.rb); R.parent = (uint8_t)parent;
+				if (RG_BSS(parent, l_pac, R.re) != R.bss) continue;   // crosses the strand boundary (memchain.c:846-849)
+				int cov = 0;
+				for (int i = lane; i < nl; i += 64) {
+					const RgXSeed td = W.sd[i];
+					if (td.qbeg >= R.qb && td.qbeg + td.len <= R.qe && td.rbeg >= R.rb && td.rbeg + td.len <= R.re) cov += td.len;
+				}
+				R.seedcov = uni(wave_sum_i32(cov));
+				R.w = aw0 > aw1 ? aw0 : aw1; R.seedlen0 = s_len; R.frac_rep = frac_rep;
+				if (uni(W.n_regs) == RG_XREGS) return 6;
+				WAVE_SYNC();
+				if (lane == 0) { W.regs[W.n_regs] = R; ++W.n_regs; }
+				WAVE_SYNC();
+			}
+		}
+	}
+	if (P.prof && lane == 0) { atomicAdd(&counters[32 + 6], (unsigned long long)((long long)__builtin_readcyclecounter() - pf_t)); atomicAdd(&counters[40], (unsigned long long)pf_ext); atomicAdd(&counters[41], (unsigned long long)pf_rows); }
+	return 0;
+}
+
+__global__ void __launch_bounds__(256, 4)
+k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X,
+      bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+      unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters)
+{
+	__shared__ RgC2r lds[4];
+	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
+	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
+	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
+	__syncthreads();
+	const int lane = wave_lane();
+	RgC2r &W = lds[threadIdx.x >> 6];
+	const int n = (int)*X.xcount;
+	for (;;) {
+		int i = 0;
+		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
+		i = uni(__shfl(i, 0));
+		if (i >= n) break;
+		const int t = uni(X.xlist[i]);
+		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent);
+		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
+		const RgXHdr *H = (const RgXHdr*)(X.base + uni64(X.xoff[t]));
+		int status = rg_c2r(W, ix, sc, P, reads, l_query, parent, qoff, H, lane, counters, gap_tab, ctg_tab);
+		WAVE_SYNC();
+		if (lane == 0) { // publish (as rg_publish)
+			const int nr = status ? 0 : W.n_regs;
+			unsigned long long base = 0;
+			if (nr > 0) {
+				base = atomicAdd(out_cursor, (unsigned long long)nr);
+				if (base + nr <= out_cap) for (int k = 0; k < nr; ++k) out[base + k] = W.regs[k];
+				else status = 7;
+			}
+			reg_off[t] = (long long)base;
+			reg_n[t] = status ? -status : nr;
+			if (status == 2 || status == 6) next_list[atomicAdd(next_count, 1u)] = t;
+		}
+		WAVE_SYNC();
+	}
+}
+
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
 template <int OCC>
 __global__ void __launch_bounds__(256, OCC)
@@ -888,7 +1188,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
           unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-          const long long *pos_off, const unsigned long long *pos, const unsigned char *cls)
+          const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, RgXPool X)
 {
 	__shared__ RgSmall lds[4];
 	__shared__ RgDp dp[4];
@@ -915,7 +1215,8 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
+		int status = rg_task<RgSmall, true>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		if (status == 11) continue;   // exported: k_c2r makes and publishes its regions
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
 	}
@@ -965,7 +1266,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
               bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
               const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-              unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+              unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X)
 {
 	__shared__ RgMid lds[2];
 	__shared__ RgDp dp[2];
@@ -988,7 +1289,8 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
+		int status = rg_task<RgMid, true>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
@@ -1081,25 +1383,34 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls)
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA)
 {
+	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 3;   // waves per SIMD the register allocation targets (the tables in LDS allow three workgroups per CU)
 	if (occ >= 4)
 		hipLaunchKernelGGL(k_regions<4>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls);
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 	else
 		hipLaunchKernelGGL(k_regions<3>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls);
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 }
 
 void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA)
 {
+	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	hipLaunchKernelGGL(k_regions_mid, dim3(grid), dim3(128), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos);
+	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X);
+}
+void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                const RgXPoolArg &XA, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters)
+{
+	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	hipLaunchKernelGGL(k_c2r, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters);
 }
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,

@@ -20,17 +20,24 @@ void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
 // Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
 // regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.
 size_t regions_slab_bytes(int tier);
+// where the LDS tiers leave the chains that survive the filter for launch_c2r (chains -> regions): a byte pool with a bump cursor,
+// the block of task t at xoff[t], and the list of tasks that have one
+struct RgXPoolArg { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls);   // cls[t] != 0: not for this tier (launch_occ)
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &X);   // cls[t] != 0: not for this tier (launch_occ)
 // the tier in between: LDS tables four times the first tier's; consumes the first tier's list, appends to the second tier's
 void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos);
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X);
+// chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
+void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

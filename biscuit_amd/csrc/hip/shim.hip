@@ -25,7 +25,7 @@ struct Lane {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -120,7 +120,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -526,6 +526,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const unsigned long long pos_cap = getenv("BSX_POS_CAP") ? strtoull(getenv("BSX_POS_CAP"), 0, 10) : (unsigned long long)n * 384 + (1u << 20);
 	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
 	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
+	// what the LDS tiers export for the chains -> regions launch: ~0.5 KB per strand search (a task that finds no room goes to the next tier)
+	const unsigned long long xcap = (unsigned long long)n * 1024 + (64u << 20);
+	if ((rc = L.xpool.reserve((size_t)xcap)) != BSX_OK) return rc;
+	if ((rc = L.xmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
@@ -536,8 +540,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
 	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
 	//                       [10] count of what the LDS tier in between hands to tier 2  [11] that tier's cursor
+	//                       u64 slot 13: cursor of the export pool; slot 14 as two u32: exported task count, k_c2r's cursor
 	unsigned long long *ctr = dev_counters(L);
 	unsigned int *c32 = (unsigned int*)(ctr + 7);
+	RgXPoolArg XA;
+	XA.base = (unsigned char*)L.xpool.p; XA.cap = xcap; XA.cursor = ctr + 13; XA.xoff = (long long*)L.xmeta.p; XA.xlist = (int*)((char*)L.xmeta.p + (size_t)n * 8);
+	XA.xcount = (unsigned int*)(ctr + 14);
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
 	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
@@ -551,13 +559,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev4, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
 	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
-	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls);
+	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls, XA);
 	HIPCHK(hipEventRecord(L.ev3, L.st));
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
 	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
 	if (use_mid)
 		launch_regions_mid(L.st, d->n_cu * 4, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos);
+		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA);
+	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
+	launch_c2r(L.st, d->n_cu * 8, d->ix, d->sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
+	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr);
 	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,

@@ -43,8 +43,8 @@ def table(path):
 
 lines = ["# rocprofv3 PMC summary (%s; MI355X, gfx950, ROCm 7.2)\n" % tag,
          "One counter group per run, never combined with sys/hip traces (tools/profile_round.sh, tools/pmc_seed.sh):\n",
-         "    rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -d <dir> -o bench -- python bench.py --genome-mbp 128 --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline\n",
-         "Workload: one chunk = 1,066,666 reads (2x150 bp) vs the synthetic 128 Mbp genome, chunks one at a time (no overlap);",
+         "    rocprofv3 --kernel-trace --pmc <COUNTERS> --output-format csv -d <dir> -o bench -- python bench.py --genome-mbp $GENOME_MBP --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline\n",
+         "Workload: one chunk = 1,066,666 reads (2x150 bp) vs the synthetic genome of $GENOME_MBP Mbp (default 3100: hg38-sized), chunks one at a time (no overlap);",
          "sums over all dispatches of a kernel in that run.  FETCH_SIZE / WRITE_SIZE are KiB as reported; the MI355X guide notes that",
          "FETCH_SIZE under-reports wide coalesced reads 2x on gfx950 and is uncalibrated for other patterns (these kernels gather 64-byte",
          "blocks, 16 B per load), so the JSON's `traffic` stays null.\n"]
@@ -87,21 +87,33 @@ def pick(agg, kernel):
 
 
 fs, ws, hm = pmc_dir("FETCH_SIZE"), pmc_dir("WRITE_SIZE"), pmc_dir("TCC_HIT_sum_TCC_MISS_sum")
+ins = pmc_dir("SQ_WAVES_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS")
+mbp = int(round(float(os.environ.get("GENOME_MBP", "3100"))))
 if fs and ws:
     traffic = {}
     for kern in ("k_seed", "k_occ", "k_regions"):
-        traffic[kern] = {"FETCH_SIZE_KiB": pick(fs, kern).get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": pick(ws, kern).get("WRITE_SIZE", 0.0)}
+        # k_regions: every tier (k_regions<>, k_regions_mid, k_regions_slab<>) -- pick() matches the name prefix
+        def pk(agg, kern=kern):
+            tot = collections.defaultdict(float)
+            for k, v in agg.items():
+                if k == kern or k.startswith(kern + "<") or (kern == "k_regions" and k.startswith("k_regions")):
+                    for c, x in v.items():
+                        tot[c] += x
+            return tot
+        traffic[kern] = {"FETCH_SIZE_KiB": pk(fs).get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": pk(ws).get("WRITE_SIZE", 0.0)}
         if hm:
-            traffic[kern]["TCC_HIT"] = pick(hm, kern).get("TCC_HIT_sum", 0.0)
-            traffic[kern]["TCC_MISS"] = pick(hm, kern).get("TCC_MISS_sum", 0.0)
-    traffic["_note"] = ("rocprofv3 --pmc passes of `python bench.py --genome-mbp 128 --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline` "
-                        "(one chunk of 1,066,666 reads; tools/profile_round.sh), summed over the dispatches of each kernel.  Calibration on this "
-                        "access pattern: k_occ reads exactly one 64-byte FM block per LF step (4 x 16 B loads per lane) plus 8 B per lookup and 16 B per "
-                        "occurrence; with the files' 1-in-32 suffix-array sample (an earlier pass of this round) its FETCH_SIZE was 0.88 x that byte count "
-                        "at a 7 % L2 hit rate, i.e. FETCH_SIZE is within a few percent of the bytes that miss L2 for 64-byte gathers (not the 1/2 the "
-                        "guide measured for wide coalesced streams).")
+            traffic[kern]["TCC_HIT"] = pk(hm).get("TCC_HIT_sum", 0.0)
+            traffic[kern]["TCC_MISS"] = pk(hm).get("TCC_MISS_sum", 0.0)
+        if ins:
+            for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+                traffic[kern][c] = pk(ins).get(c, 0.0)
+    traffic["_note"] = ("rocprofv3 --pmc passes (one counter group per run, with --kernel-trace only) of `python bench.py --genome-mbp %d --steps 1 --warmup 0 "
+                        "--no-cpu-baseline --no-pipeline` (one chunk of 1,066,666 reads; tools/profile_round.sh), summed over the dispatches of each kernel "
+                        "family.  FETCH_SIZE calibration on this access pattern (r01): k_occ reads exactly one 64-byte FM block per LF step; its FETCH_SIZE "
+                        "was 0.88 x that byte count at a 7 %% L2 hit rate, i.e. for 64-byte gathers FETCH_SIZE is within a few percent of the bytes that "
+                        "miss L2 (not the 1/2 the guide measured for wide coalesced streams)." % mbp)
     traffic["_reads_per_chunk"] = 1066666
-    json.dump(traffic, open(os.path.join(out, "%s_traffic.json" % tag), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, "%s_pmc_%dmbp.json" % (tag, mbp)), "w"), indent=1)
 
 kt = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
 if kt:
