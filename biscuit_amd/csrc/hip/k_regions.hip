@@ -13,6 +13,7 @@
 // and two chains starting at the same reference position (there the reference's B-tree shape decides).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "dev_common.hpp"
 #include "wave.hpp"
 #include "kernels.h"
@@ -1180,6 +1181,543 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 		WAVE_SYNC();
 	}
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Chains -> regions in lock-step rounds, a LANE per strand search and a LANE per extension.
+//
+// k_c2r above gives every strand search a wavefront: its seed loop is a few hundred scalar steps between extensions, and an
+// extension row costs ~400 instructions, two thirds of them scalar (band bookkeeping, uniform branches, DPP wait states), whatever
+// the width of the band -- the launch is bound by the one scalar unit a CU has (PMC: 9.4e10 SALU for 1.65e7 extensions).  The work
+// itself is the opposite of wave-shaped: a band of a dozen live cells, sequential along the row (F), a strictly ordered series of
+// such calls per strand search, millions of strand searches.  So the roles are turned: each lane runs the reference's own loop
+// nest for one job, nothing crosses lanes, and the parallelism comes from the number of jobs in flight.
+//   k_c2r_ctrl   a lane per strand search: mem_chain2region(1) (memchain.c:742-904) as a resumable state machine; it runs until the
+//                strand search needs an extension (posts one job: left or right side of one seed, one band width) or is finished
+//                (publishes its regions)
+//   k_ext_lane   a lane per job: ksw_extend2 (ksw.c:380-479) cell by cell; the eh[] row of the job lives in LDS, one 32-bit word
+//                per column (H 14 bits, E 14 bits, the query base 3 bits), lane-interleaved
+// and the two alternate: round r extends the r-th call of every strand search that has one.  State between rounds lives in HBM.
+// A strand search whose lists or region table outgrow the fixed slots, or that is still going after RG_LROUNDS rounds, is
+// handed to the HBM tier like any other that outgrows a tier.
+#define RG_LROUNDS 128
+#define RG_LSEEDS 128     // seeds of one list held in the rank array
+#define RG_LREGS 24
+
+struct RgLState {
+	int ci, k, n0, sc0, aw0, aw1, rid, n_regs;
+	short pass, stage, tryi, opened;   // stage: 0 no job out, 1 left extension out, 2 right extension out
+	long long rmax0, rmax1;
+	bsx_region_t cur;
+};
+struct RgLanes {   // everything k_c2r_ctrl / k_ext_lane keep between rounds (device pointers)
+	RgLState *state;            // per exported strand search (slot = index in xlist)
+	bsx_region_t *regs;         // RG_LREGS per slot
+	unsigned char *rank;        // RG_LSEEDS per slot: seed index at each rank of the open list (bit 7: dropped, memchain.c:817)
+	int *act[2];                // slots with a job out, by round parity
+	bsx_ext_job_t *jobs[2];
+	bsx_ext_res_t *res[2];
+	unsigned int *n_act;        // [0, 192): jobs posted in each round; [192, 384): k_ext_lane's job cursor of each round; then tracing sums
+};
+
+__device__ __forceinline__ void rgl_left_job(const RegParams &P, const RgLState &S, const RgXSeed &sd, uint32_t qoff, int parent, bsx_ext_job_t &J)
+{
+	J.qoff = qoff + (uint32_t)sd.qbeg - 1; J.qdir = -1; J.qlen = sd.qbeg; J.tpos = sd.rbeg - 1; J.tdir = -1; J.tlen = (int)(sd.rbeg - S.rmax0);
+	J.h0 = sd.len * P.a; J.w = P.w << S.tryi; J.end_bonus = P.pen_clip5; J.parent = (uint8_t)parent; J.pad = 0;
+}
+__device__ __forceinline__ void rgl_right_job(const RegParams &P, const RgLState &S, const RgXSeed &sd, uint32_t qoff, int parent, int l_query, bsx_ext_job_t &J)
+{
+	const int qe = sd.qbeg + sd.len;
+	J.qoff = qoff + (uint32_t)qe; J.qdir = 1; J.qlen = l_query - qe; J.tpos = sd.rbeg + sd.len; J.tdir = 1; J.tlen = (int)(S.rmax1 - (sd.rbeg + sd.len));
+	J.h0 = S.sc0; J.w = P.w << S.tryi; J.end_bonus = P.pen_clip3; J.parent = (uint8_t)parent; J.pad = 0;
+}
+
+// One strand search, until it posts a job (returns 1), is finished (0), or outgrows the slots (< 0: the status to decline with).
+// `have_res`: the result of the job posted in the previous round.
+__device__ int rgl_step(RgLState &S, bsx_region_t *regs, unsigned char *rank, const DevIndex &ix, const RegParams &P, int l_query, int parent, uint32_t qoff,
+                        const RgXHdr *H, const int *gap, const long long *ctg, bool have_res, const bsx_ext_res_t &res, bsx_ext_job_t &J)
+{
+	const long long l_pac = ix.l_pac;
+	const int nk = H->n_chains;
+	const RgXChain *XC = (const RgXChain*)(H + 1);
+	const RgXSeed *XS = (const RgXSeed*)(XC + nk);
+	bool to_right = false, to_finish = false;
+	if (have_res) { // feed the result back (left: memchain.c:641-671, right: memchain.c:700-729)
+		const RgXChain ch = XC[S.ci];
+		const RgXSeed sd = XS[ch.seed_off + (S.pass ? ch.n_main : 0) + (rank[S.k] & 127)];
+		const int prev = S.cur.score, aw = P.w << S.tryi;
+		S.cur.score = res.score;
+		const bool again = !(S.cur.score == prev || res.max_off < (aw >> 1) + (aw >> 2)) && S.tryi + 1 < 2;   // MAX_BAND_TRY = 2
+		if (S.stage == 1) {
+			S.aw0 = aw;
+			if (again) { ++S.tryi; rgl_left_job(P, S, sd, qoff, parent, J); return 1; }
+			if (res.gscore <= 0 || res.gscore <= S.cur.score - P.pen_clip5) { S.cur.qb = sd.qbeg - res.qle; S.cur.rb = sd.rbeg - res.tle; S.cur.truesc = S.cur.score; }
+			else { S.cur.qb = 0; S.cur.rb = sd.rbeg - res.gtle; S.cur.truesc = res.gscore; }
+			to_right = true;
+		} else {
+			const int qe = sd.qbeg + sd.len;
+			S.aw1 = aw;
+			if (again) { ++S.tryi; rgl_right_job(P, S, sd, qoff, parent, l_query, J); return 1; }
+			if (res.gscore <= 0 || res.gscore <= S.cur.score - P.pen_clip3) { S.cur.qe = qe + res.qle; S.cur.re = sd.rbeg + sd.len + res.tle; S.cur.truesc += S.cur.score - S.sc0; }
+			else { S.cur.qe = l_query; S.cur.re = sd.rbeg + sd.len + res.gtle; S.cur.truesc += res.gscore - S.sc0; }
+			to_finish = true;
+		}
+	}
+	for (;;) {
+		if (S.ci >= nk) return 0;
+		const RgXChain ch = XC[S.ci];
+		const int n_main = ch.n_main, n_extra = ch.n_extra;
+		if (!S.opened) {
+			if (n_main > RG_LSEEDS || n_extra > RG_LSEEDS) return -2;
+			// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp
+			long long r0 = l_pac << 1, r1 = 0;
+			for (int o = 0; o < n_main; ++o) {
+				const RgXSeed sd = XS[ch.seed_off + o];
+				const long long b = sd.rbeg - (sd.qbeg + rg_gap(gap, P, sd.qbeg));
+				const long long e = sd.rbeg + sd.len + ((l_query - sd.qbeg - sd.len) + rg_gap(gap, P, l_query - sd.qbeg - sd.len));
+				r0 = r0 < b ? r0 : b; r1 = r1 > e ? r1 : e;
+			}
+			r0 = r0 > 0 ? r0 : 0; r1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
+			if (r0 < l_pac && l_pac < r1) { if (ch.pos < l_pac) r1 = l_pac; else r0 = l_pac; }
+			{
+				long long far_beg = ctg[ch.rid], far_end = ctg[ch.rid + 1];
+				if (ch.pos >= l_pac) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+				r0 = r0 > far_beg ? r0 : far_beg; r1 = r1 < far_end ? r1 : far_end;
+			}
+			S.rmax0 = r0; S.rmax1 = r1; S.rid = ch.rid; S.n0 = S.n_regs; S.pass = 0; S.opened = 1; S.stage = 0;
+			S.k = -2;   // list not ranked yet
+		}
+		const int nl = S.pass ? n_extra : n_main;
+		const RgXSeed *list = XS + ch.seed_off + (S.pass ? n_main : 0);
+		if (S.k == -2) { // best-first order: ranks by (len, index) ascending (ks_introsort_64 on score<<32|i, memchain.c:748-752), insertion sort
+			for (int i = 0; i < nl; ++i) {
+				const int li = list[i].len;
+				int p = i;
+				while (p > 0 && list[rank[p - 1]].len > li) { rank[p] = rank[p - 1]; --p; }   // equal lengths keep index order
+				rank[p] = (unsigned char)i;
+			}
+			S.k = nl - 1;
+		}
+		RgXSeed sd_cur; sd_cur.rbeg = 0; sd_cur.qbeg = sd_cur.len = 0; sd_cur.bad = 0;
+		if (to_right || to_finish) sd_cur = list[rank[S.k] & 127];
+		bool finish = to_finish;
+		if (to_right) { // after the left side is settled: skip or post the right extension (memchain.c:689-693)
+			to_right = false;
+			if (sd_cur.qbeg + sd_cur.len == l_query) { S.cur.qe = l_query; S.cur.re = sd_cur.rbeg + sd_cur.len; finish = true; }
+			else { S.sc0 = S.cur.score; S.tryi = 0; S.stage = 2; rgl_right_job(P, S, sd_cur, qoff, parent, l_query, J); return 1; }
+		}
+		if (finish) { // region complete: strand-boundary check, seed coverage, book-keeping (memchain.c:839-869)
+			to_finish = false;
+			bsx_region_t &R = S.cur;
+			R.bss = (uint8_t)RG_BSS(parent, l_pac, R.rb); R.parent = (uint8_t)parent;
+			if (RG_BSS(parent, l_pac, R.re) == R.bss) {
+				int cov = 0;
+				for (int i = 0; i < nl; ++i) {
+					const RgXSeed td = list[i];
+					if (td.qbeg >= R.qb && td.qbeg + td.len <= R.qe && td.rbeg >= R.rb && td.rbeg + td.len <= R.re) cov += td.len;
+				}
+				R.seedcov = cov; R.w = S.aw0 > S.aw1 ? S.aw0 : S.aw1; R.seedlen0 = sd_cur.len; R.frac_rep = H->frac_rep;
+				if (S.n_regs == RG_LREGS) return -6;
+				regs[S.n_regs++] = R;
+			}
+			--S.k; S.stage = 0;
+		}
+		bool posted = false;
+		while (S.k >= 0) {
+			const int si = rank[S.k] & 127;
+			const RgXSeed sd = list[si];
+			if (sd.bad) { --S.k; continue; }   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
+			// is the seed inside a region this strand search already produced? (memchain.c:761-790)
+			int u;
+			for (u = 0; u < S.n_regs; ++u) {
+				const bsx_region_t rg = regs[u];
+				if (sd.rbeg < rg.rb || sd.rbeg + sd.len > rg.re || sd.qbeg < rg.qb || sd.qbeg + sd.len > rg.qe) continue;
+				if (sd.len - rg.seedlen0 > .1 * l_query) continue;
+				int qd = sd.qbeg - rg.qb; long long rd = sd.rbeg - rg.rb;
+				int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+				int w = max_gap < rg.w ? max_gap : rg.w;
+				if (qd - rd < w && rd - qd < w) break;
+				qd = rg.qe - (sd.qbeg + sd.len); rd = rg.re - (sd.rbeg + sd.len);
+				max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+				w = max_gap < rg.w ? max_gap : rg.w;
+				if (qd - rd < w && rd - qd < w) break;
+			}
+			if (u < S.n_regs) { // contained: extend anyway only if an overlapping long seed disagrees (memchain.c:794-819)
+				int i;
+				for (i = S.k + 1; i < nl; ++i) {
+					if (rank[i] & 128) continue;
+					const RgXSeed td = list[rank[i]];
+					if (td.len < sd.len * .95) continue;
+					if (sd.qbeg <= td.qbeg && sd.qbeg + sd.len - td.qbeg >= sd.len >> 2 && td.qbeg - sd.qbeg != td.rbeg - sd.rbeg) break;
+					if (td.qbeg <= sd.qbeg && td.qbeg + td.len - sd.qbeg >= sd.len >> 2 && sd.qbeg - td.qbeg != sd.rbeg - td.rbeg) break;
+				}
+				if (i == nl) { rank[S.k] |= 128; --S.k; continue; }
+			}
+			// extend this seed (memchain.c:822-836)
+			memset(&S.cur, 0, sizeof(S.cur));
+			S.aw0 = S.aw1 = P.w;
+			S.cur.score = S.cur.truesc = -1; S.cur.rid = S.rid;
+			if (sd.qbeg == 0) { // nothing to the left (memchain.c:623-626)
+				S.cur.score = S.cur.truesc = sd.len * P.a; S.cur.qb = 0; S.cur.rb = sd.rbeg;
+				to_right = true;
+			} else { S.tryi = 0; S.stage = 1; rgl_left_job(P, S, sd, qoff, parent, J); return 1; }
+			posted = true;   // (not a job: the right side is decided at the top of the outer loop)
+			break;
+		}
+		if (posted) continue;
+		// list exhausted: fall back to the contained seeds if the chain produced nothing (memchain.c:898-901)
+		if (S.pass == 0 && S.n_regs == S.n0 && n_extra > 0) { S.pass = 1; S.k = -2; continue; }
+		++S.ci; S.opened = 0;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_c2r_ctrl(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, RgLanes W, int round,
+           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+           int *next_list, unsigned int *next_count)
+{
+	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
+	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
+	const long long *ctg = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
+	__syncthreads();
+	const unsigned int n = round == 0 ? *X.xcount : W.n_act[round - 1];
+	const int in = (round + 1) & 1, ob = round & 1;   // jobs of round r live in buffer r & 1
+	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+		const int slot = round == 0 ? (int)e : W.act[in][e];
+		const int t = X.xlist[slot];
+		const int l_query = tasks[t].len, parent = tasks[t].parent;
+		const uint32_t qoff = tasks[t].qoff;
+		const RgXHdr *H = (const RgXHdr*)(X.base + X.xoff[t]);
+		RgLState S;
+		bsx_ext_res_t res; res.score = 0; res.qle = res.tle = res.gtle = res.gscore = res.max_off = 0;
+		if (round == 0) { memset(&S, 0, sizeof(S)); }
+		else { S = W.state[slot]; res = W.res[in][e]; }
+		bsx_ext_job_t J;
+		int st = round + 1 >= RG_LROUNDS ? -6 : rgl_step(S, W.regs + (size_t)slot * RG_LREGS, W.rank + (size_t)slot * RG_LSEEDS, ix, P, l_query, parent, qoff, H, gap_tab, ctg, round != 0, res, J);
+		if (round != 0 && res.score == -0x7fffffff) st = -6;   // the extension did not fit the lane kernel's number format
+		if (st == 1) {
+			const unsigned int o = atomicAdd(&W.n_act[round], 1u);
+			W.act[ob][o] = slot; W.jobs[ob][o] = J;
+			W.state[slot] = S;
+		} else {
+			const int nr = st == 0 ? S.n_regs : 0;
+			unsigned long long base = 0;
+			int status = st == 0 ? 0 : -st;
+			if (nr > 0) {
+				base = atomicAdd(out_cursor, (unsigned long long)nr);
+				if (base + nr <= out_cap) { const bsx_region_t *rg = W.regs + (size_t)slot * RG_LREGS; for (int k = 0; k < nr; ++k) out[base + k] = rg[k]; }
+				else status = 7;
+			}
+			reg_off[t] = (long long)base;
+			reg_n[t] = status ? -status : nr;
+			if (status == 2 || status == 6) next_list[atomicAdd(next_count, 1u)] = t;
+		}
+	}
+}
+
+// ksw_extend2 (lib/aln/ksw.c:380-479), one job per lane at a time.  The reference's two nested loops (rows, columns of the band)
+// are turned inside out into a per-lane state machine that does ONE cell per trip of the wave loop: lanes are in different rows and
+// at different columns of bands of different widths, and a wave that ran the loops as written would pay rows(longest job) x
+// band(widest row) -- measured 6x the cells of the average lane.  Lanes take the next job from the round's queue as soon as they
+// finish one, so a wave stays full until the queue drains.  The rare states (next job, next row) run every fourth trip or when many
+// lanes wait, as in k_seed: a wave pays for every state one of its lanes is in.  Nothing in the loop waits for HBM: k_ext_pack
+// (a lane per job, at full occupancy) has gathered the job's query and reference bases into the image of the first DP row.
+// A row lives in this wave's LDS, column j of this lane at eh[j * 64 + lane], one word per column:
+//   bits 0-10 H (the reference's eh[j].h), 11-21 E (eh[j].e), 22-24 the query base of column j, 25-30 the reference bases of rows
+//   3j, 3j+1, 3j+2.  A job never computes more than qlen + w + 1 rows (then the band is empty, ksw.c:418,454) and the band clamp
+//   keeps w <= qlen + a few, so three rows per column hold every row of any job with qlen >= 3; the ones with qlen <= 2 (a few cells)
+//   are done by k_ext_pack itself.
+#define EHL_H(x) ((int)((x) & 0x7ff))
+#define EHL_E(x) ((int)(((x) >> 11) & 0x7ff))
+#define EHL_KEEP 0x7fc00000u
+#define EHL_HE 0x003fffffu
+enum { XL_FETCH = 0, XL_ROW, XL_CELL, XL_ROWEND, XL_SHL, XL_SHR, XL_DONE };
+struct RgLJobHdr { int qlen, tlen, h0, w, moff, decl, pad0, pad1; };   // moff: 0 ctmat, 25 gamat; decl: 1 not for this kernel, 2 done by k_ext_pack
+
+// the job as k_ext_lane wants it: band clamp applied (ksw.c:399-407), first row (ksw.c:395-397) with the bases packed in
+__global__ void __launch_bounds__(256)
+k_ext_pack(DevIndex ix, DevScoring sc, const uint8_t *reads, RgLanes W, int round, int qcap, uint32_t *rows, int row_words)
+{
+	const unsigned int n = W.n_act[round];
+	const int b = round & 1;
+	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+		const bsx_ext_job_t J = W.jobs[b][e];
+		const int8_t *mat = J.parent ? sc.ctmat : sc.gamat;
+		const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
+		const int oe_ins = sc.o_ins + sc.e_ins;
+		int mx = 0;
+		for (int k = 0; k < 25; ++k) mx = mx > mat[k] ? mx : mat[k];
+		RgLJobHdr Hd;
+		Hd.qlen = qlen; Hd.tlen = tlen; Hd.h0 = h0; Hd.moff = J.parent ? 0 : 25; Hd.pad0 = Hd.pad1 = 0;
+		int w = J.w;
+		{
+			int max_ins = (int)((double)(qlen * mx + J.end_bonus - sc.o_ins) / sc.e_ins + 1.);
+			max_ins = max_ins > 1 ? max_ins : 1;
+			w = w < max_ins ? w : max_ins;
+			int max_del = (int)((double)(qlen * mx + J.end_bonus - sc.o_del) / sc.e_del + 1.);
+			max_del = max_del > 1 ? max_del : 1;
+			w = w < max_del ? w : max_del;
+		}
+		Hd.w = w;
+		const int need = tlen < qlen + w + 2 ? tlen : qlen + w + 2;   // rows that can hold a cell
+		Hd.tlen = need;
+		Hd.decl = (qlen > qcap || qlen + 1 + 8 > row_words || (long long)h0 + (long long)qlen * mx >= 2000) ? 1 : 0;
+		if (!Hd.decl && need > 3 * (qlen + 1)) { // qlen <= 2 in practice: a handful of cells, done here with the loops as the reference has them
+			if (qlen > 7) Hd.decl = 1;
+			else {
+				int hh[9], ee[9];
+				for (int c = 0; c <= 8; ++c) { int v = c == 0 ? h0 : h0 - oe_ins - (c - 1) * sc.e_ins; hh[c] = (c <= qlen && v > 0) ? v : 0; ee[c] = 0; }
+				int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
+				const int oe_del = sc.o_del + sc.e_del;
+				for (int i = 0; i < tlen; ++i) {
+					const int t = dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)i * J.tdir);
+					int f = 0, m = 0, mj = -1, h1;
+					if (beg < i - w) beg = i - w;
+					if (end > i + w + 1) end = i + w + 1;
+					if (end > qlen) end = qlen;
+					if (beg == 0) { h1 = h0 - (sc.o_del + sc.e_del * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
+					int j;
+					for (j = beg; j < end; ++j) {
+						const int q = reads[(long long)J.qoff + (long long)j * J.qdir];
+						int M = hh[j], e = ee[j];
+						hh[j] = h1;
+						M = M ? M + mat[t * 5 + q] : 0;
+						int h = M > e ? M : e; h = h > f ? h : f;
+						h1 = h;
+						mj = m > h ? mj : j; m = m > h ? m : h;
+						int tt = M - oe_del; tt = tt > 0 ? tt : 0;
+						e -= sc.e_del; e = e > tt ? e : tt; ee[j] = e;
+						tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+						f -= sc.e_ins; f = f > tt ? f : tt;
+					}
+					hh[end] = h1; ee[end] = 0;
+					if (j == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+					if (m == 0) break;
+					if (m > max) { max = m; max_i = i; max_j = mj; int off = mj - i; off = off < 0 ? -off : off; max_off = max_off > off ? max_off : off; }
+					else if (sc.zdrop > 0) {
+						if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * sc.e_del > sc.zdrop) break; }
+						else { if (max - m - ((mj - max_j) - (i - max_i)) * sc.e_ins > sc.zdrop) break; }
+					}
+					for (j = beg; j < end && hh[j] == 0 && ee[j] == 0; ++j);
+					beg = j;
+					for (j = end; j >= beg && hh[j] == 0 && ee[j] == 0; --j);
+					end = j + 2 < qlen ? j + 2 : qlen;
+				}
+				bsx_ext_res_t r;
+				r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+				W.res[b][e] = r;
+				Hd.decl = 2;
+			}
+		}
+		uint32_t *row = rows + (size_t)e * row_words;   // words 0-7: the header; then one word per column
+		*(RgLJobHdr*)row = Hd;
+		if (Hd.decl) continue;
+		row += 8;
+		for (int c = 0; c <= qlen; ++c) {
+			int v = c == 0 ? h0 : h0 - oe_ins - (c - 1) * sc.e_ins;
+			v = v > 0 ? v : 0;
+			const uint32_t q = c < qlen ? reads[(long long)J.qoff + (long long)c * J.qdir] : 4u;
+			uint32_t tb = 0;
+			for (int k = 0; k < 3; ++k) if (3 * c + k < need) tb |= (uint32_t)dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(3 * c + k) * J.tdir) << (2 * k);
+			row[c] = (uint32_t)v | q << 22 | tb << 25;
+		}
+	}
+}
+
+#define XL_IMG 40   // uint4 per job image: 8 header words + up to 152 columns
+__global__ void __launch_bounds__(64)
+k_ext_lane(DevScoring sc, RgLanes W, int round, const uint32_t *rows, int row_words, unsigned long long *prof)
+{
+	extern __shared__ uint32_t eh_lds[];   // (row_words - 8) x 64 words
+	__shared__ int8_t smat[64];
+	if (threadIdx.x < 25) { smat[threadIdx.x] = sc.ctmat[threadIdx.x]; smat[25 + threadIdx.x] = sc.gamat[threadIdx.x]; }
+	__syncthreads();
+	const unsigned int n = W.n_act[round];
+	const int b = round & 1;
+	unsigned int *cursor = W.n_act + 192 + round;   // next job of this round
+	uint32_t *eh = eh_lds + threadIdx.x;
+	const int lane = (int)threadIdx.x;
+	const int o_del = sc.o_del, e_del = sc.e_del, e_ins = sc.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = sc.o_ins + e_ins, zdrop = sc.zdrop;
+	int state = XL_FETCH;
+	unsigned int e = 0;
+	int qlen = 0, tlen = 0, h0 = 0, w = 0, moff = 0;
+	int i = 0, j = 0, beg = 0, end = 0, f = 0, m = 0, mj = -1, h1 = 0;
+	int max = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	uint32_t srow = 0;   // the five scores of the current row, 6 bits each, biased by 32
+	int ti_cell = 0, ti_slot = 0;   // where the next row's reference base sits: column i / 3, slot i % 3
+	unsigned int n_rows = 0, n_cells = 0, n_jobs = 0, trip = 0;
+	const long long t0 = (long long)__builtin_readcyclecounter();
+	// Jobs are claimed 128 at a time per wave (one atomic, its answer not needed before the range in hand runs out), and every lane
+	// holds the image of its NEXT job in registers, loaded while it works on the current one: nothing in the loop waits for HBM.
+	// the wave's ranges live in LDS (one wave per workgroup): [0] next index to hand out, [1] end of the range in hand, [2] start of the
+	// range claimed ahead.  Any lane may be the one that moves them on: lane 0 is often busy with a cell when others want a job.
+	__shared__ unsigned int pool[4];   // (the wave fence in XL_CLAIM makes other lanes' updates visible to the next claim)
+	if (lane == 0) { const unsigned int a0 = atomicAdd(cursor, 128u), a1 = atomicAdd(cursor, 128u); pool[0] = a0; pool[1] = a0 + 128u; pool[2] = a1; }
+	__syncthreads();
+	uint4 img[XL_IMG];
+	unsigned int e_nxt = 0; bool nxt_valid = false;
+#define XL_CLAIM(want) do { /* lanes with `want` take the next indices of the wave's ranges, in lane order */ \
+		const unsigned long long wm_ = __ballot(want); \
+		if (wm_) { \
+			const unsigned int take_ = (unsigned int)__popcll(wm_), rank_ = (unsigned int)__popcll(wm_ & ((1ull << lane) - 1)); \
+			const unsigned int c0_ = pool[0], c1_ = pool[1], n0_ = pool[2], left_ = c1_ - c0_; \
+			if (want) e_nxt = rank_ < left_ ? c0_ + rank_ : n0_ + (rank_ - left_); \
+			if (lane == __ffsll((long long)wm_) - 1) { \
+				if (take_ > left_) { pool[0] = n0_ + (take_ - left_); pool[1] = n0_ + 128u; pool[2] = atomicAdd(cursor, 128u); } \
+				else pool[0] = c0_ + take_; \
+			} \
+			WAVE_SYNC(); \
+			if (want) { \
+				nxt_valid = e_nxt < n; \
+				if (nxt_valid) { const uint4 *src_ = (const uint4*)(rows + (size_t)e_nxt * row_words); _Pragma("unroll") for (int g = 0; g < XL_IMG; ++g) img[g] = src_[g]; } \
+			} \
+		} } while (0)
+	XL_CLAIM(true);
+	long long c_hot = 0, c_cold = 0; unsigned int n_cold = 0;
+	for (;;) {
+		++trip;
+		const long long tc0 = prof ? (long long)__builtin_readcyclecounter() : 0;
+		// ---- every trip: a cell, or a step of the band shrink
+		if (state == XL_CELL) {
+			const uint32_t x = eh[j * 64];
+			const int q = (int)((x >> 22) & 7u);
+			int M = EHL_H(x), ee = EHL_E(x);
+			const int s = (int)((srow >> (6 * q)) & 63u) - 32;
+			M = M ? M + s : 0;
+			int h = M > ee ? M : ee;
+			h = h > f ? h : f;
+			mj = m > h ? mj : j;
+			m = m > h ? m : h;
+			int tt = M - oe_del; tt = tt > 0 ? tt : 0;
+			ee -= e_del; ee = ee > tt ? ee : tt;
+			eh[j * 64] = (uint32_t)h1 | (uint32_t)ee << 11 | (x & EHL_KEEP);   // H(i,j-1) for the next row, E(i+1,j)
+			h1 = h;
+			tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+			f -= e_ins; f = f > tt ? f : tt;
+			++j; ++n_cells;
+			if (j >= end) state = XL_ROWEND;
+		} else if (state == XL_SHL) { // the band for the next row: the non-zero cells (ksw.c:466-469), from the left ...
+			if (j < end && (eh[j * 64] & EHL_HE) == 0) ++j;
+			else { beg = j; j = end; state = XL_SHR; }
+		} else if (state == XL_SHR) { // ... and from the right
+			if (j >= beg && (eh[j * 64] & EHL_HE) == 0) --j;
+			else { end = j + 2 < qlen ? j + 2 : qlen; state = XL_ROW; }
+		}
+		const long long tc1 = prof ? (long long)__builtin_readcyclecounter() : 0;
+		c_hot += tc1 - tc0;
+		// ---- the rest every fourth trip, or when a third of the wave waits
+		const bool cold = state != XL_CELL && state != XL_SHL && state != XL_SHR && state != XL_DONE;
+		const unsigned long long cm = __ballot(cold);
+		if (cm && ((trip & 3u) == 0 || __popcll(cm) > 20 || cm == __ballot(state != XL_DONE))) ++n_cold;
+		if (cold && ((trip & 3u) == 0 || __popcll(cm) > 20 || cm == __ballot(state != XL_DONE))) {
+			if (state == XL_ROWEND) {
+				{ const uint32_t x = eh[end * 64]; eh[end * 64] = (uint32_t)h1 | (x & EHL_KEEP); }   // eh[end] = {h1, 0}
+				if ((beg < end ? end : beg) == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }   // the column loop ended at j == qlen (ksw.c:450)
+				bool stop = m == 0;
+				if (!stop) {
+					if (m > max) {
+						max = m; max_i = i; max_j = mj;
+						int off = mj - i; off = off < 0 ? -off : off;
+						max_off = max_off > off ? max_off : off;
+					} else if (zdrop > 0) {
+						if (i - max_i > mj - max_j) stop = max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop;
+						else stop = max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop;
+					}
+				}
+				if (stop) { i = tlen; state = XL_ROW; }   // the row loop ends here (ksw.c:454,460-464)
+				else { j = beg; state = XL_SHL; ++i; }
+			}
+			if (state == XL_ROW) {
+				if (i >= tlen) { // job done
+					bsx_ext_res_t r;
+					r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+					W.res[b][e] = r;
+					state = XL_FETCH;
+				} else {
+					const int t = (int)((eh[ti_cell * 64] >> (25 + (ti_slot << 1))) & 3u);
+					if (++ti_slot == 3) { ti_slot = 0; ++ti_cell; }
+					const int8_t *mt = smat + moff + t * 5;
+					srow = (uint32_t)(mt[0] + 32) | (uint32_t)(mt[1] + 32) << 6 | (uint32_t)(mt[2] + 32) << 12 | (uint32_t)(mt[3] + 32) << 18 | (uint32_t)(mt[4] + 32) << 24;
+					if (beg < i - w) beg = i - w;
+					if (end > i + w + 1) end = i + w + 1;
+					if (end > qlen) end = qlen;
+					if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
+					f = 0; m = 0; mj = -1; j = beg;
+					++n_rows;
+					state = beg < end ? XL_CELL : XL_ROWEND;
+				}
+			}
+			// next jobs: sixteen lanes at a time (or when nothing else is going on).  The images consumed here were loaded at the previous such
+			// event, dozens of trips ago; a wave has ONE counter for its loads in flight, so consuming right after another lane's load was
+			// issued would wait for that one too
+			bool took = false;
+			const unsigned long long fm = __ballot(state == XL_FETCH);
+			if (state == XL_FETCH && (__popcll(fm) >= 16 || fm == __ballot(state != XL_DONE))) { // start the job whose image is in registers, then load the image of the one after it
+				if (!nxt_valid) state = XL_DONE;
+				else {
+					took = true;
+					e = e_nxt;
+					++n_jobs;
+					const int decl = (int)img[1].y;
+					if (decl == 1) { // does not fit this kernel's rows or its number format: the strand search goes to the HBM tier
+						bsx_ext_res_t r; r.score = -0x7fffffff; r.qle = r.tle = r.gtle = r.gscore = r.max_off = 0;
+						W.res[b][e] = r;
+					} else if (decl == 0) {
+						qlen = (int)img[0].x; tlen = (int)img[0].y; h0 = (int)img[0].z; w = (int)img[0].w; moff = (int)img[1].x;
+#pragma unroll
+						for (int g = 2; g < XL_IMG; ++g) if ((g - 2) * 4 <= qlen) { uint32_t *d = eh + (size_t)(g - 2) * 4 * 64; d[0] = img[g].x; d[64] = img[g].y; d[128] = img[g].z; d[192] = img[g].w; }
+						max = h0; max_i = max_j = max_ie = -1; gscore = -1; max_off = 0;
+						beg = 0; end = qlen; i = 0; ti_cell = 0; ti_slot = 0;
+						state = XL_ROW;
+					}
+				}
+			}
+			XL_CLAIM(took);   // whoever just consumed its image
+		}
+		if (prof) c_cold += (long long)__builtin_readcyclecounter() - tc1;
+		if (__ballot(state != XL_DONE) == 0) break;
+	}
+	if (prof && (threadIdx.x & 63) == 0) { atomicAdd(&prof[8], (unsigned long long)c_hot); atomicAdd(&prof[9], (unsigned long long)c_cold); atomicAdd(&prof[10], (unsigned long long)n_cold); }
+	if (prof) { // tracing: jobs, rows, cells (lane sums) and wave cycles
+		const unsigned int mc = (unsigned int)wave_max_i32((int)n_cells);
+		atomicAdd(&prof[0], (unsigned long long)n_jobs); atomicAdd(&prof[1], (unsigned long long)n_rows); atomicAdd(&prof[2], (unsigned long long)n_cells);
+		if ((threadIdx.x & 63) == 0) { atomicAdd(&prof[3], (unsigned long long)((long long)__builtin_readcyclecounter() - t0)); atomicAdd(&prof[4], (unsigned long long)trip); atomicAdd(&prof[5], (unsigned long long)mc); atomicAdd(&prof[6], 1ull); }
+	}
+}
+
+void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                      const RgXPoolArg &XA, const RgLanesArg &WA, long long n_tasks, int max_qlen,
+                      bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                      int *next_list, unsigned int *next_count)
+{
+	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	RgLanes W;
+	W.state = (RgLState*)WA.state; W.regs = (bsx_region_t*)WA.regs; W.rank = WA.rank; W.n_act = WA.n_act;
+	for (int k = 0; k < 2; ++k) { W.act[k] = WA.act[k]; W.jobs[k] = (bsx_ext_job_t*)WA.jobs[k]; W.res[k] = (bsx_ext_res_t*)WA.res[k]; }
+	const int qcap = max_qlen < 151 ? max_qlen : 151;   // columns 0 .. qlen of a job fit the image
+	const int row_words = XL_IMG * 4;   // image of a job: 8 header words + the first DP row (qlen + 1 <= 152 columns)
+	const size_t lds = (size_t)(row_words - 8) * 64 * 4;
+	static bool attr_set = false;
+	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ext_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (RG_QCAP + 48) * 64 * 4); attr_set = true; }
+	uint32_t *rows = (uint32_t*)WA.rows;
+	const int res_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 256)));
+	// grids shrink with the rounds: most strand searches need a handful of extensions (the kernels loop over what is there)
+	for (int r = 0; r < RG_LROUNDS; ++r) {
+		const long long upper = r < 4 ? n_tasks : r < 12 ? n_tasks / 2 + 1 : r < 32 ? n_tasks / 8 + 1 : n_tasks / 64 + 1;
+		const int gc = (int)std::max<long long>(1, std::min<long long>((upper + 255) / 256, (long long)n_cu * 16));
+		hipLaunchKernelGGL(k_c2r_ctrl, dim3(gc), dim3(256), 0, st, ix, P, tasks, X, W, r, out, out_cap, out_cursor, reg_off, reg_n, next_list, next_count);
+		if (r + 1 == RG_LROUNDS) break;
+		hipLaunchKernelGGL(k_ext_pack, dim3(gc), dim3(256), 0, st, ix, sc, reads, W, r, qcap, rows, row_words);
+		const int ge = (int)std::max<long long>(1, std::min<long long>((upper + 63) / 64, (long long)n_cu * res_per_cu));   // persistent lanes: what the LDS rows let be resident
+		hipLaunchKernelGGL(k_ext_lane, dim3(ge), dim3(64), lds, st, sc, W, r, rows, row_words, P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr);
+	}
+}
+size_t c2r_lanes_row_words(int max_qlen) { (void)max_qlen; return (size_t)XL_IMG * 4; }
+int c2r_lanes_max_query(void) { return 151; }
+size_t c2r_lanes_hdr_bytes(void) { return sizeof(RgLJobHdr); }
+size_t c2r_lanes_state_bytes(void) { return sizeof(RgLState); }
 
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
 template <int OCC>

@@ -34,6 +34,18 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X);
+// the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
+// rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
+// (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
+struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; void *hdr, *rows; };   // hdr/rows: packed jobs of a round
+size_t c2r_lanes_state_bytes(void);
+size_t c2r_lanes_hdr_bytes(void);
+size_t c2r_lanes_row_words(int max_qlen);
+int c2r_lanes_max_query(void);   // reads longer than this take the wave-per-strand-search launch (launch_c2r)
+void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                      const RgXPoolArg &X, const RgLanesArg &W, long long n_tasks, int max_qlen,
+                      bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
+                      int *next_list, unsigned int *next_count);
 // chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

@@ -18,14 +18,14 @@
 
 // One lane = one HIP stream with its own staging: a chunk is bound to a lane for its whole life, so the front half
 // (seeding .. regions) of one chunk and the back half (merge .. SAM) of the previous one can be in flight together.
-#define BSX_LANES 4
+#define BSX_LANES 6
 struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -120,7 +120,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -567,6 +567,35 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		launch_regions_mid(L.st, d->n_cu * 4, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA);
 	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
+	// $BSX_C2R_LANES=1: the lane-per-strand-search / lane-per-extension rounds instead of the wavefront-per-strand-search launch.  Same
+	// regions (the tests run both); measured slower so far (k_ext_lane 398 ms + k_ext_pack 59 ms + k_c2r_ctrl 26 ms per chunk against
+	// k_c2r's 187 ms: one wave per SIMD is all its LDS rows allow, so every LDS round trip of a cell is exposed), hence not the default
+	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 0;
+	if (use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
+		const size_t sb = c2r_lanes_state_bytes();
+		if ((rc = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc;
+		if ((rc = L.lanes_regs.reserve((size_t)n * 24 * sizeof(bsx_region_t))) != BSX_OK) return rc;
+		// rank | act[2] | jobs[2] | res[2] | n_act
+		const size_t o_rank = 0, o_act = o_rank + (size_t)n * 128, o_jobs = o_act + (size_t)n * 8, o_res = o_jobs + (size_t)n * 2 * sizeof(bsx_ext_job_t),
+		             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), tot_misc = o_nact + 2048;
+		if ((rc = L.lanes_misc.reserve(tot_misc)) != BSX_OK) return rc;
+		char *mb = (char*)L.lanes_misc.p;
+		RgLanesArg WA;
+		WA.state = L.lanes_state.p; WA.regs = L.lanes_regs.p; WA.rank = (unsigned char*)(mb + o_rank);
+		WA.act[0] = (int*)(mb + o_act); WA.act[1] = WA.act[0] + n;
+		WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
+		WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
+		WA.n_act = (unsigned int*)(mb + o_nact);
+		{ // the packed jobs of one round: header + image of the first DP row
+			const size_t hb = c2r_lanes_hdr_bytes(), rw = c2r_lanes_row_words(max_len);
+			(void)hb;
+			if ((rc = L.lanes_rows.reserve((size_t)n * rw * 4 + 256)) != BSX_OK) return rc;
+			WA.rows = L.lanes_rows.p; WA.hdr = nullptr;
+		}
+		HIPCHK(hipMemsetAsync(WA.n_act, 0, 2048, L.st));   // round counters, job cursors, tracing sums of k_ext_lane
+		launch_c2r_lanes(L.st, d->n_cu, d->ix, d->sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
+		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
+	} else
 	launch_c2r(L.st, d->n_cu * 8, d->ix, d->sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr);
 	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
@@ -650,6 +679,18 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
+	if (trace && L.lanes_misc.p) {
+		unsigned long long pf[12]; unsigned int na[128];
+		const size_t o_nact = (size_t)n * 128 + (size_t)n * 8 + (size_t)n * 2 * sizeof(bsx_ext_job_t) + (size_t)n * 2 * sizeof(bsx_ext_res_t);
+		D2H(L.st, na, (char*)L.lanes_misc.p + o_nact, sizeof(na));
+		D2H(L.st, pf, (char*)L.lanes_misc.p + o_nact + 384 * 4, sizeof(pf));
+		fprintf(stderr, "[M::c2r_lanes] jobs per round:");
+		for (int r = 0; r < 128 && na[r]; r += r < 16 ? 1 : 8) fprintf(stderr, " %u", na[r]);
+		fprintf(stderr, "\n[M::c2r_lanes] %llu jobs, %llu rows, %llu cells | per wave launch: %.0f k cycles, %.0f trips, cells of the busiest lane %.0f (mean %.0f)\n",
+		        pf[0], pf[1], pf[2], pf[6] ? pf[3] * 1e-3 / pf[6] : 0.0, pf[6] ? (double)pf[4] / pf[6] : 0.0,
+		        pf[6] ? (double)pf[5] / pf[6] : 0.0, pf[6] ? (double)pf[2] / (64.0 * pf[6]) : 0.0);
+		if (pf[6]) fprintf(stderr, "[M::c2r_lanes] per wave launch: %.0f k cycles in the per-trip part, %.0f k in the rest (%.0f passes)\n", pf[8] * 1e-3 / pf[6], pf[9] * 1e-3 / pf[6], (double)pf[10] / pf[6]);
+	}
 	if (trace) {
 		unsigned int hc[12]; unsigned long long hu[12];
 		D2H(L.st, hc, c32, sizeof(hc));

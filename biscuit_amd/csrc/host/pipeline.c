@@ -1167,7 +1167,7 @@ BSX_API int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_
  * Here the overlap that matters is inside the aligning step: the front half of a chunk is device-bound, the back
  * half host-bound, so chunk k+1's front half runs (on its own device lane, from its own thread) while chunk k's
  * back half runs on the caller's thread.  Chunks stay independent: each has its own insert-size statistics. */
-#define STREAM_MAX_DEPTH 4
+#define STREAM_MAX_DEPTH 6
 struct bsx_stream {
 	bsx_backend_t be[STREAM_MAX_DEPTH];
 	int depth;                /* chunks in flight: depth-1 front halves ahead of the back half being run */
@@ -1210,7 +1210,10 @@ BSX_API int bsx_stream_open(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_i
 {
 	bsx_backend_t b[STREAM_MAX_DEPTH];
 	const char *e = getenv("BSX_STREAM_DEPTH");
-	int rc, i, depth = e ? atoi(e) : 3;
+	/* front halves in flight + 1: against a genome of hg38's size a front half is about twice as long as a back half and its kernels
+	 * leave gaps (table-bound and gather-bound launches share the device well), so three of them keep the device busier than two
+	 * (measured +5 %); against small genomes two are enough (a third was -4 % at 128 Mbp) */
+	int rc, i, depth = e ? atoi(e) : (idx && idx->ref.l_pac >= 1000000000LL ? 4 : 3);
 	if (depth < 1) depth = 1;
 	if (depth > STREAM_MAX_DEPTH) depth = STREAM_MAX_DEPTH;
 	for (i = 0; i < depth; ++i) if ((rc = bsx_hip_backend_lane(dev, i, &b[i])) != BSX_OK) return rc;

@@ -296,7 +296,7 @@ int bsx_process_seqs(bsx_device_t *dev, const bsx_opt_t *opt, const bsx_index_t 
  * read / mem_process_seqs / write) does for I/O, done here for the two halves of the aligning step itself.  The
  * device-bound front half of a chunk (seeding .. regions) runs on its own device lane and thread while the
  * host-bound back half of an older chunk (merge, pairing, CIGAR, SAM text) runs on the caller's thread; up to
- * depth-1 front halves are in flight ahead of it (depth 3 unless $BSX_STREAM_DEPTH says otherwise, at most 4).
+ * depth-1 front halves are in flight ahead of it (depth 3, or 4 against genomes of 1 Gbp and more, unless $BSX_STREAM_DEPTH says otherwise; at most 6).
  *   bsx_stream_push(chunk k) returns once chunk k-(depth-1) is complete (its reads[i].sam are set);
  *   bsx_stream_flush completes the chunks still in flight, in order.  Every chunk is independent, exactly as with
  *   bsx_process_seqs (own insert-size statistics unless pes0 is given): the output does not depend on the depth.

@@ -328,3 +328,11 @@ def test_sim_chunk_equals_cpu_restatement(tmp_path):
         L.bsx_sim_free_reads(p, 2 * n_pairs)
         dev.close()
         idx.close()
+
+
+def test_c2r_lanes_equal_waves(data):
+    """chains -> regions as lock-step rounds (a lane per strand search, a lane per extension: k_c2r_ctrl / k_ext_pack / k_ext_lane)
+    against the default wavefront-per-strand-search launch (k_c2r): identical SAM."""
+    for name, args in (CASES[0], CASES[1], CASES[8], CASES[9]):
+        want = run(HIP, args, data)
+        assert run(HIP, args, data, env={"BSX_C2R_LANES": "1"}) == want, name
