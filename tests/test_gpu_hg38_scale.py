@@ -197,3 +197,76 @@ def test_sam_identical_and_where_simulated(big):
         assert tot > 6000 and ok / tot > 0.995, (ok, tot)
     finally:
         L.bsx_sim_free_reads(p, n)
+
+
+def _run_both(big, opt, p, n, pes=None):
+    """HIP pipeline and CPU restatement on the same reads; returns the two lists of SAM texts"""
+    L = B.lib()
+    idx, dev, port = big["idx"], big["dev"], big["port"]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    r = C.cast(p, C.POINTER(B.Read))
+    B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, n, p, pes), "process_seqs")
+    hip = [C.string_at(r[i].sam) for i in range(n)]
+    L.bsx_sim_reset_reads(p, n)
+    be = port.backend()
+    os.environ["BSX_HOST_THREADS"] = "16"
+    B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(opt), idx.h, 0, n, p, pes), "process_seqs(cpu restatement)")
+    cpu = [C.string_at(r[i].sam) for i in range(n)]
+    L.bsx_sim_reset_reads(p, n)
+    return hip, cpu
+
+
+def test_directional_and_pbat_libraries(big):
+    """BASELINE configs[3] at full genome size: the same pairs (a tenth of them PBAT-like, the two reads trading roles) aligned as a
+    non-directional library (-b 0: four strand searches per pair), as a directional one (-b 1: two; -b 3 is the same thing for pairs): SAM == CPU restatement each time, and -b 1 leaves the PBAT-like pairs (only those) without a proper hit."""
+    L = B.lib()
+    idx = big["idx"]
+    n_pairs = 6000
+    L.bsx_sim_pairs_truth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p), C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs_truth(idx.h, n_pairs, 150, 77, 200, 500, 0.005, 0.1, C.byref(p), None), "sim_pairs")
+    n = 2 * n_pairs
+    try:
+        mapped = {}
+        for b in (0, 1, 3):
+            opt = default_opt()
+            opt.n_threads = 16
+            opt.flag |= 0x10 | 0x2
+            opt.parent = b
+            hip, cpu = _run_both(big, opt, p, n)
+            bad = [i for i in range(n) if hip[i] != cpu[i]]
+            assert not bad, "-b %d: SAM differs for %d reads, first: %r vs %r" % (b, len(bad), hip[bad[0]], cpu[bad[0]])
+            mapped[b] = np.mean([not (int(s.split(b"\t")[1]) & 4) for s in hip])
+        assert mapped[0] > 0.97
+        assert mapped[0] > mapped[1] > 0.85          # the PBAT-like tenth is what -b 1 cannot place
+        assert mapped[3] == mapped[1]                # paired-end: any -b other than 0 means directional (bwamem.c:352-372)
+    finally:
+        L.bsx_sim_free_reads(p, n)
+
+
+def test_long_reads(big):
+    """BASELINE configs[4] shape at full genome size: single 1 kb reads (the seed-SW filter, bands of 100-200, i16 local alignment,
+    global alignments with up to 400 x 1000 traceback bytes): SAM == CPU restatement; reads found where simulated."""
+    L = B.lib()
+    idx = big["idx"]
+    n_pairs = 1500
+    L.bsx_sim_pairs_truth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p), C.c_void_p]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs_truth(idx.h, n_pairs, 1000, 5, 1000, 1400, 0.01, 0.0, C.byref(p), None), "sim_pairs")
+    n = 2 * n_pairs
+    try:
+        opt = default_opt()
+        opt.n_threads = 16
+        opt.flag |= 0x10            # single-end: every read on its own
+        hip, cpu = _run_both(big, opt, p, n)
+        bad = [i for i in range(n) if hip[i] != cpu[i]]
+        assert not bad, "SAM differs for %d reads, first: %r vs %r" % (len(bad), hip[bad[0]][:300], cpu[bad[0]][:300])
+        prim = [s.split(b"\n")[0].split(b"\t") for s in hip]
+        assert np.mean([not (int(f[1]) & 4) for f in prim]) > 0.97
+        assert np.mean([int(f[4]) >= 30 for f in prim]) > 0.9
+    finally:
+        L.bsx_sim_free_reads(p, n)
