@@ -92,11 +92,11 @@ mbp = int(round(float(os.environ.get("GENOME_MBP", "3100"))))
 if fs and ws:
     traffic = {}
     for kern in ("k_seed", "k_occ", "k_regions"):
-        # k_regions: every tier (k_regions<>, k_regions_mid, k_regions_slab<>) -- pick() matches the name prefix
+        # k_regions: the whole family -- every tier (k_regions<>, k_regions_mid, k_regions_slab<>) and the chains -> regions launch (k_c2r)
         def pk(agg, kern=kern):
             tot = collections.defaultdict(float)
             for k, v in agg.items():
-                if k == kern or k.startswith(kern + "<") or (kern == "k_regions" and k.startswith("k_regions")):
+                if k == kern or k.startswith(kern + "<") or (kern == "k_regions" and k.startswith(("k_regions", "k_c2r", "k_ext_"))):
                     for c, x in v.items():
                         tot[c] += x
             return tot
