@@ -36,9 +36,14 @@ struct RgChain {         // mem_chain_t reduced to what chaining, the filter and
 // B-tree node of the chain index (kbtree.h with t = 3: up to 5 keys); keys are chain ids, compared through their start positions
 struct RgNode { unsigned char n, internal; unsigned short id[5], child[6]; };
 
-template <int ICAP_, int SCAP_, int CCAP_, int RCAP_, int NODES_, typename Idx, typename SIdx>
+// PCAP_ > 0 (the LDS tiers): only chains with more than one seed (or with contained seeds) have a record, at most PCAP_ of them; a chain
+// of one seed IS that seed (every field of its record follows from it).  Against an hg38-sized genome a strand search has ~100 chains and
+// all but a handful are such: the chain table was half of a wave's LDS, and LDS is what bounds these tiers' occupancy.
+// Chain ids: with PCAP_ == 0 the record index; else < RG_REC the seed index of a one-seed chain, >= RG_REC record id - RG_REC.
+#define RG_REC 0x4000
+template <int ICAP_, int SCAP_, int CCAP_, int RCAP_, int NODES_, typename Idx, typename SIdx, int PCAP_ = 0>
 struct RgStore {
-	static constexpr int ICAP = ICAP_, SCAP = SCAP_, CCAP = CCAP_, RCAP = RCAP_, NODES = NODES_;
+	static constexpr int ICAP = ICAP_, SCAP = SCAP_, CCAP = CCAP_, RCAP = RCAP_, NODES = NODES_, PCAP = PCAP_;
 	typedef Idx idx_t;
 	// intervals (sorted by info)
 	unsigned long long iv_x0[ICAP_];
@@ -47,20 +52,20 @@ struct RgStore {
 	long long s_rbeg[SCAP_];
 	int s_rid[SCAP_];
 	short s_qbeg[SCAP_], s_len[SCAP_]; SIdx s_chain[SCAP_]; signed char s_extra[SCAP_];
-	RgChain ch[CCAP_];
+	RgChain ch[PCAP_ ? PCAP_ : CCAP_];
 	Idx ord[CCAP_];                   // chain indices: by position, then in filter order
 	Idx keep[CCAP_];                  // mem_chain_flt's kept list (indices into ord)
 	Idx lst[SCAP_];                   // seed indices of the current chain / list
 	unsigned long long srt[SCAP_];    // score<<32|i, ascending (memchain.c:748-752)
-	bsx_region_t regs[RCAP_];
+	bsx_region_t regs[RCAP_ ? RCAP_ : 1];
 	int n_chains, n_regs;
 	// NODES > 0: chains are indexed by the reference's B-tree, so that chains starting at the same position are found
 	// and ordered as kb_intervalp / __kb_traverse would (the first tier declines such tasks instead)
 	RgNode node[NODES_ ? NODES_ : 1];
 	int n_nodes, root;
 };
-typedef RgStore<64, 96, 96, 16, 0, unsigned char, signed char> RgSmall;
-typedef RgStore<128, 256, 256, 24, 0, unsigned char, short> RgMid;              // still LDS: 24 KB per wave, two waves per workgroup: the
+typedef RgStore<64, 96, 96, 0, 0, unsigned short, short, 32> RgSmall;
+typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;             // still LDS: 24 KB per wave, two waves per workgroup: the
                                                                                 // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
@@ -70,6 +75,7 @@ struct RgDp {            // per-wave LDS scratch
 	uint8_t q[RG_QCAP];          // the read
 	uint8_t win[RG_WIN];         // reference bases [rmax0, rmax1) of the chain being extended, one byte each
 };
+struct RgDpLite { int32_t H[64], E[64]; uint8_t q[RG_QCAP]; uint8_t win[4]; };   // the LDS tiers stop before the extensions: no window
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -327,6 +333,20 @@ struct RgXChain { long long pos; int rid, seed_off; unsigned short n_main, n_ext
 struct RgXSeed { long long rbeg; short qbeg, len; unsigned char bad, pad[3]; };
 struct RgXPool { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
 
+// the record of chain `id` (by value); for a chain of one seed, made up from the seed (s_extra bit 2 = its contig is an ALT)
+template <typename Store>
+__device__ __forceinline__ RgChain rg_chain(const Store &S, int id)
+{
+	if (Store::PCAP == 0) return S.ch[id];
+	if (id >= RG_REC) return S.ch[id - RG_REC];
+	RgChain c;
+	const short qb = S.s_qbeg[id], ln = S.s_len[id];
+	c.pos = c.last_r = S.s_rbeg[id]; c.rid = S.s_rid[id]; c.endr_off = ln;
+	c.first_q = c.last_q = qb; c.last_len = ln; c.wq = c.wr = ln; c.endq = (short)(qb + ln); c.first = -1; c.w = ln;
+	c.n_seeds = 1; c.seed0 = (unsigned short)id; c.kept = 0; c.is_alt = (unsigned char)((S.s_extra[id] >> 2) & 1); c.n_extra = 0;
+	return c;
+}
+
 // returns 11 (exported), 0 (nothing left to extend: the strand search has no regions) or 6 (no room: the next tier takes it)
 template <typename Store>
 __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool &X, int lane)
@@ -340,7 +360,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 		const int ci = base + lane;
 		bool surv = false; int cnt = 0;
 		if (ci < nk) {
-			const RgChain c = S.ch[S.ord[ci]];
+			const RgChain c = rg_chain(S, (int)S.ord[ci]);
 			surv = !(c.n_seeds == 1 && c.n_extra == 0 && (S.s_extra[c.seed0] & 2));
 			cnt = surv ? c.n_seeds + c.n_extra : 0;
 		}
@@ -364,7 +384,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 	int so = 0;
 	for (int ci = 0; ci < n_surv; ++ci) {
 		const int c = uni(S.ord[ci]);
-		const RgChain chn = S.ch[c];
+		const RgChain chn = rg_chain(S, c);
 		const int n_main = uni(chn.n_seeds), n_extra = uni(chn.n_extra);
 		if (lane == 0) { RgXChain x; x.pos = chn.pos; x.rid = chn.rid; x.seed_off = so; x.n_main = (unsigned short)n_main; x.n_extra = (unsigned short)n_extra; x.pad = 0; XC[ci] = x; }
 		if (n_main == 1 && n_extra == 0) {
@@ -393,8 +413,8 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 //   1 seeding overflowed   9 read longer than RG_QCAP or long enough for the seed-SW filter (memchain.c:544)   8 intervals > ICAP
 //   2 occurrences > SCAP or an interval beyond max_occ      3 chains > CCAP      4 two chains start at the same position
 //   6 regions > RCAP      10 an over-represented interval has to be walked past max_occ (memchain.c:325-326)
-template <typename Store, bool SPLIT = false>
-__device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
+template <typename Store, bool SPLIT = false, typename DP = RgDp>
+__device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
                        unsigned long long *counters, const int *gap, const long long *ctg, const RgXPool *X = nullptr, int task_id = 0)
 {
@@ -509,8 +529,9 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
-			S.s_rid[o] = rg_intv2rid(ix, ctg, pos, pos + slen);
-			S.s_chain[o] = -1; S.s_extra[o] = 0;
+			const int rid_ = rg_intv2rid(ix, ctg, pos, pos + slen);
+			S.s_rid[o] = rid_;
+			S.s_chain[o] = -1; S.s_extra[o] = (Store::PCAP && rid_ >= 0 && ix.ctg_alt[rid_]) ? 4 : 0;
 		}
 		// work counters of the algorithmic-bytes model: FM blocks touched by the LF walks, SA samples read
 		lf = (uint32_t)wave_sum_i32((int)lf);
@@ -525,7 +546,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
 		int bad = 0;
 		for (int i = 0; i < ln; ++i) { const int r = dev_ref_base(ix.pac, l_pac, rb + i), q = D.q[qb + i]; bad |= (r == 3 && q == 1) || (r == 0 && q == 2); }
-		if (bad) S.s_extra[o] = 2;
+		if (bad) S.s_extra[o] |= 2;
 	}
 	WAVE_SYNC();
 	RG_STAGE(1);
@@ -537,7 +558,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	unsigned int st_lo[NR], st_hi[NR]; int st_id[NR];
 #pragma unroll
 	for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
-	int nc = 0;
+	int nc = 0, n_prom = 0;   // chains; those of them with a record (PCAP stores)
 	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
 	for (int o = 0; o < tot; ++o) {
 		while (o >= iv_stop) { // next interval with occurrences
@@ -574,44 +595,61 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		}
 		int merged = 0;
 		if (lower >= 0) { // merge_seed_to_chain, memchain.c:227-256
-			const RgChain c = S.ch[lower];
+			const RgChain c = rg_chain(S, lower);
+			int kind = 0;   // 1: contained in the chain (goes on seeds_extra), 2: appended
 			if (rid == c.rid) {
-				if (qbeg >= c.first_q && qbeg + len <= c.last_q + c.last_len && rbeg >= c.pos && rbeg + len <= c.last_r + c.last_len) {
-					if (lane == 0) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower; S.s_extra[o] |= 1; S.ch[lower].n_extra = (unsigned short)(c.n_extra + 1); }
-					merged = 1;
-				} else if (!((c.last_r < l_pac || c.pos < l_pac) && rbeg >= l_pac)) {
+				if (qbeg >= c.first_q && qbeg + len <= c.last_q + c.last_len && rbeg >= c.pos && rbeg + len <= c.last_r + c.last_len) kind = 1;
+				else if (!((c.last_r < l_pac || c.pos < l_pac) && rbeg >= l_pac)) {
 					const long long qdist = qbeg - c.last_q, rdist = rbeg - c.last_r;
-					if (rdist >= 0 && qdist - rdist <= P.w && rdist - qdist <= P.w && qdist - c.last_len < P.max_chain_gap && rdist - c.last_len < P.max_chain_gap) {
-						if (lane == 0) {
-							RgChain &d = S.ch[lower];
-							S.s_chain[o] = (decltype(S.s_chain[0] + 0))lower;
-							d.last_q = (short)qbeg; d.last_r = rbeg; d.last_len = (short)len;
-							// mem_chain_weight (memchain.c:158-180) as a running sum: seeds join a chain in the order that loop visits them
-							int wq = c.wq, wr = c.wr;
-							if (qbeg >= c.endq) wq += len; else if (qbeg + len > c.endq) wq += qbeg + len - c.endq;
-							const long long endr = c.pos + c.endr_off;
-							if (rbeg >= endr) wr += len; else if (rbeg + len > endr) wr += (int)(rbeg + len - endr);
-							d.wq = (short)wq; d.wr = (short)(wr < 32767 ? wr : 32767);   // only min(wq, wr) is read, and wq <= read length
-							if (qbeg + len > c.endq) d.endq = (short)(qbeg + len);
-							if (rbeg + len > endr) d.endr_off = (int)(rbeg + len - c.pos);
-							d.n_seeds = (unsigned short)(c.n_seeds + 1);
-						}
-						merged = 1;
-					}
+					if (rdist >= 0 && qdist - rdist <= P.w && rdist - qdist <= P.w && qdist - c.last_len < P.max_chain_gap && rdist - c.last_len < P.max_chain_gap) kind = 2;
 				}
 			}
-			merged = uni(merged);
+			kind = uni(kind);
+			if (kind) {
+				int rec = lower;   // where the chain's record is (made now if the chain was a single seed so far)
+				if (Store::PCAP) {
+					if (lower < RG_REC) {
+						if (n_prom == Store::PCAP) return 3;
+						rec = n_prom++;
+						if (lane == 0) { S.ch[rec] = c; S.s_chain[c.seed0] = (decltype(S.s_chain[0] + 0))(RG_REC + rec); }
+						const int e = at - 1, el = e & 63;   // its entry in the sorted table names the record from now on
+#pragma unroll
+						for (int r = 0; r < NR; ++r) if (r == e >> 6 && lane == el) st_id[r] = RG_REC + rec;
+					} else rec = lower - RG_REC;
+				}
+				if (lane == 0) {
+					RgChain &d = S.ch[rec];
+					S.s_chain[o] = (decltype(S.s_chain[0] + 0))(Store::PCAP ? RG_REC + rec : rec);
+					if (kind == 1) { S.s_extra[o] |= 1; d.n_extra = (unsigned short)(c.n_extra + 1); }
+					else {
+						d.last_q = (short)qbeg; d.last_r = rbeg; d.last_len = (short)len;
+						// mem_chain_weight (memchain.c:158-180) as a running sum: seeds join a chain in the order that loop visits them
+						int wq = c.wq, wr = c.wr;
+						if (qbeg >= c.endq) wq += len; else if (qbeg + len > c.endq) wq += qbeg + len - c.endq;
+						const long long endr = c.pos + c.endr_off;
+						if (rbeg >= endr) wr += len; else if (rbeg + len > endr) wr += (int)(rbeg + len - endr);
+						d.wq = (short)wq; d.wr = (short)(wr < 32767 ? wr : 32767);   // only min(wq, wr) is read, and wq <= read length
+						if (qbeg + len > c.endq) d.endq = (short)(qbeg + len);
+						if (rbeg + len > endr) d.endr_off = (int)(rbeg + len - c.pos);
+						d.n_seeds = (unsigned short)(c.n_seeds + 1);
+					}
+				}
+				merged = 1;
+			}
 		}
 		if (!merged) {
 			if (nc == Store::CCAP) return 3;
 			if (!Store::NODES && tied) return 4;   // duplicate key: the B-tree shape matters, the HBM tiers keep one
+			const int new_id = Store::PCAP ? o : nc;   // a chain of one seed has no record in the LDS tiers
 			if (lane == 0) {
-				RgChain c;
-				c.pos = c.last_r = rbeg; c.rid = rid; c.endr_off = len; c.first_q = c.last_q = (short)qbeg; c.last_len = (short)len;
-				c.wq = c.wr = (short)len; c.endq = (short)(qbeg + len); c.first = -1; c.w = 0; c.n_seeds = 1; c.seed0 = (unsigned short)o;
-				c.kept = 0; c.is_alt = ix.ctg_alt[rid] ? 1 : 0; c.n_extra = 0;
-				S.ch[nc] = c;
-				S.s_chain[o] = (decltype(S.s_chain[0] + 0))nc;
+				if (!Store::PCAP) {
+					RgChain c;
+					c.pos = c.last_r = rbeg; c.rid = rid; c.endr_off = len; c.first_q = c.last_q = (short)qbeg; c.last_len = (short)len;
+					c.wq = c.wr = (short)len; c.endq = (short)(qbeg + len); c.first = -1; c.w = 0; c.n_seeds = 1; c.seed0 = (unsigned short)o;
+					c.kept = 0; c.is_alt = ix.ctg_alt[rid] ? 1 : 0; c.n_extra = 0;
+					S.ch[nc] = c;
+				}
+				S.s_chain[o] = (decltype(S.s_chain[0] + 0))new_id;
 				if (Store::NODES) rg_bt_put(S, rbeg, nc);
 			}
 			if (!Store::NODES) { // open slot `at` of the sorted table
@@ -627,7 +665,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 						const bool keep = r == ar && lane < al, put = r == ar && lane == al;
 						st_lo[r] = keep ? st_lo[r] : put ? (unsigned int)rbeg : s_lo;
 						st_hi[r] = keep ? st_hi[r] : put ? (unsigned int)((unsigned long long)rbeg >> 32) : s_hi;
-						st_id[r] = keep ? st_id[r] : put ? nc : s_id;
+						st_id[r] = keep ? st_id[r] : put ? new_id : s_id;
 					}
 				}
 			}
@@ -639,7 +677,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 	RG_STAGE(2);
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
-		for (int c = lane; c < nc; c += 64) { RgChain &d = S.ch[c]; const int w = d.wq < d.wr ? d.wq : d.wr; d.w = (short)w; }
+		for (int c = lane; c < (Store::PCAP ? n_prom : nc); c += 64) { RgChain &d = S.ch[c]; const int w = d.wq < d.wr ? d.wq : d.wr; d.w = (short)w; }
 		if (!Store::NODES) { // the sorted table is the in-order traversal of the tree (memchain.c:372-379)
 #pragma unroll
 			for (int r = 0; r < NR; ++r) if (r * 64 + lane < nc) S.ord[r * 64 + lane] = (idx_t)st_id[r];
@@ -655,16 +693,18 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 		for (int base = 0; base < nc; base += 64) {
 			const int i = base + lane;
 			const int c = i < nc ? (int)S.ord[i] : 0;
-			const int w = i < nc ? S.ch[c].w : -1;
+			const int w = i < nc ? (Store::PCAP ? (c >= RG_REC ? (int)S.ch[c - RG_REC].w : (int)S.s_len[c]) : (int)S.ch[c].w) : -1;
 			const bool ok = i < nc && w >= P.min_chain_weight;
 			const unsigned long long b = __ballot(ok);
-			if (ok) keys[n + __popcll(b & lt_mask)] = (unsigned int)w << RG_KEY_BITS | (unsigned int)c;
+			// the key carries the chain (its record index, or with PCAP its position in the order by start: ids do not fit the key there)
+			if (ok) keys[n + __popcll(b & lt_mask)] = (unsigned int)w << RG_KEY_BITS | (unsigned int)(Store::PCAP ? i : c);
+			if (Store::PCAP && i < nc) S.keep[i] = (idx_t)c;
 			n += __popcll(b);
 		}
 		WAVE_SYNC();
 		if (lane == 0) rg_introsort_keys(keys, n, D.H);
 		WAVE_SYNC();
-		for (int i = lane; i < n; i += 64) S.ord[i] = (idx_t)(keys[i] & ((1u << RG_KEY_BITS) - 1));
+		for (int i = lane; i < n; i += 64) { const unsigned int v = keys[i] & ((1u << RG_KEY_BITS) - 1); S.ord[i] = Store::PCAP ? S.keep[v] : (idx_t)v; }
 		WAVE_SYNC();
 		RG_STAGE(4);
 		if (n > 0 && !Store::NODES) {
@@ -676,7 +716,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			for (int h = 0; h < NH; ++h) {
 				const int j = lane + 64 * h;
 				cb[h] = ce[h] = cw[h] = ca[h] = 0; kp[h] = 0; fi[h] = -1;
-				if (j < n) { const RgChain c = S.ch[S.ord[j]]; cb[h] = c.first_q; ce[h] = c.last_q + c.last_len; cw[h] = c.w; ca[h] = c.is_alt; }
+				if (j < n) { const RgChain c = rg_chain(S, (int)S.ord[j]); cb[h] = c.first_q; ce[h] = c.last_q + c.last_len; cw[h] = c.w; ca[h] = c.is_alt; }
 			}
 			if (lane == 0) kp[0] = 3;
 			for (int i = 1; i < n; ++i) {
@@ -715,10 +755,10 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 				}
 			}
 #pragma unroll
-			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n) S.ch[S.ord[j]].kept = (signed char)kp[h]; }
+			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n) { if (Store::PCAP) S.lst[j] = (idx_t)kp[h]; else S.ch[S.ord[j]].kept = (signed char)kp[h]; } }   // PCAP: kept flags by position (lst is free here)
 			WAVE_SYNC();
 #pragma unroll
-			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) S.ch[S.ord[fi[h]]].kept = 1; }
+			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) { if (Store::PCAP) S.lst[fi[h]] = 1; else S.ch[S.ord[fi[h]]].kept = 1; } }
 			WAVE_SYNC();
 		} else if (n > 0) {
 			int nk = 1;
@@ -755,8 +795,8 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			if (P.max_chain_extend < (unsigned int)n) { // at most max_chain_extend shadowed chains survive (memchain.c:474-482); off by default
 				if (lane == 0) {
 					int i; unsigned int k = 0;
-					for (i = 0; i < n; ++i) { const int kp = S.ch[S.ord[i]].kept; if (kp == 0 || kp == 3) continue; if (++k >= P.max_chain_extend) break; }
-					for (; i < n; ++i) if (S.ch[S.ord[i]].kept < 3) S.ch[S.ord[i]].kept = 0;
+					for (i = 0; i < n; ++i) { const int kp = Store::PCAP ? (int)S.lst[i] : (int)S.ch[S.ord[i]].kept; if (kp == 0 || kp == 3) continue; if (++k >= P.max_chain_extend) break; }
+					for (; i < n; ++i) { if (Store::PCAP) { if (S.lst[i] < 3) S.lst[i] = 0; } else if (S.ch[S.ord[i]].kept < 3) S.ch[S.ord[i]].kept = 0; }
 				}
 				WAVE_SYNC();
 			}
@@ -764,7 +804,7 @@ __device__ int rg_task(Store &S, RgDp &D, const DevIndex &ix, const DevScoring &
 			for (int base = 0; base < n; base += 64) {
 				const int i = base + lane;
 				const int c = i < n ? (int)S.ord[i] : 0;
-				const bool ok = i < n && S.ch[c].kept != 0;
+				const bool ok = i < n && (Store::PCAP ? S.lst[i] != 0 : S.ch[c].kept != 0);
 				const unsigned long long b = __ballot(ok);
 				WAVE_SYNC();
 				if (ok) S.ord[m + __popcll(b & lt_mask)] = (idx_t)c;
@@ -1729,7 +1769,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
           const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, RgXPool X)
 {
 	__shared__ RgSmall lds[4];
-	__shared__ RgDp dp[4];
+	__shared__ RgDpLite dp[4];
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
@@ -1738,7 +1778,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 	__syncthreads();
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
-	RgDp &D = dp[threadIdx.x >> 6];
+	RgDpLite &D = dp[threadIdx.x >> 6];
 	// each wave takes `quota` tasks and leaves (bounded workgroup life, see k_seed); the launch covers all tasks
 	for (int taken = 0; taken < quota; ++taken) {
 		int t = 0;
@@ -1753,7 +1793,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<RgSmall, true>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		int status = rg_task<RgSmall, true, RgDpLite>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;   // exported: k_c2r makes and publishes its regions
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
@@ -1807,7 +1847,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X)
 {
 	__shared__ RgMid lds[2];
-	__shared__ RgDp dp[2];
+	__shared__ RgDpLite dp[2];
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
@@ -1816,7 +1856,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 	__syncthreads();
 	const int lane = wave_lane();
 	RgMid &S = lds[threadIdx.x >> 6];
-	RgDp &D = dp[threadIdx.x >> 6];
+	RgDpLite &D = dp[threadIdx.x >> 6];
 	const int n = (int)*count;
 	for (;;) {
 		int i = 0;
@@ -1827,7 +1867,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<RgMid, true>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		int status = rg_task<RgMid, true, RgDpLite>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
@@ -1924,7 +1964,7 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 3;   // waves per SIMD the register allocation targets (the tables in LDS allow three workgroups per CU)
+	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
 	if (occ >= 4)
 		hipLaunchKernelGGL(k_regions<4>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
