@@ -501,7 +501,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
 	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 6 + 65536;
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
-	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 2;
+	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 1;   // one strand search per lane: the lanes of a wave then go through the seeding passes together (measured at hg38 scale: 335 ms with two, 292 with one, 359 with persistent lanes)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
 	static const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
