@@ -24,6 +24,7 @@ struct Lane {
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
+	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
@@ -50,8 +51,7 @@ struct bsx_device {
 	int n_cu = 0;
 	DevIndex ix; bool has_index = false;
 	DevBuf bwt[2], sa[2], pac, ctg;
-	DevScoring sc;
-	Lane lane[BSX_LANES];
+	Lane lane[BSX_LANES];   // scoring matrices and penalties are per lane (Lane::sc): chunks with different options may be in flight together
 };
 struct LaneRef { bsx_device *d; int lane; };   // what the backend vtable carries as ctx
 
@@ -106,7 +106,7 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipMemset(L.small.p, 0, 1024));
 	}
 	memset(&d->ix, 0, sizeof(d->ix));
-	memset(&d->sc, 0, sizeof(d->sc));
+	for (int l = 0; l < BSX_LANES; ++l) memset(&d->lane[l].sc, 0, sizeof(DevScoring));
 	*out = d;
 	return BSX_OK;
 }
@@ -246,13 +246,15 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 	return BSX_OK;
 }
 
-extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o)
+static int lane_set_opt(bsx_device_t *d, int lane, const bsx_opt_t *o)
 {
 	if (!d || !o) return BSX_E_ARG;
-	memcpy(d->sc.ctmat, o->ctmat, 25); memcpy(d->sc.gamat, o->gamat, 25);
-	d->sc.o_del = o->o_del; d->sc.e_del = o->e_del; d->sc.o_ins = o->o_ins; d->sc.e_ins = o->e_ins; d->sc.zdrop = o->zdrop; d->sc.a = o->a;
+	DevScoring &sc = d->lane[lane].sc;
+	memcpy(sc.ctmat, o->ctmat, 25); memcpy(sc.gamat, o->gamat, 25);
+	sc.o_del = o->o_del; sc.e_del = o->e_del; sc.o_ins = o->o_ins; sc.e_ins = o->e_ins; sc.zdrop = o->zdrop; sc.a = o->a;
 	return BSX_OK;
 }
+extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o) { return lane_set_opt(d, 0, o); }   // the batch calls of include/bsx.h run on lane 0
 
 // Large copies between pageable host memory and the device go through two pinned halves, copy and DMA overlapped:
 // handing pageable memory to hipMemcpy makes the runtime pin and unpin the user pages on every call, which costs
@@ -558,13 +560,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
-	launch_regions(L.st, rgrid, d->ix, d->sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
+	launch_regions(L.st, rgrid, d->ix, L.sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
 	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls, XA);
 	HIPCHK(hipEventRecord(L.ev3, L.st));
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
 	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
 	if (use_mid)
-		launch_regions_mid(L.st, d->n_cu * 6, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+		launch_regions_mid(L.st, d->n_cu * 6, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA);
 	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
 	// $BSX_C2R_LANES=1: the lane-per-strand-search / lane-per-extension rounds instead of the wavefront-per-strand-search launch.  Same
@@ -593,14 +595,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			WA.rows = L.lanes_rows.p; WA.hdr = nullptr;
 		}
 		HIPCHK(hipMemsetAsync(WA.n_act, 0, 2048, L.st));   // round counters, job cursors, tracing sums of k_ext_lane
-		launch_c2r_lanes(L.st, d->n_cu, d->ix, d->sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
+		launch_c2r_lanes(L.st, d->n_cu, d->ix, L.sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
 	} else
-	launch_c2r(L.st, d->n_cu * 8, d->ix, d->sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
+	launch_c2r(L.st, d->n_cu * 8, d->ix, L.sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr);
-	launch_regions_slab(L.st, 2, big_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+	launch_regions_slab(L.st, 2, big_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
-	launch_regions_slab(L.st, 3, huge_grid, d->ix, d->sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+	launch_regions_slab(L.st, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 
 	HIPCHK(hipEventRecord(L.rs.ev_tiers, L.st));
@@ -641,7 +643,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the third tier's slabs are shared with the main launch sequence
-			launch_regions_slab(L.st2, 3, huge_grid, d->ix, d->sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
+			launch_regions_slab(L.st2, 3, huge_grid, d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
@@ -826,7 +828,7 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		launch_extend(L.st, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+		launch_extend(L.st, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, QCAP[c], NCS[c], d->n_cu);
 		off += order[c].size();
 	}
@@ -872,7 +874,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
 		const long long m = (long long)order[c].size();
 		const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
-		launch_sw(L.st_hi, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
+		launch_sw(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
 		          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : 16);
 		off += order[c].size();
 	}
@@ -895,7 +897,7 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 1024, 2048}, NCS[3] = {4, 16, 32}, WPB[3] = {4, 4, 1};
 	std::vector<int> order[3];
 	size_t zmax[3] = {64, 64, 64};
-	const DevScoring &sc = d->sc;
+	const DevScoring &sc = L.sc;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_glb_job_t &j = jobs[i];
 		if (j.qlen <= 0 || j.tlen <= 0 || j.n_try < 1) { fprintf(stderr, "[bsx-hip] global job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
@@ -937,7 +939,7 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
-		launch_global(L.st_hi, d->ix, d->sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+		launch_global(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_glb_res_t*)L.res.p, (uint32_t*)L.pool.p, (uint8_t*)L.scratch.p, zmax[c],
 		              QCAP[c], NCS[c], blocks[c], WPB[c]);
 		off += order[c].size();
@@ -965,7 +967,7 @@ extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_gl
 
 // the seams as one vtable for the host pipeline; ctx = (device, lane)
 #define LR(c) ((LaneRef*)(c))->d, ((LaneRef*)(c))->lane
-static int be_set_opt(void *c, const bsx_opt_t *o) { return bsx_device_set_opt(((LaneRef*)c)->d, o); }
+static int be_set_opt(void *c, const bsx_opt_t *o) { return lane_set_opt(LR(c), o); }
 static int be_set_reads(void *c, const uint8_t *b, size_t n) { return lane_set_reads(LR(c), b, n); }
 static int be_seed(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_task_t *t, bsx_intv_t **out, int64_t *cap, int64_t *off) { return lane_seed_batch(LR(c), o, n, t, out, cap, off); }
 static int be_sa(void *c, int64_t n, const bsx_sa_job_t *j, uint64_t *p) { return lane_sa_batch(LR(c), n, j, p); }

@@ -162,6 +162,8 @@ static void classify(int n, bsx_read_t *seqs, int m[2], bsx_read_t *sep[2])
 
 /* set by the product entry: chunks go through bsx_stream_* on the device `ud` names instead of one at a time */
 static int g_use_stream = 0;
+/* set by the product entry: how to release what its open_device callback made */
+static void (*g_close_device)(void *ud) = 0;
 
 typedef int (*process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n, bsx_read_t *reads, const bsx_pestat_t *pes0);
 
@@ -194,6 +196,7 @@ static int cq_get(chunk_q_t *Q, chunk_rec_t *r)   /* 0 when the queue is closed 
 	return got;
 }
 static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok);
+static volatile int g_write_error = 0;   /* a write to stdout failed (the reference aborts there: err_fputs, utils.c:214) */
 typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; int chunk, has_bc, copy_comment; volatile int stop; } reader_t;
 static void *reader_main(void *arg)
 {
@@ -233,7 +236,7 @@ static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok)
 		bsx_emit_hook(bsx_emit_ud, chunk_idx, all, tot);
 		free(all);
 	}
-	for (i = 0; i < n; ++i) { if (ok && !bsx_emit_hook && seqs[i].sam) fputs(seqs[i].sam, stdout); bsx_read_free(&seqs[i]); }
+	for (i = 0; i < n; ++i) { if (ok && !bsx_emit_hook && !g_write_error && seqs[i].sam && fputs(seqs[i].sam, stdout) == EOF) g_write_error = 1; bsx_read_free(&seqs[i]); }
 	free(seqs);
 }
 
@@ -392,20 +395,21 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 	if ((rc = bsx_index_load(argv[optind], &idx)) != BSX_OK) { fprintf(stderr, "[E::%s] fail to locate the index files (%s)\n", "main_align", bsx_strerror(rc)); return 1; }
 	if (auto_alt) infer_alt(&idx->ref);
 	if (ignore_alt) for (i = 0; i < idx->ref.n_seqs; ++i) idx->ref.anns[i].is_alt = 0;
-	if (open_device && (rc = open_device(device, idx, &ud)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); bsx_index_free(idx); return 1; }
+	if (open_device) ud = 0;
+	if (open_device && (rc = open_device(device, idx, &ud)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); ud = 0; rc = 1; goto cleanup; }
 	if (!seq1) {
-		if ((f1 = bsx_fq_open(argv[optind + 1])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 1]); return 1; }
+		if ((f1 = bsx_fq_open(argv[optind + 1])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 1]); rc = 1; goto cleanup; }
 		if (optind + 2 < argc) {
 			if (opt->flag & BSX_F_PE) { if (bsx_verbose >= 2) fprintf(stderr, "[W::%s] when '-p' is in use, the second query file is ignored.\n", "main_align"); }
 			else {
-				if ((f2 = bsx_fq_open(argv[optind + 2])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 2]); return 1; }
+				if ((f2 = bsx_fq_open(argv[optind + 2])) == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", "main_align", argv[optind + 2]); rc = 1; goto cleanup; }
 				opt->flag |= BSX_F_PE;
 			}
 		}
 	}
 	if (!(opt->flag & BSX_F_ALN_REG) && bsx_shard_rank == 0) {
 		char *h = bsx_sam_header(idx, hdr_line, bsx_pg_line);
-		if (bsx_emit_hook) bsx_emit_hook(bsx_emit_ud, -1, h, strlen(h)); else fputs(h, stdout);
+		if (bsx_emit_hook) bsx_emit_hook(bsx_emit_ud, -1, h, strlen(h)); else if (fputs(h, stdout) == EOF) g_write_error = 1;
 		free(h);
 	}
 	{
@@ -418,7 +422,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 		int n_pend = 0, depth = 1;
 		bsx_stream_t *stream = 0;
 		if (g_use_stream && !(opt->flag & BSX_F_SMARTPE)) {
-			if ((rc = bsx_stream_open((bsx_device_t*)ud, opt, idx, pes0, &stream)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); return 1; }
+			if ((rc = bsx_stream_open((bsx_device_t*)ud, opt, idx, pes0, &stream)) != BSX_OK) { fprintf(stderr, "[E::%s] %s\n", "main_align", bsx_strerror(rc)); rc = 1; goto cleanup; }
 			depth = bsx_stream_depth(stream);
 		}
 		if (stream && !seq1) { /* reader thread -> this thread (stream push / back halves) -> writer thread */
@@ -444,6 +448,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				pend[n_pend].seqs = r.seqs; pend[n_pend].n = r.n; pend[n_pend].idx = r.idx; ++n_pend;
 				n_processed += r.n;
 				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; R.stop = 1; break; }
+				if (g_write_error) { rc = 1; R.stop = 1; break; }
 				while (n_pend > depth - 1) { /* the push completed the oldest chunk in flight */
 					chunk_rec_t d; d.seqs = pend[0].seqs; d.n = pend[0].n; d.idx = pend[0].idx; d.ok = 1;
 					cq_put(&out_q, d);
@@ -516,6 +521,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
 			n_processed += n;
 			emit_chunk(seqs, n, chunk_idx, rc == 0);
+			if (g_write_error) rc = 1;
 			if (rc) break;
 		}
 		if (stream) {
@@ -525,7 +531,10 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 		}
 loop_done: ;
 	}
-	fflush(stdout);
+	if (fflush(stdout) != 0 || ferror(stdout)) g_write_error = 1;
+	if (g_write_error) { fprintf(stderr, "[E::%s] failed to write the output: the SAM is incomplete\n", "main_align"); rc = 1; }
+cleanup:
+	if (open_device && ud && g_close_device) g_close_device(ud);   /* the device this call opened: index replica, lanes, streams */
 	free(hdr_line); free(opt->adaptor1); free(opt->adaptor2); free(pes0); free(seq1); free(seq2);
 	bsx_fq_close(f1); bsx_fq_close(f2);
 	bsx_index_free(idx);
@@ -548,8 +557,14 @@ static int hip_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, i
 	return bsx_process_seqs((bsx_device_t*)ud, opt, idx, np, n, reads, pes0);
 }
 
+static void hip_close(void *ud) { bsx_device_close((bsx_device_t*)ud); }
+
 BSX_API int bsx_align_main(int argc, char **argv)
 {
+	int rc;
 	g_use_stream = getenv("BSX_NO_STREAM") ? 0 : 1;
-	return bsx_align_main_with(argc, argv, hip_process, 0, hip_open);
+	g_close_device = hip_close;
+	rc = bsx_align_main_with(argc, argv, hip_process, 0, hip_open);
+	g_close_device = 0; g_use_stream = 0;
+	return rc;
 }
