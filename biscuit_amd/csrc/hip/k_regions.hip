@@ -1183,7 +1183,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 __global__ void __launch_bounds__(256, 4)
 k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X,
       bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-      unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters)
+      unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
 	__shared__ RgC2r lds[4];
 	__shared__ int gap_tab[RG_QCAP + 1];
@@ -1195,7 +1195,9 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 	const int lane = wave_lane();
 	RgC2r &W = lds[threadIdx.x >> 6];
 	const int n = (int)*X.xcount;
-	for (;;) {
+	// a wave takes `quota` strand searches and leaves (the launch covers the worst case): workgroups with a bounded life let the
+	// back half's short high-priority batches (k_sw, k_global) of an older chunk get compute units while this one runs
+	for (int taken = 0; taken < quota; ++taken) {
 		int i = 0;
 		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
 		i = uni(__shfl(i, 0));
@@ -1844,7 +1846,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
               bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
               const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-              unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X)
+              unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X, int quota)
 {
 	__shared__ RgMid lds[2];
 	__shared__ RgDpLite dp[2];
@@ -1858,7 +1860,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 	RgMid &S = lds[threadIdx.x >> 6];
 	RgDpLite &D = dp[threadIdx.x >> 6];
 	const int n = (int)*count;
-	for (;;) {
+	for (int taken = 0; taken < quota; ++taken) {   // bounded workgroup life, as in k_c2r
 		int i = 0;
 		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
 		i = uni(__shfl(i, 0));
@@ -1977,18 +1979,18 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA)
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	hipLaunchKernelGGL(k_regions_mid, dim3(grid), dim3(128), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X);
+	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 }
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &XA, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters)
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	hipLaunchKernelGGL(k_c2r, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters);
+	hipLaunchKernelGGL(k_c2r, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 }
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,

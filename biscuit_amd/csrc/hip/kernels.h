@@ -33,7 +33,7 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X);
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X, int quota);   // quota: strand searches per wave
 // the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
 // rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
 // (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
@@ -49,7 +49,7 @@ void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevSco
 // chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters);
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

@@ -565,9 +565,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev3, L.st));
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
 	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
+	// strand searches a wave of the larger LDS tier / of the chains -> regions launch takes before it leaves (bounded workgroup life)
+	static const int mid_quota = getenv("BSX_MID_QUOTA") ? std::max(1, atoi(getenv("BSX_MID_QUOTA"))) : 8;
+	static const int c2r_quota = getenv("BSX_C2R_QUOTA") ? std::max(1, atoi(getenv("BSX_C2R_QUOTA"))) : 16;
 	if (use_mid)
-		launch_regions_mid(L.st, d->n_cu * 6, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA);
+		launch_regions_mid(L.st, (int)((n + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA, mid_quota);
 	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
 	// $BSX_C2R_LANES=1: the lane-per-strand-search / lane-per-extension rounds instead of the wavefront-per-strand-search launch.  Same
 	// regions (the tests run both); measured slower so far (k_ext_lane 398 ms + k_ext_pack 59 ms + k_c2r_ctrl 26 ms per chunk against
@@ -598,8 +601,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		launch_c2r_lanes(L.st, d->n_cu, d->ix, L.sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
 	} else
-	launch_c2r(L.st, d->n_cu * 8, d->ix, L.sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
-	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr);
+	launch_c2r(L.st, (int)((n + 4LL * c2r_quota - 1) / (4LL * c2r_quota)), d->ix, L.sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
+	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr, c2r_quota);
 	launch_regions_slab(L.st, 2, big_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
