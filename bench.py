@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")

@@ -120,11 +120,11 @@ BSX_HD uint32_t dev_count_word(uint32_t x, int nv)
 // left of the upto+1 symbols.  nv = how many symbols of the word lie at or before `upto` (the first symbol sits in the top bits).
 BSX_HD void dev_count_tgc(uint32_t x, int nv, uint32_t &nt, uint32_t &ng, uint32_t &nc)
 {
-	nv = nv < 0 ? 0 : nv;
-	const uint32_t below = 0xffffffffu >> ((nv << 1) & 31);                          // bits under the nv leading symbols (nv < 16)
-	const uint32_t valid = nv >= 16 ? 0x55555555u : (0x55555555u & ~below);
-	const uint32_t lo = x & valid, hi = (x >> 1) & valid;
-	nt += (uint32_t)dev_popc(hi & lo); ng += (uint32_t)dev_popc(hi & ~lo); nc += (uint32_t)dev_popc(lo & ~hi);
+	nv = nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+	// the low bit of each of the nv leading symbols: a 64-bit shift has no special case at either end (0 and 16 symbols)
+	const uint32_t valid = (uint32_t)(0xffffffff00000000ull >> (nv << 1)) & 0x55555555u;
+	const uint32_t lo = x & valid, hi = (x >> 1) & valid, both = hi & lo;
+	nt += (uint32_t)dev_popc(both); ng += (uint32_t)dev_popc(hi ^ both); nc += (uint32_t)dev_popc(lo ^ both);
 }
 BSX_HD void dev_block_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t &c, uint32_t &g, uint32_t &t)
 {

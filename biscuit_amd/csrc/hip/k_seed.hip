@@ -4,7 +4,103 @@
 #include "seed_core.hpp"
 #include "kernels.h"
 
-#define SEED_LDS_WORDS 32   // 256 bases per lane in LDS: 8 KB per wave
+#include "wave.hpp"
+
+#define SEED_LDS_WORDS 24   // 192 bases per lane in LDS: 6 KB per wave
+
+// The FM blocks of one trip are fetched by the wave as a whole.  A lane that reads its own 64-byte block issues four 16-byte
+// loads, each of which is one request for a line no other lane of the instruction shares: 64 lines per instruction, and the
+// line has to survive in L1 until the fourth load (it often does not: tools/ubench/gather64.hip, 2.0 TB/s for two blocks per
+// lane against 3.5 TB/s when four adjacent lanes read one block).  So the lanes post the block addresses they need, in
+// request order; lane l then loads piece l&3 of request 16r + (l>>2) in round r -- one full 64-byte line per four lanes, every
+// line touched by exactly one instruction -- and the pieces go back to their owners through LDS.
+struct SeedXchg {
+	unsigned long long addr[128];   // block addresses of this trip's requests (<= two per lane)
+	uint4 slot[64 * 4];             // blocks of 64 requests on their way back: piece p of request r at slot[(r&63)*4 + (p ^ (r>>2 & 3))]
+};
+
+__device__ __forceinline__ int seed_mbcnt(unsigned long long m)
+{
+	return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+__device__ __forceinline__ DevBlock seed_take(const SeedXchg &X, int req)
+{
+	const int at = (req & 63) << 2, sw = (req >> 2) & 3;
+	DevBlock b; b.v0 = X.slot[at + (0 ^ sw)]; b.v1 = X.slot[at + (1 ^ sw)]; b.v2 = X.slot[at + (2 ^ sw)]; b.v3 = X.slot[at + (3 ^ sw)];
+	return b;
+}
+
+// bwt_extend (lib/aln/bwt.c:278-293) of L.ext_in for the lanes with `need`; every lane of the wave takes part in the loads.
+__device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &ix, const SeedLane &L, SeedXchg &X, uint32_t &n_slow, uint32_t &n_fast)
+{
+	const int lane = (int)(threadIdx.x & 63), piece = lane & 3, sub = lane >> 2;
+	const int which = L.ext_which ? !L.parent : L.parent;
+	const uint64_t primary = dev_ix_primary(ix, which);
+	const uint32_t *bwt = dev_ix_bwt(ix, which);
+	const int is_back = L.ext_back, c = L.ext_c;
+	const uint64_t xa = is_back ? L.ext_in.x0 : L.ext_in.x1;   // x[!is_back]
+	const uint64_t xb = is_back ? L.ext_in.x1 : L.ext_in.x0;   // x[is_back]
+	const uint64_t x2 = L.ext_in.x2;
+	// bwt_2occ4 (lib/aln/bwt.c:204-236) at k = xa - 1 and l = xa - 1 + x2
+	const uint64_t NEG1 = ~0ull;
+	const uint64_t k = xa - 1, l = xa - 1 + x2;
+	const uint64_t ka = k - (k >= primary), la = l - (l >= primary);
+	const bool kv = k != NEG1, lv = l != NEG1;
+	const bool same = kv && lv && (ka >> 7) == (la >> 7);
+	const bool r0 = need, r1 = need && !same;
+	const unsigned long long m0 = __ballot(r0), m1 = __ballot(r1);
+	const int n0 = __popcll(m0), n = n0 + __popcll(m1);
+	const int i0 = seed_mbcnt(m0), i1 = n0 + seed_mbcnt(m1);
+	if (r0) X.addr[i0] = (unsigned long long)(bwt + (((kv ? ka : 0) >> 7) << 4));   // k == -1 reads block 0 and is discarded
+	if (r1) X.addr[i1] = (unsigned long long)(bwt + (((lv ? la : 0) >> 7) << 4));
+	WAVE_SYNC();
+	const int rounds = (n + 15) >> 4;
+	uint4 V[8];
+#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		V[r] = make_uint4(0, 0, 0, 0);
+		if (r < rounds) {
+			const int req = r * 16 + sub;
+			if (req < n) V[r] = reinterpret_cast<const uint4*>(X.addr[req])[piece];
+		}
+	}
+	DevBlock B0, B1;
+	B0.v0 = B0.v1 = B0.v2 = B0.v3 = make_uint4(0, 0, 0, 0); B1 = B0;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		if (h * 64 < n) {
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr) {
+				const int r = 4 * h + rr, req = r * 16 + sub;
+				if (req < n) X.slot[((req & 63) << 2) + (piece ^ ((req >> 2) & 3))] = V[r];
+			}
+			WAVE_SYNC();
+			if (h == 0 && r0) B0 = seed_take(X, i0);          // n0 <= 64: every first block travels in the first half
+			if (r1 && (i1 >> 6) == h) B1 = seed_take(X, i1);
+			WAVE_SYNC();
+		}
+	}
+	if (same) B1 = B0;
+	if (same) ++n_fast; else ++n_slow;
+	uint64_t tk[4], tl[4];
+	uint32_t a_, c_, g_, t_;
+	dev_block_count4(B0, (int)(ka & 127), a_, c_, g_, t_);
+	tk[0] = kv ? ((uint64_t)B0.v0.y << 32 | B0.v0.x) + a_ : 0; tk[1] = kv ? ((uint64_t)B0.v0.w << 32 | B0.v0.z) + c_ : 0;
+	tk[2] = kv ? ((uint64_t)B0.v1.y << 32 | B0.v1.x) + g_ : 0; tk[3] = kv ? ((uint64_t)B0.v1.w << 32 | B0.v1.z) + t_ : 0;
+	dev_block_count4(B1, (int)(la & 127), a_, c_, g_, t_);
+	tl[0] = lv ? ((uint64_t)B1.v0.y << 32 | B1.v0.x) + a_ : 0; tl[1] = lv ? ((uint64_t)B1.v0.w << 32 | B1.v0.z) + c_ : 0;
+	tl[2] = lv ? ((uint64_t)B1.v1.y << 32 | B1.v1.x) + g_ : 0; tl[3] = lv ? ((uint64_t)B1.v1.w << 32 | B1.v1.z) + t_ : 0;
+	const uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
+	const uint64_t b3 = xb + ((xa <= primary && xa + x2 - 1 >= primary) ? 1 : 0);
+	const uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
+	const uint64_t tkc = c == 3 ? tk[3] : c == 2 ? tk[2] : c == 1 ? tk[1] : tk[0];
+	const uint64_t na = dev_ix_L2(ix, which, c) + 1 + tkc;
+	const uint64_t nb = c == 3 ? b3 : c == 2 ? b2 : c == 1 ? b1 : b0;
+	const uint64_t ns = c == 3 ? s3 : c == 2 ? s2 : c == 1 ? s1 : s0;
+	DevIntv o;
+	o.x0 = is_back ? na : nb; o.x1 = is_back ? nb : na; o.x2 = ns; o.info = 0;
+	return o;
+}
 
 // One lane = one strand search at a time; lanes pull the next task from a global cursor as soon
 // as they finish (reads differ a lot in seeding work), so a wave stays full until the queue drains.
@@ -19,7 +115,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
        long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-       int quota, unsigned int *slab_busy, int n_slabs, int trip_budget)
+       int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
 	// per-wave slab, lane-interleaved: entry i of lane l sits at slab[i*64 + l], so the 64 lanes'
 	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
@@ -40,6 +136,8 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
 	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
 	__shared__ uint32_t s_read[4][SEED_LDS_WORDS][64];
+	__shared__ SeedXchg s_xchg[4];
+	SeedXchg &X = s_xchg[threadIdx.x >> 6];
 	uint32_t *my_read = &s_read[threadIdx.x >> 6][0][threadIdx.x & 63];
 	L.qlds = nullptr;
 	L.state = SD_DONE;
@@ -48,6 +146,8 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	uint32_t tot_slow = 0, tot_fast = 0;
 
 	unsigned int trip = 0;
+	// $BSX_PHASES: where a wave's cycles go (u64 slots 48..: wave cycles, in the full machine, publishing, trips, full-machine passes)
+	long long pc_t0 = prof ? clock64() : 0, pc_cold = 0, pc_pub = 0; unsigned int pc_cold_n = 0;
 	for (;;) {
 		// Every trip: the short machine (forward walk, backward sweep, LAST-like walk).  A lane that reaches any other state
 		// waits for the full machine, which the wave runs every fourth trip, or at once when 25 lanes wait or no lane has an
@@ -59,10 +159,14 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		const bool cold = !retired && !need;
 		const unsigned long long cm = __ballot(cold);
 		++trip;
-		if (cold && ((trip & 3u) == 0 || __popcll(cm) > 24 || __ballot(need) == 0)) {
+		const bool go_cold = cold && ((trip & 3u) == 0 || __popcll(cm) > 24 || __ballot(need) == 0);
+		long long pc_c0 = 0;
+		if (prof && __ballot(go_cold)) { pc_c0 = clock64(); ++pc_cold_n; }
+		if (go_cold) {
 			for (;;) {
 				if (L.state == SD_DONE) {
 					if (task >= 0) { // publish the finished task
+						const long long pc_p0 = prof ? clock64() : 0;
 						unsigned long long base = 0;
 						int n = L.mem_n;
 						if (n > 0 && !L.overflow) {
@@ -74,6 +178,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						task_n[task] = L.overflow ? -n - 1 : n;   // any negative count: seed this strand search again
 						tot_slow += L.n_slow; tot_fast += L.n_fast;
 						task = -1;
+						if (prof) pc_pub += clock64() - pc_p0;
 					}
 					if (quota && taken >= quota) { retired = 1; break; }
 					unsigned int t = atomicAdd(task_cursor, 1u);
@@ -107,12 +212,11 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 				if (need) break;
 			}
 		}
+		if (prof && pc_c0) pc_cold += clock64() - pc_c0;
 		if (__all(retired)) break;
+		if (__ballot(need) == 0) continue;
+		const DevIntv ok = seed_extend_wave(need, ix, L, X, L.n_slow, L.n_fast);
 		if (need) {
-			const int which = L.ext_which ? !L.parent : L.parent;
-			DevFmi fx; fx.primary = dev_ix_primary(ix, which); fx.bwt = dev_ix_bwt(ix, which);
-			fx.L2[0] = fx.L2[1] = fx.L2[2] = fx.L2[3] = fx.L2[4] = dev_ix_L2(ix, which, L.ext_c);
-			DevIntv ok = dev_extend(fx, L.ext_in, L.ext_back, L.ext_c, L.n_slow, L.n_fast);
 			seed_post(L, ok, P);
 			// a strand search whose lists no longer fit is abandoned at once: its result is discarded and it is seeded again with
 			// longer lists, so finishing it here would only keep this wave (and the kernel's tail) alive for nothing
@@ -126,6 +230,14 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	}
 	// work counters for the algorithmic-bytes model: slow path = two 64-B blocks, fast = one
 	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); }
+	if (prof) {
+		long long pub = pc_pub;
+		for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(pub, off); pub = pub > o ? pub : o; }
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(&counters[48], (unsigned long long)(clock64() - pc_t0)); atomicAdd(&counters[49], (unsigned long long)pc_cold);
+			atomicAdd(&counters[50], (unsigned long long)pub); atomicAdd(&counters[51], (unsigned long long)trip); atomicAdd(&counters[52], (unsigned long long)pc_cold_n);
+		}
+	}
 	if ((threadIdx.x & 63) == 0) {
 		atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast);
 		__threadfence();
@@ -163,18 +275,18 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget)
+                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
 	static const int occ = getenv("BSX_SEED_OCC") ? atoi(getenv("BSX_SEED_OCC")) : 3;   // waves per SIMD the register allocation targets
 	if (occ <= 3)
 		hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 	else if (occ == 4)
 		hipLaunchKernelGGL(k_seed<4>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 	else
 		hipLaunchKernelGGL(k_seed<5>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget);
+		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

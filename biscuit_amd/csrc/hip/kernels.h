@@ -7,7 +7,7 @@
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget);   // scratch holds n_slabs per-wave slabs; slab_busy[n_slabs] zeroed once
+                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof = 0);   // scratch holds n_slabs per-wave slabs; slab_busy[n_slabs] zeroed once
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters);
 // DP kernels: one wavefront per job
 void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,

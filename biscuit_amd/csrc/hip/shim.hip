@@ -555,7 +555,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget);
+	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
@@ -702,6 +702,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		D2H(L.st, hu, ctr, sizeof(hu));
 		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, left tier 2: %u\n",
 		        (long long)n, hu[4], hu[11], hc[1], hc[10], hc[3]);
+		unsigned long long sp[8];
+		D2H(L.st, sp, ctr + 48, sizeof(sp));
+		HIPCHK(hipMemsetAsync(ctr + 48, 0, sizeof(sp), L.st));
+		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
+		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
 		unsigned long long pf[16];
 		D2H(L.st, pf, ctr + 32, sizeof(pf));
 		HIPCHK(hipMemsetAsync(ctr + 32, 0, sizeof(pf), L.st));
