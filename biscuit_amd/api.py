@@ -162,6 +162,28 @@ class Device(Batches):
         """both FM indices built on the device from index's pac and left resident (csrc/hip/k_index.hip)"""
         B.check(B.lib().bsx_device_build_index(self.h, index.h, int(fill_host)), "bsx_device_build_index")
 
+    def global_tags(self, jobs, pool_len):
+        """bsx_global_batch_tags: K6 plus NM / MD / ZC / ZR of every job with a CIGAR -> (res, pool, tags, [md bytes or None])"""
+        jobs = np.ascontiguousarray(jobs, dtype=GLB_DT)
+        n = len(jobs)
+        res = np.zeros(n, dtype=GLBRES_DT)
+        pool = np.zeros(max(1, pool_len), dtype=np.uint32)
+        tags = np.zeros(n, dtype=np.dtype(B.GlbTag))
+        md = C.c_void_p()
+        cap = C.c_int64(0)
+        f = B.lib().bsx_global_batch_tags
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        B.check(f(self.h, n, _p(jobs), _p(res), _p(pool), pool.size, _p(tags), C.byref(md), C.byref(cap)), "bsx_global_batch_tags")
+        out = []
+        for k in range(n):
+            if tags[k]["l_md"] < 0:
+                out.append(None)
+            else:
+                out.append(C.string_at(md.value + int(tags[k]["md_off"]), int(tags[k]["l_md"]) + 1))
+        if md.value:
+            _libc_free(md)
+        return res, pool, tags, out
+
     def counters(self, reset=False):
         c = (C.c_uint64 * 4)()
         B.check(B.lib().bsx_device_counters(self.h, c, int(reset)), "bsx_device_counters")

@@ -7,6 +7,10 @@
 // H/E rows sit in LDS in the reference's in-place eh[] layout; the 1-byte/cell direction matrix
 // z[tlen][n_col] is streamed to a per-wave slab in HBM (it does not fit LDS for long reads) and
 // walked back by lane 0.
+// The job's final CIGAR is then walked over the job's own sequences for the second half of bis_bwa_gen_cigar2
+// (lib/aln/bwa.c:342-418): NM, the MD string, BISCUIT's conversion (ZC) and retention (ZR) counts.  The read is already in
+// LDS; the target bases are staged there by the wave when they fit; lane 0 walks twice (lengths, then bytes: the strings
+// are packed, each job taking exactly its length from one cursor).
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 #include "wave.hpp"
@@ -18,15 +22,17 @@
 template <int NC>
 __global__ void __launch_bounds__(256)
 k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order, long long n,
-         bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap)
+         bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap,
+         bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap)
 {
 	extern __shared__ int32_t lds[];
 	const int lane = wave_lane();
 	const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
-	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1;
+	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1 + ((tcap + 3) >> 2);
 	int32_t *H = lds + wave * stride;
 	int32_t *E = H + (qcap + 2);
 	uint8_t *qb = reinterpret_cast<uint8_t*>(E + (qcap + 2));
+	uint8_t *tb = qb + (((qcap + 3) >> 2) << 2) + 4;   // tcap target bases (tags only)
 	uint8_t *z = zscratch + ((size_t)blockIdx.x * wpb + wave) * zstride;
 
 	for (long long jj = (long long)blockIdx.x * wpb + wave; jj < n; jj += (long long)gridDim.x * wpb) {
@@ -165,24 +171,83 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 			if (score >= J.truesc - sc.a) break;
 		}
 		if (lane == 0) { bsx_glb_res_t r; r.score = score; r.n_cigar = n_cigar; r.w_used = w_used; r.pad = 0; res[job] = r; }
+		if (tags && J.want_cigar) { // MD / NM / ZC / ZR (bwa.c:342-418)
+			const bool staged = tlen <= tcap;
+			if (n_cigar > 0 && staged) for (int k = lane; k < tlen; k += 64) tb[k] = (uint8_t)dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)k * J.tdir);
+			__threadfence_block();   // the CIGAR lane 0 wrote, read back below
+			WAVE_SYNC();
+			if (lane == 0) {
+				bsx_glb_tag_t T; T.NM = T.ZC = T.ZR = 0; T.l_md = -1; T.md_off = 0; T.bss_u = 0;
+				for (int k = 0; k < 7; ++k) T.pad[k] = 0;
+				if (n_cigar > 0) {
+					const int parent = J.use_ct, rev = J.tdir < 0;
+					unsigned long long at = 0;
+					char *dst = nullptr;
+					for (int pass = 0; pass < 2; ++pass) {
+						int x = 0, y = 0, u = 0, l = 0, n_mm = 0, n_gap = 0, n_conv = 0, n_ret = 0;
+						// decimal of the pending run of matches, then one character
+						#define MD_NUM(v) do { int v_ = (v), nd_ = v_ >= 10000 ? 5 : v_ >= 1000 ? 4 : v_ >= 100 ? 3 : v_ >= 10 ? 2 : 1; \
+							if (dst) { int t_ = v_; for (int d_ = nd_ - 1; d_ >= 0; --d_) { dst[l + d_] = (char)('0' + t_ % 10); t_ /= 10; } } l += nd_; } while (0)
+						#define MD_CHR(c) do { if (dst) dst[l] = (char)(c); ++l; } while (0)
+						#define MD_BASE(r) ((r) > 3 ? 'N' : (int)(((rev ? 0x41434754u : 0x54474341u) >> ((r) << 3)) & 0xffu))   /* "ACGT" / "TGCA" (bwa.c:297,345) */
+						for (int k = 0; k < n_cigar; ++k) {
+							const int op = (int)(cig[k] & 0xf), len = (int)(cig[k] >> 4);
+							if (op == 0) {
+								for (int i = 0; i < len; ++i) {
+									const int q = qb[x + i];
+									const int r = staged ? (int)tb[y + i] : dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir);
+									if (q == r) { n_ret += parent ? q == 1 : q == 2; ++u; }
+									else {
+										MD_NUM(u); MD_CHR(MD_BASE(r)); u = 0;
+										if (parent ? (q == 3 && r == 1) : (q == 0 && r == 2)) ++n_conv; else ++n_mm;
+									}
+								}
+								x += len; y += len;
+							} else if (op == 2) {
+								if (k > 0 && k < n_cigar - 1) {
+									MD_NUM(u); MD_CHR('^');
+									for (int i = 0; i < len; ++i) { const int r = staged ? (int)tb[y + i] : dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir); MD_CHR(MD_BASE(r)); }
+									u = 0; n_gap += len;
+								}
+								y += len;
+							} else if (op == 1) { x += len; n_gap += len; }
+						}
+						MD_NUM(u);
+						#undef MD_NUM
+						#undef MD_CHR
+						#undef MD_BASE
+						if (pass == 0) {
+							at = atomicAdd(md_cursor, (unsigned long long)l + 1);
+							if (at + (unsigned long long)l + 1 > md_cap) break;   // cannot happen: the pool holds every job's upper bound
+							dst = md_pool + at;
+							T.NM = n_mm + n_gap; T.ZC = n_conv; T.ZR = n_ret; T.bss_u = n_conv == 0; T.l_md = l; T.md_off = at;
+						} else dst[l] = 0;
+					}
+				}
+				tags[job] = T;
+			}
+		}
 		WAVE_SYNC();
 	}
 }
 
 template <int NC>
 static void launch_glb_nc(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
-                          long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks, int wpb)
+                          long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks, int wpb,
+                          bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap)
 {
-	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1;
+	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1 + ((tcap + 3) >> 2);
 	const size_t lds = (size_t)wpb * stride * 4;
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_global<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(k_global<NC>, dim3(blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap);
+	hipLaunchKernelGGL(k_global<NC>, dim3(blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap,
+	                   tags, md_pool, md_cap, md_cursor, tcap);
 }
 
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
-                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb)
+                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb,
+                   bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap)
 {
-	if (nc <= 4) launch_glb_nc<4>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
-	else if (nc <= 16) launch_glb_nc<16>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
-	else launch_glb_nc<32>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb);
+	if (nc <= 4) launch_glb_nc<4>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb, tags, md_pool, md_cap, md_cursor, tcap);
+	else if (nc <= 16) launch_glb_nc<16>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb, tags, md_pool, md_cap, md_cursor, tcap);
+	else launch_glb_nc<32>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, wpb, tags, md_pool, md_cap, md_cursor, tcap);
 }

@@ -277,16 +277,9 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
-	static const int occ = getenv("BSX_SEED_OCC") ? atoi(getenv("BSX_SEED_OCC")) : 3;   // waves per SIMD the register allocation targets
-	if (occ <= 3)
-		hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
-	else if (occ == 4)
-		hipLaunchKernelGGL(k_seed<4>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
-	else
-		hipLaunchKernelGGL(k_seed<5>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-		                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
+	// 168 VGPRs and 11 KB of LDS per wave: three waves per SIMD
+	hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

@@ -15,7 +15,8 @@ void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
 void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc);
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
-                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb);
+                   long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb,
+                   bsx_glb_tag_t *tags = nullptr, char *md_pool = nullptr, unsigned long long md_cap = 0, unsigned long long *md_cursor = nullptr, int tcap = 0);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
 // Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
 // regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.

@@ -26,7 +26,7 @@ struct Lane {
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows, tags, mdpool;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -120,7 +120,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release(); L.tags.release(); L.mdpool.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -896,7 +896,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 // K6
 // ------------------------------------------------------------------------------------------
 static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
-                             uint32_t *cigar_pool, size_t cigar_pool_len)
+                             uint32_t *cigar_pool, size_t cigar_pool_len, bsx_glb_tag_t *tags = nullptr, char **md = nullptr, int64_t *md_cap = nullptr)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
 	Lane &L = d->lane[lane];
@@ -905,9 +905,14 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 1024, 2048}, NCS[3] = {4, 16, 32}, WPB[3] = {4, 4, 1};
 	std::vector<int> order[3];
 	size_t zmax[3] = {64, 64, 64};
+	// tags: the target bases of a job are staged in LDS for the MD walk when they fit next to the DP rows (the rare longer ones are
+	// read from HBM); an MD string is at most two characters per target base plus the last count
+	static const int TCAP[3] = {512, 2048, 0};
+	size_t md_bound = 64;
 	const DevScoring &sc = L.sc;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_glb_job_t &j = jobs[i];
+		if (tags && j.want_cigar) md_bound += 2 * (size_t)j.tlen + 16;
 		if (j.qlen <= 0 || j.tlen <= 0 || j.n_try < 1) { fprintf(stderr, "[bsx-hip] global job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
 		if (j.want_cigar && (size_t)j.cigar_off + j.cigar_cap > cigar_pool_len) return BSX_E_ARG;
 		const int8_t *mat = j.use_ct ? sc.ctmat : sc.gamat;
@@ -938,6 +943,13 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	if ((rc = L.scratch.reserve(ztot + 256)) != BSX_OK) return rc;
 	if ((rc = L.pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
+	unsigned long long *md_cursor = dev_counters(L) + 60;
+	if (tags) {
+		if ((rc = L.tags.reserve((size_t)n * sizeof(bsx_glb_tag_t))) != BSX_OK) return rc;
+		if ((rc = L.mdpool.reserve(md_bound)) != BSX_OK) return rc;
+		HIPCHK(hipMemsetAsync(md_cursor, 0, 8, L.st_hi));
+		HIPCHK(hipMemsetAsync(L.tags.p, 0xff, (size_t)n * sizeof(bsx_glb_tag_t), L.st_hi));   // l_md = -1: jobs that ask for no CIGAR
+	}
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t));
 	size_t off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
@@ -949,13 +961,25 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
 		launch_global(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_glb_res_t*)L.res.p, (uint32_t*)L.pool.p, (uint8_t*)L.scratch.p, zmax[c],
-		              QCAP[c], NCS[c], blocks[c], WPB[c]);
+		              QCAP[c], NCS[c], blocks[c], WPB[c], tags ? (bsx_glb_tag_t*)L.tags.p : nullptr, (char*)L.mdpool.p, (unsigned long long)md_bound, md_cursor, tags ? TCAP[c] : 0);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
 	if ((rc = finish_timed(L, 4)) != BSX_OK) return rc;
 	D2H(L.st_hi, res, L.res.p, (size_t)n * sizeof(bsx_glb_res_t));
 	D2H(L.st_hi, cigar_pool, L.pool.p, cigar_pool_len * 4);
+	if (tags) {
+		unsigned long long used = 0;
+		D2H(L.st_hi, tags, L.tags.p, (size_t)n * sizeof(bsx_glb_tag_t));
+		D2H(L.st_hi, &used, md_cursor, 8);
+		if (used > md_bound) { fprintf(stderr, "[bsx-hip] MD pool overrun (%llu > %zu)\n", used, md_bound); return BSX_E_INTERNAL; }
+		if ((int64_t)used + 1 > *md_cap) {
+			char *g = (char*)realloc(*md, (size_t)used + 64);
+			if (!g) return BSX_E_NOMEM;
+			*md = g; *md_cap = (int64_t)used + 64;
+		}
+		D2H(L.st_hi, *md, L.mdpool.p, (size_t)used);
+	}
 	return BSX_OK;
 }
 
@@ -972,6 +996,9 @@ extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ex
 extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res) { return lane_sw_batch(d, 0, n, jobs, res); }
 extern "C" BSX_API int bsx_global_batch(bsx_device_t *d, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_len)
 { return lane_global_batch(d, 0, n, jobs, res, cigar_pool, cigar_pool_len); }
+extern "C" BSX_API int bsx_global_batch_tags(bsx_device_t *d, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res, uint32_t *cigar_pool, size_t cigar_pool_len,
+                                             bsx_glb_tag_t *tags, char **md, int64_t *md_cap)
+{ if (!tags || !md || !md_cap) return BSX_E_ARG; return lane_global_batch(d, 0, n, jobs, res, cigar_pool, cigar_pool_len, tags, md, md_cap); }
 
 // the seams as one vtable for the host pipeline; ctx = (device, lane)
 #define LR(c) ((LaneRef*)(c))->d, ((LaneRef*)(c))->lane
@@ -993,6 +1020,8 @@ static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_tas
 }
 static int be_regions_finish(void *c, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return lane_regions_finish(LR(c), out, cap, off, cnt); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
+static int be_glb_tags(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len, bsx_glb_tag_t *t, char **md, int64_t *cap)
+{ return lane_global_batch(LR(c), n, j, r, pool, len, t, md, cap); }
 
 static LaneRef g_lane_ref[8][BSX_LANES];   // ctx storage for the vtables (by device ordinal)
 
@@ -1005,7 +1034,7 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	memset(out, 0, sizeof(*out));
 	out->ctx = r; out->name = "hip-gfx950";
 	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
-	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb;
+	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb; out->global_batch_tags = be_glb_tags;
 	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;
 	out->regions_finish = out->regions_batch ? be_regions_finish : nullptr;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
 	return BSX_OK;

@@ -162,6 +162,9 @@ typedef struct bsx_backend {
 	int (*sw_batch)(void *ctx, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 	int (*global_batch)(void *ctx, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
 	                    uint32_t *cigar_pool, size_t cigar_pool_len);
+	/* optional (may be NULL): the same with MD / NM / ZC / ZR, see bsx_global_batch_tags */
+	int (*global_batch_tags)(void *ctx, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+	                         uint32_t *cigar_pool, size_t cigar_pool_len, bsx_glb_tag_t *tags, char **md, int64_t *md_cap);
 	/* optional (may be NULL): seeding through regions in one device pass, see bsx_regions_batch */
 	int (*regions_batch)(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx_seed_task_t *tasks,
 	                     bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n,

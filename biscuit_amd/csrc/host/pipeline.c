@@ -656,6 +656,7 @@ static void out_worker(void *data, long u, int tid)
 
 typedef struct {
 	chunk_t *C; samctx_t *ctx; int per; const int *todo, *jread, *jreg; const bsx_glb_job_t *sub; const bsx_glb_res_t *sres; const uint32_t *pool;
+	const bsx_glb_tag_t *tags; const char *md;   /* NM / MD / ZC / ZR from the backend, or NULL */
 } finish_par_t;
 static void finish_worker(void *data, long k, int tid)
 {
@@ -664,7 +665,7 @@ static void finish_worker(void *data, long k, int tid)
 	(void)tid;
 	if (F->sres[k].n_cigar < 0) return;   /* did not fit: redone with more room */
 	bsx_setsam_finish(F->C->opt, F->C->idx, &F->C->reads[ri], &F->C->regs[ri].a[F->jreg[jj]], F->pool + F->sub[k].cigar_off, F->sres[k].n_cigar,
-	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]]);
+	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]], F->tags ? &F->tags[k] : 0, F->tags ? F->md + F->tags[k].md_off : 0);
 }
 
 typedef struct { chunk_t *C; samctx_t *ctx; int per; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg; } plan_par_t;
@@ -715,6 +716,8 @@ static int emit_sam(chunk_t *C)
 	plan_par_t Q;
 	BSX_VEC(int) todo;
 	uint32_t *pool = 0;
+	char *md = 0;
+	int64_t md_cap = 0;
 	size_t k, pool_len = 0;
 	int64_t n_jobs;
 	double t0 = now_s(), t_batch = 0;
@@ -736,15 +739,22 @@ static int emit_sam(chunk_t *C)
 		/* the first round is every job, in place (a million 48-byte records are not copied); a later one the few whose CIGAR did not fit */
 		bsx_glb_job_t *sub = round == 0 ? Q.jobs : (bsx_glb_job_t*)malloc(sizeof(*sub) * todo.n);
 		bsx_glb_res_t *sres = (bsx_glb_res_t*)malloc(sizeof(*sres) * todo.n);
+		bsx_glb_tag_t *tags = C->be->global_batch_tags ? (bsx_glb_tag_t*)malloc(sizeof(*tags) * todo.n) : 0;
 		size_t off = 0, nt = 0;
 		if (round == 0) for (k = 0; k < todo.n; ++k) { sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		else for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
-		{ double tb = now_s(); rc = C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off); t_batch += now_s() - tb; }
+		{
+			double tb = now_s();
+			rc = tags ? C->be->global_batch_tags(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off, tags, &md, &md_cap)
+			          : C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
+			t_batch += now_s() - tb;
+		}
 		C->st.n_glb_jobs += (int64_t)todo.n;
 		if (rc == BSX_OK) {
 			finish_par_t F;
 			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = Q.jread; F.jreg = Q.jreg; F.sub = sub; F.sres = sres; F.pool = pool;
+			F.tags = tags; F.md = md;
 			bsx_parallel_for(C->nt, finish_worker, &F, (long)todo.n);
 			for (k = 0; k < todo.n; ++k) {
 				int jj = todo.a[k];
@@ -753,7 +763,7 @@ static int emit_sam(chunk_t *C)
 		}
 		todo.n = nt;
 		if (round) free(sub);
-		free(sres);
+		free(sres); free(tags);
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
 	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
@@ -762,7 +772,7 @@ static int emit_sam(chunk_t *C)
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
 	if (C->arena_set < 0) bsx_parallel_for(C->nt, plan_free_worker, &Q, n_units);   /* arena memory is rewound with the chunk */
 	C->st.t_sam += now_s() - t0;
-	free(ctx); free(pool); free(Q.cnt); free(Q.off); free(Q.jobs); free(Q.jread); free(Q.jreg);
+	free(ctx); free(pool); free(md); free(Q.cnt); free(Q.off); free(Q.jobs); free(Q.jread); free(Q.jreg);
 	bsx_vec_free(todo);
 	return rc;
 }

@@ -52,7 +52,7 @@ void bsx_reg2sam_pe(const bsx_opt_t *opt, const bsx_index_t *idx, uint64_t id, b
 void bsx_setsam_job(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, uint32_t qoff, const reg_t *reg, bsx_glb_job_t *job);
 /* finish a region's SAM record from the device CIGAR: MD/NM/ZC/ZR, D-squeezing, clipping, position */
 void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, const reg_t *reg,
-                       const uint32_t *cigar, int n_cigar, samrec_t *out);
+                       const uint32_t *cg, int n_cigar, samrec_t *out, const bsx_glb_tag_t *tag, const char *tag_md);
 
 extern char bsx_rg_id[256];
 

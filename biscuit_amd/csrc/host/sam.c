@@ -76,8 +76,9 @@ void bsx_setsam_job(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read
 	job->use_ct = reg->parent; job->want_cigar = 1;
 }
 
+/* tag != NULL: NM / MD / ZC / ZR came with the CIGAR (bsx_global_batch_tags: computed by the device over the same job) */
 void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, const reg_t *reg,
-                       const uint32_t *cg, int n_cigar, samrec_t *out)
+                       const uint32_t *cg, int n_cigar, samrec_t *out, const bsx_glb_tag_t *tag, const char *tag_md)
 {
 	int64_t l_pac = idx->ref.l_pac, rpos;
 	int rev = reg->rb >= l_pac, k, x, y, u, i, is_rev;
@@ -94,7 +95,11 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 	uint32_t *cigar;
 	(void)opt;
 	md_stack[0] = 0;
-	{
+	if (tag && tag->l_md >= 0) {
+		l_MD = tag->l_md + 1;
+		memset(out, 0, sizeof(*out));
+		out->NM = tag->NM; out->ZC = tag->ZC; out->ZR = tag->ZR; out->bss_u = tag->bss_u;
+	} else { /* a backend without them (the batch entry points one by one, the CPU checker's): here */
 		const int64_t rl = reg->re - reg->rb, f0 = rev ? (l_pac << 1) - reg->re : reg->rb;   /* forward coordinate of the first base */
 		int64_t j;
 		if (rl > (int64_t)sizeof(rb_stack)) {
@@ -102,7 +107,6 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 		}
 		if (rev) for (j = 0; j < rl; ++j) rbase[j] = (uint8_t)(3 - bsx_pac_get(idx->pac, f0 + j));
 		else for (j = 0; j < rl; ++j) rbase[j] = (uint8_t)bsx_pac_get(idx->pac, f0 + j);
-	}
 	/* MD / NM / ZC / ZR over the alignment (bwa.c:342-418); conversions are MD mismatches but not NM */
 	for (k = 0, x = y = u = 0; k < n_cigar; ++k) {
 		int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
@@ -141,6 +145,7 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 	out->ZC = parent ? n_conv_ct : n_conv_ga;
 	out->ZR = parent ? n_ret_c : n_ret_g;
 	out->bss_u = (n_conv_ct == 0 && n_conv_ga == 0) ? 1 : 0;
+	}
 	/* position, strand, D squeezing and clipping (mem_alnreg_format.c:79-120) */
 	cigar = (uint32_t*)bsx_crealloc(0, 0, 4 * ((size_t)n_cigar + 2) + l_MD + 4);   /* chunk lifetime: from the worker's arena */
 	memcpy(cigar, cg, 4 * (size_t)n_cigar);
@@ -156,7 +161,8 @@ void bsx_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_r
 		if (clip5) { memmove(cigar + 1, cigar, (size_t)n_cigar * 4); cigar[0] = (uint32_t)clip5 << 4 | 3; ++n_cigar; }
 		if (clip3) cigar[n_cigar++] = (uint32_t)clip3 << 4 | 3;
 	}
-	memcpy(cigar + n_cigar, md.s, md.l + 1);
+	if (tag && tag->l_md >= 0) memcpy(cigar + n_cigar, tag_md, (size_t)tag->l_md + 1);
+	else memcpy(cigar + n_cigar, md.s, md.l + 1);
 	if (md.s != md_stack) free(md.s);
 	if (rbase != rb_stack) free(rbase);
 	out->n_cigar = n_cigar;

@@ -274,6 +274,19 @@ int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_
 /* K6 */
 int bsx_global_batch(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
                      uint32_t *cigar_pool, size_t cigar_pool_len);
+/* K6 with the second half of bis_bwa_gen_cigar2 (lib/aln/bwa.c:342-418) done on the device as well: NM, the MD string
+ * and BISCUIT's conversion / retention counts of every job that has a CIGAR, walked over the job's own (possibly
+ * reversed) sequences.  tags[i].l_md < 0: job i has no CIGAR yet (res[i].n_cigar <= 0).  The MD strings (NUL-terminated)
+ * are packed into *md, a buffer the library grows with realloc as bsx_seed_batch grows *out. */
+typedef struct bsx_glb_tag {
+	int32_t  NM, ZC, ZR;
+	int32_t  l_md;        /* strlen of the MD string */
+	uint64_t md_off;      /* where it starts in *md */
+	uint8_t  bss_u;       /* no conversion seen (bwa.c:415-416) */
+	uint8_t  pad[7];
+} bsx_glb_tag_t;
+int bsx_global_batch_tags(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
+                          uint32_t *cigar_pool, size_t cigar_pool_len, bsx_glb_tag_t *tags, char **md, int64_t *md_cap);
 
 /* device-side work counters of the last seed/sa batch (algorithmic-bytes model):
  * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and

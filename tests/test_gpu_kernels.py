@@ -252,3 +252,61 @@ def test_global_matches_oracle(small_index, port, device):
             o = int(jobs[k]["cigar_off"])
             assert (pp[o:o + n] == dp[o:o + n]).all(), k
     assert (pr["n_cigar"] > 1).sum() > 20
+    # the second half of bis_bwa_gen_cigar2 (lib/aln/bwa.c:342-418) on the device: NM, MD, ZC, ZR of the same jobs against a
+    # restatement of that loop written here (the CIGARs were just shown to be the checker's)
+    tr, tp, tags, mds = device.global_tags(jobs, cig_off)
+    assert (tr == dr).all() and (tp == dp).all()
+    pac = np.fromfile(small_index.base + ".bis.pac", dtype=np.uint8)
+
+    def ref_base(p):
+        if p >= l_pac:
+            p = 2 * l_pac - 1 - p
+            return 3 - int((pac[p >> 2] >> ((~p & 3) << 1)) & 3)
+        return int((pac[p >> 2] >> ((~p & 3) << 1)) & 3)
+    n_checked = n_conv = n_del = 0
+    for k in range(len(jobs)):
+        J = jobs[k]
+        n = int(dr[k]["n_cigar"])
+        if not J["want_cigar"] or n <= 0:
+            assert mds[k] is None
+            continue
+        o = int(J["cigar_off"])
+        q = [int(buf[int(J["qoff"]) + i * int(J["qdir"])]) for i in range(int(J["qlen"]))]
+        t = [ref_base(int(J["tpos"]) + i * int(J["tdir"])) for i in range(int(J["tlen"]))]
+        int2base = "TGCAN" if J["tdir"] < 0 else "ACGTN"     # bwa.c:345: the forward-strand base of a reversed alignment
+        parent = int(J["use_ct"])
+        x = y = u = n_mm = n_gap = zc = zr = 0
+        md = ""
+        for c in range(n):
+            op, ln = int(dp[o + c]) & 0xf, int(dp[o + c]) >> 4
+            if op == 0:
+                for i in range(ln):
+                    a, b = q[x + i], t[y + i]
+                    if a == b:
+                        zr += (a == 1) if parent else (a == 2)
+                        u += 1
+                    else:
+                        md += "%d%s" % (u, int2base[b])
+                        u = 0
+                        if (parent and a == 3 and b == 1) or (not parent and a == 0 and b == 2):
+                            zc += 1
+                        else:
+                            n_mm += 1
+                x += ln
+                y += ln
+            elif op == 2:
+                if 0 < c < n - 1:
+                    md += "%d^%s" % (u, "".join(int2base[b] for b in t[y:y + ln]))
+                    u = 0
+                    n_gap += ln
+                    n_del += 1
+                y += ln
+            elif op == 1:
+                x += ln
+                n_gap += ln
+        md += "%d" % u
+        assert mds[k] == md.encode() + b"\0", (k, mds[k], md)
+        assert (int(tags[k]["NM"]), int(tags[k]["ZC"]), int(tags[k]["ZR"]), int(tags[k]["bss_u"])) == (n_mm + n_gap, zc, zr, int(zc == 0)), k
+        n_checked += 1
+        n_conv += zc
+    assert n_checked > 250 and n_conv > 1000 and n_del > 5
