@@ -64,7 +64,7 @@ struct RgStore {
 	RgNode node[NODES_ ? NODES_ : 1];
 	int n_nodes, root;
 };
-typedef RgStore<64, 96, 96, 0, 0, unsigned short, short, 32> RgSmall;
+typedef RgStore<64, 128, 128, 0, 0, unsigned short, short, 32> RgSmall;
 typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;             // still LDS: 24 KB per wave, two waves per workgroup: the
                                                                                 // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
@@ -950,6 +950,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 						// most extensions of a 150 bp read are shorter than a wavefront is wide: one register entry per lane then,
 						// and none of the per-chunk band tests and carries of the wider form
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? D.win : nullptr, rmax0, D.q, qoff);
+						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? D.win : nullptr, rmax0, D.q, qoff);
 						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? D.win : nullptr, rmax0, D.q, qoff);   // qlen <= l_query - 1 <= 255: fits the 256 register entries
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
@@ -1140,7 +1141,9 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 						aw = P.w << i;
 						J.w = aw;
 						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + 6], (unsigned long long)(now_ - pf_t)); pf_t = now_; }
+						// rows in registers, 64 entries per lane slot: as few slots as the query needs (a row's cost grows with them)
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
