@@ -40,13 +40,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # $BSX_BENCH_SHARE_GPU=1 (a check of the N > 1 code path on a one-GPU box, never a measurement): every rank computes on GPU 0
+    # and the ranks talk over gloo; the JSON line says so
+    share_gpu = world > 1 and os.environ.get("BSX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from biscuit_amd import _lib as B
     from biscuit_amd.api import Index, Device, default_opt
@@ -157,7 +165,7 @@ def main():
     def sink(k, buf):
         gathered[0] += 1
         gathered[1] += len(buf)
-    gdev = torch.device("cuda", local_rank) if world > 1 else torch.device("cpu")
+    gdev = torch.device("cuda", local_rank) if world > 1 and not share_gpu else torch.device("cpu")
     G = ChunkGather(rank, world, gdev, sink, max_pending=3)
     L.bsx_hook_chunk_sam.restype = C.c_int64
     L.bsx_hook_chunk_sam.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
@@ -225,10 +233,10 @@ def main():
 
     tmax, tot_reads = dt, n_reads * args.steps
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
-        c = torch.tensor([tot_reads], dtype=torch.int64, device="cuda")
+        c = torch.tensor([tot_reads], dtype=torch.int64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(c)   # "gather" of per-GPU record counts over RCCL
         tot_reads = int(c.item())
 
@@ -327,7 +335,7 @@ def main():
             "config": {"workload": "BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs a SYNTHETIC %.0f Mbp genome with repeat families "
                                    "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
                                    "built on the GPU at start-up), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp, 2 * n_bases / 1e9),
-                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": "chunk-sharded x%d" % world, "chunk_pipeline_depth": depth,
+                       "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": ("chunk-sharded x%d" % world) + (" (CODE-PATH CHECK: all ranks on one GPU, gloo; not a measurement)" if share_gpu else ""), "chunk_pipeline_depth": depth,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 4 * 8) + n_bases / 4)},
             "roofline": roof,
             "roofline_second_kernel": roof_other,

@@ -173,14 +173,82 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 		if (lane == 0) { bsx_glb_res_t r; r.score = score; r.n_cigar = n_cigar; r.w_used = w_used; r.pad = 0; res[job] = r; }
 		if (tags && J.want_cigar) { // MD / NM / ZC / ZR (bwa.c:342-418)
 			const bool staged = tlen <= tcap;
-			if (n_cigar > 0 && staged) for (int k = lane; k < tlen; k += 64) tb[k] = (uint8_t)dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)k * J.tdir);
+			const int parent = J.use_ct, rev = J.tdir < 0;
+			#define MD_BASE(r) ((r) > 3 ? 'N' : (int)(((rev ? 0x41434754u : 0x54474341u) >> ((r) << 3)) & 0xffu))   /* "ACGT" / "TGCA" (bwa.c:297,345) */
+			#define MD_DIGITS(v) ((v) >= 10000 ? 5 : (v) >= 1000 ? 4 : (v) >= 100 ? 3 : (v) >= 10 ? 2 : 1)
 			__threadfence_block();   // the CIGAR lane 0 wrote, read back below
 			WAVE_SYNC();
-			if (lane == 0) {
+			if (n_cigar > 0 && staged) {
+				// The wave walks the alignment 64 columns at a time: a lane compares one column; a mismatching lane knows the run of
+				// matches before it from the ballot (the lanes below it, or the run carried in from the columns before), hence the
+				// length of its "<run><base>" and, by a prefix sum, where it goes.  The string is assembled in the LDS the DP rows
+				// occupied (8 bytes per query column >= 2 per target base) and copied out once its length is known.
+				for (int k = lane; k < tlen; k += 64) tb[k] = (uint8_t)dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)k * J.tdir);
+				uint8_t *mdb = reinterpret_cast<uint8_t*>(H);
+				WAVE_SYNC();
+				int x = 0, y = 0, u = 0, l = 0, n_mm = 0, n_gap = 0, n_conv = 0, n_ret = 0;
+				for (int k = 0; k < n_cigar; ++k) {
+					const uint32_t cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)cig[k]);
+					const int op = (int)(cg & 0xf), len = (int)(cg >> 4);
+					if (op == 0) {
+						for (int b0 = 0; b0 < len; b0 += 64) {
+							const int n = len - b0 < 64 ? len - b0 : 64;
+							const bool act = lane < n;
+							const int q = act ? qb[x + b0 + lane] : 0, r = act ? tb[y + b0 + lane] : 0;
+							const bool mm = act && q != r;
+							const bool conv = mm && (parent ? (q == 3 && r == 1) : (q == 0 && r == 2));
+							const unsigned long long B = __ballot(mm), Bc = __ballot(conv);
+							n_ret += __popcll(__ballot(act && q == r && (parent ? q == 1 : q == 2)));
+							n_conv += __popcll(Bc); n_mm += __popcll(B) - __popcll(Bc);
+							if (B) {
+								const unsigned long long below = B & ((1ull << lane) - 1ull);
+								const int prev = below ? 63 - __builtin_clzll(below) : -1;
+								int run = lane - prev - 1 + (prev < 0 ? u : 0);
+								const int nd = MD_DIGITS(run), mine = mm ? nd + 1 : 0;
+								const int incl = wave_scan_sum_incl(mine);
+								if (mm) {
+									uint8_t *d = mdb + l + incl - mine;
+									d[nd] = (uint8_t)MD_BASE(r);
+									for (int t = nd - 1; t >= 0; --t) { d[t] = (uint8_t)('0' + run % 10); run /= 10; }
+								}
+								l += __builtin_amdgcn_readlane(incl, 63);
+								u = n - 1 - (63 - __builtin_clzll(B));
+							} else u += n;
+						}
+						x += len; y += len;
+					} else if (op == 2) {
+						if (k > 0 && k < n_cigar - 1) {
+							const int nd = MD_DIGITS(u);
+							if (lane == 0) { int v = u; mdb[l + nd] = '^'; for (int t = nd - 1; t >= 0; --t) { mdb[l + t] = (uint8_t)('0' + v % 10); v /= 10; } }
+							l += nd + 1;
+							for (int i = lane; i < len; i += 64) { const int r = tb[y + i]; mdb[l + i] = (uint8_t)MD_BASE(r); }
+							l += len; u = 0; n_gap += len;
+						}
+						y += len;
+					} else if (op == 1) { x += len; n_gap += len; }
+				}
+				{
+					const int nd = MD_DIGITS(u);
+					if (lane == 0) { int v = u; mdb[l + nd] = 0; for (int t = nd - 1; t >= 0; --t) { mdb[l + t] = (uint8_t)('0' + v % 10); v /= 10; } }
+					l += nd;
+				}
+				WAVE_SYNC();
+				unsigned long long at = 0;
+				if (lane == 0) at = atomicAdd(md_cursor, (unsigned long long)l + 1);
+				at = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(at >> 32), 0) << 32 | (unsigned)__builtin_amdgcn_readlane((int)at, 0);
+				if (at + (unsigned long long)l + 1 <= md_cap) {   // always: the pool holds every job's upper bound
+					for (int i = lane; i <= l; i += 64) md_pool[at + i] = (char)mdb[i];
+					if (lane == 0) {
+						bsx_glb_tag_t T; T.NM = n_mm + n_gap; T.ZC = n_conv; T.ZR = n_ret; T.l_md = l; T.md_off = at; T.bss_u = n_conv == 0;
+						for (int k = 0; k < 7; ++k) T.pad[k] = 0;
+						tags[job] = T;
+					}
+				}
+			} else
+			if (lane == 0) { // no CIGAR (l_md = -1), or a target longer than the LDS stage: one lane, twice (lengths, then bytes)
 				bsx_glb_tag_t T; T.NM = T.ZC = T.ZR = 0; T.l_md = -1; T.md_off = 0; T.bss_u = 0;
 				for (int k = 0; k < 7; ++k) T.pad[k] = 0;
 				if (n_cigar > 0) {
-					const int parent = J.use_ct, rev = J.tdir < 0;
 					unsigned long long at = 0;
 					char *dst = nullptr;
 					for (int pass = 0; pass < 2; ++pass) {
@@ -189,13 +257,12 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 						#define MD_NUM(v) do { int v_ = (v), nd_ = v_ >= 10000 ? 5 : v_ >= 1000 ? 4 : v_ >= 100 ? 3 : v_ >= 10 ? 2 : 1; \
 							if (dst) { int t_ = v_; for (int d_ = nd_ - 1; d_ >= 0; --d_) { dst[l + d_] = (char)('0' + t_ % 10); t_ /= 10; } } l += nd_; } while (0)
 						#define MD_CHR(c) do { if (dst) dst[l] = (char)(c); ++l; } while (0)
-						#define MD_BASE(r) ((r) > 3 ? 'N' : (int)(((rev ? 0x41434754u : 0x54474341u) >> ((r) << 3)) & 0xffu))   /* "ACGT" / "TGCA" (bwa.c:297,345) */
 						for (int k = 0; k < n_cigar; ++k) {
 							const int op = (int)(cig[k] & 0xf), len = (int)(cig[k] >> 4);
 							if (op == 0) {
 								for (int i = 0; i < len; ++i) {
 									const int q = qb[x + i];
-									const int r = staged ? (int)tb[y + i] : dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir);
+									const int r = dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir);
 									if (q == r) { n_ret += parent ? q == 1 : q == 2; ++u; }
 									else {
 										MD_NUM(u); MD_CHR(MD_BASE(r)); u = 0;
@@ -206,7 +273,7 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 							} else if (op == 2) {
 								if (k > 0 && k < n_cigar - 1) {
 									MD_NUM(u); MD_CHR('^');
-									for (int i = 0; i < len; ++i) { const int r = staged ? (int)tb[y + i] : dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir); MD_CHR(MD_BASE(r)); }
+									for (int i = 0; i < len; ++i) { const int r = dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(y + i) * J.tdir); MD_CHR(MD_BASE(r)); }
 									u = 0; n_gap += len;
 								}
 								y += len;
@@ -215,7 +282,6 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 						MD_NUM(u);
 						#undef MD_NUM
 						#undef MD_CHR
-						#undef MD_BASE
 						if (pass == 0) {
 							at = atomicAdd(md_cursor, (unsigned long long)l + 1);
 							if (at + (unsigned long long)l + 1 > md_cap) break;   // cannot happen: the pool holds every job's upper bound
@@ -226,6 +292,8 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 				}
 				tags[job] = T;
 			}
+			#undef MD_BASE
+			#undef MD_DIGITS
 		}
 		WAVE_SYNC();
 	}

@@ -1,0 +1,28 @@
+"""-m gpu: the N > 1 path of bench.py (one process per rank, barrier-bracketed timing, MAX over ranks, the per-chunk record
+gather to rank 0 inside the timed region) run with two ranks.  A test box has one GPU: both ranks compute on it and talk over
+gloo ($BSX_BENCH_SHARE_GPU, labelled in the JSON line); with one GPU per rank the same code runs over RCCL."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_line():
+    env = dict(os.environ, BSX_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--genome-mbp", "8", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # rank 0 prints, once
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert "CODE-PATH CHECK" in d["config"]["parallelism"]
+    g = d["record_gather"]
+    assert g["in_timed_region"] and g["chunks_received_by_rank0"] == 6 and g["bytes_received_by_rank0"] > 6 * 1000000
+    # whole-job rate: both ranks' reads over the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["reads_per_step_per_gpu"] * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]

@@ -213,7 +213,9 @@ def test_global_matches_oracle(small_index, port, device):
     from biscuit_amd.api import GLB_DT
     opt = default_opt()
     rng = np.random.default_rng(31)
-    seqs = _reads(small_index, n_pairs=200, read_len=150, seed=32) + [s for _, s in simdata.make_single(_contigs(small_index), 30, 900, 33)]
+    # 150 bp, 900 bp and a few 2.2 kb reads: the three size classes of the kernel (the last one walks its MD with one lane from HBM)
+    seqs = _reads(small_index, n_pairs=200, read_len=150, seed=32) + [s for _, s in simdata.make_single(_contigs(small_index), 30, 900, 33)] \
+        + [s for _, s in simdata.make_single(_contigs(small_index), 6, 2200, 34)]
     buf, offs = simdata.read_buffer(seqs)
     for be in (port, device):
         be.set_opt(opt)
