@@ -77,13 +77,18 @@ class GlbRes(C.Structure):
     _fields_ = [("score", C.c_int32), ("n_cigar", C.c_int32), ("w_used", C.c_int32), ("pad", C.c_int32)]
 
 
+class Region(C.Structure):  # bsx_region_t
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64), ("qb", C.c_int32), ("qe", C.c_int32), ("rid", C.c_int32), ("score", C.c_int32), ("truesc", C.c_int32),
+                ("w", C.c_int32), ("seedcov", C.c_int32), ("seedlen0", C.c_int32), ("frac_rep", C.c_float), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
 class GlbTag(C.Structure):
     _fields_ = [("NM", C.c_int32), ("ZC", C.c_int32), ("ZR", C.c_int32), ("l_md", C.c_int32), ("md_off", C.c_uint64), ("bss_u", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
 
 class Backend(C.Structure):  # bsx_backend_t (csrc/host/bsx_core.h)
     _fields_ = [("ctx", C.c_void_p), ("name", C.c_char_p)] + [(n, C.c_void_p) for n in
-                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "global_batch_tags", "regions_batch", "regions_finish")]
+                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "global_batch_tags", "regions_batch", "regions_finish", "regions_dedup")] + [("dedup_cap", C.c_int)]
 
 
 class PhaseStats(C.Structure):

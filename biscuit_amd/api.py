@@ -162,6 +162,29 @@ class Device(Batches):
         """both FM indices built on the device from index's pac and left resident (csrc/hip/k_index.hip)"""
         B.check(B.lib().bsx_device_build_index(self.h, index.h, int(fill_host)), "bsx_device_build_index")
 
+    def regions(self, opt, tasks):
+        """bsx_regions_batch + bsx_regions_finish: seeding through regions on the device -> (regions, offsets, counts per strand search;
+        a negative count = declined)"""
+        tasks = np.ascontiguousarray(tasks, dtype=SEED_DT)
+        n = len(tasks)
+        L = B.lib()
+        out, cap, di, dc = C.c_void_p(), C.c_int64(0), C.c_void_p(), C.c_int64(0)
+        off = np.zeros(n + 1, dtype=np.int64)
+        cnt = np.zeros(n + 1, dtype=np.int32)
+        doff = np.zeros(n + 1, dtype=np.int64)
+        L.bsx_regions_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
+        L.bsx_regions_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
+        B.check(L.bsx_regions_batch(self.h, C.byref(opt), n, _p(tasks), C.byref(out), C.byref(cap), _p(off), _p(cnt), C.byref(di), C.byref(dc), _p(doff)), "bsx_regions_batch")
+        B.check(L.bsx_regions_finish(self.h, C.byref(out), C.byref(cap), _p(off), _p(cnt)), "bsx_regions_finish")
+        dt = np.dtype(B.Region)
+        tot = int(max([off[i] + cnt[i] for i in range(n) if cnt[i] > 0] + [0]))
+        regs = np.frombuffer(C.string_at(out.value, tot * dt.itemsize), dtype=dt).copy() if tot else np.zeros(0, dtype=dt)
+        for ptr in (out, di):
+            if ptr.value:
+                _libc_free(ptr)
+        return regs, off[:n], cnt[:n]
+
     def global_tags(self, jobs, pool_len):
         """bsx_global_batch_tags: K6 plus NM / MD / ZC / ZR of every job with a CIGAR -> (res, pool, tags, [md bytes or None])"""
         jobs = np.ascontiguousarray(jobs, dtype=GLB_DT)

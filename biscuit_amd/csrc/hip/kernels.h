@@ -63,3 +63,7 @@ void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_tas
                 unsigned long long *counters, unsigned char *cls);   // cls[t]: the first tier whose interval/occurrence tables hold task t
 // out[j] = SA[j * intv] for j < n, from the (sparser) samples ix currently holds: the denser suffix-array sample kept in HBM
 void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out);
+// C5 (k_dedup.hip): mem_sort_deduplicate of every read over the regions of the chunk, a lane per read
+int dedup_cap(void);
+void launch_dedup(hipStream_t st, const bsx_region_t *regs, const long long *reg_off, const int *reg_n, int n_reads, int per_read,
+                  long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, int *out_n, unsigned char *out_idx);

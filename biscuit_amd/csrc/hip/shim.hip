@@ -26,7 +26,8 @@ struct Lane {
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows, tags, mdpool;
+	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -120,7 +121,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release(); L.tags.release(); L.mdpool.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -550,6 +551,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	XA.xcount = (unsigned int*)(ctr + 14);
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
 	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
+	L.rb_tasks = n;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipEventRecord(L.ev0, L.st));
@@ -893,6 +895,30 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 }
 
 // ------------------------------------------------------------------------------------------
+// C5 over the regions of the last regions batch of this lane
+// ------------------------------------------------------------------------------------------
+static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	if (!opt || !out_n || !out_idx || per_read < 1) return BSX_E_ARG;
+	Lane &L = d->lane[lane];
+	if (n_reads == 0) return BSX_OK;
+	if (n_reads * per_read != L.rb_tasks) { fprintf(stderr, "[bsx-hip] regions_dedup: %lld reads x %d strand searches, but the last regions batch had %lld\n", (long long)n_reads, per_read, (long long)L.rb_tasks); return BSX_E_ARG; }
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc;
+	const int64_t n = L.rb_tasks;
+	const size_t cap = (size_t)dedup_cap();
+	if ((rc = L.dd.reserve((size_t)n_reads * (4 + cap) + 64)) != BSX_OK) return rc;
+	const long long *r_off = (const long long*)L.regmeta.p; const int *r_n = (const int*)((const char*)L.regmeta.p + (size_t)n * 8);
+	int *d_n = (int*)L.dd.p; unsigned char *d_idx = (unsigned char*)L.dd.p + (size_t)n_reads * 4;
+	launch_dedup(L.st, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun, d_n, d_idx);
+	HIPCHK(hipGetLastError());
+	D2H(L.st, out_n, d_n, (size_t)n_reads * 4);
+	D2H(L.st, out_idx, d_idx, (size_t)n_reads * cap);
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // K6
 // ------------------------------------------------------------------------------------------
 static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
@@ -991,6 +1017,9 @@ extern "C" BSX_API int bsx_regions_batch(bsx_device_t *d, const bsx_opt_t *opt, 
 { return lane_regions_batch(d, 0, opt, n, tasks, out, out_cap, out_off, out_n, decl_intv, decl_cap, decl_off); }
 extern "C" BSX_API int bsx_regions_finish(bsx_device_t *d, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n)
 { return lane_regions_finish(d, 0, out, out_cap, out_off, out_n); }
+extern "C" BSX_API int bsx_regions_dedup_cap(void) { return dedup_cap(); }
+extern "C" BSX_API int bsx_regions_dedup(bsx_device_t *d, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx)
+{ return lane_regions_dedup(d, 0, opt, n_reads, per_read, out_n, out_idx); }
 extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos) { return lane_sa_batch(d, 0, n, jobs, pos); }
 extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res) { return lane_extend_batch(d, 0, n, jobs, res); }
 extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res) { return lane_sw_batch(d, 0, n, jobs, res); }
@@ -1019,6 +1048,7 @@ static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_tas
 	return rc;
 }
 static int be_regions_finish(void *c, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return lane_regions_finish(LR(c), out, cap, off, cnt); }
+static int be_dedup(void *c, const bsx_opt_t *o, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx) { return lane_regions_dedup(LR(c), o, n_reads, per_read, out_n, out_idx); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
 static int be_glb_tags(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len, bsx_glb_tag_t *t, char **md, int64_t *cap)
 { return lane_global_batch(LR(c), n, j, r, pool, len, t, md, cap); }
@@ -1037,6 +1067,8 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb; out->global_batch_tags = be_glb_tags;
 	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;
 	out->regions_finish = out->regions_batch ? be_regions_finish : nullptr;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
+	out->regions_dedup = out->regions_batch && !getenv("BSX_HOST_DEDUP") ? be_dedup : nullptr;   // BSX_HOST_DEDUP=1: C5 on the host for every read (A/B checks)
+	out->dedup_cap = dedup_cap();
 	return BSX_OK;
 }
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out) { return bsx_hip_backend_lane(dev, 0, out); }

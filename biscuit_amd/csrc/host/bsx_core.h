@@ -171,6 +171,10 @@ typedef struct bsx_backend {
 	                     bsx_intv_t **decl_intv, int64_t *decl_cap, int64_t *decl_off);
 	/* optional, with regions_batch: collect the strand searches it reported as BSX_REGIONS_PENDING */
 	int (*regions_finish)(void *ctx, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
+	/* optional, with regions_batch: mem_sort_deduplicate of every read over the regions still on the device, see bsx_regions_dedup
+	 * (dedup_cap entries of out_idx per read) */
+	int (*regions_dedup)(void *ctx, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx);
+	int dedup_cap;
 } bsx_backend_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;

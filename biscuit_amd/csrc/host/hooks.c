@@ -54,3 +54,26 @@ BSX_API void bsx_hook_fq_pair_close(void *p) { bsx_fq_pair_close((bsx_fq_pair_t*
 BSX_API bsx_read_t *bsx_hook_fq_pair_chunk(void *p, int chunk_size, int *n) { return bsx_fq_pair_read_chunk((bsx_fq_pair_t*)p, chunk_size, n); }
 const uint8_t *bsx_nt4_table(void);
 BSX_API const uint8_t *bsx_hook_nt4_table(void) { return bsx_nt4_table(); }
+
+/* mem_sort_deduplicate as the host pipeline runs it (region.c) on one read's regions, given as the device hands them over:
+ * keep[k] = index in a[] of the k-th region kept; returns their number, or -1 when a concatenation score would be needed */
+static int hook_no_score(void *ud, const reg_t *a, const reg_t *b, int w, int *score) { (void)ud; (void)a; (void)b; (void)w; *score = 0; return 1; }
+BSX_API int bsx_hook_regs_sort_dedup(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_region_t *a, int n, int *keep)
+{
+	reg_v v;
+	int k, missing = 0, m;
+	v.n = v.m = (size_t)n; v.n_pri = 0;
+	v.a = (reg_t*)calloc(n ? n : 1, sizeof(reg_t));
+	for (k = 0; k < n; ++k) {
+		reg_t *r = &v.a[k];
+		const bsx_region_t *d = &a[k];
+		r->rb = d->rb; r->re = d->re; r->qb = d->qb; r->qe = d->qe; r->rid = d->rid; r->score = d->score; r->truesc = d->truesc;
+		r->w = d->w; r->seedcov = d->seedcov; r->seedlen0 = d->seedlen0; r->frac_rep = d->frac_rep; r->bss = d->bss; r->parent = d->parent;
+		r->hash = (uint64_t)k;   /* not touched by the function: carries the index through its sorts */
+	}
+	bsx_regs_sort_dedup(opt, &idx->ref, 1, &v, hook_no_score, 0, &missing);
+	m = missing ? -1 : (int)v.n;
+	for (k = 0; k < m; ++k) keep[k] = (int)v.a[k].hash;
+	free(v.a);
+	return m;
+}

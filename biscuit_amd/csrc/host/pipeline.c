@@ -90,6 +90,7 @@ typedef struct {
 	/* strand searches the host chains itself (all of them without a device regions pass): h -> task */
 	int n_host, *hmap, n_pending;
 	bsx_region_t *dregs; int64_t dregs_cap, *dreg_off; int32_t *dreg_n;
+	int32_t *dd_n; uint8_t *dd_idx; int dd_cap;   /* C5 done by the backend (regions_dedup): per read, the regions kept and their order; dd_n < 0: here */
 	int *read_task0;             /* first task of each read; read_task0[n] = n_tasks */
 	bsx_intv_t *intv; int64_t intv_cap; int64_t *intv_off;
 	uint64_t *pos; int64_t *ipos_off;   /* per interval: its occurrences' positions */
@@ -314,7 +315,19 @@ static void merge_worker(void *data, long i, int tid)
 	size_t k;
 	(void)tid;
 	if (!P->pending[i]) return;
-	{ /* (re)start from the regions of the read's strand searches, concatenated in call order */
+	if (C->dd_n && C->dd_n[i] >= 0) { /* sorted and de-duplicated on the device: what is left of the concatenation, in order */
+		const uint8_t *ix = C->dd_idx + (size_t)i * (size_t)C->dd_cap;
+		int t, kk, m = C->dd_n[i]; size_t tot = 0;
+		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
+		if (regs->m < (size_t)m) { regs->a = (reg_t*)bsx_crealloc(regs->a, 0, sizeof(reg_t) * ((size_t)m + 2)); regs->m = (size_t)m + 2; }
+		regs->n = (size_t)m; regs->n_pri = 0;
+		for (kk = 0; kk < m; ++kk) {
+			size_t li = ix[kk];
+			for (t = C->read_task0[i]; li >= C->tasks[t].regs.n; ++t) li -= C->tasks[t].regs.n;
+			regs->a[kk] = C->tasks[t].regs.a[li];
+			regs->a[kk].n_comp = tot > 1 ? 1 : 0;   /* mem_alnreg.c:114,118 */
+		}
+	} else { /* here: (re)start from the regions of the read's strand searches, concatenated in call order */
 		int t; size_t tot = 0;
 		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
 		if (regs->m < tot) { regs->a = (reg_t*)bsx_crealloc(regs->a, 0, sizeof(reg_t) * (tot + 2)); regs->m = tot + 2; }
@@ -323,10 +336,10 @@ static void merge_worker(void *data, long i, int tid)
 			const c2r_t *T = &C->tasks[t];
 			if (T->regs.n) { memcpy(regs->a + regs->n, T->regs.a, sizeof(reg_t) * T->regs.n); regs->n += T->regs.n; }
 		}
+		P->ud[i].wanted.n = 0;
+		bsx_regs_sort_dedup(C->opt, &C->idx->ref, 1, regs, merge_score_fn, &P->ud[i], &missing);
+		if (missing) return; /* retried once the scores have been computed */
 	}
-	P->ud[i].wanted.n = 0;
-	bsx_regs_sort_dedup(C->opt, &C->idx->ref, 1, regs, merge_score_fn, &P->ud[i], &missing);
-	if (missing) return; /* retried once the scores have been computed */
 	P->pending[i] = 0;
 	/* mem_test_and_remove_exact (mem_alnreg.c:205-211) */
 	if ((C->opt->flag & BSX_F_SELF_OVLP) && regs->n > 0 && regs->a[0].truesc == C->reads[i].l_seq * C->opt->a) {
@@ -1043,6 +1056,13 @@ static int chunk_front(chunk_t *C)
 		rc = be->regions_batch(be->ctx, opt, C->n_tasks, C->stasks, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n, &decl_intv, &decl_cap, decl_off);
 		bsx_big_update(C->arena_set, 8, C->dregs, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		if (rc != BSX_OK) goto out;
+		if (be->regions_dedup && C->n_tasks == n * (C->n_tasks / (n ? n : 1))) { /* C5 of every read whose strand searches all finished on the device */
+			C->dd_cap = be->dedup_cap;
+			C->dd_n = (int32_t*)bsx_big_get(C->arena_set, 10, sizeof(int32_t) * ((size_t)n + 1));
+			C->dd_idx = (uint8_t*)bsx_big_get(C->arena_set, 11, (size_t)C->dd_cap * ((size_t)n + 1));
+			rc = be->regions_dedup(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx);
+			if (rc != BSX_OK) goto out;
+		}
 		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, adopting the regions %.3f s\n", ta - t0, now_s() - ta); }
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
@@ -1132,6 +1152,7 @@ static void chunk_free(chunk_t *C)
 	bsx_big_put(C->arena_set, 0, C->roff); bsx_big_put(C->arena_set, 2, C->read_task0);
 	bsx_big_put(C->arena_set, 4, C->stasks); bsx_big_put(C->arena_set, 1, C->buf);
 	bsx_big_put(C->arena_set, 5, C->hmap); bsx_big_put(C->arena_set, 8, C->dregs); bsx_big_put(C->arena_set, 6, C->dreg_off); bsx_big_put(C->arena_set, 7, C->dreg_n);
+	if (C->dd_n) { bsx_big_put(C->arena_set, 10, C->dd_n); bsx_big_put(C->arena_set, 11, C->dd_idx); }
 	bsx_arenas_end(C->arena_set);
 	C->st.t_cleanup = now_s() - t0;
 	C->st.t_total = now_s() - C->t_begin;

@@ -269,6 +269,13 @@ int bsx_regions_batch(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n, const 
  * regions to *out and fills out_off/out_n in (-1: seed and chain it on the host).  Same arrays as the batch call. */
 #define BSX_REGIONS_PENDING (-100)
 int bsx_regions_finish(bsx_device_t *dev, bsx_region_t **out, int64_t *out_cap, int64_t *out_off, int32_t *out_n);
+/* C5 for the regions the last bsx_regions_batch left on the device: mem_sort_deduplicate (lib/aln/mem_alnreg.c:112-202) of every
+ * read, a read's regions being those of its per_read consecutive strand searches concatenated in call order
+ * (lib/aln/bwamem.c:352-372).  out_n[i] >= 0: the read keeps that many regions, out_idx[i * bsx_regions_dedup_cap() + k]
+ * naming the k-th by its index in the concatenation; out_n[i] == -1: left to the caller (a strand search of the read was
+ * not finished on the device, too many regions, or two regions have to be tested for concatenation, mem_alnreg.c:63-108). */
+int bsx_regions_dedup_cap(void);
+int bsx_regions_dedup(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx);
 /* K5 */
 int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 /* K6 */

@@ -258,11 +258,12 @@ def test_cli_many_chunks_through_the_stream(data):
 @pytest.mark.parametrize("env", [
     {"BSX_DEVICE_SA_INTV": "32"},                                   # the files' suffix-array sample instead of the denser device one
     {"BSX_DEVICE_SA_INTV": "1"},                                    # every rank sampled: K3 is a plain load
-    {"BSX_REGIONS_OCC": "3", "BSX_SEED_OCC": "4"},                  # other register-allocation targets
+    {"BSX_REGIONS_OCC": "3", "BSX_MID_QUOTA": "1", "BSX_C2R_QUOTA": "2"},   # another register-allocation target, short-lived region workgroups
     {"BSX_RESERVE_CU_EVERY": "0", "BSX_STREAM_DEPTH": "1"},         # no reserved CUs, no overlap of chunks
     {"BSX_SEED_QUOTA": "0", "BSX_REGIONS_QUOTA": "1", "BSX_STREAM_DEPTH": "4"},   # persistent seeding waves, one task per region wave
     {"BSX_REGIONS_MID": "0", "BSX_SEED_TRIP_BUDGET": "200"},        # no LDS tier between the first and the HBM tiers; most strand searches handed to the second seeding pass
-], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget"])
+    {"BSX_HOST_DEDUP": "1"},                                        # C5 (mem_sort_deduplicate) of every read on the host instead of by k_dedup
+], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget", "host_dedup"])
 def test_device_tuning_knobs_do_not_change_the_output(data, env):
     """Launch shapes, occupancy targets, the device-side suffix-array sample and the pipeline depth are performance knobs:
     the SAM must be byte-identical whatever they are set to."""
@@ -336,3 +337,67 @@ def test_c2r_lanes_equal_waves(data):
     for name, args in (CASES[0], CASES[1], CASES[8], CASES[9]):
         want = run(HIP, args, data)
         assert run(HIP, args, data, env={"BSX_C2R_LANES": "1"}) == want, name
+
+
+def test_dedup_kernel_against_host_function(tmp_path):
+    """C5 directly: bsx_regions_dedup (k_dedup, a lane per read) on the regions a regions batch left on the device, against
+    mem_sort_deduplicate as the host runs it (csrc/host/region.c, through bsx_hook_regs_sort_dedup) on the same regions.
+    Repeat-rich genome, non-directional search (two strand searches per read): reads with up to a dozen regions, ties in
+    end position and in score."""
+    import ctypes as C
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    L = B.lib()
+    d = str(tmp_path)
+    B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(4000000), C.c_uint64(77), 4, C.c_double(0.15)), "sim_genome")
+    B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "index_build")
+    idx = Index(d + "/g")
+    dev = Device(0)
+    dev.upload_index(idx)
+    opt = default_opt()
+    opt.flag |= 0x10 | 0x2
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    n_pairs = 20000
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 5, 200, 500, 0.01, 0.2, C.byref(p)), "sim_pairs")
+    reads = C.cast(p, C.POINTER(B.Read))
+    n = 2 * n_pairs
+    seqs = [bytes(C.string_at(reads[i].seq, reads[i].l_seq)) for i in range(n)]
+    buf = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    from biscuit_amd.api import SEED_DT
+    tasks = np.zeros(2 * n, dtype=SEED_DT)
+    for i in range(n):   # the reference's call order for -b 0: parent (C>T) then daughter (G>A) search of each read
+        for k, par in enumerate((1, 0)):
+            tasks[2 * i + k] = (offs[i], len(seqs[i]), par)
+    dev.set_opt(opt)
+    dev.set_reads(buf)
+    regs, roff, rn = dev.regions(opt, tasks)
+    cap = L.bsx_regions_dedup_cap()
+    out_n = np.zeros(n, dtype=np.int32)
+    out_idx = np.zeros(n * cap, dtype=np.uint8)
+    L.bsx_regions_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    B.check(L.bsx_regions_dedup(dev.h, C.byref(opt), n, 2, out_n.ctypes.data_as(C.c_void_p), out_idx.ctypes.data_as(C.c_void_p)), "bsx_regions_dedup")
+    L.bsx_hook_regs_sort_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.bsx_hook_regs_sort_dedup.restype = C.c_int
+    done = multi = dropped = left = 0
+    for i in range(n):
+        if rn[2 * i] < 0 or rn[2 * i + 1] < 0:
+            assert out_n[i] == -1
+            continue
+        cat = np.concatenate([regs[roff[2 * i]:roff[2 * i] + rn[2 * i]], regs[roff[2 * i + 1]:roff[2 * i + 1] + rn[2 * i + 1]]])
+        if out_n[i] < 0:
+            left += 1   # more regions than the kernel holds, or a pair of regions to test for concatenation: the host's rounds
+            continue
+        keep = np.zeros(max(1, len(cat)), dtype=np.int32)
+        m = L.bsx_hook_regs_sort_dedup(C.byref(opt), idx.h, cat.ctypes.data_as(C.c_void_p), len(cat), keep.ctypes.data_as(C.c_void_p))
+        assert m >= 0, i    # the host function needed no concatenation score either
+        got = out_idx[i * cap:i * cap + out_n[i]]
+        assert out_n[i] == m and (got == keep[:m]).all(), (i, len(cat), list(got), list(keep[:m]))
+        done += 1
+        multi += len(cat) > 2
+        dropped += m < len(cat)
+    assert done > 0.95 * n and multi > 1000 and dropped > 1000 and left < 0.02 * n, (done, multi, dropped, left)
+    L.bsx_sim_free_reads(p, n)
+    dev.close()
+    idx.close()
