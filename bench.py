@@ -204,15 +204,20 @@ def main():
             phase_tot[f] = phase_tot.get(f, 0) + getattr(ps, f)
         phase_tot["_chunks"] = phase_tot.get("_chunks", 0) + 1
 
+    loop_s = [0.0, 0.0]   # waiting for a ring slot, inside bsx_stream_push
     for s in range(args.warmup, args.warmup + args.steps):
         if args.no_pipeline:
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, chunks[s], None), "process_seqs")
             account()
             retire(s)
         else:
+            tw = time.time()
             while s - len(chunks) >= args.warmup and (s - len(chunks)) not in retired:
                 time.sleep(0.001)   # the ring slot's previous use must have been consumed (it has, several steps ago)
+            loop_s[0] += time.time() - tw
+            tw = time.time()
             B.check(L.bsx_stream_push(stream, n_processed, n_reads, chunks[s]), "stream_push")
+            loop_s[1] += time.time() - tw
             if s - args.warmup >= depth - 1:
                 account()       # the push completed the chunk pushed depth-1 pushes ago
                 retire(s - (depth - 1))
@@ -346,7 +351,7 @@ def main():
             "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(8)} if alone else None),
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
-            "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),
+            "push_loop_s_per_step": {"ring_wait": round(loop_s[0] / args.steps, 4), "in_stream_push": round(loop_s[1] / args.steps, 4)}, "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "genome_and_index_build_s": round(t_build, 1), "device": dev.name,

@@ -6,12 +6,27 @@ extern "C" {
 #include "bsx_core.h"
 }
 
+// hipFree / hipHostFree wait for the whole device: when a per-chunk buffer of one lane grows while the kernels of three other chunks are
+// running, the call returns seconds later (measured: K5/K6 batches of 40 ms taking 1.2 s during the first chunks of every lane).  A
+// buffer that grows therefore leaves its old block on a list that is emptied when the device is closed.
+#include <mutex>
+#include <vector>
+struct DevbufDeferred { std::mutex mu; std::vector<void*> dev, host; };
+inline DevbufDeferred &devbuf_deferred() { static DevbufDeferred d; return d; }
+inline void devbuf_drain() {
+	DevbufDeferred &d = devbuf_deferred();
+	std::lock_guard<std::mutex> g(d.mu);
+	for (void *q : d.dev) (void)hipFree(q);
+	for (void *q : d.host) (void)hipHostFree(q);
+	d.dev.clear(); d.host.clear();
+}
+
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
 	int reserve(size_t n) {
 		if (n <= cap) return BSX_OK;
-		if (p) (void)hipFree(p);
-		size_t want = n + (n >> 2) + 4096;
+		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.dev.push_back(p); p = nullptr; }
+		size_t want = n + (n >> 1) + 4096;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed\n", want); return BSX_E_NOMEM; }
 		cap = want;
 		return BSX_OK;
@@ -31,8 +46,8 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 	void *p = nullptr; size_t cap = 0;
 	int reserve(size_t n) {
 		if (n <= cap) return BSX_OK;
-		if (p) (void)hipHostFree(p);
-		size_t want = n + (n >> 2) + 4096;
+		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.host.push_back(p); p = nullptr; }
+		size_t want = n + (n >> 1) + 4096;
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return BSX_E_NOMEM; }
 		cap = want;
 		return BSX_OK;

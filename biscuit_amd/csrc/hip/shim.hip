@@ -10,6 +10,7 @@
 #include <time.h>
 #include <algorithm>
 #include <vector>
+#include <mutex>
 #include "devbuf.hpp"
 #include "kernels.h"
 #include "index_build.h"
@@ -21,6 +22,7 @@
 #define BSX_LANES 6
 struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
+	hipEvent_t ev_seed_done = nullptr, ev_regions_done = nullptr;   // what the next chunk's launches of the same stage wait for
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
@@ -53,6 +55,11 @@ struct bsx_device {
 	DevIndex ix; bool has_index = false;
 	DevBuf bwt[2], sa[2], pac, ctg;
 	Lane lane[BSX_LANES];   // scoring matrices and penalties are per lane (Lane::sc): chunks with different options may be in flight together
+	// Front halves of consecutive chunks are chained stage by stage (the seeding launch of chunk k+1 waits for that of chunk k, the
+	// region launches likewise): four chunks that share the device evenly all finish at the same moment, and the device then idles
+	// through the first of their back halves; chained, they are one stage apart and a chunk's seeding overlaps its predecessor's regions
+	std::mutex chain_mu;
+	hipEvent_t chain_seed = nullptr, chain_regions = nullptr;
 };
 struct LaneRef { bsx_device *d; int lane; };   // what the backend vtable carries as ctx
 
@@ -93,6 +100,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		}
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
 		HIPCHK(hipEventCreate(&L.ev3));
+		HIPCHK(hipEventCreateWithFlags(&L.ev_seed_done, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&L.ev_regions_done, hipEventDisableTiming));
 		HIPCHK(hipEventCreate(&L.ev4));
 		HIPCHK(hipEventCreateWithFlags(&L.rs.ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.rs.ev_tiers, hipEventDisableTiming));
@@ -116,6 +125,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 {
 	if (!d) return;
 	(void)hipSetDevice(d->ordinal);
+	devbuf_drain();   // the blocks that buffers which grew left behind
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
 	d->pac.release(); d->ctg.release();
 	for (int l = 0; l < BSX_LANES; ++l) {
@@ -243,6 +253,7 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 		g.sa_mask = (uint32_t)dense - 1; g.sa_shift = 0;
 		while ((1 << g.sa_shift) < dense) ++g.sa_shift;
 	}
+	devbuf_drain();   // nothing else runs on the device yet: the blocks the builder's growing buffers left behind go now
 	d->has_index = true;
 	return BSX_OK;
 }
@@ -554,13 +565,27 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	L.rb_tasks = n;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
+	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 2;   // 0: none, 1: seeding, 2: seeding and regions
+	if (chain >= 1) {
+		std::lock_guard<std::mutex> g(d->chain_mu);
+		if (d->chain_seed && d->chain_seed != L.ev_seed_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_seed, 0));
+	}
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
 	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
+	if (chain >= 1) {
+		std::lock_guard<std::mutex> g(d->chain_mu);
+		HIPCHK(hipEventRecord(L.ev_seed_done, L.st));
+		d->chain_seed = L.ev_seed_done;
+	}
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
+	if (chain >= 2) {
+		std::lock_guard<std::mutex> g(d->chain_mu);
+		if (d->chain_regions && d->chain_regions != L.ev_regions_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_regions, 0));
+	}
 	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
 	launch_regions(L.st, rgrid, d->ix, L.sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
 	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls, XA);
@@ -610,6 +635,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 
+	if (chain >= 2) {
+		std::lock_guard<std::mutex> g(d->chain_mu);
+		HIPCHK(hipEventRecord(L.ev_regions_done, L.st));
+		d->chain_regions = L.ev_regions_done;
+	}
 	HIPCHK(hipEventRecord(L.rs.ev_tiers, L.st));
 	// While those run: strand searches whose interval list overflowed (reads inside tandem repeats: ~300 k dependent FM steps
 	// on one lane) are seeded again on the side stream with much longer lists and go through the third tier as well.  None of

@@ -106,7 +106,7 @@ typedef struct {
 	int arena_set, rc;
 	pthread_t th; int th_live;   /* the thread running the front half (stream mode) */
 	int back_done;               /* ... which ran the back half too */
-	double t_begin;
+	double t_begin, t_front_end;
 	bsx_phase_stats_t st;
 } chunk_t;
 
@@ -1214,6 +1214,7 @@ static void *front_thread(void *arg)
 {
 	chunk_t *C = (chunk_t*)arg;
 	C->rc = chunk_front(C);
+	C->t_front_end = now_s();
 	/* With the back half on the chunk's own thread as well, back halves of consecutive chunks overlap each other: one
 	 * chunk's serial stretches and waits for its K5/K6 batches are filled with the other's parallel loops (the worker
 	 * pool serves several loops at once).  Chunks still complete in order: the stream joins the threads in order. */
@@ -1262,7 +1263,8 @@ static int chunk_finish(chunk_t *C)
 	rc = C->rc;
 	if (rc == BSX_OK && !C->back_done) rc = chunk_back(C);
 	t2 = now_s();
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::stream] waited %.3f s for the front half, back half %.3f s\n", t1 - t0, t2 - t1);
+	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::stream] chunk begun at %.3f: front half %.3f s (prep %.3f, device pass %.3f), waited %.3f s for it from %.3f, back half %.3f s until %.3f\n",
+	                                  C->t_begin, C->t_front_end - C->t_begin, C->st.t_prep, C->st.t_regions, t1 - t0, t0, t2 - t1, t2);
 	chunk_free(C);
 	return rc;
 }
