@@ -77,3 +77,73 @@ BSX_API int bsx_hook_regs_sort_dedup(const bsx_opt_t *opt, const bsx_index_t *id
 	free(v.a);
 	return m;
 }
+
+/* ---- the per-read / per-pair functions of the back half, callable on plain arrays (tests/test_oracle_backhalf.py compares them with
+ * oracle/backhalf.py, an independent restatement of the reference's functions) */
+typedef struct {
+	int64_t rb, re;
+	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+	uint64_t hash;
+	uint8_t bss, parent, pad[6];
+} bsx_hook_reg_t;
+
+static void hook_to_reg(const bsx_hook_reg_t *h, reg_t *r)
+{
+	memset(r, 0, sizeof(*r));
+	r->rb = h->rb; r->re = h->re; r->qb = h->qb; r->qe = h->qe; r->rid = h->rid; r->score = h->score; r->truesc = h->truesc; r->sub = h->sub;
+	r->alt_sc = h->alt_sc; r->csub = h->csub; r->sub_n = h->sub_n; r->w = h->w; r->seedcov = h->seedcov; r->secondary = h->secondary;
+	r->secondary_all = h->secondary_all; r->seedlen0 = h->seedlen0; r->n_comp = h->n_comp; r->is_alt = h->is_alt; r->hash = h->hash;
+	r->bss = h->bss; r->parent = h->parent;
+}
+static void hook_from_reg(const reg_t *r, bsx_hook_reg_t *h)
+{
+	memset(h, 0, sizeof(*h));
+	h->rb = r->rb; h->re = r->re; h->qb = r->qb; h->qe = r->qe; h->rid = r->rid; h->score = r->score; h->truesc = r->truesc; h->sub = r->sub;
+	h->alt_sc = r->alt_sc; h->csub = r->csub; h->sub_n = r->sub_n; h->w = r->w; h->seedcov = r->seedcov; h->secondary = r->secondary;
+	h->secondary_all = r->secondary_all; h->seedlen0 = r->seedlen0; h->n_comp = r->n_comp; h->is_alt = r->is_alt; h->hash = r->hash;
+	h->bss = r->bss; h->parent = r->parent;
+}
+static void hook_vec(const bsx_hook_reg_t *a, int n, int n_pri, reg_v *v)
+{
+	int k;
+	v->n = v->m = (size_t)n; v->n_pri = (size_t)n_pri;
+	v->a = (reg_t*)calloc(n ? n : 1, sizeof(reg_t));
+	for (k = 0; k < n; ++k) hook_to_reg(&a[k], &v->a[k]);
+}
+
+/* mem_mark_primary_se in place; returns n_pri */
+BSX_API int bsx_hook_mark_primary(const bsx_opt_t *opt, bsx_hook_reg_t *a, int n, int64_t id)
+{
+	reg_v v;
+	int k, n_pri;
+	hook_vec(a, n, 0, &v);
+	bsx_mark_primary(opt, &v, id);
+	for (k = 0; k < n; ++k) hook_from_reg(&v.a[k], &a[k]);
+	n_pri = (int)v.n_pri;
+	free(v.a);
+	return n_pri;
+}
+
+/* mem_pestat over n_reads reads (pairs 2i, 2i+1); read i's regions are a[off[i] .. off[i+1]) */
+BSX_API void bsx_hook_pestat(const bsx_opt_t *opt, const bsx_index_t *idx, int n_reads, const bsx_hook_reg_t *a, const int64_t *off, bsx_pestat_t *out)
+{
+	reg_v *regs = (reg_v*)calloc(n_reads ? n_reads : 1, sizeof(reg_v));
+	int i;
+	for (i = 0; i < n_reads; ++i) hook_vec(a + off[i], (int)(off[i + 1] - off[i]), 0, &regs[i]);
+	*out = bsx_pestat(opt, &idx->ref, n_reads, regs);
+	for (i = 0; i < n_reads; ++i) free(regs[i].a);
+	free(regs);
+}
+
+/* mem_pair: out = score, sub, n_sub, z[0], z[1] */
+BSX_API void bsx_hook_pair(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes, const bsx_hook_reg_t *a0, int n0, int n_pri0,
+                           const bsx_hook_reg_t *a1, int n1, int n_pri1, int id, int out[5])
+{
+	reg_v pair[2];
+	int z[2] = {-1, -1};
+	hook_vec(a0, n0, n_pri0, &pair[0]);
+	hook_vec(a1, n1, n_pri1, &pair[1]);
+	bsx_pair(opt, &idx->ref, pes, pair, id, &out[0], &out[1], &out[2], z);
+	out[3] = z[0]; out[4] = z[1];
+	free(pair[0].a); free(pair[1].a);
+}

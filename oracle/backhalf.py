@@ -1,0 +1,236 @@
+"""oracle/backhalf.py -- TEST INFRASTRUCTURE, not product code.
+
+A second, independent restatement of three host-logic functions of the reference's back half, written from the reference's
+source lines (not from csrc/host/region.c) in plain Python for small cases:
+
+    mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
+    pestat            cal_sub + mem_pestat                             lib/aln/mem_pair.c:41-146
+    pair              mem_pair                                         lib/aln/mem_pair.c:149-270
+
+The reference files themselves cannot be compiled here (they include wzmisc.h from a repository that is not under
+/root/reference), so these rows stay "unpinned"; what this file adds is that the product's
+implementation (a histogram instead of a sort in pestat, qsort-style generic introsort, its own key packing) is no longer
+compared only with itself.  Every sort below orders by a key that is unique (hash_64 of distinct ids; keys that embed the
+element's index), so klib's introsort and Python's sort give the same permutation.
+
+Regions are dicts with the mem_alnreg_t fields the functions read or write: rb re qb qe rid score is_alt bss (+ sub sub_n
+alt_sc secondary secondary_all hash, written here).  opt is a dict of the mem_opt_t fields used.  Floats: opt["mask_level"]
+is the C float; products with ints are formed in single precision where the C code does (float * int), in double elsewhere.
+"""
+import math
+import struct
+
+M64 = (1 << 64) - 1
+INT_MAX = 2147483647
+
+
+def hash_64(key):   # lib/aln/utils.h:107-117
+    key &= M64
+    key = (key + (~(key << 32) & M64)) & M64
+    key ^= key >> 22
+    key = (key + (~(key << 13) & M64)) & M64
+    key ^= key >> 8
+    key = (key + (key << 3)) & M64
+    key ^= key >> 15
+    key = (key + (~(key << 27) & M64)) & M64
+    key ^= key >> 31
+    return key
+
+
+def f32(x):
+    return struct.unpack("f", struct.pack("f", x))[0]
+
+
+def _sig_overlap(a, b, mask_level):
+    """the overlap test shared by mem_mark_primary_se_core (mem_alnreg.c:268-272) and cal_sub (mem_pair.c:49-54):
+    `e_min - b_max >= min_l * opt->mask_level` is int >= int * float, evaluated in single precision"""
+    b_max = max(a["qb"], b["qb"])
+    e_min = min(a["qe"], b["qe"])
+    if e_min > b_max:
+        min_l = min(a["qe"] - a["qb"], b["qe"] - b["qb"])
+        return f32(float(e_min - b_max)) >= f32(f32(float(min_l)) * f32(mask_level))
+    return False
+
+
+def _mark_core(opt, n_mark, regs, z):   # mem_alnreg.c:252-288
+    tmp = max(opt["a"] + opt["b"], opt["o_del"] + opt["e_del"], opt["o_ins"] + opt["e_ins"])
+    del z[:]
+    z.append(0)
+    for i in range(1, n_mark):
+        a = regs[i]
+        hit = None
+        for k in z:
+            b = regs[k]
+            if _sig_overlap(a, b, opt["mask_level"]):
+                if b["sub"] == 0:
+                    b["sub"] = a["score"]
+                if b["score"] - a["score"] <= tmp and (b["is_alt"] or not a["is_alt"]):
+                    b["sub_n"] += 1
+                hit = k
+                break
+        if hit is None:
+            z.append(i)
+        else:
+            a["secondary"] = hit
+
+
+def mark_primary_se(opt, regs, rid):   # mem_alnreg.c:290-380; returns n_pri, regs reordered in place
+    n = len(regs)
+    if n == 0:
+        return 0
+    n_pri = 0
+    for i, p in enumerate(regs):
+        p["sub"] = p["alt_sc"] = 0
+        p["secondary"] = p["secondary_all"] = -1
+        p["hash"] = hash_64(rid + i)
+        if not p["is_alt"]:
+            n_pri += 1
+    regs.sort(key=lambda p: (-p["score"], p["is_alt"], p["hash"]))      # alnreg_hlt
+    z = []
+    _mark_core(opt, n, regs, z)
+    for i, p in enumerate(regs):
+        p["secondary_all"] = i
+        if not p["is_alt"] and p["secondary"] >= 0 and regs[p["secondary"]]["is_alt"]:
+            p["alt_sc"] = regs[p["secondary"]]["score"]
+    if 0 < n_pri < n:
+        regs.sort(key=lambda p: (p["is_alt"], -p["score"], p["hash"]))  # alnreg_hlt2
+        zmap = [0] * n
+        for i, p in enumerate(regs):
+            zmap[p["secondary_all"]] = i
+        for p in regs:
+            if p["secondary"] >= 0:
+                p["secondary_all"] = zmap[p["secondary"]]
+                if p["is_alt"]:
+                    p["secondary"] = INT_MAX
+            else:
+                p["secondary_all"] = -1
+        for i in range(n_pri):
+            regs[i]["sub"] = 0
+            regs[i]["secondary"] = -1
+        _mark_core(opt, n_pri, regs, z)
+    else:
+        for p in regs:
+            p["secondary_all"] = p["secondary"]
+    return n_pri
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def infer_isize(pos1, pos2, isrev1, isrev2, len1, len2):   # mem_alnreg.h:75-83
+    if isrev1 and not isrev2:
+        return pos1 - pos2 + len1
+    if isrev2 and not isrev1:
+        return pos2 - pos1 + len2
+    return None
+
+
+def alnreg_isize(l_pac, r1, r2):   # mem_alnreg.h:86-93 (note: strictly greater than l_pac)
+    if r1["rid"] != r2["rid"]:
+        return None
+    isrev1, isrev2 = r1["rb"] > l_pac, r2["rb"] > l_pac
+    pos1 = (l_pac << 1) - 1 - r1["rb"] if isrev1 else r1["rb"]
+    pos2 = (l_pac << 1) - 1 - r2["rb"] if isrev2 else r2["rb"]
+    return infer_isize(pos1, pos2, isrev1, isrev2, r1["qe"] - r1["qb"], r2["qe"] - r2["qb"])
+
+
+def cal_sub(opt, regs):   # mem_pair.c:41-57
+    best = regs[0]
+    for p in regs[1:]:
+        if _sig_overlap(p, best, opt["mask_level"]):
+            return p["score"]
+    return opt["min_seed_len"] * opt["a"]
+
+
+def pestat(opt, l_pac, reads):   # mem_pair.c:60-146; reads = list of region lists, pairs (2i, 2i+1)
+    MIN_RATIO, MIN_DIR_CNT, OUTLIER_BOUND, MAPPING_BOUND, MAX_STDDEV = 0.8, 10, 2.0, 3.0, 4.0
+    isize = []
+    for i in range(len(reads) >> 1):
+        r0, r1 = reads[2 * i], reads[2 * i + 1]
+        if not r0 or not r1:
+            continue
+        b0, b1 = r0[0], r1[0]
+        if cal_sub(opt, r0) > MIN_RATIO * b0["score"]:
+            continue
+        if cal_sub(opt, r1) > MIN_RATIO * b1["score"]:
+            continue
+        if b0["rid"] != b1["rid"] or b0["bss"] != b1["bss"]:
+            continue
+        ins = alnreg_isize(l_pac, b0, b1)
+        if ins is not None and -opt["max_ins"] <= ins <= opt["max_ins"]:
+            isize.append(ins)
+    pes = {"low": 0, "high": 0, "failed": 0, "avg": 0.0, "std": 0.0}
+    if len(isize) < MIN_DIR_CNT:
+        pes["failed"] = 1
+        return pes
+    isize.sort()
+    n = len(isize)
+    p25, p50, p75 = isize[int(.25 * n + .499)], isize[int(.50 * n + .499)], isize[int(.75 * n + .499)]
+    low = int(p25 - OUTLIER_BOUND * (p75 - p25) + .499)
+    high = int(p75 + OUTLIER_BOUND * (p75 - p25) + .499)
+    avg, x = 0.0, 0
+    for v in isize:
+        if low <= v <= high:
+            avg += v
+            x += 1
+    avg /= x
+    std = 0.0
+    for v in isize:
+        if low <= v <= high:
+            std += (v - avg) * (v - avg)
+    std = math.sqrt(std / x)
+    low = int(p25 - MAPPING_BOUND * (p75 - p25) + .499)
+    high = int(p75 + MAPPING_BOUND * (p75 - p25) + .499)
+    if low > avg - MAX_STDDEV * std:
+        low = int(avg - MAX_STDDEV * std + .499)
+    if high < avg + MAX_STDDEV * std:
+        high = int(avg + MAX_STDDEV * std + .499)
+    pes.update(low=low, high=high, avg=avg, std=std)
+    return pes
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def region_depos(l_pac, ann_offset, reg):   # mem_alnreg.h:139-144 over bns_depos
+    pos = reg["rb"] if reg["rb"] < l_pac else reg["re"] - 1
+    if pos >= l_pac:
+        pos = (l_pac << 1) - 1 - pos
+    return pos - ann_offset[reg["rid"]]
+
+
+def pair(opt, l_pac, ann_offset, pes, regs_pair, n_pri, rid):   # mem_pair.c:149-270 -> (score, sub, n_sub, z0, z1)
+    v = []
+    for r in range(2):
+        for i in range(n_pri[r]):
+            p = regs_pair[r][i]
+            x = ((p["bss"] << 63) | (p["rid"] << 32) | (region_depos(l_pac, ann_offset, p) & M64)) & M64
+            y = ((p["score"] << 32) | (i << 2) | ((1 if p["rb"] >= l_pac else 0) << 1) | r) & M64
+            v.append((x, y, p["qe"] - p["qb"]))
+    v.sort(key=lambda t: (t[0], t[1]))
+    proper = []
+    hi_lo = max(pes["low"], pes["high"])
+    for i in range(len(v)):
+        for k in range(i - 1, -1, -1):
+            if v[i][0] >> 32 != v[k][0] >> 32:
+                break
+            if v[i][0] >> 63 != v[k][0] >> 63:
+                break
+            if (v[i][0] & 0xffffffff) - (v[k][0] & 0xffffffff) > hi_lo:
+                break
+            if (v[i][1] & 1) == (v[k][1] & 1):
+                break
+            ins = infer_isize(v[k][0], v[i][0], (v[k][1] >> 1) & 1, (v[i][1] >> 1) & 1, v[k][2], v[i][2])
+            if ins is not None and pes["low"] <= ins <= pes["high"]:
+                zscore = (ins - pes["avg"]) / pes["std"]
+                sc = max(0, int((v[i][1] >> 32) + (v[k][1] >> 32) + .721 * math.log(2. * math.erfc(abs(zscore) * math.sqrt(0.5))) * opt["a"] + .499))
+                y = (k << 32) | i
+                proper.append((((sc << 32) | (hash_64(y ^ (rid << 8)) & 0xffffffff)), y))
+    if not proper:
+        return 0, 0, 0, -1, -1
+    proper.sort()
+    i, k = proper[-1][1] >> 32, proper[-1][1] & 0xffffffff
+    z = [-1, -1]
+    z[v[i][1] & 1] = (v[i][1] & 0xffffffff) >> 2
+    z[v[k][1] & 1] = (v[k][1] & 0xffffffff) >> 2
+    score = proper[-1][0] >> 32
+    sub = proper[-2][0] >> 32 if len(proper) > 1 else 0
+    tmp = max(opt["a"] + opt["b"], opt["o_del"] + opt["e_del"], opt["o_ins"] + opt["e_ins"])
+    n_sub = sum(1 for t in proper[:-1] if sub - (t[0] >> 32) <= tmp)
+    return score, sub, n_sub, z[0], z[1]

@@ -1,0 +1,174 @@
+"""CPU: the product's host implementations of mem_mark_primary_se, mem_pestat and mem_pair (csrc/host/region.c, reached through
+csrc/host/hooks.c) against oracle/backhalf.py -- an independent restatement of the same reference functions written from
+lib/aln/mem_alnreg.c:252-380 and lib/aln/mem_pair.c:41-270.  The reference files cannot be compiled here; this
+makes these rows two implementations that must agree bit for bit (doubles included) instead of one compared with itself."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import pytest
+import simdata
+from biscuit_amd import _lib as B
+from biscuit_amd.api import Index, default_opt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import backhalf  # noqa: E402
+
+
+class HookReg(C.Structure):
+    _fields_ = [("rb", C.c_int64), ("re", C.c_int64)] + [(k, C.c_int32) for k in
+                ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] + \
+               [("hash", C.c_uint64), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 6)]
+
+
+KEYS = ("rb", "re", "qb", "qe", "rid", "score", "is_alt", "bss")
+
+
+def to_c(regs):
+    a = (HookReg * max(1, len(regs)))()
+    for k, r in enumerate(regs):
+        for f in KEYS:
+            setattr(a[k], f, int(r[f]))
+        for f in ("sub", "sub_n", "alt_sc", "secondary", "secondary_all"):
+            setattr(a[k], f, int(r.get(f, 0)))
+    return a
+
+
+def opt_dict(o):
+    return {k: getattr(o, k) for k in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "min_seed_len", "max_ins", "mask_level")}
+
+
+@pytest.fixture(scope="module")
+def small(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("bh"))
+    contigs = simdata.make_genome(400000, seed=3, n_contigs=3)
+    simdata.write_genome(d + "/g.fa", contigs)
+    idx = Index.build(d + "/g.fa", d + "/g")
+    L = B.lib()
+    L.bsx_index_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    offs, lens = [], []
+    for i in range(3):
+        nm, off, ln = C.c_char_p(), C.c_int64(), C.c_int64()
+        B.check(L.bsx_index_contig(idx.h, i, C.byref(nm), C.byref(off), C.byref(ln)), "contig")
+        offs.append(off.value)
+        lens.append(ln.value)
+    yield idx, offs, lens
+    idx.close()
+
+
+def rand_regs(rng, n, l_pac, alt_frac=0.15):
+    out = []
+    for _ in range(n):
+        qb = int(rng.integers(0, 110))
+        qe = qb + int(rng.integers(20, 151 - qb))
+        rb = int(rng.integers(0, 2 * l_pac - 400))
+        out.append({"rb": rb, "re": rb + (qe - qb) + int(rng.integers(-3, 4)), "qb": qb, "qe": qe, "rid": 0,
+                    "score": int(rng.choice([30, 45, 45, 60, 80, 100, 100, 120, 149])) if rng.random() < 0.5 else int(rng.integers(20, 150)),
+                    "is_alt": int(rng.random() < alt_frac), "bss": int(rng.integers(0, 2)), "sub_n": 0})   # sub_n: zero as mem_alnreg_t comes from calloc
+    return out
+
+
+def test_mark_primary(small):
+    idx, _, _ = small
+    L = B.lib()
+    opt = default_opt()
+    od = opt_dict(opt)
+    L.bsx_hook_mark_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]
+    rng = np.random.default_rng(5)
+    seen_second_round = seen_sub_n = 0
+    for trial in range(4000):
+        n = int(rng.integers(1, 11))
+        regs = rand_regs(rng, n, idx.l_pac, alt_frac=0.0 if trial % 3 == 0 else 0.3)
+        rid = int(rng.integers(0, 1 << 40))
+        a = to_c(regs)
+        n_pri = L.bsx_hook_mark_primary(C.byref(opt), a, n, rid)
+        want_pri = backhalf.mark_primary_se(od, regs, rid)
+        assert n_pri == want_pri, trial
+        for k, r in enumerate(regs):
+            got = tuple(getattr(a[k], f) for f in ("score", "qb", "qe", "is_alt", "sub", "sub_n", "alt_sc", "secondary", "secondary_all", "hash"))
+            want = tuple(r[f] for f in ("score", "qb", "qe", "is_alt", "sub", "sub_n", "alt_sc", "secondary", "secondary_all", "hash"))
+            assert got == want, (trial, k, got, want)
+        seen_second_round += 0 < want_pri < n
+        seen_sub_n += any(r["sub_n"] > 0 for r in regs)
+    assert seen_second_round > 500 and seen_sub_n > 500
+
+
+def _pairs(rng, n_pairs, l_pac, offs, lens):
+    """reads[2i], reads[2i+1]: mostly a proper pair ~N(300, 40) apart on opposite strands, plus decoys, other contigs and strands"""
+    reads = []
+    for _ in range(n_pairs):
+        rid = int(rng.integers(0, 3))
+        ins = int(rng.normal(300, 40))
+        f = offs[rid] + int(rng.integers(0, lens[rid] - 800))
+        flip = rng.random() < 0.5
+        r1 = {"rb": f, "re": f + 150, "qb": 0, "qe": 150, "rid": rid, "score": int(rng.integers(100, 151)), "is_alt": 0, "bss": 0}
+        e = f + max(160, ins)                      # forward end of the mate, which lies on the reverse strand
+        r2 = {"rb": 2 * l_pac - e, "re": 2 * l_pac - e + 150, "qb": 0, "qe": 150, "rid": rid, "score": int(rng.integers(100, 151)), "is_alt": 0, "bss": 0}
+        if flip:
+            r1, r2 = r2, r1
+        u = rng.random()
+        if u < 0.05:
+            r2 = dict(r2, bss=1)
+        elif u < 0.10:
+            r2 = dict(r2, rid=(rid + 1) % 3)
+        elif u < 0.15:
+            r2 = dict(r2, rb=r1["rb"] + 40, re=r1["rb"] + 190)   # same strand
+        elif u < 0.18:
+            r2 = None
+        lists = []
+        for r in (r1, r2):
+            if r is None:
+                lists.append([])
+                continue
+            lst = [r]
+            for _ in range(int(rng.integers(0, 3))):           # lower hits elsewhere, some overlapping the best on the read
+                qb = int(rng.integers(0, 100))
+                d = dict(r, rb=int(rng.integers(0, 2 * l_pac - 400)), qb=qb, qe=qb + int(rng.integers(30, 151 - qb)), score=int(rng.integers(30, r["score"] + 1)))
+                d["re"] = d["rb"] + d["qe"] - d["qb"]
+                lst.append(d)
+            lists.append(lst)
+        reads += lists
+    return reads
+
+
+def test_pestat_and_pair(small):
+    idx, offs, lens = small
+    L = B.lib()
+    opt = default_opt()
+    od = opt_dict(opt)
+    l_pac = idx.l_pac
+    L.bsx_hook_pestat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bsx_hook_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(11)
+    for n_pairs in (4, 40, 3000):          # too few pairs (failed), a small and a large sample
+        reads = _pairs(rng, n_pairs, l_pac, offs, lens)
+        flat = [r for lst in reads for r in lst]
+        off = np.zeros(len(reads) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(lst) for lst in reads])
+        a = to_c(flat)
+        pes = B.PeStat()
+        L.bsx_hook_pestat(C.byref(opt), idx.h, len(reads), a, off.ctypes.data_as(C.c_void_p), C.byref(pes))
+        want = backhalf.pestat(od, l_pac, reads)
+        assert pes.failed == want["failed"], n_pairs
+        if want["failed"]:
+            continue
+        assert (pes.low, pes.high, pes.avg, pes.std) == (want["low"], want["high"], want["avg"], want["std"]), (n_pairs, pes.avg, want["avg"], pes.std, want["std"])
+        assert 400 < pes.avg < 500 and 20 < pes.std < 60   # the simulated insert + one read length (isize counts the mate, mem_alnreg.h:75-83)
+        # mem_pair of every pair with those statistics; regions ordered and counted as mem_mark_primary_se leaves them
+        n_proper = n_sub_seen = 0
+        for i in range(len(reads) >> 1):
+            pr = [sorted(reads[2 * i], key=lambda r: -r["score"]), sorted(reads[2 * i + 1], key=lambda r: -r["score"])]
+            if rng.random() < 0.3 and pr[0] and pr[1]:   # a second candidate near the mate: competing pairings
+                d = dict(pr[1][0], rb=pr[1][0]["rb"] + 7, re=pr[1][0]["re"] + 7, score=max(20, pr[1][0]["score"] - int(rng.integers(0, 12))))
+                pr[1].insert(1, d)
+            npri = [len(pr[0]), len(pr[1])]
+            out = (C.c_int * 5)()
+            a0, a1 = to_c(pr[0]), to_c(pr[1])
+            L.bsx_hook_pair(C.byref(opt), idx.h, C.byref(pes), a0, len(pr[0]), npri[0], a1, len(pr[1]), npri[1], i, out)
+            w = backhalf.pair(od, l_pac, offs, want, pr, npri, i)
+            assert tuple(out) == w, (n_pairs, i, tuple(out), w)
+            n_proper += w[3] >= 0
+            n_sub_seen += w[2] > 0
+        if n_pairs >= 3000:
+            assert n_proper > 0.6 * n_pairs and n_sub_seen > 100
