@@ -1,8 +1,9 @@
 """oracle/backhalf.py -- TEST INFRASTRUCTURE, not product code.
 
-A second, independent restatement of three host-logic functions of the reference's back half, written from the reference's
+A second, independent restatement of host-logic functions of the reference's back half, written from the reference's
 source lines (not from csrc/host/region.c) in plain Python for small cases:
 
+    sort_dedup        mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment   lib/aln/mem_alnreg.c:63-202
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
     pestat            cal_sub + mem_pestat                             lib/aln/mem_pair.c:41-146
     pair              mem_pair                                         lib/aln/mem_pair.c:149-270
@@ -10,8 +11,9 @@ source lines (not from csrc/host/region.c) in plain Python for small cases:
 The reference files themselves cannot be compiled here (they include wzmisc.h from a repository that is not under
 /root/reference), so these rows stay "unpinned"; what this file adds is that the product's
 implementation (a histogram instead of a sort in pestat, qsort-style generic introsort, its own key packing) is no longer
-compared only with itself.  Every sort below orders by a key that is unique (hash_64 of distinct ids; keys that embed the
-element's index), so klib's introsort and Python's sort give the same permutation.
+compared only with itself.  The sorts of the last three functions order by keys that are unique (hash_64 of distinct ids; keys
+that embed the element's index), so klib's introsort and Python's sort give the same permutation; sort_dedup's keys are not,
+and it takes the permutation from the real klib template (oracle/_ref) through a callback.
 
 Regions are dicts with the mem_alnreg_t fields the functions read or write: rb re qb qe rid score is_alt bss (+ sub sub_n
 alt_sc secondary secondary_all hash, written here).  opt is a dict of the mem_opt_t fields used.  Floats: opt["mask_level"]
@@ -234,3 +236,57 @@ def pair(opt, l_pac, ann_offset, pes, regs_pair, n_pri, rid):   # mem_pair.c:149
     tmp = max(opt["a"] + opt["b"], opt["o_del"] + opt["e_del"], opt["o_ins"] + opt["e_ins"])
     n_sub = sum(1 for t in proper[:-1] if sub - (t[0] >> 32) <= tmp)
     return score, sub, n_sub, z[0], z[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def sort_dedup(opt, l_pac, regs, klib_order):   # mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment, mem_alnreg.c:63-202
+    """regs: dicts with rb re qb qe rid score.  klib_order(keys) -> the permutation ks_introsort leaves for records compared by
+    these integer keys alone (the real klib template, through oracle/_ref: the keys here are NOT unique, so the algorithm's own
+    order for equal keys is part of the result).  Returns the indices of the regions kept, in their final order, or None when two
+    regions would have to be aligned across their gap (mem_alnreg.c:92-97: the score decides, and a merge rewrites a region)."""
+    n = len(regs)
+    if n <= 1:
+        return list(range(n))
+    order = klib_order([r["re"] for r in regs])            # alnreg_slt2: by END
+    a = [dict(regs[i], idx=i) for i in order]
+    mlr = opt["mask_level_redun"]
+    for i in range(1, n):
+        p = a[i]
+        j = i - 1
+        while j >= 0 and p["rid"] == a[j]["rid"] and p["rb"] < a[j]["re"] + opt["max_chain_gap"]:
+            q = a[j]
+            j -= 1
+            if q["qe"] == q["qb"]:
+                continue
+            orr = q["re"] - p["rb"]
+            oq = q["qe"] - p["qb"] if q["qb"] < p["qb"] else p["qe"] - q["qb"]
+            mr = min(q["re"] - q["rb"], p["re"] - p["rb"])
+            mq = min(q["qe"] - q["qb"], p["qe"] - p["qb"])
+            # int64 > float * int64: both sides in single precision
+            if f32(float(orr)) > f32(f32(mlr) * f32(float(mr))) and f32(float(oq)) > f32(f32(mlr) * f32(float(mq))):
+                if p["score"] < q["score"]:
+                    p["qe"] = p["qb"]
+                    break
+                q["qe"] = q["qb"]
+            elif q["rb"] < p["rb"]:
+                if q["rb"] < l_pac <= p["rb"]:
+                    continue
+                if q["qb"] >= p["qb"] or q["qe"] >= p["qe"] or q["re"] >= p["re"]:
+                    continue
+                w = abs((q["re"] - p["rb"]) - (q["qe"] - p["qb"]))
+                r = abs((q["re"] - p["rb"]) / (p["re"] - q["rb"]) - (q["qe"] - p["qb"]) / (p["qe"] - q["qb"]))
+                if q["re"] < p["rb"] or q["qe"] < p["qb"]:
+                    if w > opt["w"] << 1 or r >= f32(0.05):
+                        continue
+                elif w > opt["w"] << 2 or r >= f32(f32(0.05) * 2):
+                    continue
+                return None
+    a = [r for r in a if r["qe"] > r["qb"]]
+    # alnreg_slt: score descending, then rb, then qb -- one ascending integer key with the same order
+    order = klib_order([((1 << 19) - r["score"]) << 44 | r["rb"] << 10 | r["qb"] for r in a])
+    a = [a[i] for i in order]
+    dead = [False] * len(a)
+    for i in range(1, len(a)):
+        if a[i]["score"] == a[i - 1]["score"] and a[i]["rb"] == a[i - 1]["rb"] and a[i]["qb"] == a[i - 1]["qb"]:
+            dead[i] = True
+    return [a[i]["idx"] for i in range(len(a)) if i == 0 or not dead[i]]

@@ -172,3 +172,67 @@ def test_pestat_and_pair(small):
             n_sub_seen += w[2] > 0
         if n_pairs >= 3000:
             assert n_proper > 0.6 * n_pairs and n_sub_seen > 100
+
+
+def test_sort_dedup(small):
+    """mem_sort_deduplicate: the host function (region.c; the device's k_dedup is compared with it in tests/test_gpu_align.py) against
+    the restatement, whose two sorts are the real klib introsort (oracle/_ref) -- the keys are not unique and the order klib leaves
+    equal keys in decides which of two identical hits survives."""
+    from oracle_lib import ref_lib
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is not built")
+    idx, _, _ = small
+    L = B.lib()
+    opt = default_opt()
+    od = dict(opt_dict(opt), mask_level_redun=opt.mask_level_redun, max_chain_gap=opt.max_chain_gap, w=opt.w)
+    l_pac = idx.l_pac
+    R.ref_introsort_kv.argtypes = [C.c_int64, C.c_void_p]
+
+    def klib_order(keys):
+        kv = np.zeros((len(keys), 2), dtype=np.int64)
+        kv[:, 0] = keys
+        kv[:, 1] = np.arange(len(keys))
+        if len(keys):
+            R.ref_introsort_kv(len(keys), kv.ctypes.data_as(C.c_void_p))
+        return [int(x) for x in kv[:, 1]]
+    L.bsx_hook_regs_sort_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.bsx_hook_regs_sort_dedup.restype = C.c_int
+    dt = np.dtype(B.Region)
+    rng = np.random.default_rng(23)
+    n_cmp = n_drop = n_tie = n_concat = 0
+    for trial in range(6000):
+        n = int(rng.integers(1, 25))
+        base = int(rng.integers(1000, l_pac - 5000)) + (l_pac if rng.random() < 0.5 else 0)
+        regs = []
+        for _ in range(n):
+            if regs and rng.random() < 0.35:       # a near copy of an earlier one: same end, same start, or identical
+                r = dict(regs[int(rng.integers(0, len(regs)))])
+                u = rng.random()
+                if u < 0.4:
+                    r["rb"] -= int(rng.integers(0, 4)); r["qb"] = max(0, r["qb"] - int(rng.integers(0, 4)))
+                elif u < 0.7:
+                    r["score"] = max(20, r["score"] - int(rng.integers(0, 3)))
+            else:
+                qb = int(rng.integers(0, 100))
+                qe = qb + int(rng.integers(25, 151 - qb))
+                rb = base + int(rng.integers(-300, 1500)) if rng.random() < 0.8 else int(rng.integers(0, 2 * l_pac - 400))
+                r = {"rb": rb, "re": rb + (qe - qb) + int(rng.integers(-2, 3)), "qb": qb, "qe": qe, "rid": 0 if rng.random() < 0.9 else 1,
+                     "score": int(rng.integers(25, 150))}
+            regs.append(r)
+        want = backhalf.sort_dedup(od, l_pac, [dict(r) for r in regs], klib_order)
+        arr = np.zeros(n, dtype=dt)
+        for k, r in enumerate(regs):
+            for f in ("rb", "re", "qb", "qe", "rid", "score"):
+                arr[k][f] = r[f]
+        keep = np.zeros(n, dtype=np.int32)
+        m = L.bsx_hook_regs_sort_dedup(C.byref(opt), idx.h, arr.ctypes.data_as(C.c_void_p), n, keep.ctypes.data_as(C.c_void_p))
+        if want is None:
+            assert m == -1, trial
+            n_concat += 1
+            continue
+        assert m == len(want) and list(keep[:m]) == want, (trial, list(keep[:max(m, 0)]), want)
+        n_cmp += 1
+        n_drop += m < n
+        n_tie += len(set(r["re"] for r in regs)) < n
+    assert n_cmp > 4000 and n_drop > 2000 and n_tie > 2000 and n_concat > 20, (n_cmp, n_drop, n_tie, n_concat)
