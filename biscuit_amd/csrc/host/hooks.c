@@ -1,6 +1,7 @@
 /* hooks.c -- small exported entry points used by the Python plumbing (multi-GPU launcher, tests):
  * flat wrappers over internal host functions, no logic of their own. */
 #include "align_types.h"
+#include "hook_types.h"
 #include "fastq.h"
 
 /* ---- chunked FASTQ access for the chunk-sharded multi-GPU launcher ---- */
@@ -80,35 +81,12 @@ BSX_API int bsx_hook_regs_sort_dedup(const bsx_opt_t *opt, const bsx_index_t *id
 
 /* ---- the per-read / per-pair functions of the back half, callable on plain arrays (tests/test_oracle_backhalf.py compares them with
  * oracle/backhalf.py, an independent restatement of the reference's functions) */
-typedef struct {
-	int64_t rb, re;
-	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
-	uint64_t hash;
-	uint8_t bss, parent, pad[6];
-} bsx_hook_reg_t;
-
-static void hook_to_reg(const bsx_hook_reg_t *h, reg_t *r)
-{
-	memset(r, 0, sizeof(*r));
-	r->rb = h->rb; r->re = h->re; r->qb = h->qb; r->qe = h->qe; r->rid = h->rid; r->score = h->score; r->truesc = h->truesc; r->sub = h->sub;
-	r->alt_sc = h->alt_sc; r->csub = h->csub; r->sub_n = h->sub_n; r->w = h->w; r->seedcov = h->seedcov; r->secondary = h->secondary;
-	r->secondary_all = h->secondary_all; r->seedlen0 = h->seedlen0; r->n_comp = h->n_comp; r->is_alt = h->is_alt; r->hash = h->hash;
-	r->bss = h->bss; r->parent = h->parent;
-}
-static void hook_from_reg(const reg_t *r, bsx_hook_reg_t *h)
-{
-	memset(h, 0, sizeof(*h));
-	h->rb = r->rb; h->re = r->re; h->qb = r->qb; h->qe = r->qe; h->rid = r->rid; h->score = r->score; h->truesc = r->truesc; h->sub = r->sub;
-	h->alt_sc = r->alt_sc; h->csub = r->csub; h->sub_n = r->sub_n; h->w = r->w; h->seedcov = r->seedcov; h->secondary = r->secondary;
-	h->secondary_all = r->secondary_all; h->seedlen0 = r->seedlen0; h->n_comp = r->n_comp; h->is_alt = r->is_alt; h->hash = r->hash;
-	h->bss = r->bss; h->parent = r->parent;
-}
 static void hook_vec(const bsx_hook_reg_t *a, int n, int n_pri, reg_v *v)
 {
 	int k;
 	v->n = v->m = (size_t)n; v->n_pri = (size_t)n_pri;
 	v->a = (reg_t*)calloc(n ? n : 1, sizeof(reg_t));
-	for (k = 0; k < n; ++k) hook_to_reg(&a[k], &v->a[k]);
+	for (k = 0; k < n; ++k) bsx_hook_to_reg(&a[k], &v->a[k]);
 }
 
 /* mem_mark_primary_se in place; returns n_pri */
@@ -118,7 +96,7 @@ BSX_API int bsx_hook_mark_primary(const bsx_opt_t *opt, bsx_hook_reg_t *a, int n
 	int k, n_pri;
 	hook_vec(a, n, 0, &v);
 	bsx_mark_primary(opt, &v, id);
-	for (k = 0; k < n; ++k) hook_from_reg(&v.a[k], &a[k]);
+	for (k = 0; k < n; ++k) bsx_hook_from_reg(&v.a[k], &a[k]);
 	n_pri = (int)v.n_pri;
 	free(v.a);
 	return n_pri;

@@ -618,6 +618,44 @@ static int mate_rescue(chunk_t *C)
 	return rc;
 }
 
+/* test hook: mem_alnreg_matesw of n_reads / 2 pairs as this pipeline runs it (plan, K5 batch on the given backend, replay), on region
+ * lists given as flat records: read i's regions are a[off[i] .. off[i+1]); the lists after rescue come back the same way */
+#include "hook_types.h"
+BSX_API int bsx_hook_mate_rescue(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes, int n_reads,
+                                 bsx_read_t *reads, const bsx_hook_reg_t *a, const int64_t *off, bsx_hook_reg_t *out, int64_t *out_off, int64_t out_cap)
+{
+	chunk_t *C = (chunk_t*)calloc(1, sizeof(chunk_t));
+	int i, rc;
+	size_t tot = 0, k;
+	int64_t at = 0;
+	C->be_copy = *be; C->be = &C->be_copy; C->opt = opt; C->idx = idx; C->n = n_reads; C->reads = reads; C->nt = 1; C->is_pe = 1; C->arena_set = -1;
+	C->pes = *pes;
+	C->roff = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)n_reads + 1));
+	for (i = 0; i < n_reads; ++i) { C->roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
+	C->roff[n_reads] = (uint32_t)tot;
+	C->buf = (uint8_t*)malloc(tot + 16);
+	for (i = 0; i < n_reads; ++i) if (reads[i].l_seq) memcpy(C->buf + C->roff[i], reads[i].seq, (size_t)reads[i].l_seq);
+	C->regs = (reg_v*)calloc(n_reads ? n_reads : 1, sizeof(reg_v));
+	for (i = 0; i < n_reads; ++i) {
+		reg_v *v = &C->regs[i];
+		v->n = (size_t)(off[i + 1] - off[i]); v->m = v->n + 4;
+		v->a = (reg_t*)bsx_crealloc(0, 0, sizeof(reg_t) * v->m);
+		for (k = 0; k < v->n; ++k) bsx_hook_to_reg(&a[off[i] + (int64_t)k], &v->a[k]);
+	}
+	rc = be->set_opt(be->ctx, opt);
+	if (rc == BSX_OK) rc = be->set_reads(be->ctx, C->buf, tot);
+	if (rc == BSX_OK) rc = mate_rescue(C);
+	for (i = 0; i < n_reads && rc == BSX_OK; ++i) {
+		out_off[i] = at;
+		if (at + (int64_t)C->regs[i].n > out_cap) { rc = BSX_E_ARG; break; }
+		for (k = 0; k < C->regs[i].n; ++k) bsx_hook_from_reg(&C->regs[i].a[k], &out[at++]);
+	}
+	out_off[n_reads] = at;
+	for (i = 0; i < n_reads; ++i) bsx_cfree(C->regs[i].a);
+	free(C->regs); free(C->roff); free(C->buf); free(C);
+	return rc;
+}
+
 /* ------------------------------------------------------------------ output: plan -> K6 -> final */
 typedef struct {
 	chunk_t *C;

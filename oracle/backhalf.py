@@ -4,6 +4,7 @@ A second, independent restatement of host-logic functions of the reference's bac
 source lines (not from csrc/host/region.c) in plain Python for small cases:
 
     sort_dedup        mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment   lib/aln/mem_alnreg.c:63-202
+    matesw            mem_alnreg_matesw + mem_alnreg_matesw_core (SW by the real ksw_align2)   lib/aln/mem_alnreg.c:385-513
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
     pestat            cal_sub + mem_pestat                             lib/aln/mem_pair.c:41-146
     pair              mem_pair                                         lib/aln/mem_pair.c:149-270
@@ -239,7 +240,7 @@ def pair(opt, l_pac, ann_offset, pes, regs_pair, n_pri, rid):   # mem_pair.c:149
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def sort_dedup(opt, l_pac, regs, klib_order):   # mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment, mem_alnreg.c:63-202
+def sort_dedup(opt, l_pac, regs, klib_order, can_merge=True):   # mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment, mem_alnreg.c:63-202
     """regs: dicts with rb re qb qe rid score.  klib_order(keys) -> the permutation ks_introsort leaves for records compared by
     these integer keys alone (the real klib template, through oracle/_ref: the keys here are NOT unique, so the algorithm's own
     order for equal keys is part of the result).  Returns the indices of the regions kept, in their final order, or None when two
@@ -268,7 +269,7 @@ def sort_dedup(opt, l_pac, regs, klib_order):   # mem_sort_deduplicate + mem_tes
                     p["qe"] = p["qb"]
                     break
                 q["qe"] = q["qb"]
-            elif q["rb"] < p["rb"]:
+            elif can_merge and q["rb"] < p["rb"]:   # bns == 0 (the call after a mate rescue): mem_test_reg_concatenation returns 0 at once
                 if q["rb"] < l_pac <= p["rb"]:
                     continue
                 if q["qb"] >= p["qb"] or q["qe"] >= p["qe"] or q["re"] >= p["re"]:
@@ -290,3 +291,75 @@ def sort_dedup(opt, l_pac, regs, klib_order):   # mem_sort_deduplicate + mem_tes
         if a[i]["score"] == a[i - 1]["score"] and a[i]["rb"] == a[i - 1]["rb"] and a[i]["qb"] == a[i - 1]["qb"]:
             dead[i] = True
     return [a[i]["idx"] for i in range(len(a)) if i == 0 or not dead[i]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+KSW_XBYTE, KSW_XSUBO, KSW_XSTART = 0x10000, 0x40000, 0x80000   # lib/aln/ksw.h:6-9
+
+
+def _pos2rid(anns, pos_f):   # bns_pos2rid (bntseq.c:356-369): the contig holding forward position pos_f
+    for i, (off, ln) in enumerate(anns):
+        if off <= pos_f < off + ln:
+            return i
+    return -1
+
+
+def fetch_seq(l_pac, anns, get_base, beg, mid, end):   # bns_fetch_seq over bns_get_seq (bntseq.c:402-452) -> (seq, beg, end, rid)
+    if end < beg:
+        beg, end = end, beg
+    is_rev = mid >= l_pac
+    rid = _pos2rid(anns, (l_pac << 1) - 1 - mid if is_rev else mid)
+    far_beg, far_end = anns[rid][0], anns[rid][0] + anns[rid][1]
+    if is_rev:
+        far_beg, far_end = (l_pac << 1) - far_end, (l_pac << 1) - far_beg
+    beg, end = max(beg, far_beg), min(end, far_end)
+    if beg >= l_pac:       # reverse strand: the complement, read backwards on the forward strand
+        seq = [3 - get_base((l_pac << 1) - 1 - k) for k in range(beg, end)]
+    else:
+        seq = [get_base(k) for k in range(beg, end)]
+    return seq, beg, end, rid
+
+
+def _matesw_core(opt, l_pac, anns, get_base, pes, reg, ms, mregs, ksw_align2, klib_order):   # mem_alnreg.c:395-491
+    l_ms = len(ms)
+    for m in mregs:
+        ins = alnreg_isize(l_pac, reg, m)
+        if ins is not None and pes["low"] <= ins <= pes["high"]:
+            return
+    rev = [0] * l_ms
+    for i in range(l_ms):
+        rev[l_ms - 1 - i] = 3 - ms[i] if ms[i] < 4 else 4
+    rb = max(0, reg["rb"] + pes["low"] - l_ms)
+    re = min(l_pac << 1, reg["rb"] + pes["high"])
+    rid, ref = -1, None
+    if rb < re:
+        ref, rb, re, rid = fetch_seq(l_pac, anns, get_base, rb, (rb + re) >> 1, re)
+    if reg["rid"] != rid or re - rb < opt["min_seed_len"]:
+        return
+    parent = reg["bss"] ^ (1 if reg["rb"] < l_pac else 0)
+    xtra = KSW_XSUBO | KSW_XSTART | (KSW_XBYTE if l_ms * opt["a"] < 250 else 0) | (opt["min_seed_len"] * opt["a"])
+    aln = ksw_align2(rev, ref, opt["gamat"] if parent else opt["ctmat"], xtra)   # the mate is on the other converted strand
+    if aln["score"] >= opt["min_seed_len"] and aln["qb"] >= 0:
+        b = {"rid": reg["rid"], "is_alt": reg["is_alt"], "qb": l_ms - (aln["qe"] + 1), "qe": l_ms - aln["qb"],
+             "rb": (l_pac << 1) - (rb + aln["te"] + 1), "re": (l_pac << 1) - (rb + aln["tb"]), "score": aln["score"], "csub": aln["score2"],
+             "secondary": -1, "bss": reg["bss"], "parent": 1 - parent}
+        b["seedcov"] = min(b["re"] - b["rb"], b["qe"] - b["qb"]) >> 1
+        at = len(mregs)
+        for i, m in enumerate(mregs):
+            if m["score"] < b["score"]:
+                at = i
+                break
+        mregs.insert(at, b)
+        keep = sort_dedup(opt, l_pac, mregs, klib_order, can_merge=False)
+        mregs[:] = [mregs[i] for i in keep]
+
+
+def matesw(opt, l_pac, anns, get_base, pes, seqs, regs_pair, ksw_align2, klib_order):   # mem_alnreg.c:494-513
+    good = [[], []]
+    for i in range(2):
+        for r in regs_pair[i]:
+            if r["score"] >= regs_pair[i][0]["score"] - opt["pen_unpaired"]:
+                good[i].append(dict(r))
+    for i in range(2):
+        for j in range(min(len(good[i]), opt["max_matesw"])):
+            _matesw_core(opt, l_pac, anns, get_base, pes, good[i][j], seqs[1 - i], regs_pair[1 - i], ksw_align2, klib_order)

@@ -236,3 +236,113 @@ def test_sort_dedup(small):
         n_drop += m < n
         n_tie += len(set(r["re"] for r in regs)) < n
     assert n_cmp > 4000 and n_drop > 2000 and n_tie > 2000 and n_concat > 20, (n_cmp, n_drop, n_tie, n_concat)
+
+
+def test_mate_rescue(small):
+    """mem_alnreg_matesw: the pipeline's plan / K5 batch / replay form of it (pipeline.c, K5 by the CPU restatement of ksw_align2) against
+    the restatement's plain loop, whose Smith-Waterman is the REAL ksw_align2 and whose sorts are the real klib introsort (oracle/_ref)."""
+    from oracle_lib import ref_lib, Port
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is not built")
+    idx, offs, lens = small
+    L = B.lib()
+    opt = default_opt()
+    l_pac = idx.l_pac
+    pac = np.fromfile(idx.base + ".bis.pac", dtype=np.uint8)
+    ii = np.arange(l_pac)
+    g = ((pac[ii >> 2] >> ((~ii & 3) << 1)) & 3).astype(np.uint8)
+    od = dict(opt_dict(opt), mask_level_redun=opt.mask_level_redun, max_chain_gap=opt.max_chain_gap, w=opt.w, pen_unpaired=opt.pen_unpaired,
+              max_matesw=opt.max_matesw, ctmat=(C.c_int8 * 25)(*opt.ctmat), gamat=(C.c_int8 * 25)(*opt.gamat))
+    R.ref_introsort_kv.argtypes = [C.c_int64, C.c_void_p]
+
+    def klib_order(keys):
+        kv = np.zeros((len(keys), 2), dtype=np.int64)
+        kv[:, 0] = keys
+        kv[:, 1] = np.arange(len(keys))
+        if len(keys):
+            R.ref_introsort_kv(len(keys), kv.ctypes.data_as(C.c_void_p))
+        return [int(x) for x in kv[:, 1]]
+
+    def ksw_align2(query, target, mat, xtra):
+        q = np.array(query, dtype=np.uint8)
+        t = np.array(target, dtype=np.uint8)
+        out = (C.c_int * 7)()
+        R.ref_ksw_align2(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra, out)
+        return dict(zip(("score", "te", "qe", "score2", "te2", "tb", "qb"), out))
+    rng = np.random.default_rng(41)
+    pes_d = {"low": 120, "high": 560, "avg": 330.0, "std": 45.0, "failed": 0}
+    pes = B.PeStat(low=120, high=560, set=1, failed=0, avg=330.0, std=45.0)
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    n_pairs = 300
+    seqs, lists = [], []
+    for _ in range(n_pairs):
+        rid = int(rng.integers(0, 3))
+        ins = int(rng.integers(200, 480))
+        f = offs[rid] + int(rng.integers(0, lens[rid] - 600))
+        frag = g[f:f + ins].copy()
+        frag[(frag == 1) & (rng.random(ins) < 0.9)] = 3                  # top strand, C>T converted
+        for k in rng.integers(0, ins, size=int(rng.integers(0, 4))):    # a few substitutions
+            frag[k] = (frag[k] + 1) & 3
+        r1 = frag[:100].copy()
+        r2 = comp[frag[::-1][:100]]
+        if rng.random() < 0.3:
+            r1, r2 = r2, r1                                             # the pair the other way round: read 1 on the reverse strand
+            reg1 = {"rb": 2 * l_pac - (f + ins), "re": 2 * l_pac - (f + ins) + 100, "bss": 0}
+            reg2_true = {"rb": f, "re": f + 100, "bss": 0}
+        else:
+            reg1 = {"rb": f, "re": f + 100, "bss": 0}
+            reg2_true = {"rb": 2 * l_pac - (f + ins), "re": 2 * l_pac - (f + ins) + 100, "bss": 0}
+        base = {"qb": 0, "qe": 100, "rid": rid, "score": int(rng.integers(80, 101)), "is_alt": 0}
+        l1 = [dict(base, **reg1)]
+        u = rng.random()
+        if u < 0.5:
+            l2 = []                                                     # the mate was not found: to be rescued
+        elif u < 0.7:
+            far = int(rng.integers(0, 2 * l_pac - 300))
+            l2 = [dict(base, rb=far, re=far + 100, bss=0, score=int(rng.integers(40, 90)))]     # found elsewhere: rescue adds the proper one
+        elif u < 0.85:
+            l2 = [dict(base, **reg2_true)]                              # already properly paired: nothing to do
+        else:
+            l2 = [dict(base, **reg2_true, score=60), dict(base, rb=reg2_true["rb"] + 1, re=reg2_true["re"] + 1, bss=0, score=55)]
+        if rng.random() < 0.3:
+            l1.append(dict(base, rb=int(rng.integers(0, 2 * l_pac - 300)), bss=0, score=l1[0]["score"] - int(rng.integers(0, 25))))
+            l1[-1]["re"] = l1[-1]["rb"] + 100
+        seqs += [r1, r2]
+        lists += [l1, l2]
+    n = 2 * n_pairs
+    # the product: hook over the pipeline's own mate_rescue, K5 by the CPU restatement
+    port = Port(idx, 1)
+    be = port.backend()
+    reads = (B.Read * n)()
+    keep_alive = []
+    for i, s in enumerate(seqs):
+        buf = (C.c_uint8 * len(s))(*[int(x) for x in s])
+        keep_alive.append(buf)
+        reads[i].l_seq = len(s)
+        reads[i].seq = C.cast(buf, C.POINTER(C.c_uint8))
+    flat = [dict(r, parent=0) for lst in lists for r in lst]
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(lst) for lst in lists])
+    a = to_c(flat)
+    cap = len(flat) + 4 * n
+    out = (HookReg * cap)()
+    out_off = np.zeros(n + 1, dtype=np.int64)
+    L.bsx_hook_mate_rescue.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    B.check(L.bsx_hook_mate_rescue(C.byref(be), C.byref(opt), idx.h, C.byref(pes), n, reads, a, off.ctypes.data_as(C.c_void_p), out,
+                                   out_off.ctypes.data_as(C.c_void_p), cap), "bsx_hook_mate_rescue")
+    anns = list(zip(offs, lens))
+    rescued = unchanged = 0
+    for p in range(n_pairs):
+        pr = [[dict(r) for r in lists[2 * p]], [dict(r) for r in lists[2 * p + 1]]]
+        before = [len(pr[0]), len(pr[1])]
+        backhalf.matesw(od, l_pac, anns, lambda k: int(g[k]), pes_d, [[int(x) for x in seqs[2 * p]], [int(x) for x in seqs[2 * p + 1]]], pr, ksw_align2, klib_order)
+        for w in range(2):
+            i = 2 * p + w
+            got = [tuple(getattr(out[k], f) for f in ("rb", "re", "qb", "qe", "rid", "score", "csub", "is_alt", "bss", "parent", "seedcov", "secondary"))
+                   for k in range(out_off[i], out_off[i + 1])]
+            want = [tuple(r.get(f, 0) for f in ("rb", "re", "qb", "qe", "rid", "score", "csub", "is_alt", "bss", "parent", "seedcov", "secondary")) for r in pr[w]]
+            assert got == want, (p, w, got, want)
+        rescued += len(pr[0]) + len(pr[1]) > sum(before)
+        unchanged += len(pr[0]) + len(pr[1]) == sum(before)
+    assert rescued > 0.3 * n_pairs and unchanged > 0.1 * n_pairs, (rescued, unchanged)
