@@ -8,7 +8,9 @@ typedef struct {
 	int64_t rb, re;
 	int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
 	uint64_t hash;
-	uint8_t bss, parent, pad[6];
+	int32_t flag, mapq;
+	float frac_rep;
+	uint8_t bss, parent, pad[2];
 } bsx_hook_reg_t;
 
 static inline void bsx_hook_to_reg(const bsx_hook_reg_t *h, reg_t *r)
@@ -17,7 +19,7 @@ static inline void bsx_hook_to_reg(const bsx_hook_reg_t *h, reg_t *r)
 	r->rb = h->rb; r->re = h->re; r->qb = h->qb; r->qe = h->qe; r->rid = h->rid; r->score = h->score; r->truesc = h->truesc; r->sub = h->sub;
 	r->alt_sc = h->alt_sc; r->csub = h->csub; r->sub_n = h->sub_n; r->w = h->w; r->seedcov = h->seedcov; r->secondary = h->secondary;
 	r->secondary_all = h->secondary_all; r->seedlen0 = h->seedlen0; r->n_comp = h->n_comp; r->is_alt = h->is_alt; r->hash = h->hash;
-	r->bss = h->bss; r->parent = h->parent;
+	r->bss = h->bss; r->parent = h->parent; r->flag = h->flag; r->mapq = (unsigned)h->mapq; r->frac_rep = h->frac_rep;
 }
 static inline void bsx_hook_from_reg(const reg_t *r, bsx_hook_reg_t *h)
 {
@@ -25,6 +27,6 @@ static inline void bsx_hook_from_reg(const reg_t *r, bsx_hook_reg_t *h)
 	h->rb = r->rb; h->re = r->re; h->qb = r->qb; h->qe = r->qe; h->rid = r->rid; h->score = r->score; h->truesc = r->truesc; h->sub = r->sub;
 	h->alt_sc = r->alt_sc; h->csub = r->csub; h->sub_n = r->sub_n; h->w = r->w; h->seedcov = r->seedcov; h->secondary = r->secondary;
 	h->secondary_all = r->secondary_all; h->seedlen0 = r->seedlen0; h->n_comp = r->n_comp; h->is_alt = r->is_alt; h->hash = r->hash;
-	h->bss = r->bss; h->parent = r->parent;
+	h->bss = r->bss; h->parent = r->parent; h->flag = r->flag; h->mapq = (int32_t)r->mapq; h->frac_rep = r->frac_rep;
 }
 #endif

@@ -125,3 +125,32 @@ BSX_API void bsx_hook_pair(const bsx_opt_t *opt, const bsx_index_t *idx, const b
 	out[3] = z[0]; out[4] = z[1];
 	free(pair[0].a); free(pair[1].a);
 }
+
+/* mem_reg2sam_pe up to the text: the planning pass of the pipeline on one pair.  The region records come back as the decision left
+ * them (flag, mapq, sub, secondary, secondary_all); trace[k] = the k-th record that would be written (see samctx_t); returns their number */
+#include "pipeline.h"
+BSX_API int bsx_hook_reg2sam_pe_plan(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_pestat_t *pes, uint64_t id, const int l_seq[2],
+                                     bsx_hook_reg_t *a0, int n0, int n_pri0, bsx_hook_reg_t *a1, int n1, int n_pri1, int (*trace)[6], int m_trace)
+{
+	reg_v pair[2];
+	bsx_read_t s[2];
+	samctx_t ctx;
+	bsx_hook_reg_t *a[2] = {a0, a1};
+	int i, k, n[2] = {n0, n1};
+	char name[] = "r";
+	memset(s, 0, sizeof(s)); memset(&ctx, 0, sizeof(ctx));
+	hook_vec(a0, n0, n_pri0, &pair[0]);
+	hook_vec(a1, n1, n_pri1, &pair[1]);
+	for (i = 0; i < 2; ++i) {
+		s[i].l_seq = s[i].l_seq0 = l_seq[i]; s[i].name = name;
+		for (k = 0; k < n[i]; ++k) pair[i].a[k].hash = (uint64_t)k;   /* lets the trace name a mate's region */
+	}
+	ctx.plan = 1; ctx.trace = trace; ctx.m_trace = m_trace;
+	bsx_reg2sam_pe(opt, idx, id, s, pair, pes, &ctx, 0);
+	for (i = 0; i < 2; ++i) {
+		for (k = 0; k < n[i]; ++k) bsx_hook_from_reg(&pair[i].a[k], &a[i][k]);
+		free(pair[i].a);
+		bsx_cvec_free(ctx.want[i]);
+	}
+	return ctx.n_trace;
+}

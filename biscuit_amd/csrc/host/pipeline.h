@@ -43,6 +43,10 @@ typedef struct {
 	int plan;
 	BSX_VEC(int) want[2];     /* region indices per read of the pair (or [0] for SE) */
 	samrec_t *table[2];       /* per region, filled between plan and final pass */
+	/* tests: with trace != NULL the planning pass notes every record it would write: read of the pair, index of the region in its
+	 * list (-1: the unmapped stand-in), index of the mate's region (-1: unmapped stand-in, -2: none), flag and mapq of the region
+	 * at that moment, is_primary */
+	int (*trace)[6]; int n_trace, m_trace;
 } samctx_t;
 
 void bsx_reg2sam_se(const bsx_opt_t *opt, const bsx_index_t *idx, bsx_read_t *s, reg_v *regs, samctx_t *ctx, const char *rg_id);

@@ -294,6 +294,13 @@ static void format_sam(drv_t *D, int which, sbuf_t *str, bsx_read_t *s, const re
 	reg_t p = *p0, m;
 	int i;
 	if (D->ctx->plan) { /* planning only needs the side effects on CIGAR availability */
+		if (D->ctx->trace && D->ctx->n_trace < D->ctx->m_trace) {
+			int *t = D->ctx->trace[D->ctx->n_trace++];
+			t[0] = which;
+			t[1] = regs0 && p0 >= regs0->a && p0 < regs0->a + regs0->n ? (int)(p0 - regs0->a) : -1;
+			t[2] = !m0 ? -2 : m0->rid < 0 ? -1 : (int)m0->hash;   /* the hook numbers the mate's regions in `hash` */
+			t[3] = p0->flag; t[4] = (int)p0->mapq; t[5] = is_primary;
+		}
 		if (regs0) tag_XAXB(D, which, s, p0, regs0, str);
 		return;
 	}

@@ -5,6 +5,8 @@ source lines (not from csrc/host/region.c) in plain Python for small cases:
 
     sort_dedup        mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment   lib/aln/mem_alnreg.c:63-202
     matesw            mem_alnreg_matesw + mem_alnreg_matesw_core (SW by the real ksw_align2)   lib/aln/mem_alnreg.c:385-513
+    reg2sam_pe        mem_reg2sam_pe, mem_reg2sam_pe_nopairing, mem_alnreg_select_format up to the text (which records are written,
+                      with which flag / mapq / mate; mem_approx_mapq_se is the real function)          lib/aln/mem_alnreg_format.c:445-696
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
     pestat            cal_sub + mem_pestat                             lib/aln/mem_pair.c:41-146
     pair              mem_pair                                         lib/aln/mem_pair.c:149-270
@@ -363,3 +365,105 @@ def matesw(opt, l_pac, anns, get_base, pes, seqs, regs_pair, ksw_align2, klib_or
     for i in range(2):
         for j in range(min(len(good[i]), opt["max_matesw"])):
             _matesw_core(opt, l_pac, anns, get_base, pes, good[i][j], seqs[1 - i], regs_pair[1 - i], ksw_align2, klib_order)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+MEM_F_NOPAIRING, MEM_F_ALL, MEM_F_NO_MULTI, MEM_F_KEEP_SUPP_MAPQ = 0x4, 0x8, 0x10, 0x1000   # lib/aln/bwamem.h:42-52
+
+
+def _select_format(opt, regs, mapq_se, trace_setsam):   # mem_alnreg_select_format, mem_alnreg_format.c:445-488
+    out = []
+    for k, p in enumerate(regs):
+        if p["rb"] < 0 or p["re"] < 0:
+            continue
+        if p["score"] < opt["T"]:
+            continue
+        if p["secondary"] >= 0 and (p["is_alt"] or not (opt["flag"] & MEM_F_ALL)):
+            continue
+        if p["secondary"] >= 0 and p["secondary"] < INT_MAX and f32(float(p["score"])) < f32(f32(float(regs[p["secondary"]]["score"])) * f32(opt["drop_ratio"])):
+            continue
+        if out and p["secondary"] < 0:
+            p["flag"] |= 0x10000 if opt["flag"] & MEM_F_NO_MULTI else 0x800
+        if p["secondary"] >= 0:
+            p["flag"] |= 0x100
+        p["mapq"] = mapq_se(p) if p["secondary"] < 0 else 0
+        if not (opt["flag"] & MEM_F_KEEP_SUPP_MAPQ) and out and not p["is_alt"]:
+            p["mapq"] = min(p["mapq"], regs[0]["mapq"])
+        out.append(k)
+    return out
+
+
+def _nopairing(opt, regs_pair, mapq_se, trace):   # mem_reg2sam_pe_nopairing, mem_alnreg_format.c:519-559
+    sel = [_select_format(opt, regs_pair[i], mapq_se, None) for i in range(2)]
+    best = [sel[i][0] if sel[i] else -1 for i in range(2)]           # -1: the unmapped stand-in (flag 0x40<<i | 0x1 | 0x4)
+    for i in range(2):
+        if sel[i]:
+            for j, k in enumerate(sel[i]):
+                p = regs_pair[i][k]
+                trace.append((i, k, best[1 - i], p["flag"], p["mapq"], int(j == 0)))
+        else:
+            trace.append((i, -1, best[1 - i], 0x40 << i | 0x1 | 0x4, 0, 1))
+
+
+def raw_mapq(diff, a):
+    return int(6.02 * diff / a + .499)
+
+
+def reg2sam_pe(opt, l_pac, ann_offset, pes, rid, regs_pair, n_pri, mapq_se):   # mem_reg2sam_pe, mem_alnreg_format.c:562-696 -> the records written
+    trace = []
+    for i in range(2):
+        for p in regs_pair[i]:
+            p["flag"] |= (0x40 << i) | 1
+    if opt["flag"] & MEM_F_NOPAIRING or n_pri[0] == 0 or n_pri[1] == 0:
+        _nopairing(opt, regs_pair, mapq_se, trace)
+        return trace
+    for i in range(2):
+        for j in range(1, n_pri[i]):
+            if regs_pair[i][j]["secondary"] < 0 and regs_pair[i][j]["score"] >= opt["T"]:
+                _nopairing(opt, regs_pair, mapq_se, trace)
+                return trace
+    pscore, sub_pscore, n_sub, z0, z1 = pair(opt, l_pac, ann_offset, pes, regs_pair, n_pri, rid)
+    z = [z0, z1]
+    if pscore <= 0:
+        _nopairing(opt, regs_pair, mapq_se, trace)
+        return trace
+    score_unpaired = regs_pair[0][0]["score"] + regs_pair[1][0]["score"] - opt["pen_unpaired"]
+    if pscore > score_unpaired:
+        sub_pscore = max(sub_pscore, score_unpaired)
+        q_pe = raw_mapq(pscore - sub_pscore, opt["a"])
+        if n_sub > 0:
+            q_pe -= int(4.343 * math.log(n_sub + 1) + .499)
+        q_pe = max(0, min(60, q_pe))
+        q_pe = int(q_pe * (1. - .5 * f32(regs_pair[0][0]["frac_rep"] + regs_pair[1][0]["frac_rep"])) + .499)   # float + float, then double
+        c = [regs_pair[0][z[0]], regs_pair[1][z[1]]]
+        q_se = [0, 0]
+        for i in range(2):
+            if c[i]["secondary"] >= 0:
+                c[i]["sub"] = regs_pair[i][c[i]["secondary"]]["score"]
+                c[i]["secondary"] = -2
+            q_se[i] = mapq_se(c[i])
+        for i in range(2):
+            q_se[i] = max(q_se[i], min(q_pe, q_se[i] + 40))
+            c[i]["mapq"] = min(q_se[i], raw_mapq(c[i]["score"] - c[i]["csub"], opt["a"]))
+    else:
+        z = [0, 0]
+        for i in range(2):
+            regs_pair[i][0]["mapq"] = mapq_se(regs_pair[i][0])
+    for i in range(2):
+        regs = regs_pair[i]
+        k = regs[z[i]]["secondary_all"]
+        if 0 <= k < n_pri[i]:
+            for j, r in enumerate(regs):
+                if r["secondary_all"] == k or j == k:
+                    r["secondary_all"] = z[i]
+            regs[z[i]]["secondary_all"] = -1
+    for i in range(2):
+        regs = regs_pair[i]
+        p = regs[z[i]]
+        trace.append((i, z[i], z[1 - i], p["flag"], p["mapq"], 1))
+        if n_pri[i] < len(regs):
+            q = regs[n_pri[i]]
+            if q["score"] >= opt["T"] and q["secondary"] < 0:
+                q["flag"] |= 0x800
+                trace.append((i, n_pri[i], -2, q["flag"], q["mapq"], 0))
+    return trace

@@ -19,7 +19,7 @@ import backhalf  # noqa: E402
 class HookReg(C.Structure):
     _fields_ = [("rb", C.c_int64), ("re", C.c_int64)] + [(k, C.c_int32) for k in
                 ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] + \
-               [("hash", C.c_uint64), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 6)]
+               [("hash", C.c_uint64), ("flag", C.c_int32), ("mapq", C.c_int32), ("frac_rep", C.c_float), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 2)]
 
 
 KEYS = ("rb", "re", "qb", "qe", "rid", "score", "is_alt", "bss")
@@ -30,8 +30,9 @@ def to_c(regs):
     for k, r in enumerate(regs):
         for f in KEYS:
             setattr(a[k], f, int(r[f]))
-        for f in ("sub", "sub_n", "alt_sc", "secondary", "secondary_all"):
+        for f in ("sub", "sub_n", "alt_sc", "secondary", "secondary_all", "csub", "seedcov", "flag", "mapq"):
             setattr(a[k], f, int(r.get(f, 0)))
+        a[k].frac_rep = float(r.get("frac_rep", 0.0))
     return a
 
 
@@ -346,3 +347,61 @@ def test_mate_rescue(small):
         rescued += len(pr[0]) + len(pr[1]) > sum(before)
         unchanged += len(pr[0]) + len(pr[1]) == sum(before)
     assert rescued > 0.3 * n_pairs and unchanged > 0.1 * n_pairs, (rescued, unchanged)
+
+
+def test_reg2sam_pe_decisions(small):
+    """mem_reg2sam_pe / _nopairing / mem_alnreg_select_format up to the text: which records a pair gets, each with its flag, MAPQ and
+    mate, and the state the regions are left in.  Product: the planning pass of sam.c with its trace sink; restatement: oracle/backhalf.py
+    with the REAL mem_approx_mapq_se (oracle/_ref)."""
+    from oracle_lib import ref_lib
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is not built")
+    idx, offs, lens = small
+    L = B.lib()
+    l_pac = idx.l_pac
+    R.ref_approx_mapq_se.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_int] * 6 + [C.c_int64, C.c_int64, C.c_int, C.c_float]
+    L.bsx_hook_reg2sam_pe_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(77)
+    n_paired = n_nopair = n_alt = n_switch = 0
+    for variant, extra_flag in enumerate((0, 0x10, 0x8 | 0x10, 0x4)):      # defaults, NO_MULTI (the CLI's), ALL, NOPAIRING
+        opt = default_opt()
+        opt.flag |= 0x2 | extra_flag
+        od = dict(opt_dict(opt), T=opt.T, flag=opt.flag, drop_ratio=opt.drop_ratio, pen_unpaired=opt.pen_unpaired)
+
+        def mapq_se(p):
+            return R.ref_approx_mapq_se(opt.a, opt.b, opt.min_seed_len, opt.mapQ_coef_len, opt.mapQ_coef_fac, p["score"], p["sub"], p["csub"], p["sub_n"],
+                                        p["qb"], p["qe"], p["rb"], p["re"], p["seedcov"], p["frac_rep"])
+        reads = _pairs(rng, 1200, l_pac, offs, lens)
+        pes_d = backhalf.pestat(od, l_pac, reads)
+        pes = B.PeStat(low=pes_d["low"], high=pes_d["high"], set=1, failed=0, avg=pes_d["avg"], std=pes_d["std"])
+        for i in range(len(reads) >> 1):
+            pr = []
+            for w in range(2):
+                lst = [dict(r, sub_n=0, csub=int(rng.integers(0, 60)) if rng.random() < 0.3 else 0, seedcov=int(rng.integers(20, 120)),
+                            frac_rep=backhalf.f32(float(rng.random()) * 0.5) if rng.random() < 0.3 else 0.0, flag=0, mapq=0) for r in reads[2 * i + w]]
+                if lst and rng.random() < 0.25:       # a competing hit close to the best one
+                    lst.append(dict(lst[0], rb=lst[0]["rb"] + 5, re=lst[0]["re"] + 5, score=max(20, lst[0]["score"] - int(rng.integers(0, 15)))))
+                if lst and rng.random() < 0.15:       # a hit on an ALT contig
+                    lst.append(dict(lst[0], rb=int(rng.integers(0, l_pac - 400)), is_alt=1, score=int(rng.integers(25, 151))))
+                    lst[-1]["re"] = lst[-1]["rb"] + 150
+                pr.append(lst)
+            npri = [backhalf.mark_primary_se(od, pr[w], 2 * i + w) for w in range(2)]
+            a0, a1 = to_c(pr[0]), to_c(pr[1])
+            trace = ((C.c_int * 6) * 64)()
+            lens2 = (C.c_int * 2)(150, 150)
+            nt = L.bsx_hook_reg2sam_pe_plan(C.byref(opt), idx.h, C.byref(pes), i, lens2, a0, len(pr[0]), npri[0], a1, len(pr[1]), npri[1], trace, 64)
+            want = backhalf.reg2sam_pe(od, l_pac, offs, pes_d, i, pr, npri, mapq_se)
+            got = [tuple(trace[k]) for k in range(nt)]
+            assert got == want, (variant, i, got, want)
+            for w, a in enumerate((a0, a1)):
+                for k, r in enumerate(pr[w]):
+                    g2 = tuple(getattr(a[k], f) for f in ("flag", "mapq", "sub", "secondary", "secondary_all"))
+                    w2 = tuple(r[f] for f in ("flag", "mapq", "sub", "secondary", "secondary_all"))
+                    assert g2 == w2, (variant, i, w, k, g2, w2)
+            paired = len(want) >= 2 and want[0][2] >= 0 and want[0][5] == 1 and all(t[1] >= 0 for t in want[:2]) and len([t for t in want if t[0] == 0]) <= 2
+            n_paired += paired
+            n_nopair += not paired
+            n_alt += any(t[2] == -2 for t in want)
+            n_switch += any(r["secondary"] == -2 for lst in pr for r in lst)
+    assert n_paired > 1500 and n_nopair > 200 and n_alt > 20 and n_switch > 5, (n_paired, n_nopair, n_alt, n_switch)
