@@ -545,3 +545,32 @@ void bsx_reg2sam_pe(const bsx_opt_t *opt, const bsx_index_t *idx, uint64_t id, b
 		if (!ctx->plan) s[i].sam = str.s; else free(str.s);
 	}
 }
+
+/* test hook: mem_alnreg_formatSAM of one record (regions given with their SAM side filled in); p_idx names the record's region in
+ * regs0 when regs0 is given (the XA/XB/SA tags look at the list), m may be NULL; returns the length written to buf (cap bytes) */
+#include "hook_types.h"
+BSX_API int bsx_hook_format_sam(const bsx_opt_t *opt, const bsx_index_t *idx, bsx_read_t *s, const bsx_hook_reg_t *p, const bsx_hook_reg_t *m,
+                                const bsx_hook_reg_t *regs0, int n_regs0, int p_idx, int is_primary, const bsx_pestat_t *pes, const char *rg_id,
+                                char *buf, int cap)
+{
+	samctx_t ctx;
+	drv_t D;
+	reg_t P, M;
+	reg_v v;
+	sbuf_t str = {0, 0, 0};
+	int k, l;
+	memset(&ctx, 0, sizeof(ctx)); memset(&v, 0, sizeof(v));
+	D.opt = opt; D.idx = idx; D.ctx = &ctx; D.rg_id = rg_id;
+	if (regs0) {
+		v.n = v.m = (size_t)n_regs0;
+		v.a = (reg_t*)calloc(n_regs0 ? n_regs0 : 1, sizeof(reg_t));
+		for (k = 0; k < n_regs0; ++k) bsx_hook_to_reg(&regs0[k], &v.a[k]);
+	}
+	bsx_hook_to_reg(p, &P);
+	if (m) bsx_hook_to_reg(m, &M);
+	format_sam(&D, 0, &str, s, regs0 && p_idx >= 0 ? &v.a[p_idx] : &P, m ? &M : 0, regs0 ? &v : 0, is_primary, pes);
+	l = (int)str.l;
+	if (l < cap) memcpy(buf, str.s, (size_t)l + 1); else l = -l;
+	free(str.s); free(v.a);
+	return l;
+}

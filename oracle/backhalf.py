@@ -5,6 +5,7 @@ source lines (not from csrc/host/region.c) in plain Python for small cases:
 
     sort_dedup        mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment   lib/aln/mem_alnreg.c:63-202
     matesw            mem_alnreg_matesw + mem_alnreg_matesw_core (SW by the real ksw_align2)   lib/aln/mem_alnreg.c:385-513
+    format_sam        mem_alnreg_formatSAM with mem_alnreg_tagSA and mem_alnreg_tagXAXB: one SAM line     lib/aln/mem_alnreg_format.c:126-436
     reg2sam_pe        mem_reg2sam_pe, mem_reg2sam_pe_nopairing, mem_alnreg_select_format up to the text (which records are written,
                       with which flag / mapq / mate; mem_approx_mapq_se is the real function)          lib/aln/mem_alnreg_format.c:445-696
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
@@ -467,3 +468,153 @@ def reg2sam_pe(opt, l_pac, ann_offset, pes, rid, regs_pair, n_pri, mapq_se):   #
                 q["flag"] |= 0x800
                 trace.append((i, n_pri[i], -2, q["flag"], q["mapq"], 0))
     return trace
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+MEM_F_REF_HDR, MEM_F_SOFTCLIP = 0x100, 0x200
+
+
+def get_rlen(cigar):   # bwamem.h:200-208
+    return sum(c >> 4 for c in cigar if (c & 0xf) in (0, 2))
+
+
+def _cigar_text(opt, r, is_primary, alphabet="MIDSH"):   # the clip letter depends on the record (mem_alnreg_format.c:281-287)
+    out = []
+    for c in r["cigar"]:
+        op = c & 0xf
+        if not (opt["flag"] & MEM_F_SOFTCLIP) and not r["is_alt"] and op in (3, 4):
+            op = 3 if is_primary else 4
+        out.append("%d%s" % (c >> 4, alphabet[op]))
+    return "".join(out)
+
+
+def _pri_idx(opt, regs, i):   # get_pri_idx, mem_alnreg.h:127-131: int >= int * double
+    k = regs[i]["secondary_all"]
+    if k >= 0 and regs[i]["score"] >= regs[k]["score"] * float(f32(opt["XA_drop_ratio"])):
+        return k
+    return -1
+
+
+def _tag_sa(names, p_idx, regs0):   # mem_alnreg_format.c:194-228
+    if regs0 is None or regs0[p_idx]["flag"] & 0x100:
+        return ""
+    out = ""
+    for i, q in enumerate(regs0):
+        if i == p_idx or not q["cigar"] or q["flag"] & 0x100:
+            continue
+        out += "%s,%d,%s,%s,%d,%d;" % (names[q["rid"]], q["pos"] + 1, "+-"[q["is_rev"]], "".join("%d%s" % (c >> 4, "MIDSH"[c & 0xf]) for c in q["cigar"]), q["mapq"], q["NM"])
+    return "\tSA:Z:" + out if out else ""
+
+
+def _tag_xaxb(opt, names, p_idx, regs0):   # mem_alnreg_format.c:126-191
+    if regs0 is None or opt["flag"] & MEM_F_ALL:
+        return ""
+    mine = [i for i in range(len(regs0)) if _pri_idx(opt, regs0, i) == p_idx]
+    cnt_alt = sum(1 for i in mine if regs0[i]["is_alt"])
+    cnt_pri = len(mine) - cnt_alt
+    out = ""
+    if cnt_pri <= opt["max_XA_hits"] and cnt_alt <= opt["max_XA_hits_alt"]:
+        parts = []
+        for i in mine:
+            q = regs0[i]
+            if not q["cigar"]:
+                continue
+            parts.append("%s,%s%d,%s,%d" % (names[q["rid"]], "+-"[q["is_rev"]], q["pos"] + 1, "".join("%d%s" % (c >> 4, "MIDSHN"[c & 0xf]) for c in q["cigar"]), q["NM"]))
+        if parts:
+            out += "\tXA:Z:" + ";".join(parts)
+    if cnt_pri > 0 or cnt_alt > 0:
+        out += "\tXB:Z:%d,%d" % (cnt_pri, cnt_alt)
+    return out
+
+
+def format_sam(opt, l_pac, names, annos, s, p0, m0, regs0, p_idx, is_primary, pes, rg_id):   # mem_alnreg_format.c:237-436 -> one line
+    """s: the read (name comment seq0 qual l_seq barcode umi); p0 / m0 / regs0[*]: regions with their SAM side (pos is_rev cigar md NM ZC ZR
+    bss_u mapq flag ...); m0 may be None; regs0 None or the read's list with p0 = regs0[p_idx]"""
+    p = dict(p0)
+    m = dict(m0) if m0 is not None else {"rid": 0, "pos": 0, "is_rev": 0, "cigar": [], "mapq": 0, "flag": 0, "is_alt": 0, "bss_u": 0}
+    has_m = m0 is not None
+    if has_m:
+        p["flag"] |= 0x1
+        if m["rid"] < 0:
+            p["flag"] |= 0x8
+        if m0["bss_u"] == 0:
+            p["bss_u"] = 0
+    if p["rid"] >= 0 and has_m and m["rid"] >= 0 and pes is not None:
+        ins = alnreg_isize(l_pac, p, m)
+        if ins is not None and pes["low"] <= ins <= pes["high"]:
+            p["flag"] |= 2
+    if p["rid"] < 0 and has_m and m["rid"] >= 0:
+        p.update(rid=m["rid"], pos=m["pos"], is_rev=m["is_rev"], cigar=[])
+    if has_m and m["rid"] < 0 and p["rid"] >= 0:
+        m.update(rid=p["rid"], pos=p["pos"], is_rev=p["is_rev"], cigar=[])
+    if has_m and m["is_rev"]:
+        p["flag"] |= 0x20
+    f = [s["name"] + ("_" + s["comment"] if s.get("comment") else ""), str((p["flag"] & 0xffff) | (0x100 if p["flag"] & 0x10000 else 0))]
+    if p["rid"] >= 0:
+        f += [names[p["rid"]], str(p["pos"] + 1), str(p["mapq"]), _cigar_text(opt, p, is_primary) if p["cigar"] else "*"]
+    else:
+        f += ["*", "0", "0", "*"]
+    if has_m and m["rid"] >= 0:
+        f += ["=" if p["rid"] == m["rid"] else names[m["rid"]], str(m["pos"] + 1)]
+        tlen = "0"
+        if p["rid"] == m["rid"]:
+            q0 = q1 = -1
+            if p["is_rev"]:
+                q1 = p["pos"] + get_rlen(p["cigar"]) - 1
+            else:
+                q0 = p["pos"]
+            if m["is_rev"]:
+                q1 = m["pos"] + get_rlen(m["cigar"]) - 1
+            else:
+                q0 = m["pos"]
+            if p["cigar"] and m["cigar"] and q0 >= 0 and q1 >= 0:
+                tlen = str(q1 - q0 + 1)
+        f.append(tlen)
+    else:
+        f += ["*", "0", "0"]
+    if p["flag"] & 0x100:
+        f += ["*", "*"]
+    else:
+        qb, qe = 0, len(s["seq0"])
+        if p["cigar"] and not is_primary and not (opt["flag"] & MEM_F_SOFTCLIP) and not p["is_alt"]:
+            c0, c1 = p["cigar"][0], p["cigar"][-1]
+            if p["is_rev"]:
+                if (c0 & 0xf) in (3, 4):
+                    qe -= c0 >> 4
+                if (c1 & 0xf) in (3, 4):
+                    qb += c1 >> 4
+            else:
+                if (c0 & 0xf) in (3, 4):
+                    qb += c0 >> 4
+                if (c1 & 0xf) in (3, 4):
+                    qe -= c1 >> 4
+        if p["is_rev"]:
+            f.append("".join("TGCAN"[s["seq0"][i]] for i in range(qe - 1, qb - 1, -1)))
+            f.append(s["qual"][qb:qe][::-1] if s.get("qual") else "*")
+        else:
+            f.append("".join("ACGTN"[s["seq0"][i]] for i in range(qb, qe)))
+            f.append(s["qual"][qb:qe] if s.get("qual") else "*")
+    line = "\t".join(f)
+    if p["cigar"]:
+        line += "\tNM:i:%d\tMD:Z:%s\tZC:i:%d\tZR:i:%d" % (p["NM"], p["md"], p["ZC"], p["ZR"])
+    if p["score"] >= 0:
+        line += "\tAS:i:%d" % p["score"]
+    if p["sub"] >= 0:
+        line += "\tXS:i:%d" % max(p["sub"], p["csub"])
+    if rg_id:
+        line += "\tRG:Z:" + rg_id
+    line += _tag_sa(names, p_idx, regs0) if regs0 is not None else ""
+    if is_primary and p["alt_sc"] > 0:
+        line += "\tPA:f:%.3f" % (p["score"] / p["alt_sc"])
+    line += "\tXL:i:%d" % s["l_seq"]
+    line += _tag_xaxb(opt, names, p_idx, regs0) if regs0 is not None else ""
+    if opt["flag"] & MEM_F_REF_HDR and p["rid"] >= 0 and annos[p["rid"]]:
+        line += "\tXR:Z:" + annos[p["rid"]].replace("\t", " ")
+    if s.get("barcode"):
+        line += "\tCB:Z:" + s["barcode"]
+    if s.get("umi"):
+        line += "\tRX:Z:" + s["umi"]
+    line += "\tMC:Z:" + (_cigar_text(opt, m, is_primary) if m["cigar"] else "*")
+    line += "\tMQ:i:%d" % m["mapq"]
+    line += "\tYD:A:" + ("u" if p["bss_u"] else "fr"[p["bss"]])
+    return line + "\n"

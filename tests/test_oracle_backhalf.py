@@ -19,7 +19,9 @@ import backhalf  # noqa: E402
 class HookReg(C.Structure):
     _fields_ = [("rb", C.c_int64), ("re", C.c_int64)] + [(k, C.c_int32) for k in
                 ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] + \
-               [("hash", C.c_uint64), ("flag", C.c_int32), ("mapq", C.c_int32), ("frac_rep", C.c_float), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 2)]
+               [("hash", C.c_uint64), ("flag", C.c_int32), ("mapq", C.c_int32), ("frac_rep", C.c_float), ("bss", C.c_uint8), ("parent", C.c_uint8), ("pad", C.c_uint8 * 2),
+                ("pos", C.c_int32), ("n_cigar", C.c_int32), ("NM", C.c_int32), ("bss_u", C.c_int32), ("is_rev", C.c_uint32), ("ZC", C.c_uint32), ("ZR", C.c_uint32),
+                ("pad2", C.c_uint32), ("cigar", C.c_void_p)]
 
 
 KEYS = ("rb", "re", "qb", "qe", "rid", "score", "is_alt", "bss")
@@ -405,3 +407,130 @@ def test_reg2sam_pe_decisions(small):
             n_alt += any(t[2] == -2 for t in want)
             n_switch += any(r["secondary"] == -2 for lst in pr for r in lst)
     assert n_paired > 1500 and n_nopair > 200 and n_alt > 20 and n_switch > 5, (n_paired, n_nopair, n_alt, n_switch)
+
+
+def test_format_sam(small):
+    """mem_alnreg_formatSAM with its SA / XA / XB tags: one SAM line of sam.c against the restatement's, field by field of a record
+    built at random (clips, indels, secondary / supplementary / unmapped records, mapped / unmapped / absent mates, ALT hits, read
+    comments, barcodes, hard and soft clipping, -M)."""
+    idx, offs, lens = small
+    L = B.lib()
+    l_pac = idx.l_pac
+    L.bsx_index_contig.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    names = []
+    for i in range(3):
+        nm, off, ln = C.c_char_p(), C.c_int64(), C.c_int64()
+        L.bsx_index_contig(idx.h, i, C.byref(nm), C.byref(off), C.byref(ln))
+        names.append(nm.value.decode())
+    L.bsx_hook_format_sam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(99)
+    keep = []
+
+    def rand_cigar(qlen):
+        ops = []
+        c5, c3 = (int(rng.integers(1, 20)) if rng.random() < 0.3 else 0), (int(rng.integers(1, 20)) if rng.random() < 0.3 else 0)
+        body = qlen - c5 - c3
+        if c5:
+            ops.append(c5 << 4 | 3)
+        if rng.random() < 0.3 and body > 40:
+            a = int(rng.integers(10, body - 20))
+            ops += [a << 4, int(rng.integers(1, 5)) << 4 | int(rng.integers(1, 3)), (body - a) << 4]
+        else:
+            ops.append(body << 4)
+        if c3:
+            ops.append(c3 << 4 | 3)
+        return ops
+
+    def rand_reg(mapped=True):
+        rb = int(rng.integers(0, 2 * l_pac - 400))
+        r = {"rb": rb, "re": rb + 150, "qb": 0, "qe": 150, "rid": int(rng.integers(0, 3)) if mapped else -1, "score": int(rng.integers(30, 151)),
+             "sub": int(rng.integers(0, 100)) if rng.random() < 0.7 else 0, "csub": int(rng.integers(0, 80)) if rng.random() < 0.3 else 0,
+             "alt_sc": int(rng.integers(20, 150)) if rng.random() < 0.2 else 0, "is_alt": int(rng.random() < 0.15), "bss": int(rng.integers(0, 2)),
+             "secondary": -1, "secondary_all": -1, "flag": 0x41 if rng.random() < 0.5 else 0x81, "mapq": int(rng.integers(0, 61)),
+             "pos": int(rng.integers(0, 100000)), "is_rev": int(rng.integers(0, 2)), "NM": int(rng.integers(0, 6)), "ZC": int(rng.integers(0, 40)),
+             "ZR": int(rng.integers(0, 10)), "bss_u": int(rng.random() < 0.2)}
+        r["cigar"] = rand_cigar(150) if mapped and rng.random() < 0.9 else []
+        r["md"] = "%dA%d" % (int(rng.integers(0, 70)), int(rng.integers(0, 70))) if r["cigar"] else ""
+        if not mapped:
+            r.update(flag=0x40 | 0x1 | 0x4, score=0, sub=0, mapq=0, pos=0, is_rev=0)
+        return r
+
+    def c_reg(r):
+        h = HookReg()
+        for f in ("rb", "re", "qb", "qe", "rid", "score", "sub", "csub", "alt_sc", "is_alt", "bss", "secondary", "secondary_all", "flag", "mapq", "pos", "is_rev",
+                  "NM", "ZC", "ZR", "bss_u"):
+            setattr(h, f, int(r[f]))
+        h.n_cigar = len(r["cigar"])
+        if r["cigar"]:
+            md = r["md"].encode() + b"\0"
+            buf = (C.c_uint8 * (4 * len(r["cigar"]) + len(md) + 8))()
+            C.memmove(buf, np.array(r["cigar"], dtype=np.uint32).tobytes(), 4 * len(r["cigar"]))
+            C.memmove(C.addressof(buf) + 4 * len(r["cigar"]), md, len(md))
+            keep.append(buf)
+            h.cigar = C.addressof(buf)
+        return h
+    n_lines = n_xa = n_sa = 0
+    for trial in range(3000):
+        opt = default_opt()
+        opt.flag |= 0x2 | (0x200 if trial % 5 == 0 else 0) | (0x8 if trial % 7 == 0 else 0) | (0x10 if trial % 2 else 0)
+        opt.max_XA_hits = 2 if trial % 11 == 0 else opt.max_XA_hits
+        od = {"flag": opt.flag, "XA_drop_ratio": opt.XA_drop_ratio, "max_XA_hits": opt.max_XA_hits, "max_XA_hits_alt": opt.max_XA_hits_alt}
+        seq0 = rng.integers(0, 5, size=150).astype(np.uint8)
+        qual = "".join(chr(int(x)) for x in rng.integers(35, 74, size=150)) if rng.random() < 0.8 else None
+        s = {"name": "read%d" % trial, "comment": "c1" if rng.random() < 0.2 else None, "seq0": [int(x) for x in seq0], "qual": qual, "l_seq": int(rng.integers(120, 151)),
+             "barcode": "ACGT" if rng.random() < 0.1 else None, "umi": "TTAA" if rng.random() < 0.1 else None}
+        rd = B.Read()
+        sbuf = (C.c_uint8 * 150)(*s["seq0"])
+        keep.append(sbuf)
+        rd.l_seq, rd.l_seq0, rd.name = s["l_seq"], 150, s["name"].encode()
+        rd.comment = s["comment"].encode() if s["comment"] else None
+        rd.qual = qual.encode() if qual else None
+        rd.barcode = s["barcode"].encode() if s["barcode"] else None
+        rd.umi = s["umi"].encode() if s["umi"] else None
+        rd.seq0 = C.cast(sbuf, C.POINTER(C.c_uint8))
+        rd.seq = rd.seq0
+        regs = [rand_reg() for _ in range(int(rng.integers(1, 5)))]
+        for r in regs:     # every region of the list has its CIGAR: the tags of a final pass only read them (the planning pass asked for them)
+            if not r["cigar"]:
+                r["cigar"], r["md"] = rand_cigar(150), "150"
+        p_idx = int(rng.integers(0, len(regs)))
+        for i, r in enumerate(regs):
+            if i != p_idx and rng.random() < 0.6:       # a secondary of the record's region, near its score or not
+                r["secondary"] = r["secondary_all"] = p_idx
+                r["score"] = max(20, regs[p_idx]["score"] - int(rng.integers(0, 60)))
+                if rng.random() < 0.5:
+                    r["flag"] |= 0x100
+            elif i != p_idx and rng.random() < 0.5:
+                r["flag"] |= 0x800 if rng.random() < 0.5 else 0x10000
+        use_list = rng.random() < 0.8
+        u = rng.random()
+        if u < 0.1 and not use_list:
+            p0 = rand_reg(mapped=False)
+        else:
+            p0 = regs[p_idx]
+            if rng.random() < 0.15:
+                p0["flag"] |= 0x100
+        m0 = None if rng.random() < 0.15 else rand_reg(mapped=rng.random() < 0.85)
+        if m0 is not None and rng.random() < 0.5 and p0["rid"] >= 0 and m0["rid"] >= 0:   # a plausible mate: same contig, opposite strand, near
+            m0.update(rid=p0["rid"], rb=(2 * l_pac - p0["rb"] - int(rng.integers(150, 600))) % (2 * l_pac - 200), is_rev=1 - p0["is_rev"], pos=p0["pos"] + int(rng.integers(-400, 400)))
+            m0["re"] = m0["rb"] + 150
+        is_primary = int(rng.random() < 0.7)
+        pes_d = {"low": 100, "high": 700}
+        pes = B.PeStat(low=100, high=700, set=1, failed=0, avg=350.0, std=60.0)
+        rg = b"grp1" if rng.random() < 0.2 else None
+        want = backhalf.format_sam(od, l_pac, names, ["", "", ""], s, p0, m0, regs if use_list and p0 is regs[p_idx] else None, p_idx, is_primary, pes_d, rg.decode() if rg else None)
+        cregs = (HookReg * len(regs))(*[c_reg(r) for r in regs])
+        cp = c_reg(p0)
+        cm = c_reg(m0) if m0 is not None else None
+        buf = C.create_string_buffer(8192)
+        with_list = use_list and p0 is regs[p_idx]
+        n = L.bsx_hook_format_sam(C.byref(opt), idx.h, C.byref(rd), C.byref(cp), C.byref(cm) if cm is not None else None, cregs if with_list else None,
+                                  len(regs), p_idx if with_list else -1, is_primary, C.byref(pes), rg, buf, 8192)
+        assert n > 0
+        got = buf.raw[:n].decode()
+        assert got == want, (trial, got, want)
+        n_lines += 1
+        n_xa += "XA:Z:" in want
+        n_sa += "SA:Z:" in want
+        del keep[:]
+    assert n_lines == 3000 and n_xa > 200 and n_sa > 200, (n_xa, n_sa)
