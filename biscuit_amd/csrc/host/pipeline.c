@@ -75,6 +75,17 @@ static int pair_names_ok(const char *n1, const char *n2)   /* check_paired_read_
 	return 0;
 }
 
+/* test hooks: read_clipping (bwamem.c:286-303) and check_paired_read_names (bwamem.c:210-216) as this file has them */
+BSX_API void bsx_hook_clip_read(const bsx_opt_t *opt, int l_seq, uint8_t *seq, char *qual, const uint8_t *adaptor, int l_adaptor, int out[5])
+{
+	bsx_read_t s;
+	memset(&s, 0, sizeof(s));
+	s.l_seq = l_seq; s.seq = seq; s.qual = qual;
+	clip_read(&s, adaptor, l_adaptor, opt);
+	out[0] = s.l_adaptor; out[1] = s.clip5; out[2] = s.clip3; out[3] = s.l_seq; out[4] = (int)(s.seq - s.seq0);
+}
+BSX_API int bsx_hook_pair_names_ok(const char *n1, const char *n2) { return pair_names_ok(n1, n2); }
+
 /* ------------------------------------------------------------------ chunk state */
 typedef struct {
 	const bsx_backend_t *be;

@@ -355,5 +355,40 @@ for names, lens, hl, pg in HDR_CASES:
 out["hdr_in"], out["hdr_in_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in hdr_in], np.uint8)
 out["hdr_out"], out["hdr_out_off"] = ragged([np.frombuffer(t.encode(), np.uint8) for t in hdr_out], np.uint8)
 
+# ---- read_clipping (bwamem.c:286-303, with read_identify_adaptor and clip_read_by_quality; static there: compiled through
+# oracle/ref_statics.c) and check_paired_read_names (bwamem.c:210-216; only names it accepts -- it exits on the others)
+R.ref_read_clipping.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+crng = np.random.default_rng(4242)
+clip_in, clip_out = [], []
+for k in range(400):
+    l = int(crng.integers(30, 160))
+    seq = crng.integers(0, 4, l).astype(np.uint8)
+    la = int(crng.integers(0, 25)) if k % 3 else 0
+    ad = crng.integers(0, 4, la).astype(np.uint8) if la else np.zeros(0, np.uint8)
+    u = crng.random()
+    if la and u < 0.3:          # the whole adaptor somewhere in the read
+        at = int(crng.integers(0, l - la + 1)); seq[at:at + la] = ad
+    elif la and u < 0.6:        # a prefix of it at the 3' end
+        pre = int(crng.integers(1, la + 1)); seq[l - pre:] = ad[:pre]
+    qual = None
+    if k % 4:
+        q = crng.integers(33 + 20, 33 + 41, l)
+        a5, a3 = int(crng.integers(0, 12)), int(crng.integers(0, 12))
+        q[:a5] = crng.integers(33, 33 + 12, a5); q[l - a3:] = crng.integers(33, 33 + 12, a3) if a3 else q[l:]
+        if k % 17 == 0:
+            q[:] = 33 + 2       # nothing passes the quality threshold
+        qual = bytes(int(x) for x in q)
+    c5, c3, mbq = int(crng.integers(0, 8)) if k % 5 == 0 else 0, int(crng.integers(0, 8)) if k % 7 == 0 else 0, int(crng.choice([0, 0, 10, 20]))
+    res = (C.c_int * 5)()
+    R.ref_read_clipping(l, seq.ctypes.data_as(C.c_void_p), qual, ad.ctypes.data_as(C.c_void_p) if la else None, la, c5, c3, mbq, res)
+    clip_in.append(np.concatenate([[l, la, c5, c3, mbq, 1 if qual else 0], seq, ad, np.frombuffer(qual, np.uint8) if qual else np.zeros(0, np.uint8)]).astype(np.int32))
+    clip_out.append(list(res))
+out["clip_in"], out["clip_in_off"] = ragged(clip_in, np.int32)
+out["clip_out"] = np.array(clip_out, np.int32)
+NAME_OK = [("r1", "r1"), ("read/1", "read/2"), ("x.1", "x.2"), ("a_b_c", "a_b_c"), ("q1", "q2"), ("frag.0001/1", "frag.0001/2")]
+for n1, n2 in NAME_OK:
+    R.ref_check_paired_read_names(n1.encode(), n2.encode())      # returns: accepted by the reference
+out["names_ok"] = np.frombuffer("\x1e".join("\x1f".join(p) for p in NAME_OK).encode(), np.uint8)
+
 np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
 print("wrote", os.path.join(HERE, "ref_vectors.npz"), os.path.getsize(os.path.join(HERE, "ref_vectors.npz")), "bytes")

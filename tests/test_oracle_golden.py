@@ -241,3 +241,36 @@ def test_sam_header_vs_reference(V, tmp_path):
         _libc_free(p)
         idx.close()
         assert got == want, (k, got[:200], want[:200])
+
+
+def test_read_clipping_vs_reference(V):
+    """D1: read_clipping (adaptor search, fixed clips, quality clipping; bwamem.c:258-303) -- 400 reads recorded from the reference's own
+    (static) functions, compiled through oracle/ref_statics.c; and the read-name rule of check_paired_read_names (bwamem.c:210-216)."""
+    L = B.lib()
+    L.bsx_hook_clip_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
+    ins = _ragged(V, "clip_in", "clip_in_off")
+    n_adapt = n_qual = 0
+    for rec, want in zip(ins, V["clip_out"]):
+        l, la, c5, c3, mbq, hasq = [int(x) for x in rec[:6]]
+        seq = np.ascontiguousarray(rec[6:6 + l].astype(np.uint8))
+        ad = np.ascontiguousarray(rec[6 + l:6 + l + la].astype(np.uint8))
+        qual = bytes(int(x) for x in rec[6 + l + la:6 + l + la + l]) if hasq else None
+        opt = default_opt()
+        opt.clip5, opt.clip3, opt.min_base_qual = c5, c3, mbq
+        out = (C.c_int * 5)()
+        L.bsx_hook_clip_read(C.byref(opt), l, seq.ctypes.data_as(C.c_void_p), qual, ad.ctypes.data_as(C.c_void_p) if la else None, la, out)
+        got, ref = list(out), [int(x) for x in want]
+        if ref[3] == 0:
+            # nothing of the read is left: the reference's second quality loop then looks at qual[-1] (bwamem.c:280-281, one byte before the
+            # string) and its clip3 depends on what lies there; the read is unmapped either way and clip3 is never printed.  Not compared.
+            got[2] = ref[2] = -1
+        assert got == ref, (l, la, c5, c3, mbq, list(out), list(want))
+        n_adapt += want[0] > 0
+        n_qual += want[1] > c5 or want[2] > c3 + want[0]
+    assert n_adapt > 100 and n_qual > 100
+    L.bsx_hook_pair_names_ok.argtypes = [C.c_char_p, C.c_char_p]
+    for pair in bytes(V["names_ok"]).decode().split("\x1e"):
+        n1, n2 = pair.split("\x1f")
+        assert L.bsx_hook_pair_names_ok(n1.encode(), n2.encode()) == 1
+    for n1, n2 in (("r1", "r3"), ("a/1", "b/2"), ("x2", "x1")):
+        assert L.bsx_hook_pair_names_ok(n1.encode(), n2.encode()) == 0
