@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Device regions vs host chaining on one bench-shaped chunk (tandem-repeat reads included): python tools/parity_big.py [genome_mbp] [seed] [families]"""
+"""Device path vs host chaining / host de-duplication on one bench-shaped chunk of 1 066 666 reads (tandem-repeat reads included), SAM compared
+by checksum: python tools/parity_big.py [genome_mbp] [seed] [families]   (>= 1000 Mbp: synthetic genome indexed on the device)"""
 import ctypes as C, os, sys, tempfile, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from biscuit_amd import _lib as B
@@ -8,10 +9,13 @@ mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 fam = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 L = B.lib()
-d = tempfile.mkdtemp()
-B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(int(mbp * 1e6)), C.c_uint64(seed), fam, C.c_double(0.05)), "g")
-B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "ib")
-idx = Index(d + "/g"); dev = Device(0); dev.upload_index(idx)
+if mbp >= 1000:
+    idx = Index.synthetic(int(mbp * 1e6), seed=2024, n_contigs=24); dev = Device(0); dev.build_index(idx, fill_host=False)
+else:
+    d = tempfile.mkdtemp()
+    B.check(L.bsx_sim_genome((d + "/g.fa").encode(), C.c_int64(int(mbp * 1e6)), C.c_uint64(seed), fam, C.c_double(0.05)), "g")
+    B.check(L.bsx_index_build((d + "/g.fa").encode(), (d + "/g").encode()), "ib")
+    idx = Index(d + "/g"); dev = Device(0); dev.upload_index(idx)
 opt = default_opt(); opt.n_threads = 16; opt.flag |= 0x10 | 0x2
 L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
 L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
@@ -25,15 +29,17 @@ def crc():
     for i in range(2 * n_pairs): c = zlib.crc32(C.string_at(reads[i].sam), c)
     return c
 out = []
-for host, asy in ((0, 1), (0, 0), (1, 0)):
+for host, asy, hdd in ((0, 1, 0), (0, 0, 0), (0, 0, 1), (1, 0, 0)):
     if host: os.environ["BSX_HOST_CHAIN"] = "1"
     else: os.environ.pop("BSX_HOST_CHAIN", None)
+    if hdd: os.environ["BSX_HOST_DEDUP"] = "1"
+    else: os.environ.pop("BSX_HOST_DEDUP", None)
     os.environ["BSX_ASYNC_REDO"] = str(asy)
     t = time.time()
     B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "ps")
     dt = time.time() - t
     ps = B.PhaseStats(); L.bsx_last_phase_stats(C.byref(ps))
     out.append(crc())
-    print("host_chain", host, "async", asy, "tasks", ps.n_tasks, "host tasks", ps.n_host_tasks, "second pass", ps.n_redo_tasks, "crc %08x" % out[-1], "%.2f s" % dt, flush=True)
+    print("host_chain", host, "host_dedup", hdd, "async", asy, "tasks", ps.n_tasks, "host tasks", ps.n_host_tasks, "second pass", ps.n_redo_tasks, "crc %08x" % out[-1], "%.2f s" % dt, flush=True)
     L.bsx_sim_reset_reads(p, 2 * n_pairs)
 print("PARITY", "OK" if len(set(out)) == 1 else "MISMATCH")
