@@ -1183,12 +1183,15 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 	return 0;
 }
 
-__global__ void __launch_bounds__(256, 4)
+#ifndef C2R_WPB
+#define C2R_WPB 1    // waves per workgroup (a workgroup's slots come back when its last wave ends)
+#endif
+__global__ void __launch_bounds__(64 * C2R_WPB, 4)
 k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X,
       bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
       unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
-	__shared__ RgC2r lds[4];
+	__shared__ RgC2r lds[C2R_WPB];
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
@@ -1765,16 +1768,19 @@ size_t c2r_lanes_hdr_bytes(void) { return sizeof(RgLJobHdr); }
 size_t c2r_lanes_state_bytes(void) { return sizeof(RgLState); }
 
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
+#ifndef RG_WPB
+#define RG_WPB 1     // waves per workgroup of the LDS tiers, as C2R_WPB
+#endif
 template <int OCC>
-__global__ void __launch_bounds__(256, OCC)
+__global__ void __launch_bounds__(64 * RG_WPB, OCC)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
           unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
           const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, RgXPool X)
 {
-	__shared__ RgSmall lds[4];
-	__shared__ RgDpLite dp[4];
+	__shared__ RgSmall lds[RG_WPB];
+	__shared__ RgDpLite dp[RG_WPB];
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
@@ -1844,15 +1850,16 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 // Between the first tier and the HBM tiers: the same tables four times larger, still in LDS (two waves per workgroup, three
 // workgroups per CU).  On a larger genome a repeat family has more copies, and a quarter of the strand searches outgrow the
 // first tier's 96 seeds; in HBM slabs every table access is a memory round trip.  Same list protocol as k_regions_slab.
-__global__ void __launch_bounds__(128, 2)
+#define MID_WPB 2    // 14 KB of tables per wave: five workgroups of two waves fit a CU, only nine of one
+__global__ void __launch_bounds__(64 * MID_WPB, 2)
 k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
               bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
               const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X, int quota)
 {
-	__shared__ RgMid lds[2];
-	__shared__ RgDpLite dp[2];
+	__shared__ RgMid lds[MID_WPB];
+	__shared__ RgDpLite dp[MID_WPB];
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
@@ -1971,10 +1978,10 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
 	if (occ >= 4)
-		hipLaunchKernelGGL(k_regions<4>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		hipLaunchKernelGGL(k_regions<4>, dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 	else
-		hipLaunchKernelGGL(k_regions<3>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		hipLaunchKernelGGL(k_regions<3>, dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 }
 
@@ -1985,7 +1992,7 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	hipLaunchKernelGGL(k_regions_mid, dim3(grid), dim3(128), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	hipLaunchKernelGGL(k_regions_mid, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, /* `grid` counts pairs of waves */ ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 }
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
@@ -1993,7 +2000,7 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
                 unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	hipLaunchKernelGGL(k_c2r, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	hipLaunchKernelGGL(k_c2r, dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 }
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,

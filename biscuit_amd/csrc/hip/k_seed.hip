@@ -7,6 +7,11 @@
 #include "wave.hpp"
 
 #define SEED_LDS_WORDS 24   // 192 bases per lane in LDS: 6 KB per wave
+// One wave per workgroup: a workgroup gives its registers and LDS back when its LAST wave ends, and a wave ends when the longest of its 64
+// strand searches does -- with four waves that was the longest of 256 while the slots of the three finished waves stayed taken
+#ifndef SEED_WPB
+#define SEED_WPB 1
+#endif
 
 // The FM blocks of one trip are fetched by the wave as a whole.  A lane that reads its own 64-byte block issues four 16-byte
 // loads, each of which is one request for a line no other lane of the instruction shares: 64 lines per instruction, and the
@@ -110,7 +115,7 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 // the previous chunk) get compute units while this one is running.  Scratch slabs are therefore not tied to
 // the workgroup index: each wave takes a free slab and gives it back when it exits.
 template <int OCC>
-__global__ void __launch_bounds__(256, OCC)
+__global__ void __launch_bounds__(64 * SEED_WPB, OCC)
 k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
@@ -121,7 +126,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
 	int slab = 0;
 	if ((threadIdx.x & 63) == 0) {
-		unsigned int h = (unsigned int)((blockIdx.x * 4u + (threadIdx.x >> 6)) % (unsigned int)n_slabs);
+		unsigned int h = (unsigned int)((blockIdx.x * (unsigned)SEED_WPB + (threadIdx.x >> 6)) % (unsigned int)n_slabs);
 		while (atomicCAS(&slab_busy[h], 0u, 1u) != 0u) h = h + 1 == (unsigned int)n_slabs ? 0 : h + 1;
 		slab = (int)h;
 	}
@@ -135,8 +140,8 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.mem = L.bufB + (size_t)list_cap * 64;
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
 	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
-	__shared__ uint32_t s_read[4][SEED_LDS_WORDS][64];
-	__shared__ SeedXchg s_xchg[4];
+	__shared__ uint32_t s_read[SEED_WPB][SEED_LDS_WORDS][64];
+	__shared__ SeedXchg s_xchg[SEED_WPB];
 	SeedXchg &X = s_xchg[threadIdx.x >> 6];
 	uint32_t *my_read = &s_read[threadIdx.x >> 6][0][threadIdx.x & 63];
 	L.qlds = nullptr;
@@ -278,7 +283,7 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
 	// 168 VGPRs and 11 KB of LDS per wave: three waves per SIMD
-	hipLaunchKernelGGL(k_seed<3>, dim3(grid), dim3(256), 0, st, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+	hipLaunchKernelGGL(k_seed<3>, dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
 	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
