@@ -630,12 +630,17 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	} else
 	launch_c2r(L.st, (int)((n + 4LL * c2r_quota - 1) / (4LL * c2r_quota)), d->ix, L.sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr, c2r_quota);
+	if (chain >= 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
+		std::lock_guard<std::mutex> g(d->chain_mu);
+		HIPCHK(hipEventRecord(L.ev_regions_done, L.st));
+		d->chain_regions = L.ev_regions_done;
+	}
 	launch_regions_slab(L.st, 2, big_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
 	launch_regions_slab(L.st, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
 
-	if (chain >= 2) {
+	if (chain == 2) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		HIPCHK(hipEventRecord(L.ev_regions_done, L.st));
 		d->chain_regions = L.ev_regions_done;
