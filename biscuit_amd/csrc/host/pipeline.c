@@ -849,18 +849,28 @@ static void clip_worker(void *data, long i, int tid)
 	C->reads[i].sam = 0;
 }
 
+/* which converted index a read is searched against, in the reference's call order (bis_worker1, bwamem.c:311-376): 1 = parent (C>T read),
+ * 0 = daughter (G>A read) */
+static int strand_order(const bsx_opt_t *opt, int is_pe, int second_of_pair, int order[2])
+{
+	int no = 0;
+	if (!is_pe) {
+		if (!(opt->parent & 1) || opt->parent >> 1) order[no++] = 0;
+		if (!(opt->parent & 1) || !(opt->parent >> 1)) order[no++] = 1;
+	} else if (!second_of_pair) { order[no++] = 1; if (!opt->parent) order[no++] = 0; }
+	else { order[no++] = 0; if (!opt->parent) order[no++] = 1; }
+	return no;
+}
+BSX_API int bsx_hook_strand_order(const bsx_opt_t *opt, int is_pe, int second_of_pair, int order[2]) { return strand_order(opt, is_pe, second_of_pair, order); }
+
 static void setup_worker(void *data, long i, int tid)
 {
 	chunk_t *C = (chunk_t*)data;
 	const bsx_opt_t *opt = C->opt;
-	int order[2], no = 0, k;
+	int order[2], no, k;
 	(void)tid;
 	if (C->reads[i].l_seq) memcpy(C->buf + C->roff[i], C->reads[i].seq, (size_t)C->reads[i].l_seq);
-	if (!C->is_pe) {
-		if (!(opt->parent & 1) || opt->parent >> 1) order[no++] = 0;
-		if (!(opt->parent & 1) || !(opt->parent >> 1)) order[no++] = 1;
-	} else if (!(i & 1)) { order[no++] = 1; if (!opt->parent) order[no++] = 0; }
-	else { order[no++] = 0; if (!opt->parent) order[no++] = 1; }
+	no = strand_order(opt, C->is_pe, (int)(i & 1), order);
 	for (k = 0; k < no; ++k) {
 		int t = C->read_task0[i] + k;
 		c2r_t *T = &C->tasks[t];

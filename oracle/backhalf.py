@@ -618,3 +618,18 @@ def format_sam(opt, l_pac, names, annos, s, p0, m0, regs0, p_idx, is_primary, pe
     line += "\tMQ:i:%d" % m["mapq"]
     line += "\tYD:A:" + ("u" if p["bss_u"] else "fr"[p["bss"]])
     return line + "\n"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def strand_searches(parent, is_pe, second_of_pair):   # bis_worker1, bwamem.c:311-376: the mem_align1_core calls of one read, in order
+    """-> the `parent` argument of each call: 1 = the read as C>T against the parent index, 0 = as G>A against the daughter index"""
+    if not is_pe:
+        out = []
+        if not (parent & 1) or parent >> 1:
+            out.append(0)
+        if not (parent & 1) or not (parent >> 1):
+            out.append(1)
+        return out
+    if not second_of_pair:
+        return [1] + ([0] if not parent else [])
+    return [0] + ([1] if not parent else [])

@@ -534,3 +534,18 @@ def test_format_sam(small):
         n_sa += "SA:Z:" in want
         del keep[:]
     assert n_lines == 3000 and n_xa > 200 and n_sa > 200, (n_xa, n_sa)
+
+
+def test_strand_search_order():
+    """D1: which converted index each read is searched against and in which order (bis_worker1, bwamem.c:311-376), for every value -b can
+    give opt->parent, single-end and both reads of a pair"""
+    L = B.lib()
+    L.bsx_hook_strand_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for parent in (0, 1, 3):
+        for is_pe in (0, 1):
+            for second in (0, 1):
+                opt = default_opt()
+                opt.parent = parent
+                order = (C.c_int * 2)()
+                n = L.bsx_hook_strand_order(C.byref(opt), is_pe, second, order)
+                assert list(order)[:n] == backhalf.strand_searches(parent, is_pe, second), (parent, is_pe, second)
