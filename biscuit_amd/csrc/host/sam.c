@@ -574,3 +574,22 @@ BSX_API int bsx_hook_format_sam(const bsx_opt_t *opt, const bsx_index_t *idx, bs
 	free(str.s); free(v.a);
 	return l;
 }
+
+/* test hook: the part of mem_alnreg_setSAM after the alignment (mem_alnreg_format.c:79-120: position and strand, leading / trailing deletion
+ * squeezed out, clipping added) given a CIGAR and its NM/MD/ZC/ZR; out_cigar receives the final operations (cap entries), returns their number */
+BSX_API int bsx_hook_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_read_t *s, const bsx_hook_reg_t *reg, const uint32_t *cg, int n_cigar,
+                                   const bsx_glb_tag_t *tag, const char *md, int out[3], uint32_t *out_cigar, int cap, char *out_md, int md_cap)
+{
+	reg_t r;
+	samrec_t rec;
+	int k;
+	bsx_hook_to_reg(reg, &r);
+	bsx_setsam_finish(opt, idx, s, &r, cg, n_cigar, &rec, tag, md);
+	out[0] = rec.pos; out[1] = (int)rec.is_rev; out[2] = rec.NM;
+	if (rec.n_cigar > cap) return -1;
+	for (k = 0; k < rec.n_cigar; ++k) out_cigar[k] = rec.cigar[k];
+	snprintf(out_md, (size_t)md_cap, "%s", (const char*)(rec.cigar + rec.n_cigar));
+	k = rec.n_cigar;
+	bsx_cfree(rec.cigar);
+	return k;
+}

@@ -6,6 +6,8 @@ source lines (not from csrc/host/region.c) in plain Python for small cases:
     sort_dedup        mem_sort_deduplicate + mem_test_reg_concatenation up to its alignment   lib/aln/mem_alnreg.c:63-202
     matesw            mem_alnreg_matesw + mem_alnreg_matesw_core (SW by the real ksw_align2)   lib/aln/mem_alnreg.c:385-513
     format_sam        mem_alnreg_formatSAM with mem_alnreg_tagSA and mem_alnreg_tagXAXB: one SAM line     lib/aln/mem_alnreg_format.c:126-436
+    setsam_post       mem_alnreg_setSAM after its alignment: position, strand, squeezed deletions, clips   lib/aln/mem_alnreg_format.c:79-120
+    strand_searches   bis_worker1: which converted index a read is searched against, in order               lib/aln/bwamem.c:311-376
     reg2sam_pe        mem_reg2sam_pe, mem_reg2sam_pe_nopairing, mem_alnreg_select_format up to the text (which records are written,
                       with which flag / mapq / mate; mem_approx_mapq_se is the real function)          lib/aln/mem_alnreg_format.c:445-696
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
@@ -633,3 +635,26 @@ def strand_searches(parent, is_pe, second_of_pair):   # bis_worker1, bwamem.c:31
     if not second_of_pair:
         return [1] + ([0] if not parent else [])
     return [0] + ([1] if not parent else [])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def setsam_post(l_pac, ann_offset, s, reg, cigar):   # mem_alnreg_setSAM after the alignment, mem_alnreg_format.c:79-120
+    """s: l_seq clip5 clip3 of the read; reg: rb re qb qe rid -> (pos, is_rev, final cigar); the MD string moves with the cigar unchanged"""
+    p = reg["rb"] if reg["rb"] < l_pac else reg["re"] - 1
+    is_rev = int(p >= l_pac)
+    rpos = (l_pac << 1) - 1 - p if is_rev else p
+    cigar = list(cigar)
+    if cigar:
+        if cigar[0] & 0xf == 2:
+            rpos += cigar[0] >> 4
+            cigar = cigar[1:]
+        elif cigar[-1] & 0xf == 2:
+            cigar = cigar[:-1]
+    if reg["qb"] != 0 or reg["qe"] != s["l_seq"] or s["clip5"] or s["clip3"]:
+        clip5 = s["l_seq"] - reg["qe"] + s["clip3"] if is_rev else reg["qb"] + s["clip5"]
+        clip3 = reg["qb"] + s["clip5"] if is_rev else s["l_seq"] - reg["qe"] + s["clip3"]
+        if clip5:
+            cigar = [clip5 << 4 | 3] + cigar
+        if clip3:
+            cigar = cigar + [clip3 << 4 | 3]
+    return rpos - ann_offset[reg["rid"]], is_rev, cigar

@@ -549,3 +549,54 @@ def test_strand_search_order():
                 order = (C.c_int * 2)()
                 n = L.bsx_hook_strand_order(C.byref(opt), is_pe, second, order)
                 assert list(order)[:n] == backhalf.strand_searches(parent, is_pe, second), (parent, is_pe, second)
+
+
+def test_setsam_position_and_clipping(small):
+    """mem_alnreg_setSAM after its alignment (mem_alnreg_format.c:79-120): position on the contig and strand, a leading or trailing deletion
+    squeezed out of the CIGAR, the read's clips (adaptor / quality / fixed, and the unaligned ends) added -- sam.c against the restatement"""
+    idx, offs, lens = small
+    L = B.lib()
+    l_pac = idx.l_pac
+    L.bsx_hook_setsam_finish.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(123)
+    opt = default_opt()
+    n_rev = n_squeeze = n_clip = 0
+    for trial in range(3000):
+        rid = int(rng.integers(0, 3))
+        l_seq = int(rng.integers(60, 151))
+        qb = int(rng.integers(0, 15)) if rng.random() < 0.4 else 0
+        qe = l_seq - (int(rng.integers(0, 15)) if rng.random() < 0.4 else 0)
+        f = offs[rid] + int(rng.integers(0, lens[rid] - 400))
+        tl = qe - qb + int(rng.integers(-3, 4))
+        rev = rng.random() < 0.5
+        rb = 2 * l_pac - (f + tl) if rev else f
+        reg = {"rb": rb, "re": rb + tl, "qb": qb, "qe": qe, "rid": rid}
+        ops = [(qe - qb) << 4]
+        u = rng.random()
+        if u < 0.15:
+            ops = [int(rng.integers(1, 4)) << 4 | 2] + ops
+        elif u < 0.3:
+            ops = ops + [int(rng.integers(1, 4)) << 4 | 2]
+        elif u < 0.45:
+            a = int(rng.integers(5, qe - qb - 5))
+            ops = [a << 4, 2 << 4 | 1, (qe - qb - a - 2) << 4]
+        s = {"l_seq": l_seq, "clip5": int(rng.integers(0, 6)) if rng.random() < 0.3 else 0, "clip3": int(rng.integers(0, 20)) if rng.random() < 0.3 else 0}
+        want_pos, want_rev, want_cig = backhalf.setsam_post(l_pac, offs, s, reg, ops)
+        rd = B.Read()
+        rd.l_seq, rd.clip5, rd.clip3 = s["l_seq"], s["clip5"], s["clip3"]
+        h = HookReg()
+        for k2, v in reg.items():
+            setattr(h, k2, v)
+        cg = np.array(ops, dtype=np.uint32)
+        tag = B.GlbTag(NM=3, ZC=4, ZR=5, l_md=3, md_off=0, bss_u=0)
+        out = (C.c_int * 3)()
+        oc = np.zeros(16, dtype=np.uint32)
+        omd = C.create_string_buffer(64)
+        n = L.bsx_hook_setsam_finish(C.byref(opt), idx.h, C.byref(rd), C.byref(h), cg.ctypes.data_as(C.c_void_p), len(ops), C.byref(tag), b"7A9", out,
+                                     oc.ctypes.data_as(C.c_void_p), 16, omd, 64)
+        assert n == len(want_cig) and list(oc[:n]) == want_cig and (out[0], out[1], out[2]) == (want_pos, want_rev, 3) and omd.value == b"7A9", \
+            (trial, n, list(oc[:max(n, 0)]), want_cig, list(out), want_pos, want_rev)
+        n_rev += want_rev
+        n_squeeze += len(want_cig) < len(ops) + (1 if want_cig and want_cig[0] & 0xf == 3 else 0) + (1 if want_cig and want_cig[-1] & 0xf == 3 else 0)
+        n_clip += any(c & 0xf == 3 for c in want_cig)
+    assert n_rev > 1000 and n_squeeze > 500 and n_clip > 1000
