@@ -229,6 +229,41 @@ static int filter_chained_seeds(chunk_t *C)
 	return rc;
 }
 
+/* test hook: mem_flt_chained_seeds (memchain.c:501-568) of one chain as this pipeline runs it (window, K5 batch on the given backend, filter):
+ * seeds = (rbeg, qbeg, len) triples; on return keep[k] = index of the k-th surviving seed and score[k] its score; returns their number */
+BSX_API int bsx_hook_flt_chained_seeds(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx, int l_query, const uint8_t *query, int parent,
+                                       int n_seeds, const int64_t *seeds, int *keep, int *score)
+{
+	chunk_t *C = (chunk_t*)calloc(1, sizeof(chunk_t));
+	c2r_t *T = (c2r_t*)calloc(1, sizeof(c2r_t));
+	chain_t ch;
+	int k, n = -1;
+	C->be_copy = *be; C->be = &C->be_copy; C->opt = opt; C->idx = idx; C->nt = 1; C->arena_set = -1; C->n_tasks = 1; C->tasks = T;
+	T->l_query = l_query; T->qoff = 0; T->parent = parent; T->query = query;
+	memset(&ch, 0, sizeof(ch));
+	ch.seeds.a = (seed_t*)bsx_crealloc(0, 0, sizeof(seed_t) * (size_t)(n_seeds ? n_seeds : 1)); ch.seeds.n = ch.seeds.m = (size_t)n_seeds;
+	for (k = 0; k < n_seeds; ++k) { ch.seeds.a[k].rbeg = seeds[3 * k]; ch.seeds.a[k].qbeg = (int32_t)seeds[3 * k + 1]; ch.seeds.a[k].len = (int32_t)seeds[3 * k + 2]; ch.seeds.a[k].score = k; /* carries the index */ }
+	T->chains.a = &ch; T->chains.n = T->chains.m = 1;
+	if (be->set_opt(be->ctx, opt) == BSX_OK && be->set_reads(be->ctx, query, (size_t)l_query) == BSX_OK) {
+		/* the filter overwrites score: find the survivors by their coordinates (unique in the tests) */
+		seed_t *orig = (seed_t*)malloc(sizeof(seed_t) * (size_t)(n_seeds ? n_seeds : 1));
+		memcpy(orig, ch.seeds.a, sizeof(seed_t) * (size_t)n_seeds);
+		if (filter_chained_seeds(C) == BSX_OK) {
+			size_t u; int j;
+			n = (int)ch.seeds.n;
+			for (u = 0; u < ch.seeds.n; ++u) {
+				keep[u] = -1;
+				for (j = 0; j < n_seeds; ++j) if (orig[j].rbeg == ch.seeds.a[u].rbeg && orig[j].qbeg == ch.seeds.a[u].qbeg && orig[j].len == ch.seeds.a[u].len) { keep[u] = j; break; }
+				score[u] = ch.seeds.a[u].score;
+			}
+		}
+		free(orig);
+	}
+	bsx_cfree(ch.seeds.a);
+	free(T); free(C);
+	return n;
+}
+
 /* ------------------------------------------------------------------ extension rounds */
 typedef struct { chunk_t *C; const int *active; const int *owner; const bsx_ext_res_t *res; } round_par_t;
 

@@ -8,6 +8,7 @@ source lines (not from csrc/host/region.c) in plain Python for small cases:
     format_sam        mem_alnreg_formatSAM with mem_alnreg_tagSA and mem_alnreg_tagXAXB: one SAM line     lib/aln/mem_alnreg_format.c:126-436
     setsam_post       mem_alnreg_setSAM after its alignment: position, strand, squeezed deletions, clips   lib/aln/mem_alnreg_format.c:79-120
     strand_searches   bis_worker1: which converted index a read is searched against, in order               lib/aln/bwamem.c:311-376
+    flt_chained_seeds mem_flt_chained_seeds + mem_seed_sw (SW by the real ksw_align2)                                lib/aln/memchain.c:501-568
     reg2sam_pe        mem_reg2sam_pe, mem_reg2sam_pe_nopairing, mem_alnreg_select_format up to the text (which records are written,
                       with which flag / mapq / mate; mem_approx_mapq_se is the real function)          lib/aln/mem_alnreg_format.c:445-696
     mark_primary_se   mem_mark_primary_se + mem_mark_primary_se_core   lib/aln/mem_alnreg.c:252-380
@@ -658,3 +659,42 @@ def setsam_post(l_pac, ann_offset, s, reg, cigar):   # mem_alnreg_setSAM after t
         if clip3:
             cigar = cigar + [clip3 << 4 | 3]
     return rpos - ann_offset[reg["rid"]], is_rev, cigar
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+MEM_SHORT_EXT, MEM_SHORT_LEN = 50, 200   # memchain.c:494-498
+
+
+def _seed_sw(opt, l_pac, anns, get_base, query, seed, parent, ksw_align2):   # mem_seed_sw, memchain.c:501-537
+    rbeg, qbeg, ln = seed
+    if ln >= MEM_SHORT_LEN:
+        return -1
+    qb, qe, rb, re = qbeg, qbeg + ln, rbeg, rbeg + ln
+    mid = (rb + re) >> 1
+    qb = max(qb - MEM_SHORT_EXT, 0)
+    qe = min(qe + MEM_SHORT_EXT, len(query))
+    rb = max(rb - MEM_SHORT_EXT, 0)
+    re = min(re + MEM_SHORT_EXT, l_pac << 1)
+    if rb < l_pac < re:
+        if mid < l_pac:
+            re = l_pac
+        else:
+            rb = l_pac
+    if qe - qb >= MEM_SHORT_LEN or re - rb >= MEM_SHORT_LEN:
+        return -1
+    rseq, rb, re, _ = fetch_seq(l_pac, anns, get_base, rb, mid, re)
+    return ksw_align2(query[qb:qe], rseq, opt["ctmat"] if parent else opt["gamat"], KSW_XSTART)["score"]
+
+
+def flt_chained_seeds(opt, l_pac, anns, get_base, query, seeds, parent, ksw_align2):   # memchain.c:541-568 -> [(seed index, score)] kept
+    l_query = len(query)
+    min_l = f32(f32(1.1) * opt["min_chain_weight"]) if opt["min_chain_weight"] else float(f32(5.5)) * math.log(l_query)   # float * int; float -> double * double
+    if min_l > f32(f32(0.05) * l_query):
+        return [(i, None) for i in range(len(seeds))]     # short read: the chain is left as it is
+    min_hsp = int(opt["a"] * min_l + .499)
+    out = []
+    for i, sd in enumerate(seeds):
+        sc = _seed_sw(opt, l_pac, anns, get_base, query, sd, parent, ksw_align2)
+        if sc < 0 or sc >= min_hsp:
+            out.append((i, sd[2] * opt["a"] if sc < 0 else sc))
+    return out

@@ -600,3 +600,78 @@ def test_setsam_position_and_clipping(small):
         n_squeeze += len(want_cig) < len(ops) + (1 if want_cig and want_cig[0] & 0xf == 3 else 0) + (1 if want_cig and want_cig[-1] & 0xf == 3 else 0)
         n_clip += any(c & 0xf == 3 for c in want_cig)
     assert n_rev > 1000 and n_squeeze > 500 and n_clip > 1000
+
+
+def test_flt_chained_seeds(small):
+    """C3: mem_flt_chained_seeds / mem_seed_sw (memchain.c:501-568), the long-read seed filter: the pipeline's window + K5 batch + filter form
+    (K5 by the CPU restatement of ksw_align2) against the restatement's loop over the REAL ksw_align2.  1 kb reads on both strands, true
+    seeds, seeds at wrong loci, seeds too long to be tested, and a short read for which the filter is off."""
+    from oracle_lib import ref_lib, Port
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is not built")
+    idx, offs, lens = small
+    L = B.lib()
+    opt = default_opt()
+    l_pac = idx.l_pac
+    pac = np.fromfile(idx.base + ".bis.pac", dtype=np.uint8)
+    ii = np.arange(l_pac)
+    g = ((pac[ii >> 2] >> ((~ii & 3) << 1)) & 3).astype(np.uint8)
+    od = dict(opt_dict(opt), min_chain_weight=opt.min_chain_weight, ctmat=(C.c_int8 * 25)(*opt.ctmat), gamat=(C.c_int8 * 25)(*opt.gamat))
+
+    def ksw_align2(query, target, mat, xtra):
+        q = np.array(query, dtype=np.uint8)
+        t = np.array(target, dtype=np.uint8)
+        out = (C.c_int * 7)()
+        R.ref_ksw_align2(len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), mat, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, xtra, out)
+        return dict(zip(("score", "te", "qe", "score2", "te2", "tb", "qb"), out))
+    port = Port(idx, 1)
+    be = port.backend()
+    L.bsx_hook_flt_chained_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    anns = list(zip(offs, lens))
+    comp = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    rng = np.random.default_rng(2024)
+    n_dropped = n_kept = n_long = n_off = 0
+    for trial in range(120):
+        lq = 150 if trial % 10 == 0 else int(rng.integers(800, 1400))
+        rid = int(rng.integers(0, 3))
+        f = offs[rid] + int(rng.integers(0, lens[rid] - lq - 10))
+        seg = g[f:f + lq].copy()
+        rev = rng.random() < 0.4
+        if rev:
+            seg = comp[seg[::-1]]
+        mut = rng.random(lq) < 0.04
+        seg[mut] = (seg[mut] + 1 + rng.integers(0, 3, int(mut.sum()))) & 3
+        parent = int(rng.integers(0, 2))
+        if parent:
+            seg[(seg == 1) & (rng.random(lq) < 0.8)] = 3
+        else:
+            seg[(seg == 2) & (rng.random(lq) < 0.8)] = 0
+        r0 = 2 * l_pac - (f + lq) if rev else f          # where query position 0 lies in forward-reverse coordinates
+        seeds, used = [], set()
+        for _ in range(int(rng.integers(4, 12))):
+            ln = int(rng.integers(19, 60)) if rng.random() < 0.9 else int(rng.integers(200, 260))
+            qb = int(rng.integers(0, lq - ln)) if lq > ln else 0
+            if lq <= ln:
+                continue
+            rb = r0 + qb if rng.random() < 0.7 else int(rng.integers(0, 2 * l_pac - 400))
+            if (rb, qb, ln) not in used:
+                used.add((rb, qb, ln))
+                seeds.append((rb, qb, ln))
+        sd = np.array(seeds, dtype=np.int64)
+        keep = np.zeros(len(seeds), dtype=np.int32)
+        score = np.zeros(len(seeds), dtype=np.int32)
+        q = np.ascontiguousarray(seg)
+        n = L.bsx_hook_flt_chained_seeds(C.byref(be), C.byref(opt), idx.h, lq, q.ctypes.data_as(C.c_void_p), parent, len(seeds), sd.ctypes.data_as(C.c_void_p),
+                                         keep.ctypes.data_as(C.c_void_p), score.ctypes.data_as(C.c_void_p))
+        want = backhalf.flt_chained_seeds(od, l_pac, anns, lambda k: int(g[k]), [int(x) for x in seg], seeds, parent, ksw_align2)
+        assert n == len(want), (trial, n, want)
+        for k, (wi, ws) in enumerate(want):
+            assert keep[k] == wi and (ws is None or score[k] == ws), (trial, k, keep[:n], score[:n], want)
+        if want and want[0][1] is None:
+            n_off += 1
+        else:
+            n_dropped += len(seeds) - len(want)
+            n_kept += len(want)
+            n_long += sum(1 for s2 in seeds if s2[2] >= 200)
+    assert n_off >= 10 and n_dropped > 100 and n_kept > 300 and n_long > 30, (n_off, n_dropped, n_kept, n_long)
