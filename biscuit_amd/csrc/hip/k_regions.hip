@@ -45,9 +45,13 @@ template <int ICAP_, int SCAP_, int CCAP_, int RCAP_, int NODES_, typename Idx, 
 struct RgStore {
 	static constexpr int ICAP = ICAP_, SCAP = SCAP_, CCAP = CCAP_, RCAP = RCAP_, NODES = NODES_, PCAP = PCAP_;
 	typedef Idx idx_t;
-	// intervals (sorted by info)
-	unsigned long long iv_x0[ICAP_];
-	int iv_n[ICAP_]; short iv_beg[ICAP_], iv_end[ICAP_];
+	// intervals (sorted by info): read until the last occurrence has been chained; the sort keys of the chains and of a chain's seeds
+	// (srt) are first written after that, so the two share their bytes (2 KB of the 13.7 KB a wave of the larger LDS tier had: a
+	// sixth workgroup per CU)
+	union {
+		struct { unsigned long long iv_x0[ICAP_]; int iv_n[ICAP_]; short iv_beg[ICAP_], iv_end[ICAP_]; };
+		unsigned long long srt[SCAP_];    // score<<32|i, ascending (memchain.c:748-752)
+	};
 	// seeds in arrival order
 	long long s_rbeg[SCAP_];
 	int s_rid[SCAP_];
@@ -56,7 +60,6 @@ struct RgStore {
 	Idx ord[CCAP_];                   // chain indices: by position, then in filter order
 	Idx keep[CCAP_];                  // mem_chain_flt's kept list (indices into ord)
 	Idx lst[SCAP_];                   // seed indices of the current chain / list
-	unsigned long long srt[SCAP_];    // score<<32|i, ascending (memchain.c:748-752)
 	bsx_region_t regs[RCAP_ ? RCAP_ : 1];
 	int n_chains, n_regs;
 	// NODES > 0: chains are indexed by the reference's B-tree, so that chains starting at the same position are found
