@@ -132,12 +132,13 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	}
 	slab = __shfl(slab, 0);
 	const size_t wave_id = (size_t)slab;
-	const size_t per_lane = (size_t)2 * list_cap + mem_cap;
+	// a slab: mem_cap SMEM records of 32 bytes, then the two lists of list_cap 16-byte entries (in units of DevIntv: mem_cap + list_cap per lane)
+	const size_t per_lane = (size_t)list_cap + mem_cap;
 	SeedLane L;
 	L.stride = 64;
-	L.bufA = scratch + wave_id * per_lane * 64 + (threadIdx.x & 63);
+	L.mem = scratch + wave_id * per_lane * 64 + (threadIdx.x & 63);
+	L.bufA = reinterpret_cast<SeedEnt*>(scratch + wave_id * per_lane * 64 + (size_t)mem_cap * 64) + (threadIdx.x & 63);
 	L.bufB = L.bufA + (size_t)list_cap * 64;
-	L.mem = L.bufB + (size_t)list_cap * 64;
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
 	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
 	__shared__ uint32_t s_read[SEED_WPB][SEED_LDS_WORDS][64];

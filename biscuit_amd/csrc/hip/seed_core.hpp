@@ -6,7 +6,7 @@
 // lane -- the only step that touches HBM (one or two random 64-byte FM blocks).  All 64 lanes of a
 // wave, whatever phase each is in (forward walk, backward sweep, LAST-like pass), issue their
 // gathers together; thousands of waves in flight hide the dependent-gather latency.  Per-lane
-// interval lists live in a private slab of global scratch (L2 resident), not in registers.
+// interval lists live in a private slab of global scratch, not in registers.
 #pragma once
 #include "dev_common.hpp"
 
@@ -18,6 +18,25 @@ struct SeedParams {           // copied from bsx_opt_t
 	int32_t start_width;      // 2 with BSX_F_SELF_OVLP else 1
 };
 
+// An entry of the interval lists (bwtintv_t, lib/aln/bwt.h:80-82) in 16 bytes instead of 32: x0, x1, x2 are ranks and sizes below 2^34
+// (texts of up to 8.5 G symbols), `info` inside bwt_smem1a is the end of the match on the read (bwt.c:320,337).  The lists are written once
+// per surviving interval per row of the backward sweep and were a quarter of the kernel's HBM traffic at 32 bytes an entry.
+struct SeedEnt { uint32_t x0, x1, x2, hi; };   // hi: bits 32-33 of x0 | of x1 << 2 | of x2 << 4 | info << 8
+BSX_HD SeedEnt seed_pack(const DevIntv &v)
+{
+	SeedEnt e;
+	e.x0 = (uint32_t)v.x0; e.x1 = (uint32_t)v.x1; e.x2 = (uint32_t)v.x2;
+	e.hi = (uint32_t)(v.x0 >> 32) | (uint32_t)(v.x1 >> 32) << 2 | (uint32_t)(v.x2 >> 32) << 4 | (uint32_t)v.info << 8;
+	return e;
+}
+BSX_HD DevIntv seed_unpack(const SeedEnt &e)
+{
+	DevIntv v;
+	v.x0 = (uint64_t)(e.hi & 3u) << 32 | e.x0; v.x1 = (uint64_t)(e.hi >> 2 & 3u) << 32 | e.x1; v.x2 = (uint64_t)(e.hi >> 4 & 3u) << 32 | e.x2;
+	v.info = e.hi >> 8;
+	return v;
+}
+
 // One lane's working state.  Lists: A and B are the prev/curr interval lists of bwt_smem1a.
 // The forward list is written downwards from the top of its buffer, which yields the reversed
 // order ("longest match first") the backward sweep wants without a reversal pass.
@@ -27,7 +46,8 @@ struct SeedLane {
 	const uint32_t *qlds;     // optional: the converted read packed 8 bases per word at qlds[(i>>3)*64] (LDS, lane-interleaved)
 	int32_t len, parent;
 	// scratch
-	DevIntv *bufA, *bufB, *mem;   // element i of a list lives at base[i * stride]
+	SeedEnt *bufA, *bufB;         // the two interval lists: element i of a list lives at base[i * stride]
+	DevIntv *mem;                 // the SMEMs found so far, same layout
 	int32_t list_cap, mem_cap;
 	int32_t stride;           // 64 on the GPU: the 64 lanes' i-th entries are contiguous (one 2 KB run), 1 on the host
 	// machine
@@ -48,8 +68,8 @@ struct SeedLane {
 	// pending extend request
 	int32_t ext_back, ext_c, ext_which;   // ext_which: 0 = own index, 1 = complementary index
 	DevIntv ext_in;
-	DevIntv next_in;          // prev[j+1], requested one step ahead so that its latency overlaps the FM gathers
-	DevIntv head;             // entry 0 of the list being built (the forward list's latest push, a backward row's first survivor).
+	SeedEnt next_in;          // prev[j+1], requested one step ahead so that its latency overlaps the FM gathers
+	SeedEnt head;             // entry 0 of the list being built (the forward list's latest push, a backward row's first survivor).
 	                          // It is never stored: the next row reads it from here.  Most backward rows have a single survivor,
 	                          // so most extensions write nothing at all to the lists in scratch
 	int32_t have_next;
@@ -91,7 +111,7 @@ BSX_HD void seed_set_intv(const DevIndex &ix, int parent, int c, DevIntv &ik)   
 BSX_HD void seed_fwd_push(SeedLane &L)
 {
 	if (L.ncurr > 0) L.bufA[(size_t)(L.list_cap - L.ncurr) * L.stride] = L.head;
-	L.head = L.ik;
+	L.head = seed_pack(L.ik);
 	++L.ncurr;
 }
 
@@ -159,7 +179,7 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			break;
 		case SD_FWD_DONE: // the list is already "reversed": smallest interval first (bwt.c:341-343)
 			L.prev_is_A = 1; L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
-			L.ret = (int)(uint32_t)L.head.info;
+			L.ret = (int)(L.head.hi >> 8);
 			L.i = L.x0 - 1;
 			// first backward row set up here (x0 >= 0, so i >= -1): one trip through the switch less per SMEM
 			{
@@ -182,9 +202,13 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 				L.j = 0; L.ncurr = 0; L.have_next = 0;   // nprev = the survivors of the row just finished: at least one
 			}
 			{
-				const DevIntv *prev = (L.prev_is_A ? L.bufA : L.bufB);
-				if (L.have_next) { L.ext_in.x0 = L.next_in.x0; L.ext_in.x1 = L.next_in.x1; L.ext_in.x2 = L.next_in.x2; L.ext_in.info = L.next_in.info; }
-				else { L.ext_in.x0 = L.head.x0; L.ext_in.x1 = L.head.x1; L.ext_in.x2 = L.head.x2; L.ext_in.info = L.head.info; }   // j == 0: entry 0 lives in `head`
+				const SeedEnt *prev = (L.prev_is_A ? L.bufA : L.bufB);
+				{ // j == 0: entry 0 lives in `head` (field by field: a select between the two structs would put them in memory)
+					SeedEnt e;
+					e.x0 = L.have_next ? L.next_in.x0 : L.head.x0; e.x1 = L.have_next ? L.next_in.x1 : L.head.x1;
+					e.x2 = L.have_next ? L.next_in.x2 : L.head.x2; e.hi = L.have_next ? L.next_in.hi : L.head.hi;
+					L.ext_in = seed_unpack(e);
+				}
 				L.have_next = L.j + 1 < L.nprev;
 				if (L.have_next) L.next_in = prev[(size_t)(L.prev_off + L.j + 1) * L.stride];
 				if (L.c >= 0) { L.ext_back = 1; L.ext_c = L.c; L.ext_which = 0; L.state = SD_BWD_POST; return 1; }
@@ -228,10 +252,10 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 				L.last_beg = L.i + 1;
 			}
 		} else { // survives: keep unless it has the size of the previous survivor (bwt.c:357-360)
-			DevIntv *curr = L.prev_is_A ? L.bufB : L.bufA;
+			SeedEnt *curr = L.prev_is_A ? L.bufB : L.bufA;
 			if (L.ncurr == 0 || ok.x2 != L.last_x2) {
 				DevIntv o = ok; o.info = L.ext_in.info;
-				if (L.ncurr == 0) L.head = o; else curr[(size_t)L.ncurr * L.stride] = o;
+				if (L.ncurr == 0) L.head = seed_pack(o); else curr[(size_t)L.ncurr * L.stride] = seed_pack(o);
 				++L.ncurr;
 				L.last_x2 = ok.x2;
 			}
