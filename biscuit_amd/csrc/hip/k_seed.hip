@@ -283,7 +283,7 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
-	// 168 VGPRs and 11 KB of LDS per wave: three waves per SIMD
+	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
 	hipLaunchKernelGGL(k_seed<3>, dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
 	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
 }
