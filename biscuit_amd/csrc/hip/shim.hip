@@ -156,6 +156,8 @@ static int upload_ref(bsx_device_t *d, const bsx_index_t *idx)
 {
 	size_t npac = (size_t)(idx->ref.l_pac / 4 + 1);
 	int rc;
+	// ranks and interval sizes travel as 34-bit numbers in the seeding kernel's interval lists (seed_core.hpp: SeedEnt)
+	if (idx->ref.l_pac >= (int64_t)1 << 33) { fprintf(stderr, "[bsx-hip] genomes of 2^33 bases (8.6 Gbp) or more are not supported on the device\n"); return BSX_E_ARG; }
 	if ((rc = d->pac.reserve(npac + 16)) != BSX_OK) return rc;
 	HIPCHK(hipMemcpy(d->pac.p, idx->pac, npac, hipMemcpyHostToDevice));
 	d->ix.pac = (const uint8_t*)d->pac.p; d->ix.l_pac = idx->ref.l_pac;
