@@ -130,15 +130,15 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		while (atomicCAS(&slab_busy[h], 0u, 1u) != 0u) h = h + 1 == (unsigned int)n_slabs ? 0 : h + 1;
 		slab = (int)h;
 	}
-	slab = __shfl(slab, 0);
+	slab = __builtin_amdgcn_readfirstlane(__shfl(slab, 0));   // wave-uniform, and known to be: the slab's address stays in scalar registers
 	const size_t wave_id = (size_t)slab;
-	// a slab: mem_cap SMEM records of 32 bytes, then the two lists of list_cap 16-byte entries (in units of DevIntv: mem_cap + list_cap per lane)
-	const size_t per_lane = (size_t)list_cap + mem_cap;
+	// a slab: per lane mem_cap SMEM records of 32 bytes, then one list of list_cap 16-byte entries, both lane-interleaved
+	const size_t slab_bytes = (size_t)64 * ((size_t)mem_cap * sizeof(DevIntv) + (size_t)list_cap * sizeof(SeedEnt));
+	char *slab_base = reinterpret_cast<char*>(scratch) + wave_id * slab_bytes;
 	SeedLane L;
-	L.stride = 64;
-	L.mem = scratch + wave_id * per_lane * 64 + (threadIdx.x & 63);
-	L.bufA = reinterpret_cast<SeedEnt*>(scratch + wave_id * per_lane * 64 + (size_t)mem_cap * 64) + (threadIdx.x & 63);
-	L.bufB = L.bufA + (size_t)list_cap * 64;
+	L.stride = 64; L.lane = (int)(threadIdx.x & 63);
+	L.mem = reinterpret_cast<DevIntv*>(slab_base);
+	L.bufA = reinterpret_cast<SeedEnt*>(slab_base + (size_t)64 * mem_cap * sizeof(DevIntv));
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
 	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
 	__shared__ uint32_t s_read[SEED_WPB][SEED_LDS_WORDS][64];
@@ -177,7 +177,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						int n = L.mem_n;
 						if (n > 0 && !L.overflow) {
 							base = atomicAdd(out_cursor, (unsigned long long)n);
-							if (base + n <= out_cap) for (int k = 0; k < n; ++k) out[base + k] = L.mem[(size_t)k * 64];
+							if (base + n <= out_cap) for (int k = 0; k < n; ++k) out[base + k] = seed_mem_at(L, k);
 							else L.overflow = 1;
 						}
 						task_off[task] = (long long)base;

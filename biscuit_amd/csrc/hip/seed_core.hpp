@@ -46,10 +46,13 @@ struct SeedLane {
 	const uint32_t *qlds;     // optional: the converted read packed 8 bases per word at qlds[(i>>3)*64] (LDS, lane-interleaved)
 	int32_t len, parent;
 	// scratch
-	SeedEnt *bufA, *bufB;         // the two interval lists: element i of a list lives at base[i * stride]
+	SeedEnt *bufA;                // the interval list of the walk in progress: element i of this lane lives at base[i * stride + lane], base
+	                              // being the same for the whole wave (kept in scalar registers; the lane's part is a 32-bit offset).  ONE buffer serves the
+	                              // forward list and every row of the backward sweep: a row's survivors are written over the row they come
+	                              // from (survivor m <= j is stored after entry j has been read, the forward list sits at the top)
 	DevIntv *mem;                 // the SMEMs found so far, same layout
 	int32_t list_cap, mem_cap;
-	int32_t stride;           // 64 on the GPU: the 64 lanes' i-th entries are contiguous (one 2 KB run), 1 on the host
+	int32_t stride, lane;     // 64 and the lane number on the GPU: the 64 lanes' i-th entries are contiguous; 1 and 0 on the host
 	// machine
 	int32_t state, ret_state;
 	int32_t pass_x;           // pass-1 / pass-3 scan position
@@ -57,7 +60,6 @@ struct SeedLane {
 	int32_t x0, min_intv;     // current smem1 call
 	int32_t i, j, c;
 	int32_t nprev, ncurr;     // list sizes
-	int32_t prev_is_A;        // which buffer holds prev
 	int32_t prev_off;         // start offset of prev inside its buffer
 	int32_t last_beg;         // start of the last SMEM emitted by this call, -1 if none
 	int32_t ret;              // return value of the current smem1 call
@@ -86,10 +88,20 @@ BSX_HD int seed_qbase(const SeedLane &L, int i)
 	return L.parent ? (b == 1 ? 3 : b) : (b == 2 ? 0 : b);   // bseq_bsconvert, lib/aln/bwamem.c:161-178
 }
 
+// element idx of this lane in its slab: a wave-uniform base plus a byte offset that fits 32 bits
+BSX_HD DevIntv &seed_mem_at(const SeedLane &L, int idx)
+{
+	return *reinterpret_cast<DevIntv*>(reinterpret_cast<char*>(L.mem) + (uint32_t)((uint32_t)(idx * L.stride + L.lane) * (uint32_t)sizeof(DevIntv)));
+}
+BSX_HD SeedEnt &seed_list_at(const SeedLane &L, int idx)
+{
+	return *reinterpret_cast<SeedEnt*>(reinterpret_cast<char*>(L.bufA) + (uint32_t)((uint32_t)(idx * L.stride + L.lane) * (uint32_t)sizeof(SeedEnt)));
+}
+
 BSX_HD void seed_emit(SeedLane &L, const DevIntv &m, int beg, int end)
 {
 	if (end - beg < 0) return;
-	if (L.mem_n < L.mem_cap) { DevIntv o = m; o.info = (uint64_t)(uint32_t)beg << 32 | (uint32_t)end; L.mem[(size_t)L.mem_n * L.stride] = o; }
+	if (L.mem_n < L.mem_cap) { DevIntv o = m; o.info = (uint64_t)(uint32_t)beg << 32 | (uint32_t)end; seed_mem_at(L, L.mem_n) = o; }
 	else L.overflow = 1;
 	++L.mem_n;
 }
@@ -110,7 +122,7 @@ BSX_HD void seed_set_intv(const DevIndex &ix, int parent, int c, DevIntv &ik)   
 // sweep's first row and stays in `head`; the one that was there moves to its slot in memory
 BSX_HD void seed_fwd_push(SeedLane &L)
 {
-	if (L.ncurr > 0) L.bufA[(size_t)(L.list_cap - L.ncurr) * L.stride] = L.head;
+	if (L.ncurr > 0) seed_list_at(L, L.list_cap - L.ncurr) = L.head;
 	L.head = seed_pack(L.ik);
 	++L.ncurr;
 }
@@ -137,7 +149,7 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			{
 				int kk = L.k2++;
 				if (kk < L.mem_cap) {
-					DevIntv p = L.mem[(size_t)kk * L.stride];
+					DevIntv p = seed_mem_at(L, kk);
 					int start = (int)(p.info >> 32), end = (int)(uint32_t)p.info;
 					if (end - start < P.split_len || p.x2 > (uint64_t)P.split_width) break;
 					L.x0 = (start + end) >> 1; L.min_intv = (int)(p.x2 + 1); L.ret_state = SD_P2; L.state = SD_SMEM_BEGIN;
@@ -178,7 +190,7 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 			}
 			break;
 		case SD_FWD_DONE: // the list is already "reversed": smallest interval first (bwt.c:341-343)
-			L.prev_is_A = 1; L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
+			L.prev_off = L.list_cap - L.ncurr; L.nprev = L.ncurr;
 			L.ret = (int)(L.head.hi >> 8);
 			L.i = L.x0 - 1;
 			// first backward row set up here (x0 >= 0, so i >= -1): one trip through the switch less per SMEM
@@ -192,7 +204,7 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 		case SD_BWD_ELEM:
 			if (L.j >= L.nprev) { // end of the row (bwt.c:362-363): roll over to the next one and go on with its first element
 				if (L.ncurr == 0) { L.state = SD_SMEM_END; break; }
-				L.prev_is_A = !L.prev_is_A; L.prev_off = 0; L.nprev = L.ncurr;
+				L.prev_off = 0; L.nprev = L.ncurr;
 				--L.i;
 					if (L.i < -1) { L.state = SD_SMEM_END; break; }
 				{
@@ -202,7 +214,6 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 				L.j = 0; L.ncurr = 0; L.have_next = 0;   // nprev = the survivors of the row just finished: at least one
 			}
 			{
-				const SeedEnt *prev = (L.prev_is_A ? L.bufA : L.bufB);
 				{ // j == 0: entry 0 lives in `head` (field by field: a select between the two structs would put them in memory)
 					SeedEnt e;
 					e.x0 = L.have_next ? L.next_in.x0 : L.head.x0; e.x1 = L.have_next ? L.next_in.x1 : L.head.x1;
@@ -210,7 +221,7 @@ BSX_HD int seed_advance_t(SeedLane &L, const DevIndex &ix, const SeedParams &P)
 					L.ext_in = seed_unpack(e);
 				}
 				L.have_next = L.j + 1 < L.nprev;
-				if (L.have_next) L.next_in = prev[(size_t)(L.prev_off + L.j + 1) * L.stride];
+				if (L.have_next) L.next_in = seed_list_at(L, L.prev_off + L.j + 1);
 				if (L.c >= 0) { L.ext_back = 1; L.ext_c = L.c; L.ext_which = 0; L.state = SD_BWD_POST; return 1; }
 				// c < 0: cannot extend -> candidate SMEM (bwt.c:350-355)
 				if (L.ncurr == 0 && (L.last_beg < 0 || L.i + 1 < L.last_beg)) {
@@ -252,10 +263,9 @@ BSX_HD void seed_post(SeedLane &L, const DevIntv &ok, const SeedParams &P)
 				L.last_beg = L.i + 1;
 			}
 		} else { // survives: keep unless it has the size of the previous survivor (bwt.c:357-360)
-			SeedEnt *curr = L.prev_is_A ? L.bufB : L.bufA;
 			if (L.ncurr == 0 || ok.x2 != L.last_x2) {
 				DevIntv o = ok; o.info = L.ext_in.info;
-				if (L.ncurr == 0) L.head = seed_pack(o); else curr[(size_t)L.ncurr * L.stride] = seed_pack(o);
+				if (L.ncurr == 0) L.head = seed_pack(o); else seed_list_at(L, L.ncurr) = seed_pack(o);
 				++L.ncurr;
 				L.last_x2 = ok.x2;
 			}

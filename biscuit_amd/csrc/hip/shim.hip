@@ -427,7 +427,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		int waves = (int)std::min<int64_t>((cn + 63) / 64, (int64_t)d->n_cu * 16);
 		int grid = (waves + 3) / 4;
 		size_t lanes = (size_t)grid * 256;
-		size_t scratch_bytes = lanes * ((size_t)list_cap + mem_cap) * sizeof(DevIntv);   // per lane: mem_cap SMEMs of 32 bytes, two lists of list_cap 16-byte entries
+		size_t scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // per lane: mem_cap SMEMs of 32 bytes, one list of list_cap 16-byte entries
 		if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 		if ((rc = L.jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 		if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
@@ -527,7 +527,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	static const int seed_wpc = getenv("BSX_SEED_WAVES_PER_CU") ? std::max(1, std::min(16, atoi(getenv("BSX_SEED_WAVES_PER_CU")))) : 16;
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
 	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
-	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)list_cap + mem_cap) * sizeof(DevIntv);   // as in lane_seed_batch
+	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // as in lane_seed_batch
 	const int big_grid = d->n_cu * 2, huge_grid = 16;
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
@@ -669,7 +669,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		const size_t n2 = redo.size();
 		const int g2 = (int)((n2 + 255) / 256);
 		// one pass with the longest lists the scratch we already hold allows (up to 512x the first pass)
-		long long cap2 = (long long)(scratch_bytes / ((size_t)g2 * 256) / sizeof(DevIntv)) - (long long)list_cap;
+		long long cap2 = ((long long)(scratch_bytes / ((size_t)g2 * 256)) - 16LL * list_cap) / 32;
 		if (cap2 > (long long)mem_cap * 512) cap2 = (long long)mem_cap * 512;
 		if (cap2 >= (long long)mem_cap * 8 && g2 * 4 <= n_slabs) {
 			L.rs.tasks = redo; L.rs.sub.resize(n2); L.rs.n2u = (unsigned int)n2;

@@ -28,10 +28,10 @@ extern "C" int hostlogic_seed(const bsx_index_t *idx, const bsx_opt_t *opt, cons
 	ctr[0] = ctr[1] = 0;
 	for (int64_t t = 0; t < n; ++t) {
 		int len = tasks[t].len, list_cap = len + 2;
-		std::vector<SeedEnt> A(list_cap), B(list_cap);
+		std::vector<SeedEnt> A(list_cap);
 		std::vector<DevIntv> M(mem_cap);
 		SeedLane L;
-		L.bufA = A.data(); L.bufB = B.data(); L.mem = M.data(); L.list_cap = list_cap; L.mem_cap = mem_cap; L.stride = 1; L.qlds = nullptr;
+		L.bufA = A.data(); L.mem = M.data(); L.list_cap = list_cap; L.mem_cap = mem_cap; L.stride = 1; L.lane = 0; L.qlds = nullptr;
 		L.q = reads + tasks[t].qoff; L.len = len; L.parent = tasks[t].parent;
 		seed_lane_begin(L);
 		out_off[t] = tot;
