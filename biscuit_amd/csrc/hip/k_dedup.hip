@@ -4,11 +4,13 @@
 // The work of a read is a few dozen dependent steps over a handful of regions (two sorts with klib's introsort, whose
 // order for equal keys matters; a backward scan per region with early exits): nothing in it spans lanes, and a chunk has a
 // million reads, so each lane runs the reference's own loop nest for one read and the parallelism is the number of reads.
+// The lane keeps its order array in LDS and reads the regions' fields where they lie (no per-lane copies: those were 528
+// bytes of scratch memory and 256 registers).
 // A read's regions are the regions of its strand searches concatenated in call order (bwamem.c:352-372); without a
 // concatenation (below) the function only drops and reorders them, so the result is a list of indices into that
 // concatenation: the host builds the read's mem_alnreg_v straight in its final order.
 // Left to the host (out_n = -1): a read one of whose strand searches the device did not finish (declined, or being seeded
-// again), more than DD_CAP regions, and a read where mem_test_reg_concatenation (mem_alnreg.c:63-108) gets as far as its
+// again), more than DD_CAP regions or DD_PER_READ strand searches, and a read where mem_test_reg_concatenation (mem_alnreg.c:63-108) gets as far as its
 // global alignment -- two collinear regions a gap apart: the score is a k_global job, and the host's merge rounds batch those.
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
@@ -18,8 +20,8 @@
 
 // klib introsort (ksort.h:184-236) over region indices with the control flow of csrc/host/util.c:bsx_introsort (see
 // rg_introsort_keys in k_regions.hip); LT(x, y) compares the regions the indices name
-template <typename LT>
-__device__ __forceinline__ void dd_introsort(unsigned char *a, int n, LT lt)
+template <typename Arr, typename LT>
+__device__ __forceinline__ void dd_introsort(Arr a, int n, LT lt)
 {
 #define SWP(i, j) do { const unsigned char t_ = a[i]; a[i] = a[j]; a[j] = t_; } while (0)
 	if (n < 2) return;
@@ -69,48 +71,76 @@ __device__ __forceinline__ void dd_introsort(unsigned char *a, int n, LT lt)
 #undef SWP
 }
 
+// a read's regions, numbered through the concatenation of its strand searches' lists; the records stay where the region
+// tiers left them (32 of their 56 bytes are read here, a few times each and out of L2), so that a lane carries a handful
+// of registers and an order array of DD_CAP bytes in LDS instead of six arrays of DD_CAP entries in scratch memory
+#define DD_PER_READ 4
+struct DdRead {
+	const bsx_region_t *base[DD_PER_READ]; int cum[DD_PER_READ];   // list t holds entries cum[t-1] .. cum[t]-1
+	__device__ __forceinline__ const bsx_region_t &at(int k) const
+	{
+		const bsx_region_t *r = base[0] + k;
+#pragma unroll
+		for (int t = 1; t < DD_PER_READ; ++t) if (k >= cum[t - 1]) r = base[t] + (k - cum[t - 1]);
+		return *r;
+	}
+};
+struct DdOrd {   // the order array of one lane: entry i at p[i * 256]
+	unsigned char *p;
+	__device__ __forceinline__ unsigned char &operator[](int i) const { return p[i * 256]; }
+};
+
 __global__ void __launch_bounds__(256)
 k_dedup(const bsx_region_t *regs, const long long *reg_off, const int *reg_n, int n_reads, int per_read,
         long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, int *out_n, unsigned char *out_idx)
 {
+	__shared__ unsigned char s_ord[DD_CAP * 256];
 	const int rd = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (rd >= n_reads) return;
-	long long rb[DD_CAP], re[DD_CAP];
-	int qb[DD_CAP], qe[DD_CAP], rid[DD_CAP], sc[DD_CAP];
-	unsigned char ord[DD_CAP];
+	if (per_read > DD_PER_READ) { out_n[rd] = -1; return; }
+	DdRead R;
 	int n = 0;
-	for (int t = rd * per_read; t < (rd + 1) * per_read; ++t) {
-		const int m = reg_n[t];
-		if (m < 0 || n + m > DD_CAP) { out_n[rd] = -1; return; }
-		const bsx_region_t *src = regs + reg_off[t];
-		for (int k = 0; k < m; ++k, ++n) { rb[n] = src[k].rb; re[n] = src[k].re; qb[n] = src[k].qb; qe[n] = src[k].qe; rid[n] = src[k].rid; sc[n] = src[k].score; }
+#pragma unroll
+	for (int t = 0; t < DD_PER_READ; ++t) {
+		R.base[t] = regs; R.cum[t] = n;
+		if (t < per_read) {
+			const int m = reg_n[rd * per_read + t];
+			if (m < 0 || n + m > DD_CAP) { out_n[rd] = -1; return; }
+			R.base[t] = regs + reg_off[rd * per_read + t];
+			n += m; R.cum[t] = n;
+		}
 	}
 	unsigned char *o = out_idx + (size_t)rd * DD_CAP;
 	if (n <= 1) { if (n) o[0] = 0; out_n[rd] = n; return; }   // mem_alnreg.c:114
+	DdOrd ord; ord.p = s_ord + threadIdx.x;
 	for (int k = 0; k < n; ++k) ord[k] = (unsigned char)k;
-	dd_introsort(ord, n, [&](int x, int y) { return re[x] < re[y]; });   // by END (alnreg_slt2)
+	dd_introsort(ord, n, [&](int x, int y) { return R.at(x).re < R.at(y).re; });   // by END (alnreg_slt2)
 	unsigned int dead = 0;   // stands for qe = qb (mem_alnreg.c:137,139)
 	for (int a = 1; a < n; ++a) {
 		const int p = ord[a];
+		const bsx_region_t &P = R.at(p);
+		const long long rb_p = P.rb, re_p = P.re; const int qb_p = P.qb, qe_p = P.qe, rid_p = P.rid, sc_p = P.score;
 		for (int b = a - 1; b >= 0; --b) {
 			const int q = ord[b];
-			if (!(rid[p] == rid[q] && rb[p] < re[q] + max_chain_gap)) break;
+			const bsx_region_t &Q = R.at(q);
+			const long long rb_q = Q.rb, re_q = Q.re; const int qb_q = Q.qb, qe_q = Q.qe;
+			if (!(rid_p == Q.rid && rb_p < re_q + max_chain_gap)) break;
 			if (dead >> q & 1) continue;
-			const long long or_ = re[q] - rb[p];
-			const long long oq = qb[q] < qb[p] ? qe[q] - qb[p] : qe[p] - qb[q];
-			const long long mr = re[q] - rb[q] < re[p] - rb[p] ? re[q] - rb[q] : re[p] - rb[p];
-			const long long mq = qe[q] - qb[q] < qe[p] - qb[p] ? qe[q] - qb[q] : qe[p] - qb[p];
+			const long long or_ = re_q - rb_p;
+			const long long oq = qb_q < qb_p ? qe_q - qb_p : qe_p - qb_q;
+			const long long mr = re_q - rb_q < re_p - rb_p ? re_q - rb_q : re_p - rb_p;
+			const long long mq = qe_q - qb_q < qe_p - qb_p ? qe_q - qb_q : qe_p - qb_p;
 			if ((float)or_ > mask_level_redun * (float)mr && (float)oq > mask_level_redun * (float)mq) { // one of the two is redundant
-				if (sc[p] < sc[q]) { dead |= 1u << p; break; }
+				if (sc_p < Q.score) { dead |= 1u << p; break; }
 				else dead |= 1u << q;
-			} else if (rb[q] < rb[p]) { // mem_test_reg_concatenation(q, p) up to its alignment (mem_alnreg.c:63-91)
-				if (rb[q] < l_pac && rb[p] >= l_pac) continue;
-				if (qb[q] >= qb[p] || qe[q] >= qe[p] || re[q] >= re[p]) continue;
-				long long w = (re[q] - rb[p]) - (long long)(qe[q] - qb[p]);
+			} else if (rb_q < rb_p) { // mem_test_reg_concatenation(q, p) up to its alignment (mem_alnreg.c:63-91)
+				if (rb_q < l_pac && rb_p >= l_pac) continue;
+				if (qb_q >= qb_p || qe_q >= qe_p || re_q >= re_p) continue;
+				long long w = (re_q - rb_p) - (long long)(qe_q - qb_p);
 				int wi = (int)w; wi = wi > 0 ? wi : -wi;
-				double r = (double)(re[q] - rb[p]) / (double)(re[p] - rb[q]) - (double)(qe[q] - qb[p]) / (double)(qe[p] - qb[q]);
+				double r = (double)(re_q - rb_p) / (double)(re_p - rb_q) - (double)(qe_q - qb_p) / (double)(qe_p - qb_q);
 				r = r > 0. ? r : -r;
-				if (re[q] < rb[p] || qe[q] < qb[p]) { if (wi > opt_w << 1 || r >= (double)0.05f) continue; }
+				if (re_q < rb_p || qe_q < qb_p) { if (wi > opt_w << 1 || r >= (double)0.05f) continue; }
 				else if (wi > opt_w << 2 || r >= (double)(0.05f * 2)) continue;
 				out_n[rd] = -1;   // the two may be one alignment: scored and merged by the host's rounds
 				return;
@@ -118,12 +148,18 @@ k_dedup(const bsx_region_t *regs, const long long *reg_off, const int *reg_n, in
 		}
 	}
 	int m = 0;
-	for (int k = 0; k < n; ++k) if (!(dead >> ord[k] & 1)) ord[m++] = ord[k];
-	dd_introsort(ord, m, [&](int x, int y) { return sc[x] > sc[y] || (sc[x] == sc[y] && (rb[x] < rb[y] || (rb[x] == rb[y] && qb[x] < qb[y]))); });   // alnreg_slt
+	for (int k = 0; k < n; ++k) { const unsigned char v = ord[k]; if (!(dead >> v & 1)) ord[m++] = v; }
+	dd_introsort(ord, m, [&](int x, int y) {   // alnreg_slt
+		const bsx_region_t &X = R.at(x), &Y = R.at(y);
+		return X.score > Y.score || (X.score == Y.score && (X.rb < Y.rb || (X.rb == Y.rb && X.qb < Y.qb)));
+	});
 	dead = 0;
-	for (int k = 1; k < m; ++k) { const int x = ord[k], y = ord[k - 1]; if (sc[x] == sc[y] && rb[x] == rb[y] && qb[x] == qb[y]) dead |= 1u << x; }   // identical hits
+	for (int k = 1; k < m; ++k) { // identical hits
+		const int x = ord[k]; const bsx_region_t &X = R.at(x), &Y = R.at(ord[k - 1]);
+		if (X.score == Y.score && X.rb == Y.rb && X.qb == Y.qb) dead |= 1u << x;
+	}
 	int m2 = 0;
-	for (int k = 0; k < m; ++k) if (k == 0 || !(dead >> ord[k] & 1)) o[m2++] = ord[k];
+	for (int k = 0; k < m; ++k) { const unsigned char v = ord[k]; if (k == 0 || !(dead >> v & 1)) o[m2++] = v; }
 	out_n[rd] = m2;
 }
 
