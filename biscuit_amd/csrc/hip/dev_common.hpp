@@ -59,6 +59,33 @@ BSX_HD int dev_ref_base(const uint8_t *pac, int64_t l_pac, int64_t p)
 	return (pac[p >> 2] >> ((~p & 3) << 1)) & 3;
 }
 
+// bns_fetch_seq (memchain.c:889) of [beg, beg + span) into LDS, one byte per base: the window lies on one strand (the caller
+// clamps it at l_pac, memchain.c:606-610), i.e. it is a run of consecutive 2-bit codes of pac read forwards, or backwards and
+// complemented.  A lane takes an aligned dword of pac (16 bases): one load instruction for the whole window instead of one
+// dependent round trip to HBM per 64 bases.
+BSX_HD void dev_fetch_window(uint8_t *win, const uint8_t *pac, int64_t l_pac, int64_t beg, int span, int lane)
+{
+	if (beg < l_pac && beg + span > l_pac) { // not reached by the callers; the per-base form handles any window
+		for (int i = lane; i < span; i += 64) win[i] = (uint8_t)dev_ref_base(pac, l_pac, beg + i);
+		return;
+	}
+	const bool rev = beg >= l_pac;
+	const int64_t f_lo = rev ? (l_pac << 1) - (beg + span) : beg;   // forward coordinates [f_lo, f_lo + span)
+	const int64_t b0 = (f_lo >> 2) & ~(int64_t)3;                          // first byte of pac touched, rounded down to a dword (pac is padded)
+	const int nw = (int)((((f_lo + span - 1) >> 2) - b0) >> 2) + 1;
+	for (int w = lane; w < nw; w += 64) {
+		const uint8_t *pw = pac + b0 + (int64_t)4 * w;
+		const uint32_t v = *reinterpret_cast<const uint32_t*>(pw);
+		const int64_t f0 = (b0 + (int64_t)4 * w) << 2;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) { // base k of the dword: byte k >> 2, bits (~k & 3) << 1 (bntseq.h _get_pac)
+			const int b = (int)(v >> (8 * (k >> 2) + ((~k & 3) << 1))) & 3;
+			const int64_t i = rev ? (f_lo + span - 1) - (f0 + k) : (f0 + k) - f_lo;
+			if (i >= 0 && i < span) win[i] = (uint8_t)(rev ? 3 - b : b);
+		}
+	}
+}
+
 BSX_HD int dev_popc(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -926,7 +926,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
 					if (span > 0 && span <= RG_WIN) {
-						for (int i = lane; i < span; i += 64) D.win[i] = (uint8_t)dev_ref_base(ix.pac, l_pac, rmax0 + i);
+						dev_fetch_window(D.win, ix.pac, l_pac, rmax0, span, lane);
 						win_ok = 1;
 						WAVE_SYNC();
 					} else win_ok = -1;
@@ -1023,9 +1023,11 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 // occupancy the registers allow.
 #define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
 #define RG_XREGS 24
+#define RG_XCBLK 16      // chain records staged at a time
 struct RgC2r {
 	bsx_region_t regs[RG_XREGS];
-	RgXSeed sd[RG_XSEEDS];
+	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
+	RgXSeed sd[RG_XSEEDS];   // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
 	unsigned long long srt[RG_XSEEDS];
 	uint8_t q[RG_QCAP];
 	uint8_t win[RG_WIN];
@@ -1038,26 +1040,41 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 	const long long l_pac = ix.l_pac;
 	long long pf_t = P.prof ? (long long)__builtin_readcyclecounter() : 0;
 	unsigned int pf_ext = 0, pf_rows = 0;
-	const int nk = uni(H->n_chains);
-	const float frac_rep = H->frac_rep;
-	const RgXChain *XC = (const RgXChain*)(H + 1);
-	const RgXSeed *XS = (const RgXSeed*)(XC + nk);
-	if (lane == 0) W.n_regs = 0;
+	// The exported record (header, chains in processing order, their seeds in the same order) is staged through LDS a block of
+	// chains and a window of seeds at a time: two round trips to HBM per strand search (header + read, then chains + seeds) where
+	// reading each chain's record and lists where they lie was three per chain, twelve chains per strand search.
 	for (int i = lane; i < l_query; i += 64) W.q[i] = reads[qoff + i];
+	const int nk = uni(H->n_chains), n_sd = uni(H->n_seeds);
+	const float frac_rep = H->frac_rep;
+	const unsigned long long *XCw = (const unsigned long long*)(H + 1);                           // RgXChain = 3 words, RgXSeed = 2
+	const unsigned long long *XSw = XCw + (size_t)nk * (sizeof(RgXChain) / 8);
+	if (lane == 0) W.n_regs = 0;
+	int xc_lo = 0, sd_lo = 0, sd_hi = 0;
+#define C2R_STAGE_CHAINS(from) do { const int n_ = (nk - (from) < RG_XCBLK ? nk - (from) : RG_XCBLK) * (int)(sizeof(RgXChain) / 8); \
+		for (int i_ = lane; i_ < n_; i_ += 64) ((unsigned long long*)W.xc)[i_] = XCw[(size_t)(from) * (sizeof(RgXChain) / 8) + i_]; xc_lo = (from); } while (0)
+#define C2R_STAGE_SEEDS(from) do { const int m_ = n_sd - (from) < RG_XSEEDS ? n_sd - (from) : RG_XSEEDS; \
+		for (int i_ = lane; i_ < m_ * 2; i_ += 64) ((unsigned long long*)W.sd)[i_] = XSw[(size_t)(from) * 2 + i_]; sd_lo = (from); sd_hi = (from) + m_; } while (0)
+	C2R_STAGE_CHAINS(0);
+	C2R_STAGE_SEEDS(0);
 	WAVE_SYNC();
 	for (int ci = 0; ci < nk; ++ci) {
-		const long long ch_pos = uni64(XC[ci].pos);
-		const int rid = uni(XC[ci].rid), seed_off = uni(XC[ci].seed_off), n_main = uni((int)XC[ci].n_main), n_extra = uni((int)XC[ci].n_extra);
+		if (ci >= xc_lo + RG_XCBLK) { WAVE_SYNC(); C2R_STAGE_CHAINS(ci); WAVE_SYNC(); }
+		const RgXChain &XCc = W.xc[ci - xc_lo];
+		const long long ch_pos = uni64(XCc.pos);
+		const int rid = uni(XCc.rid), seed_off = uni(XCc.seed_off), n_main = uni((int)XCc.n_main), n_extra = uni((int)XCc.n_extra);
 		if (n_main > RG_XSEEDS || n_extra > RG_XSEEDS) return 2;
+		if (seed_off + n_main > sd_hi) { WAVE_SYNC(); C2R_STAGE_SEEDS(seed_off); WAVE_SYNC(); }
 		// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp
 		long long rmax0 = l_pac << 1, rmax1 = 0;
 		for (int o = lane; o < n_main; o += 64) {
-			const RgXSeed sd = XS[seed_off + o];
+			const RgXSeed sd = W.sd[seed_off - sd_lo + o];
 			const long long b = sd.rbeg - (sd.qbeg + rg_gap(gap, P, sd.qbeg));
 			const long long e = sd.rbeg + sd.len + ((l_query - sd.qbeg - sd.len) + rg_gap(gap, P, l_query - sd.qbeg - sd.len));
 			rmax0 = rmax0 < b ? rmax0 : b; rmax1 = rmax1 > e ? rmax1 : e;
 		}
-		rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1));
+		if (n_main == 1) { // most chains are one seed: lane 0 holds the span
+			rmax0 = uni64(rmax0); rmax1 = uni64(rmax1);
+		} else { rmax0 = uni64(-wave_max_i64(-rmax0)); rmax1 = uni64(wave_max_i64(rmax1)); }
 		rmax0 = rmax0 > 0 ? rmax0 : 0; rmax1 = rmax1 < l_pac << 1 ? rmax1 : l_pac << 1;
 		if (rmax0 < l_pac && l_pac < rmax1) { if (ch_pos < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
 		{
@@ -1071,20 +1088,19 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 		for (int pass = 0; pass < 2; ++pass) {
 			if (pass == 1 && !(uni(W.n_regs) == n0 && n_extra > 0)) break;
 			const int nl = pass ? n_extra : n_main;
-			const RgXSeed *src = XS + seed_off + (pass ? n_main : 0);
-			WAVE_SYNC();
-			for (int i = lane; i < nl; i += 64) W.sd[i] = src[i];
-			WAVE_SYNC();
+			const int l0 = seed_off + (pass ? n_main : 0);
+			if (l0 + nl > sd_hi) { WAVE_SYNC(); C2R_STAGE_SEEDS(l0); WAVE_SYNC(); }
+			const RgXSeed *Lsd = W.sd + (l0 - sd_lo);   // this list, in place in the window
 			for (int i = lane; i < nl; i += 64) { // keys score<<32|i are unique: rank by counting (ks_introsort_64, memchain.c:752)
-				const unsigned long long key = (unsigned long long)(unsigned)W.sd[i].len << 32 | (unsigned)i;
+				const unsigned long long key = (unsigned long long)(unsigned)Lsd[i].len << 32 | (unsigned)i;
 				int r = 0;
-				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)W.sd[k].len << 32 | (unsigned)k) < key;
+				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)Lsd[k].len << 32 | (unsigned)k) < key;
 				W.srt[r] = key;
 			}
 			WAVE_SYNC();
 			for (int k = nl - 1; k >= 0; --k) {
 				const int si = uni((int)(uint32_t)W.srt[k]);
-				const RgXSeed sd = W.sd[si];
+				const RgXSeed sd = Lsd[si];
 				if (uni((int)sd.bad)) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
 				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
 				// contained in a region of this strand search? (memchain.c:761-819)
@@ -1108,7 +1124,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 					int i;
 					for (i = k + 1; i < nl; ++i) {
 						if (W.srt[i] == 0) continue;
-						const RgXSeed td = W.sd[(int)(uint32_t)W.srt[i]];
+						const RgXSeed td = Lsd[(int)(uint32_t)W.srt[i]];
 						const long long t_rbeg = td.rbeg; const int t_qbeg = td.qbeg, t_len = td.len;
 						if (t_len < s_len * .95) continue;
 						if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
@@ -1120,7 +1136,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
 					if (span > 0 && span <= RG_WIN) {
-						for (int i = lane; i < span; i += 64) W.win[i] = (uint8_t)dev_ref_base(ix.pac, l_pac, rmax0 + i);
+						dev_fetch_window(W.win, ix.pac, l_pac, rmax0, span, lane);
 						win_ok = 1;
 						WAVE_SYNC();
 					} else win_ok = -1;
@@ -1170,7 +1186,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 				if (RG_BSS(parent, l_pac, R.re) != R.bss) continue;   // crosses the strand boundary (memchain.c:846-849)
 				int cov = 0;
 				for (int i = lane; i < nl; i += 64) {
-					const RgXSeed td = W.sd[i];
+					const RgXSeed td = Lsd[i];
 					if (td.qbeg >= R.qb && td.qbeg + td.len <= R.qe && td.rbeg >= R.rb && td.rbeg + td.len <= R.re) cov += td.len;
 				}
 				R.seedcov = uni(wave_sum_i32(cov));

@@ -52,3 +52,9 @@ extern "C" int hostlogic_seed(const bsx_index_t *idx, const bsx_opt_t *opt, cons
 	out_off[n] = tot;
 	return 0;
 }
+
+// dev_fetch_window as the 64 lanes of a wave run it (the region kernels' reference window in LDS)
+extern "C" void hostlogic_window(const uint8_t *pac, int64_t l_pac, int64_t beg, int span, uint8_t *win)
+{
+	for (int lane = 0; lane < 64; ++lane) dev_fetch_window(win, pac, l_pac, beg, span, lane);
+}

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _harness():
     so = os.path.join(ROOT, "tests", "_build", "libhostlogic.so")
     src = os.path.join(ROOT, "tests", "host_kernel_logic.cpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    deps = [src] + [os.path.join(ROOT, "biscuit_amd", "csrc", "hip", h) for h in ("seed_core.hpp", "dev_common.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(so), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + ROOT + "/include", "-I" + ROOT + "/biscuit_amd/csrc/host",
                                "-I" + ROOT + "/biscuit_amd/csrc/hip", src, "-o", so, "-L" + ROOT + "/biscuit_amd", "-lbiscuit_amd",
@@ -42,3 +43,26 @@ def test_seed_fsm_equals_oracle(small_index, port):
         assert (po == off).all() and (pi == out[:len(pi)]).all()
         assert pc[0] == ctr[0] and pc[1] == ctr[1]    # identical FM-block touch counts (algorithmic bytes)
         assert len(pi) > 1000
+
+
+def test_reference_window_fetch():
+    """dev_fetch_window (a dword of pac per lane, either strand) against the base-by-base definition, bntseq.h _get_pac
+    and bns_get_seq's reverse-complement rule (bntseq.c:373-391)."""
+    H = _harness()
+    rng = np.random.default_rng(5)
+    l_pac = 4099
+    bases = rng.integers(0, 4, l_pac).astype(np.uint8)
+    pac = np.zeros(l_pac // 4 + 1 + 16, np.uint8)
+    for i, b in enumerate(bases):
+        pac[i >> 2] |= b << ((~i & 3) << 1)
+    both = np.concatenate([bases, 3 - bases[::-1]])
+    cases = [(0, 1), (0, 768), (l_pac - 1, 1), (l_pac, 1), (2 * l_pac - 768, 768), (l_pac - 300, 300), (l_pac, 300), (3, 13), (l_pac + 3, 13)]
+    for _ in range(2000):
+        span = int(rng.integers(1, 769))
+        beg = int(rng.integers(0, l_pac - span + 1)) + (l_pac if rng.random() < .5 else 0)
+        cases.append((beg, span))
+    for beg, span in cases:
+        win = np.full(span + 8, 0xee, np.uint8)
+        H.hostlogic_window(pac.ctypes.data_as(C.c_void_p), C.c_int64(l_pac), C.c_int64(beg), C.c_int(span), win.ctypes.data_as(C.c_void_p))
+        assert (win[:span] == both[beg:beg + span]).all(), (beg, span)
+        assert (win[span:] == 0xee).all()
