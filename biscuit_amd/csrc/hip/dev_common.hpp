@@ -50,6 +50,7 @@ struct DevScoring {        // set by bsx_device_set_opt
 	int8_t ctmat[25];
 	int8_t gamat[25];
 	int32_t o_del, e_del, o_ins, e_ins, zdrop, a;
+	int32_t mx_ct, mx_ga;      // the largest entry of each matrix (ksw_extend2's band clamp, ksw.c:399-407)
 };
 
 // reference base at forward-reverse coordinate p (bns_get_seq, lib/aln/bntseq.c:402-422)

@@ -151,11 +151,9 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 {   // win: the reference bases [win_beg, ...) already in LDS, one byte each, covering every row of this job (else HBM)
     // qlds: the read already in LDS, qlds[k] = reads[qlds_off + k] (else the chunk's read buffer in HBM)
 	const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
-	// the 5x5 matrix of this strand as 25 scalars (constant indices: scalar loads, hoisted); indexing the kernel
-	// argument with a run-time index instead would be five vector loads from memory in every row
-	int mt[25];
-#pragma unroll
-	for (int k = 0; k < 25; ++k) mt[k] = J.parent ? sc.ctmat[k] : sc.gamat[k];
+	// the lane's column of this strand's 5x5 matrix: five byte loads per register slot from the kernel's argument block, once per
+	// job (as 25 scalars selected per lane it was a hundred scalar instructions and 25 scalar registers in kernels that spill them)
+	const int8_t *mat = J.parent ? sc.ctmat : sc.gamat;
 	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = sc.zdrop;
 	int Hr[NC], Er[NC], sq[NC][5];   // sq[c][t]: score of this lane's query base of chunk c against target base t
@@ -164,14 +162,12 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 		const int a = (c << 6) + lane;
 		const int q = a < qlen ? (qlds ? (int)qlds[(int)(J.qoff - qlds_off) + a * J.qdir] : (int)reads[(long long)J.qoff + (long long)a * J.qdir]) : 4;
 #pragma unroll
-		for (int t = 0; t < 5; ++t) sq[c][t] = q == 0 ? mt[t * 5] : q == 1 ? mt[t * 5 + 1] : q == 2 ? mt[t * 5 + 2] : q == 3 ? mt[t * 5 + 3] : mt[t * 5 + 4];
+		for (int t = 0; t < 5; ++t) sq[c][t] = mat[t * 5 + q];   // q <= 4
 		const int v = a == 0 ? h0 : h0 - oe_ins - (a - 1) * e_ins;   // first row (ksw.c:395-397)
 		Hr[c] = (a <= qlen && v > 0) ? v : 0;
 		Er[c] = 0;
 	}
-	int mx = 0;
-#pragma unroll
-	for (int k = 0; k < 25; ++k) mx = mx > mt[k] ? mx : mt[k];
+	const int mx = J.parent ? sc.mx_ct : sc.mx_ga;
 	int w = J.w;
 	{ // band clamp (ksw.c:399-407)
 		int max_ins = (int)((double)(qlen * mx + J.end_bonus - o_ins) / e_ins + 1.);

@@ -266,6 +266,8 @@ static int lane_set_opt(bsx_device_t *d, int lane, const bsx_opt_t *o)
 	DevScoring &sc = d->lane[lane].sc;
 	memcpy(sc.ctmat, o->ctmat, 25); memcpy(sc.gamat, o->gamat, 25);
 	sc.o_del = o->o_del; sc.e_del = o->e_del; sc.o_ins = o->o_ins; sc.e_ins = o->e_ins; sc.zdrop = o->zdrop; sc.a = o->a;
+	sc.mx_ct = sc.mx_ga = 0;   // as ksw_extend2 computes it: the maximum starts from 0
+	for (int k = 0; k < 25; ++k) { sc.mx_ct = std::max<int>(sc.mx_ct, sc.ctmat[k]); sc.mx_ga = std::max<int>(sc.mx_ga, sc.gamat[k]); }
 	return BSX_OK;
 }
 extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o) { return lane_set_opt(d, 0, o); }   // the batch calls of include/bsx.h run on lane 0
