@@ -896,31 +896,40 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(S.n_regs);
-				for (u = 0; u < nr; ++u) {
-					const bsx_region_t &rg = S.regs[u];
-					if (s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) continue;
-					if (s_len - rg.seedlen0 > .1 * l_query) continue;
-					int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
-					int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-					int w = max_gap < rg.w ? max_gap : rg.w;
-					if (qd - rd < w && rd - qd < w) break;
-					qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
-					max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-					w = max_gap < rg.w ? max_gap : rg.w;
-					if (qd - rd < w && rd - qd < w) break;
-				}
-				u = uni(u);
-				if (u < nr) {
-					int i;
-					for (i = k + 1; i < nl; ++i) {
-						if (S.srt[i] == 0) continue;
-						const int oo = S.lst[(int)(uint32_t)S.srt[i]];
-						const long long t_rbeg = S.s_rbeg[oo]; const int t_qbeg = S.s_qbeg[oo], t_len = S.s_len[oo];
-						if (t_len < s_len * .95) continue;
-						if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
-						if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) break;
+				u = nr;
+				for (int base = 0; base < nr && u == nr; base += 64) { // a lane per region made so far: the reference's loop stops at the first that passes
+					bool hit = false;
+					if (base + lane < nr) {
+						const bsx_region_t &rg = S.regs[base + lane];
+						if (!(s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) && !(s_len - rg.seedlen0 > .1 * l_query)) {
+							int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
+							int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+							int w = max_gap < rg.w ? max_gap : rg.w;
+							hit = qd - rd < w && rd - qd < w;
+							qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
+							max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+							w = max_gap < rg.w ? max_gap : rg.w;
+							hit = hit || (qd - rd < w && rd - qd < w);
+						}
 					}
-					if (uni(i) == nl) { WAVE_SYNC(); if (lane == 0) S.srt[k] = 0; WAVE_SYNC(); continue; }
+					const unsigned long long hm = __ballot(hit);
+					if (hm) u = base + (int)__builtin_ctzll(hm);
+				}
+				if (u < nr) { // a later seed of the list (in sorted order) that may lead to a different alignment?  A lane per seed
+					bool any = false;
+					for (int base = k + 1; base < nl && !any; base += 64) {
+						const int i = base + lane;
+						bool alt = false;
+						if (i < nl && S.srt[i] != 0) {
+							const int oo = S.lst[(int)(uint32_t)S.srt[i]];
+							const long long t_rbeg = S.s_rbeg[oo]; const int t_qbeg = S.s_qbeg[oo], t_len = S.s_len[oo];
+							if (!(t_len < s_len * .95))
+								alt = (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) ||
+								      (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg);
+						}
+						any = __ballot(alt) != 0;
+					}
+					if (!any) { WAVE_SYNC(); if (lane == 0) S.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
@@ -1106,31 +1115,39 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(W.n_regs);
-				for (u = 0; u < nr; ++u) {
-					const bsx_region_t &rg = W.regs[u];
-					if (s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) continue;
-					if (s_len - rg.seedlen0 > .1 * l_query) continue;
-					int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
-					int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-					int w = max_gap < rg.w ? max_gap : rg.w;
-					if (qd - rd < w && rd - qd < w) break;
-					qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
-					max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-					w = max_gap < rg.w ? max_gap : rg.w;
-					if (qd - rd < w && rd - qd < w) break;
-				}
-				u = uni(u);
-				if (u < nr) {
-					int i;
-					for (i = k + 1; i < nl; ++i) {
-						if (W.srt[i] == 0) continue;
-						const RgXSeed td = Lsd[(int)(uint32_t)W.srt[i]];
-						const long long t_rbeg = td.rbeg; const int t_qbeg = td.qbeg, t_len = td.len;
-						if (t_len < s_len * .95) continue;
-						if (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) break;
-						if (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg) break;
+				{ // a lane per region made so far (nr <= RG_XREGS <= 64): the reference's loop stops at the first region that passes
+					bool hit = false;
+					if (lane < nr) {
+						const bsx_region_t &rg = W.regs[lane];
+						if (!(s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) && !(s_len - rg.seedlen0 > .1 * l_query)) {
+							int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
+							int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+							int w = max_gap < rg.w ? max_gap : rg.w;
+							hit = qd - rd < w && rd - qd < w;
+							qd = rg.qe - (s_qbeg + s_len); rd = rg.re - (s_rbeg + s_len);
+							max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
+							w = max_gap < rg.w ? max_gap : rg.w;
+							hit = hit || (qd - rd < w && rd - qd < w);
+						}
 					}
-					if (uni(i) == nl) { WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
+					const unsigned long long hm = __ballot(hit);
+					u = hm ? (int)__builtin_ctzll(hm) : nr;
+				}
+				if (u < nr) { // is there a later seed of the list (in sorted order) that may lead to a different alignment?  A lane per seed
+					bool any = false;
+					for (int base = k + 1; base < nl && !any; base += 64) {
+						const int i = base + lane;
+						bool alt = false;
+						if (i < nl && W.srt[i] != 0) {
+							const RgXSeed td = Lsd[(int)(uint32_t)W.srt[i]];
+							const long long t_rbeg = td.rbeg; const int t_qbeg = td.qbeg, t_len = td.len;
+							if (!(t_len < s_len * .95))
+								alt = (s_qbeg <= t_qbeg && s_qbeg + s_len - t_qbeg >= s_len >> 2 && t_qbeg - s_qbeg != t_rbeg - s_rbeg) ||
+								      (t_qbeg <= s_qbeg && t_qbeg + t_len - s_qbeg >= s_len >> 2 && s_qbeg - t_qbeg != s_rbeg - t_rbeg);
+						}
+						any = __ballot(alt) != 0;
+					}
+					if (!any) { WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
