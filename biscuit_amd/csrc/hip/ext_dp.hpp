@@ -156,13 +156,14 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 	const int8_t *mat = J.parent ? sc.ctmat : sc.gamat;
 	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = sc.zdrop;
-	int Hr[NC], Er[NC], sq[NC][5];   // sq[c][t]: score of this lane's query base of chunk c against target base t
+	int Hr[NC], Er[NC], sq4[NC];
+	uint32_t sqp[NC];   // scores of this lane's query base of slot c against target bases 0..3, a byte each (the matrix is int8); sq4: against base 4
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		const int a = (c << 6) + lane;
 		const int q = a < qlen ? (qlds ? (int)qlds[(int)(J.qoff - qlds_off) + a * J.qdir] : (int)reads[(long long)J.qoff + (long long)a * J.qdir]) : 4;
-#pragma unroll
-		for (int t = 0; t < 5; ++t) sq[c][t] = mat[t * 5 + q];   // q <= 4
+		sqp[c] = (uint32_t)(uint8_t)mat[q] | (uint32_t)(uint8_t)mat[5 + q] << 8 | (uint32_t)(uint8_t)mat[10 + q] << 16 | (uint32_t)(uint8_t)mat[15 + q] << 24;   // q <= 4
+		sq4[c] = mat[20 + q];
 		const int v = a == 0 ? h0 : h0 - oe_ins - (a - 1) * e_ins;   // first row (ksw.c:395-397)
 		Hr[c] = (a <= qlen && v > 0) ? v : 0;
 		Er[c] = 0;
@@ -194,7 +195,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 		if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
 		int m = 0, mj = -1, h1_last = h1_init;
 		if (beg < end) {
-			const int c0 = beg >> 6, c1 = (end - 1) >> 6;
+			const int c0 = NC == 1 ? 0 : beg >> 6, c1 = NC == 1 ? 0 : (end - 1) >> 6;   // one slot: every test on c folds away
 			int hn[NC];
 			int carry = NEG_BIG, lm = -1, lj = -1;
 #pragma unroll
@@ -203,7 +204,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 				if (c >= c0 && c <= c1) {
 					const int a = (c << 6) + lane;
 					const bool act = a >= beg && a < end;
-					const int s = t == 0 ? sq[c][0] : t == 1 ? sq[c][1] : t == 2 ? sq[c][2] : t == 3 ? sq[c][3] : sq[c][4];
+					const int s = t < 4 ? (int)(int8_t)(sqp[c] >> ((t & 3) << 3)) : sq4[c];   // one bit-field extract by a scalar shift
 					const int M = (act && Hr[c]) ? Hr[c] + s : 0;
 					int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
 					const int g = act ? tins + a * e_ins : NEG_BIG;
@@ -225,7 +226,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 				}
 			}
 			// eh[end].e = 0 when `end` opens a chunk the loop above did not visit
-			if ((end & 63) == 0 && (end >> 6) < NC && (end >> 6) > c1) {
+			if (NC > 1 && (end & 63) == 0 && (end >> 6) < NC && (end >> 6) > c1) {
 #pragma unroll
 				for (int c = 0; c < NC; ++c) if (c == (end >> 6) && lane == 0) Er[c] = 0;
 			}
@@ -274,7 +275,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 			int nb = end, last;
 #pragma unroll
 			for (int c = 0; c < NC; ++c) {
-				if (nb == end && c >= (beg >> 6) && c <= ((end - 1) >> 6)) {
+				if (NC == 1 || (nb == end && c >= (beg >> 6) && c <= ((end - 1) >> 6))) {
 					const int a = (c << 6) + lane;
 					const unsigned long long b = __ballot(a >= beg && a < end && (Hr[c] != 0 || Er[c] != 0));
 					if (b) nb = (c << 6) + __builtin_ctzll(b);
@@ -283,7 +284,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 			last = nb - 1;
 #pragma unroll
 			for (int c = NC - 1; c >= 0; --c) {
-				if (last == nb - 1 && c <= (end >> 6) && c >= (nb >> 6)) {
+				if (NC == 1 || (last == nb - 1 && c <= (end >> 6) && c >= (nb >> 6))) {
 					const int a = (c << 6) + lane;
 					const unsigned long long b = __ballot(a <= end && a >= nb && (Hr[c] != 0 || Er[c] != 0));
 					if (b) last = (c << 6) + 63 - __builtin_clzll(b);
