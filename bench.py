@@ -302,7 +302,7 @@ def main():
 
     roof = roof_of("k_seed (K1+K2 SMEM seeding: dependent random 64-B FM-block gathers)", 0, 64.0 * (ctr[0] + ctr[1]),
                    {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps),
-                    "what_bounds_it": "not HBM: a trip of the wave loop is one dependent gather plus ~1.3 k instructions of per-lane state machine issued in order by one wave, and the registers allow three waves per SIMD; see DESIGN.md"}, "k_seed")
+                    "what_bounds_it": "not HBM (a fifth of the peak) nor the issue rates (a third): a trip of the wave loop is one dependent gather plus ~1.2 k instructions of per-lane state machine that one wave issues in order, a dozen cycles apiece, and 158 VGPRs + 11 KB of LDS allow three waves per SIMD; see DESIGN.md"}, "k_seed")
     roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
                          {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)}, "k_occ")
 
