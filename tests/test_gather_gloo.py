@@ -18,10 +18,6 @@ def _blob(k, big):
     return rng.integers(0, 256, size=n, dtype=np.uint8)
 
 
-def rank_warms(n_chunks):
-    return n_chunks % 2 == 0
-
-
 def _worker(rank, world, n_chunks, big, init, outdir):
     from biscuit_amd.gather import ChunkGather
     dist.init_process_group("gloo", init_method="file://" + init, rank=rank, world_size=world)
@@ -32,7 +28,7 @@ def _worker(rank, world, n_chunks, big, init, outdir):
         for k in range(rank, n_chunks, world):
             G.submit(k, _blob(k, big))
         G.close()
-    G.warm(1 << 16 if rank_warms(n_chunks) else 1)   # the connection-making round before the data (collective)
+    G.warm(1 << 16 if n_chunks % 2 == 0 else 1)   # the connection-making round before the data (collective; any size)
     th = threading.Thread(target=produce)
     th.start()
     seen = G.run()
