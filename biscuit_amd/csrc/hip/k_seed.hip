@@ -140,7 +140,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.mem = reinterpret_cast<DevIntv*>(slab_base);
 	L.bufA = reinterpret_cast<SeedEnt*>(slab_base + (size_t)64 * mem_cap * sizeof(DevIntv));
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
-	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (<= 256 bases)
+	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (reads of up to SEED_LDS_WORDS * 8 bases; longer ones are read where they lie)
 	__shared__ uint32_t s_read[SEED_WPB][SEED_LDS_WORDS][64];
 	__shared__ SeedXchg s_xchg[SEED_WPB];
 	SeedXchg &X = s_xchg[threadIdx.x >> 6];
