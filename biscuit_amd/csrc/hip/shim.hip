@@ -137,6 +137,8 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
 		if (L.ev1) (void)hipEventDestroy(L.ev1);
 		if (L.ev2) (void)hipEventDestroy(L.ev2);
+		if (L.ev_seed_done) (void)hipEventDestroy(L.ev_seed_done);
+		if (L.ev_regions_done) (void)hipEventDestroy(L.ev_regions_done);
 		if (L.st) (void)hipStreamDestroy(L.st);
 		if (L.st_hi) (void)hipStreamDestroy(L.st_hi);
 		if (L.st2) (void)hipStreamDestroy(L.st2);

@@ -252,6 +252,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 	int64_t n_processed = 0;
 	const uint8_t *nt4 = bsx_nt4_table();
 
+	g_write_error = 0;   /* per call: a failed write of an earlier call in this process must not fail this one */
 	if (getenv("BSX_DEVICE")) device = atoi(getenv("BSX_DEVICE"));
 	bsx_opt_init(opt);
 	opt->flag |= BSX_F_NO_MULTI;   /* align.c:335 */
@@ -458,11 +459,15 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			}
 			if (rc) { chunk_rec_t d; while (cq_get(&in_q, &d)) { for (i = 0; i < d.n; ++i) bsx_read_free(&d.seqs[i]); free(d.seqs); } }   /* let the reader finish */
 			if (rc == 0 && (rc = bsx_stream_flush(stream)) != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+			/* after an error chunks are still in flight: closing the stream joins their front halves and runs their back halves, which
+			 * read the pending chunks' reads -- so close it before those reads go to the writer (which frees them) */
+			if (rc) { bsx_stream_close(stream); stream = 0; }
 			for (i = 0; i < n_pend; ++i) { chunk_rec_t d; d.seqs = pend[i].seqs; d.n = pend[i].n; d.idx = pend[i].idx; d.ok = rc == 0; cq_put(&out_q, d); }
 			n_pend = 0;
 			cq_close(&out_q);
 			pthread_join(th_r, 0); pthread_join(th_w, 0);
-			bsx_stream_close(stream); stream = 0;
+			if (stream) bsx_stream_close(stream);
+			stream = 0;
 			goto loop_done;
 		}
 		for (;;) {
@@ -514,6 +519,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 					emit_chunk(pend[0].seqs, pend[0].n, pend[0].idx, 1);
 					for (i = 1; i < n_pend; ++i) pend[i - 1] = pend[i];
 					--n_pend;
+					if (g_write_error) rc = 1;
 				}
 				if (rc) break;
 				continue;
@@ -526,8 +532,9 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 		}
 		if (stream) {
 			if (rc == 0 && (rc = bsx_stream_flush(stream)) != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+			if (rc) { bsx_stream_close(stream); stream = 0; }   /* as above: before the pending reads are freed */
 			for (i = 0; i < n_pend; ++i) emit_chunk(pend[i].seqs, pend[i].n, pend[i].idx, rc == 0);
-			bsx_stream_close(stream);
+			if (stream) bsx_stream_close(stream);
 		}
 loop_done: ;
 	}

@@ -512,6 +512,7 @@ static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const re
 	re = reg->rb + C->pes.high; re = re < l_pac << 1 ? re : l_pac << 1;
 	if (rb < re) rid = bsx_fetch_span(ref, &rb, (rb + re) >> 1, &re);
 	if (reg->rid != rid || re - rb < opt->min_seed_len) return 0;
+	if (l_ms <= 0) return 0;   /* a mate clipped away entirely: ksw_align2 of an empty query scores 0 and reports no start (ksw.c:343-365), so nothing is added */
 	parent = reg->bss ^ (reg->rb < l_pac);
 	xtra = BSX_KSW_XSUBO | BSX_KSW_XSTART | (l_ms * opt->a < 250 ? BSX_KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
 	for (k = 0; k < M->slots.n; ++k) if (M->slots.a[k].i == i && M->slots.a[k].j == j) { slot = &M->slots.a[k]; break; }
