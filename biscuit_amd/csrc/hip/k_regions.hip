@@ -1278,8 +1278,8 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 //   k_c2r_ctrl   a lane per strand search: mem_chain2region(1) (memchain.c:742-904) as a resumable state machine; it runs until the
 //                strand search needs an extension (posts one job: left or right side of one seed, one band width) or is finished
 //                (publishes its regions)
-//   k_ext_lane   a lane per job: ksw_extend2 (ksw.c:380-479) cell by cell; the eh[] row of the job lives in LDS, one 32-bit word
-//                per column (H 14 bits, E 14 bits, the query base 3 bits), lane-interleaved
+//   k_ext_q      a row of 16 lanes per job, four jobs per wavefront: ksw_extend2 (ksw.c:380-479) with the DP rows in registers and
+//                nothing in scalar registers (k_extq.hip)
 // and the two alternate: round r extends the r-th call of every strand search that has one.  State between rounds lives in HBM.
 // A strand search whose lists or region table outgrow the fixed slots, or that is still going after RG_LROUNDS rounds, is
 // handed to the HBM tier like any other that outgrows a tier.
@@ -1479,7 +1479,7 @@ k_c2r_ctrl(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, Rg
 		else { S = W.state[slot]; res = W.res[in][e]; }
 		bsx_ext_job_t J;
 		int st = round + 1 >= RG_LROUNDS ? -6 : rgl_step(S, W.regs + (size_t)slot * RG_LREGS, W.rank + (size_t)slot * RG_LSEEDS, ix, P, l_query, parent, qoff, H, gap_tab, ctg, round != 0, res, J);
-		if (round != 0 && res.score == -0x7fffffff) st = -6;   // the extension did not fit the lane kernel's number format
+		if (round != 0 && res.score == EXTQ_DECLINED) st = -6;   // the extension did not fit the quarter-wave kernel's rows or number format
 		if (st == 1) {
 			const unsigned int o = atomicAdd(&W.n_act[round], 1u);
 			W.act[ob][o] = slot; W.jobs[ob][o] = J;
@@ -1500,277 +1500,6 @@ k_c2r_ctrl(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, Rg
 	}
 }
 
-// ksw_extend2 (lib/aln/ksw.c:380-479), one job per lane at a time.  The reference's two nested loops (rows, columns of the band)
-// are turned inside out into a per-lane state machine that does ONE cell per trip of the wave loop: lanes are in different rows and
-// at different columns of bands of different widths, and a wave that ran the loops as written would pay rows(longest job) x
-// band(widest row) -- measured 6x the cells of the average lane.  Lanes take the next job from the round's queue as soon as they
-// finish one, so a wave stays full until the queue drains.  The rare states (next job, next row) run every fourth trip or when many
-// lanes wait, as in k_seed: a wave pays for every state one of its lanes is in.  Nothing in the loop waits for HBM: k_ext_pack
-// (a lane per job, at full occupancy) has gathered the job's query and reference bases into the image of the first DP row.
-// A row lives in this wave's LDS, column j of this lane at eh[j * 64 + lane], one word per column:
-//   bits 0-10 H (the reference's eh[j].h), 11-21 E (eh[j].e), 22-24 the query base of column j, 25-30 the reference bases of rows
-//   3j, 3j+1, 3j+2.  A job never computes more than qlen + w + 1 rows (then the band is empty, ksw.c:418,454) and the band clamp
-//   keeps w <= qlen + a few, so three rows per column hold every row of any job with qlen >= 3; the ones with qlen <= 2 (a few cells)
-//   are done by k_ext_pack itself.
-#define EHL_H(x) ((int)((x) & 0x7ff))
-#define EHL_E(x) ((int)(((x) >> 11) & 0x7ff))
-#define EHL_KEEP 0x7fc00000u
-#define EHL_HE 0x003fffffu
-enum { XL_FETCH = 0, XL_ROW, XL_CELL, XL_ROWEND, XL_SHL, XL_SHR, XL_DONE };
-struct RgLJobHdr { int qlen, tlen, h0, w, moff, decl, pad0, pad1; };   // moff: 0 ctmat, 25 gamat; decl: 1 not for this kernel, 2 done by k_ext_pack
-
-// the job as k_ext_lane wants it: band clamp applied (ksw.c:399-407), first row (ksw.c:395-397) with the bases packed in
-__global__ void __launch_bounds__(256)
-k_ext_pack(DevIndex ix, DevScoring sc, const uint8_t *reads, RgLanes W, int round, int qcap, uint32_t *rows, int row_words)
-{
-	const unsigned int n = W.n_act[round];
-	const int b = round & 1;
-	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-		const bsx_ext_job_t J = W.jobs[b][e];
-		const int8_t *mat = J.parent ? sc.ctmat : sc.gamat;
-		const int qlen = J.qlen, tlen = J.tlen, h0 = J.h0;
-		const int oe_ins = sc.o_ins + sc.e_ins;
-		int mx = 0;
-		for (int k = 0; k < 25; ++k) mx = mx > mat[k] ? mx : mat[k];
-		RgLJobHdr Hd;
-		Hd.qlen = qlen; Hd.tlen = tlen; Hd.h0 = h0; Hd.moff = J.parent ? 0 : 25; Hd.pad0 = Hd.pad1 = 0;
-		int w = J.w;
-		{
-			int max_ins = (int)((double)(qlen * mx + J.end_bonus - sc.o_ins) / sc.e_ins + 1.);
-			max_ins = max_ins > 1 ? max_ins : 1;
-			w = w < max_ins ? w : max_ins;
-			int max_del = (int)((double)(qlen * mx + J.end_bonus - sc.o_del) / sc.e_del + 1.);
-			max_del = max_del > 1 ? max_del : 1;
-			w = w < max_del ? w : max_del;
-		}
-		Hd.w = w;
-		const int need = tlen < qlen + w + 2 ? tlen : qlen + w + 2;   // rows that can hold a cell
-		Hd.tlen = need;
-		Hd.decl = (qlen > qcap || qlen + 1 + 8 > row_words || (long long)h0 + (long long)qlen * mx >= 2000) ? 1 : 0;
-		if (!Hd.decl && need > 3 * (qlen + 1)) { // qlen <= 2 in practice: a handful of cells, done here with the loops as the reference has them
-			if (qlen > 7) Hd.decl = 1;
-			else {
-				int hh[9], ee[9];
-				for (int c = 0; c <= 8; ++c) { int v = c == 0 ? h0 : h0 - oe_ins - (c - 1) * sc.e_ins; hh[c] = (c <= qlen && v > 0) ? v : 0; ee[c] = 0; }
-				int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0, beg = 0, end = qlen;
-				const int oe_del = sc.o_del + sc.e_del;
-				for (int i = 0; i < tlen; ++i) {
-					const int t = dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)i * J.tdir);
-					int f = 0, m = 0, mj = -1, h1;
-					if (beg < i - w) beg = i - w;
-					if (end > i + w + 1) end = i + w + 1;
-					if (end > qlen) end = qlen;
-					if (beg == 0) { h1 = h0 - (sc.o_del + sc.e_del * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
-					int j;
-					for (j = beg; j < end; ++j) {
-						const int q = reads[(long long)J.qoff + (long long)j * J.qdir];
-						int M = hh[j], e = ee[j];
-						hh[j] = h1;
-						M = M ? M + mat[t * 5 + q] : 0;
-						int h = M > e ? M : e; h = h > f ? h : f;
-						h1 = h;
-						mj = m > h ? mj : j; m = m > h ? m : h;
-						int tt = M - oe_del; tt = tt > 0 ? tt : 0;
-						e -= sc.e_del; e = e > tt ? e : tt; ee[j] = e;
-						tt = M - oe_ins; tt = tt > 0 ? tt : 0;
-						f -= sc.e_ins; f = f > tt ? f : tt;
-					}
-					hh[end] = h1; ee[end] = 0;
-					if (j == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
-					if (m == 0) break;
-					if (m > max) { max = m; max_i = i; max_j = mj; int off = mj - i; off = off < 0 ? -off : off; max_off = max_off > off ? max_off : off; }
-					else if (sc.zdrop > 0) {
-						if (i - max_i > mj - max_j) { if (max - m - ((i - max_i) - (mj - max_j)) * sc.e_del > sc.zdrop) break; }
-						else { if (max - m - ((mj - max_j) - (i - max_i)) * sc.e_ins > sc.zdrop) break; }
-					}
-					for (j = beg; j < end && hh[j] == 0 && ee[j] == 0; ++j);
-					beg = j;
-					for (j = end; j >= beg && hh[j] == 0 && ee[j] == 0; --j);
-					end = j + 2 < qlen ? j + 2 : qlen;
-				}
-				bsx_ext_res_t r;
-				r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-				W.res[b][e] = r;
-				Hd.decl = 2;
-			}
-		}
-		uint32_t *row = rows + (size_t)e * row_words;   // words 0-7: the header; then one word per column
-		*(RgLJobHdr*)row = Hd;
-		if (Hd.decl) continue;
-		row += 8;
-		for (int c = 0; c <= qlen; ++c) {
-			int v = c == 0 ? h0 : h0 - oe_ins - (c - 1) * sc.e_ins;
-			v = v > 0 ? v : 0;
-			const uint32_t q = c < qlen ? reads[(long long)J.qoff + (long long)c * J.qdir] : 4u;
-			uint32_t tb = 0;
-			for (int k = 0; k < 3; ++k) if (3 * c + k < need) tb |= (uint32_t)dev_ref_base(ix.pac, ix.l_pac, J.tpos + (long long)(3 * c + k) * J.tdir) << (2 * k);
-			row[c] = (uint32_t)v | q << 22 | tb << 25;
-		}
-	}
-}
-
-#define XL_IMG 40   // uint4 per job image: 8 header words + up to 152 columns
-__global__ void __launch_bounds__(64)
-k_ext_lane(DevScoring sc, RgLanes W, int round, const uint32_t *rows, int row_words, unsigned long long *prof)
-{
-	extern __shared__ uint32_t eh_lds[];   // (row_words - 8) x 64 words
-	__shared__ int8_t smat[64];
-	if (threadIdx.x < 25) { smat[threadIdx.x] = sc.ctmat[threadIdx.x]; smat[25 + threadIdx.x] = sc.gamat[threadIdx.x]; }
-	__syncthreads();
-	const unsigned int n = W.n_act[round];
-	const int b = round & 1;
-	unsigned int *cursor = W.n_act + 192 + round;   // next job of this round
-	uint32_t *eh = eh_lds + threadIdx.x;
-	const int lane = (int)threadIdx.x;
-	const int o_del = sc.o_del, e_del = sc.e_del, e_ins = sc.e_ins;
-	const int oe_del = o_del + e_del, oe_ins = sc.o_ins + e_ins, zdrop = sc.zdrop;
-	int state = XL_FETCH;
-	unsigned int e = 0;
-	int qlen = 0, tlen = 0, h0 = 0, w = 0, moff = 0;
-	int i = 0, j = 0, beg = 0, end = 0, f = 0, m = 0, mj = -1, h1 = 0;
-	int max = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-	uint32_t srow = 0;   // the five scores of the current row, 6 bits each, biased by 32
-	int ti_cell = 0, ti_slot = 0;   // where the next row's reference base sits: column i / 3, slot i % 3
-	unsigned int n_rows = 0, n_cells = 0, n_jobs = 0, trip = 0;
-	const long long t0 = (long long)__builtin_readcyclecounter();
-	// Jobs are claimed 128 at a time per wave (one atomic, its answer not needed before the range in hand runs out), and every lane
-	// holds the image of its NEXT job in registers, loaded while it works on the current one: nothing in the loop waits for HBM.
-	// the wave's ranges live in LDS (one wave per workgroup): [0] next index to hand out, [1] end of the range in hand, [2] start of the
-	// range claimed ahead.  Any lane may be the one that moves them on: lane 0 is often busy with a cell when others want a job.
-	__shared__ unsigned int pool[4];   // (the wave fence in XL_CLAIM makes other lanes' updates visible to the next claim)
-	if (lane == 0) { const unsigned int a0 = atomicAdd(cursor, 128u), a1 = atomicAdd(cursor, 128u); pool[0] = a0; pool[1] = a0 + 128u; pool[2] = a1; }
-	__syncthreads();
-	uint4 img[XL_IMG];
-	unsigned int e_nxt = 0; bool nxt_valid = false;
-#define XL_CLAIM(want) do { /* lanes with `want` take the next indices of the wave's ranges, in lane order */ \
-		const unsigned long long wm_ = __ballot(want); \
-		if (wm_) { \
-			const unsigned int take_ = (unsigned int)__popcll(wm_), rank_ = (unsigned int)__popcll(wm_ & ((1ull << lane) - 1)); \
-			const unsigned int c0_ = pool[0], c1_ = pool[1], n0_ = pool[2], left_ = c1_ - c0_; \
-			if (want) e_nxt = rank_ < left_ ? c0_ + rank_ : n0_ + (rank_ - left_); \
-			if (lane == __ffsll((long long)wm_) - 1) { \
-				if (take_ > left_) { pool[0] = n0_ + (take_ - left_); pool[1] = n0_ + 128u; pool[2] = atomicAdd(cursor, 128u); } \
-				else pool[0] = c0_ + take_; \
-			} \
-			WAVE_SYNC(); \
-			if (want) { \
-				nxt_valid = e_nxt < n; \
-				if (nxt_valid) { const uint4 *src_ = (const uint4*)(rows + (size_t)e_nxt * row_words); _Pragma("unroll") for (int g = 0; g < XL_IMG; ++g) img[g] = src_[g]; } \
-			} \
-		} } while (0)
-	XL_CLAIM(true);
-	long long c_hot = 0, c_cold = 0; unsigned int n_cold = 0;
-	for (;;) {
-		++trip;
-		const long long tc0 = prof ? (long long)__builtin_readcyclecounter() : 0;
-		// ---- every trip: a cell, or a step of the band shrink
-		if (state == XL_CELL) {
-			const uint32_t x = eh[j * 64];
-			const int q = (int)((x >> 22) & 7u);
-			int M = EHL_H(x), ee = EHL_E(x);
-			const int s = (int)((srow >> (6 * q)) & 63u) - 32;
-			M = M ? M + s : 0;
-			int h = M > ee ? M : ee;
-			h = h > f ? h : f;
-			mj = m > h ? mj : j;
-			m = m > h ? m : h;
-			int tt = M - oe_del; tt = tt > 0 ? tt : 0;
-			ee -= e_del; ee = ee > tt ? ee : tt;
-			eh[j * 64] = (uint32_t)h1 | (uint32_t)ee << 11 | (x & EHL_KEEP);   // H(i,j-1) for the next row, E(i+1,j)
-			h1 = h;
-			tt = M - oe_ins; tt = tt > 0 ? tt : 0;
-			f -= e_ins; f = f > tt ? f : tt;
-			++j; ++n_cells;
-			if (j >= end) state = XL_ROWEND;
-		} else if (state == XL_SHL) { // the band for the next row: the non-zero cells (ksw.c:466-469), from the left ...
-			if (j < end && (eh[j * 64] & EHL_HE) == 0) ++j;
-			else { beg = j; j = end; state = XL_SHR; }
-		} else if (state == XL_SHR) { // ... and from the right
-			if (j >= beg && (eh[j * 64] & EHL_HE) == 0) --j;
-			else { end = j + 2 < qlen ? j + 2 : qlen; state = XL_ROW; }
-		}
-		const long long tc1 = prof ? (long long)__builtin_readcyclecounter() : 0;
-		c_hot += tc1 - tc0;
-		// ---- the rest every fourth trip, or when a third of the wave waits
-		const bool cold = state != XL_CELL && state != XL_SHL && state != XL_SHR && state != XL_DONE;
-		const unsigned long long cm = __ballot(cold);
-		if (cm && ((trip & 3u) == 0 || __popcll(cm) > 20 || cm == __ballot(state != XL_DONE))) ++n_cold;
-		if (cold && ((trip & 3u) == 0 || __popcll(cm) > 20 || cm == __ballot(state != XL_DONE))) {
-			if (state == XL_ROWEND) {
-				{ const uint32_t x = eh[end * 64]; eh[end * 64] = (uint32_t)h1 | (x & EHL_KEEP); }   // eh[end] = {h1, 0}
-				if ((beg < end ? end : beg) == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }   // the column loop ended at j == qlen (ksw.c:450)
-				bool stop = m == 0;
-				if (!stop) {
-					if (m > max) {
-						max = m; max_i = i; max_j = mj;
-						int off = mj - i; off = off < 0 ? -off : off;
-						max_off = max_off > off ? max_off : off;
-					} else if (zdrop > 0) {
-						if (i - max_i > mj - max_j) stop = max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop;
-						else stop = max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop;
-					}
-				}
-				if (stop) { i = tlen; state = XL_ROW; }   // the row loop ends here (ksw.c:454,460-464)
-				else { j = beg; state = XL_SHL; ++i; }
-			}
-			if (state == XL_ROW) {
-				if (i >= tlen) { // job done
-					bsx_ext_res_t r;
-					r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
-					W.res[b][e] = r;
-					state = XL_FETCH;
-				} else {
-					const int t = (int)((eh[ti_cell * 64] >> (25 + (ti_slot << 1))) & 3u);
-					if (++ti_slot == 3) { ti_slot = 0; ++ti_cell; }
-					const int8_t *mt = smat + moff + t * 5;
-					srow = (uint32_t)(mt[0] + 32) | (uint32_t)(mt[1] + 32) << 6 | (uint32_t)(mt[2] + 32) << 12 | (uint32_t)(mt[3] + 32) << 18 | (uint32_t)(mt[4] + 32) << 24;
-					if (beg < i - w) beg = i - w;
-					if (end > i + w + 1) end = i + w + 1;
-					if (end > qlen) end = qlen;
-					if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
-					f = 0; m = 0; mj = -1; j = beg;
-					++n_rows;
-					state = beg < end ? XL_CELL : XL_ROWEND;
-				}
-			}
-			// next jobs: sixteen lanes at a time (or when nothing else is going on).  The images consumed here were loaded at the previous such
-			// event, dozens of trips ago; a wave has ONE counter for its loads in flight, so consuming right after another lane's load was
-			// issued would wait for that one too
-			bool took = false;
-			const unsigned long long fm = __ballot(state == XL_FETCH);
-			if (state == XL_FETCH && (__popcll(fm) >= 16 || fm == __ballot(state != XL_DONE))) { // start the job whose image is in registers, then load the image of the one after it
-				if (!nxt_valid) state = XL_DONE;
-				else {
-					took = true;
-					e = e_nxt;
-					++n_jobs;
-					const int decl = (int)img[1].y;
-					if (decl == 1) { // does not fit this kernel's rows or its number format: the strand search goes to the HBM tier
-						bsx_ext_res_t r; r.score = -0x7fffffff; r.qle = r.tle = r.gtle = r.gscore = r.max_off = 0;
-						W.res[b][e] = r;
-					} else if (decl == 0) {
-						qlen = (int)img[0].x; tlen = (int)img[0].y; h0 = (int)img[0].z; w = (int)img[0].w; moff = (int)img[1].x;
-#pragma unroll
-						for (int g = 2; g < XL_IMG; ++g) if ((g - 2) * 4 <= qlen) { uint32_t *d = eh + (size_t)(g - 2) * 4 * 64; d[0] = img[g].x; d[64] = img[g].y; d[128] = img[g].z; d[192] = img[g].w; }
-						max = h0; max_i = max_j = max_ie = -1; gscore = -1; max_off = 0;
-						beg = 0; end = qlen; i = 0; ti_cell = 0; ti_slot = 0;
-						state = XL_ROW;
-					}
-				}
-			}
-			XL_CLAIM(took);   // whoever just consumed its image
-		}
-		if (prof) c_cold += (long long)__builtin_readcyclecounter() - tc1;
-		if (__ballot(state != XL_DONE) == 0) break;
-	}
-	if (prof && (threadIdx.x & 63) == 0) { atomicAdd(&prof[8], (unsigned long long)c_hot); atomicAdd(&prof[9], (unsigned long long)c_cold); atomicAdd(&prof[10], (unsigned long long)n_cold); }
-	if (prof) { // tracing: jobs, rows, cells (lane sums) and wave cycles
-		const unsigned int mc = (unsigned int)wave_max_i32((int)n_cells);
-		atomicAdd(&prof[0], (unsigned long long)n_jobs); atomicAdd(&prof[1], (unsigned long long)n_rows); atomicAdd(&prof[2], (unsigned long long)n_cells);
-		if ((threadIdx.x & 63) == 0) { atomicAdd(&prof[3], (unsigned long long)((long long)__builtin_readcyclecounter() - t0)); atomicAdd(&prof[4], (unsigned long long)trip); atomicAdd(&prof[5], (unsigned long long)mc); atomicAdd(&prof[6], 1ull); }
-	}
-}
-
 void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                       const RgXPoolArg &XA, const RgLanesArg &WA, long long n_tasks, int max_qlen,
                       bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
@@ -1780,27 +1509,18 @@ void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevSco
 	RgLanes W;
 	W.state = (RgLState*)WA.state; W.regs = (bsx_region_t*)WA.regs; W.rank = WA.rank; W.n_act = WA.n_act;
 	for (int k = 0; k < 2; ++k) { W.act[k] = WA.act[k]; W.jobs[k] = (bsx_ext_job_t*)WA.jobs[k]; W.res[k] = (bsx_ext_res_t*)WA.res[k]; }
-	const int qcap = max_qlen < 151 ? max_qlen : 151;   // columns 0 .. qlen of a job fit the image
-	const int row_words = XL_IMG * 4;   // image of a job: 8 header words + the first DP row (qlen + 1 <= 152 columns)
-	const size_t lds = (size_t)(row_words - 8) * 64 * 4;
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ext_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (RG_QCAP + 48) * 64 * 4); attr_set = true; }
-	uint32_t *rows = (uint32_t*)WA.rows;
-	const int res_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 256)));
 	// grids shrink with the rounds: most strand searches need a handful of extensions (the kernels loop over what is there)
 	for (int r = 0; r < RG_LROUNDS; ++r) {
 		const long long upper = r < 4 ? n_tasks : r < 12 ? n_tasks / 2 + 1 : r < 32 ? n_tasks / 8 + 1 : n_tasks / 64 + 1;
 		const int gc = (int)std::max<long long>(1, std::min<long long>((upper + 255) / 256, (long long)n_cu * 16));
 		hipLaunchKernelGGL(k_c2r_ctrl, dim3(gc), dim3(256), 0, st, ix, P, tasks, X, W, r, out, out_cap, out_cursor, reg_off, reg_n, next_list, next_count);
 		if (r + 1 == RG_LROUNDS) break;
-		hipLaunchKernelGGL(k_ext_pack, dim3(gc), dim3(256), 0, st, ix, sc, reads, W, r, qcap, rows, row_words);
-		const int ge = (int)std::max<long long>(1, std::min<long long>((upper + 63) / 64, (long long)n_cu * res_per_cu));   // persistent lanes: what the LDS rows let be resident
-		hipLaunchKernelGGL(k_ext_lane, dim3(ge), dim3(64), lds, st, sc, W, r, rows, row_words, P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr);
+		// the jobs of round r (count: n_act[r], job cursor: n_act[192 + r]), four per wavefront (k_extq.hip)
+		launch_ext_q(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + r, (unsigned int)upper, W.n_act + 192 + r, max_qlen,
+		             P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr);
 	}
 }
-size_t c2r_lanes_row_words(int max_qlen) { (void)max_qlen; return (size_t)XL_IMG * 4; }
-int c2r_lanes_max_query(void) { return 151; }
-size_t c2r_lanes_hdr_bytes(void) { return sizeof(RgLJobHdr); }
+int c2r_lanes_max_query(void) { return ext_q_max_query(16) < RG_QCAP ? ext_q_max_query(16) : RG_QCAP; }
 size_t c2r_lanes_state_bytes(void) { return sizeof(RgLState); }
 
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.

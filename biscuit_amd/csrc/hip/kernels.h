@@ -17,6 +17,13 @@ void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const u
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                    long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb,
                    bsx_glb_tag_t *tags = nullptr, char *md_pool = nullptr, unsigned long long md_cap = 0, unsigned long long *md_cursor = nullptr, int tcap = 0);
+// K4 in quarter-waves (k_extq.hip): a row of 16 lanes per job, four jobs per wavefront, persistent rows taking jobs[0 .. n) off *cursor
+// (zero at launch); n = *n_ptr (a device counter) if n_ptr, else n_upper, which also sizes the grid.  Jobs it cannot hold (query longer
+// than ext_q_max_query(16), scores of 2^21 or more) are answered with score = EXTQ_DECLINED.
+#define EXTQ_DECLINED (-0x7fffffff)
+int ext_q_max_query(int ncq);
+void launch_ext_q(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, unsigned long long *prof);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
 // Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
 // regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.
@@ -38,10 +45,8 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
 // the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
 // rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
 // (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
-struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; void *hdr, *rows; };   // hdr/rows: packed jobs of a round
+struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; };
 size_t c2r_lanes_state_bytes(void);
-size_t c2r_lanes_hdr_bytes(void);
-size_t c2r_lanes_row_words(int max_qlen);
 int c2r_lanes_max_query(void);   // reads longer than this take the wave-per-strand-search launch (launch_c2r)
 void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                       const RgXPoolArg &X, const RgLanesArg &W, long long n_tasks, int max_qlen,

@@ -29,7 +29,7 @@ struct Lane {
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, lanes_rows, tags, mdpool, dd;
+	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -131,7 +131,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.lanes_rows.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -605,10 +605,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		launch_regions_mid(L.st, (int)((n + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA, mid_quota);
 	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
-	// $BSX_C2R_LANES=1: the lane-per-strand-search / lane-per-extension rounds instead of the wavefront-per-strand-search launch.  Same
-	// regions (the tests run both); measured slower so far (k_ext_lane 398 ms + k_ext_pack 59 ms + k_c2r_ctrl 26 ms per chunk against
-	// k_c2r's 187 ms: one wave per SIMD is all its LDS rows allow, so every LDS round trip of a cell is exposed), hence not the default
-	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 0;
+	// Two forms, same regions (the tests run both).  $BSX_C2R_LANES=1 (default): lock-step rounds -- a lane per strand search runs the
+	// reference's seed loop until it needs an extension (k_c2r_ctrl), then the extensions of the round run four to a wavefront (k_ext_q,
+	// k_extq.hip).  $BSX_C2R_LANES=0: a wavefront per strand search with the extensions inline (k_c2r), which is also what reads longer
+	// than c2r_lanes_max_query() take.
+	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 1;
 	if (use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
 		const size_t sb = c2r_lanes_state_bytes();
 		if ((rc = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc;
@@ -624,13 +625,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
 		WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
 		WA.n_act = (unsigned int*)(mb + o_nact);
-		{ // the packed jobs of one round: header + image of the first DP row
-			const size_t hb = c2r_lanes_hdr_bytes(), rw = c2r_lanes_row_words(max_len);
-			(void)hb;
-			if ((rc = L.lanes_rows.reserve((size_t)n * rw * 4 + 256)) != BSX_OK) return rc;
-			WA.rows = L.lanes_rows.p; WA.hdr = nullptr;
-		}
-		HIPCHK(hipMemsetAsync(WA.n_act, 0, 2048, L.st));   // round counters, job cursors, tracing sums of k_ext_lane
+		HIPCHK(hipMemsetAsync(WA.n_act, 0, 2048, L.st));   // round counters, job cursors, tracing sums of k_ext_q
 		launch_c2r_lanes(L.st, d->n_cu, d->ix, L.sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
 	} else
@@ -734,10 +729,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		D2H(L.st, pf, (char*)L.lanes_misc.p + o_nact + 384 * 4, sizeof(pf));
 		fprintf(stderr, "[M::c2r_lanes] jobs per round:");
 		for (int r = 0; r < 128 && na[r]; r += r < 16 ? 1 : 8) fprintf(stderr, " %u", na[r]);
-		fprintf(stderr, "\n[M::c2r_lanes] %llu jobs, %llu rows, %llu cells | per wave launch: %.0f k cycles, %.0f trips, cells of the busiest lane %.0f (mean %.0f)\n",
-		        pf[0], pf[1], pf[2], pf[6] ? pf[3] * 1e-3 / pf[6] : 0.0, pf[6] ? (double)pf[4] / pf[6] : 0.0,
-		        pf[6] ? (double)pf[5] / pf[6] : 0.0, pf[6] ? (double)pf[2] / (64.0 * pf[6]) : 0.0);
-		if (pf[6]) fprintf(stderr, "[M::c2r_lanes] per wave launch: %.0f k cycles in the per-trip part, %.0f k in the rest (%.0f passes)\n", pf[8] * 1e-3 / pf[6], pf[9] * 1e-3 / pf[6], (double)pf[10] / pf[6]);
+		fprintf(stderr, "\n[M::c2r_lanes] k_ext_q: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip of 4)\n", pf[0], pf[1], pf[2], pf[2] ? (double)pf[1] / pf[2] : 0.0);
 	}
 	if (trace) {
 		unsigned int hc[12]; unsigned long long hu[12];
@@ -854,6 +846,22 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
+	if (getenv("BSX_EXTQ")) { // tests: the batch through the quarter-wave kernel of the regions path (k_extq.hip); jobs it declines fail the call
+		int rc, max_q = 0;
+		for (int64_t i = 0; i < n; ++i) max_q = std::max(max_q, jobs[i].qlen);
+		if (max_q > ext_q_max_query(16)) return BSX_E_ARG;
+		if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
+		if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
+		if ((rc = L.aux.reserve(64)) != BSX_OK) return rc;
+		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
+		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
+		launch_ext_q(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, nullptr, (unsigned int)n,
+		             (unsigned int*)L.aux.p, max_q, nullptr);
+		HIPCHK(hipGetLastError());
+		D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
+		for (int64_t i = 0; i < n; ++i) if (res[i].score == EXTQ_DECLINED) return BSX_E_ARG;
+		return BSX_OK;
+	}
 	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}
 	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 512, 2048}, NCS[3] = {4, 8, 32};
 	std::vector<int> order[3];

@@ -117,7 +117,10 @@ def _rand_ext_jobs(small_index, seqs, offs, rng, n, long_band=False):
     return jobs
 
 
-def test_extend_matches_oracle(small_index, port, device):
+@pytest.mark.parametrize("form", ["wavefront_per_job", "quarter_wave_per_job"])
+def test_extend_matches_oracle(small_index, port, device, form, monkeypatch):
+    if form == "quarter_wave_per_job":      # k_ext_q (k_extq.hip), the form the regions path runs
+        monkeypatch.setenv("BSX_EXTQ", "1")
     opt = default_opt()
     rng = np.random.default_rng(11)
     seqs = _reads(small_index, n_pairs=200, read_len=150, seed=12)
