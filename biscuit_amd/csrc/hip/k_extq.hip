@@ -17,6 +17,9 @@
 #include "wave.hpp"
 #include "kernels.h"
 
+#ifndef EXTQ_OCC
+#define EXTQ_OCC 2    // workgroups of four waves per CU the register allocation targets (2: no spills at 174 VGPRs; 4 spills 42 of them)
+#endif
 #define DPP_ROW_ROR(n) (0x120 + (n))
 #define QID ((int)0x80000000)
 
@@ -46,7 +49,7 @@ __device__ __forceinline__ int q_prev(int v, int first) { return __builtin_amdgc
 __device__ __forceinline__ int q_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(1), 0xf, 0xf, false); }
 
 template <int NCQ>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, EXTQ_OCC)
 k_ext_q(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
         const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, unsigned long long *prof)
 {

@@ -605,11 +605,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		launch_regions_mid(L.st, (int)((n + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
 		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA, mid_quota);
 	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
-	// Two forms, same regions (the tests run both).  $BSX_C2R_LANES=1 (default): lock-step rounds -- a lane per strand search runs the
-	// reference's seed loop until it needs an extension (k_c2r_ctrl), then the extensions of the round run four to a wavefront (k_ext_q,
-	// k_extq.hip).  $BSX_C2R_LANES=0: a wavefront per strand search with the extensions inline (k_c2r), which is also what reads longer
-	// than c2r_lanes_max_query() take.
-	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 1;
+	// Two forms, same regions (the tests run both).  Default: a wavefront per strand search with the extensions inline (k_c2r), which is
+	// also what reads longer than c2r_lanes_max_query() take.  $BSX_C2R_LANES=1: lock-step rounds -- a lane per strand search runs the
+	// reference's seed loop until it needs an extension (k_c2r_ctrl: 24 ms per chunk in all), then the extensions of the round run four
+	// to a wavefront (k_ext_q, k_extq.hip: 255 ms per chunk as measured in round 3 -- 16 M jobs, 480 M rows, two waves per SIMD at 174
+	// VGPRs -- against k_c2r's 150 ms).
+	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 0;
 	if (use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
 		const size_t sb = c2r_lanes_state_bytes();
 		if ((rc = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc;

@@ -332,11 +332,11 @@ def test_sim_chunk_equals_cpu_restatement(tmp_path):
 
 
 def test_c2r_lanes_equal_waves(data):
-    """chains -> regions as lock-step rounds (default: a lane per strand search in k_c2r_ctrl, four extensions per wavefront in k_ext_q)
-    against the wavefront-per-strand-search launch with the extensions inline (k_c2r, BSX_C2R_LANES=0): identical SAM."""
+    """chains -> regions as lock-step rounds (BSX_C2R_LANES=1: a lane per strand search in k_c2r_ctrl, four extensions per wavefront in
+    k_ext_q) against the default wavefront-per-strand-search launch with the extensions inline (k_c2r): identical SAM."""
     for name, args in (CASES[0], CASES[1], CASES[8], CASES[9], CASES[11]):
         want = run(HIP, args, data)
-        assert run(HIP, args, data, env={"BSX_C2R_LANES": "0"}) == want, name
+        assert run(HIP, args, data, env={"BSX_C2R_LANES": "1"}) == want, name
 
 
 def test_dedup_kernel_against_host_function(tmp_path):
