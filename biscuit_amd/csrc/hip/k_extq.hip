@@ -13,6 +13,8 @@
 // tests/test_gpu_golden.py runs this kernel too).  Needs qlen + 1 <= 16 * NCQ entries and scores below 2^21 (else the job is
 // answered with score = EXTQ_DECLINED and the caller routes the strand search elsewhere).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "dev_common.hpp"
 #include "wave.hpp"
 #include "kernels.h"
@@ -51,7 +53,7 @@ __device__ __forceinline__ int q_ror1(int v) { return __builtin_amdgcn_update_dp
 template <int NCQ>
 __global__ void __launch_bounds__(256, EXTQ_OCC)
 k_ext_q(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
-        const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, unsigned long long *prof)
+        const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, const int *list, unsigned long long *prof)
 {
 	// scores of query base q against target bases 0..3, a byte each: [parent][q]
 	__shared__ uint32_t s_sqp[2][8];
@@ -88,6 +90,7 @@ k_ext_q(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *j
 				e = base + (unsigned int)__popcll(heads & ((1ull << gsh) - 1));
 				if (e >= n) done = true;
 				else {
+					if (list) e = (unsigned int)list[e];   // the jobs named by the list (what k_ext_n left)
 					const bsx_ext_job_t J = jobs[e];
 					const int par = J.parent ? 1 : 0;
 					qlen = J.qlen; tlen = J.tlen; h0 = J.h0; tdir = J.tdir; tpos = J.tpos;
@@ -259,17 +262,246 @@ k_ext_q(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *j
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ext_n: ksw_extend2 for the NARROW jobs, a LANE per job.
+//
+// Most extensions of a strand search against an hg38-sized genome start from a chance match (h0 = 19..21): the scores decay by one
+// per row, the band is a dozen columns wide, and the job is over after ~30 rows.  Such a job keeps no lane group busy, but 64 of
+// them keep a wavefront busy: every lane runs the reference's own loops (rows, columns of the band, the two band-shrinking scans)
+// as a state machine that does one cell per trip, so lanes in different rows of different bands advance together.  The eh[] row of a
+// job is a ring of 32 entries in this wave's LDS (column j at slot j & 31, H and E 16 bits each): with h0 that small every entry
+// outside the live band is zero -- the first row's non-zero values reach column (h0 - oe_ins) / e_ins, the band only ever leaves
+// zero entries behind (ksw.c:466-469), and the cells of row 0 beyond the last non-zero value stay zero (they are not computed: see
+// `trunc`) -- so a slot that comes round again reads what the reference reads there.  The first 64 query bases (2 bits each) and the
+// pac bytes under the first 64 reference bases are loaded into registers when the job starts: nothing in the loop waits for HBM.
+// A job that outgrows any of this (band wider than the ring, beyond column or row 63, an ambiguous base, a band clamp that cuts into
+// live cells) is put on `wide_list` untouched and done by k_ext_q.
+#define XN_RING 32
+enum { XN_FETCH = 0, XN_ROW, XN_CELL, XN_ROWEND, XN_SHL, XN_SHR, XN_DONE };
+
+__global__ void __launch_bounds__(64)
+k_ext_n(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+        const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, int *wide_list, unsigned int *wide_count, unsigned long long *prof, unsigned int cold_mask)
+{
+	__shared__ uint32_t eh_lds[XN_RING * 64];
+	__shared__ uint32_t s_srow[2][4];   // [parent][target base]: scores against query bases 0..3, a byte each
+	if (threadIdx.x < 8) {
+		const int p = threadIdx.x >> 2, t = threadIdx.x & 3;
+		const int8_t *mat = p ? sc.ctmat : sc.gamat;
+		s_srow[p][t] = (uint32_t)(uint8_t)mat[t * 5] | (uint32_t)(uint8_t)mat[t * 5 + 1] << 8 | (uint32_t)(uint8_t)mat[t * 5 + 2] << 16 | (uint32_t)(uint8_t)mat[t * 5 + 3] << 24;
+	}
+	__syncthreads();
+	const int lane = (int)threadIdx.x;
+	uint32_t *eh = eh_lds + lane;
+	const unsigned int n = n_ptr ? *n_ptr : n_fixed;
+	const int o_del = sc.o_del, e_del = sc.e_del, e_ins = sc.e_ins;
+	const int oe_del = o_del + e_del, oe_ins = sc.o_ins + e_ins, zdrop = sc.zdrop;
+	int state = XN_FETCH;
+	unsigned int e = 0;
+	int qlen = 0, tlen = 0, h0 = 0, w = 0, par = 0;
+	uint32_t q2a = 0, q2b = 0, q2c = 0, q2d = 0;           // query bases 0..63, 2 bits each
+	uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;  // pac bytes [tbyte0, tbyte0 + 20)
+	long long tf0 = 0; int tfd = 1, tcomp = 0; long long tbyte0 = 0;   // forward coordinate of row 0's base, its step per row, complement?
+	int i = 0, j = 0, beg = 0, end = 0, zhi = 0, f = 0, m = 0, mj = -1, h1 = 0, jtop = 0, trunc = 0;
+	int max = 0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+	uint32_t srow = 0;
+	unsigned int pf_cells = 0, pf_rows = 0, pf_jobs = 0, pf_wide = 0, pf_trips = 0;
+#define XN_DECLINE() do { wide_list[atomicAdd(wide_count, 1u)] = (int)e; ++pf_wide; state = XN_FETCH; } while (0)
+	for (;;) {
+		++pf_trips;
+		// ---- every trip: a cell, or a step of one of the band scans
+#define XN_ONE_CELL() do { \
+			if (j >= zhi && f == 0 && h1 == 0) { trunc = 1; jtop = j; state = XN_ROWEND; }   /* the rest of the row is zero and stays zero */ \
+			else if (j - beg >= XN_RING || j >= 64) XN_DECLINE(); \
+			else { \
+				const uint32_t x = eh[(j & (XN_RING - 1)) * 64]; \
+				int M = (int)(x & 0xffffu), ee = (int)(x >> 16); \
+				const uint32_t qw = j < 16 ? q2a : j < 32 ? q2b : j < 48 ? q2c : q2d; \
+				const int q = (int)((qw >> ((j & 15) << 1)) & 3u); \
+				const int s = (int)(int8_t)(srow >> (q << 3)); \
+				M = M ? M + s : 0; \
+				int h = M > ee ? M : ee; \
+				h = h > f ? h : f; \
+				mj = m > h ? mj : j; \
+				m = m > h ? m : h; \
+				int tt = M - oe_del; tt = tt > 0 ? tt : 0; \
+				ee -= e_del; ee = ee > tt ? ee : tt; \
+				eh[(j & (XN_RING - 1)) * 64] = (uint32_t)h1 | (uint32_t)ee << 16;   /* H(i,j-1) for the next row, E(i+1,j) */ \
+				h1 = h; \
+				tt = M - oe_ins; tt = tt > 0 ? tt : 0; \
+				f -= e_ins; f = f > tt ? f : tt; \
+				++j; ++pf_cells; \
+				if (j >= end) { jtop = end; state = XN_ROWEND; } \
+			} } while (0)
+		if (state == XN_CELL) {
+			XN_ONE_CELL();
+			if (state == XN_CELL) XN_ONE_CELL();   // two cells a trip: a row of a dozen cells costs as many trips as its two ends
+		} else if (state == XN_SHL) { // the band for the next row: the non-zero cells (ksw.c:466-469), from the left ...
+			// (after a truncated row the entries from jtop on are zero and are not read: their slots may belong to lower columns)
+			if (j < end && ((trunc && j >= jtop) || eh[(j & (XN_RING - 1)) * 64] == 0)) j = (trunc && j >= jtop) ? end : j + 1;
+			else { beg = j; j = trunc ? jtop - 1 : end; state = XN_SHR; }
+		} else if (state == XN_SHR) { // ... and from the right
+			if (j >= beg && eh[(j & (XN_RING - 1)) * 64] == 0) --j;
+			else { end = j + 2 < qlen ? j + 2 : qlen; zhi = j + 1; ++i; state = XN_ROW; }
+		}
+		// ---- the rest (end of a row, start of a row, next job) on the trips the mask names, or when a third of the wave waits for it:
+		// a wave pays for every state one of its lanes is in, and with 64 lanes some lane always is in each of these
+		const bool cold = state == XN_ROWEND || state == XN_ROW || state == XN_FETCH;
+		const unsigned long long cm = __ballot(cold);
+		if (cm && ((pf_trips & cold_mask) == 0 || __popcll(cm) > 20 || cm == __ballot(state != XN_DONE))) {
+		// ---- the end of a row
+		if (state == XN_ROWEND) {
+			const int jfin = beg < end ? end : beg;
+			if (!trunc) {
+				if (end - beg >= XN_RING) XN_DECLINE();
+				else eh[(end & (XN_RING - 1)) * 64] = (uint32_t)h1;   // eh[end] = {h1, 0}
+			} else h1 = 0;
+			if (state == XN_ROWEND) {
+				if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+				bool stop = m == 0;
+				if (!stop) {
+					if (m > max) {
+						max = m; max_i = i; max_j = mj;
+						int off = mj - i; off = off < 0 ? -off : off;
+						max_off = max_off > off ? max_off : off;
+					} else if (zdrop > 0) {
+						if (i - max_i > mj - max_j) stop = max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop;
+						else stop = max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop;
+					}
+				}
+				if (stop) { i = tlen; state = XN_ROW; }   // the row loop ends here (ksw.c:454,460-464)
+				else { j = beg; state = XN_SHL; }
+			}
+		}
+		// ---- the start of a row, or the end of the job
+		if (state == XN_ROW) {
+			if (i >= tlen) {
+				bsx_ext_res_t r;
+				r.score = max; r.qle = max_j + 1; r.tle = max_i + 1; r.gtle = max_ie + 1; r.gscore = gscore; r.max_off = max_off;
+				res[e] = r;
+				state = XN_FETCH;
+			} else if (i >= 64 || beg < i - w) XN_DECLINE();   // beyond the bases in registers / a clamp that would leave live cells behind
+			else {
+				const long long tf = tf0 + (long long)i * tfd;
+				const int bi = (int)((tf >> 2) - tbyte0);
+				const uint32_t tw = bi < 4 ? tp0 : bi < 8 ? tp1 : bi < 12 ? tp2 : bi < 16 ? tp3 : tp4;
+				const int t = (int)((tw >> (((bi & 3) << 3) + (int)((~tf & 3) << 1))) & 3u) ^ tcomp;
+				srow = s_srow[par][t];
+				if (end > i + w + 1) end = i + w + 1;
+				if (end > qlen) end = qlen;
+				if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; } else h1 = 0;
+				f = 0; m = 0; mj = -1; j = beg; trunc = 0; jtop = beg;
+				++pf_rows;
+				state = beg < end ? XN_CELL : XN_ROWEND;
+			}
+		}
+		// ---- next jobs, when a quarter of the wave waits (or nothing else is going on)
+		{
+			const unsigned long long fm = __ballot(state == XN_FETCH);
+			if (fm && (__popcll(fm) >= 16 || fm == __ballot(state != XN_DONE))) {
+				const int first = (int)__builtin_ctzll(fm);
+				unsigned int base = 0;
+				if (lane == first) base = atomicAdd(cursor, (unsigned int)__popcll(fm));
+				base = (unsigned int)__builtin_amdgcn_readlane((int)base, first);
+				if (state == XN_FETCH) {
+					e = base + (unsigned int)__popcll(fm & ((1ull << lane) - 1));
+					if (e >= n) state = XN_DONE;
+					else {
+						const bsx_ext_job_t J = jobs[e];
+						++pf_jobs;
+						par = J.parent ? 1 : 0;
+						qlen = J.qlen; tlen = J.tlen; h0 = J.h0;
+						const int mx = par ? sc.mx_ct : sc.mx_ga;
+						// the first row's non-zero entries: 0 .. jmax0 (ksw.c:395-397)
+						int jmax0 = h0 > oe_ins ? (h0 - oe_ins - 1) / e_ins + 1 : 0;
+						jmax0 = jmax0 < qlen ? jmax0 : qlen;
+						const bool fits = qlen >= 1 && tlen >= 1 && h0 >= 1 && jmax0 <= XN_RING - 6 && (long long)h0 + 64ll * mx < 32768;
+						// the query's first 64 bases, 2 bits each; an ambiguous base among them sends the job to the wide kernel
+						uint32_t amb = 0;
+						if (fits) {
+							const uint8_t *qp = reads + J.qoff;
+							const int nq = qlen < 64 ? qlen : 64;
+							uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+							for (int g = 0; g < 16; ++g) {
+								uint32_t x = 0;
+								if (g * 4 + 4 <= nq) {
+									if (J.qdir > 0) { uint32_t v; __builtin_memcpy(&v, qp + g * 4, 4); x = v; }
+									else { uint32_t v; __builtin_memcpy(&v, qp - g * 4 - 3, 4); x = __builtin_bswap32(v); }
+								} else if (g * 4 < nq) { // the last bases one by one: nothing outside the query is touched
+									for (int k = 0; k < 3; ++k) if (g * 4 + k < nq) x |= (uint32_t)qp[(long long)(g * 4 + k) * J.qdir] << (k << 3);
+								}
+								amb |= x & 0xfcfcfcfcu;
+								const uint32_t p4 = (x & 3u) | ((x >> 6) & 0xcu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xc0u);
+								pk[g >> 2] |= p4 << ((g & 3) << 3);
+							}
+							q2a = pk[0]; q2b = pk[1]; q2c = pk[2]; q2d = pk[3];
+						}
+						if (!fits || amb) XN_DECLINE();
+						else {
+							// the reference bases of rows 0..63: forward coordinates tf0 + r * tfd, complemented on the reverse strand
+							const long long p0 = J.tpos;
+							if (p0 >= ix.l_pac) { tf0 = (ix.l_pac << 1) - 1 - p0; tfd = -J.tdir; tcomp = 3; } else { tf0 = p0; tfd = J.tdir; tcomp = 0; }
+							const int nr = tlen < 64 ? tlen : 64;
+							const long long flo = tfd > 0 ? tf0 : tf0 - (nr - 1);
+							tbyte0 = (flo >> 2) & ~3ll;
+							const uint32_t *pp = (const uint32_t*)(ix.pac + tbyte0);   // pac is padded past its end
+							tp0 = pp[0]; tp1 = pp[1]; tp2 = pp[2]; tp3 = pp[3]; tp4 = pp[4];
+							w = J.w;
+							{ // band clamp (ksw.c:399-407)
+								int max_ins = (int)((double)(qlen * mx + J.end_bonus - sc.o_ins) / e_ins + 1.);
+								max_ins = max_ins > 1 ? max_ins : 1;
+								w = w < max_ins ? w : max_ins;
+								int max_del = (int)((double)(qlen * mx + J.end_bonus - o_del) / e_del + 1.);
+								max_del = max_del > 1 ? max_del : 1;
+								w = w < max_del ? w : max_del;
+							}
+#pragma unroll
+							for (int c = 0; c < XN_RING; ++c) { // first row (ksw.c:395-397); the ring holds columns 0..31 now
+								const int v = c == 0 ? h0 : h0 - oe_ins - (c - 1) * e_ins;
+								eh[c * 64] = (c <= qlen && v > 0) ? (uint32_t)v : 0u;
+							}
+							max = h0; max_i = max_j = max_ie = -1; gscore = -1; max_off = 0;
+							beg = 0; end = qlen; zhi = jmax0 + 1; i = 0;
+							state = XN_ROW;
+						}
+					}
+				}
+			}
+		}
+		}
+		if (__ballot(state != XN_DONE) == 0) break;
+	}
+	if (prof) {
+		const unsigned int c = (unsigned int)wave_sum_i32((int)pf_cells), r = (unsigned int)wave_sum_i32((int)pf_rows), jb = (unsigned int)wave_sum_i32((int)pf_jobs), wd = (unsigned int)wave_sum_i32((int)pf_wide);
+		if (lane == 0) { atomicAdd(&prof[4], (unsigned long long)jb); atomicAdd(&prof[5], (unsigned long long)r); atomicAdd(&prof[6], (unsigned long long)c); atomicAdd(&prof[7], (unsigned long long)wd); atomicAdd(&prof[8], (unsigned long long)pf_trips); }
+	}
+}
+
 int ext_q_max_query(int ncq) { return 16 * ncq - 1; }
 
-// jobs[0 .. n) -> res; n is *n_ptr if n_ptr is given (a device counter), else n_fixed; *cursor must be zero
+// jobs[0 .. n) -> res; n is *n_ptr if n_ptr is given (a device counter), else n_upper; *cursor must be zero.  With `list`, the jobs are
+// jobs[list[0 .. n)].
 void launch_ext_q(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
-                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, unsigned long long *prof)
+                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, const int *list, unsigned long long *prof)
 {
 	// a workgroup = 4 waves = 16 jobs in flight; persistent rows (they take jobs until the queue is empty)
 	const long long want = ((long long)n_upper + 15) / 16;
 	const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * 8));
 	if (max_qlen <= ext_q_max_query(10))
-		hipLaunchKernelGGL(k_ext_q<10>, dim3(grid), dim3(256), 0, st, ix, sc, reads, jobs, res, n_ptr, n_upper, cursor, prof);
+		hipLaunchKernelGGL(k_ext_q<10>, dim3(grid), dim3(256), 0, st, ix, sc, reads, jobs, res, n_ptr, n_upper, cursor, list, prof);
 	else
-		hipLaunchKernelGGL(k_ext_q<16>, dim3(grid), dim3(256), 0, st, ix, sc, reads, jobs, res, n_ptr, n_upper, cursor, prof);
+		hipLaunchKernelGGL(k_ext_q<16>, dim3(grid), dim3(256), 0, st, ix, sc, reads, jobs, res, n_ptr, n_upper, cursor, list, prof);
+}
+// the narrow jobs of jobs[0 .. n) by k_ext_n (a lane per job); the others are listed in wide_list[0 .. *wide_count) for launch_ext_q
+void launch_ext_n(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int *wide_list, unsigned int *wide_count, unsigned long long *prof)
+{
+	// a workgroup = one wave = 64 jobs in flight and 8 KB of LDS; persistent lanes
+	const long long want = ((long long)n_upper + 63) / 64;
+	static const int wpc = getenv("BSX_EXTN_WPC") ? atoi(getenv("BSX_EXTN_WPC")) : 19;     // workgroups per CU: 19 rings of 8 KB fit its LDS
+	static const unsigned int cold_mask = getenv("BSX_EXTN_COLD") ? (unsigned int)atoi(getenv("BSX_EXTN_COLD")) : 1u;   // cold states every (mask + 1)-th trip
+	const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * wpc));
+	hipLaunchKernelGGL(k_ext_n, dim3(grid), dim3(64), 0, st, ix, sc, reads, jobs, res, n_ptr, n_upper, cursor, wide_list, wide_count, prof, cold_mask);
 }

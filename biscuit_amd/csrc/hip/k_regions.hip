@@ -563,20 +563,87 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
 	int nc = 0, n_prom = 0;   // chains; those of them with a record (PCAP stores)
 	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
-	for (int o = 0; o < tot; ++o) {
-		while (o >= iv_stop) { // next interval with occurrences
-			// an over-represented interval is walked past its first max_occ occurrences while it has started at most 5 chains
-			// (memchain.c:325-326): those further occurrences were not looked up, the host takes the strand search
-			if (iv_big && count < P.max_occ && count <= 5) return 10;
-			++cur_iv;
-			const int v = uni(S.iv_n[cur_iv]);
-			iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
+	// The LDS tiers first set aside the seeds that cannot meet any other: merge_seed_to_chain (memchain.c:227-256) only ever joins a
+	// seed to a chain whose last seed lies less than l_query + min(w, max_chain_gap) before it on the reference (rdist <= qdist + w,
+	// rdist - last->len < max_chain_gap) or whose span contains it, and every step inside a chain is that short too.  So cut the seeds,
+	// sorted by reference position, wherever two neighbours are at least that far apart: a seed alone in its piece starts a chain of
+	// its own whatever else the strand search holds, no later seed joins it, and it never changes the outcome of a test between two
+	// other seeds (the chain below a seed is either in the seed's own piece or too far to be joined) -- against an hg38-sized genome
+	// that is ~95 of the ~100 chains of a strand search, the chance matches of a 3-letter 19-mer.  Only the seeds of the other pieces
+	// go through the sequential loop below, in arrival order, over a table of their own chain starts.
+	int n_iso = 0, n_live = tot;
+	if (!Store::NODES) {
+		constexpr int NS = Store::SCAP / 64;
+		const long long dgap = (long long)l_query + 1 + (long long)(P.w < P.max_chain_gap ? P.w : P.max_chain_gap);
+		unsigned long long key[NS]; int rk[NS];
+		int n_dead = 0;
+#pragma unroll
+		for (int c = 0; c < NS; ++c) { // seeds that take no part (memchain.c:339-346) sort last
+			const int o = (c << 6) + lane;
+			key[c] = ~0ull; rk[c] = 0;
+			bool dead = false;
+			if (o < tot) {
+				const long long rb = S.s_rbeg[o];
+				dead = S.s_rid[o] < 0 || ((P.bsstrand & 1) && RG_BSS(parent, l_pac, rb) != P.bsstrand >> 1);
+				if (dead) S.s_rbeg[o] = (1ll << 40) + o;   // nothing reads the position of such a seed again
+				key[c] = (unsigned long long)(dead ? (1ll << 40) + o : rb) << 9 | (unsigned)o;
+			}
+			n_dead += __popcll(__ballot(dead));
+		}
+		n_live = tot - n_dead;
+		WAVE_SYNC();
+		for (int k = 0; k < tot; ++k) { // rank by counting: the keys (position, arrival index) are unique
+			const unsigned long long kk = (unsigned long long)uni64(S.s_rbeg[k]) << 9 | (unsigned)k;
+#pragma unroll
+			for (int c = 0; c < NS; ++c) rk[c] += kk < key[c];
+		}
+#pragma unroll
+		for (int c = 0; c < NS; ++c) { const int o = (c << 6) + lane; if (o < tot) S.lst[rk[c]] = (idx_t)o; }
+		WAVE_SYNC();
+		int iso = 0;
+#pragma unroll
+		for (int c = 0; c < NS; ++c) {
+			const int r = (c << 6) + lane;
+			if (r < n_live) {
+				const int o = S.lst[r];
+				const long long rb = S.s_rbeg[o];
+				const bool far_l = r == 0 || rb - S.s_rbeg[S.lst[r > 0 ? r - 1 : 0]] >= dgap;
+				const bool far_r = r == n_live - 1 || S.s_rbeg[S.lst[r + 1 < n_live ? r + 1 : r]] - rb >= dgap;
+				if (far_l && far_r) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))o; S.s_extra[o] |= 8; ++iso; }   // bit 3: the seed starts a chain
+				else S.s_extra[o] |= 16;                                                                             // bit 4: it goes through the loop
+			}
+		}
+		n_iso = wave_sum_i32(iso);
+		WAVE_SYNC();
+	}
+	int o = -1, cbase = -64;
+	unsigned long long cmask = 0;
+	for (;;) {
+		if (Store::NODES) { // every occurrence, in arrival order
+			if (++o >= tot) break;
+			while (o >= iv_stop) { // next interval with occurrences
+				// an over-represented interval is walked past its first max_occ occurrences while it has started at most 5 chains
+				// (memchain.c:325-326): those further occurrences were not looked up, the host takes the strand search
+				if (iv_big && count < P.max_occ && count <= 5) return 10;
+				++cur_iv;
+				const int v = uni(S.iv_n[cur_iv]);
+				iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
+			}
+		} else { // the seeds with neighbours, in arrival order
+			while (cmask == 0) {
+				cbase += 64;
+				if (cbase >= tot) break;
+				cmask = __ballot(cbase + lane < tot && (S.s_extra[cbase + lane < tot ? cbase + lane : 0] & 16));
+			}
+			if (cmask == 0) break;
+			o = cbase + (int)__builtin_ctzll(cmask);
+			cmask &= cmask - 1;
 		}
 		const int rid = uni(S.s_rid[o]);
 		if (rid < 0) continue;
 		const long long rbeg = uni64(S.s_rbeg[o]);
 		const int qbeg = uni(S.s_qbeg[o]), len = uni(S.s_len[o]);
-		if ((P.bsstrand & 1) && RG_BSS(parent, l_pac, rbeg) != P.bsstrand >> 1) continue;
+		if (Store::NODES && (P.bsstrand & 1) && RG_BSS(parent, l_pac, rbeg) != P.bsstrand >> 1) continue;
 		int lower = -1, at = 0;   // at: sorted index the new chain would take
 		bool tied = false;
 		if (Store::NODES) {
@@ -653,6 +720,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 					S.ch[nc] = c;
 				}
 				S.s_chain[o] = (decltype(S.s_chain[0] + 0))new_id;
+				if (!Store::NODES) S.s_extra[o] |= 8;
 				if (Store::NODES) rg_bt_put(S, rbeg, nc);
 			}
 			if (!Store::NODES) { // open slot `at` of the sorted table
@@ -676,15 +744,40 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 		WAVE_SYNC();
 	}
-	if (iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
+	if (Store::NODES && iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
+	const unsigned long long lt_mask_c = (1ull << lane) - 1;
+	if (!Store::NODES) {
+		WAVE_SYNC();
+		if (any_big) { // the same rule: an over-represented interval that started at most 5 chains would be walked further
+			int acc = 0;
+			for (int i = 0; i < n_iv; ++i) {
+				const int v = uni(S.iv_n[i]), cnt = v & 0x3fffffff;
+				if (v >> 30) {
+					int heads = 0;
+					for (int b = acc; b < acc + cnt; b += 64) heads += __popcll(__ballot(b + lane < acc + cnt && (S.s_extra[b + lane < acc + cnt ? b + lane : acc] & 8)));
+					if (heads < P.max_occ && heads <= 5) return 10;
+				}
+				acc += cnt;
+			}
+		}
+		if (nc + n_iso > Store::CCAP) return 3;
+		// chains in the order of their start positions (the in-order traversal of the reference's tree, memchain.c:372-379)
+		int n_heads = 0;
+		for (int base = 0; base < n_live; base += 64) {
+			const int r = base + lane;
+			bool hd = false; int id = 0;
+			if (r < n_live) { const int oo = S.lst[r]; hd = (S.s_extra[oo] & 8) != 0; id = (int)S.s_chain[oo]; }
+			const unsigned long long b = __ballot(hd);
+			if (hd) S.ord[n_heads + __popcll(b & lt_mask_c)] = (idx_t)id;
+			n_heads += __popcll(b);
+		}
+		nc = n_heads;
+		WAVE_SYNC();
+	}
 	RG_STAGE(2);
 	// ---- D. chain order = by start position; weights; filter (mem_chain_flt, memchain.c:406-488)
 	if (nc > 0) {
 		for (int c = lane; c < (Store::PCAP ? n_prom : nc); c += 64) { RgChain &d = S.ch[c]; const int w = d.wq < d.wr ? d.wq : d.wr; d.w = (short)w; }
-		if (!Store::NODES) { // the sorted table is the in-order traversal of the tree (memchain.c:372-379)
-#pragma unroll
-			for (int r = 0; r < NR; ++r) if (r * 64 + lane < nc) S.ord[r * 64 + lane] = (idx_t)st_id[r];
-		}
 		WAVE_SYNC();
 		if (Store::NODES && lane == 0) rg_bt_traverse(S, D.E);
 		WAVE_SYNC();
@@ -1515,9 +1608,12 @@ void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevSco
 		const int gc = (int)std::max<long long>(1, std::min<long long>((upper + 255) / 256, (long long)n_cu * 16));
 		hipLaunchKernelGGL(k_c2r_ctrl, dim3(gc), dim3(256), 0, st, ix, P, tasks, X, W, r, out, out_cap, out_cursor, reg_off, reg_n, next_list, next_count);
 		if (r + 1 == RG_LROUNDS) break;
-		// the jobs of round r (count: n_act[r], job cursor: n_act[192 + r]), four per wavefront (k_extq.hip)
-		launch_ext_q(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + r, (unsigned int)upper, W.n_act + 192 + r, max_qlen,
-		             P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr);
+		// the jobs of round r (count: n_act[r]): the narrow ones a lane each (k_ext_n; cursor n_act[192 + r]), what it leaves -- listed in
+		// wide[r & 1], count n_act[512 + r] -- four per wavefront (k_ext_q; cursor n_act[640 + r])
+		unsigned long long *pf = P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr;
+		int *wl = WA.wide + (size_t)(r & 1) * (size_t)n_tasks;
+		launch_ext_n(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + r, (unsigned int)upper, W.n_act + 192 + r, wl, W.n_act + 512 + r, pf);
+		launch_ext_q(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + 512 + r, (unsigned int)(upper / 4 + 1), W.n_act + 640 + r, max_qlen, wl, pf);
 	}
 }
 int c2r_lanes_max_query(void) { return ext_q_max_query(16) < RG_QCAP ? ext_q_max_query(16) : RG_QCAP; }

@@ -23,7 +23,12 @@ void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
 #define EXTQ_DECLINED (-0x7fffffff)
 int ext_q_max_query(int ncq);
 void launch_ext_q(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
-                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, unsigned long long *prof);
+                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, const int *list, unsigned long long *prof);
+// K4 for the narrow jobs, a lane per job (k_ext_n in k_extq.hip): the jobs of jobs[0 .. n) that start from a short seed and stay inside a
+// ring of 32 columns are answered; the indices of the others are appended to wide_list (count in *wide_count, zero at launch) for
+// launch_ext_q(..., list = wide_list)
+void launch_ext_n(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int *wide_list, unsigned int *wide_count, unsigned long long *prof);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
 // Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
 // regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.
@@ -45,7 +50,7 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
 // the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
 // rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
 // (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
-struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; };
+struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; int *wide; };   // wide: a job list per round parity (2 x n ints)
 size_t c2r_lanes_state_bytes(void);
 int c2r_lanes_max_query(void);   // reads longer than this take the wave-per-strand-search launch (launch_c2r)
 void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,

@@ -617,7 +617,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if ((rc = L.lanes_regs.reserve((size_t)n * 24 * sizeof(bsx_region_t))) != BSX_OK) return rc;
 		// rank | act[2] | jobs[2] | res[2] | n_act
 		const size_t o_rank = 0, o_act = o_rank + (size_t)n * 128, o_jobs = o_act + (size_t)n * 8, o_res = o_jobs + (size_t)n * 2 * sizeof(bsx_ext_job_t),
-		             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), tot_misc = o_nact + 2048;
+		             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), o_wide = o_nact + 4096, tot_misc = o_wide + (size_t)n * 8;
 		if ((rc = L.lanes_misc.reserve(tot_misc)) != BSX_OK) return rc;
 		char *mb = (char*)L.lanes_misc.p;
 		RgLanesArg WA;
@@ -626,7 +626,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
 		WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
 		WA.n_act = (unsigned int*)(mb + o_nact);
-		HIPCHK(hipMemsetAsync(WA.n_act, 0, 2048, L.st));   // round counters, job cursors, tracing sums of k_ext_q
+		WA.wide = (int*)(mb + o_wide);
+		HIPCHK(hipMemsetAsync(WA.n_act, 0, 4096, L.st));   // u32: [0,128) jobs per round, [192,320) k_ext_n's job cursors, [384,512) tracing sums, [512,640) wide jobs per round, [640,768) k_ext_q's cursors
 		launch_c2r_lanes(L.st, d->n_cu, d->ix, L.sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
 		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
 	} else
@@ -730,7 +731,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		D2H(L.st, pf, (char*)L.lanes_misc.p + o_nact + 384 * 4, sizeof(pf));
 		fprintf(stderr, "[M::c2r_lanes] jobs per round:");
 		for (int r = 0; r < 128 && na[r]; r += r < 16 ? 1 : 8) fprintf(stderr, " %u", na[r]);
-		fprintf(stderr, "\n[M::c2r_lanes] k_ext_q: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip of 4)\n", pf[0], pf[1], pf[2], pf[2] ? (double)pf[1] / pf[2] : 0.0);
+		fprintf(stderr, "\n[M::c2r_lanes] k_ext_n: %llu jobs taken, %llu of them left to k_ext_q; %llu rows, %llu cells in %llu wave trips | k_ext_q: %llu jobs, %llu rows in %llu wave trips\n",
+		        pf[4], pf[7], pf[5], pf[6], pf[8], pf[0], pf[1], pf[2]);
 	}
 	if (trace) {
 		unsigned int hc[12]; unsigned long long hu[12];
@@ -856,8 +858,16 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 		if ((rc = L.aux.reserve(64)) != BSX_OK) return rc;
 		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
+		if (atoi(getenv("BSX_EXTQ")) == 2) { // the narrow jobs a lane each (k_ext_n), the rest through k_ext_q: what a round of the regions path does
+			if ((rc = L.scratch.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
+			launch_ext_n(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, nullptr, (unsigned int)n,
+			             (unsigned int*)L.aux.p, (int*)L.scratch.p, (unsigned int*)L.aux.p + 2, nullptr);
+			launch_ext_q(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int*)L.aux.p + 2, (unsigned int)n,
+			             (unsigned int*)L.aux.p + 4, max_q, (const int*)L.scratch.p, nullptr);
+			if (getenv("BSX_PHASES")) { unsigned int c[4]; D2H(L.st, c, L.aux.p, 16); fprintf(stderr, "[M::extq] %lld jobs, %u left to k_ext_q by k_ext_n\n", (long long)n, c[2]); }
+		} else
 		launch_ext_q(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, nullptr, (unsigned int)n,
-		             (unsigned int*)L.aux.p, max_q, nullptr);
+		             (unsigned int*)L.aux.p, max_q, nullptr, nullptr);
 		HIPCHK(hipGetLastError());
 		D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
 		for (int64_t i = 0; i < n; ++i) if (res[i].score == EXTQ_DECLINED) return BSX_E_ARG;
