@@ -33,7 +33,7 @@ $(CLI): biscuit_amd/csrc/cli_main.c $(LIB)
 
 # test infrastructure: CPU restatement of the device kernels (never linked into $(LIB))
 $(PORT): oracle/port.c $(LIB)
-	$(CC) $(CFLAGS) -shared -o $@ oracle/port.c -Lbiscuit_amd -lbiscuit_amd -Wl,-rpath,'$$ORIGIN/../biscuit_amd' -lm -lpthread
+	$(CC) $(CFLAGS) -shared -o $@ oracle/port.c -Lbiscuit_amd -lbiscuit_amd -Wl,-rpath,'$$ORIGIN/../biscuit_amd' -lm -lpthread -ldl
 
 $(ORACLE_CLI): oracle/oracle_align_main.c $(PORT)
 	$(CC) -O2 -o $@ $< -Loracle -loracle_port -Lbiscuit_amd -lbiscuit_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../biscuit_amd' -Wl,-rpath,$(ROCM)/lib

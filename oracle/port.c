@@ -15,8 +15,31 @@
  *   K6  ksw_global2 + band set-up/retry lib/aln/ksw.c:504-606, bwa.c:314-340,
  *                                       mem_alnreg_format.c:63-77
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <assert.h>
 #include "../biscuit_amd/csrc/host/bsx_core.h"
+
+/* Optional: the reference's OWN kernels (oracle/_ref/libbiscuit_ref.so: bwt.c and ksw.c compiled where they lie, SSE2 ksw_u8/i16
+ * included) behind the same seams, for timing: the restatements above are plain scalar C and 2-3x slower than the code they restate.
+ * oracle_port_use_reference_kernels() switches a context over; results are the same (tests/test_oracle_vs_ref.py pins the
+ * restatements against these very functions). */
+#include <dlfcn.h>
+typedef struct {
+	void *lib;
+	void *bwt[2];
+	void *(*bwt_wrap)(uint64_t, const uint64_t*, uint64_t, uint64_t, uint32_t*, int, uint64_t, uint64_t*);
+	void (*bwt_unwrap)(void*);
+	void *(*smem_ctx_new)(void);
+	void (*smem_ctx_free)(void*);
+	int (*smem1a_ctx)(void*, void*, void*, int, const uint8_t*, int, int, const uint64_t**, int*);
+	int (*seed_strategy1)(void*, void*, int, const uint8_t*, int, int, int, uint64_t*);
+	uint64_t (*sa)(void*, uint64_t);
+	void (*extend2)(int, const uint8_t*, int, const uint8_t*, const int8_t*, int, int, int, int, int, int, int, int, int*);
+	void (*align2)(int, uint8_t*, int, uint8_t*, const int8_t*, int, int, int, int, int, int*);
+	int (*global2)(int, const uint8_t*, int, const uint8_t*, const int8_t*, int, int, int, int, int, int, int*, uint32_t*, int);
+} ref_kernels_t;
 
 typedef struct {
 	const bsx_index_t *idx;
@@ -24,6 +47,7 @@ typedef struct {
 	const uint8_t *reads; size_t n_reads;
 	int n_threads;
 	uint64_t counters[4]; /* occ4 calls, same-block 2occ4 calls, occ calls, sa calls */
+	ref_kernels_t R;
 } port_ctx_t;
 
 /* ============================== FM index ============================== */
@@ -175,6 +199,41 @@ static int fm_seed_strategy1(const bsx_fmi_t *f, const bsx_fmi_t *fc, int len, c
 }
 
 static int intv_lt(const void *a, const void *b) { return ((const bsx_intv_t*)a)->info < ((const bsx_intv_t*)b)->info; }
+
+/* mem_collect_intv (memchain.c:50-106) over the reference's own bwt_smem1a / bwt_seed_strategy1 */
+static void ref_collect_intv(const ref_kernels_t *R, void *sctx, const bsx_opt_t *opt, int parent, int len, const uint8_t *seq, intv_v *mem)
+{
+	int k, x = 0, old_n, n, j;
+	const uint64_t *v;
+	void *b = R->bwt[parent], *bc = R->bwt[!parent];
+	int start_width = (opt->flag & BSX_F_SELF_OVLP) ? 2 : 1;
+	int split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
+	mem->n = 0;
+#define REF_TAKE() do { for (j = 0; j < n; ++j) if ((uint32_t)v[4 * j + 3] - (v[4 * j + 3] >> 32) >= (uint64_t)opt->min_seed_len) { bsx_intv_t t_; memcpy(&t_, v + 4 * j, 32); bsx_vec_push(*mem, t_); } } while (0)
+	while (x < len) {
+		if (seq[x] < 4) { x = R->smem1a_ctx(sctx, b, bc, len, seq, x, start_width, &v, &n); REF_TAKE(); }
+		else ++x;
+	}
+	old_n = (int)mem->n;
+	for (k = 0; k < old_n; ++k) {
+		bsx_intv_t p = mem->a[k];
+		int start = (int)(p.info >> 32), end = (int32_t)p.info;
+		if (end - start < split_len || p.x[2] > (uint64_t)opt->split_width) continue;
+		R->smem1a_ctx(sctx, b, bc, len, seq, (start + end) >> 1, (int)(p.x[2] + 1), &v, &n); REF_TAKE();
+	}
+	if (opt->max_mem_intv > 0) {
+		x = 0;
+		while (x < len) {
+			if (seq[x] < 4) {
+				bsx_intv_t m;
+				x = R->seed_strategy1(b, bc, len, seq, x, opt->min_seed_len, (int)opt->max_mem_intv, (uint64_t*)&m);
+				if (m.x[2] > 0) bsx_vec_push(*mem, m);
+			} else ++x;
+		}
+	}
+#undef REF_TAKE
+	bsx_introsort(mem->a, mem->n, sizeof(bsx_intv_t), intv_lt);
+}
 
 /* mem_collect_intv, memchain.c:50-106 */
 static void fm_collect_intv(const bsx_opt_t *opt, const bsx_fmi_t *f, const bsx_fmi_t *fc, int len, const uint8_t *seq,
@@ -510,6 +569,10 @@ static void glb_job(const port_ctx_t *c, const bsx_glb_job_t *jb, bsx_glb_res_t 
 			w = w < w_ ? w : w_;
 			min_w = dl + 3;
 			w = w > min_w ? w : min_w;
+			if (c->R.lib) {
+				score = c->R.global2(jb->qlen, q, jb->tlen, t, mat, o->o_del, o->e_del, o->o_ins, o->e_ins, w, jb->want_cigar, &n_cigar, jb->want_cigar ? pool + jb->cigar_off : 0, (int)jb->cigar_cap);
+				if (n_cigar > (int)jb->cigar_cap) n_cigar = -n_cigar;   /* the room it needs (pipeline.c redoes the job) */
+			} else
 			score = dp_global(jb->qlen, q, jb->tlen, t, mat, o->o_del, o->e_del, o->o_ins, o->e_ins, w,
 			                  jb->want_cigar, pool + jb->cigar_off, (int)jb->cigar_cap, &n_cigar);
 		}
@@ -529,7 +592,7 @@ static int port_set_reads(void *ctx, const uint8_t *buf, size_t n) { port_ctx_t 
 typedef struct {
 	port_ctx_t *c; const bsx_opt_t *opt; const bsx_seed_task_t *tasks;
 	intv_v *per_task; uint64_t (*ctr)[4];
-	struct seed_tls { intv_v mem1, tmp[2]; uint8_t *conv; int m_conv; } *tls;
+	struct seed_tls { intv_v mem1, tmp[2]; uint8_t *conv; int m_conv; void *sctx; } *tls;
 } seed_par_t;
 
 static void seed_worker(void *data, long i, int tid)
@@ -545,6 +608,10 @@ static void seed_worker(void *data, long i, int tid)
 	for (j = 0; j < t->len; ++j) L->conv[j] = t->parent ? (raw[j] == 1 ? 3 : raw[j]) : (raw[j] == 2 ? 0 : raw[j]);
 	bsx_vec_init(P->per_task[i]);
 	if (t->len < P->opt->min_seed_len) return; /* mem_chain's early return, memchain.c:279 */
+	if (P->c->R.lib) {
+		if (!L->sctx) L->sctx = P->c->R.smem_ctx_new();
+		ref_collect_intv(&P->c->R, L->sctx, P->opt, t->parent, t->len, L->conv, &P->per_task[i]);
+	} else
 	fm_collect_intv(P->opt, &idx->fmi[t->parent], &idx->fmi[!t->parent], t->len, L->conv, &P->per_task[i], &L->mem1, L->tmp, P->ctr[tid]);
 }
 
@@ -570,6 +637,7 @@ static int port_seed_batch(void *ctx, const bsx_opt_t *opt, int64_t n, const bsx
 	for (t = 0; t < nt; ++t) {
 		int k; for (k = 0; k < 4; ++k) c->counters[k] += P.ctr[t][k];
 		bsx_vec_free(P.tls[t].mem1); bsx_vec_free(P.tls[t].tmp[0]); bsx_vec_free(P.tls[t].tmp[1]); free(P.tls[t].conv);
+		if (P.tls[t].sctx) c->R.smem_ctx_free(P.tls[t].sctx);
 	}
 	free(P.per_task); free(P.ctr); free(P.tls);
 	return BSX_OK;
@@ -581,6 +649,8 @@ static void sa_worker(void *d, long i, int tid)
 {
 	job_par_t *P = (job_par_t*)d;
 	const bsx_sa_job_t *j = (const bsx_sa_job_t*)P->jobs + i;
+	if (P->c->R.lib) ((uint64_t*)P->res)[i] = P->c->R.sa(P->c->R.bwt[j->parent], j->k);
+	else
 	((uint64_t*)P->res)[i] = fm_sa(&P->c->idx->fmi[j->parent], j->k, P->ctr[tid]);
 }
 static int port_sa_batch(void *ctx, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos)
@@ -604,6 +674,9 @@ static void ext_worker(void *d, long i, int tid)
 	(void)tid;
 	read_view(P->c->reads, j->qoff, j->qlen, j->qdir, 0, q);
 	ref_view(P->c->idx, j->tpos, j->tlen, j->tdir, t);
+	if (P->c->R.lib) P->c->R.extend2(j->qlen, q, j->tlen, t, j->parent ? o->ctmat : o->gamat, o->o_del, o->e_del, o->o_ins, o->e_ins,
+	                                 j->w, j->end_bonus, o->zdrop, j->h0, (int*)((bsx_ext_res_t*)P->res + i));   /* {score,qle,tle,gtle,gscore,max_off} */
+	else
 	dp_extend(j->qlen, q, j->tlen, t, j->parent ? o->ctmat : o->gamat, o->o_del, o->e_del, o->o_ins, o->e_ins,
 	          j->w, j->end_bonus, o->zdrop, j->h0, (bsx_ext_res_t*)P->res + i);
 	free(q); free(t);
@@ -625,6 +698,8 @@ static void sw_worker(void *d, long i, int tid)
 	(void)tid;
 	read_view(P->c->reads, j->qoff, j->qlen, j->qdir, j->qcomp, q);
 	ref_view(P->c->idx, j->tpos, j->tlen, j->tdir, t);
+	if (P->c->R.lib) P->c->R.align2(j->qlen, q, j->tlen, t, j->use_ct ? o->ctmat : o->gamat, o->o_del, o->e_del, o->o_ins, o->e_ins, j->xtra, (int*)((bsx_sw_res_t*)P->res + i));   /* {score,te,qe,score2,te2,tb,qb} */
+	else
 	dp_sw(j->qlen, q, j->tlen, t, j->use_ct ? o->ctmat : o->gamat, o->o_del, o->e_del, o->o_ins, o->e_ins, j->xtra, (bsx_sw_res_t*)P->res + i);
 	free(q); free(t);
 }
@@ -659,7 +734,33 @@ BSX_API void *oracle_port_new(const bsx_index_t *idx, int n_threads)
 	bsx_opt_init(&c->opt);
 	return c;
 }
-BSX_API void oracle_port_free(void *c) { free(c); }
+BSX_API void oracle_port_free(void *c_)
+{
+	port_ctx_t *c = (port_ctx_t*)c_;
+	if (c && c->R.lib) { c->R.bwt_unwrap(c->R.bwt[0]); c->R.bwt_unwrap(c->R.bwt[1]); dlclose(c->R.lib); }
+	free(c);
+}
+/* the batch seams of this context over the reference's own kernels (oracle/_ref/libbiscuit_ref.so); 0 on success */
+BSX_API int oracle_port_use_reference_kernels(void *c_, const char *so_path)
+{
+	port_ctx_t *c = (port_ctx_t*)c_;
+	ref_kernels_t R;
+	int i;
+	memset(&R, 0, sizeof(R));
+	if ((R.lib = dlopen(so_path, RTLD_NOW | RTLD_LOCAL)) == 0) return -1;
+#define REF_SYM(field, name) do { *(void**)&R.field = dlsym(R.lib, name); if (!R.field) { dlclose(R.lib); return -2; } } while (0)
+	REF_SYM(bwt_wrap, "ref_bwt_wrap"); REF_SYM(bwt_unwrap, "ref_bwt_unwrap"); REF_SYM(smem_ctx_new, "ref_smem_ctx_new"); REF_SYM(smem_ctx_free, "ref_smem_ctx_free");
+	REF_SYM(smem1a_ctx, "ref_bwt_smem1a_ctx"); REF_SYM(seed_strategy1, "ref_bwt_seed_strategy1"); REF_SYM(sa, "ref_bwt_sa");
+	REF_SYM(extend2, "ref_ksw_extend2"); REF_SYM(align2, "ref_ksw_align2"); REF_SYM(global2, "ref_ksw_global2");
+#undef REF_SYM
+	for (i = 0; i < 2; ++i) {
+		const bsx_fmi_t *f = &c->idx->fmi[i];
+		if (!f->bwt || !f->sa) { dlclose(R.lib); return -3; }
+		R.bwt[i] = R.bwt_wrap(f->primary, f->L2, f->seq_len, f->bwt_size, f->bwt, f->sa_intv, f->n_sa, f->sa);
+	}
+	c->R = R;
+	return 0;
+}
 BSX_API void oracle_port_backend(void *c, bsx_backend_t *be)
 {
 	memset(be, 0, sizeof(*be));   /* no regions_batch: the CPU checker always runs the host chaining path */
@@ -734,7 +835,26 @@ BSX_API void oracle_extend_intv(const bsx_index_t *idx, int parent, const uint64
 BSX_API uint64_t oracle_sa(const bsx_index_t *idx, int parent, uint64_t k) { return fm_sa(&idx->fmi[parent], k, 0); }
 
 /* `biscuit align` on the CPU restatement: the timed CPU baseline and the SAM-level checker */
-static int port_open(int ordinal, const bsx_index_t *idx, void **ud) { (void)ordinal; *ud = oracle_port_new(idx, 1); return BSX_OK; }
+/* where the reference's kernels live: $ORACLE_REF_KERNELS names the library, or "1" = _ref/libbiscuit_ref.so next to this one */
+BSX_API int oracle_port_use_reference_kernels_env(void *c)
+{
+	const char *e = getenv("ORACLE_REF_KERNELS");
+	char path[4096];
+	Dl_info di;
+	if (!e || !*e || !strcmp(e, "0")) return 1;
+	if (strcmp(e, "1")) return oracle_port_use_reference_kernels(c, e);
+	if (!dladdr((void*)oracle_port_use_reference_kernels_env, &di) || !di.dli_fname) return -1;
+	snprintf(path, sizeof(path), "%s", di.dli_fname);
+	{ char *sl = strrchr(path, '/'); if (!sl) return -1; snprintf(sl + 1, sizeof(path) - (size_t)(sl + 1 - path), "_ref/libbiscuit_ref.so"); }
+	return oracle_port_use_reference_kernels(c, path);
+}
+static int port_open(int ordinal, const bsx_index_t *idx, void **ud)
+{
+	(void)ordinal;
+	*ud = oracle_port_new(idx, 1);
+	if (oracle_port_use_reference_kernels_env(*ud) < 0) { fprintf(stderr, "[oracle_align] $ORACLE_REF_KERNELS is set but oracle/_ref/libbiscuit_ref.so could not be used\n"); return BSX_E_ARG; }
+	return BSX_OK;
+}
 static int port_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t np, int n, bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
 	bsx_backend_t be;

@@ -101,6 +101,32 @@ API int ref_bwt_seed_strategy1(void *hb, void *hc, int len, const uint8_t *q, in
 	return r;
 }
 
+/* a bwt_t over arrays that live elsewhere (nothing is copied): the fields bwt_restore_bwt / bwt_restore_sa fill from the files
+ * (bwt.c:412-491) plus the count table bwt_restore_bwt builds.  For timing the reference's kernels on an index that was never
+ * written to disk (bench.py's cpu_baseline). */
+API void *ref_bwt_wrap(uint64_t primary, const uint64_t *L2, uint64_t seq_len, uint64_t bwt_size, uint32_t *bwt_, int sa_intv, uint64_t n_sa, uint64_t *sa)
+{
+	bwt_t *b = (bwt_t*)calloc(1, sizeof(bwt_t));
+	int i;
+	b->primary = primary; for (i = 0; i < 5; ++i) b->L2[i] = L2[i];
+	b->seq_len = seq_len; b->bwt_size = bwt_size; b->bwt = bwt_;
+	b->sa_intv = sa_intv; b->n_sa = n_sa; b->sa = (bwtint_t*)sa;
+	bwt_gen_cnt_table(b);
+	return b;
+}
+API void ref_bwt_unwrap(void *h) { free(h); }
+/* bwt_smem1a with the caller's vectors kept between calls, as mem_collect_intv keeps them in its bwtintv_cache_t (memchain.c:57-59,68) */
+typedef struct { bwtintv_v mem, tmp[2]; bwtintv_v *tmpv[2]; } ref_smem_ctx_t;
+API void *ref_smem_ctx_new(void) { ref_smem_ctx_t *c = (ref_smem_ctx_t*)calloc(1, sizeof(*c)); c->tmpv[0] = &c->tmp[0]; c->tmpv[1] = &c->tmp[1]; return c; }
+API void ref_smem_ctx_free(void *c_) { ref_smem_ctx_t *c = (ref_smem_ctx_t*)c_; free(c->mem.a); free(c->tmp[0].a); free(c->tmp[1].a); free(c); }
+API int ref_bwt_smem1a_ctx(void *c_, void *hb, void *hc, int len, const uint8_t *q, int x, int min_intv, const uint64_t **out, int *n)
+{
+	ref_smem_ctx_t *c = (ref_smem_ctx_t*)c_;
+	int r = bwt_smem1a((bwt_t*)hb, (bwt_t*)hc, len, q, x, min_intv, 0, &c->mem, c->tmpv);
+	*out = (const uint64_t*)c->mem.a; *n = (int)c->mem.n;   /* bwtintv_t = 4 x u64 */
+	return r;
+}
+
 /* ---------------- BWT construction primitive (is.c) ---------------- */
 int is_bwt(ubyte_t *T, int n); /* is.c:208 */
 /* in-place: T (n bytes of 0..3, plus one spare byte) becomes the BWT; returns primary */

@@ -46,6 +46,13 @@ class Port(Batches):
                "global_batch": L.oracle_port_global_batch}
         Batches.__init__(self, fns, self.h)
 
+    def use_reference_kernels(self):
+        """the same seams over the reference's own kernels (oracle/_ref: bwt.c, ksw.c); False when the library is absent"""
+        if not os.path.exists(REF_PATH):
+            return False
+        self.L.oracle_port_use_reference_kernels.argtypes = [C.c_void_p, C.c_char_p]
+        return self.L.oracle_port_use_reference_kernels(self.h, REF_PATH.encode()) == 0
+
     def backend(self):
         be = B.Backend()
         self.L.oracle_port_backend(self.h, C.byref(be))

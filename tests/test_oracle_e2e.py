@@ -36,3 +36,13 @@ def test_e2e_alt_contigs(data, name, args):
     finally:
         os.rename(data + "/g.alt", data + "/g.alt.off")
     E.assert_same_sam(got, want, name)
+
+
+@pytest.mark.parametrize("name,args", E.CASES_CORE + E.CASES_MORE[4:6], ids=[c[0] for c in E.CASES_CORE + E.CASES_MORE[4:6]])
+def test_host_pipeline_over_reference_kernels(data, name, args):
+    """bench.py's cpu_baseline: the host pipeline over the reference's OWN kernels (ORACLE_REF_KERNELS: oracle/_ref's bwt_smem1a,
+    bwt_seed_strategy1, bwt_sa, ksw_extend2, ksw_align2 (SSE2), ksw_global2 instead of oracle/port.c's scalar restatements) gives the
+    same SAM as the end-to-end oracle."""
+    want = E.run_e2e(args, data, procs=4)
+    got = E.run_exe(CPU, args, data, env={"ORACLE_REF_KERNELS": "1"})
+    E.assert_same_sam(got, want, name)
