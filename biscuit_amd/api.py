@@ -54,12 +54,13 @@ class Index:
         return cls._wrap(h)
 
     @classmethod
-    def synthetic(cls, n_bases, seed, n_contigs=8, repeat_frac=0.05):
-        """seeded synthetic genome (csrc/host/sim.c) straight into an index without FM indices"""
+    def synthetic(cls, n_bases, seed, n_contigs=8, repeat_frac=0.05, profile=0):
+        """seeded synthetic genome (csrc/host/sim.c) straight into an index without FM indices; profile 1 = with the high-copy
+        interspersed repeat families of a mammalian genome (~43 % repeats)"""
         L = B.lib()
-        L.bsx_sim_genome_index.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+        L.bsx_sim_genome_index2.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_void_p)]
         h = C.c_void_p()
-        B.check(L.bsx_sim_genome_index(n_bases, seed, n_contigs, repeat_frac, C.byref(h)), "bsx_sim_genome_index")
+        B.check(L.bsx_sim_genome_index2(n_bases, seed, n_contigs, repeat_frac, profile, C.byref(h)), "bsx_sim_genome_index2")
         return cls._wrap(h)
 
     def build_host(self):
