@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one chunk at a time through bsx_process_seqs (no overlap of consecutive chunks)")
+    ap.add_argument("--genome-profile", choices=["clean", "hg38-like"], default="clean",
+                    help="clean: i.i.d. bases + 5 %% planted repeats (the workload of rounds 1-2); hg38-like: + interspersed repeat families with up to a million copies, ~43 %% repeats (csrc/host/sim.c)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,7 +78,7 @@ def main():
     # genome takes ~5 s to generate and ~13 s to index), resident in HBM from then on.  Rank 0 of a single-GPU run also
     # takes the file-format arrays back to the host: the CPU baseline needs them.
     t0 = time.time()
-    idx = Index.synthetic(n_bases, seed=2024, n_contigs=24 if n_bases >= 1_000_000_000 else 8)
+    idx = Index.synthetic(n_bases, seed=2024, n_contigs=24 if n_bases >= 1_000_000_000 else 8, profile=1 if args.genome_profile == "hg38-like" else 0)
     dev = Device(local_rank)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     dev.build_index(idx, fill_host=want_cpu)
@@ -340,15 +342,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L, B, idx, opt, args, ncores)
 
+    repeats = ("with hg38-like repeat content (SINE/LINE/LTR-like families of up to a million copies, satellite arrays: ~43 % repeats)"
+               if args.genome_profile == "hg38-like" else "with repeat families (5 % planted repeats of 1-5 copies)")
+    workload = ("BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs a SYNTHETIC %.0f Mbp genome %s "
+                "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
+                "built on the GPU at start-up), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9))
     if rank == 0:
         names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_host_path_batches"]
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs a SYNTHETIC %.0f Mbp genome with repeat families "
-                                   "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
-                                   "built on the GPU at start-up), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp, 2 * n_bases / 1e9),
+            "config": {"workload": workload,
                        "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": ("chunk-sharded x%d" % world) + (" (CODE-PATH CHECK: all ranks on one GPU, gloo; not a measurement)" if share_gpu else ""), "chunk_pipeline_depth": depth,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 4 * 8) + n_bases / 4)},
             "roofline": roof,

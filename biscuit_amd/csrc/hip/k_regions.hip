@@ -1124,7 +1124,7 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 // so far, the read, the current chain's seeds and its reference window live in LDS (5.5 KB per wave), so the launch runs at the
 // occupancy the registers allow.
 #define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
-#define RG_XREGS 24
+#define RG_XREGS 64      // regions of one strand search (a lane each in the containment test); a read inside a high-copy repeat has dozens
 #define RG_XCBLK 16      // chain records staged at a time
 struct RgC2r {
 	bsx_region_t regs[RG_XREGS];
@@ -1782,12 +1782,13 @@ k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_den
 }
 
 __global__ void __launch_bounds__(256)
-k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const unsigned long long *cursor, unsigned long long *counters)
+k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const unsigned long long *cursor, unsigned long long *counters, const unsigned long long *start)
 {
 	unsigned long long n = *cursor;
 	if (n > desc_cap) n = desc_cap;
 	uint32_t lf = 0, calls = 0;
-	for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * blockDim.x) {
+	// start: where this launch's ranks begin (what lies before was turned into positions by an earlier launch over the same pool)
+	for (unsigned long long j = (start ? *start : 0ull) + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * blockDim.x) {
 		const unsigned long long v = desc[j];
 		desc[j] = (unsigned long long)rg_sa(ix, (int)(v >> 63), v & 0x7fffffffffffffffull, lf);
 		++calls;
@@ -1798,10 +1799,11 @@ k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const 
 
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters, unsigned char *cls)
+                unsigned long long *counters, unsigned char *cls, unsigned long long *start)
 {
+	if (start) (void)hipMemcpyAsync(start, cursor, 8, hipMemcpyDeviceToDevice, st);   // a later launch over the same pool: only the ranks it adds
 	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off, cls);
-	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters);
+	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters, (const unsigned long long*)start);
 }
 
 // The index files sample the suffix array every 32nd rank (bwtindex.c:328,340), which makes bwt_sa a walk of 31 LF steps

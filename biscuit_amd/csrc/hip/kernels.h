@@ -70,7 +70,7 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 // t's start, -1 = none listed), then turned into reference positions in place.  pos_off/pos feed launch_regions*.
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters, unsigned char *cls);   // cls[t]: the first tier whose interval/occurrence tables hold task t
+                unsigned long long *counters, unsigned char *cls, unsigned long long *start = nullptr);   // start: an 8-byte device slot; set = only the ranks this call adds to the pool are walked   // cls[t]: the first tier whose interval/occurrence tables hold task t
 // out[j] = SA[j * intv] for j < n, from the (sparser) samples ix currently holds: the denser suffix-array sample kept in HBM
 void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out);
 // C5 (k_dedup.hip): mem_sort_deduplicate of every read over the regions of the chunk, a lane per read

@@ -29,7 +29,7 @@ struct Lane {
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
-	DevBuf jobs, res, scratch, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
+	DevBuf jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -130,7 +130,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	d->pac.release(); d->ctg.release();
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
-		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.out.release(); L.aux.release(); L.pool.release();
+		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
 		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
@@ -519,7 +519,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
-	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 6 + 65536;
+	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 1;   // one strand search per lane: the lanes of a wave then go through the seeding passes together (measured at hg38 scale: 335 ms with two, 292 with one, 359 with persistent lanes)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
@@ -532,7 +532,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
 	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
 	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // as in lane_seed_batch
-	const int big_grid = d->n_cu * 2, huge_grid = 16;
+	const int big_grid = d->n_cu * 2, huge_grid = d->n_cu / 2;   // four waves a block; the third tier's slabs are 1.3 MB a wave (0.65 GB per chunk in flight)
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
@@ -662,32 +662,52 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipEventSynchronize(L.ev1));
 		D2H(L.st2, s_n.data(), d_n, (size_t)n * 4);
 		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i);
-		if (redo.size() > 4096) redo.clear();   // not the rare case this is for: leave them to the caller
+		if (redo.size() > 262144) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	L.rs.active = false;
 	if (!redo.empty()) {
+		// Seeded again on the side stream with lists eight times as long and no trip budget, then through the same tiers as everything else
+		// (on a genome with hg38's repeat content these are 4 % of the strand searches -- reads inside young copies of a repeat family -- not
+		// the few dozen tandem-repeat reads of a clean one)
 		const size_t n2 = redo.size();
 		const int g2 = (int)((n2 + 255) / 256);
-		// one pass with the longest lists the scratch we already hold allows (up to 512x the first pass)
-		long long cap2 = ((long long)(scratch_bytes / ((size_t)g2 * 256)) - 16LL * list_cap) / 32;
-		if (cap2 > (long long)mem_cap * 512) cap2 = (long long)mem_cap * 512;
-		if (cap2 >= (long long)mem_cap * 8 && g2 * 4 <= n_slabs) {
+		const long long cap2 = std::max<long long>((long long)mem_cap * 8, 1024);
+		const size_t scratch2 = (size_t)g2 * 256 * ((size_t)cap2 * 32 + (size_t)list_cap * 16);
+		if (g2 * 4 <= n_slabs && scratch2 <= ((size_t)24 << 30)) {
+			if ((rc = L.scratch2.reserve(scratch2)) != BSX_OK) return rc;
 			L.rs.tasks = redo; L.rs.sub.resize(n2); L.rs.n2u = (unsigned int)n2;
 			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[redo[j]];
-			// device side: tasks2 | off2 | roff2 | cnt2 | rn2
-			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 4 + 4) + 256)) != BSX_OK) return rc;
+			// device side, per re-seeded strand search: task | interval offset | region offset | position offset | export offset | interval
+			// count | region count | three tier lists | export list | tier class
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 12 + 4 + 1) + 1024)) != BSX_OK) return rc;
 			if ((rc = L.rs.hres.reserve(n2 * 12 + 64)) != BSX_OK) return rc;
 			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
-			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; int *cnt2 = (int*)(roff2 + n2); int *rn2 = cnt2 + n2;
+			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; long long *posoff2 = roff2 + n2; long long *xoff2 = posoff2 + n2;
+			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *xlist2 = rb2 + n2;
+			unsigned char *cls2 = (unsigned char*)(xlist2 + n2);
+			// its own cursors (u64 slots 96.. of the lane's counter block): u32 [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3
+			// count [4] tier-3 cursor [7] seed task cursor [10] count of what the larger LDS tier hands on [11] its cursor; slot 102: exported
+			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
+			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemcpyAsync(c32 + 5, &L.rs.n2u, 4, hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemsetAsync(c32 + 7, 0, 4, L.st2));
-			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, c32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
-			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the third tier's slabs are shared with the main launch sequence
+			HIPCHK(hipMemsetAsync(ctr + 96, 0, 64, L.st2));
+			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
+			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
+			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
+			RgXPoolArg XB = XA;
+			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
+			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
+			launch_regions(L.st2, (int)((n2 + 4LL * reg_quota - 1) / (4LL * reg_quota)), d->ix, L.sc, R, d_reads, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2,
+			               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, q32 + 0, ra2, q32 + 1, reg_quota, ctr, posoff2, d_pos, cls2, XB);
+			launch_regions_mid(L.st2, (int)((n2 + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
+			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, ra2, q32 + 1, q32 + 11, rm2, q32 + 10, ctr, posoff2, d_pos, XB, mid_quota);
+			launch_c2r(L.st2, (int)((n2 + 4LL * c2r_quota - 1) / (4LL * c2r_quota)), d->ix, L.sc, R, d_reads, t2, XB, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2,
+			           (unsigned int*)(ctr + 102) + 1, rm2, q32 + 10, ctr, c2r_quota);
+			launch_regions_slab(L.st2, 2, big_grid, d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, rm2, q32 + 10, q32 + 2, L.slabs.p, rb2, q32 + 3, ctr, posoff2, d_pos);
 			launch_regions_slab(L.st2, 3, huge_grid, d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, nullptr, c32 + 5, c32 + 6, L.slabs3.p, nullptr, nullptr, ctr, nullptr, nullptr);   // a handful of tasks: LF walks inline
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, rb2, q32 + 3, q32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoff2, d_pos);
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
