@@ -11,21 +11,28 @@ extern "C" {
 // buffer that grows therefore leaves its old block on a list that is emptied when the device is closed.
 #include <mutex>
 #include <vector>
-struct DevbufDeferred { std::mutex mu; std::vector<void*> dev, host; };
+#include <utility>
+struct DevbufDeferred { std::mutex mu; std::vector<std::pair<int, void*>> dev, host; };   // (device ordinal current when the block was retired, block)
 inline DevbufDeferred &devbuf_deferred() { static DevbufDeferred d; return d; }
-inline void devbuf_drain() {
+inline int devbuf_current() { int o = 0; if (hipGetDevice(&o) != hipSuccess) { (void)hipGetLastError(); o = -1; } return o; }
+// frees what the buffers of device `ordinal` left behind (the current device must be that one): another open device's lanes may be in
+// the middle of a chunk, and hipFree waits for whatever runs on the device the block belongs to
+inline void devbuf_drain(int ordinal) {
 	DevbufDeferred &d = devbuf_deferred();
 	std::lock_guard<std::mutex> g(d.mu);
-	for (void *q : d.dev) (void)hipFree(q);
-	for (void *q : d.host) (void)hipHostFree(q);
-	d.dev.clear(); d.host.clear();
+	size_t k = 0;
+	for (auto &q : d.dev) { if (q.first == ordinal || q.first < 0) (void)hipFree(q.second); else d.dev[k++] = q; }
+	d.dev.resize(k);
+	k = 0;
+	for (auto &q : d.host) { if (q.first == ordinal || q.first < 0) (void)hipHostFree(q.second); else d.host[k++] = q; }
+	d.host.resize(k);
 }
 
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
 	int reserve(size_t n) {
 		if (n <= cap) return BSX_OK;
-		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.dev.push_back(p); p = nullptr; }
+		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.dev.push_back(std::make_pair(devbuf_current(), p)); p = nullptr; }
 		size_t want = n + (n >> 1) + 4096;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed\n", want); return BSX_E_NOMEM; }
 		cap = want;
@@ -46,7 +53,7 @@ struct HostBuf {   // pinned host staging (D2H/H2D at full PCIe rate, no hidden 
 	void *p = nullptr; size_t cap = 0;
 	int reserve(size_t n) {
 		if (n <= cap) return BSX_OK;
-		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.host.push_back(p); p = nullptr; }
+		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.host.push_back(std::make_pair(devbuf_current(), p)); p = nullptr; }
 		size_t want = n + (n >> 1) + 4096;
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; return BSX_E_NOMEM; }
 		cap = want;

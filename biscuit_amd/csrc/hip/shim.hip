@@ -125,7 +125,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 {
 	if (!d) return;
 	(void)hipSetDevice(d->ordinal);
-	devbuf_drain();   // the blocks that buffers which grew left behind
+	devbuf_drain(d->ordinal);   // the blocks this device's buffers left behind when they grew
 	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
 	d->pac.release(); d->ctg.release();
 	for (int l = 0; l < BSX_LANES; ++l) {
@@ -257,7 +257,7 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 		g.sa_mask = (uint32_t)dense - 1; g.sa_shift = 0;
 		while ((1 << g.sa_shift) < dense) ++g.sa_shift;
 	}
-	devbuf_drain();   // nothing else runs on the device yet: the blocks the builder's growing buffers left behind go now
+	devbuf_drain(d->ordinal);   // the blocks the builder's growing buffers left behind on this device go now
 	d->has_index = true;
 	return BSX_OK;
 }
@@ -400,6 +400,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc, max_len = 0;
 	for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, tasks[i].len);
+	if (max_len >= 1 << 18) return BSX_E_ARG;   // a lane addresses its slab with 32-bit byte offsets (seed_core.hpp): 64 lanes x 32 B x (8 x max_len) entries of the second pass must stay below 2^32
 	SeedParams P;
 	P.min_seed_len = opt->min_seed_len;
 	P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);
@@ -503,6 +504,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	clock_gettime(CLOCK_MONOTONIC, &ts_in);
 	int rc, max_len = 0;
 	for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, tasks[i].len);
+	if (max_len >= 1 << 18) return BSX_E_ARG;   // a lane addresses its slab with 32-bit byte offsets (seed_core.hpp): 64 lanes x 32 B x (8 x max_len) entries of the second pass must stay below 2^32
 	SeedParams P;
 	P.min_seed_len = opt->min_seed_len;
 	P.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);

@@ -317,6 +317,7 @@ struct bsx_gsink {
 	BSX_VEC(bsx_amb_t) holes;
 	int n_anns, m_anns;
 	int lasts;               /* last character of the current contig (runs of one ambiguity code form one hole) */
+	unsigned short xs[3];    /* the 48-bit state srand48(11) sets (bntseq.c:558-559), kept per sink: nrand48 over it is lrand48's sequence */
 };
 
 bsx_gsink_t *bsx_gsink_new(void)
@@ -325,7 +326,7 @@ bsx_gsink_t *bsx_gsink_new(void)
 	g->idx = (bsx_index_t*)calloc(1, sizeof(bsx_index_t));
 	g->idx->ref.seed = 11;
 	bsx_vec_init(g->holes);
-	srand48(11);
+	g->xs[0] = 0x330E; g->xs[1] = 11; g->xs[2] = 0;
 	return g;
 }
 
@@ -369,7 +370,7 @@ int bsx_gsink_bases(bsx_gsink_t *g, const char *chars, int64_t n)
 				bsx_vec_push(g->holes, h);
 				++p->n_ambs;
 			}
-			c = (int)(lrand48() & 3);
+			c = (int)(nrand48(g->xs) & 3);
 		}
 		g->lasts = ch;
 		pac[l >> 2] |= (uint8_t)(c << ((~l & 3) << 1));

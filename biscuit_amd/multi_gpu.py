@@ -4,8 +4,8 @@
         -m biscuit_amd.multi_gpu [--out FILE] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
 
 Every rank cuts the input into the reference's chunks (10 Mbp x -@, align.c:576) and aligns chunks
-r, r+N, ... on its own GPU against its own HBM-resident copy of the index (the chunks of other ranks are
-skipped by the reader without being parsed into records).  A chunk is the only unit whose reads depend on
+r, r+N, ... on its own GPU against its own HBM-resident copy of the index (every rank's reader still parses the
+whole input -- the chunk rule is cumulative -- and drops the chunks of the other ranks: csrc/host/cli.c).  A chunk is the only unit whose reads depend on
 each other (per-chunk insert-size statistics), so the SAM equals the single-GPU / CPU output for the same
 -@.  The only communication is the streaming gather of the per-chunk SAM text to rank 0
 (biscuit_amd/gather.py: sizes, then exactly the payload, point to point -> RCCL over xGMI), overlapped
@@ -57,9 +57,17 @@ def main(argv=None, entry=None, use_gpu=True):
         out = open(out_path, "wb") if out_path else sys.stdout.buffer
     written = [0]
 
+    failed = [0]      # an output or hook failure on this rank: the rounds go on (the other ranks are inside collectives), the exit status says so
+
     def sink(idx, buf):
-        out.write(buf)
-        written[0] += len(buf)
+        if failed[0]:
+            return
+        try:
+            out.write(buf)
+            written[0] += len(buf)
+        except Exception as e:
+            failed[0] = 1
+            sys.stderr.write("[E::multi_gpu] writing the SAM failed: %r\n" % (e,))
 
     dev = torch.device("cuda", local_rank) if (use_gpu and world > 1) else torch.device("cpu")
     G = ChunkGather(rank, world, dev, sink)
@@ -67,11 +75,18 @@ def main(argv=None, entry=None, use_gpu=True):
 
     def emit(ud, idx, text, n):
         # called on the aligner's writer thread, chunk by chunk in this rank's order; idx -1 = the header (rank 0 only)
-        data = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint8)
-        if idx < 0:
-            out.write(data)
-        else:
-            G.submit(idx, data)   # blocks when a few chunks are waiting for their round: back-pressure on the aligner
+        try:
+            data = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint8)
+            if idx < 0:
+                out.write(data)
+                return
+        except Exception as e:     # (an exception must not leave a ctypes callback: it would only be printed)
+            failed[0] = 1
+            sys.stderr.write("[E::multi_gpu] taking a chunk's records failed: %r\n" % (e,))
+            data = np.zeros(0, dtype=np.uint8)
+            if idx < 0:
+                return
+        G.submit(idx, data)   # blocks when a few chunks are waiting for their round: back-pressure on the aligner
 
     hook = HOOK(emit)
     C.c_void_p.in_dll(L, "bsx_emit_hook").value = C.cast(hook, C.c_void_p).value
@@ -89,7 +104,7 @@ def main(argv=None, entry=None, use_gpu=True):
     th.start()
     G.run()
     th.join()
-    rc = rc_box[0]
+    rc = rc_box[0] or failed[0]
     if world > 1:
         t = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

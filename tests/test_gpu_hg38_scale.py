@@ -270,3 +270,41 @@ def test_long_reads(big):
         assert np.mean([int(f[4]) >= 30 for f in prim]) > 0.9
     finally:
         L.bsx_sim_free_reads(p, n)
+
+
+def test_command_line_equals_end_to_end_oracle_from_index_files(big, tmp_path_factory):
+    """The index the device built, written out as the reference's seven files, then the two command lines on those files: the product
+    (`biscuit_align`: HIP kernels + C host pipeline) and oracle/e2e.py -- the end-to-end restatement that shares no host code with the
+    product and runs the reference's own bwt_restore_* / bwt_smem1a / bwt_sa / ksw_* (oracle/_ref) over the same files.  Suffix-array
+    ranks and forward-reverse coordinates are beyond 2^32 on both sides.  Needs ~11 GB of disk for the files (skipped without it)."""
+    import shutil
+    import subprocess
+    import sys
+    import e2e_cases as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libbiscuit_ref.so")):
+        pytest.skip("oracle/_ref is absent")
+    d = str(tmp_path_factory.mktemp("hg38_files"))
+    need = int(big["l_pac"] * 3.6) + (2 << 30)
+    if shutil.disk_usage(d).free < need:
+        pytest.skip("not enough disk for the index files (%d GB)" % (need >> 30))
+    L = B.lib()
+    idx = big["idx"]
+    idx.save(d + "/g")
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_sim_write_fastq.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    n_pairs = 2500
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 4242, 200, 500, 0.008, 0.15, C.byref(p)), "sim_pairs")
+    B.check(L.bsx_sim_write_fastq(p, 2 * n_pairs, (d + "/r1.fq").encode(), (d + "/r2.fq").encode(), 0), "write_fastq")
+    L.bsx_sim_free_reads(p, 2 * n_pairs)
+    try:
+        for args in (["-@", "4", "g", "r1.fq", "r2.fq"], ["-@", "4", "-b", "1", "g", "r1.fq"]):
+            want = E.run_e2e(args, d)
+            got = E.run_exe(os.path.join(root, "biscuit_amd", "biscuit_align"), args, d)
+            assert got.count(b"\n") > n_pairs
+            E.assert_same_sam(got, want, " ".join(args))
+    finally:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))

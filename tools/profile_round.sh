@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-3100} --steps ${STEPS:-24} --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --genome-mbp ${GENOME_MBP:-3100} --steps ${STEPS:-24} --warmup 1 --no-cpu-baseline --no-hard-genome"
 cd /tmp
 $BENCH > "$OUT/bench_untraced.json" 2> "$OUT/bench_untraced.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
