@@ -571,7 +571,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	// other seeds (the chain below a seed is either in the seed's own piece or too far to be joined) -- against an hg38-sized genome
 	// that is ~95 of the ~100 chains of a strand search, the chance matches of a 3-letter 19-mer.  Only the seeds of the other pieces
 	// go through the sequential loop below, in arrival order, over a table of their own chain starts.
-	int n_iso = 0, n_live = tot;
+	int n_iso = 0, n_live = tot, n_pieces = 0;
 	if (!Store::NODES) {
 		constexpr int NS = Store::SCAP / 64;
 		const long long dgap = (long long)l_query + 1 + (long long)(P.w < P.max_chain_gap ? P.w : P.max_chain_gap);
@@ -604,19 +604,27 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 #pragma unroll
 		for (int c = 0; c < NS; ++c) {
 			const int r = (c << 6) + lane;
+			bool opens = false; int o = 0;
 			if (r < n_live) {
-				const int o = S.lst[r];
+				o = S.lst[r];
 				const long long rb = S.s_rbeg[o];
 				const bool far_l = r == 0 || rb - S.s_rbeg[S.lst[r > 0 ? r - 1 : 0]] >= dgap;
 				const bool far_r = r == n_live - 1 || S.s_rbeg[S.lst[r + 1 < n_live ? r + 1 : r]] - rb >= dgap;
 				if (far_l && far_r) { S.s_chain[o] = (decltype(S.s_chain[0] + 0))o; S.s_extra[o] |= 8; ++iso; }   // bit 3: the seed starts a chain
-				else S.s_extra[o] |= 16;                                                                             // bit 4: it goes through the loop
+				else { S.s_extra[o] |= 16; opens = far_l; }                                                          // bit 4: it goes through the loop
 			}
+			// the piece a seed with neighbours lies in (pieces numbered along the reference): keep[] is free until the chains are filtered
+			const unsigned long long om = __ballot(opens);
+			if (r < n_live && (S.s_extra[o] & 16)) S.keep[o] = (idx_t)(n_pieces + __popcll(om & ((2ull << lane) - 1)) - 1);
+			n_pieces += __popcll(om);
 		}
 		n_iso = wave_sum_i32(iso);
 		WAVE_SYNC();
 	}
-	int o = -1, cbase = -64;
+	// The pieces do not interact, so each is chained on its own, its seeds in arrival order over a table of its own chain starts: a read
+	// inside a repeat family has hundreds of seeds in a hundred pieces of a few seeds each, and a search over one register set instead of
+	// one per 64 chains of the whole strand search
+	int o = -1, cbase = -64, piece = 0, nc_tot = 0;
 	unsigned long long cmask = 0;
 	for (;;) {
 		if (Store::NODES) { // every occurrence, in arrival order
@@ -629,11 +637,18 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				const int v = uni(S.iv_n[cur_iv]);
 				iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
 			}
-		} else { // the seeds with neighbours, in arrival order
-			while (cmask == 0) {
+		} else { // the seeds of the current piece, in arrival order; then the next piece with an empty table
+			while (cmask == 0 && piece < n_pieces) {
 				cbase += 64;
-				if (cbase >= tot) break;
-				cmask = __ballot(cbase + lane < tot && (S.s_extra[cbase + lane < tot ? cbase + lane : 0] & 16));
+				if (cbase >= tot) {
+					++piece; cbase = -64;
+					nc_tot += nc; nc = 0;
+#pragma unroll
+					for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
+					continue;
+				}
+				const int oo = cbase + lane < tot ? cbase + lane : 0;
+				cmask = __ballot(cbase + lane < tot && (S.s_extra[oo] & 16) && (int)S.keep[oo] == piece);
 			}
 			if (cmask == 0) break;
 			o = cbase + (int)__builtin_ctzll(cmask);
@@ -760,7 +775,8 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				acc += cnt;
 			}
 		}
-		if (nc + n_iso > Store::CCAP) return 3;
+		nc_tot += nc;
+		if (nc_tot + n_iso > Store::CCAP) return 3;
 		// chains in the order of their start positions (the in-order traversal of the reference's tree, memchain.c:372-379)
 		int n_heads = 0;
 		for (int base = 0; base < n_live; base += 64) {

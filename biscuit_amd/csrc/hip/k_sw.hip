@@ -33,8 +33,20 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 	for (int a = 0; a < 25; ++a) { shift = mat[a] < shift ? mat[a] : shift; mx = mat[a] > mx ? mat[a] : mx; }
 	shift = (int)(uint8_t)(256 - (int)(uint8_t)shift);   // ksw.c:84-88
 	int Hp[NC], Hc[NC], E[NC], Hm[NC];
+	// per column, fixed for the job: the scores of its query base against target bases 0..3 (a byte each; a padding column scores 0),
+	// whether it opens a stripe, and its stripe number times seg_step.  The stripe-restricted F below is a prefix maximum that must not
+	// look past the start of the column's stripe: with that added on top of every term (terms stay below seg_step) the
+	// plain prefix maximum of the row can only be attained inside the column's own stripe, so both F's are DPP scans.
+	uint32_t sqp[NC]; int segoff[NC]; bool headc[NC];
+	const int seg_step = 1 << (32 - __builtin_clz((unsigned)(32768 + Q * e_ins)));   // above every term of the scans (h <= 32767, plus j * e_ins); 16 stripes stay far below 2^29
 #pragma unroll
-	for (int c = 0; c < NC; ++c) { Hp[c] = 0; Hc[c] = 0; E[c] = 0; Hm[c] = 0; }
+	for (int c = 0; c < NC; ++c) {
+		Hp[c] = 0; Hc[c] = 0; E[c] = 0; Hm[c] = 0;
+		const int j = (c << 6) + lane, q = qv[c];
+		sqp[c] = q > 4 ? 0u : ((uint32_t)(uint8_t)mat[q] | (uint32_t)(uint8_t)mat[5 + q] << 8 | (uint32_t)(uint8_t)mat[10 + q] << 16 | (uint32_t)(uint8_t)mat[15 + q] << 24);
+		const int sg = j / slen;
+		segoff[c] = sg * seg_step; headc[c] = j < Q && j - sg * slen == 0;
+	}
 	int gmax = 0, te = -1, n_b = 0;
 	unsigned long long b_last = 0;
 	int tb_reg = 4;
@@ -44,8 +56,7 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 			const long long src = (ii <= te_rev) ? (long long)(te_rev - ii) : (long long)ii;  // reversed prefix in pass 2
 			tb_reg = ii < tlen ? dev_ref_base(ix.pac, ix.l_pac, tpos + src * tdir) : 4;
 		}
-		const int t = wave_bcast(tb_reg, i & 63);
-		const int s0 = mat[t * 5], s1 = mat[t * 5 + 1], s2 = mat[t * 5 + 2], s3 = mat[t * 5 + 3], s4 = mat[t * 5 + 4];
+		const int tsh = (wave_bcast(tb_reg, i & 63) & 3) << 3;   // the reference never holds an ambiguous base (bntseq.c:558-559)
 		int rowmax = 0, pm_full = NEG_BIG, carry_seg = NEG_BIG;
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
@@ -55,8 +66,7 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 				int d = wave_prev(Hp[c], 0);
 				if (lane == 0) d = 0;
 				if (c > 0) { const int pv = __builtin_amdgcn_readlane(Hp[c > 0 ? c - 1 : 0], 63); if (lane == 0) d = pv; }
-				const int q = qv[c];
-				const int s = q == 0 ? s0 : q == 1 ? s1 : q == 2 ? s2 : q == 3 ? s3 : q == 4 ? s4 : 0;
+				const int s = (int)(int8_t)(sqp[c] >> tsh);
 				int h;
 				if (is_u8) { h = d + s + shift; h = h > 255 ? 255 : h; h -= shift; h = h < 0 ? 0 : h; }
 				else { h = d + s; h = h > 32767 ? 32767 : h; }
@@ -71,13 +81,11 @@ __device__ __forceinline__ SwPass sw_pass(const DevIndex &ix, const int8_t *mat,
 				int ff = j == 0 ? 0 : excl - (j - 1) * e_ins;
 				ff = ff > 0 ? ff : 0;
 				// stripe-restricted F (restarts at every multiple of slen)
-				const int head = (act && (j % slen) == 0) ? 1 : 0;
-				int hflag = head;
-				int sincl = wave_segscan_max_incl(g, hflag);
-				if (!hflag) sincl = sincl > carry_seg ? sincl : carry_seg;
+				int sincl = wave_scan_max_incl(act ? g + segoff[c] : NEG_BIG);
+				sincl = sincl > carry_seg ? sincl : carry_seg;
 				const int sexcl = wave_prev(sincl, carry_seg);
 				carry_seg = __builtin_amdgcn_readlane(sincl, 63);
-				int fs = head ? 0 : sexcl - (j - 1) * e_ins;
+				int fs = headc[c] ? 0 : sexcl - segoff[c] - (j - 1) * e_ins;
 				fs = fs > 0 ? fs : 0;
 				const int hpre = h > fs ? h : fs;
 				const int hh = h > ff ? h : ff;
