@@ -273,7 +273,7 @@ def main():
     pmc = {}
     import glob
     cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%dmbp.json" % int(round(args.genome_mbp)))))
-    if cand and args.read_len == 150 and threads == 16:
+    if cand and args.read_len == 150 and threads == 16 and args.genome_profile == "clean":
         with open(cand[-1]) as f:
             tj = json.load(f)
         if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
