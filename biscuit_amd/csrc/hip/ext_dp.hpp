@@ -181,7 +181,7 @@ __device__ __forceinline__ bsx_ext_res_t ext_dp_reg(const DevIndex &ix, const De
 	int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
 	int beg = 0, end = qlen;
 	int tb_reg = 4;
-	const bool packed_max = (long long)h0 + (long long)qlen * mx < (1 << 21);   // every H of this job fits 22 bits
+	const bool packed_max = qlen <= 512 && (long long)h0 + (long long)qlen * mx < (1 << 21);   // every H of this job fits 22 bits and every column 9
 	for (int i = 0; i < tlen; ++i) {
 		if ((i & 63) == 0) {
 			const long long tp = J.tpos + (long long)(i + lane) * J.tdir;

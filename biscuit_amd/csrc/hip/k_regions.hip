@@ -74,11 +74,14 @@ typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
 struct RgDp {            // per-wave LDS scratch
+	static const int QCAP = RG_QCAP;
 	int32_t H[64], E[64];        // the one-lane passes (introsort stack, tree traversal stack)
 	uint8_t q[RG_QCAP];          // the read
 	uint8_t win[RG_WIN];         // reference bases [rmax0, rmax1) of the chain being extended, one byte each
 };
-struct RgDpLite { int32_t H[64], E[64]; uint8_t q[RG_QCAP]; uint8_t win[4]; };   // the LDS tiers stop before the extensions: no window
+struct RgDpLite { static const int QCAP = RG_QCAP; int32_t H[64], E[64]; uint8_t q[RG_QCAP]; uint8_t win[4]; };   // the LDS tiers stop before the extensions: no window
+#define RG_QCAP_LONG 1024   // the launches for chunks with longer reads (a read of a kilobase; anything longer is chained by the caller)
+struct RgDpLiteL { static const int QCAP = RG_QCAP_LONG; int32_t H[64], E[64]; uint8_t q[RG_QCAP_LONG]; uint8_t win[4]; };
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -129,7 +132,7 @@ __device__ __forceinline__ int rg_cal_max_gap(const RegParams &P, int qlen)   //
 	return l < P.w << 1 ? l : P.w << 1;
 }
 // cal_max_gap for every length a read of this kernel can ask about, tabulated once per workgroup (two double divisions each)
-__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (unsigned)qlen <= (unsigned)RG_QCAP ? tab[qlen] : rg_cal_max_gap(P, qlen); }
+__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (unsigned)qlen <= (unsigned)P.gap_cap ? tab[qlen] : rg_cal_max_gap(P, qlen); }
 #define RG_BSS(parent, l_pac, rb) ((((rb) > (l_pac)) == (parent)) ? 1 : 0)
 
 // klib introsort (ksort.h:184-236) of the chains by weight, descending, with the control flow of
@@ -331,9 +334,12 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 // wave at the larger size, six waves per CU), the chain-to-region loop needs registers and latency hiding (extension rows are
 // dependent DPP chains) but almost no tables.  One launch each, with the occupancy each can have.  What is exported per strand
 // search: the kept chains in processing order, each with its seeds (main list, then seeds_extra) in arrival order.
-struct RgXHdr { int n_chains, n_seeds; float frac_rep; int pad; };
+struct RgXHdr { int n_chains, n_seeds; float frac_rep; int flt; };   // flt: min_HSP_score when the seed-SW filter applies to this read (k_seedsw runs before k_c2r), RG_NOFLT otherwise
+#define RG_NOFLT ((int)0x80000000)
 struct RgXChain { long long pos; int rid, seed_off; unsigned short n_main, n_extra; int pad; };
-struct RgXSeed { long long rbeg; short qbeg, len; unsigned char bad, pad[3]; };
+struct RgXSeed { long long rbeg; short qbeg, len; int sb; };   // sb: mem_seed_t.score << 1 | failed asymmetric_flt_seed
+#define XS_BAD(x) ((x).sb & 1)
+#define XS_SCORE(x) ((x).sb >> 1)
 struct RgXPool { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
 
 // the record of chain `id` (by value); for a chain of one seed, made up from the seed (s_extra bit 2 = its contig is an ALT)
@@ -352,7 +358,7 @@ __device__ __forceinline__ RgChain rg_chain(const Store &S, int id)
 
 // returns 11 (exported), 0 (nothing left to extend: the strand search has no regions) or 6 (no room: the next tier takes it)
 template <typename Store>
-__device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool &X, int lane)
+__device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool &X, int lane, int flt)
 {
 	typedef typename Store::idx_t idx_t;
 	const int nk = uni(S.n_chains);
@@ -383,7 +389,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 	RgXHdr *H = (RgXHdr*)(X.base + at);
 	RgXChain *XC = (RgXChain*)(H + 1);
 	RgXSeed *XS = (RgXSeed*)(XC + n_surv);
-	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->pad = 0; }
+	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->flt = flt; }
 	int so = 0;
 	for (int ci = 0; ci < n_surv; ++ci) {
 		const int c = uni(S.ord[ci]);
@@ -391,7 +397,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 		const int n_main = uni(chn.n_seeds), n_extra = uni(chn.n_extra);
 		if (lane == 0) { RgXChain x; x.pos = chn.pos; x.rid = chn.rid; x.seed_off = so; x.n_main = (unsigned short)n_main; x.n_extra = (unsigned short)n_extra; x.pad = 0; XC[ci] = x; }
 		if (n_main == 1 && n_extra == 0) {
-			if (lane == 0) { const int o = chn.seed0; RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.bad = (unsigned char)((S.s_extra[o] >> 1) & 1); x.pad[0] = x.pad[1] = x.pad[2] = 0; XS[so] = x; }
+			if (lane == 0) { const int o = chn.seed0; RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.sb = (int)x.len << 1 | ((S.s_extra[o] >> 1) & 1); XS[so] = x; }
 			so += 1;
 			continue;
 		}
@@ -402,7 +408,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 				const int o = base + lane;
 				const bool in = o < tot && S.s_chain[o] == c && (int)(S.s_extra[o] & 1) == pass;
 				const unsigned long long b = __ballot(in);
-				if (in) { RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.bad = (unsigned char)((S.s_extra[o] >> 1) & 1); x.pad[0] = x.pad[1] = x.pad[2] = 0; XS[so + nl + __popcll(b & lt_mask)] = x; }
+				if (in) { RgXSeed x; x.rbeg = S.s_rbeg[o]; x.qbeg = S.s_qbeg[o]; x.len = S.s_len[o]; x.sb = (int)x.len << 1 | ((S.s_extra[o] >> 1) & 1); XS[so + nl + __popcll(b & lt_mask)] = x; }
 				nl += __popcll(b);
 			}
 			so += nl;
@@ -434,12 +440,12 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	}
 	WAVE_SYNC();
 	if (n_iv < 0) return 1;
-	if (l_query > RG_QCAP) return 9;
+	if (l_query > DP::QCAP) return 9;
 	if (n_iv > Store::ICAP) return 8;
-	{
-		const double min_l = P.min_chain_weight ? 1.1f * P.min_chain_weight : 5.5f * log((double)l_query);
-		if (l_query >= 1 && !(min_l > 0.05f * l_query)) return 9;
-	}
+	// mem_flt_chained_seeds (memchain.c:537-568) runs for reads of this length?  Then the chains are exported with the threshold and
+	// k_seedsw scores their seeds before k_c2r; the tiers that make regions themselves leave such a strand search to the caller
+	const int flt = (P.flt_tab && l_query <= P.flt_len) ? uni(P.flt_tab[l_query]) : RG_NOFLT;
+	if (!SPLIT && flt != RG_NOFLT) return 9;
 	if (n_iv == 0 || l_query < P.min_seed_len) return 0;
 	for (int i = lane; i < l_query; i += 64) D.q[i] = query[i];   // the read, for the seed tests and the extensions (ordered by the stage barriers below)
 
@@ -929,7 +935,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	}
 	RG_STAGE(5);
 	if (SPLIT) { // the chain-to-region loop runs in k_c2r
-		const int st = rg_export(S, task_id, tot, frac_rep, *X, lane);
+		const int st = rg_export(S, task_id, tot, frac_rep, *X, lane, flt);
 		RG_STAGE(6);
 		return st;
 	}
@@ -1142,17 +1148,22 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 #define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
 #define RG_XREGS 64      // regions of one strand search (a lane each in the containment test); a read inside a high-copy repeat has dozens
 #define RG_XCBLK 16      // chain records staged at a time
-struct RgC2r {
+template <int QC, int WC, int XSD>
+struct RgC2rT {
+	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD;
 	bsx_region_t regs[RG_XREGS];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
-	RgXSeed sd[RG_XSEEDS];   // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
-	unsigned long long srt[RG_XSEEDS];
-	uint8_t q[RG_QCAP];
-	uint8_t win[RG_WIN];
+	RgXSeed sd[XSD];         // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
+	unsigned long long srt[XSD];
+	uint8_t q[QC];
+	uint8_t win[WC];
 	int n_regs;
 };
+typedef RgC2rT<RG_QCAP, RG_WIN, RG_XSEEDS> RgC2r;
+typedef RgC2rT<RG_QCAP_LONG, 2048, 512> RgC2rL;   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
 
-__device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, int l_query, int parent, uint32_t qoff,
+template <typename WT>
+__device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, int l_query, int parent, uint32_t qoff,
                       const RgXHdr *H, int lane, unsigned long long *counters, const int *gap, const long long *ctg)
 {
 	const long long l_pac = ix.l_pac;
@@ -1170,7 +1181,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 	int xc_lo = 0, sd_lo = 0, sd_hi = 0;
 #define C2R_STAGE_CHAINS(from) do { const int n_ = (nk - (from) < RG_XCBLK ? nk - (from) : RG_XCBLK) * (int)(sizeof(RgXChain) / 8); \
 		for (int i_ = lane; i_ < n_; i_ += 64) ((unsigned long long*)W.xc)[i_] = XCw[(size_t)(from) * (sizeof(RgXChain) / 8) + i_]; xc_lo = (from); } while (0)
-#define C2R_STAGE_SEEDS(from) do { const int m_ = n_sd - (from) < RG_XSEEDS ? n_sd - (from) : RG_XSEEDS; \
+#define C2R_STAGE_SEEDS(from) do { const int m_ = n_sd - (from) < WT::XSEEDS ? n_sd - (from) : WT::XSEEDS; \
 		for (int i_ = lane; i_ < m_ * 2; i_ += 64) ((unsigned long long*)W.sd)[i_] = XSw[(size_t)(from) * 2 + i_]; sd_lo = (from); sd_hi = (from) + m_; } while (0)
 	C2R_STAGE_CHAINS(0);
 	C2R_STAGE_SEEDS(0);
@@ -1180,7 +1191,8 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 		const RgXChain &XCc = W.xc[ci - xc_lo];
 		const long long ch_pos = uni64(XCc.pos);
 		const int rid = uni(XCc.rid), seed_off = uni(XCc.seed_off), n_main = uni((int)XCc.n_main), n_extra = uni((int)XCc.n_extra);
-		if (n_main > RG_XSEEDS || n_extra > RG_XSEEDS) return 2;
+		if (n_main == 0) continue;   // every seed of the chain failed the seed-SW filter (memchain.c:880)
+		if (n_main > WT::XSEEDS || n_extra > WT::XSEEDS) return 2;
 		if (seed_off + n_main > sd_hi) { WAVE_SYNC(); C2R_STAGE_SEEDS(seed_off); WAVE_SYNC(); }
 		// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp
 		long long rmax0 = l_pac << 1, rmax1 = 0;
@@ -1210,16 +1222,16 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 			if (l0 + nl > sd_hi) { WAVE_SYNC(); C2R_STAGE_SEEDS(l0); WAVE_SYNC(); }
 			const RgXSeed *Lsd = W.sd + (l0 - sd_lo);   // this list, in place in the window
 			for (int i = lane; i < nl; i += 64) { // keys score<<32|i are unique: rank by counting (ks_introsort_64, memchain.c:752)
-				const unsigned long long key = (unsigned long long)(unsigned)Lsd[i].len << 32 | (unsigned)i;
+				const unsigned long long key = (unsigned long long)(unsigned)XS_SCORE(Lsd[i]) << 32 | (unsigned)i;
 				int r = 0;
-				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)Lsd[k].len << 32 | (unsigned)k) < key;
+				for (int k = 0; k < nl; ++k) r += ((unsigned long long)(unsigned)XS_SCORE(Lsd[k]) << 32 | (unsigned)k) < key;
 				W.srt[r] = key;
 			}
 			WAVE_SYNC();
 			for (int k = nl - 1; k >= 0; --k) {
 				const int si = uni((int)(uint32_t)W.srt[k]);
 				const RgXSeed sd = Lsd[si];
-				if (uni((int)sd.bad)) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
+				if (uni(XS_BAD(sd))) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
 				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
@@ -1261,7 +1273,7 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
-					if (span > 0 && span <= RG_WIN) {
+					if (span > 0 && span <= WT::WINCAP) {
 						dev_fetch_window(W.win, ix.pac, l_pac, rmax0, span, lane);
 						win_ok = 1;
 						WAVE_SYNC();
@@ -1289,7 +1301,9 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 						// rows in registers, 64 entries per lane slot: as few slots as the query needs (a row's cost grows with them)
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
-						else res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else if (WT::QCAP <= 256 || J.qlen < 256) res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else if (J.qlen < 512) res = ext_dp_reg<8>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else res = ext_dp_reg<16>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
@@ -1328,23 +1342,112 @@ __device__ int rg_c2r(RgC2r &W, const DevIndex &ix, const DevScoring &sc, const 
 	return 0;
 }
 
+// ---- C3: mem_flt_chained_seeds (memchain.c:537-568) over the exported chains of the strand searches it applies to (reads long enough,
+// or a small -W): every seed of a chain's main list shorter than MEM_SHORT_LEN is scored by ksw_align2 (16-bit, score only: the
+// reference asks for the start too and never looks at it) over the seed +- MEM_SHORT_EXT on both sequences (mem_seed_sw,
+// memchain.c:501-535); seeds below the threshold leave the list, the others carry their score into mem_chain2region1's best-first
+// order.  One wavefront per strand search, the lists compacted in place ahead of k_c2r.
+#include "sw_pass.hpp"
+#define RG_SHORT_EXT 50
+#define RG_SHORT_LEN 200
+__global__ void __launch_bounds__(64, 4)
+k_seedsw(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X, unsigned int *cursor, unsigned long long *counters)
+{
+	const int lane = wave_lane();
+	const int n = (int)*X.xcount;
+	const long long l_pac = ix.l_pac;
+	unsigned int n_sw = 0;
+	for (;;) {
+		int i = 0;
+		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
+		i = uni(__shfl(i, 0));
+		if (i >= n) break;
+		const int t = uni(X.xlist[i]);
+		RgXHdr *H = (RgXHdr*)(X.base + uni64(X.xoff[t]));
+		const int flt = uni(H->flt);
+		if (flt == RG_NOFLT) continue;
+		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent);
+		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
+		const int8_t *mat = parent ? sc.ctmat : sc.gamat;
+		const int nk = uni(H->n_chains);
+		RgXChain *XC = (RgXChain*)(H + 1);
+		RgXSeed *XS = (RgXSeed*)(XC + nk);
+		for (int ci = 0; ci < nk; ++ci) {
+			const int seed_off = uni(XC[ci].seed_off), n_main = uni((int)XC[ci].n_main), n_extra = uni((int)XC[ci].n_extra);
+			int k = 0;
+			for (int j = 0; j < n_main; ++j) {
+				RgXSeed sd = XS[seed_off + j];
+				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
+				int score = -1;
+				if (s_len < RG_SHORT_LEN) {
+					int qb = s_qbeg, qe = s_qbeg + s_len;
+					long long rb = s_rbeg, re = s_rbeg + s_len;
+					const long long mid = (rb + re) >> 1;
+					qb -= RG_SHORT_EXT; qb = qb > 0 ? qb : 0;
+					qe += RG_SHORT_EXT; qe = qe < l_query ? qe : l_query;
+					rb -= RG_SHORT_EXT; rb = rb > 0 ? rb : 0;
+					re += RG_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+					if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+					if (!(qe - qb >= RG_SHORT_LEN || re - rb >= RG_SHORT_LEN)) {
+						// bns_fetch_seq (bntseq.c:415-437): the span is cut to the contig of its middle
+						const int is_rev = mid >= l_pac;
+						const int rid = rg_pos2rid(ix, (const long long*)ix.ctg_off, rg_depos(l_pac, mid));
+						long long far_beg = ix.ctg_off[rid], far_end = ix.ctg_off[rid + 1];
+						if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+						rb = rb > far_beg ? rb : far_beg; re = re < far_end ? re : far_end;
+						const int qlen = qe - qb, tlen = (int)(re - rb);
+						if (qlen > 0 && tlen > 0) {
+							int qv[4];
+#pragma unroll
+							for (int c = 0; c < 4; ++c) { const int jj = (c << 6) + lane; qv[c] = jj < qlen ? (int)reads[(size_t)qoff + qb + jj] : 5; }
+							const SwPass r = sw_pass<4>(ix, mat, 0, qlen, qv, tlen, rb, 1, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, 0, nullptr, lane);
+							score = uni(r.score);
+							++n_sw;
+						}
+					}
+				}
+				if (score < 0 || score >= flt) {
+					sd.sb = (score < 0 ? s_len * P.a : score) << 1 | XS_BAD(sd);
+					if (lane == 0) XS[seed_off + k] = sd;   // k <= j: behind every entry still to be read
+					++k;
+				}
+			}
+			if (k != n_main) {
+				const int shift = n_main - k;
+				for (int base = 0; base < n_extra; base += 64) { // the backup list moves up behind the shortened main list (targets never pass the sources of a later round)
+					const int e = base + lane;
+					RgXSeed v; v.rbeg = 0; v.qbeg = v.len = 0; v.sb = 0;
+					if (e < n_extra) v = XS[seed_off + n_main + e];
+					WAVE_SYNC();
+					if (e < n_extra) XS[seed_off + n_main + e - shift] = v;
+					WAVE_SYNC();
+				}
+				if (lane == 0) XC[ci].n_main = (unsigned short)k;
+			}
+		}
+	}
+	if (P.prof && lane == 0 && n_sw) atomicAdd(&counters[42], (unsigned long long)n_sw);
+}
+
 #ifndef C2R_WPB
 #define C2R_WPB 1    // waves per workgroup (a workgroup's slots come back when its last wave ends)
 #endif
-__global__ void __launch_bounds__(64 * C2R_WPB, 4)
+template <typename WT, int OCC>
+__global__ void __launch_bounds__(64 * C2R_WPB, OCC)
 k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X,
       bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
       unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
-	__shared__ RgC2r lds[C2R_WPB];
-	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ WT lds[C2R_WPB];
+	__shared__ int gap_tab[WT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = WT::QCAP;
+	for (int q = threadIdx.x; q <= WT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
-	RgC2r &W = lds[threadIdx.x >> 6];
+	WT &W = lds[threadIdx.x >> 6];
 	const int n = (int)*X.xcount;
 	// a wave takes `quota` strand searches and leaves (the launch covers the worst case): workgroups with a bounded life let the
 	// back half's short high-priority batches (k_sw, k_global) of an older chunk get compute units while this one runs
@@ -1369,7 +1472,7 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 			}
 			reg_off[t] = (long long)base;
 			reg_n[t] = status ? -status : nr;
-			if (status == 2 || status == 6) next_list[atomicAdd(next_count, 1u)] = t;
+			if (next_list && (status == 2 || status == 6)) next_list[atomicAdd(next_count, 1u)] = t;
 		}
 		WAVE_SYNC();
 	}
@@ -1490,7 +1593,7 @@ __device__ int rgl_step(RgLState &S, bsx_region_t *regs, unsigned char *rank, co
 			}
 			S.k = nl - 1;
 		}
-		RgXSeed sd_cur; sd_cur.rbeg = 0; sd_cur.qbeg = sd_cur.len = 0; sd_cur.bad = 0;
+		RgXSeed sd_cur; sd_cur.rbeg = 0; sd_cur.qbeg = sd_cur.len = 0; sd_cur.sb = 0;
 		if (to_right || to_finish) sd_cur = list[rank[S.k] & 127];
 		bool finish = to_finish;
 		if (to_right) { // after the left side is settled: skip or post the right extension (memchain.c:689-693)
@@ -1518,7 +1621,7 @@ __device__ int rgl_step(RgLState &S, bsx_region_t *regs, unsigned char *rank, co
 		while (S.k >= 0) {
 			const int si = rank[S.k] & 127;
 			const RgXSeed sd = list[si];
-			if (sd.bad) { --S.k; continue; }   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
+			if (XS_BAD(sd)) { --S.k; continue; }   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
 			// is the seed inside a region this strand search already produced? (memchain.c:761-790)
 			int u;
 			for (u = 0; u < S.n_regs; ++u) {
@@ -1570,6 +1673,7 @@ k_c2r_ctrl(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, Rg
 {
 	__shared__ int gap_tab[RG_QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
+	P.gap_cap = RG_QCAP;
 	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
@@ -1639,7 +1743,7 @@ size_t c2r_lanes_state_bytes(void) { return sizeof(RgLState); }
 #ifndef RG_WPB
 #define RG_WPB 1     // waves per workgroup of the LDS tiers, as C2R_WPB
 #endif
-template <int OCC>
+template <int OCC, typename DPT>
 __global__ void __launch_bounds__(64 * RG_WPB, OCC)
 k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks,
           const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -1648,16 +1752,17 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
           const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, RgXPool X)
 {
 	__shared__ RgSmall lds[RG_WPB];
-	__shared__ RgDpLite dp[RG_WPB];
-	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ DPT dp[RG_WPB];
+	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = DPT::QCAP;
+	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
-	RgDpLite &D = dp[threadIdx.x >> 6];
+	DPT &D = dp[threadIdx.x >> 6];
 	// each wave takes `quota` tasks and leaves (bounded workgroup life, see k_seed); the launch covers all tasks
 	for (int taken = 0; taken < quota; ++taken) {
 		int t = 0;
@@ -1672,7 +1777,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<RgSmall, true, RgDpLite>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		int status = rg_task<RgSmall, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;   // exported: k_c2r makes and publishes its regions
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
@@ -1681,24 +1786,25 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 
 // second and third tier: the same code over per-wave tables in HBM, for the strand searches of repeat-rich reads.
 // `list` names the tasks (null: 0..*count-1); what this tier declines for table size goes on next_list.
-template <typename Store>
+template <typename Store, bool XSPLIT, typename DPT>
 __global__ void __launch_bounds__(256, 2)
 k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                const int *list, const unsigned int *count, unsigned int *cursor, Store *slabs, int *next_list, unsigned int *next_count,
-               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X)
 {
-	__shared__ RgDp dp[4];
-	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ DPT dp[4];
+	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = DPT::QCAP;
+	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
 	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
-	RgDp &D = dp[threadIdx.x >> 6];
+	DPT &D = dp[threadIdx.x >> 6];
 	const int n = (int)*count;
 	for (;;) {
 		int i = 0;
@@ -1709,7 +1815,8 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab);
+		int status = rg_task<Store, XSPLIT, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		if (status == 11) continue;   // exported (XSPLIT: chunks with long reads, whose chains go through k_seedsw and k_c2r)
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
@@ -1719,6 +1826,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 // workgroups per CU).  On a larger genome a repeat family has more copies, and a quarter of the strand searches outgrow the
 // first tier's 96 seeds; in HBM slabs every table access is a memory round trip.  Same list protocol as k_regions_slab.
 #define MID_WPB 2    // 14 KB of tables per wave: five workgroups of two waves fit a CU, only nine of one
+template <typename DPT>
 __global__ void __launch_bounds__(64 * MID_WPB, 2)
 k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -1727,16 +1835,17 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X, int quota)
 {
 	__shared__ RgMid lds[MID_WPB];
-	__shared__ RgDpLite dp[MID_WPB];
-	__shared__ int gap_tab[RG_QCAP + 1];
+	__shared__ DPT dp[MID_WPB];
+	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = DPT::QCAP;
+	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
 	RgMid &S = lds[threadIdx.x >> 6];
-	RgDpLite &D = dp[threadIdx.x >> 6];
+	DPT &D = dp[threadIdx.x >> 6];
 	const int n = (int)*count;
 	for (int taken = 0; taken < quota; ++taken) {   // bounded workgroup life, as in k_c2r
 		int i = 0;
@@ -1747,7 +1856,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<RgMid, true, RgDpLite>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		int status = rg_task<RgMid, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
@@ -1843,15 +1952,18 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA)
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
-	if (occ >= 4)
-		hipLaunchKernelGGL(k_regions<4>, dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+	if (long_reads)
+		hipLaunchKernelGGL((k_regions<3, RgDpLiteL>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
+	else if (occ >= 4)
+		hipLaunchKernelGGL((k_regions<4, RgDpLite>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 	else
-		hipLaunchKernelGGL(k_regions<3>, dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		hipLaunchKernelGGL((k_regions<3, RgDpLite>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 }
 
@@ -1859,29 +1971,52 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota)
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	hipLaunchKernelGGL(k_regions_mid, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, /* `grid` counts pairs of waves */ ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	if (long_reads)
+		hipLaunchKernelGGL(k_regions_mid<RgDpLiteL>, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
+	else
+	hipLaunchKernelGGL(k_regions_mid<RgDpLite>, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, /* `grid` counts pairs of waves */ ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 }
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &XA, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	hipLaunchKernelGGL(k_c2r, dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	if (long_reads)
+		hipLaunchKernelGGL((k_c2r<RgC2rL, 1>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	else
+	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 }
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
-                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos)
+                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg *XA)
 {
-	if (tier == 2)
-		hipLaunchKernelGGL(k_regions_slab<RgBig>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos);
+	RgXPool X; X.base = nullptr; X.cap = 0; X.cursor = nullptr; X.xoff = nullptr; X.xlist = nullptr; X.xcount = nullptr;
+	if (XA) { X.base = XA->base; X.cap = XA->cap; X.cursor = XA->cursor; X.xoff = XA->xoff; X.xlist = XA->xlist; X.xcount = XA->xcount; }
+	// XA given: the tier stops after the chain filter and exports (chunks with long reads or an active seed-SW filter)
+	if (tier == 2 && XA)
+		hipLaunchKernelGGL((k_regions_slab<RgBig, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos, X);
+	else if (tier == 2)
+		hipLaunchKernelGGL((k_regions_slab<RgBig, false, RgDp>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos, X);
+	else if (XA)
+		hipLaunchKernelGGL((k_regions_slab<RgHuge, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters, pos_off, pos, X);
 	else
-		hipLaunchKernelGGL(k_regions_slab<RgHuge>, dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters, pos_off, pos);
+		hipLaunchKernelGGL((k_regions_slab<RgHuge, false, RgDp>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters, pos_off, pos, X);
 }
+void launch_seedsw(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                   const RgXPoolArg &XA, unsigned int *cursor, unsigned long long *counters)
+{
+	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	hipLaunchKernelGGL(k_seedsw, dim3(grid), dim3(64), 0, st, ix, sc, P, reads, tasks, X, cursor, counters);
+}
+int regions_long_max_query(void) { return RG_QCAP_LONG; }

@@ -40,13 +40,13 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
-                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &X);   // cls[t] != 0: not for this tier (launch_occ)
+                    const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &X, int long_reads = 0);   // cls[t] != 0: not for this tier (launch_occ)
 // the tier in between: LDS tables four times the first tier's; consumes the first tier's list, appends to the second tier's
 void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                         const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
-                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X, int quota);   // quota: strand searches per wave
+                        unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X, int quota, int long_reads = 0);   // quota: strand searches per wave; long_reads: the instantiation for reads up to regions_long_max_query()
 // the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
 // rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
 // (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
@@ -60,12 +60,16 @@ void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevSco
 // chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota);
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads = 0);   // next_list may be null (long reads: what outgrows the tables is left to the caller)
+// C3 between the tiers and launch_c2r: the seed-SW filter of the exported strand searches it applies to (mem_flt_chained_seeds, memchain.c:537-568)
+void launch_seedsw(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                   const RgXPoolArg &X, unsigned int *cursor, unsigned long long *counters);
+int regions_long_max_query(void);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
-                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos);
+                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg *X = nullptr);   // X: export the chains (as the LDS tiers do) instead of making the regions
 // K3 ahead of the region kernels: SA ranks of all occurrences of all strand searches listed into desc (pos_off[t] = where task
 // t's start, -1 = none listed), then turned into reference positions in place.  pos_off/pos feed launch_regions*.
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,

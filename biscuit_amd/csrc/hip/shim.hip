@@ -29,7 +29,7 @@ struct Lane {
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
-	DevBuf jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
+	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -516,6 +516,27 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
+	R.gap_cap = 0;
+	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
+	// here because the rule goes through log() and the float / double conversions of the reference's expression.
+	bool any_flt = false;
+	{
+		std::vector<int32_t> ft((size_t)max_len + 1, INT32_MIN);
+		for (int l = 1; l <= max_len; ++l) {
+			const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)l);
+			if (min_l > 0.05f * l) continue;
+			ft[l] = (int32_t)(opt->a * min_l + .499);
+			any_flt = true;
+		}
+		if ((rc = L.fltab.reserve(ft.size() * 4)) != BSX_OK) return rc;
+		H2D(L.st, L.fltab.p, ft.data(), ft.size() * 4);
+		R.flt_tab = (const int32_t*)L.fltab.p; R.flt_len = max_len;
+	}
+	// Chunks with reads above the short kernels' 256 bases (up to regions_long_max_query(); longer ones are chained by the caller) or with
+	// the seed-SW filter active take the instantiations with longer tables, every tier exports its chains, and the filter (k_seedsw)
+	// runs ahead of chains -> regions.
+	const int long_reads = max_len > 256 ? 1 : 0;
+	const bool export_all = long_reads || any_flt;
 
 	// $BSX_SEED_MEM_CAP (tests): a short first-pass list, so that ordinary reads take the seeded-again path too
 	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
@@ -594,56 +615,75 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		if (d->chain_regions && d->chain_regions != L.ev_regions_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_regions, 0));
 	}
-	const int rgrid = (int)((n + 4LL * reg_quota - 1) / (4LL * reg_quota));
-	launch_regions(L.st, rgrid, d->ix, L.sc, R, d_reads, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n,
-	               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, c32 + 0, retry_a, c32 + 1, reg_quota, ctr, d_posoff, d_pos, d_cls, XA);
-	HIPCHK(hipEventRecord(L.ev3, L.st));
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
 	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
 	// strand searches a wave of the larger LDS tier / of the chains -> regions launch takes before it leaves (bounded workgroup life)
 	static const int mid_quota = getenv("BSX_MID_QUOTA") ? std::max(1, atoi(getenv("BSX_MID_QUOTA"))) : 8;
 	static const int c2r_quota = getenv("BSX_C2R_QUOTA") ? std::max(1, atoi(getenv("BSX_C2R_QUOTA"))) : 16;
-	if (use_mid)
-		launch_regions_mid(L.st, (int)((n + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-		                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_a, c32 + 1, c32 + 11, retry_m, c32 + 10, ctr, d_posoff, d_pos, XA, mid_quota);
-	// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
-	// Two forms, same regions (the tests run both).  Default: a wavefront per strand search with the extensions inline (k_c2r), which is
-	// also what reads longer than c2r_lanes_max_query() take.  $BSX_C2R_LANES=1: lock-step rounds -- a lane per strand search runs the
-	// reference's seed loop until it needs an extension (k_c2r_ctrl: 24 ms per chunk in all), then the extensions of the round run four
-	// to a wavefront (k_ext_q, k_extq.hip: 255 ms per chunk as measured in round 3 -- 16 M jobs, 480 M rows, two waves per SIMD at 174
-	// VGPRs -- against k_c2r's 150 ms).
 	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 0;
-	if (use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
-		const size_t sb = c2r_lanes_state_bytes();
-		if ((rc = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc;
-		if ((rc = L.lanes_regs.reserve((size_t)n * 24 * sizeof(bsx_region_t))) != BSX_OK) return rc;
-		// rank | act[2] | jobs[2] | res[2] | n_act
-		const size_t o_rank = 0, o_act = o_rank + (size_t)n * 128, o_jobs = o_act + (size_t)n * 8, o_res = o_jobs + (size_t)n * 2 * sizeof(bsx_ext_job_t),
-		             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), o_wide = o_nact + 4096, tot_misc = o_wide + (size_t)n * 8;
-		if ((rc = L.lanes_misc.reserve(tot_misc)) != BSX_OK) return rc;
-		char *mb = (char*)L.lanes_misc.p;
-		RgLanesArg WA;
-		WA.state = L.lanes_state.p; WA.regs = L.lanes_regs.p; WA.rank = (unsigned char*)(mb + o_rank);
-		WA.act[0] = (int*)(mb + o_act); WA.act[1] = WA.act[0] + n;
-		WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
-		WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
-		WA.n_act = (unsigned int*)(mb + o_nact);
-		WA.wide = (int*)(mb + o_wide);
-		HIPCHK(hipMemsetAsync(WA.n_act, 0, 4096, L.st));   // u32: [0,128) jobs per round, [192,320) k_ext_n's job cursors, [384,512) tracing sums, [512,640) wide jobs per round, [640,768) k_ext_q's cursors
-		launch_c2r_lanes(L.st, d->n_cu, d->ix, L.sc, R, d_reads, d_tasks, XA, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
-		                 use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1);
-	} else
-	launch_c2r(L.st, (int)((n + 4LL * c2r_quota - 1) / (4LL * c2r_quota)), d->ix, L.sc, R, d_reads, d_tasks, XA, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n,
-	           (unsigned int*)(ctr + 14) + 1, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, ctr, c2r_quota);
-	if (chain >= 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
-		std::lock_guard<std::mutex> g(d->chain_mu);
-		HIPCHK(hipEventRecord(L.ev_regions_done, L.st));
-		d->chain_regions = L.ev_regions_done;
-	}
-	launch_regions_slab(L.st, 2, big_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, use_mid ? retry_m : retry_a, use_mid ? c32 + 10 : c32 + 1, c32 + 2, L.slabs.p, retry_b, c32 + 3, ctr, d_posoff, d_pos);
-	launch_regions_slab(L.st, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
-	                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_b, c32 + 3, c32 + 4, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
+	// The tier sequence over a task list (the chunk's, and once more the re-seeded strand searches' on the side stream).  k32: u32 cursors and
+	// counts ([0] tier-1 cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor [5] k_seedsw's cursor [10] what the
+	// larger LDS tier hands on [11] its cursor); xc32: exported count | k_c2r's cursor.
+	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
+	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
+	                     const unsigned char *clsx, bool main_seq) -> int {
+		int rc2;
+		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
+		launch_regions(st, rgrid, d->ix, L.sc, R, d_reads, T, (int)nT, (const DevIntv*)L.out.p, offs, cnts,
+		               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, k32 + 0, ra, k32 + 1, reg_quota, ctr, posoffs, d_pos, clsx, XP, long_reads);
+		if (main_seq) HIPCHK(hipEventRecord(L.ev3, st));
+		if (use_mid)
+			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, ra, k32 + 1, k32 + 11, rm, k32 + 10, ctr, posoffs, d_pos, XP, mid_quota, long_reads);
+		int *to2 = use_mid ? rm : ra; unsigned int *n2c = use_mid ? k32 + 10 : k32 + 1;
+		const int c2r_grid = (int)((nT + 4LL * c2r_quota - 1) / (4LL * c2r_quota));
+		if (export_all) {
+			// every tier exports; then the seed-SW filter where it applies, then chains -> regions (what outgrows its tables is left to the caller)
+			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XP);
+			launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos, &XP);
+			if (any_flt) launch_seedsw(st, (int)std::min<int64_t>((nT + 3) / 4, (int64_t)d->n_cu * 32), d->ix, L.sc, R, d_reads, T, XP, k32 + 5, ctr);
+			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, nullptr, nullptr, ctr, c2r_quota, long_reads);
+			return BSX_OK;
+		}
+		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
+		// Two forms, same regions (the tests run both).  Default: a wavefront per strand search with the extensions inline (k_c2r).
+		// $BSX_C2R_LANES=1: lock-step rounds -- a lane per strand search runs the reference's seed loop until it needs an extension
+		// (k_c2r_ctrl: 24 ms per chunk in all), then the extensions of the round run a lane per narrow job (k_ext_n) and four to a
+		// wavefront (k_ext_q, k_extq.hip): 255 ms per chunk as measured in round 3 against k_c2r's 150 ms.
+		if (main_seq && use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
+			const size_t sb = c2r_lanes_state_bytes();
+			if ((rc2 = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc2;
+			if ((rc2 = L.lanes_regs.reserve((size_t)n * 24 * sizeof(bsx_region_t))) != BSX_OK) return rc2;
+			// rank | act[2] | jobs[2] | res[2] | n_act
+			const size_t o_rank = 0, o_act = o_rank + (size_t)n * 128, o_jobs = o_act + (size_t)n * 8, o_res = o_jobs + (size_t)n * 2 * sizeof(bsx_ext_job_t),
+			             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), o_wide = o_nact + 4096, tot_misc = o_wide + (size_t)n * 8;
+			if ((rc2 = L.lanes_misc.reserve(tot_misc)) != BSX_OK) return rc2;
+			char *mb = (char*)L.lanes_misc.p;
+			RgLanesArg WA;
+			WA.state = L.lanes_state.p; WA.regs = L.lanes_regs.p; WA.rank = (unsigned char*)(mb + o_rank);
+			WA.act[0] = (int*)(mb + o_act); WA.act[1] = WA.act[0] + n;
+			WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
+			WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
+			WA.n_act = (unsigned int*)(mb + o_nact);
+			WA.wide = (int*)(mb + o_wide);
+			HIPCHK(hipMemsetAsync(WA.n_act, 0, 4096, st));   // u32: [0,128) jobs per round, [192,320) k_ext_n's job cursors, [384,512) tracing sums, [512,640) wide jobs per round, [640,768) k_ext_q's cursors
+			launch_c2r_lanes(st, d->n_cu, d->ix, L.sc, R, d_reads, T, XP, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c);
+		} else
+			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
+		if (main_seq && chain >= 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
+			std::lock_guard<std::mutex> g(d->chain_mu);
+			HIPCHK(hipEventRecord(L.ev_regions_done, st));
+			d->chain_regions = L.ev_regions_done;
+		}
+		launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
+		launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos);
+		return BSX_OK;
+	};
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true)) != BSX_OK) return rc;
 
 	if (chain == 2) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -700,16 +740,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			launch_regions(L.st2, (int)((n2 + 4LL * reg_quota - 1) / (4LL * reg_quota)), d->ix, L.sc, R, d_reads, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2,
-			               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, q32 + 0, ra2, q32 + 1, reg_quota, ctr, posoff2, d_pos, cls2, XB);
-			launch_regions_mid(L.st2, (int)((n2 + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, ra2, q32 + 1, q32 + 11, rm2, q32 + 10, ctr, posoff2, d_pos, XB, mid_quota);
-			launch_c2r(L.st2, (int)((n2 + 4LL * c2r_quota - 1) / (4LL * c2r_quota)), d->ix, L.sc, R, d_reads, t2, XB, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2,
-			           (unsigned int*)(ctr + 102) + 1, rm2, q32 + 10, ctr, c2r_quota);
-			launch_regions_slab(L.st2, 2, big_grid, d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, rm2, q32 + 10, q32 + 2, L.slabs.p, rb2, q32 + 3, ctr, posoff2, d_pos);
-			launch_regions_slab(L.st2, 3, huge_grid, d->ix, L.sc, R, d_reads, t2, (const DevIntv*)L.out.p, off2, cnt2,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roff2, rn2, rb2, q32 + 3, q32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoff2, d_pos);
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false)) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));

@@ -36,6 +36,12 @@ def data(tmp_path_factory):
         simdata.write_fastq(d + "/%s1.fq" % tag, [(n, a) for n, a, b in pairs])
         simdata.write_fastq(d + "/%s2.fq" % tag, [(n, b) for n, a, b in pairs])
     simdata.write_fastq(d + "/long.fq", simdata.make_single(contigs, 300, 1000, 5))
+    # reads between the short kernels' 256 bases and a kilobase, mixed lengths in one chunk; and reads past the long kernels' tables
+    mixed = []
+    for k, ln in enumerate((300, 420, 600, 760, 900, 1024)):
+        mixed += [("m%d_%s" % (ln, n), q) for n, q in simdata.make_single(contigs, 120, ln, 40 + k)]
+    simdata.write_fastq(d + "/mixed.fq", mixed)
+    simdata.write_fastq(d + "/xlong.fq", simdata.make_single(contigs, 60, 1500, 9) + simdata.make_single(contigs, 200, 150, 10))
     return d
 
 
@@ -51,6 +57,10 @@ CASES = [
     ("se150_clip", ["-@", "4", "-J", "AGATCGGAAGAGC", "-z", "10", "-5", "2", "-3", "1", "g", "b1.fq"]),
     ("se150_scoring", ["-@", "4", "-A", "2", "-B", "3", "-O", "5,7", "-E", "2,1", "-L", "4,6", "-T", "40", "-k", "17", "-w", "60", "g", "b1.fq"]),
     ("long_1kb", ["-@", "4", "g", "long.fq"]),
+    ("long_mixed_lengths", ["-@", "4", "g", "mixed.fq"]),
+    ("long_1kb_scoring", ["-@", "4", "-A", "2", "-B", "5", "-O", "7,8", "-k", "17", "-w", "80", "g", "long.fq"]),
+    ("short_with_seed_sw_filter", ["-@", "4", "-W", "5", "g", "b1.fq", "b2.fq"]),   # a small -W turns mem_flt_chained_seeds on for 150 bp reads
+    ("longer_than_device_tables", ["-@", "4", "g", "xlong.fq"]),
     # options the device chaining/extension pass reads: occurrence cap, chain filter knobs, strand restriction, band, clip penalties
     ("pe150_chain_knobs", ["-@", "4", "-c", "12", "-D", "0.3", "-W", "25", "-m", "30", "-G", "4000", "g", "b1.fq", "b2.fq"]),
     ("se150_bsstrand_band", ["-@", "4", "-f", "1", "-w", "12", "-L", "0,9", "-r", "1.2", "-y", "30", "g", "b1.fq"]),
@@ -87,7 +97,7 @@ def _on_device(stderr):
     return on, off
 
 
-@pytest.mark.parametrize("name,args", [CASES[1], CASES[3], CASES[9], CASES[11], CASES[12]], ids=lambda c: c if isinstance(c, str) else "")
+@pytest.mark.parametrize("name,args", [CASES[1], CASES[3], CASES[9], CASES[10], CASES[11], CASES[12], CASES[13], CASES[15], CASES[16]], ids=lambda c: c if isinstance(c, str) else "")
 def test_device_regions_equal_host_chaining(data, name, args):
     """k_regions (SA lookup + chaining + chain filter + chain-to-region on the device) against the same
     strand searches chained on the host through the batch kernels: identical SAM, and the device pass
