@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads for the host stages; 0 = cores / ranks, capped at 64")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--single-end", action="store_true", help="every read on its own (BASELINE configs[4] shape with --read-len 1000: long single-end reads)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one chunk at a time through bsx_process_seqs (no overlap of consecutive chunks)")
@@ -89,7 +90,8 @@ def main():
     opt = default_opt()
     opt.n_threads = threads
     # defaults: -b 0 (non-directional search: 4 strand searches per pair)
-    opt.flag |= 0x10 | 0x2            # MEM_F_NO_MULTI (align.c:335) | MEM_F_PE
+    opt.flag |= 0x10 | (0 if args.single_end else 0x2)            # MEM_F_NO_MULTI (align.c:335) | MEM_F_PE
+    frag = (args.read_len, args.read_len + 400) if args.single_end else (200, 500)
     pairs_per_step = (opt.chunk_size * threads) // (2 * args.read_len)   # the reference's chunk: 10 Mbp x threads
     n_reads = pairs_per_step * 2
 
@@ -101,7 +103,7 @@ def main():
 
     def gen(seed, n_pairs):
         p = C.c_void_p()
-        B.check(L.bsx_sim_pairs(idx.h, n_pairs, args.read_len, seed, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
+        B.check(L.bsx_sim_pairs(idx.h, n_pairs, args.read_len, seed, frag[0], frag[1], 0.005, 0.0, C.byref(p)), "sim_pairs")
         return p
 
     C.c_int.in_dll(L, "bsx_verbose").value = 1   # silence per-chunk messages inside the timed region
@@ -345,9 +347,10 @@ def main():
 
     repeats = ("with hg38-like repeat content (SINE/LINE/LTR-like families of up to a million copies, satellite arrays: ~43 % repeats)"
                if args.genome_profile == "hg38-like" else "with repeat families (5 % planted repeats of 1-5 copies)")
-    workload = ("BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs a SYNTHETIC %.0f Mbp genome %s "
+    workload = (("BASELINE configs[4] shape: 1x%d bp synthetic directional bisulfite single-end reads vs" if args.single_end else "BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs")
+                + " a SYNTHETIC %.0f Mbp genome %s "
                 "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
-                "built on the GPU at start-up), biscuit align defaults (-b 0)" % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9))
+                "built on the GPU at start-up), biscuit align defaults (-b 0)") % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9)
     if rank == 0:
         names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_host_path_batches"]
         out = {
@@ -441,7 +444,7 @@ def cpu_baseline(L, B, idx, opt, args, ncores):
 
     def run(port, pairs):
         p = C.c_void_p()
-        B.check(L.bsx_sim_pairs(idx.h, pairs, args.read_len, 999, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
+        B.check(L.bsx_sim_pairs(idx.h, pairs, args.read_len, 999, args.read_len if args.single_end else 200, args.read_len + 400 if args.single_end else 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
         be = port.backend()
         t0 = time.time()
         B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(o), idx.h, 0, pairs * 2, p, None), "cpu baseline")
@@ -468,4 +471,12 @@ def cpu_baseline(L, B, idx, opt, args, ncores):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        # a failure in the middle of the stream leaves worker threads behind (the pipeline's front halves, the SAM consumer):
+        # report and leave at once instead of waiting for them
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

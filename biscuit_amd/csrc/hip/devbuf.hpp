@@ -1,5 +1,6 @@
 // devbuf.hpp -- growable device / pinned host buffers shared by shim.hip and the index builder
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 extern "C" {
@@ -34,7 +35,11 @@ struct DevBuf {
 		if (n <= cap) return BSX_OK;
 		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.dev.push_back(std::make_pair(devbuf_current(), p)); p = nullptr; }
 		size_t want = n + (n >> 1) + 4096;
-		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed\n", want); return BSX_E_NOMEM; }
+		if (hipMalloc(&p, want) != hipSuccess) {
+			size_t fr = 0, tot = 0; (void)hipGetLastError(); (void)hipMemGetInfo(&fr, &tot);
+			p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed (%zu of %zu bytes free)\n", want, fr, tot); return BSX_E_NOMEM;
+		}
+		{ static const bool tr = getenv("BSX_TRACE_ALLOC") != nullptr; if (tr && want >= ((size_t)1 << 30)) fprintf(stderr, "[bsx-hip] DevBuf %p: %.1f GB (was %.1f)\n", (void*)this, want / 1073741824.0, cap / 1073741824.0); }
 		cap = want;
 		return BSX_OK;
 	}

@@ -70,6 +70,9 @@ struct RgStore {
 typedef RgStore<64, 128, 128, 0, 0, unsigned short, short, 32> RgSmall;
 typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;             // still LDS: 24 KB per wave, two waves per workgroup: the
                                                                                 // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
+// chunks with long reads (a kilobase against an hg38-sized index: ~360 intervals, ~830 seeds, most of them alone in their piece): still
+// LDS, 62 KB per wave, two workgroups of one wave per CU -- every table access of the HBM tiers below is a memory round trip
+typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongS;
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
@@ -563,7 +566,8 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	// Without the B-tree (LDS tiers): the chain starts live sorted across the wave's registers, entry e in lane e & 63 of register set
 	// e >> 6.  kb_intervalp's `lower` (the largest start <= rbeg) is a compare, a ballot and a population count per register set; a
 	// new chain shifts the entries above it up one lane (DPP).  Unique starts make the sorted order the tree's in-order traversal.
-	constexpr int NR = Store::NODES ? 1 : (Store::CCAP + 63) / 64;
+	constexpr int TCAP = Store::CCAP < 512 ? Store::CCAP : 512;   // chain starts of one piece (the whole strand search in the HBM tiers' tree)
+	constexpr int NR = Store::NODES ? 1 : (TCAP + 63) / 64;
 	unsigned int st_lo[NR], st_hi[NR]; int st_id[NR];
 #pragma unroll
 	for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
@@ -580,6 +584,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	int n_iso = 0, n_live = tot, n_pieces = 0;
 	if (!Store::NODES) {
 		constexpr int NS = Store::SCAP / 64;
+		constexpr int KB = Store::SCAP <= 512 ? 9 : 12;   // bits of the arrival index below the position in the sort keys
 		const long long dgap = (long long)l_query + 1 + (long long)(P.w < P.max_chain_gap ? P.w : P.max_chain_gap);
 		unsigned long long key[NS]; int rk[NS];
 		int n_dead = 0;
@@ -592,14 +597,14 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				const long long rb = S.s_rbeg[o];
 				dead = S.s_rid[o] < 0 || ((P.bsstrand & 1) && RG_BSS(parent, l_pac, rb) != P.bsstrand >> 1);
 				if (dead) S.s_rbeg[o] = (1ll << 40) + o;   // nothing reads the position of such a seed again
-				key[c] = (unsigned long long)(dead ? (1ll << 40) + o : rb) << 9 | (unsigned)o;
+				key[c] = (unsigned long long)(dead ? (1ll << 40) + o : rb) << KB | (unsigned)o;
 			}
 			n_dead += __popcll(__ballot(dead));
 		}
 		n_live = tot - n_dead;
 		WAVE_SYNC();
 		for (int k = 0; k < tot; ++k) { // rank by counting: the keys (position, arrival index) are unique
-			const unsigned long long kk = (unsigned long long)uni64(S.s_rbeg[k]) << 9 | (unsigned)k;
+			const unsigned long long kk = (unsigned long long)uni64(S.s_rbeg[k]) << KB | (unsigned)k;
 #pragma unroll
 			for (int c = 0; c < NS; ++c) rk[c] += kk < key[c];
 		}
@@ -729,7 +734,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			}
 		}
 		if (!merged) {
-			if (nc == Store::CCAP) return 3;
+			if (nc == (Store::NODES ? Store::CCAP : TCAP)) return 3;
 			if (!Store::NODES && tied) return 4;   // duplicate key: the B-tree shape matters, the HBM tiers keep one
 			const int new_id = Store::PCAP ? o : nc;   // a chain of one seed has no record in the LDS tiers
 			if (lane == 0) {
@@ -1826,16 +1831,16 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 // workgroups per CU).  On a larger genome a repeat family has more copies, and a quarter of the strand searches outgrow the
 // first tier's 96 seeds; in HBM slabs every table access is a memory round trip.  Same list protocol as k_regions_slab.
 #define MID_WPB 2    // 14 KB of tables per wave: five workgroups of two waves fit a CU, only nine of one
-template <typename DPT>
-__global__ void __launch_bounds__(64 * MID_WPB, 2)
+template <typename Store, typename DPT, int WPB, int OCC>
+__global__ void __launch_bounds__(64 * WPB, OCC)
 k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
               const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
               bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
               const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X, int quota)
 {
-	__shared__ RgMid lds[MID_WPB];
-	__shared__ DPT dp[MID_WPB];
+	__shared__ Store lds[WPB];
+	__shared__ DPT dp[WPB];
 	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
 	P.gap_cap = DPT::QCAP;
@@ -1844,7 +1849,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
 	const int lane = wave_lane();
-	RgMid &S = lds[threadIdx.x >> 6];
+	Store &S = lds[threadIdx.x >> 6];
 	DPT &D = dp[threadIdx.x >> 6];
 	const int n = (int)*count;
 	for (int taken = 0; taken < quota; ++taken) {   // bounded workgroup life, as in k_c2r
@@ -1856,7 +1861,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<RgMid, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		int status = rg_task<Store, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
@@ -1974,11 +1979,11 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	if (long_reads)
-		hipLaunchKernelGGL(k_regions_mid<RgDpLiteL>, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	if (long_reads)   // tables for a kilobase read, one wave per workgroup
+		hipLaunchKernelGGL((k_regions_mid<RgLongS, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 	else
-	hipLaunchKernelGGL(k_regions_mid<RgDpLite>, dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, /* `grid` counts pairs of waves */ ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	hipLaunchKernelGGL((k_regions_mid<RgMid, RgDpLite, MID_WPB, 2>), dim3(grid * (2 / MID_WPB)), dim3(64 * MID_WPB), 0, st, /* `grid` counts pairs of waves */ ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 	                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 }
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,

@@ -413,7 +413,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 	std::vector<int64_t> todo;           // tasks whose interval list did not fit: redone with more room
 	std::vector<bsx_seed_task_t> sub;
 	int mem_cap = std::max(64, max_len);
-	unsigned long long dense_cap = (unsigned long long)n * 24 + 4096;
+	unsigned long long dense_cap = (unsigned long long)n * 24 * (unsigned long long)((max_len + 149) / 150 > 1 ? (max_len + 149) / 150 : 1) + 4096;   // (in proportion to the read length)
 	std::vector<std::vector<bsx_intv_t>> redo_results;
 	std::vector<int64_t> redo_index;
 	const bsx_intv_t *h_dense = nullptr;
@@ -430,9 +430,11 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		}
 		int list_cap = max_len + 2;
 		int waves = (int)std::min<int64_t>((cn + 63) / 64, (int64_t)d->n_cu * 16);
+		const size_t per_lane = (size_t)mem_cap * 32 + (size_t)list_cap * 16;   // mem_cap SMEMs of 32 bytes, one list of list_cap 16-byte entries
+		waves = (int)std::max<size_t>(4, std::min<size_t>((size_t)waves, ((size_t)8 << 30) / (64 * per_lane)));   // (long reads seeded again with long lists: fewer waves, not tens of GB)
 		int grid = (waves + 3) / 4;
 		size_t lanes = (size_t)grid * 256;
-		size_t scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // per lane: mem_cap SMEMs of 32 bytes, one list of list_cap 16-byte entries
+		size_t scratch_bytes = lanes * per_lane;
 		if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 		if ((rc = L.jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 		if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
@@ -542,11 +544,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
-	const unsigned long long dense_cap = (unsigned long long)n * 96 + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
+	const unsigned long long lf = (unsigned long long)std::max(1, (max_len + 149) / 150);   // pools are sized per 150 bases of read
+	const unsigned long long dense_cap = (unsigned long long)n * 96 * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 1;   // one strand search per lane: the lanes of a wave then go through the seeding passes together (measured at hg38 scale: 335 ms with two, 292 with one, 359 with persistent lanes)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
-	static const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;
+	// (4096 for reads of 150 bases, which need ~1.2 k; in proportion for longer ones)
+	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : std::max(4096, 28 * max_len);
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
 	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
@@ -566,11 +570,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
 	// copies there), a few dozen against small ones.  $BSX_POS_CAP (tests): a cap small enough for strand searches to find no room.
-	const unsigned long long pos_cap = getenv("BSX_POS_CAP") ? strtoull(getenv("BSX_POS_CAP"), 0, 10) : (unsigned long long)n * 384 + (1u << 20);
+	const unsigned long long pos_cap = getenv("BSX_POS_CAP") ? strtoull(getenv("BSX_POS_CAP"), 0, 10) : (unsigned long long)n * 384 * lf + (1u << 20);
 	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
 	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
 	// what the LDS tiers export for the chains -> regions launch: ~0.5 KB per strand search (a task that finds no room goes to the next tier)
-	const unsigned long long xcap = (unsigned long long)n * 1024 + (64u << 20);
+	const unsigned long long xcap = (unsigned long long)n * 1024 * lf + (64u << 20);
 	if ((rc = L.xpool.reserve((size_t)xcap)) != BSX_OK) return rc;
 	if ((rc = L.xmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
@@ -1075,6 +1079,10 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 		const long long m = (long long)order[c].size();
 		blocks[c] = (int)std::min<long long>((m + WPB[c] - 1) / WPB[c], (long long)d->n_cu * 8);
 		zmax[c] = (zmax[c] + 255) & ~(size_t)255;
+		// every wave's traceback scratch is sized for the class's largest job (a kilobase read across a long deletion: megabytes): fewer
+		// waves rather than tens of GB
+		const size_t zbudget = (size_t)4 << 30;
+		if ((size_t)blocks[c] * WPB[c] * zmax[c] > zbudget) blocks[c] = (int)std::max<size_t>(1, zbudget / (WPB[c] * zmax[c]));
 		ztot = std::max(ztot, (size_t)blocks[c] * WPB[c] * zmax[c]);
 	}
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_glb_job_t))) != BSX_OK) return rc;
