@@ -171,7 +171,7 @@ typedef int (*process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx
 /* ---- step 0 and step 2 of the reference's kt_pipeline (align.c:100-170) as two helper threads: one parses the next
  * chunks of FASTQ ahead of the aligner, one writes finished chunks out, so that neither sits on the thread that runs
  * the back half of the alignment.  Bounded queues of chunk records between them. */
-typedef struct { bsx_read_t *seqs; int n; int64_t idx; int ok; } chunk_rec_t;
+typedef struct { bsx_read_t *seqs; int n; int64_t idx; int ok; int64_t n_before; } chunk_rec_t;   /* n_before: reads of the input ahead of the chunk (-1: count along) */
 typedef struct {
 	pthread_mutex_t mu; pthread_cond_t cv;
 	chunk_rec_t q[4]; int head, count, closed;
@@ -197,23 +197,49 @@ static int cq_get(chunk_q_t *Q, chunk_rec_t *r)   /* 0 when the queue is closed 
 }
 static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok);
 static volatile int g_write_error = 0;   /* a write to stdout failed (the reference aborts there: err_fputs, utils.c:214) */
-typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; int chunk, has_bc, copy_comment; volatile int stop; } reader_t;
+/* Several ranks over plain files: a scanner thread lists the chunk boundaries without building records (fastq.c) and this rank
+ * parses only its own chunks r, r+N, ..., seeking to each.  Compressed or piped input: every rank parses everything and drops
+ * the chunks of the others (the chunk rule is cumulative). */
+static bsx_fq_scan_t *shard_scan_start(const char *fn1, const char *fn2, int chunk)
+{
+	bsx_fq_scan_t *s;
+	if (bsx_shard_world <= 1 || getenv("BSX_NO_CHUNK_SCAN")) return 0;
+	s = bsx_fq_scan_start(fn1, fn2, chunk);
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] rank %d of %d: %s\n", "main_align", bsx_shard_rank, bsx_shard_world,
+	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank parses all of it and drops the chunks of the others");
+	return s;
+}
+typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; const char *fn1, *fn2; int chunk, has_bc, copy_comment; volatile int stop; } reader_t;
 static void *reader_main(void *arg)
 {
 	reader_t *R = (reader_t*)arg;
 	int64_t idx = 0;
-	bsx_fq_pair_t *P = bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
+	bsx_fq_scan_t *scan = shard_scan_start(R->fn1, R->fn2, R->chunk);
+	bsx_fq_pair_t *P = scan ? 0 : bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
+	if (scan) idx = bsx_shard_rank;
 	while (!R->stop) {
 		chunk_rec_t r;
 		int i;
-		r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
+		r.n_before = -1;
+		if (scan) { /* this rank's next chunk: where it starts is known, the parser threads start there */
+			bsx_fq_chunkpos_t cp;
+			if (!bsx_fq_scan_get(scan, idx, &cp)) break;
+			if (bsx_fq_seek(R->f1, cp.off1) != 0 || (R->f2 && bsx_fq_seek(R->f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "reader"); break; }
+			P = bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
+			r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
+			bsx_fq_pair_close(P); P = 0;
+			if (r.seqs == 0 || r.n != cp.n) { fprintf(stderr, "[E::%s] chunk %ld: %d reads where the scan counted %d\n", "reader", (long)idx, r.n, cp.n); break; }
+			r.n_before = cp.n_before;
+		} else r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
 		if (r.seqs == 0 || r.n == 0) { free(r.seqs); break; }
 		if (!R->copy_comment) for (i = 0; i < r.n; ++i) { free(r.seqs[i].comment); r.seqs[i].comment = 0; }
-		r.idx = idx++; r.ok = 1;
+		r.idx = idx; r.ok = 1;
+		idx += scan ? bsx_shard_world : 1;
 		cq_put(R->Q, r);
 	}
 	cq_close(R->Q);
-	bsx_fq_pair_close(P);
+	if (P) bsx_fq_pair_close(P);
+	bsx_fq_scan_close(scan);
 	return 0;
 }
 static void *writer_main(void *arg)
@@ -417,6 +443,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 		/* $BSX_CHUNK_SIZE overrides the per-thread chunk size (tests only; the reference's is fixed at 10 Mbp) */
 		int chunk = (getenv("BSX_CHUNK_SIZE") ? atoi(getenv("BSX_CHUNK_SIZE")) : opt->chunk_size) * opt->n_threads, done_cmdline = 0;
 		int64_t chunk_idx = -1;
+		bsx_fq_scan_t *scan = 0;
 		/* pipelined mode: chunks in flight, oldest first (the reference's kt_pipeline keeps reading/aligning/writing
 		 * of consecutive chunks in flight the same way, align.c:165-170) */
 		struct { bsx_read_t *seqs; int n; int64_t idx; } pend[8];
@@ -432,12 +459,13 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			pthread_t th_r, th_w;
 			chunk_rec_t r;
 			cq_init(&in_q); cq_init(&out_q);
-			R.Q = &in_q; R.f1 = f1; R.f2 = f2; R.chunk = chunk; R.has_bc = opt->has_bc; R.copy_comment = copy_comment; R.stop = 0;
+			R.Q = &in_q; R.f1 = f1; R.f2 = f2; R.fn1 = argv[optind + 1]; R.fn2 = f2 ? argv[optind + 2] : 0; R.chunk = chunk; R.has_bc = opt->has_bc; R.copy_comment = copy_comment; R.stop = 0;
 			pthread_create(&th_r, 0, reader_main, &R);
 			pthread_create(&th_w, 0, writer_main, &out_q);
 			while (cq_get(&in_q, &r)) {
 				int64_t size = 0;
 				for (i = 0; i < r.n; ++i) size += r.seqs[i].l_seq;
+				if (r.n_before >= 0) n_processed = r.n_before;   /* the reader skipped the chunks of the other ranks */
 				if (bsx_shard_world > 1 && r.idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
 					n_processed += r.n;
 					for (i = 0; i < r.n; ++i) bsx_read_free(&r.seqs[i]);
@@ -451,7 +479,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; R.stop = 1; break; }
 				if (g_write_error) { rc = 1; R.stop = 1; break; }
 				while (n_pend > depth - 1) { /* the push completed the oldest chunk in flight */
-					chunk_rec_t d; d.seqs = pend[0].seqs; d.n = pend[0].n; d.idx = pend[0].idx; d.ok = 1;
+					chunk_rec_t d; d.seqs = pend[0].seqs; d.n = pend[0].n; d.idx = pend[0].idx; d.ok = 1; d.n_before = -1;
 					cq_put(&out_q, d);
 					for (i = 1; i < n_pend; ++i) pend[i - 1] = pend[i];
 					--n_pend;
@@ -462,7 +490,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			/* after an error chunks are still in flight: closing the stream joins their front halves and runs their back halves, which
 			 * read the pending chunks' reads -- so close it before those reads go to the writer (which frees them) */
 			if (rc) { bsx_stream_close(stream); stream = 0; }
-			for (i = 0; i < n_pend; ++i) { chunk_rec_t d; d.seqs = pend[i].seqs; d.n = pend[i].n; d.idx = pend[i].idx; d.ok = rc == 0; cq_put(&out_q, d); }
+			for (i = 0; i < n_pend; ++i) { chunk_rec_t d; d.seqs = pend[i].seqs; d.n = pend[i].n; d.idx = pend[i].idx; d.ok = rc == 0; d.n_before = -1; cq_put(&out_q, d); }
 			n_pend = 0;
 			cq_close(&out_q);
 			pthread_join(th_r, 0); pthread_join(th_w, 0);
@@ -489,6 +517,15 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				}
 				if (seq2) opt->flag |= BSX_F_PE;
 			} else {
+				if (chunk_idx < 0) scan = shard_scan_start(argv[optind + 1], f2 ? argv[optind + 2] : 0, chunk);
+				if (scan) { /* straight to this rank's next chunk (see reader_main) */
+					bsx_fq_chunkpos_t cp;
+					const int64_t k = chunk_idx < 0 ? bsx_shard_rank : chunk_idx + bsx_shard_world;
+					if (!bsx_fq_scan_get(scan, k, &cp)) break;
+					if (bsx_fq_seek(f1, cp.off1) != 0 || (f2 && bsx_fq_seek(f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "main_align"); rc = 1; break; }
+					chunk_idx = k - 1;
+					n_processed = cp.n_before;
+				}
 				seqs = bsx_fq_read_chunk(f1, f2, chunk, opt->has_bc, &n);
 				if (seqs == 0 || n == 0) { free(seqs); break; }
 				if (!copy_comment) for (i = 0; i < n; ++i) { free(seqs[i].comment); seqs[i].comment = 0; }
@@ -536,7 +573,8 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			for (i = 0; i < n_pend; ++i) emit_chunk(pend[i].seqs, pend[i].n, pend[i].idx, rc == 0);
 			if (stream) bsx_stream_close(stream);
 		}
-loop_done: ;
+loop_done:
+		bsx_fq_scan_close(scan);
 	}
 	if (fflush(stdout) != 0 || ferror(stdout)) g_write_error = 1;
 	if (g_write_error) { fprintf(stderr, "[E::%s] failed to write the output: the SAM is incomplete\n", "main_align"); rc = 1; }

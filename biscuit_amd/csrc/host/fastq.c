@@ -17,6 +17,8 @@ struct bsx_fq {
 	gzFile fp;
 	unsigned char *buf;
 	int begin, end, is_eof, last_char;
+	int64_t base;        /* file offset of buf[0] (plain files: the chunk scan and bsx_fq_seek) */
+	int64_t last_off;    /* where last_char was read */
 	BSX_VEC(char) name, comment, seq, qual;
 };
 
@@ -46,6 +48,7 @@ static inline int fq_getc(bsx_fq_t *f)
 {
 	if (f->is_eof && f->begin >= f->end) return -1;
 	if (f->begin >= f->end) {
+		f->base += f->end;
 		f->begin = 0;
 		f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
 		if (f->end <= 0) { f->is_eof = 1; f->end = 0; return -1; }
@@ -59,6 +62,7 @@ static inline int fq_fill(bsx_fq_t *f)
 {
 	if (f->begin < f->end) return 1;
 	if (f->is_eof) return 0;
+	f->base += f->end;
 	f->begin = 0;
 	f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
 	if (f->end <= 0) { f->is_eof = 1; f->end = 0; return 0; }
@@ -112,7 +116,7 @@ static int fq_read(bsx_fq_t *f)
 	if (f->last_char == 0) {
 		while ((c = fq_getc(f)) != -1 && c != '>' && c != '@');
 		if (c == -1) return -1;
-		f->last_char = c;
+		f->last_char = c; f->last_off = f->base + f->begin - 1;
 	}
 	f->comment.n = f->seq.n = f->qual.n = 0;
 	if ((c = fq_until(f, 0, &f->name, 0)) < 0 && f->name.n == 0) return -1;
@@ -123,7 +127,7 @@ static int fq_read(bsx_fq_t *f)
 		vec_putc(f->seq, c);
 		fq_until(f, 1, &f->seq, 1);
 	}
-	if (c == '>' || c == '@') f->last_char = c;
+	if (c == '>' || c == '@') { f->last_char = c; f->last_off = f->base + f->begin - 1; }
 	bsx_vec_reserve(f->seq, f->seq.n + 1);
 	f->seq.a[f->seq.n] = 0;
 	if (c != '+') { if (c == -1) f->last_char = 0; return (int)f->seq.n; }
@@ -268,6 +272,175 @@ bsx_read_t *bsx_fq_pair_read_chunk(bsx_fq_pair_t *P, int chunk_size, int *n_)
 	if (size == 0 && P->has_b && feed_next(&P->b, &rb)) { fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", "bsx_fq_read_chunk"); bsx_read_free(&rb); }
 	*n_ = n;
 	return seqs;
+}
+
+/* ---- chunk boundaries by a light scan.  With several GPUs every rank aligns chunks r, r+N, ...: the chunk rule is cumulative, so a rank
+ * has to know where its chunks start, but it does not have to build the records of the others.  Over plain (seekable, uncompressed)
+ * files a scanner thread walks the record grammar above counting bases only -- no copies, no allocations: a few memchr calls per
+ * record -- and lists each chunk's byte offsets in the files and its read count; the rank's parser seeks to its own chunks. */
+/* length of the rest of the current line as fq_until(line_only) would append it; *last: its last character (or `first` if the rest is
+ * empty); returns the delimiter or -1 at end of file (*got: something was there) */
+static int scan_line(bsx_fq_t *f, int first, int64_t *len, int *got_)
+{
+	int64_t n = 0; int last = first, c = -1, got = 0;
+	for (;;) {
+		const unsigned char *p, *q;
+		size_t l;
+		if (!fq_fill(f)) { c = -1; break; }
+		got = 1;
+		p = f->buf + f->begin;
+		q = (const unsigned char*)memchr(p, '\n', (size_t)(f->end - f->begin));
+		l = (size_t)((q ? q : f->buf + f->end) - p);
+		if (l) { last = p[l - 1]; n += (int64_t)l; }
+		f->begin += (int)l + (q ? 1 : 0);
+		if (q) { c = '\n'; break; }
+	}
+	if (got_) *got_ = got;
+	if (!got && c < 0) { *len = first >= 0 ? 1 : 0; return -1; }   /* (fq_until leaves the vector as it was) */
+	if (first >= 0) ++n;               /* the character the caller had already taken */
+	if (n > 0 && last == '\r') --n;    /* fq_until strips one trailing CR per call */
+	*len = n;
+	return c;
+}
+/* fq_read without building the record: sequence length, -1 at end of file, -2 truncated; *off = where the record's header starts */
+static int fq_scan(bsx_fq_t *f, int64_t *off)
+{
+	int c, got;
+	int64_t slen = 0, qlen = 0, l;
+	if (f->last_char == 0) {
+		while ((c = fq_getc(f)) != -1 && c != '>' && c != '@');
+		if (c == -1) return -1;
+		f->last_char = c; f->last_off = f->base + f->begin - 1;
+	}
+	*off = f->last_off;
+	{ /* name: up to the first white space */
+		int64_t nl = 0; int gotn = 0;
+		c = -1;
+		for (;;) {
+			const unsigned char *p, *q, *e;
+			if (!fq_fill(f)) { c = -1; break; }
+			gotn = 1;
+			p = f->buf + f->begin; e = f->buf + f->end;
+			for (q = p; q < e && !isspace(*q); ++q);
+			nl += q - p;
+			if (q < e) { c = *q; f->begin += (int)(q - p) + 1; break; }
+			f->begin = f->end;
+		}
+		if (c < 0 && (nl == 0 || !gotn)) return -1;
+	}
+	if (c != '\n' && c >= 0) fq_skip_line(f);
+	while ((c = fq_getc(f)) != -1 && c != '>' && c != '+' && c != '@') {
+		if (c == '\n') continue;
+		scan_line(f, c, &l, 0);
+		slen += l;
+	}
+	if (c == '>' || c == '@') { f->last_char = c; f->last_off = f->base + f->begin - 1; }
+	if (c != '+') { if (c == -1) f->last_char = 0; return (int)slen; }
+	if (fq_skip_line(f) < 0) return -2;
+	while (qlen < slen) { if (scan_line(f, -1, &l, &got) < 0) { qlen += l; break; } qlen += l; }
+	f->last_char = 0;
+	if (qlen != slen) return -2;
+	return (int)slen;
+}
+static int64_t fq_next_off(const bsx_fq_t *f) { return f->last_char ? f->last_off : f->base + f->begin; }
+
+int bsx_fq_plain_file(const char *fn)   /* a regular, uncompressed file: offsets into it mean something */
+{
+	unsigned char m[2] = {0, 0};
+	FILE *fp;
+	size_t k;
+	if (strcmp(fn, "-") == 0) return 0;
+	if ((fp = fopen(fn, "rb")) == 0) return 0;
+	if (fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return 0; }   /* pipes, sockets */
+	rewind(fp);
+	k = fread(m, 1, 2, fp);
+	fclose(fp);
+	return !(k == 2 && m[0] == 0x1f && m[1] == 0x8b);
+}
+int bsx_fq_seek(bsx_fq_t *f, int64_t off)
+{
+	if (gzseek(f->fp, (z_off_t)off, SEEK_SET) < 0) return -1;
+	f->begin = f->end = 0; f->is_eof = 0; f->last_char = 0; f->base = off; f->last_off = 0;
+	return 0;
+}
+
+struct bsx_fq_scan {
+	bsx_fq_t *f1, *f2;
+	int chunk_size;
+	pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+	BSX_VEC(bsx_fq_chunkpos_t) tab;
+	int done, stop;
+};
+static void *scan_main(void *arg)
+{
+	bsx_fq_scan_t *S = (bsx_fq_scan_t*)arg;
+	int64_t n_before = 0;
+	for (;;) {
+		bsx_fq_chunkpos_t cp;
+		int64_t size = 0, o;
+		int n = 0, l, stop;
+		cp.off1 = fq_next_off(S->f1); cp.off2 = S->f2 ? fq_next_off(S->f2) : 0; cp.n_before = n_before;
+		while ((l = fq_scan(S->f1, &o)) >= 0) {   /* the rule of bsx_fq_read_chunk */
+			int l2 = 0;
+			if (S->f2 && (l2 = fq_scan(S->f2, &o)) < 0) break;
+			size += l; ++n;
+			if (S->f2) { size += l2; ++n; }
+			if (size >= S->chunk_size && (n & 1) == 0) break;
+		}
+		cp.n = n; cp.pad = 0;
+		pthread_mutex_lock(&S->mu);
+		if (n > 0) bsx_vec_push(S->tab, cp);
+		if (n == 0) S->done = 1;
+		stop = S->stop;
+		pthread_cond_broadcast(&S->cv);
+		pthread_mutex_unlock(&S->mu);
+		if (n == 0 || stop) break;
+		n_before += n;
+	}
+	pthread_mutex_lock(&S->mu); S->done = 1; pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu);
+	return 0;
+}
+bsx_fq_scan_t *bsx_fq_scan_start(const char *fn1, const char *fn2, int chunk_size)
+{
+	bsx_fq_scan_t *S;
+	if (!bsx_fq_plain_file(fn1) || (fn2 && !bsx_fq_plain_file(fn2))) return 0;
+	S = (bsx_fq_scan_t*)calloc(1, sizeof(*S));
+	S->chunk_size = chunk_size;
+	if ((S->f1 = bsx_fq_open(fn1)) == 0 || (fn2 && (S->f2 = bsx_fq_open(fn2)) == 0)) { bsx_fq_close(S->f1); free(S); return 0; }
+	bsx_vec_init(S->tab);
+	pthread_mutex_init(&S->mu, 0); pthread_cond_init(&S->cv, 0);
+	pthread_create(&S->th, 0, scan_main, S);
+	return S;
+}
+int bsx_fq_scan_get(bsx_fq_scan_t *S, int64_t k, bsx_fq_chunkpos_t *out)   /* waits for chunk k; 0: the input has fewer chunks */
+{
+	int ok;
+	pthread_mutex_lock(&S->mu);
+	while ((int64_t)S->tab.n <= k && !S->done) pthread_cond_wait(&S->cv, &S->mu);
+	ok = (int64_t)S->tab.n > k;
+	if (ok) *out = S->tab.a[k];
+	pthread_mutex_unlock(&S->mu);
+	return ok;
+}
+void bsx_fq_scan_close(bsx_fq_scan_t *S)
+{
+	if (!S) return;
+	pthread_mutex_lock(&S->mu); S->stop = 1; pthread_mutex_unlock(&S->mu);
+	pthread_join(S->th, 0);
+	bsx_fq_close(S->f1); bsx_fq_close(S->f2);
+	bsx_vec_free(S->tab);
+	free(S);
+}
+/* test hook: the whole table at once */
+BSX_API int64_t bsx_fq_scan_table(const char *fn1, const char *fn2, int chunk_size, int64_t cap, bsx_fq_chunkpos_t *out)
+{
+	bsx_fq_scan_t *S = bsx_fq_scan_start(fn1, fn2, chunk_size);
+	int64_t k = 0;
+	bsx_fq_chunkpos_t cp;
+	if (!S) return -1;
+	while (bsx_fq_scan_get(S, k, &cp)) { if (k < cap) out[k] = cp; ++k; }
+	bsx_fq_scan_close(S);
+	return k;
 }
 
 void bsx_read_free(bsx_read_t *s)

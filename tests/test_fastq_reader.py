@@ -196,3 +196,72 @@ def test_parser_threads_give_the_same_chunks(tmp_path):
     L.bsx_sim_free_reads(r, n.value)
     L.bsx_hook_fq_pair_close(p)
     L.bsx_hook_fq_close(f1)
+
+
+class ChunkPos(C.Structure):
+    _fields_ = [("off1", C.c_int64), ("off2", C.c_int64), ("n_before", C.c_int64), ("n", C.c_int), ("pad", C.c_int)]
+
+
+def scan_table(path1, path2, chunk_size):
+    L = B.lib()
+    L.bsx_fq_scan_table.restype = C.c_int64
+    L.bsx_fq_scan_table.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int64, C.POINTER(ChunkPos)]
+    tab = (ChunkPos * 4096)()
+    k = L.bsx_fq_scan_table(path1.encode(), path2.encode() if path2 else None, chunk_size, 4096, tab)
+    return None if k < 0 else [tab[i] for i in range(k)]
+
+
+def read_chunk_at(path1, path2, off1, off2, chunk_size):
+    L = B.lib()
+    L.bsx_hook_fq_seek.argtypes = [C.c_void_p, C.c_int64]
+    f1 = L.bsx_hook_fq_open(path1.encode())
+    f2 = L.bsx_hook_fq_open(path2.encode()) if path2 else None
+    assert L.bsx_hook_fq_seek(f1, off1) == 0 and (f2 is None or L.bsx_hook_fq_seek(f2, off2) == 0)
+    n = C.c_int()
+    r = L.bsx_hook_fq_chunk(f1, f2, chunk_size, 0, C.byref(n))
+    out = [(r[i].name.decode(), "".join("ACGTN"[r[i].seq[k]] for k in range(r[i].l_seq)), r[i].qual.decode() if r[i].qual else None) for i in range(n.value)]
+    if r:
+        L.bsx_sim_free_reads(r, n.value)
+    L.bsx_hook_fq_close(f1)
+    if f2:
+        L.bsx_hook_fq_close(f2)
+    return out
+
+
+def test_chunk_scan_equals_the_reader(tmp_path):
+    """Multi-GPU input: the chunk boundaries found by the light scan (no records built: fastq.c, fq_scan) are the chunks the reader
+    makes, for every grammar variant; a reader that seeks to a chunk's offsets reads exactly that chunk."""
+    rng = random.Random(9)
+    texts = [make_text(rng, 400), make_text(rng, 300, crlf=True), make_text(rng, 300, multiline=True), make_text(rng, 300, fastq=False, multiline=True),
+             make_text(rng, 50).rstrip("\n"), "garbage before\n" + make_text(rng, 20), make_text(rng, 5000),
+             make_text(rng, 40, fastq=False) + make_text(rng, 40) + make_text(rng, 40, fastq=False, multiline=True)]
+    for ti, text in enumerate(texts):
+        p = str(tmp_path / ("s%d.fq" % ti))
+        open(p, "w", newline="").write(text)
+        for chunk_size in (700, 2000, 100000):
+            chunks = read_all(p, None, chunk_size)
+            tab = scan_table(p, None, chunk_size)
+            assert [t.n for t in tab] == [len(c) for c in chunks], (ti, chunk_size)
+            assert [t.n_before for t in tab] == [sum(len(c) for c in chunks[:k]) for k in range(len(chunks))]
+            for k in sorted(set([0, len(tab) // 2, len(tab) - 1])):
+                got = read_chunk_at(p, None, tab[k].off1, 0, chunk_size)
+                assert got == [(r[0], r[2], r[3]) for r in chunks[k]], (ti, chunk_size, k)
+    # two files, records of different byte lengths in each; and one file shorter than the other
+    a, b = make_text(rng, 300, multiline=True), make_text(rng, 300, crlf=True)
+    p1, p2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    open(p1, "w", newline="").write(a)
+    open(p2, "w", newline="").write(b)
+    for chunk_size in (1500, 9000):
+        chunks = read_all(p1, p2, chunk_size)
+        tab = scan_table(p1, p2, chunk_size)
+        assert [t.n for t in tab] == [len(c) for c in chunks]
+        for k in range(len(tab)):
+            got = read_chunk_at(p1, p2, tab[k].off1, tab[k].off2, chunk_size)
+            assert got == [(r[0], r[2], r[3]) for r in chunks[k]], (chunk_size, k)
+    open(p2, "w", newline="").write(make_text(random.Random(1), 120))
+    chunks = read_all(p1, p2, 1500)
+    assert [t.n for t in scan_table(p1, p2, 1500)] == [len(c) for c in chunks] and sum(len(c) for c in chunks) == 240
+    # compressed input has no offsets to seek to: no table, the ranks fall back to parsing everything
+    pz = str(tmp_path / "z.fq.gz")
+    gzip.open(pz, "wt").write(a)
+    assert scan_table(pz, None, 2000) is None

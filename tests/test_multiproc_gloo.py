@@ -39,3 +39,18 @@ def test_two_ranks_equal_one(tmp_path, pe):
     a, b = strip_pg(one.stdout), strip_pg(open(d + "/two.sam", "rb").read())
     assert a.count(b"\n") > 3000
     assert a == b
+    # plain files: each rank found its chunks through the boundary scan and parsed nothing else
+    assert two.stderr.count(b"this rank parses its own chunks only") == 2, two.stderr.decode()[-2000:]
+    if pe:
+        # compressed input has no offsets to seek to: every rank parses everything and drops the other rank's chunks; same SAM
+        import gzip
+        import shutil
+        for f in files:
+            with open(d + "/" + f, "rb") as fi, gzip.open(d + "/" + f + ".gz", "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+        gz = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                             "--master-port", "29533", os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/gz.sam", "--", "-@", "1", "g"] + [f + ".gz" for f in files],
+                            cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert gz.returncode == 0, gz.stderr.decode()[-3000:]
+        assert strip_pg(open(d + "/gz.sam", "rb").read()) == a
+        assert gz.stderr.count(b"parses all of it") == 2
