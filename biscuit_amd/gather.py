@@ -4,8 +4,11 @@ Chunks are dealt round-robin: chunk k is aligned by rank k % world.  The gather 
 carries chunks r*world .. r*world+world-1, one per rank at most:
     1. every rank reports (has_chunk, n_bytes) -> all ranks (a 2-int all_gather: everybody must see the end),
     2. every rank but 0 that has a chunk sends exactly n_bytes to rank 0 (send/recv: RCCL point-to-point over
-       xGMI on GPUs, gloo in the CPU tests); nothing is padded and no other rank receives anything,
-    3. rank 0 hands the round's chunks to `sink` in input order and drops them.
+       xGMI on GPUs, gloo in the CPU tests); nothing is padded and no other rank receives anything.  Rank 0 posts the
+       receives of a round together, each into its own staging buffer: xGMI is point to point, every sender has its own
+       link into rank 0, so the round's transfers run side by side instead of one after the other,
+    3. rank 0 hands the round's chunks to `sink` in input order and drops them; the device-to-host copies of the later
+       senders' chunks (a side stream, pinned buffers) overlap the sink of the earlier ones.
 It ends with the first round in which some rank has no chunk (round-robin dealing: no later chunk exists).
 Producers (the aligner's writer thread) hand chunks in through `submit`, which blocks once `max_pending`
 chunks wait: host memory of a rank is bounded by a few chunks whatever the input size, rank 0 writes as it
@@ -30,6 +33,8 @@ class ChunkGather:
         self._stash = {}
         self._pin = None
         self._dev_buf = None
+        self._src_buf = {}            # rank 0: per-sender staging (device tensor, pinned host tensor)
+        self._copy_stream = None
         self._dead = False            # set when the gather has ended: late producers (another rank failed) are not blocked
 
     # ---- producer side -------------------------------------------------------------------------------------------
@@ -77,6 +82,16 @@ class ChunkGather:
                 self._pin = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
         return self._dev_buf[:n]
 
+    def _staging_src(self, src, n):
+        """rank 0: sender `src`'s own staging pair, so that the receives of a round can be in flight together"""
+        cur = self._src_buf.get(src)
+        if cur is None or cur[0].numel() < n:
+            cap = max(n + (n >> 2), 1 << 20)
+            dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            pin = torch.empty(cap, dtype=torch.uint8, pin_memory=True) if self.device.type == "cuda" else None
+            cur = self._src_buf[src] = (dev, pin)
+        return cur[0][:n], (cur[1][:n] if cur[1] is not None else None)
+
     def warm(self, n_bytes=1 << 20):
         """one empty round before the data: the metadata all_gather and a send from every rank to rank 0, so that the
         point-to-point connections (RCCL sets a pair's channel up on its first transfer) and the staging buffers exist
@@ -114,23 +129,48 @@ class ChunkGather:
             dist.all_gather(metas, meta)
             metas = [(int(m[0]), int(m[1])) for m in torch.stack(metas).cpu()]
             if self.rank == 0:
-                for src in range(self.world):
+                # all receives of the round at once, each into the sender's own buffer
+                bufs, ops = {}, []
+                for src in range(1, self.world):
+                    has, nb = metas[src]
+                    if has and nb:
+                        bufs[src] = self._staging_src(src, nb)
+                        ops.append(dist.P2POp(dist.irecv, bufs[src][0], src))
+                reqs = dist.batch_isend_irecv(ops) if ops else []
+                if metas[0][0]:
+                    self.sink(r * self.world, mine)   # this rank's own chunk while the others arrive
+                    n_chunks += 1
+                for q in reqs:
+                    q.wait()
+                done = {}
+                if self.device.type == "cuda" and bufs:
+                    # device -> pinned host on a side stream, sender by sender; the sink of one chunk runs while the next one is copied
+                    # (a pageable copy of a chunk's records -- half a GB -- takes longer than the chunk took to align on eight GPUs)
+                    if self._copy_stream is None:
+                        self._copy_stream = torch.cuda.Stream(device=self.device)
+                    self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(self._copy_stream):
+                        for src in sorted(bufs):
+                            dev, pin = bufs[src]
+                            pin.copy_(dev, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(self._copy_stream)
+                            done[src] = ev
+                for src in range(1, self.world):
                     has, nb = metas[src]
                     if not has:
                         continue
-                    if src == 0:
-                        self.sink(r * self.world, mine)
-                    else:
-                        buf = self._staging(nb)
-                        if nb:
-                            dist.recv(buf, src=src)
-                        if self.device.type == "cuda":   # through the pinned staging buffer: a pageable copy of a chunk's records
-                            host = self._pin[:nb]        # (half a GB) takes longer than the chunk took to align on eight GPUs
-                            host.copy_(buf)
+                    if nb:
+                        dev, pin = bufs[src]
+                        if pin is not None:
+                            done[src].synchronize()
+                            host = pin
                         else:
-                            host = buf
+                            host = dev
                         self.sink(r * self.world + src, memoryview(host.numpy()))
-                        self.bytes_moved += nb
+                    else:
+                        self.sink(r * self.world + src, memoryview(b""))
+                    self.bytes_moved += nb
                     n_chunks += 1
             else:
                 n_chunks += sum(1 for has, _ in metas if has)

@@ -39,10 +39,32 @@ class _Group:
         assert buf.is_cuda
         buf.copy_(self.q[(src, self.tl.rank)].get())
 
+    # rank 0 posts a round's receives together (batch_isend_irecv over P2POp(irecv, ...)): here each becomes a deferred copy
+    def irecv(self, buf, src):
+        raise AssertionError("only through batch_isend_irecv")
 
-@pytest.mark.parametrize("n_chunks", [5, 8])
-def test_device_branch_moves_the_records(monkeypatch, n_chunks):
-    world = 2
+    class _Op:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def P2POp(self, op, tensor, peer):
+        assert op == self.irecv and tensor.is_cuda
+        return self._Op(op, tensor, peer)
+
+    class _Req:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def wait(self):
+            self.fn()
+
+    def batch_isend_irecv(self, ops):
+        me = self.tl.rank
+        return [self._Req(lambda o=o: o.tensor.copy_(self.q[(o.peer, me)].get())) for o in ops]
+
+
+@pytest.mark.parametrize("n_chunks,world", [(5, 2), (8, 2), (11, 3)])
+def test_device_branch_moves_the_records(monkeypatch, n_chunks, world):
     grp = _Group(world)
     monkeypatch.setattr(gather_mod, "dist", grp)
     dev = torch.device("cuda", 0)
@@ -73,8 +95,8 @@ def test_device_branch_moves_the_records(monkeypatch, n_chunks):
     for t in th:
         t.join(timeout=120)
         assert not t.is_alive()
-    assert res[0] == res[1] == n_chunks
+    assert all(x == n_chunks for x in res)
     assert [k for k, _ in got] == list(range(n_chunks))
     for k, b in got:
         assert b == chunks[k].tobytes()
-    assert gs[0].bytes_moved == sum(sizes[k] for k in range(1, n_chunks, world))
+    assert gs[0].bytes_moved == sum(sizes[k] for k in range(n_chunks) if k % world)
