@@ -18,14 +18,15 @@
 template <int NC>
 __global__ void __launch_bounds__(256)
 k_extend(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order, long long n,
-         bsx_ext_res_t *res, int qcap)
+         bsx_ext_res_t *res, int qcap, int32_t *hbm_rows)
 {
 	extern __shared__ int32_t lds[];
 	const int lane = wave_lane();
 	const int waves_per_block = blockDim.x >> 6;
 	const int wave = threadIdx.x >> 6;
 	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1;
-	int32_t *H = lds + wave * stride;
+	// hbm_rows: the rows of queries too long for LDS live in a per-wave slab in HBM (reads of tens of kilobases: rare, and slow)
+	int32_t *H = hbm_rows ? hbm_rows + ((size_t)blockIdx.x * waves_per_block + wave) * (size_t)stride : lds + wave * stride;
 	int32_t *E = H + (qcap + 2);
 	uint8_t *qb = reinterpret_cast<uint8_t*>(E + (qcap + 2));
 
@@ -50,7 +51,13 @@ static void launch_ext_nc(hipStream_t st, const DevIndex &ix, const DevScoring &
 	long long cap = (long long)n_cu * 32;
 	if (blocks > cap) blocks = cap;
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_extend<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	hipLaunchKernelGGL(k_extend<NC>, dim3((unsigned)blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, qcap);
+	hipLaunchKernelGGL(k_extend<NC>, dim3((unsigned)blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, qcap, (int32_t*)nullptr);
+}
+size_t extend_hbm_row_bytes(int qcap) { return (size_t)(2 * (qcap + 2) + ((qcap + 3) >> 2) + 1) * 4; }
+void launch_extend_hbm(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,
+                       long long n, bsx_ext_res_t *res, int qcap, int blocks, void *rows)
+{
+	hipLaunchKernelGGL(k_extend<32>, dim3((unsigned)blocks), dim3(256), 0, st, ix, sc, reads, jobs, order, n, res, qcap, (int32_t*)rows);
 }
 
 void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,

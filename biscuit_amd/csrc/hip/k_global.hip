@@ -23,13 +23,14 @@ template <int NC>
 __global__ void __launch_bounds__(256)
 k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order, long long n,
          bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap,
-         bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap)
+         bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap, int32_t *hbm_rows)
 {
 	extern __shared__ int32_t lds[];
 	const int lane = wave_lane();
 	const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
 	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1 + ((tcap + 3) >> 2);
-	int32_t *H = lds + wave * stride;
+	// hbm_rows: queries too long for LDS keep their rows in a per-wave slab in HBM (as k_extend)
+	int32_t *H = hbm_rows ? hbm_rows + ((size_t)blockIdx.x * wpb + wave) * (size_t)stride : lds + wave * stride;
 	int32_t *E = H + (qcap + 2);
 	uint8_t *qb = reinterpret_cast<uint8_t*>(E + (qcap + 2));
 	uint8_t *tb = qb + (((qcap + 3) >> 2) << 2) + 4;   // tcap target bases (tags only)
@@ -302,13 +303,20 @@ k_global(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_glb_job_t *
 template <int NC>
 static void launch_glb_nc(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                           long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks, int wpb,
-                          bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap)
+                          bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, int tcap, void *hbm_rows = nullptr)
 {
 	const int stride = 2 * (qcap + 2) + ((qcap + 3) >> 2) + 1 + ((tcap + 3) >> 2);
-	const size_t lds = (size_t)wpb * stride * 4;
+	const size_t lds = hbm_rows ? 0 : (size_t)wpb * stride * 4;
 	if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_global<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipLaunchKernelGGL(k_global<NC>, dim3(blocks), dim3(wpb * 64), lds, st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap,
-	                   tags, md_pool, md_cap, md_cursor, tcap);
+	                   tags, md_pool, md_cap, md_cursor, tcap, (int32_t*)hbm_rows);
+}
+size_t global_hbm_row_bytes(int qcap) { return (size_t)(2 * (qcap + 2) + ((qcap + 3) >> 2) + 1) * 4; }
+void launch_global_hbm(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
+                       long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks,
+                       bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, void *rows)
+{
+	launch_glb_nc<32>(st, ix, sc, reads, jobs, order, n, res, pool, zscratch, zstride, qcap, blocks, 1, tags, md_pool, md_cap, md_cursor, 0, rows);
 }
 
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,

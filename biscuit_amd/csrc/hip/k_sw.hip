@@ -19,8 +19,8 @@
 
 #include "sw_pass.hpp"
 
-template <int NC>
-__global__ void __launch_bounds__(256)
+template <int NC, int TPB>
+__global__ void __launch_bounds__(TPB)
 k_sw(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order, long long n,
      bsx_sw_res_t *res, unsigned long long *bscratch, int bcap)
 {
@@ -65,12 +65,14 @@ template <int NC>
 static void launch_sw_nc(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
                          long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks)
 {
-	hipLaunchKernelGGL(k_sw<NC>, dim3(blocks), dim3(256), 0, st, ix, sc, reads, jobs, order, n, res, bscratch, bcap);
+	hipLaunchKernelGGL((k_sw<NC, 256>), dim3(blocks), dim3(256), 0, st, ix, sc, reads, jobs, order, n, res, bscratch, bcap);
 }
 
 void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc)
 {
 	if (nc <= 4) launch_sw_nc<4>(st, ix, sc, reads, jobs, order, n, res, bscratch, bcap, blocks);
-	else launch_sw_nc<16>(st, ix, sc, reads, jobs, order, n, res, bscratch, bcap, blocks);
+	else if (nc <= 16) launch_sw_nc<16>(st, ix, sc, reads, jobs, order, n, res, bscratch, bcap, blocks);
+	else // queries up to 3072 columns (mates of paired reads longer than a kilobase): 48 register slots per lane, one wave per workgroup and SIMD
+		hipLaunchKernelGGL((k_sw<48, 64>), dim3(blocks * 4), dim3(64), 0, st, ix, sc, reads, jobs, order, n, res, bscratch, bcap);
 }

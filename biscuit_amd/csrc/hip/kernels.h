@@ -12,6 +12,14 @@ void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t 
 // DP kernels: one wavefront per job
 void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,
                    long long n, bsx_ext_res_t *res, int qcap, int nc, int n_cu);
+// the same for queries whose rows outgrow LDS (longer than 16 k bases): rows in `rows`, extend_hbm_row_bytes(qcap) per wave, blocks x 4 waves
+size_t extend_hbm_row_bytes(int qcap);
+void launch_extend_hbm(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,
+                       long long n, bsx_ext_res_t *res, int qcap, int blocks, void *rows);
+size_t global_hbm_row_bytes(int qcap);
+void launch_global_hbm(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
+                       long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int blocks,
+                       bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, void *rows);   // one wave per workgroup
 void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc);
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,

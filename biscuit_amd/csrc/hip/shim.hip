@@ -931,30 +931,40 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 		return BSX_OK;
 	}
 	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}
-	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 512, 2048}, NCS[3] = {4, 8, 32};
-	std::vector<int> order[3];
+	// the last class: queries of any length, rows in HBM (reads of tens of kilobases).  What remains out of reach is a band of more
+	// than 2048 columns, i.e. -w above 511 -- a limit of the option, not of the data
+	static const int QCAP[4] = {256, 1024, 16384, 0x7fffffff}, BAND[4] = {256, 512, 2048, 2048}, NCS[4] = {4, 8, 32, 32};
+	std::vector<int> order[4];
+	int hbm_qmax = 0, rc0;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_ext_job_t &j = jobs[i];
 		if (j.qlen <= 0 || j.tlen < 0 || j.h0 <= 0) { fprintf(stderr, "[bsx-hip] extend job %lld: invalid (qlen=%d tlen=%d h0=%d)\n", (long long)i, j.qlen, j.tlen, j.h0); return BSX_E_ARG; }
 		long long band = std::min<long long>(j.qlen, 2LL * j.w + 1);
 		int c = 0;
-		while (c < 3 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
-		if (c == 3) { fprintf(stderr, "[bsx-hip] extend job %lld: query %d / band %lld beyond kernel limits\n", (long long)i, j.qlen, band); return BSX_E_ARG; }
+		while (c < 4 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
+		if (c == 4) { fprintf(stderr, "[bsx-hip] extend job %lld: a band of %lld columns is beyond the kernel's 2048 (-w above 511)\n", (long long)i, band); return BSX_E_ARG; }
+		if (c == 3) hbm_qmax = std::max(hbm_qmax, j.qlen);
 		order[c].push_back((int)i);
 	}
+	const int hbm_blocks = order[3].empty() ? 0 : (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((order[3].size() + 3) / 4, (size_t)d->n_cu), ((size_t)2 << 30) / (4 * extend_hbm_row_bytes(hbm_qmax))));
+	if (hbm_blocks && (rc0 = L.scratch.reserve((size_t)hbm_blocks * 4 * extend_hbm_row_bytes(hbm_qmax))) != BSX_OK) return rc0;
 	int rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 	size_t off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
 		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st));
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
+		if (c == 3)
+			launch_extend_hbm(L.st, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+			                  (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, hbm_qmax, hbm_blocks, L.scratch.p);
+		else
 		launch_extend(L.st, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, QCAP[c], NCS[c], d->n_cu);
 		off += order[c].size();
@@ -974,14 +984,14 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
-	std::vector<int> order[2];
+	std::vector<int> order[3];   // by padded query length: up to 256, 1024, 3072 columns
 	int max_tlen = 1;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_sw_job_t &j = jobs[i];
 		if (j.qlen <= 0 || j.tlen < 0) { fprintf(stderr, "[bsx-hip] sw job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
 		const int p = (j.xtra & BSX_KSW_XBYTE) ? 16 : 8, Q = (j.qlen + p - 1) / p * p;
-		if (Q > 1024) { fprintf(stderr, "[bsx-hip] sw job %lld: query %d beyond kernel limit (1024)\n", (long long)i, j.qlen); return BSX_E_ARG; }
-		order[Q <= 256 ? 0 : 1].push_back((int)i);
+		if (Q > 3072) { fprintf(stderr, "[bsx-hip] sw job %lld: query %d beyond kernel limit (3072)\n", (long long)i, j.qlen); return BSX_E_ARG; }
+		order[Q <= 256 ? 0 : Q <= 1024 ? 1 : 2].push_back((int)i);
 		max_tlen = std::max(max_tlen, j.tlen);
 	}
 	int rc;
@@ -992,17 +1002,17 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t));
 	size_t off = 0;
-	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
 		H2D(L.st_hi, (int*)L.aux.p + off, order[c].data(), order[c].size() * 4);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
-	for (int c = 0; c < 2; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
 		const long long m = (long long)order[c].size();
 		const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
 		launch_sw(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
-		          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : 16);
+		          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : c == 1 ? 16 : 48);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
@@ -1045,12 +1055,14 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
-	static const int QCAP[3] = {256, 1024, 16384}, BAND[3] = {256, 1024, 2048}, NCS[3] = {4, 16, 32}, WPB[3] = {4, 4, 1};
-	std::vector<int> order[3];
-	size_t zmax[3] = {64, 64, 64};
+	// the last class: queries of any length with their rows in HBM (as lane_extend_batch); a band above 2048 columns stays out of reach
+	static const int QCAP[4] = {256, 1024, 16384, 0x7fffffff}, BAND[4] = {256, 1024, 2048, 2048}, NCS[4] = {4, 16, 32, 32}, WPB[4] = {4, 4, 1, 1};
+	std::vector<int> order[4];
+	size_t zmax[4] = {64, 64, 64, 64};
+	int hbm_qmax = 0;
 	// tags: the target bases of a job are staged in LDS for the MD walk when they fit next to the DP rows (the rare longer ones are
 	// read from HBM); an MD string is at most two characters per target base plus the last count
-	static const int TCAP[3] = {512, 2048, 0};
+	static const int TCAP[4] = {512, 2048, 0, 0};
 	size_t md_bound = 64;
 	const DevScoring &sc = L.sc;
 	for (int64_t i = 0; i < n; ++i) {
@@ -1068,14 +1080,15 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 		long long wk = std::max<long long>(std::min<long long>((max_gap + dl + 1) >> 1, wtop), dl + 3);
 		long long band = std::min<long long>(j.qlen, 2 * wk + 1);
 		int c = 0;
-		while (c < 3 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
-		if (c == 3) { fprintf(stderr, "[bsx-hip] global job %lld: query %d / band %lld beyond kernel limits\n", (long long)i, j.qlen, band); return BSX_E_ARG; }
+		while (c < 4 && (j.qlen > QCAP[c] || band > BAND[c])) ++c;
+		if (c == 4) { fprintf(stderr, "[bsx-hip] global job %lld: a band of %lld columns (query %d, target %d) is beyond the kernel's 2048\n", (long long)i, band, j.qlen, j.tlen); return BSX_E_ARG; }
+		if (c == 3) hbm_qmax = std::max(hbm_qmax, j.qlen);
 		order[c].push_back((int)i);
 		if (j.want_cigar) zmax[c] = std::max(zmax[c], (size_t)band * (size_t)j.tlen + 64);
 	}
-	int rc, blocks[3];
+	int rc, blocks[4];
 	size_t ztot = 0;
-	for (int c = 0; c < 3; ++c) {
+	for (int c = 0; c < 4; ++c) {
 		const long long m = (long long)order[c].size();
 		blocks[c] = (int)std::min<long long>((m + WPB[c] - 1) / WPB[c], (long long)d->n_cu * 8);
 		zmax[c] = (zmax[c] + 255) & ~(size_t)255;
@@ -1083,12 +1096,15 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 		// waves rather than tens of GB
 		const size_t zbudget = (size_t)4 << 30;
 		if ((size_t)blocks[c] * WPB[c] * zmax[c] > zbudget) blocks[c] = (int)std::max<size_t>(1, zbudget / (WPB[c] * zmax[c]));
+		if (c == 3 && hbm_qmax) blocks[c] = (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks[c], ((size_t)2 << 30) / global_hbm_row_bytes(hbm_qmax)));
 		ztot = std::max(ztot, (size_t)blocks[c] * WPB[c] * zmax[c]);
 	}
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_glb_job_t))) != BSX_OK) return rc;
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_glb_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	if ((rc = L.scratch.reserve(ztot + 256)) != BSX_OK) return rc;
+	// traceback slabs first, then (queries beyond LDS) the DP rows of the HBM class
+	const size_t rows_off = (ztot + 256 + 255) & ~(size_t)255, rows_bytes = hbm_qmax ? (size_t)blocks[3] * global_hbm_row_bytes(hbm_qmax) : 0;
+	if ((rc = L.scratch.reserve(rows_off + rows_bytes)) != BSX_OK) return rc;
 	if ((rc = L.pool.reserve(cigar_pool_len * 4 + 64)) != BSX_OK) return rc;
 	unsigned long long *md_cursor = dev_counters(L) + 60;
 	if (tags) {
@@ -1099,13 +1115,18 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	}
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_glb_job_t));
 	size_t off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
 		H2D(L.st_hi, (int*)L.aux.p + off, order[c].data(), order[c].size() * 4);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
+		if (c == 3)
+			launch_global_hbm(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+			                  (long long)order[c].size(), (bsx_glb_res_t*)L.res.p, (uint32_t*)L.pool.p, (uint8_t*)L.scratch.p, zmax[c], hbm_qmax, blocks[c],
+			                  tags ? (bsx_glb_tag_t*)L.tags.p : nullptr, (char*)L.mdpool.p, (unsigned long long)md_bound, md_cursor, (char*)L.scratch.p + rows_off);
+		else
 		launch_global(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_glb_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_glb_res_t*)L.res.p, (uint32_t*)L.pool.p, (uint8_t*)L.scratch.p, zmax[c],
 		              QCAP[c], NCS[c], blocks[c], WPB[c], tags ? (bsx_glb_tag_t*)L.tags.p : nullptr, (char*)L.mdpool.p, (unsigned long long)md_bound, md_cursor, tags ? TCAP[c] : 0);

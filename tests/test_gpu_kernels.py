@@ -355,3 +355,90 @@ def test_global_matches_oracle(small_index, port, device):
         n_checked += 1
         n_conv += zc
     assert n_checked > 250 and n_conv > 1000 and n_del > 5
+
+
+def test_oversize_jobs_take_the_large_classes(small_index, port, device):
+    """Jobs beyond the LDS-resident classes do not fail their batch: extension and global alignment of queries longer than
+    16384 bases keep their DP rows in HBM, local alignment of queries up to 3072 bases runs with 48 register slots per lane.
+    Same results as the CPU restatement, mixed into batches with ordinary jobs."""
+    from biscuit_amd.api import EXT_DT, SW_DT, GLB_DT
+    opt = default_opt()
+    rng = np.random.default_rng(77)
+    contigs = _contigs(small_index)
+    big = [s for _, s in simdata.make_single(contigs, 3, 20000, 71, sub=0.02, indel=0.002)]
+    mid = [s for _, s in simdata.make_single(contigs, 6, 2500, 72)]
+    seqs = big + mid + _reads(small_index, n_pairs=20, read_len=150, seed=73)
+    buf, offs = simdata.read_buffer(seqs)
+    for be in (port, device):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    loci = {r: (par, pos, qb) for (r, par, pos, qb) in _locus_of(small_index, port, opt, seqs, offs)}
+    l_pac = small_index.l_pac
+    # ---- extension: the whole long read to the right of its first seed, plus ordinary jobs around it
+    jobs = list(_rand_ext_jobs(small_index, seqs[len(big) + len(mid):], offs[len(big) + len(mid):], rng, 50))
+    n_big = 0
+    for r in range(len(big)):
+        if r not in loci:
+            continue
+        par, pos, qb = loci[r]
+        L = len(seqs[r])
+        hi = l_pac if pos < l_pac else 2 * l_pac
+        q0 = qb + 19
+        if pos + 19 + (L - q0) + 300 >= hi:
+            continue
+        j = np.zeros(1, dtype=EXT_DT)[0]
+        j["tpos"] = pos + 19; j["qoff"] = offs[r] + q0; j["qlen"] = L - q0; j["tlen"] = L - q0 + 200
+        j["h0"] = 19; j["w"] = 100; j["end_bonus"] = 5; j["qdir"] = 1; j["tdir"] = 1; j["parent"] = par
+        assert j["qlen"] > 16384
+        jobs.append(j)
+        n_big += 1
+    assert n_big >= 1
+    jobs = np.array(jobs, dtype=EXT_DT)
+    pr, dr = port.extend(jobs), device.extend(jobs)
+    assert (pr == dr).all(), (jobs[pr != dr][:2], pr[pr != dr][:2], dr[pr != dr][:2])
+    assert (pr["score"][-n_big:] > 5000).all()
+    # ---- global alignment with traceback and tags of the long reads against their loci
+    gj, cig_off = [], 0
+    for r in list(range(len(big))) + list(range(len(big) + len(mid), len(big) + len(mid) + 10)):
+        if r not in loci:
+            continue
+        par, pos, qb = loci[r]
+        L = len(seqs[r])
+        lo, hi = (0, l_pac) if pos < l_pac else (l_pac, 2 * l_pac)
+        b, e = max(pos - qb, lo), min(pos - qb + L + 3, hi)
+        rev = b >= l_pac
+        cap = 4096
+        gj.append((e - 1 if rev else b, offs[r] + (L - 1 if rev else 0), L, e - b, 100, 400, L, 3, cig_off, cap, -1 if rev else 1, -1 if rev else 1, par, 1))
+        cig_off += cap
+    gj = np.array(gj, dtype=GLB_DT)
+    assert (gj["qlen"] > 16384).sum() >= 1
+    pr, pp = port.global_(gj, cig_off)
+    tr, tp, tags, mds = device.global_tags(gj, cig_off)
+    assert (pr == tr).all(), (pr[pr != tr][:2], tr[pr != tr][:2])
+    for k in range(len(gj)):
+        n, o = int(pr[k]["n_cigar"]), int(gj[k]["cigar_off"])
+        assert n > 0 and (pp[o:o + n] == tp[o:o + n]).all(), k
+    dr, dp = device.global_(gj, cig_off)
+    assert (dr == pr).all()
+    # ---- local alignment: queries of 2500 bases (mate rescue of long paired reads)
+    sj = []
+    for r in range(len(big), len(big) + len(mid)):
+        if r not in loci:
+            continue
+        par, pos, qb = loci[r]
+        L = len(seqs[r])
+        lo, hi = (0, l_pac) if pos < l_pac else (l_pac, 2 * l_pac)
+        tpos = max(pos - qb - 300, lo)
+        tlen = min(L + 700, hi - tpos)
+        sj.append((tpos, offs[r], L, tlen, 0x80000 | 0x40000 | 19, 1, 1, 0, par))
+    for r in range(len(big) + len(mid), len(big) + len(mid) + 10):
+        if r in loci:
+            par, pos, qb = loci[r]
+            lo, hi = (0, l_pac) if pos < l_pac else (l_pac, 2 * l_pac)
+            tpos = max(pos - qb - 200, lo)
+            sj.append((tpos, offs[r], len(seqs[r]), min(600, hi - tpos), 0x80000 | 0x40000 | 0x10000 | 19, 1, 1, 0, par))
+    sj = np.array(sj, dtype=SW_DT)
+    assert (sj["qlen"] > 1024).sum() >= 3
+    pr, dr = port.sw(sj), device.sw(sj)
+    assert (pr == dr).all(), (sj[pr != dr][:2], pr[pr != dr][:2], dr[pr != dr][:2])
+    assert (pr["score"][sj["qlen"] > 1024] > 1000).all()
