@@ -528,8 +528,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)l);
 			if (min_l > 0.05f * l) continue;
 			ft[l] = (int32_t)(opt->a * min_l + .499);
-			any_flt = true;
 		}
+		for (int64_t i = 0; i < n && !any_flt; ++i) any_flt = tasks[i].len >= 0 && ft[tasks[i].len] != INT32_MIN;   // (for a read of this chunk, not for some length below its longest)
 		if ((rc = L.fltab.reserve(ft.size() * 4)) != BSX_OK) return rc;
 		H2D(L.st, L.fltab.p, ft.data(), ft.size() * 4);
 		R.flt_tab = (const int32_t*)L.fltab.p; R.flt_len = max_len;
@@ -795,8 +795,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		unsigned int hc[12]; unsigned long long hu[12];
 		D2H(L.st, hc, c32, sizeof(hc));
 		D2H(L.st, hu, ctr, sizeof(hu));
-		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, left tier 2: %u\n",
-		        (long long)n, hu[4], hu[11], hc[1], hc[10], hc[3]);
+		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, left tier 2: %u | every tier exports: %d\n",
+		        (long long)n, hu[4], hu[11], hc[1], hc[10], hc[3], export_all ? 1 : 0);
 		unsigned long long sp[8];
 		D2H(L.st, sp, ctr + 48, sizeof(sp));
 		HIPCHK(hipMemsetAsync(ctr + 48, 0, sizeof(sp), L.st));

@@ -18,6 +18,42 @@ static int reg_score_lt(const void *a_, const void *b_)                         
 	return a->score > b->score || (a->score == b->score && (a->rb < b->rb || (a->rb == b->rb && a->qb < b->qb)));
 }
 
+/* The two sorts of mem_sort_deduplicate on small proxies (the key and the record's index) instead of the 150-byte records: the same
+ * introsort over the same keys in the same starting order takes the same decisions, so the records end in the same order -- ties
+ * included -- and are moved once instead of three copies per swap.  (Mate rescue re-sorts a read's list after every hit it adds: on a
+ * repeat-rich genome that was most of the host's time.) */
+typedef struct { int64_t re; int idx; } prox_re_t;
+typedef struct { int64_t rb; int score, qb, idx; } prox_sc_t;
+static int prox_re_lt(const void *a, const void *b) { return ((const prox_re_t*)a)->re < ((const prox_re_t*)b)->re; }
+static int prox_sc_lt(const void *a_, const void *b_)
+{
+	const prox_sc_t *a = (const prox_sc_t*)a_, *b = (const prox_sc_t*)b_;
+	return a->score > b->score || (a->score == b->score && (a->rb < b->rb || (a->rb == b->rb && a->qb < b->qb)));
+}
+static void regs_sort(reg_v *regs, int by_score)
+{
+	size_t n = regs->n, i;
+	char stackbuf[4096];
+	const size_t w = by_score ? sizeof(prox_sc_t) : sizeof(prox_re_t);
+	char *px;
+	reg_t *tmp;
+	int moved = 0;
+	if (n < 2) return;
+	if (n < 4) { bsx_introsort(regs->a, n, sizeof(reg_t), by_score ? reg_score_lt : reg_re_lt); return; }
+	px = n * w <= sizeof(stackbuf) ? stackbuf : (char*)malloc(n * w);
+	if (by_score) { prox_sc_t *q = (prox_sc_t*)px; for (i = 0; i < n; ++i) { q[i].rb = regs->a[i].rb; q[i].score = regs->a[i].score; q[i].qb = regs->a[i].qb; q[i].idx = (int)i; } }
+	else { prox_re_t *q = (prox_re_t*)px; for (i = 0; i < n; ++i) { q[i].re = regs->a[i].re; q[i].idx = (int)i; } }
+	bsx_introsort(px, n, w, by_score ? prox_sc_lt : prox_re_lt);
+	for (i = 0; i < n; ++i) if ((by_score ? ((prox_sc_t*)px)[i].idx : ((prox_re_t*)px)[i].idx) != (int)i) { moved = 1; break; }
+	if (moved) {
+		tmp = (reg_t*)malloc(sizeof(reg_t) * n);
+		for (i = 0; i < n; ++i) tmp[i] = regs->a[by_score ? ((prox_sc_t*)px)[i].idx : ((prox_re_t*)px)[i].idx];
+		memcpy(regs->a, tmp, sizeof(reg_t) * n);
+		free(tmp);
+	}
+	if (px != stackbuf) free(px);
+}
+
 /* mem_test_reg_concatenation, mem_alnreg.c:63-108 */
 static int try_concat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const reg_t *a, const reg_t *b, int *_w,
                       bsx_glb_score_fn score_fn, void *ud, int *missing)
@@ -49,7 +85,7 @@ void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can
 {
 	int i, m;
 	if (regs->n <= 1) return;
-	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_re_lt);   /* by END, not start */
+	regs_sort(regs, 0);   /* by END, not start (ks_introsort(mem_ars2)) */
 	for (i = 0; (size_t)i < regs->n; ++i) regs->a[i].n_comp = 1;
 	for (i = 1; (size_t)i < regs->n; ++i) {
 		reg_t *p = &regs->a[i];
@@ -81,7 +117,7 @@ void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can
 	for (i = 0, m = 0; (size_t)i < regs->n; ++i)
 		if (regs->a[i].qe > regs->a[i].qb) { if (m != i) regs->a[m++] = regs->a[i]; else ++m; }
 	regs->n = m;
-	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_score_lt);
+	regs_sort(regs, 1);
 	for (i = 1; (size_t)i < regs->n; ++i)
 		if (regs->a[i].score == regs->a[i - 1].score && regs->a[i].rb == regs->a[i - 1].rb && regs->a[i].qb == regs->a[i - 1].qb)
 			regs->a[i].qe = regs->a[i].qb;
