@@ -75,6 +75,11 @@ void bsx_chain_ref_span(const bsx_opt_t *opt, int l_query, int64_t l_pac, const 
 typedef int (*bsx_glb_score_fn)(void *ud, const reg_t *a, const reg_t *b, int w, int *score); /* returns 0 ok, 1 = not available yet */
 void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can_merge, reg_v *regs,
                          bsx_glb_score_fn score_fn, void *ud, int *missing);   /* mem_sort_deduplicate, mem_alnreg.c:112-202 */
+/* a rescued hit into the mate's list by score, then mem_sort_deduplicate without merging (mem_alnreg.c:478-488), hit after hit onto the
+ * same list: st (zeroed before the first hit, freed after the last) carries the list's order by end between the calls */
+typedef struct { int valid, m; int *ord; } bsx_regs_inc_t;
+void bsx_regs_insert_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, reg_v *regs, const reg_t *b, bsx_regs_inc_t *st, bsx_glb_score_fn no_score_fn);
+void bsx_regs_inc_free(bsx_regs_inc_t *st);
 void bsx_mark_primary(const bsx_opt_t *opt, reg_v *regs, int64_t id);          /* mem_mark_primary_se, mem_alnreg.c:290-380 */
 bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, const reg_v *regs); /* mem_pestat, mem_pair.c:60-144 */
 void bsx_pair(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const bsx_pestat_t *pes, reg_v pair[2], int id,

@@ -80,6 +80,32 @@ BSX_API int bsx_hook_regs_sort_dedup(const bsx_opt_t *opt, const bsx_index_t *id
 	return m;
 }
 
+/* mate rescue's "add the hit by score, then mem_sort_deduplicate" (mem_alnreg.c:478-488) for hits a[n0..n) added one after the other to the
+ * list a[0..n0) as it stands (bsx_regs_insert_dedup: the incremental form mate rescue uses); keep[] = the ids left, in their final order */
+BSX_API int bsx_hook_regs_insert_seq(const bsx_opt_t *opt, const bsx_index_t *idx, const bsx_region_t *a, int n0, int n, int *keep)
+{
+	reg_v v;
+	bsx_regs_inc_t st;
+	int k, m;
+	memset(&st, 0, sizeof(st));
+	v.n = (size_t)n0; v.m = (size_t)n0 + 1; v.n_pri = 0;
+	v.a = (reg_t*)calloc(v.m, sizeof(reg_t));
+	for (k = 0; k < n; ++k) {
+		reg_t r;
+		const bsx_region_t *d = &a[k];
+		memset(&r, 0, sizeof(r));
+		r.rb = d->rb; r.re = d->re; r.qb = d->qb; r.qe = d->qe; r.rid = d->rid; r.score = d->score; r.truesc = d->truesc;
+		r.hash = (uint64_t)k;
+		if (k < n0) v.a[k] = r;
+		else bsx_regs_insert_dedup(opt, &idx->ref, &v, &r, &st, hook_no_score);
+	}
+	m = (int)v.n;
+	for (k = 0; k < m; ++k) keep[k] = (int)v.a[k].hash;
+	bsx_regs_inc_free(&st);
+	free(v.a);
+	return m;
+}
+
 /* ---- the per-read / per-pair functions of the back half, callable on plain arrays (tests/test_oracle_backhalf.py compares them with
  * oracle/backhalf.py, an independent restatement of the reference's functions) */
 static void hook_vec(const bsx_hook_reg_t *a, int n, int n_pri, reg_v *v)

@@ -494,10 +494,12 @@ typedef struct {
 	int pending;
 } msw_pair_t;
 
+static int g_msw_prof = 0;                       /* $BSX_PHASES: where mate rescue's host time goes */
+static int64_t g_msw_ns = 0, g_msw_calls = 0, g_msw_elems = 0, g_msw_replay_ns = 0;
 static int no_glb(void *ud, const reg_t *a, const reg_t *b, int w, int *score) { (void)ud; (void)a; (void)b; (void)w; *score = 0; return 0; }
 
 /* one mem_alnreg_matesw_core; returns 1 if its SW result was needed but is not available yet */
-static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const reg_t *reg, int mate_read, reg_v *mregs, int apply)
+static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const reg_t *reg, int mate_read, reg_v *mregs, int apply, bsx_regs_inc_t *inc)
 {
 	const bsx_opt_t *opt = C->opt;
 	const bsx_refmeta_t *ref = &C->idx->ref;
@@ -542,12 +544,14 @@ static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const re
 		b.seedcov = (int)((d1 < d2 ? d1 : d2) >> 1);
 		b.bss = reg->bss; b.parent = (uint8_t)(1 - parent);
 		/* keep the mate list ordered by score, then de-duplicate without merging (mem_alnreg.c:478-488) */
-		if (mregs->n == mregs->m) { size_t m2 = mregs->m ? mregs->m << 1 : 4; mregs->a = (reg_t*)bsx_crealloc(mregs->a, sizeof(reg_t) * mregs->n, sizeof(reg_t) * m2); mregs->m = m2; }
-		++mregs->n;
-		for (ins = 0; (size_t)ins < mregs->n - 1; ++ins) if (mregs->a[ins].score < b.score) break;
-		for (pos = (int)mregs->n - 1; pos > ins; --pos) mregs->a[pos] = mregs->a[pos - 1];
-		mregs->a[ins] = b;
-		bsx_regs_sort_dedup(opt, ref, 0, mregs, no_glb, 0, &missing);
+		(void)missing; (void)ins; (void)pos;
+		if (g_msw_prof) {
+			double t0 = now_s();
+			size_t n0 = mregs->n;
+			bsx_regs_insert_dedup(opt, ref, mregs, &b, inc, no_glb);
+			__atomic_fetch_add(&g_msw_ns, (int64_t)((now_s() - t0) * 1e9), __ATOMIC_RELAXED);
+			__atomic_fetch_add(&g_msw_calls, 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_msw_elems, (int64_t)n0, __ATOMIC_RELAXED);
+		} else bsx_regs_insert_dedup(opt, ref, mregs, &b, inc, no_glb);
 	}
 	return 0;
 }
@@ -559,8 +563,10 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 	reg_v *pair = &C->regs[pi << 1];
 	reg_v good[2];
 	reg_t small[2][8];
+	bsx_regs_inc_t inc[2];   /* the order by end of each mate list between the hits added to it */
 	int i, missing = 0;
 	size_t j;
+	memset(inc, 0, sizeof(inc));
 	/* The first pass only collects SW requests: a request returns before anything is applied, so the lists are still
 	 * the originals.  They are saved when the first results are about to be applied, and every later pass (a rescued
 	 * hit can change what the following candidates see) restarts from that copy. */
@@ -585,7 +591,8 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 	for (i = 0; i < 2; ++i)
 		for (j = 0; j < good[i].n && (int)j < opt->max_matesw; ++j)
 			/* once a result is missing, keep walking (without applying) only to collect further requests */
-			missing |= matesw_core(C, M, pi, i, (int)j, &good[i].a[j], (pi << 1) | !i, &pair[!i], !missing);
+			missing |= matesw_core(C, M, pi, i, (int)j, &good[i].a[j], (pi << 1) | !i, &pair[!i], !missing, &inc[!i]);
+	bsx_regs_inc_free(&inc[0]); bsx_regs_inc_free(&inc[1]);
 	if (good[0].a != small[0]) free(good[0].a);
 	if (good[1].a != small[1]) free(good[1].a);
 	return missing;
@@ -596,7 +603,11 @@ static void msw_worker(void *data, long pi, int tid)
 {
 	msw_par_t *P = (msw_par_t*)data;
 	(void)tid;
-	if (P->M[pi].pending) P->M[pi].pending = matesw_replay(P->C, &P->M[pi], (int)pi);
+	if (P->M[pi].pending) {
+		double t0 = g_msw_prof ? now_s() : 0;
+		P->M[pi].pending = matesw_replay(P->C, &P->M[pi], (int)pi);
+		if (g_msw_prof) __atomic_fetch_add(&g_msw_replay_ns, (int64_t)((now_s() - t0) * 1e9), __ATOMIC_RELAXED);
+	}
 }
 static void msw_init_worker(void *data, long pi, int tid)
 {
@@ -639,6 +650,7 @@ static int mate_rescue(chunk_t *C)
 	double t_batch = 0, t_all = now_s();
 	msw_pair_t *M = (msw_pair_t*)calloc(np ? np : 1, sizeof(msw_pair_t));
 	msw_par_t P;
+	g_msw_prof = getenv("BSX_PHASES") != 0;
 	P.C = C; P.M = M;
 	P.cnt = (int*)malloc(sizeof(int) * ((size_t)np + 1)); P.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)np + 1));
 	bsx_parallel_for(C->nt, msw_init_worker, &P, np);
@@ -660,7 +672,11 @@ static int mate_rescue(chunk_t *C)
 		if (rc != BSX_OK) break;
 	}
 	bsx_parallel_for(C->nt, msw_free_worker, &P, np);
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host\n", round, t_batch, now_s() - t_all - t_batch);
+	if (getenv("BSX_PHASES")) {
+		fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host | thread-seconds: %.2f in the per-pair passes, %.2f of them in %ld list sorts (%.1f regions each)\n",
+		        round, t_batch, now_s() - t_all - t_batch, g_msw_replay_ns * 1e-9, g_msw_ns * 1e-9, (long)g_msw_calls, g_msw_calls ? (double)g_msw_elems / g_msw_calls : 0.0);
+		g_msw_replay_ns = g_msw_ns = g_msw_calls = g_msw_elems = 0;
+	}
 	free(M); free(P.cnt); free(P.off);
 	return rc;
 }

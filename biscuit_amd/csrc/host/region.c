@@ -126,6 +126,88 @@ void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can
 	regs->n = m;
 }
 
+/* mem_alnreg_matesw_core's "put the rescued hit into the mate's list by score, then mem_sort_deduplicate" (mem_alnreg.c:478-488), one
+ * hit after another onto the same list.  A read inside a repeat family gets a hundred such hits onto a list of two hundred regions,
+ * and sorting the list twice per hit was most of the host's time on a repeat-rich genome.  Between two hits nothing but the new
+ * region is new: the list is already in the second sort's order and free of redundant pairs.  So the order by end is kept as an
+ * index array beside the list, the new region is put into both orders by search, and the redundancy scan -- the reference's loop,
+ * line by line, over the index array -- is all that runs.  That is the reference's result whenever the two sorts have no ties to
+ * break (equal ends, or equal (score, start, query start) with the new region): with ties the outcome depends on klib's introsort
+ * and on the order it starts from, so those calls go through bsx_regs_sort_dedup on the list as the reference would hold it. */
+void bsx_regs_inc_free(bsx_regs_inc_t *st) { free(st->ord); st->ord = 0; st->valid = st->m = 0; }
+static int inc_re_cmp(const void *a, const void *b) { const prox_re_t *x = (const prox_re_t*)a, *y = (const prox_re_t*)b; return x->re < y->re ? -1 : x->re > y->re; }
+static void inc_rebuild(reg_v *regs, bsx_regs_inc_t *st)
+{
+	size_t n = regs->n, i;
+	prox_re_t *px = (prox_re_t*)malloc(sizeof(prox_re_t) * (n ? n : 1));
+	if (st->m < (int)n + 8) { st->m = (int)n * 2 + 16; st->ord = (int*)realloc(st->ord, sizeof(int) * (size_t)st->m); }
+	for (i = 0; i < n; ++i) { px[i].re = regs->a[i].re; px[i].idx = (int)i; }
+	qsort(px, n, sizeof(prox_re_t), inc_re_cmp);
+	st->valid = 1;
+	for (i = 0; i < n; ++i) { st->ord[i] = px[i].idx; if (i && px[i].re == px[i - 1].re) st->valid = 0; }
+	/* (the list comes out of mem_sort_deduplicate: in the second sort's order, identical (score, rb, qb) already removed) */
+	free(px);
+}
+void bsx_regs_insert_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, reg_v *regs, const reg_t *b, bsx_regs_inc_t *st,
+                           bsx_glb_score_fn no_score_fn)
+{
+	int ins, pos, i, n, lo, hi, at, m, any_dead = 0, missing = 0;
+	if (regs->n == regs->m) { size_t m2 = regs->m ? regs->m << 1 : 4; regs->a = (reg_t*)bsx_crealloc(regs->a, sizeof(reg_t) * regs->n, sizeof(reg_t) * m2); regs->m = m2; }
+	n = (int)regs->n;
+	for (ins = 0; ins < n; ++ins) if (regs->a[ins].score < b->score) break;   /* where the reference puts it: ahead of the first lower score */
+	if (st->valid && n >= 1) {
+		/* ties?  equal end with a region of the list; equal (score, rb, qb) among the regions of b's score (they start at ins - run) */
+		lo = 0; hi = n;
+		while (lo < hi) { const int mid = (lo + hi) >> 1; if (regs->a[st->ord[mid]].re < b->re) lo = mid + 1; else hi = mid; }
+		at = lo;
+		if (at < n && regs->a[st->ord[at]].re == b->re) st->valid = 0;
+		for (i = ins - 1; st->valid && i >= 0 && regs->a[i].score == b->score; --i)
+			if (regs->a[i].rb == b->rb && regs->a[i].qb == b->qb) st->valid = 0;
+	} else st->valid = 0;
+	if (!st->valid) { /* the reference's own sequence on the reference's own arrangement, then the orders are set up afresh */
+		for (pos = n; pos > ins; --pos) regs->a[pos] = regs->a[pos - 1];
+		regs->a[ins] = *b; ++regs->n;
+		bsx_regs_sort_dedup(opt, ref, 0, regs, no_score_fn, 0, &missing);
+		inc_rebuild(regs, st);
+		return;
+	}
+	/* b's place in the second sort's order: among its own score by (rb, qb) */
+	for (pos = ins; pos > 0 && regs->a[pos - 1].score == b->score && (b->rb < regs->a[pos - 1].rb || (b->rb == regs->a[pos - 1].rb && b->qb < regs->a[pos - 1].qb)); --pos);
+	for (i = n; i > pos; --i) regs->a[i] = regs->a[i - 1];
+	regs->a[pos] = *b; ++regs->n; ++n;
+	if (st->m < n + 8) { st->m = n * 2 + 16; st->ord = (int*)realloc(st->ord, sizeof(int) * (size_t)st->m); }
+	for (i = 0; i < n - 1; ++i) if (st->ord[i] >= pos) ++st->ord[i];
+	memmove(st->ord + at + 1, st->ord + at, sizeof(int) * (size_t)(n - 1 - at));
+	st->ord[at] = pos;
+	/* the redundancy scan of mem_sort_deduplicate (mem_alnreg.c:131-160, no merging here) over the order by end */
+	for (i = 0; i < n; ++i) regs->a[i].n_comp = 1;
+	for (i = 1; i < n; ++i) {
+		reg_t *p = &regs->a[st->ord[i]];
+		int j;
+		for (j = i - 1; j >= 0 && p->rid == regs->a[st->ord[j]].rid && p->rb < regs->a[st->ord[j]].re + opt->max_chain_gap; --j) {
+			reg_t *q = &regs->a[st->ord[j]];
+			int64_t or_, oq, mr, mq;
+			if (q->qe == q->qb) continue;
+			or_ = q->re - p->rb;
+			oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+			mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+			mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+			if (or_ > opt->mask_level_redun * mr && oq > opt->mask_level_redun * mq) {
+				any_dead = 1;
+				if (p->score < q->score) { p->qe = p->qb; break; }
+				else q->qe = q->qb;
+			}
+		}
+	}
+	if (any_dead) { /* drop them from both orders */
+		int *nw = (int*)malloc(sizeof(int) * (size_t)n);
+		for (i = 0, m = 0; i < n; ++i) { if (regs->a[i].qe > regs->a[i].qb) { nw[i] = m; if (m != i) regs->a[m] = regs->a[i]; ++m; } else nw[i] = -1; }
+		regs->n = (size_t)m;
+		for (i = 0, m = 0; i < n; ++i) if (nw[st->ord[i]] >= 0) st->ord[m++] = nw[st->ord[i]];
+		free(nw);
+	}
+}
+
 /* ------------------------------------------------------------------ primary marking */
 static int reg_hash_lt(const void *a_, const void *b_)   /* alnreg_hlt: score desc, is_alt, hash */
 {

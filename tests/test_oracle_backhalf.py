@@ -241,6 +241,85 @@ def test_sort_dedup(small):
     assert n_cmp > 4000 and n_drop > 2000 and n_tie > 2000 and n_concat > 20, (n_cmp, n_drop, n_tie, n_concat)
 
 
+def test_rescued_hits_added_one_by_one(small):
+    """Mate rescue adds hit after hit to a list, each followed by mem_sort_deduplicate (mem_alnreg.c:478-488).  The product keeps the list's
+    order by end between the hits and runs only the redundancy scan (region.c, bsx_regs_insert_dedup), falling back to the two sorts
+    when one of them would have a tie to break.  Against the restatement's plain sequence with the real klib introsort, on lists full of
+    near copies: shared ends, shared starts, equal scores, identical hits, hits that knock out several regions and then lose themselves."""
+    from oracle_lib import ref_lib
+    R = ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref is not built")
+    idx, _, _ = small
+    L = B.lib()
+    opt = default_opt()
+    od = dict(opt_dict(opt), mask_level_redun=opt.mask_level_redun, max_chain_gap=opt.max_chain_gap, w=opt.w)
+    l_pac = idx.l_pac
+    R.ref_introsort_kv.argtypes = [C.c_int64, C.c_void_p]
+
+    def klib_order(keys):
+        kv = np.zeros((len(keys), 2), dtype=np.int64)
+        kv[:, 0] = keys
+        kv[:, 1] = np.arange(len(keys))
+        if len(keys):
+            R.ref_introsort_kv(len(keys), kv.ctypes.data_as(C.c_void_p))
+        return [int(x) for x in kv[:, 1]]
+    L.bsx_hook_regs_insert_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.bsx_hook_regs_insert_seq.restype = C.c_int
+    dt = np.dtype(B.Region)
+    rng = np.random.default_rng(29)
+    n_drop = n_tie = n_multi = 0
+    for trial in range(1500):
+        tie_rate = float(rng.choice([0.0, 0.0, 0.15, 0.4]))       # lists without ties take the incremental path all the way
+        n0, nh = int(rng.integers(0, 40)), int(rng.integers(1, 30))
+        base = int(rng.integers(1000, l_pac - 8000)) + (l_pac if rng.random() < 0.5 else 0)
+        regs = []
+        for k in range(n0 + nh):
+            if regs and rng.random() < 0.45:
+                r = dict(regs[int(rng.integers(0, len(regs)))])
+                u = rng.random()
+                if u < tie_rate:
+                    pass                                            # identical
+                elif u < 0.5:
+                    d = int(rng.integers(1, 6)); r["rb"] -= d; r["qb"] = max(0, r["qb"] - d); r["score"] += int(rng.integers(-3, 6))
+                    if rng.random() > tie_rate:
+                        r["re"] += int(rng.integers(1, 4)) * (1 if rng.random() < 0.5 else -1)
+                else:
+                    d = int(rng.integers(1, 6)); r["re"] += d; r["qe"] += d; r["score"] += int(rng.integers(-3, 6))
+            else:
+                qb = int(rng.integers(0, 100))
+                qe = qb + int(rng.integers(25, 151 - qb))
+                rb = base + int(rng.integers(-300, 2500 if tie_rate else 6000)) if rng.random() < 0.85 else int(rng.integers(0, 2 * l_pac - 400))
+                r = {"rb": rb, "re": rb + (qe - qb) + int(rng.integers(-2, 3)), "qb": qb, "qe": qe, "rid": 0 if rng.random() < 0.9 else 1,
+                     "score": int(rng.integers(25, 150))}
+                if tie_rate == 0:
+                    while any(x["re"] == r["re"] for x in regs):
+                        r["re"] += 1; r["rb"] += 1
+            if tie_rate == 0 and any(x["re"] == r["re"] for x in regs):
+                r["re"] += 7; r["qe"] += 7
+                while any(x["re"] == r["re"] for x in regs):
+                    r["re"] += 1
+            regs.append(r)
+        # the restatement: the starting list as it stands, then per hit: ahead of the first lower score, sort + de-duplicate
+        cur = list(range(n0))
+        for k in range(n0, n0 + nh):
+            ins = next((i for i, c in enumerate(cur) if regs[c]["score"] < regs[k]["score"]), len(cur))
+            arr = cur[:ins] + [k] + cur[ins:]
+            kept = backhalf.sort_dedup(od, l_pac, [dict(regs[c]) for c in arr], klib_order, can_merge=False)
+            n_drop += len(kept) < len(arr)
+            n_multi += len(kept) < len(arr) - 1
+            cur = [arr[i] for i in kept]
+        n_tie += len(set(r["re"] for r in regs)) < len(regs)
+        arr = np.zeros(n0 + nh, dtype=dt)
+        for k, r in enumerate(regs):
+            for f in ("rb", "re", "qb", "qe", "rid", "score"):
+                arr[k][f] = r[f]
+        keep = np.zeros(n0 + nh, dtype=np.int32)
+        m = L.bsx_hook_regs_insert_seq(C.byref(opt), idx.h, arr.ctypes.data_as(C.c_void_p), n0, n0 + nh, keep.ctypes.data_as(C.c_void_p))
+        assert list(keep[:m]) == cur, (trial, list(keep[:m]), cur)
+    assert n_drop > 2000 and n_multi > 100 and 300 < n_tie < 1100, (n_drop, n_multi, n_tie)
+
+
 def test_mate_rescue(small):
     """mem_alnreg_matesw: the pipeline's plan / K5 batch / replay form of it (pipeline.c, K5 by the CPU restatement of ksw_align2) against
     the restatement's plain loop, whose Smith-Waterman is the REAL ksw_align2 and whose sorts are the real klib introsort (oracle/_ref)."""
