@@ -6,7 +6,8 @@
 
 #include "wave.hpp"
 
-#define SEED_LDS_WORDS 24   // 192 bases per lane in LDS: 6 KB per wave
+#define SEED_FORM_DEFAULT 0   // measured (tools/seed_forms.sh, 3.1 Gbp): 0 = 209 ms per chunk, 1 = 221 ms (the second half of a trip with more than 64 requests waits for the first), 2 = 363 ms (15 VGPRs spilled)
+// the read in LDS: 24 words = 192 bases per lane, 6 KB per wave
 // One wave per workgroup: a workgroup gives its registers and LDS back when its LAST wave ends, and a wave ends when the longest of its 64
 // strand searches does -- with four waves that was the longest of 256 while the slots of the three finished waves stayed taken
 #ifndef SEED_WPB
@@ -36,6 +37,7 @@ __device__ __forceinline__ DevBlock seed_take(const SeedXchg &X, int req)
 }
 
 // bwt_extend (lib/aln/bwt.c:278-293) of L.ext_in for the lanes with `need`; every lane of the wave takes part in the loads.
+template <bool DIRECT>
 __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &ix, const SeedLane &L, SeedXchg &X, uint32_t &n_slow, uint32_t &n_fast)
 {
 	const int lane = (int)(threadIdx.x & 63), piece = lane & 3, sub = lane >> 2;
@@ -60,41 +62,51 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 	if (r1) X.addr[i1] = (unsigned long long)(bwt + (((lv ? la : 0) >> 7) << 4));
 	WAVE_SYNC();
 	const int rounds = (n + 15) >> 4;
-	uint4 V[8];
+	uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
+	// block -> the four cumulative counts at position pos_ (bwt_occ4): counted as soon as a block is taken, so that only one is held in registers
+#define SEED_COUNT(B_, pos_, valid_, t_) do { uint32_t a_, c_, g_, t4_; dev_block_count4(B_, (int)((pos_) & 127), a_, c_, g_, t4_); \
+		t_[0] = (valid_) ? ((uint64_t)B_.v0.y << 32 | B_.v0.x) + a_ : 0; t_[1] = (valid_) ? ((uint64_t)B_.v0.w << 32 | B_.v0.z) + c_ : 0; \
+		t_[2] = (valid_) ? ((uint64_t)B_.v1.y << 32 | B_.v1.x) + g_ : 0; t_[3] = (valid_) ? ((uint64_t)B_.v1.w << 32 | B_.v1.z) + t4_ : 0; } while (0)
+	// DIRECT: the pieces go from memory straight into the exchange slots (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, masked
+	// lanes leave theirs alone -- tools/ubench/lds_direct.hip): lane l of round r asks for piece (l & 3) ^ sw of request 16 r + (l >> 2), which
+	// is the piece the slot layout wants at position l & 3.  No registers hold blocks on their way, no LDS stores; a trip with more than 64
+	// requests takes its second half after the first has been handed out.
+	uint4 V[DIRECT ? 1 : 8];
+	if (!DIRECT) {
 #pragma unroll
-	for (int r = 0; r < 8; ++r) {
-		V[r] = make_uint4(0, 0, 0, 0);
-		if (r < rounds) {
-			const int req = r * 16 + sub;
-			if (req < n) V[r] = reinterpret_cast<const uint4*>(X.addr[req])[piece];
+		for (int r = 0; r < (DIRECT ? 1 : 8); ++r) {
+			V[r] = make_uint4(0, 0, 0, 0);
+			if (r < rounds) {
+				const int req = r * 16 + sub;
+				if (req < n) V[r] = reinterpret_cast<const uint4*>(X.addr[req])[piece];
+			}
 		}
 	}
-	DevBlock B0, B1;
-	B0.v0 = B0.v1 = B0.v2 = B0.v3 = make_uint4(0, 0, 0, 0); B1 = B0;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		if (h * 64 < n) {
 #pragma unroll
 			for (int rr = 0; rr < 4; ++rr) {
 				const int r = 4 * h + rr, req = r * 16 + sub;
-				if (req < n) X.slot[((req & 63) << 2) + (piece ^ ((req >> 2) & 3))] = V[r];
+				if (DIRECT) {
+					if (r < rounds && req < n) {
+						const uint4 *src = reinterpret_cast<const uint4*>(X.addr[req]) + (piece ^ ((req >> 2) & 3));
+						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)&X.slot[rr * 64], 16, 0, 0);
+					}
+				} else if (req < n) X.slot[((req & 63) << 2) + (piece ^ ((req >> 2) & 3))] = V[DIRECT ? 0 : r];
 			}
+			if (DIRECT) __builtin_amdgcn_s_waitcnt(0);
 			WAVE_SYNC();
-			if (h == 0 && r0) B0 = seed_take(X, i0);          // n0 <= 64: every first block travels in the first half
-			if (r1 && (i1 >> 6) == h) B1 = seed_take(X, i1);
+			if (h == 0 && r0) { // n0 <= 64: every first block travels in the first half
+				const DevBlock B = seed_take(X, i0);
+				SEED_COUNT(B, ka, kv, tk);
+				if (same) SEED_COUNT(B, la, lv, tl);
+			}
+			if (r1 && (i1 >> 6) == h) { const DevBlock B = seed_take(X, i1); SEED_COUNT(B, la, lv, tl); }
 			WAVE_SYNC();
 		}
 	}
-	if (same) B1 = B0;
 	if (same) ++n_fast; else ++n_slow;
-	uint64_t tk[4], tl[4];
-	uint32_t a_, c_, g_, t_;
-	dev_block_count4(B0, (int)(ka & 127), a_, c_, g_, t_);
-	tk[0] = kv ? ((uint64_t)B0.v0.y << 32 | B0.v0.x) + a_ : 0; tk[1] = kv ? ((uint64_t)B0.v0.w << 32 | B0.v0.z) + c_ : 0;
-	tk[2] = kv ? ((uint64_t)B0.v1.y << 32 | B0.v1.x) + g_ : 0; tk[3] = kv ? ((uint64_t)B0.v1.w << 32 | B0.v1.z) + t_ : 0;
-	dev_block_count4(B1, (int)(la & 127), a_, c_, g_, t_);
-	tl[0] = lv ? ((uint64_t)B1.v0.y << 32 | B1.v0.x) + a_ : 0; tl[1] = lv ? ((uint64_t)B1.v0.w << 32 | B1.v0.z) + c_ : 0;
-	tl[2] = lv ? ((uint64_t)B1.v1.y << 32 | B1.v1.x) + g_ : 0; tl[3] = lv ? ((uint64_t)B1.v1.w << 32 | B1.v1.z) + t_ : 0;
 	const uint64_t s3 = tl[3] - tk[3], s2 = tl[2] - tk[2], s1 = tl[1] - tk[1], s0 = tl[0] - tk[0];
 	const uint64_t b3 = xb + ((xa <= primary && xa + x2 - 1 >= primary) ? 1 : 0);
 	const uint64_t b2 = b3 + s3, b1 = b2 + s2, b0 = b1 + s1;
@@ -114,7 +126,7 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 // many more workgroups than fit on the chip, which lets kernels of a higher-priority stream (the back half of
 // the previous chunk) get compute units while this one is running.  Scratch slabs are therefore not tied to
 // the workgroup index: each wave takes a free slab and gives it back when it exits.
-template <int OCC>
+template <int OCC, bool DIRECT, int LDS_WORDS>
 __global__ void __launch_bounds__(64 * SEED_WPB, OCC)
 k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
        DevIntv *scratch, int list_cap, int mem_cap,
@@ -140,8 +152,8 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.mem = reinterpret_cast<DevIntv*>(slab_base);
 	L.bufA = reinterpret_cast<SeedEnt*>(slab_base + (size_t)64 * mem_cap * sizeof(DevIntv));
 	L.list_cap = list_cap; L.mem_cap = mem_cap;
-	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (reads of up to SEED_LDS_WORDS * 8 bases; longer ones are read where they lie)
-	__shared__ uint32_t s_read[SEED_WPB][SEED_LDS_WORDS][64];
+	// the read, bisulfite-converted and packed 8 bases/word, lane-interleaved in LDS (reads of up to LDS_WORDS * 8 bases; longer ones are read where they lie)
+	__shared__ uint32_t s_read[SEED_WPB][LDS_WORDS][64];
 	__shared__ SeedXchg s_xchg[SEED_WPB];
 	SeedXchg &X = s_xchg[threadIdx.x >> 6];
 	uint32_t *my_read = &s_read[threadIdx.x >> 6][0][threadIdx.x & 63];
@@ -193,7 +205,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 					task = (int)t;
 					L.q = reads + tasks[t].qoff; L.len = tasks[t].len; L.parent = tasks[t].parent;
 					L.qlds = nullptr;
-					if (L.len <= SEED_LDS_WORDS * 8) {
+					if (L.len <= LDS_WORDS * 8) {
 						for (int w = 0; w * 8 < L.len; ++w) {
 							uint32_t pk = 0;
 							for (int b = 0; b < 8 && w * 8 + b < L.len; ++b) {
@@ -221,7 +233,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		if (prof && pc_c0) pc_cold += clock64() - pc_c0;
 		if (__all(retired)) break;
 		if (__ballot(need) == 0) continue;
-		const DevIntv ok = seed_extend_wave(need, ix, L, X, L.n_slow, L.n_fast);
+		const DevIntv ok = seed_extend_wave<DIRECT>(need, ix, L, X, L.n_slow, L.n_fast);
 		if (need) {
 			seed_post(L, ok, P);
 			// a strand search whose lists no longer fit is abandoned at once: its result is discarded and it is seeded again with
@@ -284,8 +296,13 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
 {
 	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
-	hipLaunchKernelGGL(k_seed<3>, dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
-	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof);
+	// $BSX_SEED_FORM (measurements): 0 = blocks through registers and LDS stores, 1 = straight into LDS, 2 = that at four waves per SIMD (spills)
+	static const int form = getenv("BSX_SEED_FORM") ? atoi(getenv("BSX_SEED_FORM")) : SEED_FORM_DEFAULT;
+#define SEED_LAUNCH(...) hipLaunchKernelGGL((k_seed<__VA_ARGS__>), dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, \
+	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof)
+	if (form == 0) SEED_LAUNCH(3, false, 24);
+	else if (form == 2) SEED_LAUNCH(4, true, 20);
+	else SEED_LAUNCH(3, true, 24);
 }
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {

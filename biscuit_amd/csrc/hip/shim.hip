@@ -550,7 +550,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 1;   // one strand search per lane: the lanes of a wave then go through the seeding passes together (measured at hg38 scale: 335 ms with two, 292 with one, 359 with persistent lanes)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
 	// (4096 for reads of 150 bases, which need ~1.2 k; in proportion for longer ones)
-	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : std::max(4096, 28 * max_len);
+	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;   // (the kernel scales it per 256 bases of read)
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
 	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
