@@ -602,6 +602,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		if (d->chain_seed && d->chain_seed != L.ev_seed_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_seed, 0));
+		// 4: front halves one after the other -- a chunk's seeding also waits for the region kernels of the chunk before it
+		if (chain >= 4 && d->chain_regions && d->chain_regions != L.ev_regions_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_regions, 0));
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
@@ -676,7 +678,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			launch_c2r_lanes(st, d->n_cu, d->ix, L.sc, R, d_reads, T, XP, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c);
 		} else
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
-		if (main_seq && chain >= 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
+		if (main_seq && chain == 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
 			std::lock_guard<std::mutex> g(d->chain_mu);
 			HIPCHK(hipEventRecord(L.ev_regions_done, st));
 			d->chain_regions = L.ev_regions_done;
@@ -689,7 +691,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	};
 	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true)) != BSX_OK) return rc;
 
-	if (chain == 2) {
+	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		HIPCHK(hipEventRecord(L.ev_regions_done, L.st));
 		d->chain_regions = L.ev_regions_done;
