@@ -1155,7 +1155,7 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 #define RG_XCBLK 16      // chain records staged at a time
 template <int QC, int WC, int XSD>
 struct RgC2rT {
-	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD;
+	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
 	bsx_region_t regs[RG_XREGS];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
 	RgXSeed sd[XSD];         // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
@@ -1163,9 +1163,13 @@ struct RgC2rT {
 	uint8_t q[QC];
 	uint8_t win[WC];
 	int n_regs;
+	// long reads: the extension's rows in LDS (ext_dp: registers for the band only, so that the launch keeps several waves per SIMD;
+	// rows in registers would need a slot per 64 query bases, 16 of them for a kilobase)
+	int32_t Hrow[QC > RG_QCAP ? QC + 2 : 1], Erow[QC > RG_QCAP ? QC + 2 : 1];
+	uint8_t qrow[QC > RG_QCAP ? QC : 4];
 };
 typedef RgC2rT<RG_QCAP, RG_WIN, RG_XSEEDS> RgC2r;
-typedef RgC2rT<RG_QCAP_LONG, 2048, 512> RgC2rL;   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
+typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
 
 template <typename WT>
 __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, int l_query, int parent, uint32_t qoff,
@@ -1307,8 +1311,8 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (WT::QCAP <= 256 || J.qlen < 256) res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
-						else if (J.qlen < 512) res = ext_dp_reg<8>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
-						else res = ext_dp_reg<16>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else if (2 * J.w + 1 <= 512) { WAVE_SYNC(); res = ext_dp<8>(ix, sc, reads, J, W.Hrow, W.Erow, W.qrow, lane); }   // rows in LDS, the band (<= 8 x 64 columns) in registers
+						else return 2;   // (-w above 127 with reads beyond 256 bases: left to the caller's batch kernels)
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
@@ -1444,10 +1448,10 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
       unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
 {
 	__shared__ WT lds[C2R_WPB];
-	__shared__ int gap_tab[WT::QCAP + 1];
+	__shared__ int gap_tab[WT::GAPCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	P.gap_cap = WT::QCAP;
-	for (int q = threadIdx.x; q <= WT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = WT::GAPCAP;
+	for (int q = threadIdx.x; q <= WT::GAPCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
@@ -1992,7 +1996,7 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
 	if (long_reads)
-		hipLaunchKernelGGL((k_c2r<RgC2rL, 1>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 	else
 	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 }
