@@ -831,33 +831,29 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		WAVE_SYNC();
 		RG_STAGE(4);
 		if (n > 0 && !Store::NODES) {
-			// The overlap filter with every chain's four numbers in registers: lane l holds the chains at sorted positions l + 64 h.
-			// The kept list grows in sorted order, so "the first kept chain that drops chain i" is the lowest position that says so.
+			// The overlap filter (mem_chain_flt, memchain.c:430-470) with the KEPT chains' numbers in registers: kept chain k lives in lane
+			// k & 63 of register set k >> 6, in the order it was kept (= sorted order), so "the first kept chain that drops chain i" is
+			// the lowest lane that says so, and a chain is tested against as many register sets as the kept list fills -- one, for all
+			// but the reads inside repeats (a kilobase read has 800 chains and keeps a few dozen).  Chain i's own numbers come from LDS.
 			constexpr int NH = (Store::CCAP + 63) / 64;
-			int cb[NH], ce[NH], cw[NH], ca[NH], kp[NH], fi[NH];
+			int kb[NH], ke[NH], kw[NH], ka[NH], kpos[NH], kst[NH], kfi[NH];
 #pragma unroll
-			for (int h = 0; h < NH; ++h) {
-				const int j = lane + 64 * h;
-				cb[h] = ce[h] = cw[h] = ca[h] = 0; kp[h] = 0; fi[h] = -1;
-				if (j < n) { const RgChain c = rg_chain(S, (int)S.ord[j]); cb[h] = c.first_q; ce[h] = c.last_q + c.last_len; cw[h] = c.w; ca[h] = c.is_alt; }
+			for (int h = 0; h < NH; ++h) { kb[h] = ke[h] = kw[h] = ka[h] = 0; kpos[h] = -1; kst[h] = 0; kfi[h] = -1; }
+			int n_kept = 1;
+			{
+				const RgChain c0 = rg_chain(S, (int)uni(S.ord[0]));
+				if (lane == 0) { kb[0] = c0.first_q; ke[0] = c0.last_q + c0.last_len; kw[0] = c0.w; ka[0] = c0.is_alt; kpos[0] = 0; kst[0] = 3; }
 			}
-			if (lane == 0) kp[0] = 3;
 			for (int i = 1; i < n; ++i) {
-				const int sl = i & 63, hi = i >> 6;
-				int ib = 0, ie = 0, iw = 0, ia = 0;
-#pragma unroll
-				for (int h = 0; h < NH; ++h) if (h == hi) {
-					ib = __builtin_amdgcn_readlane(cb[h], sl); ie = __builtin_amdgcn_readlane(ce[h], sl);
-					iw = __builtin_amdgcn_readlane(cw[h], sl); ia = __builtin_amdgcn_readlane(ca[h], sl);
-				}
+				const RgChain ci = rg_chain(S, (int)uni(S.ord[i]));
+				const int ib = uni((int)ci.first_q), ie = uni((int)ci.last_q + (int)ci.last_len), iw = uni((int)ci.w), ia = uni((int)ci.is_alt);
 				int r[NH];
 				int stop = 0x7fffffff;
 #pragma unroll
 				for (int h = 0; h < NH; ++h) {
 					r[h] = 0;
-					if (h <= hi) { // kept chains sit at positions < i only
-						const int j = lane + 64 * h;
-						r[h] = (j < i && kp[h]) ? rg_flt_vals(P, ib, ie, iw, ia, cb[h], ce[h], cw[h], ca[h]) : 0;
+					if (h * 64 < n_kept) {
+						r[h] = (lane + 64 * h < n_kept) ? rg_flt_vals(P, ib, ie, iw, ia, kb[h], ke[h], kw[h], ka[h]) : 0;
 						const unsigned long long d = __ballot(r[h] & 2);
 						if (d && stop == 0x7fffffff) stop = 64 * h + __ffsll((long long)d) - 1;
 					}
@@ -865,23 +861,27 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				int large = 0;
 #pragma unroll
 				for (int h = 0; h < NH; ++h) {
-					if (h <= hi) {
-						const int j = lane + 64 * h;
-						const int hit = (r[h] & 1) && j <= stop;
-						if (hit && fi[h] < 0) fi[h] = i;
+					if (h * 64 < n_kept) {
+						const int hit = (r[h] & 1) && lane + 64 * h <= stop;
+						if (hit && kfi[h] < 0) kfi[h] = i;
 						if (__ballot(hit)) large = 1;
 					}
 				}
-				if (stop == 0x7fffffff) {
+				if (stop == 0x7fffffff) { // kept: the next entry of the list
+					const int sl = n_kept & 63, hi = n_kept >> 6;
 #pragma unroll
-					for (int h = 0; h < NH; ++h) if (h == hi && lane == sl) kp[h] = large ? 2 : 3;
+					for (int h = 0; h < NH; ++h) if (h == hi && lane == sl) { kb[h] = ib; ke[h] = ie; kw[h] = iw; ka[h] = ia; kpos[h] = i; kst[h] = large ? 2 : 3; kfi[h] = -1; }
+					++n_kept;
 				}
 			}
-#pragma unroll
-			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n) { if (Store::PCAP) S.lst[j] = (idx_t)kp[h]; else S.ch[S.ord[j]].kept = (signed char)kp[h]; } }   // PCAP: kept flags by position (lst is free here)
+			// kept flags by sorted position (PCAP: lst is free here), then the first chain each kept one shadows (chn->first, memchain.c:455-460)
+			for (int j = lane; j < n; j += 64) { if (Store::PCAP) S.lst[j] = 0; else S.ch[S.ord[j]].kept = 0; }
 			WAVE_SYNC();
 #pragma unroll
-			for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < n && kp[h] && fi[h] >= 0) { if (Store::PCAP) S.lst[fi[h]] = 1; else S.ch[S.ord[fi[h]]].kept = 1; } }
+			for (int h = 0; h < NH; ++h) if (lane + 64 * h < n_kept) { if (Store::PCAP) S.lst[kpos[h]] = (idx_t)kst[h]; else S.ch[S.ord[kpos[h]]].kept = (signed char)kst[h]; }
+			WAVE_SYNC();
+#pragma unroll
+			for (int h = 0; h < NH; ++h) if (lane + 64 * h < n_kept && kfi[h] >= 0) { if (Store::PCAP) S.lst[kfi[h]] = 1; else S.ch[S.ord[kfi[h]]].kept = 1; }
 			WAVE_SYNC();
 		} else if (n > 0) {
 			int nk = 1;

@@ -25,6 +25,7 @@ struct Lane {
 	hipEvent_t ev_seed_done = nullptr, ev_regions_done = nullptr;   // what the next chunk's launches of the same stage wait for
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
+	hipEvent_t tier_ev[12] = {};   // $BSX_PHASES: between the region launches
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
@@ -630,27 +631,38 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// The tier sequence over a task list (the chunk's, and once more the re-seeded strand searches' on the side stream).  k32: u32 cursors and
 	// counts ([0] tier-1 cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor [5] k_seedsw's cursor [10] what the
 	// larger LDS tier hands on [11] its cursor); xc32: exported count | k_c2r's cursor.
+	const bool trace_tiers = getenv("BSX_PHASES") != nullptr;
+	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
 	                     const unsigned char *clsx, bool main_seq) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
+		// $BSX_PHASES: the main sequence's launches one by one (events between them)
+#define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; } } while (0)
+		TIER_MARK("start");
 		launch_regions(st, rgrid, d->ix, L.sc, R, d_reads, T, (int)nT, (const DevIntv*)L.out.p, offs, cnts,
 		               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, k32 + 0, ra, k32 + 1, reg_quota, ctr, posoffs, d_pos, clsx, XP, long_reads);
 		if (main_seq) HIPCHK(hipEventRecord(L.ev3, st));
+		TIER_MARK("tier 1");
 		if (use_mid)
 			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, ra, k32 + 1, k32 + 11, rm, k32 + 10, ctr, posoffs, d_pos, XP, mid_quota, long_reads);
+		TIER_MARK("tier 1b");
 		int *to2 = use_mid ? rm : ra; unsigned int *n2c = use_mid ? k32 + 10 : k32 + 1;
 		const int c2r_grid = (int)((nT + 4LL * c2r_quota - 1) / (4LL * c2r_quota));
 		if (export_all) {
 			// every tier exports; then the seed-SW filter where it applies, then chains -> regions (what outgrows its tables is left to the caller)
 			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XP);
+			TIER_MARK("tier 2 (exports)");
 			launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos, &XP);
+			TIER_MARK("tier 3 (exports)");
 			if (any_flt) launch_seedsw(st, (int)std::min<int64_t>((nT + 3) / 4, (int64_t)d->n_cu * 32), d->ix, L.sc, R, d_reads, T, XP, k32 + 5, ctr);
+			TIER_MARK("seed filter");
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, nullptr, nullptr, ctr, c2r_quota, long_reads);
+			TIER_MARK("chains -> regions");
 			return BSX_OK;
 		}
 		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
@@ -683,10 +695,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			HIPCHK(hipEventRecord(L.ev_regions_done, st));
 			d->chain_regions = L.ev_regions_done;
 		}
+		TIER_MARK("chains -> regions");
 		launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
+		TIER_MARK("tier 2");
 		launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos);
+		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
 	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true)) != BSX_OK) return rc;
@@ -759,6 +774,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		float ms0 = 0, ms1 = 0, ms2 = 0;
 		HIPCHK(hipEventSynchronize(L.ev2));
 		clock_gettime(CLOCK_MONOTONIC, &ts3);
+		if (trace && n_marks > 1) {
+			fprintf(stderr, "[M::regions_batch] region launches (ms):");
+			for (int k = 1; k < n_marks; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, L.tier_ev[k - 1], L.tier_ev[k]) == hipSuccess) fprintf(stderr, " %s %.1f |", mark_name[k], ms); }
+			fprintf(stderr, "\n");
+		}
 		if (trace) fprintf(stderr, "[M::regions_batch] seed kernel done +%.0f ms | redo of %zu strand searches enqueued +%.0f ms | all region tiers done +%.0f ms\n",
 		                   (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, redo.size(), (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6,
 		                   (ts3.tv_sec - ts0.tv_sec) * 1e3 + (ts3.tv_nsec - ts0.tv_nsec) * 1e-6);
