@@ -1983,7 +1983,10 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	if (long_reads)   // tables for a kilobase read, one wave per workgroup
+	if (long_reads == 2)   // the larger tables for reads of ordinary length (the tier behind k_regions_mid<RgMid>)
+		hipLaunchKernelGGL((k_regions_mid<RgLongS, RgDpLite, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
+	else if (long_reads)   // tables for a kilobase read, one wave per workgroup
 		hipLaunchKernelGGL((k_regions_mid<RgLongS, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 	else

@@ -566,7 +566,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 25 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 29 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
@@ -583,7 +583,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
 	int *retry_a = (int*)((char*)L.regmeta.p + (size_t)n * 12), *retry_b = (int*)((char*)L.regmeta.p + (size_t)n * 16);
 	int *retry_m = (int*)((char*)L.regmeta.p + (size_t)n * 20);
-	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 24;
+	int *retry_l = (int*)((char*)L.regmeta.p + (size_t)n * 24);
+	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 28;
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
 	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
@@ -635,7 +636,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
-	                     const unsigned char *clsx, bool main_seq) -> int {
+	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
@@ -650,6 +651,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, ra, k32 + 1, k32 + 11, rm, k32 + 10, ctr, posoffs, d_pos, XP, mid_quota, long_reads);
 		TIER_MARK("tier 1b");
 		int *to2 = use_mid ? rm : ra; unsigned int *n2c = use_mid ? k32 + 10 : k32 + 1;
+		// $BSX_REGIONS_1C=1: a third LDS tier for what outgrows the second (reads inside repeat families: the 768-interval / 1536-seed tables
+		// made for kilobase reads, two waves per CU).  Measured and off: 378 against 343 ms per chunk on the clean genome, 1337 against 1088 on
+		// the hg38-like one -- two waves per CU at LDS speed lose to eight at HBM speed (as the 512-seed tier tried earlier in round 3 did).
+		static const int use_1c = getenv("BSX_REGIONS_1C") ? atoi(getenv("BSX_REGIONS_1C")) : 0;
+		if (use_mid && use_1c && !export_all) {
+			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 2);   // (the launch covers the worst case: every strand search on the list)
+			to2 = rl; n2c = l_count;
+			TIER_MARK("tier 1c");
+		}
 		const int c2r_grid = (int)((nT + 4LL * c2r_quota - 1) / (4LL * c2r_quota));
 		if (export_all) {
 			// every tier exports; then the seed-SW filter where it applies, then chains -> regions (what outgrows its tables is left to the caller)
@@ -704,7 +715,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true)) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7)) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -743,11 +754,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[redo[j]];
 			// device side, per re-seeded strand search: task | interval offset | region offset | position offset | export offset | interval
 			// count | region count | three tier lists | export list | tier class
-			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 12 + 4 + 1) + 1024)) != BSX_OK) return rc;
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 16 + 4 + 1) + 1024)) != BSX_OK) return rc;
 			if ((rc = L.rs.hres.reserve(n2 * 12 + 64)) != BSX_OK) return rc;
 			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
 			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; long long *posoff2 = roff2 + n2; long long *xoff2 = posoff2 + n2;
-			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *xlist2 = rb2 + n2;
+			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *rl2 = rb2 + n2, *xlist2 = rl2 + n2;
 			unsigned char *cls2 = (unsigned char*)(xlist2 + n2);
 			// its own cursors (u64 slots 96.. of the lane's counter block): u32 [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3
 			// count [4] tier-3 cursor [7] seed task cursor [10] count of what the larger LDS tier hands on [11] its cursor; slot 102: exported
@@ -761,7 +772,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false)) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8)) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
