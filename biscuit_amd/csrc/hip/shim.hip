@@ -567,7 +567,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
 	if ((rc = L.regmeta.reserve((size_t)n * 29 + 64)) != BSX_OK) return rc;
-	if ((rc = L.slabs.reserve((size_t)big_grid * 4 * regions_slab_bytes(2))) != BSX_OK) return rc;
+	if ((rc = L.slabs.reserve((size_t)big_grid * 6 * regions_slab_bytes(2))) != BSX_OK) return rc;   // (the exporting form runs three workgroups per CU)
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
 	// copies there), a few dozen against small ones.  $BSX_POS_CAP (tests): a cap small enough for strand searches to find no room.
@@ -681,6 +681,30 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// $BSX_C2R_LANES=1: lock-step rounds -- a lane per strand search runs the reference's seed loop until it needs an extension
 		// (k_c2r_ctrl: 24 ms per chunk in all), then the extensions of the round run a lane per narrow job (k_ext_n) and four to a
 		// wavefront (k_ext_q, k_extq.hip): 255 ms per chunk as measured in round 3 against k_c2r's 150 ms.
+		// $BSX_SLAB_EXPORT=1: the first HBM tier stops after the chain filter and exports too (156 instead of 225 VGPRs: three waves per
+		// SIMD instead of two); its chains go through k_c2r with everybody else's, and what k_c2r cannot hold (a chain of more than 128 seeds,
+		// more than 64 regions) then takes the same tier in its full form.  Measured and off: 359 against 342 ms per chunk on the clean genome,
+		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).
+		static const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
+		if (slab_export && !(main_seq && use_lanes)) {
+			launch_regions_slab(st, 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XP);
+			TIER_MARK("tier 2 (exports)");
+			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rl, l_count, ctr, c2r_quota);
+			TIER_MARK("chains -> regions");
+			if (main_seq && chain == 3) {
+				std::lock_guard<std::mutex> g(d->chain_mu);
+				HIPCHK(hipEventRecord(L.ev_regions_done, st));
+				d->chain_regions = L.ev_regions_done;
+			}
+			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rl, l_count, l_cursor, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
+			TIER_MARK("tier 2");
+			launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos);
+			TIER_MARK("tier 3");
+			return BSX_OK;
+		}
 		if (main_seq && use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
 			const size_t sb = c2r_lanes_state_bytes();
 			if ((rc2 = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc2;
