@@ -145,6 +145,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.st2) (void)hipStreamDestroy(L.st2);
 		if (L.ev3) (void)hipEventDestroy(L.ev3);
 		if (L.ev4) (void)hipEventDestroy(L.ev4);
+		for (int k = 0; k < 12; ++k) if (L.tier_ev[k]) { (void)hipEventDestroy(L.tier_ev[k]); L.tier_ev[k] = nullptr; }
 		if (L.rs.ev) (void)hipEventDestroy(L.rs.ev);
 		if (L.rs.ev_tiers) (void)hipEventDestroy(L.rs.ev_tiers);
 		L.rs.hres.release();

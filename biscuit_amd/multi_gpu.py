@@ -4,8 +4,9 @@
         -m biscuit_amd.multi_gpu [--out FILE] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
 
 Every rank cuts the input into the reference's chunks (10 Mbp x -@, align.c:576) and aligns chunks
-r, r+N, ... on its own GPU against its own HBM-resident copy of the index (every rank's reader still parses the
-whole input -- the chunk rule is cumulative -- and drops the chunks of the other ranks: csrc/host/cli.c).  A chunk is the only unit whose reads depend on
+r, r+N, ... on its own GPU against its own HBM-resident copy of the index.  The chunk rule is cumulative, so over plain files a
+light scan (no records built: csrc/host/fastq.c) finds the chunk boundaries and each rank seeks to and parses only its own chunks;
+over compressed or piped input every rank parses everything and drops the chunks of the others (csrc/host/cli.c).  A chunk is the only unit whose reads depend on
 each other (per-chunk insert-size statistics), so the SAM equals the single-GPU / CPU output for the same
 -@.  The only communication is the streaming gather of the per-chunk SAM text to rank 0
 (biscuit_amd/gather.py: sizes, then exactly the payload, point to point -> RCCL over xGMI), overlapped
