@@ -415,3 +415,18 @@ def test_dedup_kernel_against_host_function(tmp_path):
     L.bsx_sim_free_reads(p, n)
     dev.close()
     idx.close()
+
+
+def test_failed_output_ends_cleanly_with_chunks_in_flight(data):
+    """A write to stdout that fails (ENOSPC) while several chunks are in the pipeline: the front halves in flight are joined and the
+    stream is closed before their reads are released, and the command exits with status 1 and the reference's message -- not with a
+    signal (the streamed loop of csrc/host/cli.c; utils.c:214-240 for the reference's behaviour)."""
+    args = ["-@", "4", "g", "b1.fq", "b2.fq"]
+    e = dict(os.environ, BSX_CHUNK_SIZE="20000")     # ~15 chunks, four in flight
+    ok = subprocess.run([HIP] + args, cwd=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=e)
+    assert ok.returncode == 0 and ok.stdout.count(b"\n") > 8000
+    for _ in range(3):
+        with open("/dev/full", "wb") as full:
+            bad = subprocess.run([HIP] + args, cwd=data, stdout=full, stderr=subprocess.PIPE, timeout=600, env=e)
+        assert bad.returncode == 1, (bad.returncode, bad.stderr.decode()[-800:])
+        assert b"failed to write" in bad.stderr
