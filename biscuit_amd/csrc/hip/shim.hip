@@ -921,13 +921,34 @@ static int lane_regions_finish(bsx_device_t *d, int lane, bsx_region_t **out, in
 	const long long *roff = (const long long*)L.rs.hres.p;
 	const int *rn = (const int*)((const char*)L.rs.hres.p + n2 * 8);
 	int64_t used = (int64_t)L.rs.used_main;
+	// their regions lie behind the main sequence's in the device's pool: one copy of that stretch (a copy per strand search was tens
+	// of thousands of small transfers per chunk on a repeat-rich genome), then each list is taken from it
+	unsigned long long used_all = 0;
+	D2H(L.st2, &used_all, dev_counters(L) + 6, 8);
+	const unsigned long long lo = L.rs.used_main, hi = std::max<unsigned long long>(used_all, lo);
+	std::vector<bsx_region_t> stretch;
+	if (hi > lo) {
+		bool any = false;
+		for (size_t j = 0; j < n2 && !any; ++j) any = rn[j] > 0;
+		if (any) { stretch.resize((size_t)(hi - lo)); D2H(L.st2, stretch.data(), (const bsx_region_t*)L.regs.p + lo, sizeof(bsx_region_t) * (size_t)(hi - lo)); }
+	}
+	long hist[16] = {0};
 	for (size_t j = 0; j < n2; ++j) {
 		const int64_t i = L.rs.tasks[j];
-		if (rn[j] < 0) { out_n[i] = -1; out_off[i] = 0; continue; }
-		if (*out_cap < used + rn[j]) { *out_cap = used + rn[j] + 1024; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
-		D2H(L.st2, *out + used, (const bsx_region_t*)L.regs.p + roff[j], sizeof(bsx_region_t) * (size_t)rn[j]);
+		if (rn[j] < 0) { out_n[i] = -1; out_off[i] = 0; ++hist[(-rn[j]) & 15]; continue; }
+		if (*out_cap < used + rn[j]) { *out_cap = used + rn[j] + 1024 + (*out_cap >> 2); *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
+		if (rn[j] > 0) {
+			if (!stretch.empty() && (unsigned long long)roff[j] >= lo && (unsigned long long)roff[j] + (unsigned long long)rn[j] <= hi)
+				memcpy(*out + used, stretch.data() + ((unsigned long long)roff[j] - lo), sizeof(bsx_region_t) * (size_t)rn[j]);
+			else D2H(L.st2, *out + used, (const bsx_region_t*)L.regs.p + roff[j], sizeof(bsx_region_t) * (size_t)rn[j]);
+		}
 		out_off[i] = used; out_n[i] = rn[j];
 		used += rn[j];
+	}
+	if (getenv("BSX_PHASES")) {
+		fprintf(stderr, "[M::regions_finish] left to the caller after the second pass, by reason:");
+		for (int k = 1; k < 16; ++k) if (hist[k]) fprintf(stderr, " %d: %ld", k, hist[k]);
+		fprintf(stderr, "\n");
 	}
 	L.rs.active = false;
 	return BSX_OK;
