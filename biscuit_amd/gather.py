@@ -34,6 +34,8 @@ class ChunkGather:
         self._pin = None
         self._dev_buf = None
         self._src_buf = {}            # rank 0: per-sender staging (device tensor, pinned host tensor)
+        import os
+        self._sequential = bool(os.environ.get("BSX_GATHER_SEQUENTIAL"))   # one receive at a time (the form of rounds 1-2)
         self._copy_stream = None
         self._dead = False            # set when the gather has ended: late producers (another rank failed) are not blocked
 
@@ -136,7 +138,17 @@ class ChunkGather:
                     if has and nb:
                         bufs[src] = self._staging_src(src, nb)
                         ops.append(dist.P2POp(dist.irecv, bufs[src][0], src))
-                reqs = dist.batch_isend_irecv(ops) if ops else []
+                reqs = []
+                if ops and not self._sequential:
+                    try:
+                        reqs = dist.batch_isend_irecv(ops)
+                    except Exception as e:   # a backend without grouped point-to-point: nothing was posted, take them one by one from here on
+                        import sys
+                        sys.stderr.write("[W::gather] receives posted one after the other (%r)\n" % (e,))
+                        self._sequential = True
+                if ops and self._sequential:
+                    for src in sorted(bufs):
+                        dist.recv(bufs[src][0], src=src)
                 if metas[0][0]:
                     self.sink(r * self.world, mine)   # this rank's own chunk while the others arrive
                     n_chunks += 1
