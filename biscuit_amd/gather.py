@@ -102,13 +102,14 @@ class ChunkGather:
             return
         meta = torch.zeros(2, dtype=torch.int64, device=self.device)
         dist.all_gather([torch.zeros(2, dtype=torch.int64, device=self.device) for _ in range(self.world)], meta)
-        buf = self._staging(n_bytes)
         if self.rank == 0:
-            for src in range(1, self.world):
-                dist.recv(buf, src=src)
-            if self.device.type == "cuda":
-                self._pin[:n_bytes].copy_(buf)
+            for src in range(1, self.world):   # every sender's own staging pair at its final size, touched once
+                dev, pin = self._staging_src(src, n_bytes)
+                dist.recv(dev, src=src)
+                if pin is not None:
+                    pin.copy_(dev)
         else:
+            buf = self._staging(n_bytes)
             buf.zero_()
             dist.send(buf, dst=0)
 
