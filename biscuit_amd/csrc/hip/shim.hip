@@ -1010,6 +1010,11 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 		return BSX_OK;
 	}
 	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}
+	// The host chaining path calls this once per round of its strand searches' extensions -- a thousand rounds of a few hundred jobs for
+	// the reads inside satellite arrays of a repeat-rich genome -- while the front-half kernels of other chunks fill the device.
+	// $BSX_HOSTPATH_STREAM=1 puts the rounds on the lane's high-priority stream: measured, no difference (3.36-3.60 against 3.52 s per chunk).
+	static const int hp_hi = getenv("BSX_HOSTPATH_STREAM") ? atoi(getenv("BSX_HOSTPATH_STREAM")) : 0;
+	hipStream_t S = hp_hi ? L.st_hi : L.st;
 	// the last class: queries of any length, rows in HBM (reads of tens of kilobases).  What remains out of reach is a band of more
 	// than 2048 columns, i.e. -w above 511 -- a limit of the option, not of the data
 	static const int QCAP[4] = {256, 1024, 16384, 0x7fffffff}, BAND[4] = {256, 512, 2048, 2048}, NCS[4] = {4, 8, 32, 32};
@@ -1031,26 +1036,26 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
+	HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, S));
 	size_t off = 0;
 	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
-		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, L.st));
+		HIPCHK(hipMemcpyAsync((int*)L.aux.p + off, order[c].data(), order[c].size() * 4, hipMemcpyHostToDevice, S));
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(L.ev0, L.st));
+	HIPCHK(hipEventRecord(L.ev0, S));
 	off = 0;
 	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
 		if (c == 3)
-			launch_extend_hbm(L.st, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+			launch_extend_hbm(S, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 			                  (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, hbm_qmax, hbm_blocks, L.scratch.p);
 		else
-		launch_extend(L.st, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
+		launch_extend(S, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (const int*)L.aux.p + off,
 		              (long long)order[c].size(), (bsx_ext_res_t*)L.res.p, QCAP[c], NCS[c], d->n_cu);
 		off += order[c].size();
 	}
-	HIPCHK(hipEventRecord(L.ev1, L.st));
+	HIPCHK(hipEventRecord(L.ev1, S));
 	if ((rc = finish_timed(L, 2)) != BSX_OK) return rc;
-	D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
+	D2H(S, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
 	return BSX_OK;
 }
 
