@@ -209,7 +209,7 @@ static bsx_fq_scan_t *shard_scan_start(const char *fn1, const char *fn2, int chu
 	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank parses all of it and drops the chunks of the others");
 	return s;
 }
-typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; const char *fn1, *fn2; int chunk, has_bc, copy_comment; volatile int stop; } reader_t;
+typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; const char *fn1, *fn2; int chunk, has_bc, copy_comment; volatile int stop, failed; } reader_t;
 static void *reader_main(void *arg)
 {
 	reader_t *R = (reader_t*)arg;
@@ -224,11 +224,11 @@ static void *reader_main(void *arg)
 		if (scan) { /* this rank's next chunk: where it starts is known, the parser threads start there */
 			bsx_fq_chunkpos_t cp;
 			if (!bsx_fq_scan_get(scan, idx, &cp)) break;
-			if (bsx_fq_seek(R->f1, cp.off1) != 0 || (R->f2 && bsx_fq_seek(R->f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "reader"); break; }
+			if (bsx_fq_seek(R->f1, cp.off1) != 0 || (R->f2 && bsx_fq_seek(R->f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "reader"); R->failed = 1; break; }
 			P = bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
 			r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
 			bsx_fq_pair_close(P); P = 0;
-			if (r.seqs == 0 || r.n != cp.n) { fprintf(stderr, "[E::%s] chunk %ld: %d reads where the scan counted %d\n", "reader", (long)idx, r.n, cp.n); break; }
+			if (r.seqs == 0 || r.n != cp.n) { fprintf(stderr, "[E::%s] chunk %ld: %d reads where the scan counted %d\n", "reader", (long)idx, r.n, cp.n); if (r.seqs) { for (i = 0; i < r.n; ++i) bsx_read_free(&r.seqs[i]); free(r.seqs); } R->failed = 1; break; }
 			r.n_before = cp.n_before;
 		} else r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
 		if (r.seqs == 0 || r.n == 0) { free(r.seqs); break; }
@@ -459,7 +459,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			pthread_t th_r, th_w;
 			chunk_rec_t r;
 			cq_init(&in_q); cq_init(&out_q);
-			R.Q = &in_q; R.f1 = f1; R.f2 = f2; R.fn1 = argv[optind + 1]; R.fn2 = f2 ? argv[optind + 2] : 0; R.chunk = chunk; R.has_bc = opt->has_bc; R.copy_comment = copy_comment; R.stop = 0;
+			R.Q = &in_q; R.f1 = f1; R.f2 = f2; R.fn1 = argv[optind + 1]; R.fn2 = f2 ? argv[optind + 2] : 0; R.chunk = chunk; R.has_bc = opt->has_bc; R.copy_comment = copy_comment; R.stop = 0; R.failed = 0;
 			pthread_create(&th_r, 0, reader_main, &R);
 			pthread_create(&th_w, 0, writer_main, &out_q);
 			while (cq_get(&in_q, &r)) {
@@ -494,6 +494,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			n_pend = 0;
 			cq_close(&out_q);
 			pthread_join(th_r, 0); pthread_join(th_w, 0);
+			if (R.failed) rc = 1;   /* the reader gave up on the input: the SAM is incomplete */
 			if (stream) bsx_stream_close(stream);
 			stream = 0;
 			goto loop_done;
