@@ -1406,11 +1406,11 @@ k_seedsw(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bs
 						rb = rb > far_beg ? rb : far_beg; re = re < far_end ? re : far_end;
 						const int qlen = qe - qb, tlen = (int)(re - rb);
 						if (qlen > 0 && tlen > 0) {
-							int qv[4];
-#pragma unroll
-							for (int c = 0; c < 4; ++c) { const int jj = (c << 6) + lane; qv[c] = jj < qlen ? (int)reads[(size_t)qoff + qb + jj] : 5; }
-							const SwPass r = sw_pass<4>(ix, mat, 0, qlen, qv, tlen, rb, 1, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, 0, nullptr, lane);
-							score = uni(r.score);
+							// as many 64-column register slots as the padded query needs (a seed of 19 with its 2 x 50 bases: two)
+							const int Q = ((qlen + 7) >> 3) << 3;
+#define SEEDSW_RUN(NC_) do { int qv[NC_]; _Pragma("unroll") for (int c = 0; c < NC_; ++c) { const int jj = (c << 6) + lane; qv[c] = jj < qlen ? (int)reads[(size_t)qoff + qb + jj] : 5; } \
+								const SwPass r = sw_pass<NC_>(ix, mat, 0, qlen, qv, tlen, rb, 1, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, 0, nullptr, lane); score = uni(r.score); } while (0)
+							if (Q <= 128) SEEDSW_RUN(2); else if (Q <= 192) SEEDSW_RUN(3); else SEEDSW_RUN(4);
 							++n_sw;
 						}
 					}
