@@ -72,7 +72,8 @@ typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;          
                                                                                 // strand search of a read against an hg38-sized index (~50 intervals, ~125 seeds, ~100 chains)
 // chunks with long reads (a kilobase against an hg38-sized index: ~360 intervals, ~830 seeds, most of them alone in their piece): still
 // LDS, 62 KB per wave, two workgroups of one wave per CU -- every table access of the HBM tiers below is a memory round trip
-typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongS;
+typedef RgStore<640, 1152, 1152, 0, 0, unsigned short, short, 160> RgLongS;   // 49 KB: three workgroups per CU; four fifths of the kilobase reads' strand searches fit
+typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongB;   // 62 KB, two per CU: most of the rest
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
@@ -1845,10 +1846,11 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 {
 	__shared__ Store lds[WPB];
 	__shared__ DPT dp[WPB];
-	__shared__ int gap_tab[DPT::QCAP + 1];
+	constexpr int GAPCAP = DPT::QCAP > RG_QCAP ? RG_QCAP : DPT::QCAP;   // (LDS bounds this launch: longer lengths are computed)
+	__shared__ int gap_tab[GAPCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	P.gap_cap = DPT::QCAP;
-	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+	P.gap_cap = GAPCAP;
+	for (int q = threadIdx.x; q <= GAPCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
@@ -1983,8 +1985,11 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota, int long_reads)
 {
 	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	if (long_reads == 2)   // the larger tables for reads of ordinary length (the tier behind k_regions_mid<RgMid>)
-		hipLaunchKernelGGL((k_regions_mid<RgLongS, RgDpLite, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+	if (long_reads == 3)   // kilobase reads, the larger of the two table sizes
+		hipLaunchKernelGGL((k_regions_mid<RgLongB, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
+	else if (long_reads == 2)   // the larger tables for reads of ordinary length (the tier behind k_regions_mid<RgMid>)
+		hipLaunchKernelGGL((k_regions_mid<RgLongB, RgDpLite, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 	else if (long_reads)   // tables for a kilobase read, one wave per workgroup
 		hipLaunchKernelGGL((k_regions_mid<RgLongS, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,

@@ -656,7 +656,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// made for kilobase reads, two waves per CU).  Measured and off: 378 against 343 ms per chunk on the clean genome, 1337 against 1088 on
 		// the hg38-like one -- two waves per CU at LDS speed lose to eight at HBM speed (as the 512-seed tier tried earlier in round 3 did).
 		static const int use_1c = getenv("BSX_REGIONS_1C") ? atoi(getenv("BSX_REGIONS_1C")) : 0;
-		if (use_mid && use_1c && !export_all) {
+		if (use_mid && long_reads) { // kilobase reads: a second LDS tier with larger tables (two workgroups per CU) for what outgrows the first (three)
+			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 3);
+			to2 = rl; n2c = l_count;
+			TIER_MARK("tier 1c");
+		} else if (use_mid && use_1c && !export_all) {
 			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 2);   // (the launch covers the worst case: every strand search on the list)
 			to2 = rl; n2c = l_count;
