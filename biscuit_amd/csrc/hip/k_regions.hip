@@ -74,7 +74,10 @@ typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;          
 // LDS, 62 KB per wave, two workgroups of one wave per CU -- every table access of the HBM tiers below is a memory round trip
 typedef RgStore<640, 1152, 1152, 0, 0, unsigned short, short, 160> RgLongS;   // 49 KB: three workgroups per CU; four fifths of the kilobase reads' strand searches fit
 typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongB;   // 62 KB, two per CU: most of the rest
-typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;      // a region comes from one seed: RCAP = SCAP never binds
+typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;
+// the same capacity chained as the LDS tiers do it (pieces, chain starts in registers, records for multi-seed chains only), tables in an HBM
+// slab, exporting: for the repeat reads that outgrow the LDS tiers but have no tied chain starts
+typedef RgStore<512, 1024, 1024, 0, 0, unsigned short, short, 256> RgBigP;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
 struct RgDp {            // per-wave LDS scratch
@@ -1828,7 +1831,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		int status = rg_task<Store, XSPLIT, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;   // exported (XSPLIT: chunks with long reads, whose chains go through k_seedsw and k_c2r)
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
-		if (next_list && (status == 8 || status == 2 || status == 3 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
+		if (next_list && (status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
 }
 
@@ -1957,7 +1960,7 @@ void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, u
 	hipLaunchKernelGGL(k_sa_dense, dim3(n_cu * 32), dim3(256), 0, st, ix, parent, intv, n, out);
 }
 
-size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
+size_t regions_slab_bytes(int tier) { return tier == 2 ? (sizeof(RgBig) > sizeof(RgBigP) ? sizeof(RgBig) : sizeof(RgBigP)) : sizeof(RgHuge); }
 
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -2017,7 +2020,10 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 	RgXPool X; X.base = nullptr; X.cap = 0; X.cursor = nullptr; X.xoff = nullptr; X.xlist = nullptr; X.xcount = nullptr;
 	if (XA) { X.base = XA->base; X.cap = XA->cap; X.cursor = XA->cursor; X.xoff = XA->xoff; X.xlist = XA->xlist; X.xcount = XA->xcount; }
 	// XA given: the tier stops after the chain filter and exports (chunks with long reads or an active seed-SW filter)
-	if (tier == 2 && XA)
+	if (tier == 4 && XA)
+		hipLaunchKernelGGL((k_regions_slab<RgBigP, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBigP*)slabs, next_list, next_count, counters, pos_off, pos, X);
+	else if (tier == 2 && XA)
 		hipLaunchKernelGGL((k_regions_slab<RgBig, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos, X);
 	else if (tier == 2)

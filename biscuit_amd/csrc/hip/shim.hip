@@ -690,11 +690,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// $BSX_SLAB_EXPORT=1: the first HBM tier stops after the chain filter and exports too (156 instead of 225 VGPRs: three waves per
 		// SIMD instead of two); its chains go through k_c2r with everybody else's, and what k_c2r cannot hold (a chain of more than 128 seeds,
 		// more than 64 regions) then takes the same tier in its full form.  Measured and off: 359 against 342 ms per chunk on the clean genome,
-		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).
+		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).  =2: that tier chained as the
+		// LDS tiers do it (pieces, chain starts in registers) over its HBM slab: 344 against 342, 1140 against 1095 -- no better either.
 		static const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
 		if (slab_export && !(main_seq && use_lanes)) {
-			launch_regions_slab(st, 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XP);
+			launch_regions_slab(st, slab_export == 2 ? 4 : 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, slab_export == 2 ? rl : rb, slab_export == 2 ? l_count : k32 + 3, ctr, posoffs, d_pos, &XP);   // 2: chained by pieces; what it declines (tied starts, tables) takes the full form next
 			TIER_MARK("tier 2 (exports)");
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rl, l_count, ctr, c2r_quota);
 			TIER_MARK("chains -> regions");
