@@ -49,7 +49,8 @@ struct RgStore {
 	// (srt) are first written after that, so the two share their bytes (2 KB of the 13.7 KB a wave of the larger LDS tier had: a
 	// sixth workgroup per CU)
 	union {
-		struct { unsigned long long iv_x0[ICAP_]; int iv_n[ICAP_]; short iv_beg[ICAP_], iv_end[ICAP_]; };
+		struct { unsigned long long iv_x0[ICAP_]; int iv_n[ICAP_]; short iv_beg[ICAP_], iv_end[ICAP_];
+		         unsigned long long iv_rank[NODES_ ? ICAP_ : 1]; };   // iv_n: count | more beyond << 29 | over-represented << 30; iv_rank (HBM tiers): first SA rank
 		unsigned long long srt[SCAP_];    // score<<32|i, ascending (memchain.c:748-752)
 	};
 	// seeds in arrival order
@@ -62,6 +63,7 @@ struct RgStore {
 	Idx lst[SCAP_];                   // seed indices of the current chain / list
 	bsx_region_t regs[RCAP_ ? RCAP_ : 1];
 	int n_chains, n_regs;
+	int boost_iv;                     // status 10: the interval (sorted index) that has to be walked further
 	// NODES > 0: chains are indexed by the reference's B-tree, so that chains starting at the same position are found
 	// and ordered as kb_intervalp / __kb_traverse would (the first tier declines such tasks instead)
 	RgNode node[NODES_ ? NODES_ : 1];
@@ -432,7 +434,8 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 template <typename Store, bool SPLIT = false, typename DP = RgDp>
 __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                        int l_query, int parent, uint32_t qoff, const DevIntv *src, int n_iv, const unsigned long long *posl, int lane,
-                       unsigned long long *counters, const int *gap, const long long *ctg, const RgXPool *X = nullptr, int task_id = 0)
+                       unsigned long long *counters, const int *gap, const long long *ctg, const RgXPool *X = nullptr, int task_id = 0,
+                       int n_boost = 0, const int *boost_iv = nullptr, const int *boost_lvl = nullptr)
 {
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
@@ -466,8 +469,8 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		if (i < n_iv) mine = src[i];
 		// occurrences this strand search will visit: all of them, or the first max_occ of an over-represented interval (memchain.c:325-326)
 		const int big = mine.x2 > (unsigned long long)P.max_occ;
-		const int cnt = big ? P.max_occ : (int)mine.x2;
-		long long incl = cnt;
+		const int lk = big ? P.max_occ : (int)mine.x2;   // what k_occ looked up ahead
+		long long incl = lk;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
 			const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
@@ -485,8 +488,17 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			}
 		}
 		if (i < n_iv) {
-			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - cnt) : mine.x0;
-			S.iv_n[rank] = cnt | big << 30;
+			// The reference walks an over-represented interval past its first max_occ occurrences while it has started at most five chains
+			// (memchain.c:325-326).  The HBM tiers do too: when the rule asks for more of an interval the strand search is run again with that
+			// interval's share multiplied (boost_*), the further positions walked here
+			long long want = lk;
+			if (Store::NODES && big) for (int b = 0; b < n_boost; ++b) if (boost_iv[b] == rank) want = (long long)P.max_occ * boost_lvl[b];
+			if (want > (long long)mine.x2) want = (long long)mine.x2;
+			if (want > 0x0fffffff) want = 0x0fffffff;
+			const int cnt = (int)want;
+			S.iv_x0[rank] = posl ? (unsigned long long)(run + incl - lk) : mine.x0;
+			if (Store::NODES) S.iv_rank[rank] = mine.x0;
+			S.iv_n[rank] = cnt | ((big && (unsigned long long)cnt < mine.x2) ? 1 << 29 : 0) | big << 30;
 			S.iv_beg[rank] = (short)(mine.info >> 32); S.iv_end[rank] = (short)(uint32_t)mine.info;
 		}
 		run += uni64((long long)((unsigned long long)(unsigned)__shfl((int)(incl >> 32), 63) << 32 | (unsigned)__shfl((int)incl, 63)));
@@ -498,7 +510,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	for (int base = 0; base < n_iv; base += 64) { // totals with one pass over the table, 64 intervals at a time
 		const int i = base + lane;
 		const int v = i < n_iv ? S.iv_n[i] : 0;
-		const int c = v & 0x3fffffff;
+		const int c = v & 0x1fffffff;
 		if (__ballot(c > Store::SCAP)) over = 1;
 		if (__ballot(v >> 30)) any_big = 1;
 		tot += wave_sum_i32(c > Store::SCAP ? Store::SCAP : c);
@@ -523,14 +535,16 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			int run_o = 0;
 			for (int base = 0; base < n_iv; base += 64) {
 				const int ii = base + lane;
-				const int cnt = ii < n_iv ? (S.iv_n[ii] & 0x3fffffff) : 0;
+				const int cnt = ii < n_iv ? (S.iv_n[ii] & 0x1fffffff) : 0;
 				const int incl = wave_scan_sum_incl(cnt);
 				const int o0 = run_o + incl - cnt;
 				if (cnt) {
 					const unsigned long long x0 = S.iv_x0[ii];
 					const int qb = S.iv_beg[ii], slen = S.iv_end[ii] - qb;
+					const int lkc = (S.iv_n[ii] >> 30) && cnt > P.max_occ ? P.max_occ : cnt;   // looked up ahead; the rest is walked here
+					const unsigned long long rk0 = Store::NODES ? S.iv_rank[ii] : x0;
 					for (int c = 0; c < cnt; ++c) {
-						const long long pos = posl ? (long long)posl[x0 + (unsigned long long)c] : rg_sa(ix, parent, x0 + (unsigned long long)c, lf);
+						const long long pos = (posl && c < lkc) ? (long long)posl[x0 + (unsigned long long)c] : rg_sa(ix, parent, (posl ? rk0 : x0) + (unsigned long long)c, lf);
 						const int o = o0 + c;
 						S.s_rbeg[o] = pos; S.s_qbeg[o] = (short)qb; S.s_len[o] = (short)slen;
 						S.s_rid[o] = rg_intv2rid(ix, ctg, pos, pos + slen);
@@ -541,8 +555,10 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			}
 		} else
 		for (int o = lane; o < tot; o += 64) {
-			while (acc + (S.iv_n[i] & 0x3fffffff) <= o) { acc += S.iv_n[i] & 0x3fffffff; ++i; }
-			const long long pos = posl ? (long long)posl[S.iv_x0[i] + (unsigned long long)(o - acc)] : rg_sa(ix, parent, S.iv_x0[i] + (unsigned long long)(o - acc), lf);
+			while (acc + (S.iv_n[i] & 0x1fffffff) <= o) { acc += S.iv_n[i] & 0x1fffffff; ++i; }
+			const int kk_ = o - acc, vv_ = S.iv_n[i], lkc_ = (vv_ >> 30) && (vv_ & 0x1fffffff) > P.max_occ ? P.max_occ : (vv_ & 0x1fffffff);
+			const long long pos = (posl && kk_ < lkc_) ? (long long)posl[S.iv_x0[i] + (unsigned long long)kk_]
+			                                            : rg_sa(ix, parent, ((posl && Store::NODES) ? S.iv_rank[Store::NODES ? i : 0] : S.iv_x0[i]) + (unsigned long long)kk_, lf);
 			const int slen = S.iv_end[i] - S.iv_beg[i];
 			S.s_rbeg[o] = pos; S.s_qbeg[o] = S.iv_beg[i]; S.s_len[o] = (short)slen;
 			const int rid_ = rg_intv2rid(ix, ctg, pos, pos + slen);
@@ -577,6 +593,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	for (int r = 0; r < NR; ++r) { st_lo[r] = st_hi[r] = 0xffffffffu; st_id[r] = -1; }
 	int nc = 0, n_prom = 0;   // chains; those of them with a record (PCAP stores)
 	int cur_iv = -1, iv_stop = 0, iv_big = 0, count = 0;   // the interval the occurrence belongs to, and the chains it has started
+	int iv_more = 0, iv_o0 = 0;                            // (HBM tiers) the interval has occurrences beyond the ones listed; its first seed
 	// The LDS tiers first set aside the seeds that cannot meet any other: merge_seed_to_chain (memchain.c:227-256) only ever joins a
 	// seed to a chain whose last seed lies less than l_query + min(w, max_chain_gap) before it on the reference (rdist <= qdist + w,
 	// rdist - last->len < max_chain_gap) or whose span contains it, and every step inside a chain is that short too.  So cut the seeds,
@@ -647,11 +664,15 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			while (o >= iv_stop) { // next interval with occurrences
 				// an over-represented interval is walked past its first max_occ occurrences while it has started at most 5 chains
 				// (memchain.c:325-326): those further occurrences were not looked up, the host takes the strand search
-				if (iv_big && count < P.max_occ && count <= 5) return 10;
+				if (iv_more && count < P.max_occ && count <= 5) { if (lane == 0) S.boost_iv = cur_iv; return 10; }
 				++cur_iv;
 				const int v = uni(S.iv_n[cur_iv]);
-				iv_stop += v & 0x3fffffff; iv_big = v >> 30; count = 0;
+				iv_o0 = iv_stop;
+				iv_stop += v & 0x1fffffff; iv_big = v >> 30; iv_more = (v >> 29) & 1; count = 0;
 			}
+			// the loop condition of memchain.c:325-326: no more than max_occ chains from one interval; past the first max_occ occurrences only
+			// while it has started at most five
+			if (iv_big && (count >= P.max_occ || (count > 5 && o - iv_o0 >= P.max_occ))) { o = iv_stop - 1; continue; }
 		} else { // the seeds of the current piece, in arrival order; then the next piece with an empty table
 			while (cmask == 0 && piece < n_pieces) {
 				cbase += 64;
@@ -774,14 +795,14 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 		WAVE_SYNC();
 	}
-	if (Store::NODES && iv_big && count < P.max_occ && count <= 5) return 10;   // the last interval with occurrences, same rule
+	if (Store::NODES && iv_more && count < P.max_occ && count <= 5) { if (lane == 0) S.boost_iv = cur_iv; return 10; }   // the last interval with occurrences, same rule
 	const unsigned long long lt_mask_c = (1ull << lane) - 1;
 	if (!Store::NODES) {
 		WAVE_SYNC();
 		if (any_big) { // the same rule: an over-represented interval that started at most 5 chains would be walked further
 			int acc = 0;
 			for (int i = 0; i < n_iv; ++i) {
-				const int v = uni(S.iv_n[i]), cnt = v & 0x3fffffff;
+				const int v = uni(S.iv_n[i]), cnt = v & 0x1fffffff;
 				if (v >> 30) {
 					int heads = 0;
 					for (int b = acc; b < acc + cnt; b += 64) heads += __popcll(__ballot(b + lane < acc + cnt && (S.s_extra[b + lane < acc + cnt ? b + lane : acc] & 8)));
@@ -1793,7 +1814,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		int status = rg_task<RgSmall, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;   // exported: k_c2r makes and publishes its regions
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
-		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
+		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;   // (10: the HBM tiers walk an over-represented interval further)
 	}
 }
 
@@ -1828,7 +1849,20 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
-		int status = rg_task<Store, XSPLIT, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
+		// status 10: an over-represented interval has to be walked past its first max_occ occurrences; again with eight times as many of it, ...
+		int bi[4], bl[4], nb = 0, status;
+		for (;;) {
+			status = rg_task<Store, XSPLIT, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t, nb, bi, bl);
+			if (status != 10 || !Store::NODES || !P.walk_on) break;
+			WAVE_SYNC();
+			const int iv = uni(S.boost_iv);
+			int j = 0;
+			while (j < nb && bi[j] != iv) ++j;
+			if (j == nb) { if (nb == 4) break; bi[nb] = iv; bl[nb] = 8; ++nb; }
+			else if (bl[j] >= (1 << 20)) break;
+			else bl[j] <<= 3;
+			WAVE_SYNC();
+		}
 		if (status == 11) continue;   // exported (XSPLIT: chunks with long reads, whose chains go through k_seedsw and k_c2r)
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
@@ -1873,7 +1907,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		int status = rg_task<Store, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
-		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
+		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
 }
 
