@@ -155,6 +155,9 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
             ps = B.PhaseStats()
             L.bsx_last_phase_stats(C.byref(ps))
             assert ps.n_host_tasks * 5 < ps.n_tasks, (max_occ, ps.n_host_tasks, ps.n_tasks)
+            # with max_occ = 8 hundreds of strand searches have an over-represented interval that has to be walked past its first 8 occurrences
+            # (memchain.c:325-326): the HBM tiers do that themselves (533 of 240 000 were left to the host before they did, 27 since)
+            assert ps.n_host_tasks < 200, (max_occ, ps.n_host_tasks)
             a = crc()
             L.bsx_sim_reset_reads(p, 2 * n_pairs)
             os.environ["BSX_HOST_CHAIN"] = "1"
