@@ -132,7 +132,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
        DevIntv *scratch, int list_cap, int mem_cap,
        DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
        long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-       int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
+       int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof, unsigned int cold_mask, int cold_lanes)
 {
 	// per-wave slab, lane-interleaved: entry i of lane l sits at slab[i*64 + l], so the 64 lanes'
 	// accesses to the same list position form one contiguous 2 KB run (coalesced, one TLB page)
@@ -177,7 +177,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		const bool cold = !retired && !need;
 		const unsigned long long cm = __ballot(cold);
 		++trip;
-		const bool go_cold = cold && ((trip & 3u) == 0 || __popcll(cm) > 24 || __ballot(need) == 0);
+		const bool go_cold = cold && ((trip & cold_mask) == 0 || __popcll(cm) > cold_lanes || __ballot(need) == 0);
 		long long pc_c0 = 0;
 		if (prof && __ballot(go_cold)) { pc_c0 = clock64(); ++pc_cold_n; }
 		if (go_cold) {
@@ -297,9 +297,14 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
 {
 	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
 	// $BSX_SEED_FORM (measurements): 0 = blocks through registers and LDS stores, 1 = straight into LDS, 2 = that at four waves per SIMD (spills)
+	// the full state machine runs every (cold_mask + 1)-th trip, or when more than cold_lanes lanes wait for it ($BSX_SEED_COLD_EVERY, a power of two,
+	// $BSX_SEED_COLD_LANES).  The launch does not care (tools/seed_cold.sh: 208.2-209.8 ms from every 2nd trip / 16 lanes to every 16th / 32): what
+	// bounds it is the vector issue of the trips themselves -- 820 wave64 instructions at four cycles each on a 16-wide SIMD, three waves deep
+	static const unsigned int cold_mask = (getenv("BSX_SEED_COLD_EVERY") ? (unsigned int)atoi(getenv("BSX_SEED_COLD_EVERY")) : 4u) - 1u;
+	static const int cold_lanes = getenv("BSX_SEED_COLD_LANES") ? atoi(getenv("BSX_SEED_COLD_LANES")) : 24;
 	static const int form = getenv("BSX_SEED_FORM") ? atoi(getenv("BSX_SEED_FORM")) : SEED_FORM_DEFAULT;
 #define SEED_LAUNCH(...) hipLaunchKernelGGL((k_seed<__VA_ARGS__>), dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, \
-	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof)
+	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof, cold_mask, cold_lanes)
 	if (form == 0) SEED_LAUNCH(3, false, 24);
 	else if (form == 2) SEED_LAUNCH(4, true, 20);
 	else SEED_LAUNCH(3, true, 24);
