@@ -170,6 +170,30 @@ BSX_HD void dev_block_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t 
 	a = (uint32_t)n - nt - ng - nc; c = nc; g = ng; t = nt;
 }
 
+// ---- the device's own block layout.  In HBM the 128 symbols of a block are two BIT PLANES instead of the file's 2-bit fields: words 8-11
+// hold the low bit of symbols 0-31, 32-63, 64-95, 96-127 (the first symbol in the top bit), words 12-15 the high bit (k_bwt_planes turns
+// the file layout into this one, in place, right after the upload or the build).  A rank query then masks four words per plane with a
+// prefix mask and takes twelve population counts -- 40 vector instructions where the 2-bit fields cost 104 (a shift, two masks and a
+// combination per 16-symbol word), and the seeding kernel is bound by exactly those: a quarter of its instructions were the two block
+// counts of an extension.  The cumulative counts in words 0-7 are the file's.
+BSX_HD void dev_planes_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t &c, uint32_t &g, uint32_t &t)
+{
+	const int n = upto + 1;
+	uint32_t nt = 0, nh = 0, nl = 0;
+#define BSX_PLANE_WORD(L_, H_, off_) do { int nv = n - (off_); nv = nv < 0 ? 0 : (nv > 32 ? 32 : nv); \
+		const uint32_t m = (uint32_t)(0xffffffff00000000ull >> nv), lo = (L_) & m, hi = (H_) & m; \
+		nl += (uint32_t)dev_popc(lo); nh += (uint32_t)dev_popc(hi); nt += (uint32_t)dev_popc(lo & hi); } while (0)
+	BSX_PLANE_WORD(b.v2.x, b.v3.x, 0); BSX_PLANE_WORD(b.v2.y, b.v3.y, 32); BSX_PLANE_WORD(b.v2.z, b.v3.z, 64); BSX_PLANE_WORD(b.v2.w, b.v3.w, 96);
+#undef BSX_PLANE_WORD
+	t = nt; g = nh - nt; c = nl - nt; a = (uint32_t)n - nh - nl + nt;
+}
+BSX_HD int dev_planes_symbol(const DevBlock &b, int pos)   // the symbol at position pos (0..127) of the block
+{
+	const int p = pos >> 5, bit = 31 - (pos & 31);
+	const uint32_t lo = p == 0 ? b.v2.x : p == 1 ? b.v2.y : p == 2 ? b.v2.z : b.v2.w, hi = p == 0 ? b.v3.x : p == 1 ? b.v3.y : p == 2 ? b.v3.z : b.v3.w;
+	return (int)(((hi >> bit) & 1u) << 1 | ((lo >> bit) & 1u));
+}
+
 // bwt_2occ4 (lib/aln/bwt.c:204-236): ranks of all four symbols at k and l (scalars, no indexed arrays).
 // returns 1 when the reference would take its one-block fast path (one 64-B touch), else 0 (two).
 BSX_HD int dev_2occ4(const DevFmi &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])

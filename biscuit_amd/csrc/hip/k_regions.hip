@@ -308,12 +308,9 @@ __device__ __forceinline__ long long rg_sa(const DevIndex &ix, int parent, unsig
 		if (k == prim) { k = 0; ++steps; continue; }
 		const unsigned long long x = k - (k > prim);
 		const DevBlock B = dev_load_block4(bw, x);
-		const uint32_t wsel = (uint32_t)((x & 127) >> 4);
-		const uint32_t word = wsel == 0 ? B.v2.x : wsel == 1 ? B.v2.y : wsel == 2 ? B.v2.z : wsel == 3 ? B.v2.w :
-		                      wsel == 4 ? B.v3.x : wsel == 5 ? B.v3.y : wsel == 6 ? B.v3.z : B.v3.w;
-		const int c = (int)((word >> ((~x & 15) << 1)) & 3);
+		const int c = dev_planes_symbol(B, (int)(x & 127));
 		uint32_t ca, cc, cg, ct;
-		dev_block_count4(B, (int)(x & 127), ca, cc, cg, ct);
+		dev_planes_count4(B, (int)(x & 127), ca, cc, cg, ct);
 		const unsigned long long base = c == 0 ? ((unsigned long long)B.v0.y << 32 | B.v0.x) : c == 1 ? ((unsigned long long)B.v0.w << 32 | B.v0.z) :
 		                                c == 2 ? ((unsigned long long)B.v1.y << 32 | B.v1.x) : ((unsigned long long)B.v1.w << 32 | B.v1.z);
 		k = dev_ix_L2(ix, parent, c) + base + (c == 0 ? ca : c == 1 ? cc : c == 2 ? cg : ct);

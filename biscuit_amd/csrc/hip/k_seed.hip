@@ -64,7 +64,7 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 	const int rounds = (n + 15) >> 4;
 	uint64_t tk[4] = {0, 0, 0, 0}, tl[4] = {0, 0, 0, 0};
 	// block -> the four cumulative counts at position pos_ (bwt_occ4): counted as soon as a block is taken, so that only one is held in registers
-#define SEED_COUNT(B_, pos_, valid_, t_) do { uint32_t a_, c_, g_, t4_; dev_block_count4(B_, (int)((pos_) & 127), a_, c_, g_, t4_); \
+#define SEED_COUNT(B_, pos_, valid_, t_) do { uint32_t a_, c_, g_, t4_; dev_planes_count4(B_, (int)((pos_) & 127), a_, c_, g_, t4_); \
 		t_[0] = (valid_) ? ((uint64_t)B_.v0.y << 32 | B_.v0.x) + a_ : 0; t_[1] = (valid_) ? ((uint64_t)B_.v0.w << 32 | B_.v0.z) + c_ : 0; \
 		t_[2] = (valid_) ? ((uint64_t)B_.v1.y << 32 | B_.v1.x) + g_ : 0; t_[3] = (valid_) ? ((uint64_t)B_.v1.w << 32 | B_.v1.z) + t4_ : 0; } while (0)
 	// DIRECT: the pieces go from memory straight into the exchange slots (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, masked
@@ -276,11 +276,12 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 			// bwt_invPsi (bwt.c:54-60): symbol at k and its rank come from the same 64-byte block
 			if (k == f.primary) { k = 0; ++sa; ++steps; continue; }
 			uint64_t x = k - (k > f.primary);
-			uint64_t base[4]; uint32_t w[8], c4[4];
-			dev_load_block(f.bwt, x, base, w);
-			int c = (w[(x & 127) >> 4] >> ((~x & 15) << 1)) & 3;
-			dev_block_count(w, (int)(x & 127), c4);
-			k = dev_L2(f, c) + (c == 0 ? base[0] + c4[0] : c == 1 ? base[1] + c4[1] : c == 2 ? base[2] + c4[2] : base[3] + c4[3]);
+			const DevBlock B = dev_load_block4(f.bwt, x);
+			const int c = dev_planes_symbol(B, (int)(x & 127));
+			uint32_t c4[4];
+			dev_planes_count4(B, (int)(x & 127), c4[0], c4[1], c4[2], c4[3]);
+			const uint64_t b0 = (uint64_t)B.v0.y << 32 | B.v0.x, b1 = (uint64_t)B.v0.w << 32 | B.v0.z, b2 = (uint64_t)B.v1.y << 32 | B.v1.x, b3 = (uint64_t)B.v1.w << 32 | B.v1.z;
+			k = dev_L2(f, c) + (c == 0 ? b0 + c4[0] : c == 1 ? b1 + c4[1] : c == 2 ? b2 + c4[2] : b3 + c4[3]);
 			++sa; ++steps;
 		}
 		pos[i] = sa + f.sa[k >> f.sa_shift];
@@ -309,6 +310,37 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
 	else if (form == 2) SEED_LAUNCH(4, true, 20);
 	else SEED_LAUNCH(3, true, 24);
 }
+// the file's 2-bit symbol fields of every block into the device's bit planes (dev_common.hpp), in place; a thread per block
+__global__ void __launch_bounds__(256)
+k_bwt_planes(uint32_t *bwt, unsigned long long n_blocks)
+{
+	const unsigned long long blk = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (blk >= n_blocks) return;
+	uint4 *p = reinterpret_cast<uint4*>(bwt + blk * 16);
+	const uint4 v2 = p[2], v3 = p[3];
+	const uint32_t w[8] = {v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+	uint32_t lo[4], hi[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		uint32_t pl[2], ph[2];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) { // the even (low) and odd (high) bits of a word squeezed into 16 bits each, order kept
+			uint32_t e = w[2 * q + h] & 0x55555555u, o = (w[2 * q + h] >> 1) & 0x55555555u;
+			e = (e | e >> 1) & 0x33333333u; e = (e | e >> 2) & 0x0f0f0f0fu; e = (e | e >> 4) & 0x00ff00ffu; e = (e | e >> 8) & 0x0000ffffu;
+			o = (o | o >> 1) & 0x33333333u; o = (o | o >> 2) & 0x0f0f0f0fu; o = (o | o >> 4) & 0x00ff00ffu; o = (o | o >> 8) & 0x0000ffffu;
+			pl[h] = e; ph[h] = o;
+		}
+		lo[q] = pl[0] << 16 | pl[1]; hi[q] = ph[0] << 16 | ph[1];
+	}
+	p[2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+	p[3] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+void launch_bwt_planes(hipStream_t st, uint32_t *bwt, unsigned long long n_words)
+{
+	const unsigned long long n_blocks = (n_words + 15) / 16;
+	hipLaunchKernelGGL(k_bwt_planes, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, bwt, n_blocks);
+}
+
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters)
 {
 	hipLaunchKernelGGL(k_sa, dim3(grid), dim3(256), 0, st, ix, jobs, n, pos, counters);

@@ -8,6 +8,8 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof = 0);   // scratch holds n_slabs per-wave slabs; slab_busy[n_slabs] zeroed once
+// the symbols of every 64-byte block from the file's 2-bit fields into the device's two bit planes, in place (n_words: the .bwt body)
+void launch_bwt_planes(hipStream_t st, uint32_t *bwt, unsigned long long n_words);
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters);
 // DP kernels: one wavefront per job
 void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, const int *order,

@@ -190,6 +190,8 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 		if ((rc = d->bwt[i].reserve((size_t)f->bwt_size * 4 + 64)) != BSX_OK) return rc;
 		if ((rc = d->sa[i].reserve((size_t)f->n_sa * 8)) != BSX_OK) return rc;
 		HIPCHK(hipMemcpy(d->bwt[i].p, f->bwt, (size_t)f->bwt_size * 4, hipMemcpyHostToDevice));
+		launch_bwt_planes(d->lane[0].st, (uint32_t*)d->bwt[i].p, (unsigned long long)f->bwt_size);   // the device's block layout (dev_common.hpp); ahead of everything that reads symbols
+		HIPCHK(hipStreamSynchronize(d->lane[0].st));
 		HIPCHK(hipMemcpy(d->sa[i].p, f->sa, (size_t)f->n_sa * 8, hipMemcpyHostToDevice));
 		DevFmi &g = d->ix.fmi[i];
 		g.primary = f->primary; for (int k = 0; k < 5; ++k) g.L2[k] = f->L2[k];
@@ -252,6 +254,8 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 		}
 		rc = bsx_ix_build_fmi(L.st, d->n_cu, (const uint8_t*)d->pac.p, idx->ref.l_pac, i, dense, 32, &d->bwt[i], &d->sa[i], &meta, h_bwt, h_sa);
 		if (rc != BSX_OK) { free(h_bwt); free(h_sa); return rc; }
+		launch_bwt_planes(L.st, (uint32_t*)d->bwt[i].p, (unsigned long long)meta.bwt_size);   // (the host copy above is the file layout)
+		HIPCHK(hipStreamSynchronize(L.st));
 		*f = meta; f->bwt = h_bwt; f->sa = h_sa;   // bwt == NULL: the FM index lives on the device only
 		DevFmi &g = d->ix.fmi[i];
 		g.primary = meta.primary; for (int k = 0; k < 5; ++k) g.L2[k] = meta.L2[k];
