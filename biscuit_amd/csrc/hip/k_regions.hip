@@ -18,6 +18,7 @@
 #include "wave.hpp"
 #include "kernels.h"
 #include "ext_dp.hpp"
+#include "rgx.hpp"
 
 #define RG_QCAP 256
 #define RG_NC 4          // extension rows live in registers: 64 * RG_NC entries >= qlen + 1
@@ -132,16 +133,6 @@ __device__ __forceinline__ int rg_intv2rid(const DevIndex &ix, const long long *
 	const int b = rb < re ? rg_pos2rid(ix, ctg, rg_depos(ix.l_pac, re - 1)) : a;
 	return a == b ? a : -1;
 }
-__device__ __forceinline__ int rg_cal_max_gap(const RegParams &P, int qlen)   // memchain.c:576-582
-{
-	int l_del = (int)((double)(qlen * P.a - P.o_del) / P.e_del + 1.);
-	int l_ins = (int)((double)(qlen * P.a - P.o_ins) / P.e_ins + 1.);
-	int l = l_del > l_ins ? l_del : l_ins;
-	l = l > 1 ? l : 1;
-	return l < P.w << 1 ? l : P.w << 1;
-}
-// cal_max_gap for every length a read of this kernel can ask about, tabulated once per workgroup (two double divisions each)
-__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (unsigned)qlen <= (unsigned)P.gap_cap ? tab[qlen] : rg_cal_max_gap(P, qlen); }
 #define RG_BSS(parent, l_pac, rb) ((((rb) > (l_pac)) == (parent)) ? 1 : 0)
 
 // klib introsort (ksort.h:184-236) of the chains by weight, descending, with the control flow of
@@ -340,14 +331,6 @@ __device__ __forceinline__ int rg_flt_test(const RegParams &P, const RgChain &ci
 // wave at the larger size, six waves per CU), the chain-to-region loop needs registers and latency hiding (extension rows are
 // dependent DPP chains) but almost no tables.  One launch each, with the occupancy each can have.  What is exported per strand
 // search: the kept chains in processing order, each with its seeds (main list, then seeds_extra) in arrival order.
-struct RgXHdr { int n_chains, n_seeds; float frac_rep; int flt; };   // flt: min_HSP_score when the seed-SW filter applies to this read (k_seedsw runs before k_c2r), RG_NOFLT otherwise
-#define RG_NOFLT ((int)0x80000000)
-struct RgXChain { long long pos; int rid, seed_off; unsigned short n_main, n_extra; int pad; };
-struct RgXSeed { long long rbeg; short qbeg, len; int sb; };   // sb: mem_seed_t.score << 1 | failed asymmetric_flt_seed
-#define XS_BAD(x) ((x).sb & 1)
-#define XS_SCORE(x) ((x).sb >> 1)
-struct RgXPool { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
-
 // the record of chain `id` (by value); for a chain of one seed, made up from the seed (s_extra bit 2 = its contig is an ALT)
 template <typename Store>
 __device__ __forceinline__ RgChain rg_chain(const Store &S, int id)
@@ -387,7 +370,8 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 		WAVE_SYNC();
 	}
 	if (n_surv == 0) return 0;
-	const unsigned long long bytes = sizeof(RgXHdr) + (unsigned long long)n_surv * sizeof(RgXChain) + (unsigned long long)n_sd * sizeof(RgXSeed);
+	const int ext = X.ext && flt == RG_NOFLT;   // room for the extensions made ahead of k_c2r (k_ext4.hip); the seed-SW filter rewrites the lists after the export
+	const unsigned long long bytes = sizeof(RgXHdr) + (unsigned long long)n_surv * sizeof(RgXChain) + (unsigned long long)n_sd * sizeof(RgXSeed) + (ext ? (unsigned long long)n_surv * sizeof(RgXExt) : 0ull);
 	unsigned long long at = 0;
 	if (lane == 0) at = atomicAdd(X.cursor, bytes);
 	at = (unsigned long long)uni64((long long)at);
@@ -395,7 +379,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 	RgXHdr *H = (RgXHdr*)(X.base + at);
 	RgXChain *XC = (RgXChain*)(H + 1);
 	RgXSeed *XS = (RgXSeed*)(XC + n_surv);
-	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->flt = flt; }
+	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->flt = flt; H->has_ext = ext; H->pad = 0; }
 	int so = 0;
 	for (int ci = 0; ci < n_surv; ++ci) {
 		const int c = uni(S.ord[ci]);
@@ -1180,6 +1164,7 @@ struct RgC2rT {
 	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
 	bsx_region_t regs[RG_XREGS];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
+	RgXExt xe[RG_XCBLK];     // and, when the record has them, the extensions made ahead of this launch (k_ext4.hip)
 	RgXSeed sd[XSD];         // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
 	unsigned long long srt[XSD];
 	uint8_t q[QC];
@@ -1208,10 +1193,13 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 	const float frac_rep = H->frac_rep;
 	const unsigned long long *XCw = (const unsigned long long*)(H + 1);                           // RgXChain = 3 words, RgXSeed = 2
 	const unsigned long long *XSw = XCw + (size_t)nk * (sizeof(RgXChain) / 8);
+	const int has_ext = uni(H->has_ext);
+	const unsigned long long *XEw = XSw + (size_t)n_sd * (sizeof(RgXSeed) / 8);
 	if (lane == 0) W.n_regs = 0;
 	int xc_lo = 0, sd_lo = 0, sd_hi = 0;
 #define C2R_STAGE_CHAINS(from) do { const int n_ = (nk - (from) < RG_XCBLK ? nk - (from) : RG_XCBLK) * (int)(sizeof(RgXChain) / 8); \
-		for (int i_ = lane; i_ < n_; i_ += 64) ((unsigned long long*)W.xc)[i_] = XCw[(size_t)(from) * (sizeof(RgXChain) / 8) + i_]; xc_lo = (from); } while (0)
+		for (int i_ = lane; i_ < n_; i_ += 64) ((unsigned long long*)W.xc)[i_] = XCw[(size_t)(from) * (sizeof(RgXChain) / 8) + i_]; \
+		if (has_ext) for (int i_ = lane; i_ < n_ * 2; i_ += 64) ((unsigned long long*)W.xe)[i_] = XEw[(size_t)(from) * (sizeof(RgXExt) / 8) + i_]; xc_lo = (from); } while (0)
 #define C2R_STAGE_SEEDS(from) do { const int m_ = n_sd - (from) < WT::XSEEDS ? n_sd - (from) : WT::XSEEDS; \
 		for (int i_ = lane; i_ < m_ * 2; i_ += 64) ((unsigned long long*)W.sd)[i_] = XSw[(size_t)(from) * 2 + i_]; sd_lo = (from); sd_hi = (from) + m_; } while (0)
 	C2R_STAGE_CHAINS(0);
@@ -1301,8 +1289,11 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 					}
 					if (!any) { WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
-				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
-				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
+				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths -- taken from the record when this
+				// is the seed k_ext4 extended ahead of the loop (the first one the loop reaches in a chain's main list)
+				const RgXExt &xe = W.xe[ci - xc_lo];
+				const bool cached = has_ext && pass == 0 && uni(xe.status) == 1 && uni(xe.si) == si;
+				if (!cached && win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
 					if (span > 0 && span <= WT::WINCAP) {
 						dev_fetch_window(W.win, ix.pac, l_pac, rmax0, span, lane);
@@ -1314,6 +1305,10 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 				int aw0 = P.w, aw1 = P.w;
 				const int qe = s_qbeg + s_len;
 				R.score = R.truesc = -1; R.rid = rid;
+				if (cached) {
+					R.rb = uni64(xe.rb); R.re = uni64(xe.re); R.qb = uni(xe.qb); R.qe = uni(xe.qe); R.score = uni(xe.score); R.truesc = uni(xe.truesc);
+					aw0 = uni(xe.aw0); aw1 = uni(xe.aw1);
+				} else
 				for (int side = 0; side < 2; ++side) {
 					if (side == 0 && s_qbeg == 0) { R.score = R.truesc = s_len * P.a; R.qb = 0; R.rb = s_rbeg; continue; }
 					if (side == 1 && qe == l_query) { R.qe = l_query; R.re = s_rbeg + s_len; continue; }
@@ -1508,267 +1503,6 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 		WAVE_SYNC();
 	}
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Chains -> regions in lock-step rounds, a LANE per strand search and a LANE per extension.
-//
-// k_c2r above gives every strand search a wavefront: its seed loop is a few hundred scalar steps between extensions, and an
-// extension row costs ~400 instructions, two thirds of them scalar (band bookkeeping, uniform branches, DPP wait states), whatever
-// the width of the band -- the launch is bound by the one scalar unit a CU has (PMC: 9.4e10 SALU for 1.65e7 extensions).  The work
-// itself is the opposite of wave-shaped: a band of a dozen live cells, sequential along the row (F), a strictly ordered series of
-// such calls per strand search, millions of strand searches.  So the roles are turned: each lane runs the reference's own loop
-// nest for one job, nothing crosses lanes, and the parallelism comes from the number of jobs in flight.
-//   k_c2r_ctrl   a lane per strand search: mem_chain2region(1) (memchain.c:742-904) as a resumable state machine; it runs until the
-//                strand search needs an extension (posts one job: left or right side of one seed, one band width) or is finished
-//                (publishes its regions)
-//   k_ext_q      a row of 16 lanes per job, four jobs per wavefront: ksw_extend2 (ksw.c:380-479) with the DP rows in registers and
-//                nothing in scalar registers (k_extq.hip)
-// and the two alternate: round r extends the r-th call of every strand search that has one.  State between rounds lives in HBM.
-// A strand search whose lists or region table outgrow the fixed slots, or that is still going after RG_LROUNDS rounds, is
-// handed to the HBM tier like any other that outgrows a tier.
-#define RG_LROUNDS 128
-#define RG_LSEEDS 128     // seeds of one list held in the rank array
-#define RG_LREGS 24
-
-struct RgLState {
-	int ci, k, n0, sc0, aw0, aw1, rid, n_regs;
-	short pass, stage, tryi, opened;   // stage: 0 no job out, 1 left extension out, 2 right extension out
-	long long rmax0, rmax1;
-	bsx_region_t cur;
-};
-struct RgLanes {   // everything k_c2r_ctrl / k_ext_lane keep between rounds (device pointers)
-	RgLState *state;            // per exported strand search (slot = index in xlist)
-	bsx_region_t *regs;         // RG_LREGS per slot
-	unsigned char *rank;        // RG_LSEEDS per slot: seed index at each rank of the open list (bit 7: dropped, memchain.c:817)
-	int *act[2];                // slots with a job out, by round parity
-	bsx_ext_job_t *jobs[2];
-	bsx_ext_res_t *res[2];
-	unsigned int *n_act;        // [0, 192): jobs posted in each round; [192, 384): k_ext_lane's job cursor of each round; then tracing sums
-};
-
-__device__ __forceinline__ void rgl_left_job(const RegParams &P, const RgLState &S, const RgXSeed &sd, uint32_t qoff, int parent, bsx_ext_job_t &J)
-{
-	J.qoff = qoff + (uint32_t)sd.qbeg - 1; J.qdir = -1; J.qlen = sd.qbeg; J.tpos = sd.rbeg - 1; J.tdir = -1; J.tlen = (int)(sd.rbeg - S.rmax0);
-	J.h0 = sd.len * P.a; J.w = P.w << S.tryi; J.end_bonus = P.pen_clip5; J.parent = (uint8_t)parent; J.pad = 0;
-}
-__device__ __forceinline__ void rgl_right_job(const RegParams &P, const RgLState &S, const RgXSeed &sd, uint32_t qoff, int parent, int l_query, bsx_ext_job_t &J)
-{
-	const int qe = sd.qbeg + sd.len;
-	J.qoff = qoff + (uint32_t)qe; J.qdir = 1; J.qlen = l_query - qe; J.tpos = sd.rbeg + sd.len; J.tdir = 1; J.tlen = (int)(S.rmax1 - (sd.rbeg + sd.len));
-	J.h0 = S.sc0; J.w = P.w << S.tryi; J.end_bonus = P.pen_clip3; J.parent = (uint8_t)parent; J.pad = 0;
-}
-
-// One strand search, until it posts a job (returns 1), is finished (0), or outgrows the slots (< 0: the status to decline with).
-// `have_res`: the result of the job posted in the previous round.
-__device__ int rgl_step(RgLState &S, bsx_region_t *regs, unsigned char *rank, const DevIndex &ix, const RegParams &P, int l_query, int parent, uint32_t qoff,
-                        const RgXHdr *H, const int *gap, const long long *ctg, bool have_res, const bsx_ext_res_t &res, bsx_ext_job_t &J)
-{
-	const long long l_pac = ix.l_pac;
-	const int nk = H->n_chains;
-	const RgXChain *XC = (const RgXChain*)(H + 1);
-	const RgXSeed *XS = (const RgXSeed*)(XC + nk);
-	bool to_right = false, to_finish = false;
-	if (have_res) { // feed the result back (left: memchain.c:641-671, right: memchain.c:700-729)
-		const RgXChain ch = XC[S.ci];
-		const RgXSeed sd = XS[ch.seed_off + (S.pass ? ch.n_main : 0) + (rank[S.k] & 127)];
-		const int prev = S.cur.score, aw = P.w << S.tryi;
-		S.cur.score = res.score;
-		const bool again = !(S.cur.score == prev || res.max_off < (aw >> 1) + (aw >> 2)) && S.tryi + 1 < 2;   // MAX_BAND_TRY = 2
-		if (S.stage == 1) {
-			S.aw0 = aw;
-			if (again) { ++S.tryi; rgl_left_job(P, S, sd, qoff, parent, J); return 1; }
-			if (res.gscore <= 0 || res.gscore <= S.cur.score - P.pen_clip5) { S.cur.qb = sd.qbeg - res.qle; S.cur.rb = sd.rbeg - res.tle; S.cur.truesc = S.cur.score; }
-			else { S.cur.qb = 0; S.cur.rb = sd.rbeg - res.gtle; S.cur.truesc = res.gscore; }
-			to_right = true;
-		} else {
-			const int qe = sd.qbeg + sd.len;
-			S.aw1 = aw;
-			if (again) { ++S.tryi; rgl_right_job(P, S, sd, qoff, parent, l_query, J); return 1; }
-			if (res.gscore <= 0 || res.gscore <= S.cur.score - P.pen_clip3) { S.cur.qe = qe + res.qle; S.cur.re = sd.rbeg + sd.len + res.tle; S.cur.truesc += S.cur.score - S.sc0; }
-			else { S.cur.qe = l_query; S.cur.re = sd.rbeg + sd.len + res.gtle; S.cur.truesc += res.gscore - S.sc0; }
-			to_finish = true;
-		}
-	}
-	for (;;) {
-		if (S.ci >= nk) return 0;
-		const RgXChain ch = XC[S.ci];
-		const int n_main = ch.n_main, n_extra = ch.n_extra;
-		if (!S.opened) {
-			if (n_main > RG_LSEEDS || n_extra > RG_LSEEDS) return -2;
-			// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp
-			long long r0 = l_pac << 1, r1 = 0;
-			for (int o = 0; o < n_main; ++o) {
-				const RgXSeed sd = XS[ch.seed_off + o];
-				const long long b = sd.rbeg - (sd.qbeg + rg_gap(gap, P, sd.qbeg));
-				const long long e = sd.rbeg + sd.len + ((l_query - sd.qbeg - sd.len) + rg_gap(gap, P, l_query - sd.qbeg - sd.len));
-				r0 = r0 < b ? r0 : b; r1 = r1 > e ? r1 : e;
-			}
-			r0 = r0 > 0 ? r0 : 0; r1 = r1 < l_pac << 1 ? r1 : l_pac << 1;
-			if (r0 < l_pac && l_pac < r1) { if (ch.pos < l_pac) r1 = l_pac; else r0 = l_pac; }
-			{
-				long long far_beg = ctg[ch.rid], far_end = ctg[ch.rid + 1];
-				if (ch.pos >= l_pac) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
-				r0 = r0 > far_beg ? r0 : far_beg; r1 = r1 < far_end ? r1 : far_end;
-			}
-			S.rmax0 = r0; S.rmax1 = r1; S.rid = ch.rid; S.n0 = S.n_regs; S.pass = 0; S.opened = 1; S.stage = 0;
-			S.k = -2;   // list not ranked yet
-		}
-		const int nl = S.pass ? n_extra : n_main;
-		const RgXSeed *list = XS + ch.seed_off + (S.pass ? n_main : 0);
-		if (S.k == -2) { // best-first order: ranks by (len, index) ascending (ks_introsort_64 on score<<32|i, memchain.c:748-752), insertion sort
-			for (int i = 0; i < nl; ++i) {
-				const int li = list[i].len;
-				int p = i;
-				while (p > 0 && list[rank[p - 1]].len > li) { rank[p] = rank[p - 1]; --p; }   // equal lengths keep index order
-				rank[p] = (unsigned char)i;
-			}
-			S.k = nl - 1;
-		}
-		RgXSeed sd_cur; sd_cur.rbeg = 0; sd_cur.qbeg = sd_cur.len = 0; sd_cur.sb = 0;
-		if (to_right || to_finish) sd_cur = list[rank[S.k] & 127];
-		bool finish = to_finish;
-		if (to_right) { // after the left side is settled: skip or post the right extension (memchain.c:689-693)
-			to_right = false;
-			if (sd_cur.qbeg + sd_cur.len == l_query) { S.cur.qe = l_query; S.cur.re = sd_cur.rbeg + sd_cur.len; finish = true; }
-			else { S.sc0 = S.cur.score; S.tryi = 0; S.stage = 2; rgl_right_job(P, S, sd_cur, qoff, parent, l_query, J); return 1; }
-		}
-		if (finish) { // region complete: strand-boundary check, seed coverage, book-keeping (memchain.c:839-869)
-			to_finish = false;
-			bsx_region_t &R = S.cur;
-			R.bss = (uint8_t)RG_BSS(parent, l_pac, R.rb); R.parent = (uint8_t)parent;
-			if (RG_BSS(parent, l_pac, R.re) == R.bss) {
-				int cov = 0;
-				for (int i = 0; i < nl; ++i) {
-					const RgXSeed td = list[i];
-					if (td.qbeg >= R.qb && td.qbeg + td.len <= R.qe && td.rbeg >= R.rb && td.rbeg + td.len <= R.re) cov += td.len;
-				}
-				R.seedcov = cov; R.w = S.aw0 > S.aw1 ? S.aw0 : S.aw1; R.seedlen0 = sd_cur.len; R.frac_rep = H->frac_rep;
-				if (S.n_regs == RG_LREGS) return -6;
-				regs[S.n_regs++] = R;
-			}
-			--S.k; S.stage = 0;
-		}
-		bool posted = false;
-		while (S.k >= 0) {
-			const int si = rank[S.k] & 127;
-			const RgXSeed sd = list[si];
-			if (XS_BAD(sd)) { --S.k; continue; }   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
-			// is the seed inside a region this strand search already produced? (memchain.c:761-790)
-			int u;
-			for (u = 0; u < S.n_regs; ++u) {
-				const bsx_region_t rg = regs[u];
-				if (sd.rbeg < rg.rb || sd.rbeg + sd.len > rg.re || sd.qbeg < rg.qb || sd.qbeg + sd.len > rg.qe) continue;
-				if (sd.len - rg.seedlen0 > .1 * l_query) continue;
-				int qd = sd.qbeg - rg.qb; long long rd = sd.rbeg - rg.rb;
-				int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-				int w = max_gap < rg.w ? max_gap : rg.w;
-				if (qd - rd < w && rd - qd < w) break;
-				qd = rg.qe - (sd.qbeg + sd.len); rd = rg.re - (sd.rbeg + sd.len);
-				max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
-				w = max_gap < rg.w ? max_gap : rg.w;
-				if (qd - rd < w && rd - qd < w) break;
-			}
-			if (u < S.n_regs) { // contained: extend anyway only if an overlapping long seed disagrees (memchain.c:794-819)
-				int i;
-				for (i = S.k + 1; i < nl; ++i) {
-					if (rank[i] & 128) continue;
-					const RgXSeed td = list[rank[i]];
-					if (td.len < sd.len * .95) continue;
-					if (sd.qbeg <= td.qbeg && sd.qbeg + sd.len - td.qbeg >= sd.len >> 2 && td.qbeg - sd.qbeg != td.rbeg - sd.rbeg) break;
-					if (td.qbeg <= sd.qbeg && td.qbeg + td.len - sd.qbeg >= sd.len >> 2 && sd.qbeg - td.qbeg != sd.rbeg - td.rbeg) break;
-				}
-				if (i == nl) { rank[S.k] |= 128; --S.k; continue; }
-			}
-			// extend this seed (memchain.c:822-836)
-			memset(&S.cur, 0, sizeof(S.cur));
-			S.aw0 = S.aw1 = P.w;
-			S.cur.score = S.cur.truesc = -1; S.cur.rid = S.rid;
-			if (sd.qbeg == 0) { // nothing to the left (memchain.c:623-626)
-				S.cur.score = S.cur.truesc = sd.len * P.a; S.cur.qb = 0; S.cur.rb = sd.rbeg;
-				to_right = true;
-			} else { S.tryi = 0; S.stage = 1; rgl_left_job(P, S, sd, qoff, parent, J); return 1; }
-			posted = true;   // (not a job: the right side is decided at the top of the outer loop)
-			break;
-		}
-		if (posted) continue;
-		// list exhausted: fall back to the contained seeds if the chain produced nothing (memchain.c:898-901)
-		if (S.pass == 0 && S.n_regs == S.n0 && n_extra > 0) { S.pass = 1; S.k = -2; continue; }
-		++S.ci; S.opened = 0;
-	}
-}
-
-__global__ void __launch_bounds__(256)
-k_c2r_ctrl(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, RgLanes W, int round,
-           bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-           int *next_list, unsigned int *next_count)
-{
-	__shared__ int gap_tab[RG_QCAP + 1];
-	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	P.gap_cap = RG_QCAP;
-	for (int q = threadIdx.x; q <= RG_QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
-	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
-	const long long *ctg = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
-	__syncthreads();
-	const unsigned int n = round == 0 ? *X.xcount : W.n_act[round - 1];
-	const int in = (round + 1) & 1, ob = round & 1;   // jobs of round r live in buffer r & 1
-	for (unsigned int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-		const int slot = round == 0 ? (int)e : W.act[in][e];
-		const int t = X.xlist[slot];
-		const int l_query = tasks[t].len, parent = tasks[t].parent;
-		const uint32_t qoff = tasks[t].qoff;
-		const RgXHdr *H = (const RgXHdr*)(X.base + X.xoff[t]);
-		RgLState S;
-		bsx_ext_res_t res; res.score = 0; res.qle = res.tle = res.gtle = res.gscore = res.max_off = 0;
-		if (round == 0) { memset(&S, 0, sizeof(S)); }
-		else { S = W.state[slot]; res = W.res[in][e]; }
-		bsx_ext_job_t J;
-		int st = round + 1 >= RG_LROUNDS ? -6 : rgl_step(S, W.regs + (size_t)slot * RG_LREGS, W.rank + (size_t)slot * RG_LSEEDS, ix, P, l_query, parent, qoff, H, gap_tab, ctg, round != 0, res, J);
-		if (round != 0 && res.score == EXTQ_DECLINED) st = -6;   // the extension did not fit the quarter-wave kernel's rows or number format
-		if (st == 1) {
-			const unsigned int o = atomicAdd(&W.n_act[round], 1u);
-			W.act[ob][o] = slot; W.jobs[ob][o] = J;
-			W.state[slot] = S;
-		} else {
-			const int nr = st == 0 ? S.n_regs : 0;
-			unsigned long long base = 0;
-			int status = st == 0 ? 0 : -st;
-			if (nr > 0) {
-				base = atomicAdd(out_cursor, (unsigned long long)nr);
-				if (base + nr <= out_cap) { const bsx_region_t *rg = W.regs + (size_t)slot * RG_LREGS; for (int k = 0; k < nr; ++k) out[base + k] = rg[k]; }
-				else status = 7;
-			}
-			reg_off[t] = (long long)base;
-			reg_n[t] = status ? -status : nr;
-			if (status == 2 || status == 6) next_list[atomicAdd(next_count, 1u)] = t;
-		}
-	}
-}
-
-void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
-                      const RgXPoolArg &XA, const RgLanesArg &WA, long long n_tasks, int max_qlen,
-                      bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                      int *next_list, unsigned int *next_count)
-{
-	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
-	RgLanes W;
-	W.state = (RgLState*)WA.state; W.regs = (bsx_region_t*)WA.regs; W.rank = WA.rank; W.n_act = WA.n_act;
-	for (int k = 0; k < 2; ++k) { W.act[k] = WA.act[k]; W.jobs[k] = (bsx_ext_job_t*)WA.jobs[k]; W.res[k] = (bsx_ext_res_t*)WA.res[k]; }
-	// grids shrink with the rounds: most strand searches need a handful of extensions (the kernels loop over what is there)
-	for (int r = 0; r < RG_LROUNDS; ++r) {
-		const long long upper = r < 4 ? n_tasks : r < 12 ? n_tasks / 2 + 1 : r < 32 ? n_tasks / 8 + 1 : n_tasks / 64 + 1;
-		const int gc = (int)std::max<long long>(1, std::min<long long>((upper + 255) / 256, (long long)n_cu * 16));
-		hipLaunchKernelGGL(k_c2r_ctrl, dim3(gc), dim3(256), 0, st, ix, P, tasks, X, W, r, out, out_cap, out_cursor, reg_off, reg_n, next_list, next_count);
-		if (r + 1 == RG_LROUNDS) break;
-		// the jobs of round r (count: n_act[r]): the narrow ones a lane each (k_ext_n; cursor n_act[192 + r]), what it leaves -- listed in
-		// wide[r & 1], count n_act[512 + r] -- four per wavefront (k_ext_q; cursor n_act[640 + r])
-		unsigned long long *pf = P.prof ? (unsigned long long*)(W.n_act + 384) : nullptr;
-		int *wl = WA.wide + (size_t)(r & 1) * (size_t)n_tasks;
-		launch_ext_n(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + r, (unsigned int)upper, W.n_act + 192 + r, wl, W.n_act + 512 + r, pf);
-		launch_ext_q(st, n_cu, ix, sc, reads, W.jobs[r & 1], W.res[r & 1], W.n_act + 512 + r, (unsigned int)(upper / 4 + 1), W.n_act + 640 + r, max_qlen, wl, pf);
-	}
-}
-int c2r_lanes_max_query(void) { return ext_q_max_query(16) < RG_QCAP ? ext_q_max_query(16) : RG_QCAP; }
-size_t c2r_lanes_state_bytes(void) { return sizeof(RgLState); }
 
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
 #ifndef RG_WPB
@@ -1999,7 +1733,7 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
                     const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA, int long_reads)
 {
-	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	RgXPool X = rgx_pool(&XA);
 	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
 	if (long_reads)
 		hipLaunchKernelGGL((k_regions<3, RgDpLiteL>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
@@ -2018,7 +1752,7 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &XA, int quota, int long_reads)
 {
-	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	RgXPool X = rgx_pool(&XA);
 	if (long_reads == 3)   // kilobase reads, the larger of the two table sizes
 		hipLaunchKernelGGL((k_regions_mid<RgLongB, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
@@ -2036,7 +1770,7 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
                 const RgXPoolArg &XA, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                 unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads)
 {
-	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	RgXPool X = rgx_pool(&XA);
 	if (long_reads)
 		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 	else
@@ -2048,8 +1782,7 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
                          unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg *XA)
 {
-	RgXPool X; X.base = nullptr; X.cap = 0; X.cursor = nullptr; X.xoff = nullptr; X.xlist = nullptr; X.xcount = nullptr;
-	if (XA) { X.base = XA->base; X.cap = XA->cap; X.cursor = XA->cursor; X.xoff = XA->xoff; X.xlist = XA->xlist; X.xcount = XA->xcount; }
+	RgXPool X = rgx_pool(XA);
 	// XA given: the tier stops after the chain filter and exports (chunks with long reads or an active seed-SW filter)
 	if (tier == 4 && XA)
 		hipLaunchKernelGGL((k_regions_slab<RgBigP, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
@@ -2070,7 +1803,7 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 void launch_seedsw(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                    const RgXPoolArg &XA, unsigned int *cursor, unsigned long long *counters)
 {
-	RgXPool X; X.base = XA.base; X.cap = XA.cap; X.cursor = XA.cursor; X.xoff = XA.xoff; X.xlist = XA.xlist; X.xcount = XA.xcount;
+	RgXPool X = rgx_pool(&XA);
 	hipLaunchKernelGGL(k_seedsw, dim3(grid), dim3(64), 0, st, ix, sc, P, reads, tasks, X, cursor, counters);
 }
 int regions_long_max_query(void) { return RG_QCAP_LONG; }

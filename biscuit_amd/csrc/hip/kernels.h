@@ -27,25 +27,27 @@ void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const u
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                    long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb,
                    bsx_glb_tag_t *tags = nullptr, char *md_pool = nullptr, unsigned long long md_cap = 0, unsigned long long *md_cursor = nullptr, int tcap = 0);
-// K4 in quarter-waves (k_extq.hip): a row of 16 lanes per job, four jobs per wavefront, persistent rows taking jobs[0 .. n) off *cursor
-// (zero at launch); n = *n_ptr (a device counter) if n_ptr, else n_upper, which also sizes the grid.  Jobs it cannot hold (query longer
-// than ext_q_max_query(16), scores of 2^21 or more) are answered with score = EXTQ_DECLINED.
-#define EXTQ_DECLINED (-0x7fffffff)
-int ext_q_max_query(int ncq);
-void launch_ext_q(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
-                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int max_qlen, const int *list, unsigned long long *prof);
-// K4 for the narrow jobs, a lane per job (k_ext_n in k_extq.hip): the jobs of jobs[0 .. n) that start from a short seed and stay inside a
-// ring of 32 columns are answered; the indices of the others are appended to wide_list (count in *wide_count, zero at launch) for
-// launch_ext_q(..., list = wide_list)
-void launch_ext_n(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
-                  const unsigned int *n_ptr, unsigned int n_upper, unsigned int *cursor, int *wide_list, unsigned int *wide_count, unsigned long long *prof);
+// K4 four to a wavefront (k_ext4.hip): a row of 16 lanes per job, persistent rows taking jobs off *cursor (zero at launch).
+// launch_x4: the extensions of the best seed of every chain the tiers exported (records with has_ext), written into the records ahead of
+// launch_c2r; jobs = room for job_cap jobs of x4_job_bytes(), ctr32[0..1] zero at launch (job count, cursor).
+// launch_ext4_batch: plain ksw_extend2 jobs through the same rows (tests); jobs it cannot hold (query longer than x4_max_query(16),
+// scores of 2^21 or more) are answered with score = X4_DECLINED.
+#define X4_DECLINED (-0x7fffffff)
+int x4_max_query(int ncq);
+size_t x4_job_bytes(void);
+struct RgXPoolArg;
+void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+               long long n_tasks, const RgXPoolArg &X, void *jobs, unsigned long long job_cap, unsigned int *ctr32, unsigned long long *prof);
+void launch_ext4_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+                       unsigned int n, unsigned int *cursor, int max_qlen);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.
 // Tier 1 keeps its tables in LDS; tiers 2 and 3 run what did not fit over per-wave slabs in HBM (grid * 4 slabs of
 // regions_slab_bytes(tier)); a tier appends what it declines for table size to the next tier's list.
 size_t regions_slab_bytes(int tier);
 // where the LDS tiers leave the chains that survive the filter for launch_c2r (chains -> regions): a byte pool with a bump cursor,
 // the block of task t at xoff[t], and the list of tasks that have one
-struct RgXPoolArg { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount; };
+struct RgXPoolArg { unsigned char *base; unsigned long long cap; unsigned long long *cursor; long long *xoff; int *xlist; unsigned int *xcount;
+                    int ext; };   // ext: the records leave room for the extensions launch_x4 makes ahead of launch_c2r
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                     bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
@@ -57,16 +59,6 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
                         bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                         const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
                         unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg &X, int quota, int long_reads = 0);   // quota: strand searches per wave; long_reads: the instantiation for reads up to regions_long_max_query()
-// the same in lock-step rounds, a lane per strand search (control) and a lane per extension (DP): see k_regions.hip.  State between
-// rounds: state (c2r_lanes_state_bytes() per task), regs (24 regions per task), rank (128 B per task), act/jobs/res per round parity
-// (4 / sizeof(bsx_ext_job_t) / sizeof(bsx_ext_res_t) bytes per task), n_act (64 u32, zeroed per chunk)
-struct RgLanesArg { void *state, *regs; unsigned char *rank; int *act[2]; void *jobs[2], *res[2]; unsigned int *n_act; int *wide; };   // wide: a job list per round parity (2 x n ints)
-size_t c2r_lanes_state_bytes(void);
-int c2r_lanes_max_query(void);   // reads longer than this take the wave-per-strand-search launch (launch_c2r)
-void launch_c2r_lanes(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
-                      const RgXPoolArg &X, const RgLanesArg &W, long long n_tasks, int max_qlen,
-                      bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                      int *next_list, unsigned int *next_count);
 // chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

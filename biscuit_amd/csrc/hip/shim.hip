@@ -30,7 +30,7 @@ struct Lane {
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
-	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, lanes_state, lanes_regs, lanes_misc, tags, mdpool, dd;
+	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -132,7 +132,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.lanes_state.release(); L.lanes_regs.release(); L.lanes_misc.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -581,9 +581,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
 	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
 	// what the LDS tiers export for the chains -> regions launch: ~0.5 KB per strand search (a task that finds no room goes to the next tier)
-	const unsigned long long xcap = (unsigned long long)n * 1024 * lf + (64u << 20);
+	const unsigned long long xcap = (unsigned long long)n * 2560 * lf + (64u << 20);   // (a dozen chains per strand search at hg38 size: 24 + 16 bytes each, 48 more for its extensions)
 	if ((rc = L.xpool.reserve((size_t)xcap)) != BSX_OK) return rc;
 	if ((rc = L.xmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	// the extensions of the exported chains' best seeds are made ahead of chains -> regions, four to a wavefront (k_ext4.hip); $BSX_X4=0: all
+	// of them inline in k_c2r (the tests compare the two).  Not for chunks whose lists the seed-SW filter rewrites after the export.
+	static const int use_x4 = getenv("BSX_X4") ? atoi(getenv("BSX_X4")) : 1;
+	const unsigned long long x4_cap = (unsigned long long)n * 12 * lf + (1u << 20);
+	if (use_x4 && !export_all && (rc = L.x4jobs.reserve((size_t)x4_cap * x4_job_bytes())) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
@@ -601,6 +606,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	RgXPoolArg XA;
 	XA.base = (unsigned char*)L.xpool.p; XA.cap = xcap; XA.cursor = ctr + 13; XA.xoff = (long long*)L.xmeta.p; XA.xlist = (int*)((char*)L.xmeta.p + (size_t)n * 8);
 	XA.xcount = (unsigned int*)(ctr + 14);
+	XA.ext = use_x4 && !export_all ? 1 : 0;
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
 	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
 	L.rb_tasks = n;
@@ -634,15 +640,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// strand searches a wave of the larger LDS tier / of the chains -> regions launch takes before it leaves (bounded workgroup life)
 	static const int mid_quota = getenv("BSX_MID_QUOTA") ? std::max(1, atoi(getenv("BSX_MID_QUOTA"))) : 8;
 	static const int c2r_quota = getenv("BSX_C2R_QUOTA") ? std::max(1, atoi(getenv("BSX_C2R_QUOTA"))) : 16;
-	static const int use_lanes = getenv("BSX_C2R_LANES") ? atoi(getenv("BSX_C2R_LANES")) : 0;
 	// The tier sequence over a task list (the chunk's, and once more the re-seeded strand searches' on the side stream).  k32: u32 cursors and
 	// counts ([0] tier-1 cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor [5] k_seedsw's cursor [10] what the
 	// larger LDS tier hands on [11] its cursor); xc32: exported count | k_c2r's cursor.
-	const bool trace_tiers = getenv("BSX_PHASES") != nullptr;
+	const bool trace_tiers = getenv("BSX_PHASES") != nullptr || getenv("BSX_TIERS") != nullptr;   // $BSX_TIERS: the launch times alone (no cycle counters in the kernels)
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
-	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor) -> int {
+	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
@@ -657,18 +662,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, ra, k32 + 1, k32 + 11, rm, k32 + 10, ctr, posoffs, d_pos, XP, mid_quota, long_reads);
 		TIER_MARK("tier 1b");
 		int *to2 = use_mid ? rm : ra; unsigned int *n2c = use_mid ? k32 + 10 : k32 + 1;
-		// $BSX_REGIONS_1C=1: a third LDS tier for what outgrows the second (reads inside repeat families: the 768-interval / 1536-seed tables
-		// made for kilobase reads, two waves per CU).  Measured and off: 378 against 343 ms per chunk on the clean genome, 1337 against 1088 on
-		// the hg38-like one -- two waves per CU at LDS speed lose to eight at HBM speed (as the 512-seed tier tried earlier in round 3 did).
-		static const int use_1c = getenv("BSX_REGIONS_1C") ? atoi(getenv("BSX_REGIONS_1C")) : 0;
 		if (use_mid && long_reads) { // kilobase reads: a second LDS tier with larger tables (two workgroups per CU) for what outgrows the first (three)
 			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 3);
-			to2 = rl; n2c = l_count;
-			TIER_MARK("tier 1c");
-		} else if (use_mid && use_1c && !export_all) {
-			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
-			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 2);   // (the launch covers the worst case: every strand search on the list)
 			to2 = rl; n2c = l_count;
 			TIER_MARK("tier 1c");
 		}
@@ -688,20 +684,17 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			return BSX_OK;
 		}
 		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
-		// Two forms, same regions (the tests run both).  Default: a wavefront per strand search with the extensions inline (k_c2r).
-		// $BSX_C2R_LANES=1: lock-step rounds -- a lane per strand search runs the reference's seed loop until it needs an extension
-		// (k_c2r_ctrl: 24 ms per chunk in all), then the extensions of the round run a lane per narrow job (k_ext_n) and four to a
-		// wavefront (k_ext_q, k_extq.hip): 255 ms per chunk as measured in round 3 against k_c2r's 150 ms.
 		// $BSX_SLAB_EXPORT=1: the first HBM tier stops after the chain filter and exports too (156 instead of 225 VGPRs: three waves per
 		// SIMD instead of two); its chains go through k_c2r with everybody else's, and what k_c2r cannot hold (a chain of more than 128 seeds,
 		// more than 64 regions) then takes the same tier in its full form.  Measured and off: 359 against 342 ms per chunk on the clean genome,
 		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).  =2: that tier chained as the
 		// LDS tiers do it (pieces, chain starts in registers) over its HBM slab: 344 against 342, 1140 against 1095 -- no better either.
 		static const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
-		if (slab_export && !(main_seq && use_lanes)) {
+		if (slab_export) {
 			launch_regions_slab(st, slab_export == 2 ? 4 : 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, slab_export == 2 ? rl : rb, slab_export == 2 ? l_count : k32 + 3, ctr, posoffs, d_pos, &XP);   // 2: chained by pieces; what it declines (tied starts, tables) takes the full form next
 			TIER_MARK("tier 2 (exports)");
+			if (XP.ext) launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rl, l_count, ctr, c2r_quota);
 			TIER_MARK("chains -> regions");
 			if (main_seq && chain == 3) {
@@ -717,26 +710,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			TIER_MARK("tier 3");
 			return BSX_OK;
 		}
-		if (main_seq && use_lanes && max_len <= c2r_lanes_max_query()) { // a lane per strand search / per extension, in rounds
-			const size_t sb = c2r_lanes_state_bytes();
-			if ((rc2 = L.lanes_state.reserve((size_t)n * sb)) != BSX_OK) return rc2;
-			if ((rc2 = L.lanes_regs.reserve((size_t)n * 24 * sizeof(bsx_region_t))) != BSX_OK) return rc2;
-			// rank | act[2] | jobs[2] | res[2] | n_act
-			const size_t o_rank = 0, o_act = o_rank + (size_t)n * 128, o_jobs = o_act + (size_t)n * 8, o_res = o_jobs + (size_t)n * 2 * sizeof(bsx_ext_job_t),
-			             o_nact = o_res + (size_t)n * 2 * sizeof(bsx_ext_res_t), o_wide = o_nact + 4096, tot_misc = o_wide + (size_t)n * 8;
-			if ((rc2 = L.lanes_misc.reserve(tot_misc)) != BSX_OK) return rc2;
-			char *mb = (char*)L.lanes_misc.p;
-			RgLanesArg WA;
-			WA.state = L.lanes_state.p; WA.regs = L.lanes_regs.p; WA.rank = (unsigned char*)(mb + o_rank);
-			WA.act[0] = (int*)(mb + o_act); WA.act[1] = WA.act[0] + n;
-			WA.jobs[0] = mb + o_jobs; WA.jobs[1] = mb + o_jobs + (size_t)n * sizeof(bsx_ext_job_t);
-			WA.res[0] = mb + o_res; WA.res[1] = mb + o_res + (size_t)n * sizeof(bsx_ext_res_t);
-			WA.n_act = (unsigned int*)(mb + o_nact);
-			WA.wide = (int*)(mb + o_wide);
-			HIPCHK(hipMemsetAsync(WA.n_act, 0, 4096, st));   // u32: [0,128) jobs per round, [192,320) k_ext_n's job cursors, [384,512) tracing sums, [512,640) wide jobs per round, [640,768) k_ext_q's cursors
-			launch_c2r_lanes(st, d->n_cu, d->ix, L.sc, R, d_reads, T, XP, WA, (long long)n, max_len, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c);
-		} else
-			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
+		if (XP.ext) {
+			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
+			TIER_MARK("extensions");
+		}
+		launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
 		if (main_seq && chain == 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
 			std::lock_guard<std::mutex> g(d->chain_mu);
 			HIPCHK(hipEventRecord(L.ev_regions_done, st));
@@ -751,7 +729,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7)) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 15))) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -801,14 +779,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
 			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemsetAsync(ctr + 96, 0, 64, L.st2));
+			HIPCHK(hipMemsetAsync(ctr + 96, 0, 72, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8)) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 104))) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
@@ -821,7 +799,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		float ms0 = 0, ms1 = 0, ms2 = 0;
 		HIPCHK(hipEventSynchronize(L.ev2));
 		clock_gettime(CLOCK_MONOTONIC, &ts3);
-		if (trace && n_marks > 1) {
+		if (trace_tiers && n_marks > 1) {
 			fprintf(stderr, "[M::regions_batch] region launches (ms):");
 			for (int k = 1; k < n_marks; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, L.tier_ev[k - 1], L.tier_ev[k]) == hipSuccess) fprintf(stderr, " %s %.1f |", mark_name[k], ms); }
 			fprintf(stderr, "\n");
@@ -850,16 +828,6 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
 
-	if (trace && L.lanes_misc.p) {
-		unsigned long long pf[12]; unsigned int na[128];
-		const size_t o_nact = (size_t)n * 128 + (size_t)n * 8 + (size_t)n * 2 * sizeof(bsx_ext_job_t) + (size_t)n * 2 * sizeof(bsx_ext_res_t);
-		D2H(L.st, na, (char*)L.lanes_misc.p + o_nact, sizeof(na));
-		D2H(L.st, pf, (char*)L.lanes_misc.p + o_nact + 384 * 4, sizeof(pf));
-		fprintf(stderr, "[M::c2r_lanes] jobs per round:");
-		for (int r = 0; r < 128 && na[r]; r += r < 16 ? 1 : 8) fprintf(stderr, " %u", na[r]);
-		fprintf(stderr, "\n[M::c2r_lanes] k_ext_n: %llu jobs taken, %llu of them left to k_ext_q; %llu rows, %llu cells in %llu wave trips | k_ext_q: %llu jobs, %llu rows in %llu wave trips\n",
-		        pf[4], pf[7], pf[5], pf[6], pf[8], pf[0], pf[1], pf[2]);
-	}
 	if (trace) {
 		unsigned int hc[12]; unsigned long long hu[12];
 		D2H(L.st, hc, c32, sizeof(hc));
@@ -871,6 +839,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipMemsetAsync(ctr + 48, 0, sizeof(sp), L.st));
 		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
 		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
+		{
+			unsigned long long xp[4];
+			D2H(L.st, xp, ctr + 56, sizeof(xp));
+			HIPCHK(hipMemsetAsync(ctr + 56, 0, sizeof(xp), L.st));
+			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3]);
+		}
 		unsigned long long pf[16];
 		D2H(L.st, pf, ctr + 32, sizeof(pf));
 		HIPCHK(hipMemsetAsync(ctr + 32, 0, sizeof(pf), L.st));
@@ -996,28 +970,19 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
-	if (getenv("BSX_EXTQ")) { // tests: the batch through the quarter-wave kernel of the regions path (k_extq.hip); jobs it declines fail the call
+	if (getenv("BSX_EXT4")) { // tests: the batch through the quarter-wave kernel of the regions path (k_ext4.hip); jobs it declines fail the call
 		int rc, max_q = 0;
 		for (int64_t i = 0; i < n; ++i) max_q = std::max(max_q, jobs[i].qlen);
-		if (max_q > ext_q_max_query(16)) return BSX_E_ARG;
+		if (max_q > x4_max_query(16) || n > 0x7fffffff) return BSX_E_ARG;
 		if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
 		if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
 		if ((rc = L.aux.reserve(64)) != BSX_OK) return rc;
 		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
-		if (atoi(getenv("BSX_EXTQ")) == 2) { // the narrow jobs a lane each (k_ext_n), the rest through k_ext_q: what a round of the regions path does
-			if ((rc = L.scratch.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-			launch_ext_n(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, nullptr, (unsigned int)n,
-			             (unsigned int*)L.aux.p, (int*)L.scratch.p, (unsigned int*)L.aux.p + 2, nullptr);
-			launch_ext_q(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int*)L.aux.p + 2, (unsigned int)n,
-			             (unsigned int*)L.aux.p + 4, max_q, (const int*)L.scratch.p, nullptr);
-			if (getenv("BSX_PHASES")) { unsigned int c[4]; D2H(L.st, c, L.aux.p, 16); fprintf(stderr, "[M::extq] %lld jobs, %u left to k_ext_q by k_ext_n\n", (long long)n, c[2]); }
-		} else
-		launch_ext_q(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, nullptr, (unsigned int)n,
-		             (unsigned int*)L.aux.p, max_q, nullptr, nullptr);
+		launch_ext4_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p, max_q);
 		HIPCHK(hipGetLastError());
 		D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
-		for (int64_t i = 0; i < n; ++i) if (res[i].score == EXTQ_DECLINED) return BSX_E_ARG;
+		for (int64_t i = 0; i < n; ++i) if (res[i].score == X4_DECLINED) return BSX_E_ARG;
 		return BSX_OK;
 	}
 	// classes by LDS footprint (query length) and row width (band): {qcap, max band columns, NC}

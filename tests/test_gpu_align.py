@@ -348,12 +348,12 @@ def test_sim_chunk_equals_cpu_restatement(tmp_path):
         idx.close()
 
 
-def test_c2r_lanes_equal_waves(data):
-    """chains -> regions as lock-step rounds (BSX_C2R_LANES=1: a lane per strand search in k_c2r_ctrl, four extensions per wavefront in
-    k_ext_q) against the default wavefront-per-strand-search launch with the extensions inline (k_c2r): identical SAM."""
+def test_extensions_ahead_equal_inline(data):
+    """chains -> regions with the extensions of every chain's best seed made ahead of the seed loop, four to a wavefront (k_ext4, the
+    default), against all extensions inline in the wavefront-per-strand-search loop (BSX_X4=0): identical SAM."""
     for name, args in (CASES[0], CASES[1], CASES[8], CASES[9], CASES[11]):
-        want = run(HIP, args, data)
-        assert run(HIP, args, data, env={"BSX_C2R_LANES": "1"}) == want, name
+        want = run(HIP, args, data, env={"BSX_X4": "0"})
+        assert run(HIP, args, data) == want, name
 
 
 def test_dedup_kernel_against_host_function(tmp_path):
