@@ -176,6 +176,10 @@ BSX_HD void dev_block_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t 
 // prefix mask and takes twelve population counts -- 40 vector instructions where the 2-bit fields cost 104 (a shift, two masks and a
 // combination per 16-symbol word), and the seeding kernel is bound by exactly those: a quarter of its instructions were the two block
 // counts of an extension.  The cumulative counts in words 0-7 are the file's.
+// NOT part of the device image: the file's final 8-word cumulative-count tail.  It sits right behind the last, partial block's symbol
+// words, i.e. inside the 16 words that block takes in this layout, and k_bwt_planes shuffles it along with them.  Nothing on the device
+// reads it (a rank query masks the planes to positions before its own, and the totals are in DevFmi::L2); a copy of the device's bwt back
+// to the host is not a .bwt file body.
 BSX_HD void dev_planes_count4(const DevBlock &b, int upto, uint32_t &a, uint32_t &c, uint32_t &g, uint32_t &t)
 {
 	const int n = upto + 1;

@@ -39,6 +39,7 @@ size_t x4_job_bytes(void) { return sizeof(X4Job); }
 #define X4_GAPCAP 256
 #define X4_XSEEDS 128    // = RG_XSEEDS: k_c2r hands longer lists to the next tier
 #define X4P_WPB 4
+#define X4_NARROW 32
 // ---- k_x4prep: the exported strand searches 64 to a wave (a lane reads a header), then the wave's chains a lane each
 __global__ void __launch_bounds__(64 * X4P_WPB)
 k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Job *jobs, unsigned int jcap, unsigned int *jcount)
@@ -127,13 +128,19 @@ k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Jo
 			}
 			XE[ci] = xe;
 		}
-		const unsigned long long jm = __ballot(job);
-		if (jm) {
-			unsigned int base = 0;
-			if (lane == 0) base = atomicAdd(jcount, (unsigned int)__popcll(jm));
-			base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-			const unsigned int at = base + (unsigned int)__popcll(jm & ((1ull << lane) - 1));
-			if (job && at < jcap) jobs[at] = J;   // no room: the chain keeps status 0 and k_c2r extends it inline
+		// Two queues, each in its half of the pool: a seed of fewer than X4_NARROW bases is nearly always a chance match whose extensions
+		// stay inside a band of a dozen columns and die within thirty rows; the others (the read's own locus) run for as many rows as the
+		// read has bases left, over all of its columns.  A wave pays for the widest band among its four rows, so the two kinds do not mix.
+		const bool narrow = job && J.s_len < X4_NARROW;
+		for (int q = 0; q < 2; ++q) {
+			const unsigned long long jm = __ballot(job && narrow == (q == 1));
+			if (jm) {
+				unsigned int base = 0;
+				if (lane == 0) base = atomicAdd(jcount + 2 * q, (unsigned int)__popcll(jm));
+				base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+				const unsigned int at = base + (unsigned int)__popcll(jm & ((1ull << lane) - 1));
+				if (job && narrow == (q == 1) && at < jcap / 2) jobs[(size_t)q * (jcap / 2) + at] = J;   // no room: the chain keeps status 0 and k_c2r extends it inline
+			}
 		}
 	}
 }
@@ -155,14 +162,25 @@ __device__ __forceinline__ int q_scan_max_incl(int v)
 	t = __builtin_amdgcn_update_dpp(QID, v, DPP_ROW_SHR(8), 0xf, 0xf, false); v = v > t ? v : t;
 	return v;
 }
-// maximum over the 16 lanes of a row, in every lane of it
+// maximum over the 16 lanes of a row, in every lane of it (a rotation has a source for every lane: `old` is never taken, and the
+// identity there lets the compiler fold each step into one v_max_i32 with a DPP operand)
 __device__ __forceinline__ int q_allmax(int v)
 {
 	int t;
-	t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(1), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(2), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(4), 0xf, 0xf, false); v = v > t ? v : t;
-	t = __builtin_amdgcn_update_dpp(v, v, DPP_ROW_ROR(8), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(QID, v, DPP_ROW_ROR(1), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(QID, v, DPP_ROW_ROR(2), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(QID, v, DPP_ROW_ROR(4), 0xf, 0xf, false); v = v > t ? v : t;
+	t = __builtin_amdgcn_update_dpp(QID, v, DPP_ROW_ROR(8), 0xf, 0xf, false); v = v > t ? v : t;
+	return v;
+}
+// the same for two unsigned 16-bit numbers packed in a word, each on its own (v_pk_max_u16)
+typedef unsigned short x4_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t q_allmax_pk(uint32_t v)
+{
+#define X4_PK_STEP(n) do { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR(n), 0xf, 0xf, false); \
+		const x4_us2 m_ = __builtin_elementwise_max(__builtin_bit_cast(x4_us2, v), __builtin_bit_cast(x4_us2, t_)); v = __builtin_bit_cast(uint32_t, m_); } while (0)
+	X4_PK_STEP(1); X4_PK_STEP(2); X4_PK_STEP(4); X4_PK_STEP(8);
+#undef X4_PK_STEP
 	return v;
 }
 // the previous lane's value inside the row; lane 0 of the row gets `first`
@@ -215,8 +233,13 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	}
 	__syncthreads();
 	const int lane = wave_lane(), l = lane & 15, gsh = lane & 48;
-	unsigned int n = n_ptr ? *n_ptr : n_fixed;
-	if (CHAIN && n > n_fixed) n = n_fixed;   // (the job pool's capacity)
+	// CHAIN: two queues, n_ptr[0] jobs from jobs[0] and n_ptr[2] from jobs[n_fixed / 2] (n_fixed = the pool's capacity); taken in that order
+	unsigned int n = n_ptr ? *n_ptr : n_fixed, n_first = n;
+	if (CHAIN) {
+		n_first = n < n_fixed / 2 ? n : n_fixed / 2;
+		const unsigned int n_second = n_ptr[2] < n_fixed / 2 ? n_ptr[2] : n_fixed / 2;
+		n = n_first + n_second;
+	}
 	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
 	const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = sc.zdrop;
 	const long long l_pac = ix.l_pac;
@@ -237,7 +260,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	int Hr[NCQ], Er[NCQ]; uint32_t sqp[NCQ];
 #pragma unroll
 	for (int c = 0; c < NCQ; ++c) { Hr[c] = Er[c] = 0; sqp[c] = 0; }
-	unsigned int pf_rows = 0, pf_trips = 0, pf_jobs = 0, pf_cold = 0;
+	unsigned int pf_rows = 0, pf_trips = 0, pf_jobs = 0, pf_cold = 0, pf_slots = 0;
 	for (;;) {
 		// ---- between extensions: results, the next side or band, the next job.  Run when two rows of lanes wait for it, when a row has
 		// waited for a few trips, or when no extension is under way (a wave pays for this block whichever of its rows is in it)
@@ -311,7 +334,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 					if (!served) { if (wdone) st = X4_DONE; }   // (else: idle until the next pass refills the share)
 					else if (CHAIN) {
 						e = e_new;
-						const X4Job J = ((const X4Job*)jobs_)[e];
+						const X4Job J = ((const X4Job*)jobs_)[e < n_first ? e : n_fixed / 2 + (e - n_first)];
 						s_rbeg = J.s_rbeg; rmax0 = J.rmax0; rmax1 = J.rmax1; ext_at = J.ext_at; qoff0 = J.qoff;
 						l_query = J.l_query; s_qbeg = J.s_qbeg; s_len = J.s_len; par = J.parent; si = J.si;
 						side = 0; attempt = 0; aw0 = aw1 = P.w; R_score = R_truesc = -1; R_qb = R_qe = 0; R_rb = R_re = 0;
@@ -382,18 +405,16 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 			if (rm == 0 && __ballot(st == X4_ROW) == 0) { if (__ballot(st != X4_DONE) == 0) break; continue; }
 		}
 		++pf_trips;
-		// ---- one row of every extension under way
+		// ---- one row of every extension under way.  Straight-line code: what a row of lanes without an extension computes is thrown
+		// away by selects (a branch per 16 lanes costs the wave more than the instructions it skips)
 		const bool run = st == X4_ROW;
-		int t = 0, h1_init = 0;
-		if (run) {
-			++pf_rows;
-			t = (int)(y0 & 3u) ^ tcomp;
-			y0 = __builtin_amdgcn_alignbit(y1, y0, 2); y1 = __builtin_amdgcn_alignbit(y2, y1, 2); y2 >>= 2; --yleft;
-			if (beg < i - w) beg = i - w;
-			if (end > i + w + 1) end = i + w + 1;
-			if (end > qlen) end = qlen;
-			if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
-		}
+		if (run) ++pf_rows;
+		// (what the lanes of a row without an extension do to these is of no consequence: the next set-up writes them all)
+		const int t = (int)(y0 & 3u) ^ tcomp;
+		y0 = __builtin_amdgcn_alignbit(y1, y0, 2); y1 = __builtin_amdgcn_alignbit(y2, y1, 2); y2 >>= 2; --yleft;
+		beg = beg > i - w ? beg : i - w;
+		end = end < i + w + 1 ? end : i + w + 1; end = end < qlen ? end : qlen;
+		int h1_init = h0 - (o_del + e_del * (i + 1)); h1_init = (beg == 0 && h1_init > 0) ? h1_init : 0;
 		int m = 0, mj = -1, h1_last = h1_init;
 		const bool nonempty = run && beg < end;
 		const int c_lo = beg >> 4, c_hi = end >> 4;   // slots holding entries beg .. end (entry `end` gets its E cleared and its H set)
@@ -401,63 +422,63 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 		const unsigned int sm_l = nonempty ? (2u << c_hi) - (1u << c_lo) : 0u;
 		const unsigned int smask = (unsigned int)__builtin_amdgcn_readlane((int)sm_l, 0) | (unsigned int)__builtin_amdgcn_readlane((int)sm_l, 16) |
 		                           (unsigned int)__builtin_amdgcn_readlane((int)sm_l, 32) | (unsigned int)__builtin_amdgcn_readlane((int)sm_l, 48);
-		int fz = 0x7fffffff, lz = -1;
+		uint32_t zpk = 0;   // the non-zero cells of the row: (0xffff - first) << 16 | last + 1, each the maximum over the columns
+		pf_slots += (unsigned int)__builtin_popcount(smask);
 		if (smask) {
-			int carry = NEG_BIG, lm = -1, lj = -1, hprev = 0, vlast = 0;
+			int carry = NEG_BIG, kmax = -1, hprev = 0, vlast = 0;
 			const int tsh = t << 3;
 #pragma unroll
 			for (int c = 0; c < NCQ; ++c) {
 				if (smask >> c & 1u) {
+					const int a = (c << 4) + l;
 					const bool in = nonempty && c >= c_lo && c <= c_hi;
-					if (in) {
-						const int a = (c << 4) + l;
-						const bool act = a >= beg && a < end;
-						const int s = (int)(int8_t)(sqp[c] >> tsh);
-						const int M = (act && Hr[c]) ? Hr[c] + s : 0;
-						int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
-						const int g = act ? tins + a * e_ins : NEG_BIG;
-						const int incl = q_scan_max_incl(g);
-						int excl = q_prev(incl, NEG_BIG);
-						excl = excl > carry ? excl : carry;                 // prefix max over all earlier columns
-						{ const int tot = q_last(incl); carry = carry > tot ? carry : tot; }
-						int f = a == beg ? 0 : excl - (a - 1) * e_ins;
-						if (f < 0) f = 0;
-						int h = 0;
-						if (act) {
-							h = M > Er[c] ? M : Er[c];
-							h = h > f ? h : f;
-							int tdel = M - oe_del; tdel = tdel > 0 ? tdel : 0;
-							int ee = Er[c] - e_del; ee = ee > tdel ? ee : tdel;
-							Er[c] = ee;
-							if (h >= lm) { lm = h; lj = a; }
-							if (a == end - 1) vlast = h;
-						} else if (a == end) Er[c] = 0;
-						// H: entry a takes h(i, a-1) for a-1 in the band, entry beg takes the first-column value
-						int up = q_prev(h, 0);
-						const int edge = q_ror1(hprev);
-						if (l == 0) up = edge;
-						if (a == beg) Hr[c] = h1_init;
-						else if (a - 1 >= beg && a - 1 < end) Hr[c] = up;
-						hprev = h;
-						// the non-zero cells of the row as the next one finds them (ksw.c:466-469)
-						const bool nz = a >= beg && a <= end && (Hr[c] != 0 || Er[c] != 0);
-						if (nz && a < end) fz = fz < a ? fz : a;
-						if (nz) lz = lz > a ? lz : a;
+					const bool act = in && a >= beg && a < end;
+					const int hr = Hr[c], er = Er[c];
+					const int s = (int)(int8_t)(sqp[c] >> tsh);
+					const int M = (act && hr) ? hr + s : 0;
+					int tins = M - oe_ins; tins = tins > 0 ? tins : 0;
+					const int g = act ? tins + a * e_ins : NEG_BIG;
+					const int incl = q_scan_max_incl(g);
+					int excl = q_prev(incl, NEG_BIG);
+					excl = excl > carry ? excl : carry;                 // prefix max over all earlier columns
+					{ const int tot = q_last(incl); carry = carry > tot ? carry : tot; }
+					int f = excl - (a - 1) * e_ins;
+					f = (a == beg || f < 0) ? 0 : f;
+					int h = M > er ? M : er; h = h > f ? h : f; h = act ? h : 0;
+					int ee = M - oe_del; ee = ee > 0 ? ee : 0; ee = ee > er - e_del ? ee : er - e_del;
+					const int en = act ? ee : ((in && a == end) ? 0 : er);
+					Er[c] = en;
+					// row maximum and the last column that attains it: (h << 9 | column), columns < 512
+					{ const int key = act ? (h << 9 | a) : -1; kmax = kmax > key ? kmax : key; }
+					vlast = (act && a == end - 1) ? h : vlast;
+					// H: entry a takes h(i, a-1) for a-1 in the band, entry beg takes the first-column value
+					int up = q_prev(h, 0);
+					const int edge = q_ror1(hprev);
+					up = l == 0 ? edge : up;
+					const int hn = !in ? hr : a == beg ? h1_init : (a - 1 >= beg && a - 1 < end) ? up : hr;
+					Hr[c] = hn;
+					hprev = h;
+					// the non-zero cells of the row as the next one finds them (ksw.c:466-469)
+					const bool nz = in && a >= beg && a <= end && (hn | en) != 0;
+					{ // (within a lane the columns grow with the slot: the first one seen stays, the last one seen wins)
+						const uint32_t hi = (nz && a < end && (zpk >> 16) == 0) ? (uint32_t)(0xffff - a) << 16 : zpk & 0xffff0000u;
+						const uint32_t lo = nz ? (uint32_t)(a + 1) : zpk & 0xffffu;
+						zpk = hi | lo;
 					}
 				}
 			}
-			if (nonempty) { // row maximum and the last column that attains it in one reduction: (h << 9 | column), columns < 512
-				const int key = q_allmax(lm < 0 ? -1 : (lm << 9 | lj));
-				m = key >> 9; mj = key < 0 ? -1 : (key & 511);
+			{
+				const int key = q_allmax(kmax);
+				m = nonempty ? key >> 9 : 0; mj = (nonempty && key >= 0) ? (key & 511) : -1;
 			}
 			if (__ballot(nonempty && end == qlen)) { // h(i, end-1), only read for the to-the-end score
 				const int v = q_allmax(vlast);   // h >= 0
-				if (nonempty && end == qlen) h1_last = v;
+				h1_last = (nonempty && end == qlen) ? v : h1_last;
 			}
 		}
 		if (__ballot(run && !nonempty)) { // empty row: only the boundary cell is written (ksw.c:449)
 #pragma unroll
-			for (int c = 0; c < NCQ; ++c) if (run && !nonempty && (c << 4) + l == end) { Hr[c] = h1_init; Er[c] = 0; }
+			for (int c = 0; c < NCQ; ++c) { const bool hit = run && !nonempty && (c << 4) + l == end; Hr[c] = hit ? h1_init : Hr[c]; Er[c] = hit ? 0 : Er[c]; }
 		}
 		bool stop = false;
 		if (run) {
@@ -476,9 +497,10 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 			}
 		}
 		const bool shrink = run && !stop;
-		if (__ballot(shrink)) { // the band of the next row: the non-zero cells (ksw.c:466-469)
-			int nb = -q_allmax(-fz);
-			int last = q_allmax(lz);
+		{ // the band of the next row: the non-zero cells (ksw.c:466-469)
+			const uint32_t zr = q_allmax_pk(zpk);
+			int nb = (zr >> 16) ? 0xffff - (int)(zr >> 16) : 0x7fffffff;
+			int last = (int)(zr & 0xffffu) - 1;
 			if (shrink) {
 				nb = nb < end ? nb : end;
 				last = last > nb - 1 ? last : nb - 1;
@@ -493,7 +515,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	}
 	if (prof) { // tracing: jobs, rows, trips (a trip advances up to four rows) and passes through the block between extensions
 		pf_rows = (unsigned int)wave_sum_i32(l == 0 ? (int)pf_rows : 0); pf_jobs = (unsigned int)wave_sum_i32(l == 0 ? (int)pf_jobs : 0);
-		if (lane == 0) { atomicAdd(&prof[0], (unsigned long long)pf_jobs); atomicAdd(&prof[1], (unsigned long long)pf_rows); atomicAdd(&prof[2], (unsigned long long)pf_trips); atomicAdd(&prof[3], (unsigned long long)pf_cold); }
+		if (lane == 0) { atomicAdd(&prof[0], (unsigned long long)pf_jobs); atomicAdd(&prof[1], (unsigned long long)pf_rows); atomicAdd(&prof[2], (unsigned long long)pf_trips); atomicAdd(&prof[3], (unsigned long long)pf_cold); atomicAdd(&prof[4], (unsigned long long)pf_slots); }
 	}
 }
 
@@ -512,16 +534,17 @@ void launch_ext4_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevSc
 		hipLaunchKernelGGL((k_ext4<16, false>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)res, (unsigned char*)nullptr, (const unsigned int*)nullptr, n, cursor, (unsigned long long*)nullptr);
 }
 
-// The extensions of the chains the tiers exported (records with has_ext), ahead of launch_c2r: k_x4prep lists the jobs (ctr32[0] = their
-// number, ctr32[1] = k_ext4's cursor: both zero at launch), k_ext4 runs them.  n_tasks bounds the number of exported strand searches.
+// The extensions of the chains the tiers exported (records with has_ext), ahead of launch_c2r: k_x4prep lists the jobs (ctr32[0], [2] = their
+// numbers, ctr32[1] = k_ext4's cursor: zeroed here), k_ext4 runs them.  n_tasks bounds the number of exported strand searches.
 void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                long long n_tasks, const RgXPoolArg &XA, void *jobs, unsigned long long job_cap, unsigned int *ctr32, unsigned long long *prof)
 {
 	RgXPool X = rgx_pool(&XA);
 	const unsigned int jcap = (unsigned int)std::min<unsigned long long>(job_cap, 0xfffffff0ull);
 	const int pgrid = (int)((n_tasks + 64 * X4P_WPB - 1) / (64 * X4P_WPB));
+	(void)hipMemsetAsync(ctr32, 0, 16, st);
 	hipLaunchKernelGGL(k_x4prep, dim3(std::max(1, pgrid)), dim3(64 * X4P_WPB), 0, st, ix, P, tasks, X, (X4Job*)jobs, jcap, ctr32);
-	static const int wpc = getenv("BSX_X4_WG_PER_CU") ? std::max(1, atoi(getenv("BSX_X4_WG_PER_CU"))) : X4_OCC;
+	static const int wpc = getenv("BSX_X4_WG_PER_CU") ? std::max(1, atoi(getenv("BSX_X4_WG_PER_CU"))) : 3;   // (three waves per SIMD at 167 VGPRs)
 	const int grid = (int)std::max<long long>(1, std::min<long long>((n_tasks * 4 + 15) / 16, (long long)n_cu * wpc));
 	hipLaunchKernelGGL((k_ext4<10, true>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)nullptr, X.base, (const unsigned int*)ctr32, jcap, ctr32 + 1, prof);
 }

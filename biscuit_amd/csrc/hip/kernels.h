@@ -29,7 +29,7 @@ void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
                    bsx_glb_tag_t *tags = nullptr, char *md_pool = nullptr, unsigned long long md_cap = 0, unsigned long long *md_cursor = nullptr, int tcap = 0);
 // K4 four to a wavefront (k_ext4.hip): a row of 16 lanes per job, persistent rows taking jobs off *cursor (zero at launch).
 // launch_x4: the extensions of the best seed of every chain the tiers exported (records with has_ext), written into the records ahead of
-// launch_c2r; jobs = room for job_cap jobs of x4_job_bytes(), ctr32[0..1] zero at launch (job count, cursor).
+// launch_c2r; jobs = room for job_cap jobs of x4_job_bytes(), ctr32[0..3]: job counts and cursor (zeroed by the call).
 // launch_ext4_batch: plain ksw_extend2 jobs through the same rows (tests); jobs it cannot hold (query longer than x4_max_query(16),
 // scores of 2^21 or more) are answered with score = X4_DECLINED.
 #define X4_DECLINED (-0x7fffffff)

@@ -30,6 +30,7 @@ struct Lane {
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
+	int flt_key[3] = {-1, -1, -1};   // what fltab was made for
 	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
@@ -44,6 +45,7 @@ struct Lane {
 		HostBuf hres;                          // pinned: region offsets (8 B each) then counts (4 B each)
 		hipEvent_t ev = nullptr, ev_tiers = nullptr;
 		unsigned long long used_main = 0;      // regions the caller already holds
+		unsigned long long regs_cap = 0;       // size of the device's region pool for this chunk
 	} rs;
 	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -132,7 +134,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.tags.release(); L.mdpool.release(); L.dd.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -189,6 +191,7 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 		int rc;
 		if ((rc = d->bwt[i].reserve((size_t)f->bwt_size * 4 + 64)) != BSX_OK) return rc;
 		if ((rc = d->sa[i].reserve((size_t)f->n_sa * 8)) != BSX_OK) return rc;
+		HIPCHK(hipMemset((char*)d->bwt[i].p + (size_t)f->bwt_size * 4, 0, 64));   // the slack the last thread of k_bwt_planes reads and writes
 		HIPCHK(hipMemcpy(d->bwt[i].p, f->bwt, (size_t)f->bwt_size * 4, hipMemcpyHostToDevice));
 		launch_bwt_planes(d->lane[0].st, (uint32_t*)d->bwt[i].p, (unsigned long long)f->bwt_size);   // the device's block layout (dev_common.hpp); ahead of everything that reads symbols
 		HIPCHK(hipStreamSynchronize(d->lane[0].st));
@@ -537,8 +540,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			ft[l] = (int32_t)(opt->a * min_l + .499);
 		}
 		for (int64_t i = 0; i < n && !any_flt; ++i) any_flt = tasks[i].len >= 0 && ft[tasks[i].len] != INT32_MIN;   // (for a read of this chunk, not for some length below its longest)
-		if ((rc = L.fltab.reserve(ft.size() * 4)) != BSX_OK) return rc;
-		H2D(L.st, L.fltab.p, ft.data(), ft.size() * 4);
+		// (the table follows from the longest read, -W and -A: uploaded again only when one of them changes)
+		if (!(L.fltab.p && L.flt_key[0] == max_len && L.flt_key[1] == opt->min_chain_weight && L.flt_key[2] == opt->a)) {
+			if ((rc = L.fltab.reserve(ft.size() * 4)) != BSX_OK) return rc;
+			H2D(L.st, L.fltab.p, ft.data(), ft.size() * 4);
+			L.flt_key[0] = max_len; L.flt_key[1] = opt->min_chain_weight; L.flt_key[2] = opt->a;
+		}
 		R.flt_tab = (const int32_t*)L.fltab.p; R.flt_len = max_len;
 	}
 	// Chunks with reads above the short kernels' 256 bases (up to regions_long_max_query(); longer ones are chained by the caller) or with
@@ -729,7 +736,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 15))) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16))) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -779,14 +786,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
 			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemsetAsync(ctr + 96, 0, 72, L.st2));
+			HIPCHK(hipMemsetAsync(ctr + 96, 0, 64, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 104))) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18))) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
@@ -823,7 +830,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	D2H(L.st, &used, ctr + 6, 8);
 	if (used > regs_cap) used = regs_cap;
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
-	L.rs.used_main = used;
+	L.rs.used_main = used; L.rs.regs_cap = regs_cap;
 	for (size_t j = 0; j < redo.size(); ++j) out_n[redo[j]] = BSX_REGIONS_PENDING;   // lane_regions_finish fills these in
 	if (*out_cap < (int64_t)used + 65536) { *out_cap = (int64_t)used + 65536; *out = (bsx_region_t*)realloc(*out, sizeof(bsx_region_t) * (size_t)*out_cap); }
 	D2H(L.st, *out, L.regs.p, (size_t)used * sizeof(bsx_region_t));
@@ -840,10 +847,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
 		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
 		{
-			unsigned long long xp[4];
+			unsigned long long xp[5];
 			D2H(L.st, xp, ctr + 56, sizeof(xp));
 			HIPCHK(hipMemsetAsync(ctr + 56, 0, sizeof(xp), L.st));
-			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3]);
+			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions, %.2f slots per trip\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3], xp[2] ? (double)xp[4] / xp[2] : 0.0);
 		}
 		unsigned long long pf[16];
 		D2H(L.st, pf, ctr + 32, sizeof(pf));
@@ -910,6 +917,7 @@ static int lane_regions_finish(bsx_device_t *d, int lane, bsx_region_t **out, in
 	// of thousands of small transfers per chunk on a repeat-rich genome), then each list is taken from it
 	unsigned long long used_all = 0;
 	D2H(L.st2, &used_all, dev_counters(L) + 6, 8);
+	if (used_all > L.rs.regs_cap) used_all = L.rs.regs_cap;   // (a cursor past the pool: the strand searches that found no room carry status 7)
 	const unsigned long long lo = L.rs.used_main, hi = std::max<unsigned long long>(used_all, lo);
 	std::vector<bsx_region_t> stretch;
 	if (hi > lo) {

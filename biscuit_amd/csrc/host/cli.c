@@ -225,7 +225,7 @@ static void *reader_main(void *arg)
 			bsx_fq_chunkpos_t cp;
 			if (!bsx_fq_scan_get(scan, idx, &cp)) break;
 			if (bsx_fq_seek(R->f1, cp.off1) != 0 || (R->f2 && bsx_fq_seek(R->f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "reader"); R->failed = 1; break; }
-			P = bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
+			P = bsx_fq_pair_open_n(R->f1, R->f2, R->has_bc, R->f2 ? cp.n / 2 : cp.n);   /* (no parsing ahead into the chunks of other ranks) */
 			r.seqs = bsx_fq_pair_read_chunk(P, R->chunk, &r.n);
 			bsx_fq_pair_close(P); P = 0;
 			if (r.seqs == 0 || r.n != cp.n) { fprintf(stderr, "[E::%s] chunk %ld: %d reads where the scan counted %d\n", "reader", (long)idx, r.n, cp.n); if (r.seqs) { for (i = 0; i < r.n; ++i) bsx_read_free(&r.seqs[i]); free(r.seqs); } R->failed = 1; break; }

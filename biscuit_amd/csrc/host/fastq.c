@@ -186,6 +186,7 @@ bsx_read_t *bsx_fq_read_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size, int ha
 typedef struct { bsx_read_t *r; int n, eof; } feed_block_t;
 typedef struct {
 	bsx_fq_t *f; int has_bc;
+	long limit, taken;      /* limit >= 0: the thread parses this many records and reports the end of its input (a chunk whose size is known) */
 	pthread_t th;
 	pthread_mutex_t mu; pthread_cond_t cv;
 	feed_block_t ring[FEED_RING]; int head, count, stop;
@@ -200,8 +201,10 @@ static void *feed_main(void *arg)
 		feed_block_t blk;
 		blk.r = (bsx_read_t*)malloc(sizeof(bsx_read_t) * FEED_BLOCK); blk.n = 0; blk.eof = 0;
 		while (blk.n < FEED_BLOCK) {
+			if (F->limit >= 0 && F->taken >= F->limit) { blk.eof = 1; break; }
 			if (fq_read(F->f) < 0) { blk.eof = 1; break; }
 			to_read(F->f, &blk.r[blk.n++], F->has_bc);
+			++F->taken;
 		}
 		pthread_mutex_lock(&F->mu);
 		while (F->count == FEED_RING && !F->stop) pthread_cond_wait(&F->cv, &F->mu);
@@ -212,10 +215,10 @@ static void *feed_main(void *arg)
 		if (blk.eof) return 0;
 	}
 }
-static void feed_start(feed_t *F, bsx_fq_t *f, int has_bc)
+static void feed_start(feed_t *F, bsx_fq_t *f, int has_bc, long limit)
 {
 	memset(F, 0, sizeof(*F));
-	F->f = f; F->has_bc = has_bc;
+	F->f = f; F->has_bc = has_bc; F->limit = limit;
 	pthread_mutex_init(&F->mu, 0); pthread_cond_init(&F->cv, 0);
 	pthread_create(&F->th, 0, feed_main, F);
 }
@@ -244,13 +247,15 @@ static void feed_stop(feed_t *F)
 	while (F->count) { feed_block_t *b = &F->ring[F->head]; for (i = 0; i < b->n; ++i) bsx_read_free(&b->r[i]); free(b->r); F->head = (F->head + 1) % FEED_RING; --F->count; }
 }
 
-bsx_fq_pair_t *bsx_fq_pair_open(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc)
+/* n_records >= 0: each file's parser stops after that many records (the rest of the file belongs to other chunks, other ranks) */
+bsx_fq_pair_t *bsx_fq_pair_open_n(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc, long n_records)
 {
 	bsx_fq_pair_t *P = (bsx_fq_pair_t*)calloc(1, sizeof(*P));
-	feed_start(&P->a, f1, has_bc);
-	if (f2) { feed_start(&P->b, f2, has_bc); P->has_b = 1; }
+	feed_start(&P->a, f1, has_bc, n_records);
+	if (f2) { feed_start(&P->b, f2, has_bc, n_records); P->has_b = 1; }
 	return P;
 }
+bsx_fq_pair_t *bsx_fq_pair_open(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc) { return bsx_fq_pair_open_n(f1, f2, has_bc, -1); }
 void bsx_fq_pair_close(bsx_fq_pair_t *P)
 {
 	if (!P) return;

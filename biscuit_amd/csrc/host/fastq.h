@@ -11,6 +11,7 @@ void bsx_read_free(bsx_read_t *s);
 /* the same chunks, with one parser thread per file working ahead of the caller */
 typedef struct bsx_fq_pair bsx_fq_pair_t;
 bsx_fq_pair_t *bsx_fq_pair_open(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc);
+bsx_fq_pair_t *bsx_fq_pair_open_n(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc, long n_records);   /* the parsers stop after n_records records per file */
 bsx_read_t *bsx_fq_pair_read_chunk(bsx_fq_pair_t *p, int chunk_size, int *n);
 void bsx_fq_pair_close(bsx_fq_pair_t *p);
 /* chunk boundaries over plain files by a scan that builds no records (fastq.c): NULL from _start when a file is compressed or not seekable */

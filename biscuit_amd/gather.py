@@ -112,6 +112,26 @@ class ChunkGather:
             buf = self._staging(n_bytes)
             buf.zero_()
             dist.send(buf, dst=0)
+        # Does the backend post the receives of a round together?  Found out here, on 16 bytes per sender, where a backend that fails
+        # half-way is attributable to the probe; run() then either groups its receives or takes them one by one, and treats a failure
+        # of a grouped round as fatal instead of re-issuing receives that may already be matched.
+        if self.rank == 0:
+            if not self._sequential:
+                ops = [dist.P2POp(dist.irecv, self._staging_src(src, n_bytes)[0][:16], src) for src in range(1, self.world)]
+                try:
+                    for q in dist.batch_isend_irecv(ops):
+                        q.wait()
+                except Exception as e:
+                    import sys
+                    sys.stderr.write("[W::gather] no grouped point-to-point (%r): receives one after the other\n" % (e,))
+                    self._sequential = True
+                    for src in range(1, self.world):
+                        dist.recv(self._staging_src(src, n_bytes)[0][:16], src=src)
+            else:
+                for src in range(1, self.world):
+                    dist.recv(self._staging_src(src, n_bytes)[0][:16], src=src)
+        else:
+            dist.send(self._staging(n_bytes)[:16], dst=0)
 
     def run(self):
         """gather until the input ends; returns the number of chunks seen (all ranks return the same)"""
@@ -143,10 +163,9 @@ class ChunkGather:
                 if ops and not self._sequential:
                     try:
                         reqs = dist.batch_isend_irecv(ops)
-                    except Exception as e:   # a backend without grouped point-to-point: nothing was posted, take them one by one from here on
-                        import sys
-                        sys.stderr.write("[W::gather] receives posted one after the other (%r)\n" % (e,))
-                        self._sequential = True
+                    except Exception:   # (warm() probed this form: a failure here may have posted part of the group, so nothing is retried)
+                        self._dead = True
+                        raise
                 if ops and self._sequential:
                     for src in sorted(bufs):
                         dist.recv(bufs[src][0], src=src)
