@@ -260,7 +260,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	int Hr[NCQ], Er[NCQ]; uint32_t sqp[NCQ];
 #pragma unroll
 	for (int c = 0; c < NCQ; ++c) { Hr[c] = Er[c] = 0; sqp[c] = 0; }
-	unsigned int pf_rows = 0, pf_trips = 0, pf_jobs = 0, pf_cold = 0, pf_slots = 0;
+	unsigned int pf_rows = 0, pf_trips = 0, pf_jobs = 0, pf_cold = 0, pf_slots = 0, pf_nrows = 0;
 	for (;;) {
 		// ---- between extensions: results, the next side or band, the next job.  Run when two rows of lanes wait for it, when a row has
 		// waited for a few trips, or when no extension is under way (a wave pays for this block whichever of its rows is in it)
@@ -408,7 +408,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 		// ---- one row of every extension under way.  Straight-line code: what a row of lanes without an extension computes is thrown
 		// away by selects (a branch per 16 lanes costs the wave more than the instructions it skips)
 		const bool run = st == X4_ROW;
-		if (run) ++pf_rows;
+		if (run) { ++pf_rows; if (CHAIN && s_len < X4_NARROW) ++pf_nrows; }
 		// (what the lanes of a row without an extension do to these is of no consequence: the next set-up writes them all)
 		const int t = (int)(y0 & 3u) ^ tcomp;
 		y0 = __builtin_amdgcn_alignbit(y1, y0, 2); y1 = __builtin_amdgcn_alignbit(y2, y1, 2); y2 >>= 2; --yleft;
@@ -516,6 +516,8 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	if (prof) { // tracing: jobs, rows, trips (a trip advances up to four rows) and passes through the block between extensions
 		pf_rows = (unsigned int)wave_sum_i32(l == 0 ? (int)pf_rows : 0); pf_jobs = (unsigned int)wave_sum_i32(l == 0 ? (int)pf_jobs : 0);
 		if (lane == 0) { atomicAdd(&prof[0], (unsigned long long)pf_jobs); atomicAdd(&prof[1], (unsigned long long)pf_rows); atomicAdd(&prof[2], (unsigned long long)pf_trips); atomicAdd(&prof[3], (unsigned long long)pf_cold); atomicAdd(&prof[4], (unsigned long long)pf_slots); }
+		pf_nrows = (unsigned int)wave_sum_i32(l == 0 ? (int)pf_nrows : 0);
+		if (lane == 0) atomicAdd(&prof[5], (unsigned long long)pf_nrows);
 	}
 }
 

@@ -847,10 +847,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
 		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
 		{
-			unsigned long long xp[5];
+			unsigned long long xp[6];
 			D2H(L.st, xp, ctr + 56, sizeof(xp));
 			HIPCHK(hipMemsetAsync(ctr + 56, 0, sizeof(xp), L.st));
-			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions, %.2f slots per trip\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3], xp[2] ? (double)xp[4] / xp[2] : 0.0);
+			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions, %.2f slots per trip, %llu rows of narrow jobs\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3], xp[2] ? (double)xp[4] / xp[2] : 0.0, xp[5]);
 		}
 		unsigned long long pf[16];
 		D2H(L.st, pf, ctr + 32, sizeof(pf));
