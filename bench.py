@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one chunk at a time through bsx_process_seqs (no overlap of consecutive chunks)")
+    ap.add_argument("--no-long-reads", action="store_true", help="skip the third, short measurement on 1 kb single-end reads (BASELINE configs[4] shape; own subprocess)")
     ap.add_argument("--no-hard-genome", action="store_true", help="skip the second, shorter measurement on the hg38-like genome (run after the headline one, in a subprocess)")
     ap.add_argument("--genome-profile", choices=["clean", "hg38-like"], default="clean",
                     help="clean: i.i.d. bases + 5 %% planted repeats (the workload of rounds 1-2); hg38-like: + interspersed repeat families with up to a million copies, ~43 %% repeats (csrc/host/sim.c)")
@@ -400,6 +401,19 @@ def main():
                 out["hg38_like_genome"]["workload"] = sub["config"]["workload"]
             except Exception as e:      # the headline line must not depend on it
                 out["hg38_like_genome"] = {"error": repr(e)[:300]}
+            # BASELINE configs[4] shape (single-end reads of 1 kb, clean genome of the same size): the long-read kernels, timed the same way
+            # (a chunk is 160 Mbp of reads: 160 k of them)
+            if not args.no_long_reads:
+                cmd = [sys.executable, os.path.abspath(__file__), "--genome-mbp", str(args.genome_mbp), "--threads", str(threads), "--single-end", "--read-len", "1000",
+                       "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hard-genome", "--no-long-reads"]
+                try:
+                    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                    sub = json.loads(pr.stdout.decode().strip().split("\n")[-1])
+                    out["long_reads"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms_per_step", "kernel_ms_per_step_standalone",
+                                                                 "strand_searches_chained_on_host_per_step", "host_cpu_s_per_step")}
+                    out["long_reads"]["workload"] = sub["config"]["workload"]
+                except Exception as e:
+                    out["long_reads"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
