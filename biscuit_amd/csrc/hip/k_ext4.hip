@@ -26,20 +26,13 @@
 #include "wave.hpp"
 #include "kernels.h"
 #include "rgx.hpp"
+#include "x4.hpp"
 
-struct X4Job {                    // 48 bytes
-	long long s_rbeg, rmax0, rmax1;   // the seed's reference start; the chain's window (memchain.c:585-610)
-	unsigned long long ext_at;        // byte offset of the chain's RgXExt in the export pool
-	unsigned int qoff;                // the read in the chunk's read buffer
-	short l_query, s_qbeg, s_len; unsigned char parent, pad;
-	int si;                           // the seed's index in its list
-};
 size_t x4_job_bytes(void) { return sizeof(X4Job); }
 
 #define X4_GAPCAP 256
 #define X4_XSEEDS 128    // = RG_XSEEDS: k_c2r hands longer lists to the next tier
 #define X4P_WPB 4
-#define X4_NARROW 32
 // ---- k_x4prep: the exported strand searches 64 to a wave (a lane reads a header), then the wave's chains a lane each
 __global__ void __launch_bounds__(64 * X4P_WPB)
 k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Job *jobs, unsigned int jcap, unsigned int *jcount)
@@ -190,30 +183,6 @@ __device__ __forceinline__ int q_ror1(int v) { return __builtin_amdgcn_update_dp
 // lane 15's value in every lane of the row
 __device__ __forceinline__ int q_last(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_ROW_NEWBCAST(15), 0xf, 0xf, false); }
 
-// 2-bit fields of a word in reverse order
-__device__ __forceinline__ uint32_t x4_rev2(uint32_t x) { x = __builtin_bitreverse32(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); }
-
-// The reference bases of rows r0 .. r0 + 47 of an extension (fewer when the target ends: need = rows left, >= 1) as 2-bit fields, row
-// r0 + m at bits 2m of the 96-bit number y2:y1:y0.  F = forward-strand coordinate of row r0's base, fd = its step per row; the rows
-// lie on one strand, so they are consecutive fields of pac read up or down (bns_get_seq, bntseq.c:402-422).  Four aligned dwords of
-// pac (64 bases) hold any 48 consecutive ones; pac is padded past its end.
-__device__ __forceinline__ void x4_bases(const uint8_t *pac, long long F, int fd, int need, uint32_t &y0, uint32_t &y1, uint32_t &y2)
-{
-	(void)need;   // (the rows that exist lie inside the window, i.e. at coordinates >= 0; the fields of the others are never read)
-	const long long P0 = (fd > 0 ? F : (F - 47 > 0 ? F - 47 : 0)) & ~15ll;   // first base of the first dword
-	const uint4 v = *reinterpret_cast<const uint4*>(pac + (P0 >> 2));
-	// base q of pac sits at bits 126 - 2 (q - P0) of the bytes read as one big-endian number
-	const unsigned __int128 B = (unsigned __int128)__builtin_bswap32(v.x) << 96 | (unsigned __int128)__builtin_bswap32(v.y) << 64 |
-	                            (unsigned __int128)__builtin_bswap32(v.z) << 32 | (unsigned __int128)__builtin_bswap32(v.w);
-	if (fd > 0) { // row m = base F + m: the top 96 bits after the shift, field order reversed
-		const unsigned __int128 S = B << (2 * (int)(F - P0));
-		y0 = x4_rev2((uint32_t)(S >> 96)); y1 = x4_rev2((uint32_t)(S >> 64)); y2 = x4_rev2((uint32_t)(S >> 32));
-	} else {      // row m = base F - m: base F to bits 0
-		const unsigned __int128 S = B >> (126 - 2 * (int)(F - P0));
-		y0 = (uint32_t)S; y1 = (uint32_t)(S >> 32); y2 = (uint32_t)(S >> 64);
-	}
-}
-
 enum { X4_IDLE = 0, X4_NEXT, X4_ROW, X4_AFTER, X4_REFILL, X4_DONE };
 #define X4_ROWS 48
 
@@ -222,7 +191,7 @@ enum { X4_IDLE = 0, X4_NEXT, X4_ROW, X4_AFTER, X4_REFILL, X4_DONE };
 template <int NCQ, bool CHAIN>
 __global__ void __launch_bounds__(256, X4_OCC)
 k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void *jobs_, void *res_, unsigned char *xbase,
-       const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, unsigned long long *prof)
+       const unsigned int *n_ptr, unsigned int n_fixed, unsigned int *cursor, unsigned long long *prof, int take_second)
 {
 	// scores of query base q against target bases 0..3, a byte each: [parent][q]
 	__shared__ uint32_t s_sqp[2][8];
@@ -237,7 +206,7 @@ k_ext4(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const void
 	unsigned int n = n_ptr ? *n_ptr : n_fixed, n_first = n;
 	if (CHAIN) {
 		n_first = n < n_fixed / 2 ? n : n_fixed / 2;
-		const unsigned int n_second = n_ptr[2] < n_fixed / 2 ? n_ptr[2] : n_fixed / 2;
+		const unsigned int n_second = take_second ? (n_ptr[2] < n_fixed / 2 ? n_ptr[2] : n_fixed / 2) : 0u;   // (else k_extl has run that queue)
 		n = n_first + n_second;
 	}
 	const int o_del = sc.o_del, e_del = sc.e_del, o_ins = sc.o_ins, e_ins = sc.e_ins;
@@ -531,9 +500,9 @@ void launch_ext4_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevSc
 	const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * 8));
 	RegParams P; memset(&P, 0, sizeof(P));
 	if (max_qlen <= x4_max_query(10))
-		hipLaunchKernelGGL((k_ext4<10, false>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)res, (unsigned char*)nullptr, (const unsigned int*)nullptr, n, cursor, (unsigned long long*)nullptr);
+		hipLaunchKernelGGL((k_ext4<10, false>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)res, (unsigned char*)nullptr, (const unsigned int*)nullptr, n, cursor, (unsigned long long*)nullptr, 0);
 	else
-		hipLaunchKernelGGL((k_ext4<16, false>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)res, (unsigned char*)nullptr, (const unsigned int*)nullptr, n, cursor, (unsigned long long*)nullptr);
+		hipLaunchKernelGGL((k_ext4<16, false>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)res, (unsigned char*)nullptr, (const unsigned int*)nullptr, n, cursor, (unsigned long long*)nullptr, 0);
 }
 
 // The extensions of the chains the tiers exported (records with has_ext), ahead of launch_c2r: k_x4prep lists the jobs (ctr32[0], [2] = their
@@ -546,7 +515,9 @@ void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &s
 	const int pgrid = (int)((n_tasks + 64 * X4P_WPB - 1) / (64 * X4P_WPB));
 	(void)hipMemsetAsync(ctr32, 0, 16, st);
 	hipLaunchKernelGGL(k_x4prep, dim3(std::max(1, pgrid)), dim3(64 * X4P_WPB), 0, st, ix, P, tasks, X, (X4Job*)jobs, jcap, ctr32);
+	const int use_l = getenv("BSX_XL") ? atoi(getenv("BSX_XL")) : 1;   // 0: the narrow queue through k_ext4 too
+	if (use_l) launch_extl(st, n_cu, ix, sc, P, reads, jobs, jcap, ctr32, X.base, n_tasks * 4, prof);
 	static const int wpc = getenv("BSX_X4_WG_PER_CU") ? std::max(1, atoi(getenv("BSX_X4_WG_PER_CU"))) : 3;   // (three waves per SIMD at 167 VGPRs)
 	const int grid = (int)std::max<long long>(1, std::min<long long>((n_tasks * 4 + 15) / 16, (long long)n_cu * wpc));
-	hipLaunchKernelGGL((k_ext4<10, true>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)nullptr, X.base, (const unsigned int*)ctr32, jcap, ctr32 + 1, prof);
+	hipLaunchKernelGGL((k_ext4<10, true>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)nullptr, X.base, (const unsigned int*)ctr32, jcap, ctr32 + 1, prof, use_l ? 0 : 1);
 }

@@ -38,6 +38,11 @@ size_t x4_job_bytes(void);
 struct RgXPoolArg;
 void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                long long n_tasks, const RgXPoolArg &X, void *jobs, unsigned long long job_cap, unsigned int *ctr32, unsigned long long *prof);
+// K4 a lane per job (k_extl.hip) for the narrow queue of launch_x4's pool; called by launch_x4
+void launch_extl(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, void *jobs, unsigned int jcap,
+                 unsigned int *ctr32, unsigned char *xbase, long long n_upper, unsigned long long *prof);
+void launch_extl_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
+                       unsigned int n, unsigned int *ctr32);
 void launch_ext4_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res,
                        unsigned int n, unsigned int *cursor, int max_qlen);
 // K3+C1+C2+C4 fused: one wavefront per strand search, from the dense interval lists of launch_seed to alignment regions.

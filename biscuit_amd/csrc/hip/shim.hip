@@ -718,8 +718,48 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			return BSX_OK;
 		}
 		if (XP.ext) {
-			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
+			if (main_seq && getenv("BSX_XL_CHECK")) R.prof = 77;
+			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof && R.prof != 77 ? ctr + 56 : nullptr);
+			if (R.prof == 77) R.prof = 0;
 			TIER_MARK("extensions");
+			if (main_seq && getenv("BSX_XL_CHECK")) { // debugging: the records as k_extl + k_ext4 left them against k_ext4 alone
+				unsigned long long used = 0; unsigned int xn = 0;
+				HIPCHK(hipStreamSynchronize(st));
+				D2H(st, &used, XP.cursor, 8); D2H(st, &xn, XP.xcount, 4);
+				if (used > XP.cap) used = XP.cap;
+				std::vector<unsigned char> a((size_t)used), b((size_t)used);
+				std::vector<long long> xo((size_t)nT); std::vector<int> xl((size_t)xn);
+				D2H(st, a.data(), XP.base, (size_t)used); D2H(st, xo.data(), XP.xoff, (size_t)nT * 8); D2H(st, xl.data(), XP.xlist, (size_t)xn * 4);
+				setenv("BSX_XL", "0", 1);
+				launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, nullptr);
+				unsetenv("BSX_XL");
+				HIPCHK(hipStreamSynchronize(st));
+				D2H(st, b.data(), XP.base, (size_t)used);
+				long n_diff = 0, n_tot = 0;
+				for (unsigned int k = 0; k < xn; ++k) {
+					const int t = xl[k];
+					const int *H = (const int*)(a.data() + xo[t]);
+					const int nk = H[0], nsd = H[1], has = H[4];
+					if (!has) continue;
+					const size_t eo = (size_t)xo[t] + 24 + (size_t)nk * 24 + (size_t)nsd * 16;
+					for (int c = 0; c < nk; ++c) {
+						const long long *ea = (const long long*)(a.data() + eo + (size_t)c * 48), *eb = (const long long*)(b.data() + eo + (size_t)c * 48);
+						++n_tot;
+						if (memcmp(ea, eb, 48) != 0) {
+							if (n_diff++ < 12) {
+								int iaa[12]; memcpy(iaa, ea, 48); const int by_l = iaa[10] >> 30 & 1; iaa[10] &= 0x3fffffff; const int *ia = iaa, *ib = (const int*)eb; if (memcmp(iaa, eb, 48) == 0) { --n_diff; continue; }
+								const long long *sd = (const long long*)(a.data() + xo[t] + 24 + (size_t)nk * 24);
+								const int *ch = (const int*)(a.data() + xo[t] + 24 + (size_t)c * 24);
+								const int so = ch[3];
+								const short *sq = (const short*)(sd + 2 * (so + ia[10]) + 1);
+								fprintf(stderr, "[xl_check] by %s task %d (len %d) chain %d seed rbeg %lld qbeg %d len %d | xl: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d | x4: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d\n",
+								        by_l ? "k_extl" : "k_ext4", t, tasks[t].len, c, sd[2 * (so + ia[10])], (int)sq[0], (int)sq[1], ea[0], ea[1], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], eb[0], eb[1], ib[4], ib[5], ib[6], ib[7], ib[8], ib[9], ib[10], ib[11]);
+							}
+						}
+					}
+				}
+				fprintf(stderr, "[xl_check] %ld of %ld chain records differ\n", n_diff, n_tot);
+			}
 		}
 		launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
 		if (main_seq && chain == 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
@@ -847,10 +887,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
 		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
 		{
-			unsigned long long xp[6];
+			unsigned long long xp[11];
 			D2H(L.st, xp, ctr + 56, sizeof(xp));
 			HIPCHK(hipMemsetAsync(ctr + 56, 0, sizeof(xp), L.st));
-			if (xp[0]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions, %.2f slots per trip, %llu rows of narrow jobs\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3], xp[2] ? (double)xp[4] / xp[2] : 0.0, xp[5]);
+			if (xp[0] || xp[6]) fprintf(stderr, "[M::regions_batch] k_ext4: %llu jobs, %llu rows in %llu wave trips (%.2f rows per trip), %llu passes between extensions, %.2f slots per trip, %llu rows of narrow jobs\n", xp[0], xp[1], xp[2], xp[2] ? (double)xp[1] / xp[2] : 0.0, xp[3], xp[2] ? (double)xp[4] / xp[2] : 0.0, xp[5]);
+			if (xp[6]) fprintf(stderr, "[M::regions_batch] k_extl: %llu jobs (%llu sent on to k_ext4), %llu rows in %llu wave trips (%.1f rows per trip), %llu passes between extensions\n", xp[6], xp[10], xp[7], xp[8], xp[8] ? (double)xp[7] / xp[8] : 0.0, xp[9]);
 		}
 		unsigned long long pf[16];
 		D2H(L.st, pf, ctr + 32, sizeof(pf));
@@ -988,6 +1029,12 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
 		launch_ext4_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p, max_q);
+		if (atoi(getenv("BSX_EXT4")) == 2) { // then the lane-per-job kernel (k_extl.hip) over the same jobs: its answers replace the others'
+			HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
+			launch_extl_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p);
+			unsigned int c[4]; D2H(L.st, c, L.aux.p, 16);
+			fprintf(stderr, "[M::extl] %lld jobs, %u left to k_ext4\n", (long long)n, c[0]);
+		}
 		HIPCHK(hipGetLastError());
 		D2H(L.st, res, L.res.p, (size_t)n * sizeof(bsx_ext_res_t));
 		for (int64_t i = 0; i < n; ++i) if (res[i].score == X4_DECLINED) return BSX_E_ARG;

@@ -117,10 +117,10 @@ def _rand_ext_jobs(small_index, seqs, offs, rng, n, long_band=False):
     return jobs
 
 
-@pytest.mark.parametrize("form", ["wavefront_per_job", "quarter_wave_per_job"])
+@pytest.mark.parametrize("form", ["wavefront_per_job", "quarter_wave_per_job", "lane_per_job"])
 def test_extend_matches_oracle(small_index, port, device, form, monkeypatch):
-    if form != "wavefront_per_job":      # the rows of 16 lanes the regions path extends with (k_ext4.hip), on plain jobs
-        monkeypatch.setenv("BSX_EXT4", "1")
+    if form != "wavefront_per_job":      # the rows of 16 lanes the regions path extends with (k_ext4.hip), on plain jobs; "2": then the lane-per-job
+        monkeypatch.setenv("BSX_EXT4", "1" if form == "quarter_wave_per_job" else "2")   # kernel (k_extl.hip) over the same jobs, its answers replacing the others'
     opt = default_opt()
     rng = np.random.default_rng(11)
     seqs = _reads(small_index, n_pairs=200, read_len=150, seed=12)
@@ -160,12 +160,15 @@ def test_extend_matches_oracle(small_index, port, device, form, monkeypatch):
     assert (pr["score"] > jobs["h0"]).sum() > 50   # real extensions happened
 
 
-def test_extend_narrow_jobs_quarter_wave(small_index, port, device, monkeypatch):
+@pytest.mark.parametrize("form", ["quarter_wave_per_job", "lane_per_job"])
+def test_extend_narrow_jobs_quarter_wave(small_index, port, device, monkeypatch, form, capfd):
     """k_ext4 (k_ext4.hip: a row of 16 lanes per job) on the jobs the regions path is full of -- extensions from chance matches of
     19..26 bases: scores that decay, bands of a dozen columns, queries of any length, both directions and strands, targets on either side of
     the forward-reverse boundary, a few real continuations (the read's own locus) that run past the 48 rows of reference bases a row holds --
-    against the CPU restatement job by job."""
-    monkeypatch.setenv("BSX_EXT4", "1")
+    against the CPU restatement job by job.  lane_per_job: k_extl (k_extl.hip: a lane per job, the row a window of 64 columns in registers), which
+    has to answer most of them itself."""
+    import re
+    monkeypatch.setenv("BSX_EXT4", "1" if form == "quarter_wave_per_job" else "2")
     opt = default_opt()
     rng = np.random.default_rng(77)
     seqs = _reads(small_index, n_pairs=300, read_len=150, seed=13)
@@ -187,11 +190,37 @@ def test_extend_narrow_jobs_quarter_wave(small_index, port, device, monkeypatch)
         jobs[k]["tpos"] = pos + 20; jobs[k]["qoff"] = offs[r] + qe; jobs[k]["qlen"] = L - qe
         jobs[k]["tlen"] = L - qe + 100; jobs[k]["h0"] = 20; jobs[k]["w"] = 100; jobs[k]["end_bonus"] = 10
         jobs[k]["qdir"] = 1; jobs[k]["tdir"] = 1; jobs[k]["parent"] = par
+    # and continuations with mismatches (a diverged copy of a repeat: the scores neither take off nor die, the band stays a few dozen columns
+    # wide over many rows and the lane kernel's window has to follow it): the reads' buffer is mutated once the loci are known
+    mut = buf.copy()
+    pick = rng.random(len(mut)) < 0.06
+    mut[pick] = (mut[pick] + rng.integers(1, 4, int(pick.sum()))) & 3
+    for be in (port, device):
+        be.set_reads(mut)
+    for k, (r, par, pos, qb) in enumerate(loci[400:1400]):
+        k += 400
+        L = len(seqs[r])
+        qe = qb + int(rng.integers(19, 30))
+        if qe + 5 >= L or pos + L + 130 >= 2 * small_index.l_pac or pos < small_index.l_pac <= pos + L + 130 or qb < 8:
+            continue
+        if k & 1:   # to the right of the seed
+            jobs[k]["tpos"] = pos + (qe - qb); jobs[k]["qoff"] = offs[r] + qe; jobs[k]["qlen"] = L - qe
+            jobs[k]["tlen"] = L - qe + 100; jobs[k]["qdir"] = 1; jobs[k]["tdir"] = 1
+        else:       # to its left
+            jobs[k]["tpos"] = pos - 1; jobs[k]["qoff"] = offs[r] + qb - 1; jobs[k]["qlen"] = qb
+            jobs[k]["tlen"] = min(qb + 100, pos - (small_index.l_pac if pos >= small_index.l_pac else 0)); jobs[k]["qdir"] = -1; jobs[k]["tdir"] = -1
+        jobs[k]["h0"] = qe - qb; jobs[k]["w"] = 100; jobs[k]["end_bonus"] = 10; jobs[k]["parent"] = par
+    jobs = jobs[jobs["tlen"] > 0]
     pr = port.extend(jobs)
+    capfd.readouterr()
     dr = device.extend(jobs)
+    err = capfd.readouterr().err
     bad = np.nonzero(pr != dr)[0]
     assert len(bad) == 0, (len(bad), jobs[bad[:3]], pr[bad[:3]], dr[bad[:3]])
     assert (pr["tle"] > 48).sum() > 20    # extensions that refill their reference bases
+    if form == "lane_per_job":
+        m = re.search(r"(\d+) jobs, (\d+) left to k_ext4", err)
+        assert m and int(m.group(1)) == len(jobs) and int(m.group(2)) < len(jobs) // 3, err[-300:]
 
 
 def _locus_of(small_index, port, opt, seqs, offs):
