@@ -119,7 +119,7 @@ k_extl(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, void *jobs
 						if (side == 1 && s_qbeg + s_len == l_query) { R_qe = l_query; R_re = s_rbeg + s_len; side = 2; }
 						if (side >= 2) {
 							RgXExt xe; xe.rb = R_rb; xe.re = R_re; xe.qb = R_qb; xe.qe = R_qe; xe.score = R_score; xe.truesc = R_truesc;
-							xe.aw0 = aw0; xe.aw1 = aw1; xe.si = si | (P.prof == 77 ? 1 << 30 : 0); xe.status = 1;
+							xe.aw0 = aw0; xe.aw1 = aw1; xe.si = si; xe.status = 1;
 							*(RgXExt*)(xbase + ext_at) = xe;
 							st = XL_IDLE;
 						}

@@ -718,11 +718,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			return BSX_OK;
 		}
 		if (XP.ext) {
-			if (main_seq && getenv("BSX_XL_CHECK")) R.prof = 77;
-			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof && R.prof != 77 ? ctr + 56 : nullptr);
-			if (R.prof == 77) R.prof = 0;
+			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
-			if (main_seq && getenv("BSX_XL_CHECK")) { // debugging: the records as k_extl + k_ext4 left them against k_ext4 alone
+			if (main_seq && getenv("BSX_XL_CHECK")) { // $BSX_XL_CHECK (tools/dbg/xlchk.sh): the records as k_extl + k_ext4 left them against k_ext4 alone, record by record
 				unsigned long long used = 0; unsigned int xn = 0;
 				HIPCHK(hipStreamSynchronize(st));
 				D2H(st, &used, XP.cursor, 8); D2H(st, &xn, XP.xcount, 4);
@@ -747,13 +745,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 						++n_tot;
 						if (memcmp(ea, eb, 48) != 0) {
 							if (n_diff++ < 12) {
-								int iaa[12]; memcpy(iaa, ea, 48); const int by_l = iaa[10] >> 30 & 1; iaa[10] &= 0x3fffffff; const int *ia = iaa, *ib = (const int*)eb; if (memcmp(iaa, eb, 48) == 0) { --n_diff; continue; }
+								const int *ia = (const int*)ea, *ib = (const int*)eb;
 								const long long *sd = (const long long*)(a.data() + xo[t] + 24 + (size_t)nk * 24);
 								const int *ch = (const int*)(a.data() + xo[t] + 24 + (size_t)c * 24);
 								const int so = ch[3];
 								const short *sq = (const short*)(sd + 2 * (so + ia[10]) + 1);
-								fprintf(stderr, "[xl_check] by %s task %d (len %d) chain %d seed rbeg %lld qbeg %d len %d | xl: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d | x4: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d\n",
-								        by_l ? "k_extl" : "k_ext4", t, tasks[t].len, c, sd[2 * (so + ia[10])], (int)sq[0], (int)sq[1], ea[0], ea[1], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], eb[0], eb[1], ib[4], ib[5], ib[6], ib[7], ib[8], ib[9], ib[10], ib[11]);
+								fprintf(stderr, "[xl_check] task %d (len %d) chain %d seed rbeg %lld qbeg %d len %d | xl: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d | x4: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d\n",
+								        t, tasks[t].len, c, sd[2 * (so + ia[10])], (int)sq[0], (int)sq[1], ea[0], ea[1], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], eb[0], eb[1], ib[4], ib[5], ib[6], ib[7], ib[8], ib[9], ib[10], ib[11]);
 							}
 						}
 					}
