@@ -198,15 +198,16 @@ static int cq_get(chunk_q_t *Q, chunk_rec_t *r)   /* 0 when the queue is closed 
 static void emit_chunk(bsx_read_t *seqs, int n, int64_t chunk_idx, int ok);
 static volatile int g_write_error = 0;   /* a write to stdout failed (the reference aborts there: err_fputs, utils.c:214) */
 /* Several ranks over plain files: a scanner thread lists the chunk boundaries without building records (fastq.c) and this rank
- * parses only its own chunks r, r+N, ..., seeking to each.  Compressed or piped input: every rank parses everything and drops
- * the chunks of the others (the chunk rule is cumulative). */
+ * parses only its own chunks r, r+N, ..., seeking to each.  Compressed or piped input: every rank inflates everything (threads of
+ * fastq.c, ahead of the parser), parses its own chunks and walks the others' by the record grammar without building records (the chunk
+ * rule is cumulative). */
 static bsx_fq_scan_t *shard_scan_start(const char *fn1, const char *fn2, int chunk)
 {
 	bsx_fq_scan_t *s;
 	if (bsx_shard_world <= 1 || getenv("BSX_NO_CHUNK_SCAN")) return 0;
 	s = bsx_fq_scan_start(fn1, fn2, chunk);
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] rank %d of %d: %s\n", "main_align", bsx_shard_rank, bsx_shard_world,
-	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank parses all of it and drops the chunks of the others");
+	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank inflates all of it, parses its own chunks and walks the others without building records");
 	return s;
 }
 typedef struct { chunk_q_t *Q; bsx_fq_t *f1, *f2; const char *fn1, *fn2; int chunk, has_bc, copy_comment; volatile int stop, failed; } reader_t;
@@ -215,12 +216,27 @@ static void *reader_main(void *arg)
 	reader_t *R = (reader_t*)arg;
 	int64_t idx = 0;
 	bsx_fq_scan_t *scan = shard_scan_start(R->fn1, R->fn2, R->chunk);
-	bsx_fq_pair_t *P = scan ? 0 : bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
+	/* several ranks over input that cannot be sought in (compressed, piped): the chunks of the other ranks are walked without building
+	 * their records (bsx_fq_skip_chunk); this rank's own are parsed in place, the inflate threads of fastq.c running ahead of both */
+	const int skip_mode = !scan && bsx_shard_world > 1 && !getenv("BSX_NO_CHUNK_SKIP");
+	int64_t n_before = 0;
+	bsx_fq_pair_t *P = (scan || skip_mode) ? 0 : bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
 	if (scan) idx = bsx_shard_rank;
 	while (!R->stop) {
 		chunk_rec_t r;
 		int i;
 		r.n_before = -1;
+		if (skip_mode) {
+			if (idx % bsx_shard_world != bsx_shard_rank) {
+				const int n = bsx_fq_skip_chunk(R->f1, R->f2, R->chunk);
+				if (n == 0) break;
+				n_before += n; ++idx;
+				continue;
+			}
+			r.seqs = bsx_fq_read_chunk(R->f1, R->f2, R->chunk, R->has_bc, &r.n);
+			r.n_before = n_before;
+			n_before += r.n;
+		} else
 		if (scan) { /* this rank's next chunk: where it starts is known, the parser threads start there */
 			bsx_fq_chunkpos_t cp;
 			if (!bsx_fq_scan_get(scan, idx, &cp)) break;
@@ -526,6 +542,13 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 					if (bsx_fq_seek(f1, cp.off1) != 0 || (f2 && bsx_fq_seek(f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "main_align"); rc = 1; break; }
 					chunk_idx = k - 1;
 					n_processed = cp.n_before;
+				}
+				if (!scan && bsx_shard_world > 1 && (chunk_idx + 1) % bsx_shard_world != bsx_shard_rank && !getenv("BSX_NO_CHUNK_SKIP")) {
+					/* another rank's chunk of input that cannot be sought in: walked, not parsed (bsx_fq_skip_chunk) */
+					const int ns = bsx_fq_skip_chunk(f1, f2, chunk);
+					if (ns == 0) break;
+					n_processed += ns; ++chunk_idx;
+					continue;
 				}
 				seqs = bsx_fq_read_chunk(f1, f2, chunk, opt->has_bc, &n);
 				if (seqs == 0 || n == 0) { free(seqs); break; }

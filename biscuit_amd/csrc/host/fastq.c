@@ -12,9 +12,32 @@
 #include "fastq.h"
 
 const uint8_t *bsx_nt4_table(void);
+int bsx_fq_plain_file(const char *fn);
+
+/* ---- where a reader gets its bytes.  A plain regular file is read in place (offsets into it mean something: the chunk scan and
+ * bsx_fq_seek).  Compressed or piped input is inflated AHEAD of the parser by threads of its own (with the aligner on
+ * the GPU, inflating and parsing the FASTQ is what the command line waits for):
+ *   - a BGZF file (gzip members of <= 64 KB with a 'BC' extra field, what bgzip and most sequencers' tools write) is inflated block by
+ *     block by several workers, each block on its own (raw deflate, the member's size is in its header);
+ *   - any other gzip stream (one member, or members of unknown size) has one thread that runs zlib's gzread into a ring of buffers,
+ *     so that inflating overlaps parsing.
+ * $BSX_INFLATE_THREADS: workers per BGZF file (default 3); 0 = no threads at all, every read a plain gzread as before. */
+#define SRC_SLOT (1 << 20)
+#define SRC_RING 24
+typedef struct { unsigned char *data; int n, cap; unsigned char *comp; int ncomp; int state; } src_slot_t;   /* state: 0 free, 1 compressed block loaded, 2 being inflated, 3 ready */
+typedef struct fq_src {
+	int mode;                 /* 1: gzread thread, 2: BGZF workers */
+	gzFile gz; FILE *fp;
+	src_slot_t ring[SRC_RING];
+	int64_t head, tail, next_job;   /* consumer's slot, producer's next slot, next compressed slot a worker takes */
+	int eof, stop, failed, head_pos;
+	pthread_mutex_t mu; pthread_cond_t cv;
+	pthread_t th_read, th_work[8]; int n_work;
+} fq_src_t;
 
 struct bsx_fq {
 	gzFile fp;
+	fq_src_t *src;
 	unsigned char *buf;
 	int begin, end, is_eof, last_char;
 	int64_t base;        /* file offset of buf[0] (plain files: the chunk scan and bsx_fq_seek) */
@@ -24,14 +47,172 @@ struct bsx_fq {
 
 #define FQ_BUFSZ (1 << 18)
 
+static void *src_gz_main(void *arg)   /* mode 1: the one thread that inflates */
+{
+	fq_src_t *S = (fq_src_t*)arg;
+	for (;;) {
+		src_slot_t *sl;
+		int n;
+		pthread_mutex_lock(&S->mu);
+		while (S->tail - S->head >= SRC_RING && !S->stop) pthread_cond_wait(&S->cv, &S->mu);
+		if (S->stop) { pthread_mutex_unlock(&S->mu); return 0; }
+		sl = &S->ring[S->tail % SRC_RING];
+		pthread_mutex_unlock(&S->mu);
+		if (!sl->data) { sl->data = (unsigned char*)malloc(SRC_SLOT); sl->cap = SRC_SLOT; }
+		n = gzread(S->gz, sl->data, SRC_SLOT);
+		pthread_mutex_lock(&S->mu);
+		if (n <= 0) { S->eof = 1; if (n < 0) S->failed = 1; pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu); return 0; }
+		sl->n = n; sl->state = 3; ++S->tail;
+		pthread_cond_broadcast(&S->cv);
+		pthread_mutex_unlock(&S->mu);
+	}
+}
+/* a BGZF block header at the file's current position: its total size, 0 at a clean end of file, -1 if it is not one */
+static int bgzf_block_size(FILE *fp, unsigned char hdr[18])
+{
+	size_t k = fread(hdr, 1, 18, fp);
+	if (k == 0) return 0;
+	if (k < 18 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4) || hdr[10] != 6 || hdr[11] != 0 || hdr[12] != 'B' || hdr[13] != 'C' || hdr[14] != 2 || hdr[15] != 0) return -1;
+	return (hdr[16] | hdr[17] << 8) + 1;
+}
+static void *src_bgzf_read_main(void *arg)   /* mode 2: loads the compressed blocks, in order */
+{
+	fq_src_t *S = (fq_src_t*)arg;
+	for (;;) {
+		src_slot_t *sl;
+		unsigned char hdr[18];
+		int bs;
+		pthread_mutex_lock(&S->mu);
+		while (S->tail - S->head >= SRC_RING && !S->stop) pthread_cond_wait(&S->cv, &S->mu);
+		if (S->stop) { pthread_mutex_unlock(&S->mu); return 0; }
+		sl = &S->ring[S->tail % SRC_RING];
+		pthread_mutex_unlock(&S->mu);
+		bs = bgzf_block_size(S->fp, hdr);
+		if (bs > 0) {
+			if (!sl->comp) sl->comp = (unsigned char*)malloc(65536 + 64);
+			if (bs < 26 || bs > 65536 || fread(sl->comp, 1, (size_t)bs - 18, S->fp) != (size_t)bs - 18) bs = -1;
+			else sl->ncomp = bs - 18 - 8;   /* the deflate stream; behind it CRC32 and ISIZE */
+		}
+		pthread_mutex_lock(&S->mu);
+		if (bs <= 0) { S->eof = 1; if (bs < 0) S->failed = 1; pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu); return 0; }
+		sl->state = 1; ++S->tail;
+		pthread_cond_broadcast(&S->cv);
+		pthread_mutex_unlock(&S->mu);
+	}
+}
+static void *src_bgzf_work_main(void *arg)   /* mode 2: a worker inflates the next loaded block */
+{
+	fq_src_t *S = (fq_src_t*)arg;
+	z_stream z;
+	memset(&z, 0, sizeof(z));
+	if (inflateInit2(&z, -15) != Z_OK) return 0;
+	for (;;) {
+		src_slot_t *sl;
+		int ok;
+		pthread_mutex_lock(&S->mu);
+		while (!(S->next_job < S->tail) && !S->stop && !S->eof) pthread_cond_wait(&S->cv, &S->mu);
+		if (S->stop || !(S->next_job < S->tail)) { pthread_mutex_unlock(&S->mu); break; }
+		sl = &S->ring[S->next_job % SRC_RING];
+		++S->next_job;
+		sl->state = 2;
+		pthread_mutex_unlock(&S->mu);
+		if (!sl->data) { sl->data = (unsigned char*)malloc(65536); sl->cap = 65536; }
+		inflateReset(&z);
+		z.next_in = sl->comp; z.avail_in = (unsigned)sl->ncomp; z.next_out = sl->data; z.avail_out = 65536;
+		ok = inflate(&z, Z_FINISH) == Z_STREAM_END;
+		pthread_mutex_lock(&S->mu);
+		sl->n = ok ? (int)z.total_out : 0;
+		if (!ok) S->failed = 1;
+		sl->state = 3;
+		pthread_cond_broadcast(&S->cv);
+		pthread_mutex_unlock(&S->mu);
+	}
+	inflateEnd(&z);
+	return 0;
+}
+/* the next bytes of the stream, up to cap of them; 0 at its end */
+static int src_read(fq_src_t *S, unsigned char *dst, int cap)
+{
+	int got = 0;
+	while (got == 0) {
+		src_slot_t *sl;
+		int k;
+		pthread_mutex_lock(&S->mu);
+		for (;;) {
+			sl = &S->ring[S->head % SRC_RING];
+			if (S->head < S->tail && sl->state == 3) break;
+			if (S->head >= S->tail && S->eof) { pthread_mutex_unlock(&S->mu); if (S->failed) fprintf(stderr, "[E::%s] the compressed input is damaged or truncated\n", "fastq"); return 0; }
+			pthread_cond_wait(&S->cv, &S->mu);
+		}
+		pthread_mutex_unlock(&S->mu);
+		k = sl->n - S->head_pos; k = k < cap ? k : cap;
+		if (k > 0) { memcpy(dst, sl->data + S->head_pos, (size_t)k); S->head_pos += k; got = k; }
+		if (S->head_pos >= sl->n) {
+			pthread_mutex_lock(&S->mu);
+			sl->state = 0; S->head_pos = 0; ++S->head;
+			pthread_cond_broadcast(&S->cv);
+			pthread_mutex_unlock(&S->mu);
+		}
+	}
+	return got;
+}
+static fq_src_t *src_open(const char *fn)
+{
+	const char *e = getenv("BSX_INFLATE_THREADS");
+	int nw = e ? atoi(e) : 3, is_gz = 0, is_bgzf = 0, i;
+	fq_src_t *S;
+	if (nw <= 0) return 0;
+	if (strcmp(fn, "-") != 0) {
+		FILE *fp = fopen(fn, "rb");
+		unsigned char hdr[18];
+		if (!fp) return 0;
+		if (fread(hdr, 1, 2, fp) == 2 && hdr[0] == 0x1f && hdr[1] == 0x8b) { is_gz = 1; rewind(fp); is_bgzf = bgzf_block_size(fp, hdr) > 0; }
+		else if (bsx_fq_plain_file(fn)) { fclose(fp); return 0; }   /* a plain regular file: read in place */
+		fclose(fp);
+	}
+	(void)is_gz;
+	S = (fq_src_t*)calloc(1, sizeof(*S));
+	pthread_mutex_init(&S->mu, 0); pthread_cond_init(&S->cv, 0);
+	if (is_bgzf) {
+		S->mode = 2;
+		S->fp = fopen(fn, "rb");
+		S->n_work = nw < 8 ? nw : 8;
+		pthread_create(&S->th_read, 0, src_bgzf_read_main, S);
+		for (i = 0; i < S->n_work; ++i) pthread_create(&S->th_work[i], 0, src_bgzf_work_main, S);
+	} else {
+		S->mode = 1;
+		S->gz = strcmp(fn, "-") == 0 ? gzdopen(0, "r") : gzopen(fn, "r");
+		if (!S->gz) { free(S); return 0; }
+		gzbuffer(S->gz, 1 << 20);
+		pthread_create(&S->th_read, 0, src_gz_main, S);
+	}
+	return S;
+}
+static void src_close(fq_src_t *S)
+{
+	int i;
+	if (!S) return;
+	pthread_mutex_lock(&S->mu); S->stop = 1; pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu);
+	pthread_join(S->th_read, 0);
+	for (i = 0; i < S->n_work; ++i) pthread_join(S->th_work[i], 0);
+	for (i = 0; i < SRC_RING; ++i) { free(S->ring[i].data); free(S->ring[i].comp); }
+	if (S->gz) gzclose(S->gz);
+	if (S->fp) fclose(S->fp);
+	free(S);
+}
+
 bsx_fq_t *bsx_fq_open(const char *fn)
 {
 	bsx_fq_t *f;
-	gzFile fp = strcmp(fn, "-") == 0 ? gzdopen(0, "r") : gzopen(fn, "r");
-	if (!fp) return 0;
-	gzbuffer(fp, 1 << 20);
+	fq_src_t *src = src_open(fn);
+	gzFile fp = 0;
+	if (!src) {
+		fp = strcmp(fn, "-") == 0 ? gzdopen(0, "r") : gzopen(fn, "r");
+		if (!fp) return 0;
+		gzbuffer(fp, 1 << 20);
+	}
 	f = (bsx_fq_t*)calloc(1, sizeof(*f));
-	f->fp = fp;
+	f->fp = fp; f->src = src;
 	f->buf = (unsigned char*)malloc(FQ_BUFSZ);
 	return f;
 }
@@ -39,18 +220,20 @@ bsx_fq_t *bsx_fq_open(const char *fn)
 void bsx_fq_close(bsx_fq_t *f)
 {
 	if (!f) return;
-	gzclose(f->fp);
+	if (f->fp) gzclose(f->fp);
+	src_close(f->src);
 	free(f->buf); bsx_vec_free(f->name); bsx_vec_free(f->comment); bsx_vec_free(f->seq); bsx_vec_free(f->qual);
 	free(f);
 }
 
+static inline int fq_more(bsx_fq_t *f) { return f->src ? src_read(f->src, f->buf, FQ_BUFSZ) : gzread(f->fp, f->buf, FQ_BUFSZ); }
 static inline int fq_getc(bsx_fq_t *f)
 {
 	if (f->is_eof && f->begin >= f->end) return -1;
 	if (f->begin >= f->end) {
 		f->base += f->end;
 		f->begin = 0;
-		f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
+		f->end = fq_more(f);
 		if (f->end <= 0) { f->is_eof = 1; f->end = 0; return -1; }
 	}
 	return (int)f->buf[f->begin++];
@@ -64,7 +247,7 @@ static inline int fq_fill(bsx_fq_t *f)
 	if (f->is_eof) return 0;
 	f->base += f->end;
 	f->begin = 0;
-	f->end = gzread(f->fp, f->buf, FQ_BUFSZ);
+	f->end = fq_more(f);
 	if (f->end <= 0) { f->is_eof = 1; f->end = 0; return 0; }
 	return 1;
 }
@@ -364,6 +547,7 @@ int bsx_fq_plain_file(const char *fn)   /* a regular, uncompressed file: offsets
 }
 int bsx_fq_seek(bsx_fq_t *f, int64_t off)
 {
+	if (f->src) return -1;   /* (only plain files are sought in, and those have no inflate threads) */
 	if (gzseek(f->fp, (z_off_t)off, SEEK_SET) < 0) return -1;
 	f->begin = f->end = 0; f->is_eof = 0; f->last_char = 0; f->base = off; f->last_off = 0;
 	return 0;
@@ -446,6 +630,23 @@ BSX_API int64_t bsx_fq_scan_table(const char *fn1, const char *fn2, int chunk_si
 	while (bsx_fq_scan_get(S, k, &cp)) { if (k < cap) out[k] = cp; ++k; }
 	bsx_fq_scan_close(S);
 	return k;
+}
+
+/* the next chunk walked without building its records (the chunk rule of bsx_fq_read_chunk over fq_scan): how many reads it holds.  What a
+ * rank does with the chunks of the other ranks when the input cannot be sought in (compressed, piped): the stream has to be inflated
+ * and its grammar followed, but nothing is copied or allocated. */
+int bsx_fq_skip_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size)
+{
+	int64_t size = 0, o;
+	int n = 0, l;
+	while ((l = fq_scan(f1, &o)) >= 0) {
+		int l2 = 0;
+		if (f2 && (l2 = fq_scan(f2, &o)) < 0) break;
+		size += l; ++n;
+		if (f2) { size += l2; ++n; }
+		if (size >= chunk_size && (n & 1) == 0) break;
+	}
+	return n;
 }
 
 void bsx_read_free(bsx_read_t *s)

@@ -10,6 +10,7 @@ bsx_read_t *bsx_fq_read_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size, int ha
 void bsx_read_free(bsx_read_t *s);
 /* the same chunks, with one parser thread per file working ahead of the caller */
 typedef struct bsx_fq_pair bsx_fq_pair_t;
+int bsx_fq_skip_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size);   /* reads in the next chunk, walked without building records */
 bsx_fq_pair_t *bsx_fq_pair_open(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc);
 bsx_fq_pair_t *bsx_fq_pair_open_n(bsx_fq_t *f1, bsx_fq_t *f2, int has_bc, long n_records);   /* the parsers stop after n_records records per file */
 bsx_read_t *bsx_fq_pair_read_chunk(bsx_fq_pair_t *p, int chunk_size, int *n);

@@ -265,3 +265,86 @@ def test_chunk_scan_equals_the_reader(tmp_path):
     pz = str(tmp_path / "z.fq.gz")
     gzip.open(pz, "wt").write(a)
     assert scan_table(pz, None, 2000) is None
+
+
+def write_bgzf(path, data, block=20000):
+    """a BGZF file (what bgzip writes): gzip members of at most 64 KB, each with a 'BC' extra field holding its own size, then the empty
+    end-of-file member"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for i in list(range(0, len(data), block)) + [None]:
+            raw = b"" if i is None else data[i:i + block]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = c.compress(raw) + c.flush()
+            bsize = 18 + len(body) + 8
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + body + struct.pack("<II", zlib.crc32(raw), len(raw)))
+
+
+def test_inflate_threads_give_the_same_records(tmp_path, monkeypatch):
+    """Compressed input inflated ahead of the parser (fastq.c: several workers over the blocks of a BGZF file, one gzread thread over any
+    other gzip stream, multi-member ones included) against the plain file and against the reader with the threads off: same chunks."""
+    rng = random.Random(11)
+    a, b = make_text(rng, 6000), make_text(rng, 6000, multiline=True)
+    plain1, plain2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    open(plain1, "w").write(a); open(plain2, "w").write(b)
+    gz1, gz2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq.gz")
+    gzip.open(gz1, "wt").write(a)
+    with open(gz2, "wb") as f:   # three members
+        k = len(b) // 3
+        for part in (b[:k], b[k:2 * k], b[2 * k:]):
+            f.write(gzip.compress(part.encode()))
+    bg1, bg2 = str(tmp_path / "a.bgz.fq.gz"), str(tmp_path / "b.bgz.fq.gz")
+    write_bgzf(bg1, a.encode()); write_bgzf(bg2, b.encode(), block=65000)
+    assert gzip.open(bg1, "rt").read() == a          # (zlib itself reads what write_bgzf wrote)
+    for chunk in (5000, 200000):
+        want = read_all(plain1, plain2, chunk)
+        for p1, p2 in ((gz1, gz2), (bg1, bg2), (bg1, plain2)):
+            for threads in ("3", "1", "0"):
+                monkeypatch.setenv("BSX_INFLATE_THREADS", threads)
+                assert read_all(p1, p2, chunk) == want, (p1, p2, threads)
+                assert read_all_threaded(p1, p2, chunk) == [[r + (i,) for i, r in enumerate(ch)] for ch in want]
+    # a truncated BGZF file ends the input at the damage instead of hanging
+    monkeypatch.setenv("BSX_INFLATE_THREADS", "3")
+    cut = str(tmp_path / "cut.fq.gz")
+    open(cut, "wb").write(open(bg1, "rb").read()[:30000])
+    got = read_all(cut, None, 10 ** 7)
+    assert 0 < sum(len(c) for c in got) < 6000
+
+
+def test_skip_chunk_counts_what_the_reader_reads(tmp_path):
+    """What a rank does with the chunks of the other ranks over compressed input: bsx_fq_skip_chunk walks a chunk without building records and
+    leaves the stream where the next chunk starts -- alternating skipped and parsed chunks gives every other chunk of the plain reader."""
+    L = B.lib()
+    L.bsx_hook_fq_skip_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.bsx_hook_fq_open.restype = C.c_void_p
+    L.bsx_hook_fq_open.argtypes = [C.c_char_p]
+    L.bsx_hook_fq_close.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_chunk.restype = C.POINTER(B.Read)
+    L.bsx_hook_fq_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    rng = random.Random(12)
+    a, b = make_text(rng, 4000, multiline=True), make_text(rng, 4000, crlf=True)
+    p1, p2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq.gz")
+    write_bgzf(p1, a.encode()); gzip.open(p2, "wt", newline="").write(b)
+    for chunk in (3000, 40000):
+        want = read_all(p1, p2, chunk)
+        for mine in (0, 1):
+            f1, f2 = L.bsx_hook_fq_open(p1.encode()), L.bsx_hook_fq_open(p2.encode())
+            k = 0
+            while True:
+                if k % 2 != mine:
+                    n = L.bsx_hook_fq_skip_chunk(f1, f2, chunk)
+                    if n == 0:
+                        break
+                    assert n == len(want[k]), (chunk, k)
+                else:
+                    n = C.c_int()
+                    r = L.bsx_hook_fq_chunk(f1, f2, chunk, 0, C.byref(n))
+                    if not r or n.value == 0:
+                        break
+                    assert [r[i].name.decode() for i in range(n.value)] == [x[0] for x in want[k]]
+                    L.bsx_sim_free_reads(r, n.value)
+                k += 1
+            assert k == len(want)
+            L.bsx_hook_fq_close(f1); L.bsx_hook_fq_close(f2)
