@@ -70,16 +70,6 @@ def big():
     g["idx"].close()
 
 
-@pytest.fixture(scope="module")
-def hard():
-    """the genome behind bench.py's `hg38_like_genome` line: profile 1 of csrc/host/sim.c (SINE/LINE/LTR-like families of up to a million
-    copies, satellite arrays: ~43 % repeats), same seed, size and contigs"""
-    g = _make(1)
-    yield g
-    g["dev"].close()
-    g["idx"].close()
-
-
 def _text(pac, l_pac, parent, pos, n):
     """n symbols of the converted text [fwd ; revcomp(fwd)] from pos"""
     i = np.arange(pos, min(pos + n, 2 * l_pac), dtype=np.int64)
@@ -316,152 +306,6 @@ def test_command_line_equals_end_to_end_oracle_from_index_files(big, tmp_path_fa
     L.bsx_sim_free_reads(p, 2 * n_pairs)
     try:
         for args in (["-@", "4", "g", "r1.fq", "r2.fq"], ["-@", "4", "-b", "1", "g", "r1.fq"]):
-            want = E.run_e2e(args, d)
-            got = E.run_exe(os.path.join(root, "biscuit_amd", "biscuit_align"), args, d)
-            assert got.count(b"\n") > n_pairs
-            E.assert_same_sam(got, want, " ".join(args))
-    finally:
-        for f in os.listdir(d):
-            os.remove(os.path.join(d, f))
-
-
-# ---- the hg38-like genome at the size the bench reports a number on: what is hot there (the HBM tiers walking over-represented
-# intervals past max_occ, the second seeding pass, thousands of seeds per strand search, strand searches chained on the host)
-def _sim(idx, n_pairs, seed, sub=0.005, pbat=0.1, truth=None):
-    L = B.lib()
-    L.bsx_sim_pairs_truth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p), C.c_void_p]
-    p = C.c_void_p()
-    B.check(L.bsx_sim_pairs_truth(idx.h, n_pairs, 150, seed, 200, 500, sub, pbat, C.byref(p), truth.ctypes.data_as(C.c_void_p) if truth is not None else None), "sim_pairs")
-    return p
-
-
-@pytest.mark.parametrize("max_occ", [500, 100])
-def test_hg38_like_sam_identical(hard, max_occ, capfd):
-    """20 k pairs against the 3.1 Gbp hg38-like genome, defaults and -c 100: SAM of the HIP pipeline == SAM of the CPU restatement byte
-    for byte; the paths that are hot on this genome were really taken (strand searches seeded again with longer lists; with -c 100,
-    over-represented intervals)."""
-    import re
-    L = B.lib()
-    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
-    n_pairs = 20000
-    n = 2 * n_pairs
-    p = _sim(hard["idx"], n_pairs, 31337)
-    opt = default_opt()
-    opt.n_threads = 16
-    opt.flag |= 0x10 | 0x2
-    opt.max_occ = max_occ
-    os.environ["BSX_PHASES"] = "1"
-    try:
-        capfd.readouterr()
-        hip, cpu = _run_both(hard, opt, p, n)
-        err = capfd.readouterr().err
-        bad = [i for i in range(n) if hip[i] != cpu[i]]
-        assert not bad, "-c %d: SAM differs for %d reads, first: %r vs %r" % (max_occ, len(bad), hip[bad[0]][:400], cpu[bad[0]][:400])
-        m = re.search(r"redo of (\d+) strand searches", err)
-        assert m and int(m.group(1)) > 0, err[-600:]              # the second seeding pass ran
-        m = re.search(r"left tier 1: (\d+), left tier 1b: (\d+)", err)
-        assert m and int(m.group(2)) > 0, err[-600:]              # strand searches reached the HBM tiers
-        mapped = np.mean([not (int(s.split(b"\t")[1]) & 4) for s in hip])
-        assert mapped > 0.9, mapped
-    finally:
-        os.environ.pop("BSX_PHASES", None)
-        L.bsx_sim_free_reads(p, n)
-
-
-def test_hg38_like_full_chunk_properties(hard):
-    """One full chunk of the bench (-@ 16: 1 066 666 reads) on the bench's hg38-like genome: every record of a sample valid against the
-    genome, reads found where they were simulated from, the same chunk twice gives the same SAM (checksum of checksums), and the pipelined
-    stream gives it too."""
-    import zlib
-    L = B.lib()
-    idx, dev = hard["idx"], hard["dev"]
-    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
-    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
-    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
-    L.bsx_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
-    L.bsx_stream_push.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    L.bsx_stream_flush.argtypes = [C.c_void_p]
-    L.bsx_stream_close.argtypes = [C.c_void_p]
-    L.bsx_stream_close.restype = None
-    opt = default_opt()
-    opt.n_threads = 16
-    opt.flag |= 0x10 | 0x2
-    n_pairs = (opt.chunk_size * 16) // 300
-    n = 2 * n_pairs
-    truth = np.zeros(2 * n_pairs, dtype=np.int64)
-    p = _sim(idx, n_pairs, 900, pbat=0.0, truth=truth)
-    r = C.cast(p, C.POINTER(B.Read))
-
-    def crc():
-        c = 0
-        for i in range(n):
-            c = zlib.crc32(C.string_at(r[i].sam), c)
-        return c
-
-    try:
-        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, n, p, None), "process_seqs")
-        first = crc()
-        genome = {nm: PacContig(hard["pac"], off, ln) for nm, off, ln in hard["contigs"]}
-        ctg_off = {nm: off for nm, off, ln in hard["contigs"]}
-        rng = np.random.default_rng(3)
-        pick = rng.choice(n_pairs, 3000, replace=False)
-        text = b"".join(C.string_at(r[int(i) * 2 + e].sam) for i in pick for e in (0, 1)).decode()
-        hdr, recs = samcheck.parse_sam(text)
-        for rec in recs:
-            samcheck.check_record(rec, genome, 150)
-        samcheck.check_pairs(recs)
-        prim = [x for x in recs if not x["flag"] & 0x900]
-        assert len(prim) == 6000
-        assert np.mean([not x["flag"] & 4 for x in prim]) > 0.95
-        ok = tot = 0
-        for x in prim:
-            if x["flag"] & 4 or x["mapq"] < 30:
-                continue
-            pi = int(x["qname"][1:])
-            s, fl = int(truth[2 * pi]), int(truth[2 * pi + 1]) >> 1
-            g = ctg_off[x["rname"]] + x["pos"] - 1
-            tot += 1
-            ok += s - 10 <= g <= s + fl + 10
-        assert tot > 3000 and ok / tot > 0.99, (ok, tot)
-        L.bsx_sim_reset_reads(p, n)
-        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, n, p, None), "process_seqs")
-        assert crc() == first
-        L.bsx_sim_reset_reads(p, n)
-        s = C.c_void_p()
-        B.check(L.bsx_stream_open(dev.h, C.byref(opt), idx.h, None, C.byref(s)), "stream_open")
-        B.check(L.bsx_stream_push(s, 0, n, p), "push")
-        B.check(L.bsx_stream_flush(s), "flush")
-        L.bsx_stream_close(s)
-        assert crc() == first
-    finally:
-        L.bsx_sim_free_reads(p, n)
-
-
-def test_hg38_like_command_line_equals_end_to_end_oracle(hard, tmp_path_factory):
-    """The command line against oracle/e2e.py (the independent end-to-end restatement over the reference's own kernels) from the index
-    files of the hg38-like genome, 2 500 pairs: defaults and -c 100."""
-    import shutil
-    import e2e_cases as E
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libbiscuit_ref.so")):
-        pytest.skip("oracle/_ref is absent")
-    d = str(tmp_path_factory.mktemp("hg38_like_files"))
-    need = int(hard["l_pac"] * 3.6) + (2 << 30)
-    if shutil.disk_usage(d).free < need:
-        pytest.skip("not enough disk for the index files (%d GB)" % (need >> 30))
-    L = B.lib()
-    idx = hard["idx"]
-    idx.save(d + "/g")
-    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
-    L.bsx_sim_write_fastq.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int]
-    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
-    n_pairs = 2500
-    p = C.c_void_p()
-    B.check(L.bsx_sim_pairs(idx.h, n_pairs, 150, 777, 200, 500, 0.008, 0.15, C.byref(p)), "sim_pairs")
-    B.check(L.bsx_sim_write_fastq(p, 2 * n_pairs, (d + "/r1.fq").encode(), (d + "/r2.fq").encode(), 0), "write_fastq")
-    L.bsx_sim_free_reads(p, 2 * n_pairs)
-    try:
-        for args in (["-@", "4", "g", "r1.fq", "r2.fq"], ["-@", "4", "-c", "100", "g", "r1.fq", "r2.fq"]):
             want = E.run_e2e(args, d)
             got = E.run_exe(os.path.join(root, "biscuit_amd", "biscuit_align"), args, d)
             assert got.count(b"\n") > n_pairs
