@@ -213,6 +213,12 @@ class Device(Batches):
         B.check(B.lib().bsx_device_counters(self.h, c, int(reset)), "bsx_device_counters")
         return list(c)
 
+    def seed_table(self, reset=False):
+        """(table entries read by the seeding kernel since the last reset, depth K of the resident table of k-mer intervals; 0 = none)"""
+        n, k = C.c_uint64(), C.c_int()
+        B.check(B.lib().bsx_device_seed_table(self.h, C.byref(n), C.byref(k), int(reset)), "bsx_device_seed_table")
+        return int(n.value), int(k.value)
+
     def kernel_time(self, k, reset=False):
         ms = C.c_double()
         n = C.c_int64()

@@ -28,6 +28,10 @@ struct DevFmi {
 	uint32_t sa_shift;     // log2(sa_intv)
 };
 
+// bi-intervals of every string of up to K letters of a converted read's three-letter alphabet (seed_tab.hpp): 16-byte entries
+// (x0, x1, x2 low words, high bits), level L at ((3^L - 3) >> 1), a string's letters as base-3 digits, first letter most significant
+struct DevSeedTab { const uint4 *t[2]; int32_t K; int32_t pad_; };   // [1] parent, [0] daughter; K = 0: none
+
 struct DevIndex {
 	DevFmi fmi[2];         // [1] parent, [0] daughter
 	const uint8_t *pac;
@@ -35,6 +39,7 @@ struct DevIndex {
 	const int64_t *ctg_off;    // n_seqs + 1 contig offsets on the forward strand (bntann1_t.offset; [n_seqs] = l_pac)
 	const uint8_t *ctg_alt;    // n_seqs: is_alt
 	int32_t n_seqs;
+	DevSeedTab tab;
 };
 
 // the options the region kernel reads (mem_opt_t fields of the same name)
@@ -218,6 +223,25 @@ BSX_HD int dev_2occ4(const DevFmi &f, uint64_t k, uint64_t l, uint64_t ck[4], ui
 	cl[0] = lv ? ((uint64_t)B1.v0.y << 32 | B1.v0.x) + a : 0; cl[1] = lv ? ((uint64_t)B1.v0.w << 32 | B1.v0.z) + c : 0;
 	cl[2] = lv ? ((uint64_t)B1.v1.y << 32 | B1.v1.x) + g : 0; cl[3] = lv ? ((uint64_t)B1.v1.w << 32 | B1.v1.z) + t : 0;
 	return same ? 1 : 0;
+}
+
+// the same over the device's bit-plane blocks (the table builder of k_seedt.hip: a thread per extension)
+BSX_HD void dev_2occ4_planes(const DevFmi &f, uint64_t k, uint64_t l, uint64_t ck[4], uint64_t cl[4])
+{
+	const uint64_t NEG1 = ~0ull;
+	const uint64_t ka = k - (k >= f.primary), la = l - (l >= f.primary);
+	const bool kv = k != NEG1, lv = l != NEG1;
+	const bool same = kv && lv && (ka >> 7) == (la >> 7);
+	const DevBlock B0 = dev_load_block4(f.bwt, kv ? ka : 0);
+	DevBlock B1 = B0;
+	if (!same) B1 = dev_load_block4(f.bwt, lv ? la : 0);
+	uint32_t a, c, g, t;
+	dev_planes_count4(B0, (int)(ka & 127), a, c, g, t);
+	ck[0] = kv ? ((uint64_t)B0.v0.y << 32 | B0.v0.x) + a : 0; ck[1] = kv ? ((uint64_t)B0.v0.w << 32 | B0.v0.z) + c : 0;
+	ck[2] = kv ? ((uint64_t)B0.v1.y << 32 | B0.v1.x) + g : 0; ck[3] = kv ? ((uint64_t)B0.v1.w << 32 | B0.v1.z) + t : 0;
+	dev_planes_count4(B1, (int)(la & 127), a, c, g, t);
+	cl[0] = lv ? ((uint64_t)B1.v0.y << 32 | B1.v0.x) + a : 0; cl[1] = lv ? ((uint64_t)B1.v0.w << 32 | B1.v0.z) + c : 0;
+	cl[2] = lv ? ((uint64_t)B1.v1.y << 32 | B1.v1.x) + g : 0; cl[3] = lv ? ((uint64_t)B1.v1.w << 32 | B1.v1.z) + t : 0;
 }
 
 // One of the two resident indices picked by value with selects: indexing the kernel-argument struct with a

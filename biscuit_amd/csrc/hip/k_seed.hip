@@ -294,7 +294,7 @@ k_sa(DevIndex ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof)
+                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof, uint32_t *qpack, unsigned long long direct_off)
 {
 	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
 	// $BSX_SEED_FORM (measurements): 0 = blocks through registers and LDS stores, 1 = straight into LDS, 2 = that at four waves per SIMD (spills)
@@ -303,6 +303,13 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
 	// bounds it is the vector issue of the trips themselves -- 820 wave64 instructions at four cycles each on a 16-wide SIMD, three waves deep
 	static const unsigned int cold_mask = (getenv("BSX_SEED_COLD_EVERY") ? (unsigned int)atoi(getenv("BSX_SEED_COLD_EVERY")) : 4u) - 1u;
 	static const int cold_lanes = getenv("BSX_SEED_COLD_LANES") ? atoi(getenv("BSX_SEED_COLD_LANES")) : 24;
+	// the table form (k_seedt.hip) whenever the index has its table; $BSX_SEED_FORM=classic (or a number: the forms below) keeps this kernel
+	const bool classic = getenv("BSX_SEED_FORM") != nullptr;   // (read per launch: the tests switch it)
+	if (!classic) {
+		launch_seedt(st, grid, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, task_off, task_n, task_cursor, counters,
+		             quota, slab_busy, n_slabs, trip_budget, prof, qpack, direct_off);
+		return;
+	}
 	static const int form = getenv("BSX_SEED_FORM") ? atoi(getenv("BSX_SEED_FORM")) : SEED_FORM_DEFAULT;
 #define SEED_LAUNCH(...) hipLaunchKernelGGL((k_seed<__VA_ARGS__>), dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, \
 	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof, cold_mask, cold_lanes)

@@ -3,11 +3,22 @@
 #include <hip/hip_runtime.h>
 #include "dev_common.hpp"
 #include "seed_core.hpp"
+#include "seed_tab.hpp"
 
 void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
-                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof = 0);   // scratch holds n_slabs per-wave slabs; slab_busy[n_slabs] zeroed once
+                 int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof = 0, uint32_t *qpack = nullptr, unsigned long long direct_off = ~0ull);   // direct_off (table form only): the lists of strand search t go to out[direct_off + t * mem_cap ...] and stay there (task_off says so; no cursor); scratch holds n_slabs per-wave slabs; slab_busy[n_slabs] zeroed once; qpack: seedt_pack_bytes(n_tasks) of scratch for the table form (the reads as base-3 digits)
+// the same over the table of k-mer intervals (k_seedt.hip, seed_tab.hpp): what launch_seed runs when ix.tab.K >= 2 (and $BSX_SEED_FORM is not "classic");
+// counters[120] += table entries read
+void launch_seedt(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, const SeedParams &P,
+                  DevIntv *scratch, int list_cap, int mem_cap, DevIntv *out, unsigned long long out_cap, unsigned long long *out_cursor,
+                  long long *task_off, int *task_n, unsigned int *task_cursor, unsigned long long *counters,
+                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof = 0, uint32_t *qpack = nullptr, unsigned long long direct_off = ~0ull);
+size_t seedt_pack_bytes(long long n_tasks);
+void launch_gather_lists(hipStream_t st, const DevIntv *src, const long long *off, const int *cnt, const long long *which, const long long *dst_off, long long n_list, DevIntv *dst);
+// the table of one converted index, K levels (seed_tab_entries(K) entries of 16 bytes at `table`), from the index resident in ix
+int seedtab_build(hipStream_t st, const DevIndex &ix, int parent, int K, void *table);
 // the symbols of every 64-byte block from the file's 2-bit fields into the device's two bit planes, in place (n_words: the .bwt body)
 void launch_bwt_planes(hipStream_t st, uint32_t *bwt, unsigned long long n_words);
 void launch_sa(hipStream_t st, int grid, const DevIndex &ix, const bsx_sa_job_t *jobs, long long n, uint64_t *pos, unsigned long long *counters);

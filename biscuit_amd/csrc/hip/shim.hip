@@ -29,6 +29,8 @@ struct Lane {
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
+	DevBuf gath;             // lists gathered for the download of strand searches the caller takes back
+	DevBuf qpack;            // the chunk's reads as base-3 digits for the seeding kernel (k_seedt.hip)
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
 	int flt_key[3] = {-1, -1, -1};   // what fltab was made for
 	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd;
@@ -56,7 +58,7 @@ struct bsx_device {
 	char name[256];
 	int n_cu = 0;
 	DevIndex ix; bool has_index = false;
-	DevBuf bwt[2], sa[2], pac, ctg;
+	DevBuf bwt[2], sa[2], pac, ctg, seedtab[2];
 	Lane lane[BSX_LANES];   // scoring matrices and penalties are per lane (Lane::sc): chunks with different options may be in flight together
 	// Front halves of consecutive chunks are chained stage by stage (the seeding launch of chunk k+1 waits for that of chunk k, the
 	// region launches likewise): four chunks that share the device evenly all finish at the same moment, and the device then idles
@@ -129,11 +131,11 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	if (!d) return;
 	(void)hipSetDevice(d->ordinal);
 	devbuf_drain(d->ordinal);   // the blocks this device's buffers left behind when they grew
-	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); }
+	for (int i = 0; i < 2; ++i) { d->bwt[i].release(); d->sa[i].release(); d->seedtab[i].release(); }
 	d->pac.release(); d->ctg.release();
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
-		L.reads.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
+		L.reads.release(); L.qpack.release(); L.gath.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
 		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
@@ -178,6 +180,26 @@ static int upload_ref(bsx_device_t *d, const bsx_index_t *idx)
 		HIPCHK(hipMemcpy((char*)d->ctg.p + ((size_t)ns + 1) * 8, alt.data(), (size_t)ns, hipMemcpyHostToDevice));
 		d->ix.ctg_off = (const int64_t*)d->ctg.p; d->ix.ctg_alt = (const uint8_t*)d->ctg.p + ((size_t)ns + 1) * 8; d->ix.n_seqs = ns;
 	}
+	return BSX_OK;
+}
+
+// The table of k-mer intervals of both converted indices (seed_tab.hpp), built from the indices now resident: K levels, K chosen from the
+// text's size (18 for an hg38-sized genome: 2 x 9.3 GB), $BSX_SEED_TAB_K overrides (0: no table, every seeding step an FM extension).
+static int build_seed_tables(bsx_device_t *d)
+{
+	int K = seed_tab_depth(d->ix.fmi[0].seq_len);
+	if (const char *e = getenv("BSX_SEED_TAB_K")) { K = atoi(e); if (K < 2) K = 0; if (K > 19) K = 19; }
+	d->ix.tab.K = 0; d->ix.tab.t[0] = d->ix.tab.t[1] = nullptr; d->ix.tab.pad_ = 0;
+	if (K < 2) { d->seedtab[0].release(); d->seedtab[1].release(); return BSX_OK; }
+	Lane &L = d->lane[0];
+	for (int i = 0; i < 2; ++i) {
+		int rc;
+		if ((rc = d->seedtab[i].reserve_exact((size_t)seed_tab_entries(K) * sizeof(SeedEnt))) != BSX_OK) return rc;
+		if ((rc = seedtab_build(L.st, d->ix, i, K, d->seedtab[i].p)) != BSX_OK) return rc;
+	}
+	HIPCHK(hipStreamSynchronize(L.st));
+	HIPCHK(hipGetLastError());
+	d->ix.tab.t[0] = (const uint4*)d->seedtab[0].p; d->ix.tab.t[1] = (const uint4*)d->seedtab[1].p; d->ix.tab.K = K;
 	return BSX_OK;
 }
 
@@ -228,6 +250,7 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 			}
 		}
 	}
+	if ((rc = build_seed_tables(d)) != BSX_OK) return rc;
 	d->has_index = true;
 	return BSX_OK;
 }
@@ -267,6 +290,7 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 		while ((1 << g.sa_shift) < dense) ++g.sa_shift;
 	}
 	devbuf_drain(d->ordinal);   // the blocks the builder's growing buffers left behind on this device go now
+	if ((rc = build_seed_tables(d)) != BSX_OK) return rc;
 	d->has_index = true;
 	return BSX_OK;
 }
@@ -364,6 +388,23 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 	return BSX_OK;
 }
 
+// table entries read by the seeding kernel since the last reset (summed over the lanes), and the depth of the resident table
+extern "C" BSX_API int bsx_device_seed_table(bsx_device_t *d, uint64_t *lookups, int *depth, int reset)
+{
+	if (!d) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	uint64_t tot = 0;
+	for (int l = 0; l < BSX_LANES; ++l) {
+		uint64_t t = 0;
+		HIPCHK(hipMemcpy(&t, (char*)d->lane[l].small.p + 120 * 8, 8, hipMemcpyDeviceToHost));
+		tot += t;
+		if (reset) HIPCHK(hipMemset((char*)d->lane[l].small.p + 120 * 8, 0, 8));
+	}
+	if (lookups) *lookups = tot;
+	if (depth) *depth = d->has_index ? d->ix.tab.K : 0;
+	return BSX_OK;
+}
+
 extern "C" BSX_API int bsx_device_kernel_time(bsx_device_t *d, int k, double *total_ms, int64_t *launches, int reset)
 {
 	if (!d || k < 0 || k >= 8) return BSX_E_ARG;
@@ -448,6 +489,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		if ((rc = L.jobs.reserve((size_t)cn * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 		if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 		if ((rc = L.aux.reserve((size_t)cn * 12 + 64)) != BSX_OK) return rc;
+		if ((rc = L.qpack.reserve(seedt_pack_bytes(cn))) != BSX_OK) return rc;
 		long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)cn * 8);
 		unsigned long long *ctr = dev_counters(L);
 		HIPCHK(hipMemcpyAsync(L.jobs.p, cur, (size_t)cn * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st));
@@ -455,7 +497,7 @@ static int lane_seed_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, int6
 		HIPCHK(hipEventRecord(L.ev0, L.st));
 		launch_seed(L.st, grid, d->ix, (const uint8_t*)L.reads.p, (const bsx_seed_task_t*)L.jobs.p, (int)cn, P,
 		            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4, 0);
+		            (unsigned int*)(ctr + 5), ctr, 0, (unsigned int*)L.slabflags.p, grid * 4, 0, 0, (uint32_t*)L.qpack.p);
 		HIPCHK(hipEventRecord(L.ev1, L.st));
 		if ((rc = finish_timed(L, 7)) != BSX_OK) return rc;   // the batch form, for what the host chains: not the chunk-wide launch of slot 0
 		std::vector<long long> r_off((size_t)cn); std::vector<int> r_n((size_t)cn);
@@ -559,9 +601,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
 	const unsigned long long lf = (unsigned long long)std::max(1, (max_len + 149) / 150);   // pools are sized per 150 bases of read
-	const unsigned long long dense_cap = (unsigned long long)n * 96 * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
+	// the interval lists: strand search t's own stretch of mem_cap entries (k_seedt writes them where they stay), then room for the lists of the
+	// strand searches seeded again with longer lists, which go one behind the other from the cursor
+	const unsigned long long direct_n = (unsigned long long)n * (unsigned long long)mem_cap;
+	const unsigned long long dense_cap = direct_n + (unsigned long long)n * 16 * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
-	static const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : 1;   // one strand search per lane: the lanes of a wave then go through the seeding passes together (measured at hg38 scale: 335 ms with two, 292 with one, 359 with persistent lanes)
+	const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : (getenv("BSX_SEED_FORM") ? 1 : 0);   // strand searches per lane, 0 = lanes take them until none is left.  The table form (k_seedt.hip) runs persistent lanes: a lane that is done takes the next strand search in the same trip (measured at hg38 scale: 68 ms against 97 with one per lane and 86 with four); the kernel without the table does best with one (292 ms against 335 with two and 359 persistent: its lanes then move through the seeding passes together)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
 	// (4096 for reads of 150 bases, which need ~1.2 k; in proportion for longer ones)
 	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;   // (the kernel scales it per 256 bases of read)
@@ -569,7 +614,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const int n_slabs = d->n_cu * 16;
 	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
 	// gathers in flight on a given box
-	static const int seed_wpc = getenv("BSX_SEED_WAVES_PER_CU") ? std::max(1, std::min(16, atoi(getenv("BSX_SEED_WAVES_PER_CU")))) : 16;
+	const int seed_wpc = getenv("BSX_SEED_WAVES_PER_CU") ? std::max(1, std::min(16, atoi(getenv("BSX_SEED_WAVES_PER_CU")))) : 16;
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
 	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
 	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // as in lane_seed_batch
@@ -578,6 +623,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
+	if ((rc = L.qpack.reserve(seedt_pack_bytes(n))) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
 	if ((rc = L.regmeta.reserve((size_t)n * 29 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 6 * regions_slab_bytes(2))) != BSX_OK) return rc;   // (the exporting form runs three workgroups per CU)
@@ -619,6 +665,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	L.rb_tasks = n;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
+	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
+	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)(ctr + 4) + 1), (int)(uint32_t)(direct_n >> 32), 1, L.st));
 	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 2;   // 0: none, 1: seeding, 2: seeding and regions
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -629,7 +677,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof);
+	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof, (uint32_t*)L.qpack.p, 0ull);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -826,7 +874,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
 			HIPCHK(hipMemsetAsync(ctr + 96, 0, 64, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0);
+			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
@@ -885,6 +933,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (sp[0]) fprintf(stderr, "[M::regions_batch] k_seed: %.0f M wave cycles, %.1f%% in the full machine (%llu passes, %.0f cycles each), publishing %.1f%% | %llu wave trips, %.0f cycles per trip\n",
 		                   sp[0] * 1e-6, 100.0 * sp[1] / sp[0], sp[4], sp[4] ? (double)sp[1] / sp[4] : 0.0, 100.0 * sp[2] / sp[0], sp[3], sp[3] ? (double)sp[0] / sp[3] : 0.0);
 		{
+			unsigned long long tq[4];
+			D2H(L.st, tq, ctr + 121, sizeof(tq));
+			HIPCHK(hipMemsetAsync(ctr + 121, 0, sizeof(tq), L.st));
+			if (sp[0] && tq[3]) fprintf(stderr, "[M::regions_batch] k_seedt: short machine %.1f%%, fetch %.1f%%, post %.1f%% of the wave cycles | %.1f requests per wave trip\n",
+			                            100.0 * tq[0] / sp[0], 100.0 * tq[1] / sp[0], 100.0 * tq[2] / sp[0], sp[3] ? (double)tq[3] / sp[3] : 0.0);
+		}
+		{
 			unsigned long long xp[11];
 			D2H(L.st, xp, ctr + 56, sizeof(xp));
 			HIPCHK(hipMemsetAsync(ctr + 56, 0, sizeof(xp), L.st));
@@ -914,19 +969,26 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		decl_off[decl.size()] = tot;
 		if (*decl_cap < tot) { *decl_cap = tot + (tot >> 2) + 16; *decl_intv = (bsx_intv_t*)realloc(*decl_intv, sizeof(bsx_intv_t) * (size_t)*decl_cap); }
 		const bsx_intv_t *dense = nullptr;
-		if (decl.size() > 2048) { // many: one bulk copy of the dense lists, gathered on the host
-			unsigned long long sused = 0;
-			D2H(L.st, &sused, ctr + 4, 8);
-			if (sused > dense_cap) sused = dense_cap;
-			if ((rc = L.hstage.reserve((size_t)sused * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
-			if (sused) D2H(L.st, L.hstage.p, L.out.p, (size_t)sused * sizeof(bsx_intv_t));
-			dense = (const bsx_intv_t*)L.hstage.p;
+		if (decl.size() > 256 && tot > 0) { // many: their lists gathered on the device (they lie a strand search's stretch apart), one copy
+			std::vector<long long> which(decl.begin(), decl.end()), doff(decl_off, decl_off + decl.size());
+			for (size_t j = 0; j < decl.size(); ++j) if (s_n[decl[j]] < 0) { which.clear(); break; }   // (a list that did not fit has no entries to fetch: leave the one-by-one path to skip it)
+			if (!which.empty()) {
+				const size_t nb = decl.size() * 8;
+				if ((rc = L.gath.reserve(2 * nb + (size_t)tot * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+				H2D(L.st, L.gath.p, which.data(), nb);
+				H2D(L.st, (char*)L.gath.p + nb, doff.data(), nb);
+				DevIntv *gd = (DevIntv*)((char*)L.gath.p + 2 * nb);
+				launch_gather_lists(L.st, (const DevIntv*)L.out.p, d_off, d_n, (const long long*)L.gath.p, (const long long*)((char*)L.gath.p + nb), (long long)decl.size(), gd);
+				if ((rc = L.hstage.reserve((size_t)tot * sizeof(bsx_intv_t) + 64)) != BSX_OK) return rc;
+				D2H(L.st, L.hstage.p, gd, (size_t)tot * sizeof(bsx_intv_t));
+				dense = (const bsx_intv_t*)L.hstage.p;
+			}
 		}
 		for (size_t j = 0; j < decl.size(); ++j) {
 			const int64_t i = decl[j]; const int cnt = s_n[i];
 			bsx_intv_t *dst = *decl_intv + decl_off[j];
 			if (cnt <= 0) continue;
-			if (dense) memcpy(dst, dense + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
+			if (dense) memcpy(dst, dense + decl_off[j], sizeof(bsx_intv_t) * (size_t)cnt);
 			else D2H(L.st, dst, (const bsx_intv_t*)L.out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
 			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
 		}

@@ -299,6 +299,8 @@ int bsx_global_batch_tags(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *job
  * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and
  * from the region kernels), c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
+/* the seeding kernel's table of k-mer intervals: entries read since the last reset, depth K of the resident table (0: none) */
+int bsx_device_seed_table(bsx_device_t *dev, uint64_t *lookups, int *depth, int reset);
 /* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since
  * the last reset: k = 0 seed (the chunk-wide launch of bsx_regions_batch), 1 sa, 2 extend, 3 sw, 4 global, 5 regions (first tier),
  * 6 regions (tiers 1b, 2 and 3), 7 seed (bsx_seed_batch launches: the strand searches the host chains) */

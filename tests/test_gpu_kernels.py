@@ -64,7 +64,30 @@ def test_seed_and_sa_match_oracle(small_index, port, device):
     assert pi.shape == di.shape and (pi == di).all()
     assert int(po[-1]) > len(seqs)          # the test is not vacuous
     pc, dc = port.counters(), device.counters()
-    assert pc[0] == dc[0] and pc[1] == dc[1], (pc, dc)
+    looks, depth = device.seed_table(reset=True)
+    # the table of k-mer intervals (seed_tab.hpp) takes most FM extensions off the path: fewer blocks than the reference touches
+    assert depth >= 8 and looks > 0 and dc[0] + dc[1] < 0.7 * (pc[0] + pc[1]), (pc, dc, looks, depth)
+    # the same lists from every table depth (0: none, every step an FM extension) and from the kernel without the table,
+    # whose FM-block touches are the reference's own (the algorithmic-bytes figure of SURVEY 8(d))
+    import os
+    try:
+        for k in (0, 2, 5, depth - 1):
+            os.environ["BSX_SEED_TAB_K"] = str(k)
+            device.upload_index(small_index)
+            assert device.seed_table()[1] == k
+            di, do = device.seed(opt, tasks)
+            assert (po == do).all() and (pi == di).all(), k
+        os.environ["BSX_SEED_FORM"] = "classic"
+        device.counters(reset=True)
+        di, do = device.seed(opt, tasks)
+        assert (po == do).all() and (pi == di).all()
+        dc = device.counters()
+        assert pc[0] == dc[0] and pc[1] == dc[1], (pc, dc)
+    finally:
+        os.environ.pop("BSX_SEED_TAB_K", None)
+        os.environ.pop("BSX_SEED_FORM", None)
+        device.upload_index(small_index)
+    assert device.seed_table()[1] == depth
     # K3 on every occurrence the chaining step would look up (capped like memchain.c:325)
     jobs = []
     for t in range(len(tasks)):
