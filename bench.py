@@ -143,6 +143,7 @@ def main():
     for k in range(8):
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
+    dev.seed_table(reset=True)
     phase_tot = {}
     # the gather of the records to rank 0 (below) is part of the timed region; its connections are made here, as part of the warm-up
     import numpy as np
@@ -262,13 +263,28 @@ def main():
     ctr = dev.counters()
     ktimes = [dev.kernel_time(k) for k in range(8)]
     alone = None
+    ref_blocks_per_read, ref_seed_ms = None, None
+    tab_touch = [ctr[0] + ctr[1], dev.seed_table()[0], dev.seed_table()[1]]   # FM blocks and table entries the seeding kernel read in the timed region
     if not args.no_pipeline:
         for k in range(8):
             dev.kernel_time(k, reset=True)
         extra = gen(777, pairs_per_step)
         B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(standalone)")
-        L.bsx_sim_free_reads(extra, n_reads)
         alone = [dev.kernel_time(k) for k in range(8)]
+        # SURVEY 8(d)'s algorithmic bytes are the REFERENCE algorithm's FM-block touches (bwt_occ4 / bwt_2occ4 calls of bwt_smem1a and
+        # bwt_seed_strategy1: deterministic integers for a given input).  The seeding kernel of the timed region does not make them all (it
+        # reads most intervals from its table of k-mer intervals), so they are counted here, after the timed region, by the same chunk
+        # through the kernel that walks the FM index step by step as the reference does (k_seed.hip, $BSX_SEED_FORM=classic).
+        os.environ["BSX_SEED_FORM"] = "classic"
+        try:
+            dev.counters(reset=True)
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(reference block count)")
+            rc_ = dev.counters()
+            ref_blocks_per_read = (rc_[0] + rc_[1]) / float(n_reads)
+            ref_seed_ms = dev.kernel_time(0)[0] - alone[0][0]
+        finally:
+            os.environ.pop("BSX_SEED_FORM", None)
+        L.bsx_sim_free_reads(extra, n_reads)
 
     # Counter passes cannot run inside this process (rocprofv3 --pmc wraps a command): HBM traffic and instruction counts per
     # launch come from the committed passes of THIS command at THIS genome size (profiles/*_pmc_<Mbp>mbp.json, written by
@@ -306,9 +322,20 @@ def main():
         r.update(extra)
         return r
 
-    roof = roof_of("k_seed (K1+K2 SMEM seeding: dependent random 64-B FM-block gathers)", 0, 64.0 * (ctr[0] + ctr[1]),
-                   {"fm_block_touches_per_read": (ctr[0] + ctr[1]) / float(n_reads * args.steps),
-                    "what_bounds_it": "not HBM (a fifth of the peak) nor the issue rates (a third): a trip of the wave loop is one dependent gather plus ~1.2 k instructions of per-lane state machine that one wave issues in order, a dozen cycles apiece, and 158 VGPRs + 11 KB of LDS allow three waves per SIMD; see DESIGN.md"}, "k_seed")
+    # k_seedt (K1+K2): `achieved` = the reference algorithm's FM-block bytes for these reads (counted above) over the launch time, as SURVEY 8(d)
+    # defines it; what the kernel itself moved (the FM blocks it did touch + a 64-byte line per table entry read) is reported beside it
+    touched = 64.0 * (ctr[0] + ctr[1]) + 64.0 * (tab_touch[1] if tab_touch else 0)
+    alg = 64.0 * ref_blocks_per_read * n_reads * args.steps if ref_blocks_per_read else 64.0 * (ctr[0] + ctr[1])
+    roof = roof_of("k_seedt (K1+K2 SMEM seeding over the table of k-mer intervals + dependent random 64-B FM-block gathers)", 0, alg,
+                   {"fm_block_touches_per_read": (ref_blocks_per_read if ref_blocks_per_read else (ctr[0] + ctr[1]) / float(n_reads * args.steps)),
+                    "algorithmic_bytes_are": "the reference algorithm's bwt_occ4/bwt_2occ4 touches for these reads (SURVEY 8(d)), counted on one chunk by the kernel that walks the FM index as the reference does (BSX_SEED_FORM=classic, after the timed region)" if ref_blocks_per_read else "the blocks this kernel touched",
+                    "kernel_touches_per_read": {"fm_blocks": (ctr[0] + ctr[1]) / float(n_reads * args.steps), "table_entries": (tab_touch[1] / float(n_reads * args.steps)) if tab_touch else 0.0,
+                                                "table_depth": tab_touch[2] if tab_touch else 0},
+                    "bytes_touched_per_launch": touched / args.steps,
+                    "achieved_touched": round(touched / (ktimes[0][0] * 1e-3) / 1e9, 2) if ktimes[0][0] > 0 else None,
+                    "frac_touched": round(touched / (ktimes[0][0] * 1e-3) / 1e9 / PEAK_HBM, 5) if ktimes[0][0] > 0 else None,
+                    "kernel_without_table_ms_standalone": round(ref_seed_ms, 3) if ref_seed_ms else None,
+                    "what_bounds_it": "vector and scalar issue of the per-lane state machine (a lane per strand search, persistent lanes, three waves per SIMD at 168 VGPRs): a trip of the wave loop is one request per lane -- an FM extension (one or two dependent random 64-B blocks, fetched by the wave as a whole) or a 16-byte table entry -- and about half its cycles are the machine that decides the next request; the table (18 levels, 2 x 9.3 GB) removes three of four FM-block touches of the reference algorithm, so the kernel runs far above the rate at which it could fetch the reference's bytes; see DESIGN.md"}, "k_seed")
     roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
                          {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)}, "k_occ")
 

@@ -68,6 +68,8 @@ struct bsx_device {
 };
 struct LaneRef { bsx_device *d; int lane; };   // what the backend vtable carries as ctx
 
+#include <sys/time.h>
+static double bsx_now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
 static inline unsigned long long *dev_counters(Lane &L) { return (unsigned long long*)L.small.p; }
 
 extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
@@ -77,6 +79,9 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fprintf(stderr, "[bsx-hip] no HIP device available\n"); return BSX_E_NODEVICE; }
 	if (ordinal < 0 || ordinal >= n) return BSX_E_ARG;
 	HIPCHK(hipSetDevice(ordinal));
+	// host threads that wait for the device sleep instead of polling: a chunk stream has half a dozen threads waiting at any time (front
+	// halves, K5/K6 batches), and on a 16-core quota their polling was a third of the host's CPU time ($BSX_BLOCKING_SYNC=0: the runtime's default)
+	if (!(getenv("BSX_BLOCKING_SYNC") && atoi(getenv("BSX_BLOCKING_SYNC")) == 0)) { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
 	bsx_device *d = new bsx_device();
 	d->ordinal = ordinal;
 	hipDeviceProp_t prop;
@@ -311,10 +316,35 @@ extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o) {
 // handing pageable memory to hipMemcpy makes the runtime pin and unpin the user pages on every call, which costs
 // more system time per chunk than the copies themselves.  Synchronous: complete on return.
 #define XFER_CHUNK ((size_t)8 << 20)
+// The back half's batches (K5, K6: a megabyte of jobs up, a megabyte of results down, on the lane's high-priority stream) do not go through
+// the copy engines: those serve every stream first come first served, and behind another chunk's region download (half a gigabyte) a
+// one-megabyte copy waited half a second (measured: "download 0.656 s" of a 15 ms K5 batch).  A kernel on the batch's own stream moves the
+// bytes between the lane's pinned halves (mapped into the device's address space) and HBM instead.
+__global__ void __launch_bounds__(256)
+k_copy_bytes(const unsigned char *src, unsigned char *dst, size_t n)
+{
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+	if ((((size_t)src | (size_t)dst) & 15) == 0) {
+		const size_t n16 = n >> 4;
+		for (size_t i = tid; i < n16; i += nth) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+		for (size_t i = (n16 << 4) + tid; i < n; i += nth) dst[i] = src[i];
+	} else if ((((size_t)src | (size_t)dst) & 3) == 0) {
+		const size_t n4 = n >> 2;
+		for (size_t i = tid; i < n4; i += nth) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+		for (size_t i = (n4 << 2) + tid; i < n; i += nth) dst[i] = src[i];
+	} else for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+}
+static void copy_by_kernel(hipStream_t st, void *dst, const void *src, size_t n)
+{
+	const unsigned int blocks = (unsigned int)std::min<size_t>(std::max<size_t>(1, (n / 16 + 255) / 256), 2048);
+	hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, st, (const unsigned char*)src, (unsigned char*)dst, n);
+}
 static int xfer(Lane &L, hipStream_t st, void *dst, const void *src, size_t n, bool h2d)
 {
 	if (n == 0) return BSX_OK;
-	if (n < ((size_t)256 << 10)) {
+	static const bool zc_on = !(getenv("BSX_COPY_KERNELS") && atoi(getenv("BSX_COPY_KERNELS")) == 0);
+	const bool zc = zc_on && st == L.st_hi;
+	if (!zc && n < ((size_t)256 << 10)) {
 		HIPCHK(hipMemcpyAsync(dst, src, n, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		return BSX_OK;
@@ -330,10 +360,10 @@ static int xfer(Lane &L, hipStream_t st, void *dst, const void *src, size_t n, b
 		if (h2d) {
 			if (i >= 2) HIPCHK(hipEventSynchronize(L.pev[i & 1]));   // the DMA that last read this half is done
 			memcpy(p, (const char*)src + off, m);
-			HIPCHK(hipMemcpyAsync((char*)dst + off, p, m, hipMemcpyHostToDevice, st));
+			if (zc) copy_by_kernel(st, (char*)dst + off, p, m); else HIPCHK(hipMemcpyAsync((char*)dst + off, p, m, hipMemcpyHostToDevice, st));
 			HIPCHK(hipEventRecord(L.pev[i & 1], st));
 		} else {
-			HIPCHK(hipMemcpyAsync(p, (const char*)src + off, m, hipMemcpyDeviceToHost, st));
+			if (zc) copy_by_kernel(st, p, (const char*)src + off, m); else HIPCHK(hipMemcpyAsync(p, (const char*)src + off, m, hipMemcpyDeviceToHost, st));
 			HIPCHK(hipEventRecord(L.pev[i & 1], st));
 			if (i >= 1) { // drain the previous half while this one is in flight
 				HIPCHK(hipEventSynchronize(L.pev[(i - 1) & 1]));
@@ -603,8 +633,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const unsigned long long lf = (unsigned long long)std::max(1, (max_len + 149) / 150);   // pools are sized per 150 bases of read
 	// the interval lists: strand search t's own stretch of mem_cap entries (k_seedt writes them where they stay), then room for the lists of the
 	// strand searches seeded again with longer lists, which go one behind the other from the cursor
-	const unsigned long long direct_n = (unsigned long long)n * (unsigned long long)mem_cap;
-	const unsigned long long dense_cap = direct_n + (unsigned long long)n * 16 * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
+	const bool seed_direct = !(getenv("BSX_SEED_DIRECT") && atoi(getenv("BSX_SEED_DIRECT")) == 0) && !getenv("BSX_SEED_FORM");   // ($BSX_SEED_DIRECT=0: one list behind the other, copied there when a strand search is done)
+	const unsigned long long direct_n = seed_direct ? (unsigned long long)n * (unsigned long long)mem_cap : 0;
+	const unsigned long long dense_cap = direct_n + (unsigned long long)n * (seed_direct ? 16 : 96) * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
 	const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : (getenv("BSX_SEED_FORM") ? 1 : 0);   // strand searches per lane, 0 = lanes take them until none is left.  The table form (k_seedt.hip) runs persistent lanes: a lane that is done takes the next strand search in the same trip (measured at hg38 scale: 68 ms against 97 with one per lane and 86 with four); the kernel without the table does best with one (292 ms against 335 with two and 359 persistent: its lanes then move through the seeding passes together)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
@@ -677,7 +708,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipEventRecord(L.ev0, L.st));
 	launch_seed(L.st, grid, d->ix, d_reads, d_tasks, (int)n, P,
 	            (DevIntv*)L.scratch.p, list_cap, mem_cap, (DevIntv*)L.out.p, dense_cap, ctr + 4, d_off, d_n,
-	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof, (uint32_t*)L.qpack.p, 0ull);
+	            (unsigned int*)(ctr + 5), ctr, seed_quota, (unsigned int*)L.slabflags.p, n_slabs, trip_budget, R.prof, (uint32_t*)L.qpack.p, seed_direct ? 0ull : ~0ull);
 	HIPCHK(hipEventRecord(L.ev1, L.st));
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -744,7 +775,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// more than 64 regions) then takes the same tier in its full form.  Measured and off: 359 against 342 ms per chunk on the clean genome,
 		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).  =2: that tier chained as the
 		// LDS tiers do it (pieces, chain starts in registers) over its HBM slab: 344 against 342, 1140 against 1095 -- no better either.
-		static const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
+		const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
 		if (slab_export) {
 			launch_regions_slab(st, slab_export == 2 ? 4 : 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, slab_export == 2 ? rl : rb, slab_export == 2 ? l_count : k32 + 3, ctr, posoffs, d_pos, &XP);   // 2: chained by pieces; what it declines (tied starts, tables) takes the full form next
@@ -1175,6 +1206,8 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
+	static const bool tr_sw = getenv("BSX_PHASES") != nullptr;
+	const double ts0 = tr_sw ? bsx_now_s() : 0;
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t));
 	size_t off = 0;
 	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
@@ -1191,8 +1224,12 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));
+	const double ts1 = tr_sw ? bsx_now_s() : 0;
 	if ((rc = finish_timed(L, 3)) != BSX_OK) return rc;
+	const double ts2 = tr_sw ? bsx_now_s() : 0;
 	D2H(L.st_hi, res, L.res.p, (size_t)n * sizeof(bsx_sw_res_t));
+	if (tr_sw) { float ms = 0; (void)hipEventElapsedTime(&ms, L.ev0, L.ev1);
+		fprintf(stderr, "[M::sw_batch] %lld jobs: upload %.3f s, waited %.3f s for the kernels (%.3f s on the device), download %.3f s\n", (long long)n, ts1 - ts0, ts2 - ts1, ms * 1e-3, bsx_now_s() - ts2); }
 	return BSX_OK;
 }
 

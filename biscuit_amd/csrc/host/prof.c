@@ -1,0 +1,59 @@
+/* prof.c -- $BSX_PROF_SAMPLE=<file>: a sampling profile of the host side of a run (there is no perf on the GPU boxes).  A process-CPU-time
+ * timer (ITIMER_PROF, 1 kHz) interrupts whichever thread is running; the handler notes the interrupted instruction's address and the
+ * and at exit the samples are written as "count offset object" lines (tools/prof_symbols.py names the functions).  Debug facility: off
+ * unless the variable is set. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <ucontext.h>
+#include "bsx_core.h"
+
+#define PROF_MAX (1 << 22)
+static void **g_pc; static volatile long g_n; static const char *g_path;
+
+static void on_prof(int sig, siginfo_t *si, void *uc_)
+{
+	ucontext_t *uc = (ucontext_t*)uc_;
+	long k = __sync_fetch_and_add(&g_n, 1);
+	(void)sig; (void)si;
+	if (k < PROF_MAX) g_pc[k] = (void*)uc->uc_mcontext.gregs[REG_RIP];
+}
+static int cmp_ptr(const void *a, const void *b) { const void *x = *(void* const*)a, *y = *(void* const*)b; return x < y ? -1 : x > y; }
+/* "count offset object" per distinct address (offset inside its shared object: tools/prof_symbols.py turns them into functions with nm) */
+static void prof_dump(void)
+{
+	struct itimerval off; long n = g_n < PROF_MAX ? g_n : PROF_MAX, i;
+	FILE *f;
+	memset(&off, 0, sizeof(off));
+	setitimer(ITIMER_PROF, &off, 0);
+	if (!g_path || n == 0) return;
+	qsort(g_pc, (size_t)n, sizeof(void*), cmp_ptr);
+	f = fopen(g_path, "w");
+	if (!f) return;
+	fprintf(f, "# %ld samples at 1 kHz of process CPU time\n", n);
+	for (i = 0; i < n; ) {
+		long j = i; Dl_info di; const char *fl = "?"; unsigned long base = 0;
+		while (j < n && g_pc[j] == g_pc[i]) ++j;
+		if (dladdr(g_pc[i], &di) && di.dli_fname) { fl = di.dli_fname; base = (unsigned long)di.dli_fbase; }
+		fprintf(f, "%ld %lx %s\n", j - i, (unsigned long)g_pc[i] - base, fl);
+		i = j;
+	}
+	fclose(f);
+}
+__attribute__((constructor)) static void prof_init(void)
+{
+	struct sigaction sa; struct itimerval it;
+	g_path = getenv("BSX_PROF_SAMPLE");
+	if (!g_path || !*g_path) { g_path = 0; return; }
+	g_pc = (void**)malloc(sizeof(void*) * PROF_MAX);
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
+	sigaction(SIGPROF, &sa, 0);
+	it.it_interval.tv_sec = 0; it.it_interval.tv_usec = 1000; it.it_value = it.it_interval;
+	setitimer(ITIMER_PROF, &it, 0);
+	atexit(prof_dump);
+}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Stand-alone kernel times of one unpipelined chunk of the bench workload under different environments, the index built once:
+   python tools/chunk_ab.py [--genome-mbp 3100] [--profile 0|1] "" "BSX_SEED_DIRECT=0" ...   (knobs read per call only)"""
+import argparse
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-mbp", type=float, default=3100)
+    ap.add_argument("--profile", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("cfgs", nargs="*", default=[""])
+    a = ap.parse_args()
+    from biscuit_amd import _lib as B
+    from biscuit_amd.api import Index, Device, default_opt
+    L = B.lib()
+    n_bases = int(a.genome_mbp * 1e6)
+    idx = Index.synthetic(n_bases, seed=2024, n_contigs=24 if n_bases >= 1_000_000_000 else 8, profile=a.profile)
+    dev = Device(0)
+    dev.build_index(idx)
+    opt = default_opt()
+    opt.n_threads = 16
+    opt.flag |= 0x10 | 0x2
+    pairs = (opt.chunk_size * 16) // 300
+    L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+    L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
+    C.c_int.in_dll(L, "bsx_verbose").value = 1
+    p = C.c_void_p()
+    B.check(L.bsx_sim_pairs(idx.h, pairs, 150, 1001, 200, 500, 0.005, 0.0, C.byref(p)), "sim")
+    B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * pairs, p, None), "warm")
+    L.bsx_sim_reset_reads(p, 2 * pairs)
+    names = ["seed", "occ", "extend", "sw", "global", "tier1", "tiers23", "seed2"]
+    import time
+    for cfg in a.cfgs:
+        kv = dict(x.split("=", 1) for x in cfg.split())
+        for k, v in kv.items():
+            os.environ[k] = v
+        for k in range(8):
+            dev.kernel_time(k, reset=True)
+        t0 = time.time()
+        for _ in range(a.reps):
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * pairs, p, None), "chunk")
+            L.bsx_sim_reset_reads(p, 2 * pairs)
+        dt = (time.time() - t0) / a.reps
+        print("%-50s %s | chunk %.0f ms" % (cfg or "(defaults)", " ".join("%s %.1f" % (names[k], dev.kernel_time(k)[0] / a.reps) for k in range(8)), dt * 1e3), flush=True)
+        for k in kv:
+            os.environ.pop(k, None)
+
+
+if __name__ == "__main__":
+    main()

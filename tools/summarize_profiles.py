@@ -96,7 +96,7 @@ if fs and ws:
         def pk(agg, kern=kern):
             tot = collections.defaultdict(float)
             for k, v in agg.items():
-                if k == kern or k.startswith(kern + "<") or (kern == "k_regions" and k.startswith(("k_regions", "k_c2r", "k_ext_"))):
+                if k == kern or k.startswith(kern + "<") or (kern == "k_seed" and k.startswith("k_seedt")) or (kern == "k_regions" and k.startswith(("k_regions", "k_c2r", "k_ext_", "k_ext4", "k_extl", "k_x4prep"))):
                     for c, x in v.items():
                         tot[c] += x
             return tot
