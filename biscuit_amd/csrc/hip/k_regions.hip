@@ -1552,7 +1552,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 // second and third tier: the same code over per-wave tables in HBM, for the strand searches of repeat-rich reads.
 // `list` names the tasks (null: 0..*count-1); what this tier declines for table size goes on next_list.
 template <typename Store, bool XSPLIT, typename DPT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
                bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,

@@ -649,7 +649,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
 	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
 	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // as in lane_seed_batch
-	const int big_grid = d->n_cu * 2, huge_grid = d->n_cu / 2;   // four waves a block; the third tier's slabs are 1.3 MB a wave (0.65 GB per chunk in flight)
+	// the HBM tiers: workgroups of four waves over per-wave slabs; they are bound by the latency of their slabs, so what counts is waves in flight:
+	// three workgroups per CU for the first (its kernel is held to 168 VGPRs for that and spills: 710 -> 578 ms per chunk on the hg38-like genome
+	// all the same), one per CU for the second (1.3 MB of slab a wave; 222 -> 167 ms: a launch lasts as long as its largest strand search)
+	const int big_grid = d->n_cu * (getenv("BSX_SLAB_GRID_PER_CU") ? std::max(1, std::min(6, atoi(getenv("BSX_SLAB_GRID_PER_CU")))) : 3), huge_grid = getenv("BSX_SLAB3_GRID_X2") ? std::max(1, d->n_cu * atoi(getenv("BSX_SLAB3_GRID_X2")) / 2) : d->n_cu;
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
