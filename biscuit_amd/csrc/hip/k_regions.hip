@@ -191,6 +191,124 @@ __device__ void rg_introsort_keys(unsigned int *a, int n, int *stk)
 #undef SWP
 }
 
+// The same sort by the whole wavefront, keys in registers (position p in lane p & 63 of v[p >> 6]): EXACTLY klib's sequence of swaps
+// (ksort.h:138-216 -- median-of-three introsort on the runs longer than 16, then one insertion pass over the whole array), because the order
+// of chains of equal weight is part of the result and a strand search against an hg38-sized genome has a hundred chains of weight 19-22.
+// One lane walking the keys in LDS spent a quarter of the larger LDS tier's cycles here (two dependent LDS trips per comparison); in
+// registers a scan "do ++i while (a[i] < pivot)" is a compare, a ballot and a count of trailing zeros, a swap two v_readlane and two
+// v_writelane, and an insertion a population count plus a one-lane shift of the run it passes (DPP).  Up to 64 * NS keys; returns false
+// (nothing sorted: v is scratch) when the depth limit would send klib into its comb sort -- the caller then runs the one-lane form.
+template <int NS>
+__device__ __forceinline__ unsigned int rgw_get(const unsigned int (&v)[NS], int p)
+{
+	unsigned int r = 0;
+#pragma unroll
+	for (int s = 0; s < NS; ++s) if (s == (p >> 6)) r = (unsigned int)__builtin_amdgcn_readlane((int)v[s], p & 63);
+	return r;
+}
+template <int NS>
+__device__ __forceinline__ void rgw_set(unsigned int (&v)[NS], int p, unsigned int x, int lane)
+{
+#pragma unroll
+	for (int s = 0; s < NS; ++s) if (s == (p >> 6) && lane == (p & 63)) v[s] = x;
+}
+template <int NS>
+__device__ __forceinline__ bool rg_introsort_wave(unsigned int (&v)[NS], int n, int *stk, int lane)
+{
+#define WGT(x) ((x) >> RG_KEY_BITS)
+	if (n < 2) return true;
+	if (n == 2) { const unsigned int a0 = rgw_get(v, 0), a1 = rgw_get(v, 1); if (WGT(a1) > WGT(a0)) { rgw_set(v, 0, a1, lane); rgw_set(v, 1, a0, lane); } return true; }
+	int d, s = 0, t = n - 1, top = 0;
+	int *stk_l = stk, *stk_r = stk + 16, *stk_d = stk + 32;
+	for (d = 2; (1 << d) < n; ++d);
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) return false;
+			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
+			{
+				const unsigned int ak = WGT(rgw_get(v, k)), ai = WGT(rgw_get(v, i)), aj = WGT(rgw_get(v, j));
+				// LT(x, y) = weight(x) > weight(y)
+				if (ak > ai) { if (ak > aj) k = j; }
+				else k = aj > ai ? i : j;
+			}
+			const unsigned int rp = rgw_get(v, k), wp = WGT(rp);
+			if (k != t) { const unsigned int at = rgw_get(v, t); rgw_set(v, k, at, lane); rgw_set(v, t, rp, lane); }
+			for (;;) {
+				{ // do ++i; while (LT(a[i], rp)): the next position whose weight is <= the pivot's (a[t] is the pivot: it stops there at the latest)
+					const int from = i + 1;
+					int found = -1;
+#pragma unroll
+					for (int q = 0; q < NS; ++q) {
+						if (found < 0 && q >= (from >> 6)) {
+							unsigned long long m = __ballot(WGT(v[q]) <= wp);
+							if (q == (from >> 6)) m &= ~0ull << (from & 63);
+							if (m) found = q * 64 + (int)__builtin_ctzll(m);
+						}
+					}
+					i = found;
+				}
+				{ // do --j; while (i <= j && LT(rp, a[j])): the last position in [i, j) whose weight is >= the pivot's, or i - 1
+					const int last = j - 1;
+					int found = i - 1; bool got = false;
+#pragma unroll
+					for (int q = NS - 1; q >= 0; --q) {
+						if (!got && last >= i && q <= (last >> 6) && q >= (i >> 6)) {
+							unsigned long long m = __ballot(WGT(v[q]) >= wp);
+							if (q == (last >> 6)) m &= (2ull << (last & 63)) - 1;
+							if (q == (i >> 6)) m &= ~0ull << (i & 63);
+							if (m) { found = q * 64 + 63 - (int)__builtin_clzll(m); got = true; }
+						}
+					}
+					j = found;
+				}
+				if (j <= i) break;
+				{ const unsigned int xi = rgw_get(v, i), xj = rgw_get(v, j); rgw_set(v, i, xj, lane); rgw_set(v, j, xi, lane); }
+			}
+			{ const unsigned int xi = rgw_get(v, i), xt = rgw_get(v, t); rgw_set(v, i, xt, lane); rgw_set(v, t, xi, lane); }
+			if (i - s > t - i) {
+				if (i - s > 16) { if (lane == 0) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; } ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (lane == 0) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; } ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) break;
+			--top;
+			WAVE_SYNC();
+			s = uni(stk_l[top]); t = uni(stk_r[top]); d = uni(stk_d[top]);
+		}
+	}
+	// the insertion pass: a[i] moves left past every predecessor of smaller weight; the positions before it are in order by then, so it
+	// lands behind the last one whose weight is >= its own, and the run it passes moves up one position
+	for (int i = 1; i < n; ++i) {
+		const unsigned int x = rgw_get(v, i), wx = WGT(x);
+		if (!(wx > WGT(rgw_get(v, i - 1)))) continue;
+		int q = 0;
+#pragma unroll
+		for (int c = 0; c < NS; ++c) {
+			if (c * 64 < i) {
+				unsigned long long m = __ballot(WGT(v[c]) >= wx);
+				if (c == (i >> 6)) m &= (1ull << (i & 63)) - 1;
+				q += __popcll(m);
+			}
+		}
+#pragma unroll
+		for (int c = NS - 1; c >= 0; --c) {
+			if (c >= (q >> 6) && c <= (i >> 6)) {
+				const unsigned int carry = c > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)v[c > 0 ? c - 1 : 0], 63) : 0u;
+				const unsigned int sh = (unsigned int)wave_prev((int)v[c], (int)carry);
+				const int pos = c * 64 + lane;
+				v[c] = (pos > q && pos <= i) ? sh : v[c];
+			}
+		}
+		rgw_set(v, q, x, lane);
+	}
+	return true;
+#undef WGT
+}
+
 // ---- the chain index as the reference keeps it: kbtree.h instantiated with t = 3 (pre-emptive split on the way down,
 // lower-bound search inside a node, duplicates allowed); same structure as csrc/host/util.c:bsx_bt_*.  One lane runs it.
 template <typename Store>
@@ -557,8 +675,25 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	for (int o = lane; o < tot; o += 64) {
 		if (S.s_rid[o] < 0) continue;
 		const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
+		// the seed's reference bases come 32 at a time (one unaligned 8-byte load of pac: a chance match of 19-22 bases is one load, where a
+		// load per base was twenty dependent trips to the same line); a seed lies on one strand, the reverse one read backwards and complemented
 		int bad = 0;
-		for (int i = 0; i < ln; ++i) { const int r = dev_ref_base(ix.pac, l_pac, rb + i), q = D.q[qb + i]; bad |= (r == 3 && q == 1) || (r == 0 && q == 2); }
+		const bool rev = rb >= l_pac;
+		const long long f0 = rev ? (l_pac << 1) - rb - ln : rb;   // forward coordinate of the seed's lowest base
+		for (int done = 0; done < ln; ) {
+			const long long f = f0 + done;
+			unsigned long long w;
+			__builtin_memcpy(&w, ix.pac + (f >> 2), 8);   // (pac is padded: upload_ref)
+			const int k0 = (int)(f & 3);
+			int m = 32 - k0; if (m > ln - done) m = ln - done;
+			for (int k = k0; k < k0 + m; ++k) {
+				const int b = (int)(w >> (((k >> 2) << 3) + ((~k & 3) << 1))) & 3;
+				const int at = done + (k - k0);   // position along the forward strand
+				const int i = rev ? ln - 1 - at : at, r = rev ? 3 - b : b, q = D.q[qb + i];
+				bad |= (r == 3 && q == 1) || (r == 0 && q == 2);
+			}
+			done += m;
+		}
 		if (bad) S.s_extra[o] |= 2;
 	}
 	WAVE_SYNC();
@@ -831,7 +966,16 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			n += __popcll(b);
 		}
 		WAVE_SYNC();
-		if (lane == 0) rg_introsort_keys(keys, n, D.H);
+		bool sorted = false;
+		if (n <= 64) { // by the wave, a key per lane (exactly klib's permutation); its depth-limit case and longer lists: one lane over LDS.
+			// (Measured with two and four register slots for up to 256 keys: every slot is a compare, a ballot and a branch more in every scan and
+			// access, and the larger LDS tier got slower -- sort 199 G -> 269 G wave cycles per chunk -- where the one-slot form halves the first tier's.)
+			unsigned int kv[1] = { lane < n ? keys[lane] : 0u };
+			sorted = rg_introsort_wave<1>(kv, n, D.H, lane);
+			if (sorted) { WAVE_SYNC(); if (lane < n) keys[lane] = kv[0]; }
+		}
+		WAVE_SYNC();
+		if (!sorted && lane == 0) rg_introsort_keys(keys, n, D.H);
 		WAVE_SYNC();
 		for (int i = lane; i < n; i += 64) { const unsigned int v = keys[i] & ((1u << RG_KEY_BITS) - 1); S.ord[i] = Store::PCAP ? S.keep[v] : (idx_t)v; }
 		WAVE_SYNC();

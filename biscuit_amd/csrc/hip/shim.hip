@@ -740,7 +740,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
-#define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; } } while (0)
+		// $BSX_PHASES=2: the stage counters read (and zeroed) after every launch of the main sequence: where each tier's wave cycles go
+		static const bool per_tier = getenv("BSX_PHASES") && atoi(getenv("BSX_PHASES")) == 2;
+#define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; \
+		if (per_tier) { unsigned long long pf_[8]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
+			double tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) tot_ += (double)pf_[k_]; \
+			if (tot_ > 0) fprintf(stderr, "[M::regions_batch] %s: intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% prologues+seed tests %.1f%% extension %.1f%% of %.0f M wave cycles\n", name_, \
+			                      100 * pf_[0] / tot_, 100 * pf_[1] / tot_, 100 * pf_[2] / tot_, 100 * pf_[3] / tot_, 100 * pf_[4] / tot_, 100 * pf_[5] / tot_, 100 * pf_[6] / tot_, 100 * pf_[7] / tot_, tot_ * 1e-6); } } } while (0)
 		TIER_MARK("start");
 		launch_regions(st, rgrid, d->ix, L.sc, R, d_reads, T, (int)nT, (const DevIntv*)L.out.p, offs, cnts,
 		               (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, k32 + 0, ra, k32 + 1, reg_quota, ctr, posoffs, d_pos, clsx, XP, long_reads);
