@@ -400,6 +400,8 @@ def main():
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "push_loop_s_per_step": {"ring_wait": round(loop_s[0] / args.steps, 4), "in_stream_push": round(loop_s[1] / args.steps, 4)}, "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),
             "host_cpu_s_per_step": {"user": round((ru1.ru_utime - ru0.ru_utime) / args.steps, 2), "system": round((ru1.ru_stime - ru0.ru_stime) / args.steps, 2)},
+            # what a rank asks of the host at this rate (an 8-GPU node runs eight of them on its cores): CPU seconds per second of the timed region
+            "host_cores_busy_per_gpu": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(1e-9, dt), 2),
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "genome_and_index_build_s": round(t_build, 1), "device": dev.name,
             "hg38_like_genome": None,

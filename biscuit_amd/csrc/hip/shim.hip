@@ -633,7 +633,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const unsigned long long lf = (unsigned long long)std::max(1, (max_len + 149) / 150);   // pools are sized per 150 bases of read
 	// the interval lists: strand search t's own stretch of mem_cap entries (k_seedt writes them where they stay), then room for the lists of the
 	// strand searches seeded again with longer lists, which go one behind the other from the cursor
-	const bool seed_direct = !(getenv("BSX_SEED_DIRECT") && atoi(getenv("BSX_SEED_DIRECT")) == 0) && !getenv("BSX_SEED_FORM");   // ($BSX_SEED_DIRECT=0: one list behind the other, copied there when a strand search is done)
+	const bool seed_direct = !(getenv("BSX_SEED_DIRECT") && atoi(getenv("BSX_SEED_DIRECT")) == 0) && !getenv("BSX_SEED_FORM")
+	                         && (unsigned long long)n * (unsigned long long)mem_cap <= (768ull << 20);   // (24 GB of lists: a chunk of short reads with one very long one keeps the lists one behind the other)   // ($BSX_SEED_DIRECT=0: one list behind the other, copied there when a strand search is done)
 	const unsigned long long direct_n = seed_direct ? (unsigned long long)n * (unsigned long long)mem_cap : 0;
 	const unsigned long long dense_cap = direct_n + (unsigned long long)n * (seed_direct ? 16 : 96) * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip

@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=3100)
     ap.add_argument("--profile", type=int, default=0)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--single-end", action="store_true")
     ap.add_argument("cfgs", nargs="*", default=[""])
     a = ap.parse_args()
     from biscuit_amd import _lib as B
@@ -26,14 +28,14 @@ def main():
     dev.build_index(idx)
     opt = default_opt()
     opt.n_threads = 16
-    opt.flag |= 0x10 | 0x2
-    pairs = (opt.chunk_size * 16) // 300
+    opt.flag |= 0x10 | (0 if a.single_end else 0x2)
+    pairs = (opt.chunk_size * 16) // (2 * a.read_len)
     L.bsx_sim_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
     L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
     L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
     C.c_int.in_dll(L, "bsx_verbose").value = 1
     p = C.c_void_p()
-    B.check(L.bsx_sim_pairs(idx.h, pairs, 150, 1001, 200, 500, 0.005, 0.0, C.byref(p)), "sim")
+    B.check(L.bsx_sim_pairs(idx.h, pairs, a.read_len, 1001, a.read_len if a.single_end else 200, a.read_len + 400 if a.single_end else 500, 0.005, 0.0, C.byref(p)), "sim")
     B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * pairs, p, None), "warm")
     L.bsx_sim_reset_reads(p, 2 * pairs)
     names = ["seed", "occ", "extend", "sw", "global", "tier1", "tiers23", "seed2"]
