@@ -161,9 +161,15 @@ if kt:
 if kt:
     cls = collections.defaultdict(list)
     for r in csv.DictReader(open(kt[0])):
-        if short(r["Kernel_Name"]).startswith("k_seed"):
+        nm = short(r["Kernel_Name"])
+        ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+        if nm.startswith("k_seedt<"):   # the table form: the chunk-wide launch is persistent waves (thousands of one-wave workgroups), the second pass a few dozen
             wgs = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
-            cls["chunk-wide (>= 1000 workgroups)" if wgs >= 1000 else "second pass / host path (<= 16 workgroups)"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+            cls["k_seedt, chunk-wide (>= 1000 workgroups): what bench.py's roofline times" if wgs >= 1000 else "k_seedt, second pass / host path (small grids)"].append(ms)
+        elif nm.startswith("k_seedt_pack"):
+            cls["k_seedt_pack (the reads as base-3 digits, ahead of every k_seedt launch)"].append(ms)
+        elif nm.startswith("k_seed<"):
+            cls["k_seed without the table (one chunk after the timed region: counts the reference's FM-block touches)"].append(ms)
     with open(os.path.join(out, "%s_kseed_launches.md" % tag), "w") as g:
         g.write("# k_seed launches in the kernel trace (%s), by kind\n\n" % tag)
         g.write("`%s_kernel_stats.csv` averages every launch of a kernel; bench.py's `roofline.avg_launch_ms` is the chunk-wide launch only\n"
