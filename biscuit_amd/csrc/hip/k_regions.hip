@@ -80,7 +80,6 @@ typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongB;   //
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;
 // the same capacity chained as the LDS tiers do it (pieces, chain starts in registers, records for multi-seed chains only), tables in an HBM
 // slab, exporting: for the repeat reads that outgrow the LDS tiers but have no tied chain starts
-typedef RgStore<512, 1024, 1024, 0, 0, unsigned short, short, 256> RgBigP;      // a region comes from one seed: RCAP = SCAP never binds
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
 struct RgDp {            // per-wave LDS scratch
@@ -1869,7 +1868,7 @@ void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, u
 	hipLaunchKernelGGL(k_sa_dense, dim3(n_cu * 32), dim3(256), 0, st, ix, parent, intv, n, out);
 }
 
-size_t regions_slab_bytes(int tier) { return tier == 2 ? (sizeof(RgBig) > sizeof(RgBigP) ? sizeof(RgBig) : sizeof(RgBigP)) : sizeof(RgHuge); }
+size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
 
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -1928,10 +1927,7 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 {
 	RgXPool X = rgx_pool(XA);
 	// XA given: the tier stops after the chain filter and exports (chunks with long reads or an active seed-SW filter)
-	if (tier == 4 && XA)
-		hipLaunchKernelGGL((k_regions_slab<RgBigP, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
-		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBigP*)slabs, next_list, next_count, counters, pos_off, pos, X);
-	else if (tier == 2 && XA)
+	if (tier == 2 && XA)
 		hipLaunchKernelGGL((k_regions_slab<RgBig, true, RgDpLiteL>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgBig*)slabs, next_list, next_count, counters, pos_off, pos, X);
 	else if (tier == 2)

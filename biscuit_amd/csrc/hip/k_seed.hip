@@ -6,7 +6,6 @@
 
 #include "wave.hpp"
 
-#define SEED_FORM_DEFAULT 0   // measured (tools/seed_forms.sh, 3.1 Gbp): 0 = 209 ms per chunk, 1 = 221 ms (the second half of a trip with more than 64 requests waits for the first), 2 = 363 ms (15 VGPRs spilled)
 // the read in LDS: 24 words = 192 bases per lane, 6 KB per wave
 // One wave per workgroup: a workgroup gives its registers and LDS back when its LAST wave ends, and a wave ends when the longest of its 64
 // strand searches does -- with four waves that was the longest of 256 while the slots of the three finished waves stayed taken
@@ -37,7 +36,6 @@ __device__ __forceinline__ DevBlock seed_take(const SeedXchg &X, int req)
 }
 
 // bwt_extend (lib/aln/bwt.c:278-293) of L.ext_in for the lanes with `need`; every lane of the wave takes part in the loads.
-template <bool DIRECT>
 __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &ix, const SeedLane &L, SeedXchg &X, uint32_t &n_slow, uint32_t &n_fast)
 {
 	const int lane = (int)(threadIdx.x & 63), piece = lane & 3, sub = lane >> 2;
@@ -67,14 +65,11 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 #define SEED_COUNT(B_, pos_, valid_, t_) do { uint32_t a_, c_, g_, t4_; dev_planes_count4(B_, (int)((pos_) & 127), a_, c_, g_, t4_); \
 		t_[0] = (valid_) ? ((uint64_t)B_.v0.y << 32 | B_.v0.x) + a_ : 0; t_[1] = (valid_) ? ((uint64_t)B_.v0.w << 32 | B_.v0.z) + c_ : 0; \
 		t_[2] = (valid_) ? ((uint64_t)B_.v1.y << 32 | B_.v1.x) + g_ : 0; t_[3] = (valid_) ? ((uint64_t)B_.v1.w << 32 | B_.v1.z) + t4_ : 0; } while (0)
-	// DIRECT: the pieces go from memory straight into the exchange slots (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, masked
-	// lanes leave theirs alone -- tools/ubench/lds_direct.hip): lane l of round r asks for piece (l & 3) ^ sw of request 16 r + (l >> 2), which
-	// is the piece the slot layout wants at position l & 3.  No registers hold blocks on their way, no LDS stores; a trip with more than 64
-	// requests takes its second half after the first has been handed out.
-	uint4 V[DIRECT ? 1 : 8];
-	if (!DIRECT) {
+	// (FM blocks straight into LDS -- global_load_lds_dwordx4 -- were measured in round 3: 221 against 209 ms, and 363 at four waves per SIMD)
+	uint4 V[8];
+	{
 #pragma unroll
-		for (int r = 0; r < (DIRECT ? 1 : 8); ++r) {
+		for (int r = 0; r < 8; ++r) {
 			V[r] = make_uint4(0, 0, 0, 0);
 			if (r < rounds) {
 				const int req = r * 16 + sub;
@@ -88,14 +83,8 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 #pragma unroll
 			for (int rr = 0; rr < 4; ++rr) {
 				const int r = 4 * h + rr, req = r * 16 + sub;
-				if (DIRECT) {
-					if (r < rounds && req < n) {
-						const uint4 *src = reinterpret_cast<const uint4*>(X.addr[req]) + (piece ^ ((req >> 2) & 3));
-						__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)&X.slot[rr * 64], 16, 0, 0);
-					}
-				} else if (req < n) X.slot[((req & 63) << 2) + (piece ^ ((req >> 2) & 3))] = V[DIRECT ? 0 : r];
+				if (req < n) X.slot[((req & 63) << 2) + (piece ^ ((req >> 2) & 3))] = V[r];
 			}
-			if (DIRECT) __builtin_amdgcn_s_waitcnt(0);
 			WAVE_SYNC();
 			if (h == 0 && r0) { // n0 <= 64: every first block travels in the first half
 				const DevBlock B = seed_take(X, i0);
@@ -126,7 +115,7 @@ __device__ __forceinline__ DevIntv seed_extend_wave(bool need, const DevIndex &i
 // many more workgroups than fit on the chip, which lets kernels of a higher-priority stream (the back half of
 // the previous chunk) get compute units while this one is running.  Scratch slabs are therefore not tied to
 // the workgroup index: each wave takes a free slab and gives it back when it exits.
-template <int OCC, bool DIRECT, int LDS_WORDS>
+template <int OCC, int LDS_WORDS>
 __global__ void __launch_bounds__(64 * SEED_WPB, OCC)
 k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_tasks, SeedParams P,
        DevIntv *scratch, int list_cap, int mem_cap,
@@ -233,7 +222,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		if (prof && pc_c0) pc_cold += clock64() - pc_c0;
 		if (__all(retired)) break;
 		if (__ballot(need) == 0) continue;
-		const DevIntv ok = seed_extend_wave<DIRECT>(need, ix, L, X, L.n_slow, L.n_fast);
+		const DevIntv ok = seed_extend_wave(need, ix, L, X, L.n_slow, L.n_fast);
 		if (need) {
 			seed_post(L, ok, P);
 			// a strand search whose lists no longer fit is abandoned at once: its result is discarded and it is seeded again with
@@ -297,7 +286,6 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof, uint32_t *qpack, unsigned long long direct_off)
 {
 	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
-	// $BSX_SEED_FORM (measurements): 0 = blocks through registers and LDS stores, 1 = straight into LDS, 2 = that at four waves per SIMD (spills)
 	// the full state machine runs every (cold_mask + 1)-th trip, or when more than cold_lanes lanes wait for it ($BSX_SEED_COLD_EVERY, a power of two,
 	// $BSX_SEED_COLD_LANES).  The launch does not care (tools/seed_cold.sh: 208.2-209.8 ms from every 2nd trip / 16 lanes to every 16th / 32): what
 	// bounds it is the vector issue of the trips themselves -- 820 wave64 instructions at four cycles each on a 16-wide SIMD, three waves deep
@@ -310,12 +298,8 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
 		             quota, slab_busy, n_slabs, trip_budget, prof, qpack, direct_off);
 		return;
 	}
-	static const int form = getenv("BSX_SEED_FORM") ? atoi(getenv("BSX_SEED_FORM")) : SEED_FORM_DEFAULT;
-#define SEED_LAUNCH(...) hipLaunchKernelGGL((k_seed<__VA_ARGS__>), dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, \
-	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof, cold_mask, cold_lanes)
-	if (form == 0) SEED_LAUNCH(3, false, 24);
-	else if (form == 2) SEED_LAUNCH(4, true, 20);
-	else SEED_LAUNCH(3, true, 24);
+	hipLaunchKernelGGL((k_seed<3, 24>), dim3(grid * (4 / SEED_WPB)), dim3(64 * SEED_WPB), 0, st, /* `grid` counts groups of four waves */ ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor,
+	                   task_off, task_n, task_cursor, counters, quota, slab_busy, n_slabs, trip_budget, prof, cold_mask, cold_lanes);
 }
 // the file's 2-bit symbol fields of every block into the device's bit planes (dev_common.hpp), in place; a thread per block
 __global__ void __launch_bounds__(256)

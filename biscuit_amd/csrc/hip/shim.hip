@@ -779,33 +779,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			TIER_MARK("chains -> regions");
 			return BSX_OK;
 		}
-		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers
-		// $BSX_SLAB_EXPORT=1: the first HBM tier stops after the chain filter and exports too (156 instead of 225 VGPRs: three waves per
-		// SIMD instead of two); its chains go through k_c2r with everybody else's, and what k_c2r cannot hold (a chain of more than 128 seeds,
-		// more than 64 regions) then takes the same tier in its full form.  Measured and off: 359 against 342 ms per chunk on the clean genome,
-		// 1593 against 1089 on the hg38-like one (the export walks the seed table once per chain and list, in HBM).  =2: that tier chained as the
-		// LDS tiers do it (pieces, chain starts in registers) over its HBM slab: 344 against 342, 1140 against 1095 -- no better either.
-		const int slab_export = getenv("BSX_SLAB_EXPORT") ? atoi(getenv("BSX_SLAB_EXPORT")) : 0;
-		if (slab_export) {
-			launch_regions_slab(st, slab_export == 2 ? 4 : 2, big_grid + big_grid / 2, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, slab_export == 2 ? rl : rb, slab_export == 2 ? l_count : k32 + 3, ctr, posoffs, d_pos, &XP);   // 2: chained by pieces; what it declines (tied starts, tables) takes the full form next
-			TIER_MARK("tier 2 (exports)");
-			if (XP.ext) launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
-			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rl, l_count, ctr, c2r_quota);
-			TIER_MARK("chains -> regions");
-			if (main_seq && chain == 3) {
-				std::lock_guard<std::mutex> g(d->chain_mu);
-				HIPCHK(hipEventRecord(L.ev_regions_done, st));
-				d->chain_regions = L.ev_regions_done;
-			}
-			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rl, l_count, l_cursor, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
-			TIER_MARK("tier 2");
-			launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
-			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos);
-			TIER_MARK("tier 3");
-			return BSX_OK;
-		}
+		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers.
+		// (The first HBM tier exporting its chains as well -- 156 instead of 225 VGPRs, its chains through k_c2r with everybody else's -- was
+		// measured in rounds 3 and 4 and removed: what k_c2r cannot hold, 64 regions and 128 seeds a chain, takes the full form afterwards anyway,
+		// 1468 against 1287 ms per chunk on the hg38-like genome.)
 		if (XP.ext) {
 			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
