@@ -243,6 +243,10 @@ def main():
     barrier()
     dt = time.time() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    try:
+        hbm_free = torch.cuda.mem_get_info(local_rank)   # (free, total) with the index, the table and every lane's buffers resident
+    except Exception:
+        hbm_free = (None, None)
     sam_bytes = sam_bytes_box[0]
 
     tmax, tot_reads = dt, n_reads * args.steps
@@ -387,7 +391,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload,
                        "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": ("chunk-sharded x%d" % world) + (" (CODE-PATH CHECK: all ranks on one GPU, gloo; not a measurement)" if share_gpu else ""), "chunk_pipeline_depth": depth,
-                       "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 4 * 8) + n_bases / 4)},
+                       "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 2 * 8) + n_bases / 4),
+                       "seed_table_bytes_in_hbm": int(2 * 16 * sum(3 ** l for l in range(1, (tab_touch[2] if tab_touch else 0) + 1)))},
             "roofline": roof,
             "roofline_second_kernel": roof_other,
             "roofline_whole_path": whole,
@@ -404,6 +409,7 @@ def main():
             "host_cores_busy_per_gpu": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / max(1e-9, dt), 2),
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "genome_and_index_build_s": round(t_build, 1), "device": dev.name,
+            "hbm_bytes_free_of_total_after_the_run": list(hbm_free),
             "hg38_like_genome": None,
         }
     dev_name = dev.name

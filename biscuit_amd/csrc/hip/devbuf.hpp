@@ -34,7 +34,9 @@ struct DevBuf {
 	int reserve(size_t n) {
 		if (n <= cap) return BSX_OK;
 		if (p) { DevbufDeferred &d = devbuf_deferred(); std::lock_guard<std::mutex> g(d.mu); d.dev.push_back(std::make_pair(devbuf_current(), p)); p = nullptr; }
-		size_t want = n + (n >> 1) + 4096;
+		// room to grow into: half again for the small buffers (their sizes follow the data), a sixteenth for those of a gigabyte and more (pools
+		// sized from the chunk's read count: the four lanes of a stream held 60 GB of slack between them)
+		size_t want = n + (n >= ((size_t)1 << 30) ? n >> 4 : n >> 1) + 4096;
 		if (hipMalloc(&p, want) != hipSuccess) {
 			size_t fr = 0, tot = 0; (void)hipGetLastError(); (void)hipMemGetInfo(&fr, &tot);
 			p = nullptr; cap = 0; fprintf(stderr, "[bsx-hip] hipMalloc(%zu) failed (%zu of %zu bytes free)\n", want, fr, tot); return BSX_E_NOMEM;

@@ -70,6 +70,9 @@ struct LaneRef { bsx_device *d; int lane; };   // what the backend vtable carrie
 
 #include <sys/time.h>
 static double bsx_now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
+// the device's suffix-array sample: every 2nd rank (the files keep every 32nd, bwtindex.c:328,340): bwt_sa walks one LF step on average.
+// Measured at hg38 size, k_occ per chunk: 28 ms at every 4th (12.4 GB per index), 16.5 at every 2nd (24.8 GB), 8.9 with the whole array (49.6 GB)
+#define BSX_DEVICE_SA_INTV_DEFAULT 2
 static inline unsigned long long *dev_counters(Lane &L) { return (unsigned long long*)L.small.p; }
 
 extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
@@ -234,7 +237,7 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
 	{ // denser suffix-array sample for the device (the files' 1-in-32 stays what the loader and the host see)
 		const char *e = getenv("BSX_DEVICE_SA_INTV");
-		int want = e ? atoi(e) : 4;
+		int want = e ? atoi(e) : BSX_DEVICE_SA_INTV_DEFAULT;
 		const int file_intv = (int)d->ix.fmi[0].sa_mask + 1;
 		if (want >= 1 && want < file_intv && (want & (want - 1)) == 0 && d->ix.fmi[1].sa_mask == d->ix.fmi[0].sa_mask) {
 			DevBuf dense[2];
@@ -268,8 +271,8 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 	int rc;
 	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
 	const char *e = getenv("BSX_DEVICE_SA_INTV");
-	int dense = e ? atoi(e) : 4;
-	if (dense < 1 || dense > 32 || (dense & (dense - 1))) dense = 4;
+	int dense = e ? atoi(e) : BSX_DEVICE_SA_INTV_DEFAULT;
+	if (dense < 1 || dense > 32 || (dense & (dense - 1))) dense = BSX_DEVICE_SA_INTV_DEFAULT;
 	Lane &L = d->lane[0];
 	for (int i = 1; i >= 0; --i) {
 		bsx_fmi_t *f = &idx->fmi[i], meta;
