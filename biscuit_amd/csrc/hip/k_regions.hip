@@ -308,6 +308,148 @@ __device__ __forceinline__ bool rg_introsort_wave(unsigned int (&v)[NS], int n, 
 #undef WGT
 }
 
+// The same sort with every partition made AT ONCE (round 4, second form).  klib's partition loop (ksort.h:212-217) is Hoare's: i stops at the
+// positions whose weight is <= the pivot's ("L stops", the pivot at a[t] among them), j at those in (s, t) whose weight is >= it ("R
+// stops"), and round k swaps the k-th L stop from the left with the k-th R stop from the right while the first lies below the second -- the
+// swaps never touch what later rounds scan, so which positions swap, and with whom, follows from the two stop masks of the ORIGINAL segment:
+// L stop number k (from the left) takes part iff at least k R stops lie above it, R stop number k (from the right) iff at least k L stops lie
+// below it, partners have equal numbers; the loop ends at the first L stop that takes no part or at the lowest R stop that does, whichever
+// comes first.  A lane per position (segment-relative: only a segment longer than 64 spans register slots), partners meet through two
+// lists in LDS.  The closing insertion pass (ksort.h:229) never carries an element across a pivot, and is stable: it is the order by
+// (weight descending, position ascending) of the array as the partitions leave it -- a rank by counting.  Same stack discipline and depth
+// count as klib, so the comb-sort case (pre-sorted input) meets the array klib would have: one lane runs it on that segment.  Checked
+// against the sequential algorithm on random keys with ties in tools/dbg/parsort_model.py.  For n <= 256.
+__device__ void rg_combsort_keys(unsigned int *a, int m)   // ks_combsort (ksort.h:162-183) over a[0, m), by one lane
+{
+#define LT(x, y) (((x) >> RG_KEY_BITS) > ((y) >> RG_KEY_BITS))
+#define SWP(i, j) do { const unsigned int t_ = a[i]; a[i] = a[j]; a[j] = t_; } while (0)
+	const double shrink = 1.2473309501039786540366528676643;
+	int gap = m, swapped, i, j;
+	do {
+		if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+		swapped = 0;
+		for (i = 0; i + gap < m; ++i) if (LT(a[i + gap], a[i])) { SWP(i, i + gap); swapped = 1; }
+	} while (swapped || gap > 2);
+	if (gap != 1) for (i = 1; i < m; ++i) for (j = i; j > 0 && LT(a[j], a[j - 1]); --j) SWP(j, j - 1);
+#undef LT
+#undef SWP
+}
+template <int NS>
+__device__ __forceinline__ int rg_par_partition(unsigned int *a, unsigned int *tmpL, unsigned int *tmpR, int s, int t, unsigned int rp, int lane)
+{
+	const unsigned int wp = rp >> RG_KEY_BITS;
+	const int len = t - s + 1;
+	unsigned int x[NS]; unsigned long long Lm[NS], Rm[NS]; int kk[NS];
+	int r_after = 0;
+#pragma unroll
+	for (int c = 0; c < NS; ++c) {
+		const int r = c * 64 + lane;
+		const bool in = r >= 1 && r < len;
+		x[c] = in ? a[s + r] : 0u;
+		const unsigned int w = x[c] >> RG_KEY_BITS;
+		Lm[c] = __ballot(in && w <= wp);
+		Rm[c] = __ballot(in && r < len - 1 && w >= wp);
+		r_after += __popcll(Rm[c]);
+	}
+	int l_before = 0, first_free = 0x7fffffff, low_r = 0x7fffffff;
+#pragma unroll
+	for (int c = 0; c < NS; ++c) {
+		const int rc = __popcll(Rm[c]);
+		r_after -= rc;                                  // R stops in the slots above this one
+		const int is_l = (int)((Lm[c] >> lane) & 1), is_r = (int)((Rm[c] >> lane) & 1);
+		const int l_lt = l_before + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(Lm[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)Lm[c], 0u));
+		const int r_lt = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(Rm[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)Rm[c], 0u));
+		const int k_l = l_lt + 1;                       // my number among the L stops, from the left
+		const int r_gt = r_after + rc - r_lt - is_r;    // R stops above me
+		const int k_r = r_gt + 1;                       // my number among the R stops, from the right
+		const bool pl = is_l && r_gt >= k_l, pr = is_r && l_lt >= k_r;
+		if (pl) tmpL[k_l - 1] = x[c];
+		if (pr) tmpR[k_r - 1] = x[c];
+		kk[c] = pl ? k_l : pr ? -k_r : 0;
+		const unsigned long long fm = Lm[c] & ~__ballot(pl), rm = __ballot(pr);
+		if (fm && first_free == 0x7fffffff) first_free = c * 64 + (int)__builtin_ctzll(fm);
+		if (rm && low_r == 0x7fffffff) low_r = c * 64 + (int)__builtin_ctzll(rm);
+		l_before += __popcll(Lm[c]);
+	}
+	WAVE_SYNC();
+#pragma unroll
+	for (int c = 0; c < NS; ++c) {
+		if (kk[c] > 0) a[s + c * 64 + lane] = tmpR[kk[c] - 1];
+		else if (kk[c] < 0) a[s + c * 64 + lane] = tmpL[-kk[c] - 1];
+	}
+	const int i = s + (first_free < low_r ? first_free : low_r);
+	WAVE_SYNC();
+	if (i != t && lane == 0) { const unsigned int v = a[i]; a[t] = v; a[i] = rp; }
+	WAVE_SYNC();
+	return i;
+}
+template <int MS>   // register slots of 64 keys: n <= 64 * MS
+__device__ __forceinline__ void rg_introsort_par(unsigned int *a, int n, unsigned int *tmpL, unsigned int *tmpR, int *stk, int lane)
+{
+#define WGT(x) ((x) >> RG_KEY_BITS)
+	if (n < 2) return;
+	if (n == 2) { if (lane == 0) { const unsigned int a0 = a[0], a1 = a[1]; if (WGT(a1) > WGT(a0)) { a[0] = a1; a[1] = a0; } } WAVE_SYNC(); return; }
+	int d, s = 0, t = n - 1, top = 0;
+	int *stk_l = stk, *stk_r = stk + 16, *stk_d = stk + 32;
+	for (d = 2; (1 << d) < n; ++d);
+	d <<= 1;
+	for (;;) {
+		if (s < t) {
+			if (--d == 0) { if (lane == 0) rg_combsort_keys(a + s, t - s + 1); WAVE_SYNC(); t = s; continue; }
+			const int k0 = s + ((t - s) >> 1) + 1;
+			const unsigned int ai = (unsigned int)uni((int)a[s]), ak = (unsigned int)uni((int)a[k0]), aj = (unsigned int)uni((int)a[t]);
+			int k = k0;
+			if (WGT(ak) > WGT(ai)) { if (WGT(ak) > WGT(aj)) k = t; }
+			else k = WGT(aj) > WGT(ai) ? s : t;
+			const unsigned int rp = k == k0 ? ak : k == s ? ai : aj;
+			if (k != t) { WAVE_SYNC(); if (lane == 0) { a[k] = aj; a[t] = rp; } WAVE_SYNC(); }
+			const int len = t - s + 1;
+			int i;
+			if (len <= 64) i = rg_par_partition<1>(a, tmpL, tmpR, s, t, rp, lane);
+			else if (MS <= 2 || len <= 128) i = rg_par_partition<2>(a, tmpL, tmpR, s, t, rp, lane);
+			else i = rg_par_partition<MS <= 2 ? 2 : 4>(a, tmpL, tmpR, s, t, rp, lane);
+			if (i - s > t - i) {
+				if (i - s > 16) { if (lane == 0) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; } ++top; }
+				s = t - i > 16 ? i + 1 : t;
+			} else {
+				if (t - i > 16) { if (lane == 0) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; } ++top; }
+				t = i - s > 16 ? i - 1 : s;
+			}
+		} else {
+			if (top == 0) break;
+			--top;
+			WAVE_SYNC();
+			s = uni(stk_l[top]); t = uni(stk_r[top]); d = uni(stk_d[top]);
+		}
+	}
+	// the insertion pass: every key to its rank by (weight descending, position ascending)
+	WAVE_SYNC();
+	unsigned int x[MS], u[MS]; int rk[MS];
+#pragma unroll
+	for (int c = 0; c < MS; ++c) {
+		const int p = c * 64 + lane;
+		x[c] = (c * 64 < n && p < n) ? a[p] : 0u;
+		u[c] = p < n ? (WGT(x[c]) << 9 | (unsigned int)(256 - p)) : 0u;   // unique, heavier and earlier = larger; 0: no key
+		rk[c] = 0;
+	}
+#pragma unroll
+	for (int cq = 0; cq < MS; ++cq) {
+		if (cq * 64 < n) {
+			const int lim = n - cq * 64 < 64 ? n - cq * 64 : 64;
+			for (int q = 0; q < lim; ++q) {
+				const unsigned int uq = (unsigned int)__builtin_amdgcn_readlane((int)u[cq], q);
+#pragma unroll
+				for (int c = 0; c < MS; ++c) if (c * 64 < n) rk[c] += uq > u[c];
+			}
+		}
+	}
+	WAVE_SYNC();
+#pragma unroll
+	for (int c = 0; c < MS; ++c) if (c * 64 + lane < n) a[rk[c]] = x[c];
+	WAVE_SYNC();
+#undef WGT
+}
+
 // ---- the chain index as the reference keeps it: kbtree.h instantiated with t = 3 (pre-emptive split on the way down,
 // lower-bound search inside a node, duplicates allowed); same structure as csrc/host/util.c:bsx_bt_*.  One lane runs it.
 template <typename Store>
@@ -966,6 +1108,11 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 		WAVE_SYNC();
 		bool sorted = false;
+		constexpr int SORT_MS = Store::CCAP <= 64 ? 1 : Store::CCAP <= 128 ? 2 : 4;
+		if (!Store::NODES && n <= 64 * SORT_MS && !(P.knobs & 1)) { // every partition at once (rg_introsort_par): the second half of srt[] holds the partners' lists
+			rg_introsort_par<SORT_MS>(keys, n, keys + Store::SCAP, keys + Store::SCAP + Store::SCAP / 2, D.H, lane);
+			sorted = true;
+		} else
 		if (n <= 64) { // by the wave, a key per lane (exactly klib's permutation); its depth-limit case and longer lists: one lane over LDS.
 			// (Measured with two and four register slots for up to 256 keys: every slot is a compare, a ballot and a branch more in every scan and
 			// access, and the larger LDS tier got slower -- sort 199 G -> 269 G wave cycles per chunk -- where the one-slot form halves the first tier's.)
@@ -993,6 +1140,111 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				const RgChain c0 = rg_chain(S, (int)uni(S.ord[0]));
 				if (lane == 0) { kb[0] = c0.first_q; ke[0] = c0.last_q + c0.last_len; kw[0] = c0.w; ka[0] = c0.is_alt; kpos[0] = 0; kst[0] = 3; }
 			}
+			if (!(P.knobs & 2)) {
+				// A LANE PER CANDIDATE, 64 chains of the sorted order at a time, the kept list walked entry by entry (round 4): what chain i does to
+				// a kept chain k, and k to i, depends on the two alone, and i meets the kept chains in the order they were kept.  So every lane
+				// first tests its chain against the list as it stands (a drop ends the lane); then the lowest lane left is the next kept chain,
+				// the lanes above it meet it straight from its lane's registers, and so on until no lane is left.  chn->first of a kept chain =
+				// the lowest chain that overlaps it significantly having got that far = the lowest lane that says so in the one round it is met.
+				// The test itself (memchain.c:436-452) in integers: "overlap >= min_l * mask_level" in float is overlap >= T(min_l) with
+				// T(l) = ceil of the float product, T grows with l so T(min(li, lk)) = min(T(li), T(lk)); T >= 1 carries "e_min > b_max" and
+				// T = 0xffff "min_l >= max_chain_gap"; "w_i < w_k * drop_ratio && w_k - w_i >= 2 * min_seed_len" is w_i < D(w_k).  T and D are
+				// computed once per chain, a test is a max, two min, a subtraction and two compares, and who is alive, who overlapped somebody
+				// and who is met are masks of the wave in scalar registers.
+				// Kept chains: kb = begin | end << 16, kw = T | D << 16 | alt << 31, km = position | state << 12 | (first + 1) << 16.
+				int km[NH];
+#pragma unroll
+				for (int h = 0; h < NH; ++h) km[h] = 0;
+				const auto flt_T = [&](int l) -> int { if (!(l < P.max_chain_gap)) return 0xffff; const int t = (int)ceilf((float)l * P.mask_level); return t < 1 ? 1 : t; };
+				const auto flt_D = [&](int w) -> int { int d = (int)ceilf((float)w * P.drop_ratio); const int e = w - (P.min_seed_len << 1) + 1; d = d < e ? d : e; return d < 0 ? 0 : d > 0x7fff ? 0x7fff : d; };
+				// The chains no kept chain can drop are kept whatever the list holds: a drop needs w_i < w_k * drop_ratio and w_k - w_i >= 2 *
+				// min_seed_len (memchain.c:449), no kept chain is heavier than the first, and the order is by weight -- so they are a PREFIX of the
+				// sorted order (all of it for a strand search on the strand the read does not come from: a hundred chance matches of weight 19-22).
+				// They enter the list up front, each from its own lane (entry = sorted position); what is left to find out about them -- whether
+				// they overlap an earlier one significantly (kept = 2 instead of 3) and the first chain that does so to them -- are tests of
+				// pairs that do not depend on each other: a pass over the list per 64 of them, no round per kept chain.
+				int U = 0;
+				{
+					const int d0 = flt_D((int)(uni((int)keys[0]) >> RG_KEY_BITS));
+					for (int base = 0; base < n; base += 64) {
+						const int i = base + lane;
+						const int wi = i < n ? (int)(keys[i] >> RG_KEY_BITS) : 0;
+						const unsigned long long can = __ballot(i >= n || wi < d0);
+						if (can) { U = base + (int)__builtin_ctzll(can); break; }
+						U = base + 64;
+					}
+					if (U > n) U = n;
+				}
+#pragma unroll
+				for (int h = 0; h < NH; ++h) {
+					const int i = h * 64 + lane;
+					if (h * 64 < U && i < U) {
+						const RgChain cu = rg_chain(S, (int)S.ord[i]);
+						const int b = cu.first_q, e = (int)cu.last_q + (int)cu.last_len;
+						kb[h] = b | e << 16; kw[h] = flt_T(e - b) | flt_D((int)cu.w) << 16 | (int)((unsigned int)(cu.is_alt ? 1 : 0) << 31); km[h] = i | 3 << 12;
+					}
+				}
+				n_kept = U;
+				// When that prefix is the whole list nothing is left to find out: what the tests would add -- kept = 2 for 3, and the first
+				// chain overlapping each (which mem_chain_flt turns into kept = 1, memchain.c:461-464) -- only ever tells kept chains apart
+				// from each other, which nothing reads unless max_chain_extend is in force (memchain.c:467-475).  That is every strand search
+				// on the strand its read does not come from: half of all, and the ones with the longest lists.
+				const bool all_kept = U == n && P.max_chain_extend >= (unsigned int)n;
+				for (int base = 0; base < n && !all_kept; base += 64) {
+					const int i = base + lane;
+					const bool valid = i >= 1 && i < n;
+					int ib = 0, ie = 0, iw = 0, ia = 0;
+					if (valid) { const RgChain ci = rg_chain(S, (int)S.ord[i]); ib = ci.first_q; ie = (int)ci.last_q + (int)ci.last_len; iw = ci.w; ia = ci.is_alt ? 1 : 0; }
+					const int ti = flt_T(ie - ib);
+					const int q0v = ib | ie << 16, q1v = ti | flt_D(iw) << 16 | (int)((unsigned int)ia << 31);
+					unsigned long long live_m = __ballot(valid), large_m = 0;
+					const unsigned long long pre_m = __ballot(i < U), alt_m = __ballot(ia != 0);   // pre: in the list already, meets the entries before its own
+					const int k_end = base + 64 <= U ? base + 64 : n_kept;
+					for (int k = 0; k < k_end; ++k) { // the list as it stands
+						unsigned int p0 = 0, p1 = 0;
+						const int kh = k >> 6, kl = k & 63;
+#pragma unroll
+						for (int h = 0; h < NH; ++h) if (h == kh) { p0 = (unsigned int)__builtin_amdgcn_readlane(kb[h], kl); p1 = (unsigned int)__builtin_amdgcn_readlane(kw[h], kl); }
+						const int kbk = (int)(p0 & 0xffff), kek = (int)(p0 >> 16), tk = (int)(p1 & 0xffff), dk = (int)((p1 >> 16) & 0x7fff);
+						const int ov = (kek < ie ? kek : ie) - (kbk > ib ? kbk : ib), tm = ti < tk ? ti : tk;
+						unsigned long long hm = __ballot(ov >= tm) & live_m;
+						if (k >= base) hm &= ~pre_m | (k - base < 63 ? ~0ull << (k - base + 1) : 0ull);
+						if (p1 >> 31) hm &= alt_m;
+						large_m |= hm;
+						if (hm) {
+							const int f = base + (int)__builtin_ctzll(hm);
+#pragma unroll
+							for (int h = 0; h < NH; ++h) if (h == kh) { if (lane == kl && !(km[h] >> 16)) km[h] |= (f + 1) << 16; }
+							live_m &= ~(hm & __ballot(iw < dk));
+						}
+					}
+					if (base < U) { // the entries of this batch's own lanes: kept = 2 when they overlap an earlier one
+						const bool two = ((pre_m & live_m & large_m) >> lane) & 1;
+#pragma unroll
+						for (int h = 0; h < NH; ++h) if (h == base >> 6) { if (two) km[h] = (km[h] & ~(3 << 12)) | 2 << 12; }
+					}
+					unsigned long long um = live_m & ~pre_m;
+					while (um) {
+						const int l = (int)__builtin_ctzll(um);   // kept: the next entry of the list
+						const unsigned int p0 = (unsigned int)__builtin_amdgcn_readlane(q0v, l), p1 = (unsigned int)__builtin_amdgcn_readlane(q1v, l);
+						const int kbk = (int)(p0 & 0xffff), kek = (int)(p0 >> 16), tk = (int)(p1 & 0xffff), dk = (int)((p1 >> 16) & 0x7fff);
+						const int ov = (kek < ie ? kek : ie) - (kbk > ib ? kbk : ib), tm = ti < tk ? ti : tk;
+						unsigned long long hm = __ballot(ov >= tm) & live_m & (l < 63 ? ~0ull << (l + 1) : 0ull);
+						if (p1 >> 31) hm &= alt_m;
+						large_m |= hm;
+						const unsigned long long dm = hm ? hm & __ballot(iw < dk) : 0ull;
+						live_m &= ~dm;
+						const int meta = (base + l) | (((large_m >> l) & 1) ? 2 : 3) << 12 | (hm ? base + (int)__builtin_ctzll(hm) + 1 : 0) << 16;
+						const int sl = n_kept & 63, hi = n_kept >> 6;
+#pragma unroll
+						for (int h = 0; h < NH; ++h) if (h == hi) { if (lane == sl) { kb[h] = (int)p0; kw[h] = (int)p1; km[h] = meta; } }
+						++n_kept;
+						um &= ~dm & ~(1ull << l);
+					}
+				}
+#pragma unroll
+				for (int h = 0; h < NH; ++h) { kpos[h] = km[h] & 0xfff; kst[h] = (km[h] >> 12) & 3; kfi[h] = (km[h] >> 16) - 1; }
+			} else
 			for (int i = 1; i < n; ++i) {
 				const RgChain ci = rg_chain(S, (int)uni(S.ord[i]));
 				const int ib = uni((int)ci.first_q), ie = uni((int)ci.last_q + (int)ci.last_len), iw = uni((int)ci.w), ia = uni((int)ci.is_alt);
@@ -1036,7 +1288,15 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			int nk = 1;
 			if (lane == 0) { S.ch[S.ord[0]].kept = 3; S.keep[0] = 0; keepc[0] = S.ord[0]; }
 			WAVE_SYNC();
-			for (int i = 1; i < n; ++i) {
+			// no chain light enough for the heaviest one to drop it (memchain.c:449): then none is dropped by anybody, every chain is kept, and
+			// the pair tests would only tell kept chains apart (2 for 3, `first`), which nothing reads unless max_chain_extend is in force
+			bool all_kept = false;
+			if (!(P.knobs & 2) && P.max_chain_extend >= (unsigned int)n) {
+				const int w0 = (int)(uni((int)keys[0]) >> RG_KEY_BITS), wl = (int)(uni((int)keys[n - 1]) >> RG_KEY_BITS);
+				all_kept = !((float)wl < (float)w0 * P.drop_ratio && w0 - wl >= P.min_seed_len << 1);
+				if (all_kept) { for (int j = lane; j < n; j += 64) S.ch[S.ord[j]].kept = 3; WAVE_SYNC(); }
+			}
+			for (int i = 1; i < n && !all_kept; ++i) {
 				// chain i against the kept chains, 64 at a time; the reference's loop stops at the first kept chain that drops it
 				const int cidx = uni(S.ord[i]);
 				const RgChain ci = S.ch[cidx];
@@ -1877,9 +2137,12 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA, int long_reads)
 {
 	RgXPool X = rgx_pool(&XA);
-	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 4;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
+	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 5;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
 	if (long_reads)
 		hipLaunchKernelGGL((k_regions<3, RgDpLiteL>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
+	else if (occ >= 5)
+		hipLaunchKernelGGL((k_regions<5, RgDpLite>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
 	else if (occ >= 4)
 		hipLaunchKernelGGL((k_regions<4, RgDpLite>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,

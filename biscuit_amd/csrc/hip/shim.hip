@@ -601,7 +601,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.a = opt->a; R.w = opt->w; R.o_del = opt->o_del; R.e_del = opt->e_del; R.o_ins = opt->o_ins; R.e_ins = opt->e_ins;
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
-	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
+	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0; R.knobs = getenv("BSX_RG_KNOBS") ? atoi(getenv("BSX_RG_KNOBS")) : 0;
 	R.gap_cap = 0;
 	{ static const int walk = getenv("BSX_WALK_PAST_MAX_OCC") ? atoi(getenv("BSX_WALK_PAST_MAX_OCC")) : 1; R.walk_on = walk; }
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
@@ -705,7 +705,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)(ctr + 4) + 1), (int)(uint32_t)(direct_n >> 32), 1, L.st));
-	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 2;   // 0: none, 1: seeding, 2: seeding and regions
+	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 3;   // 0: none, 1: seeding, 2: seeding and regions, 3: the same but the HBM tiers (a few long strand searches on a few waves) hold nobody back (measured A/B on one box, 16 chunks: 1.76 / 1.81 M reads/s with 2, 2.00 / 1.89 M with 3)
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		if (d->chain_seed && d->chain_seed != L.ev_seed_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_seed, 0));
@@ -745,7 +745,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
 		// $BSX_PHASES=2: the stage counters read (and zeroed) after every launch of the main sequence: where each tier's wave cycles go
-		static const bool per_tier = getenv("BSX_PHASES") && atoi(getenv("BSX_PHASES")) == 2;
+		const bool per_tier = getenv("BSX_PHASES") && atoi(getenv("BSX_PHASES")) == 2;
 #define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; \
 		if (per_tier) { unsigned long long pf_[8]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
 			double tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) tot_ += (double)pf_[k_]; \

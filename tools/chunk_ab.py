@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--single-end", action="store_true")
+    ap.add_argument("--crc", action="store_true", help="checksum of the chunk's SAM text per configuration (the knobs must not change it)")
     ap.add_argument("cfgs", nargs="*", default=[""])
     a = ap.parse_args()
     from biscuit_amd import _lib as B
@@ -47,11 +48,18 @@ def main():
         for k in range(8):
             dev.kernel_time(k, reset=True)
         t0 = time.time()
+        crc = None
         for _ in range(a.reps):
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * pairs, p, None), "chunk")
+            if a.crc and crc is None:
+                import zlib
+                reads = C.cast(p, C.POINTER(B.Read))
+                crc = 0
+                for i in range(2 * pairs):
+                    crc = zlib.crc32(C.string_at(reads[i].sam), crc)
             L.bsx_sim_reset_reads(p, 2 * pairs)
         dt = (time.time() - t0) / a.reps
-        print("%-50s %s | chunk %.0f ms" % (cfg or "(defaults)", " ".join("%s %.1f" % (names[k], dev.kernel_time(k)[0] / a.reps) for k in range(8)), dt * 1e3), flush=True)
+        print("%-50s %s | chunk %.0f ms" % (cfg or "(defaults)", " ".join("%s %.1f" % (names[k], dev.kernel_time(k)[0] / a.reps) for k in range(8)), dt * 1e3) + (" | sam crc %08x" % crc if crc is not None else ""), flush=True)
         for k in kv:
             os.environ.pop(k, None)
 
