@@ -138,6 +138,32 @@ __device__ __forceinline__ int rg_intv2rid(const DevIndex &ix, const long long *
 // csrc/host/util.c:bsx_introsort so that equal weights end in the reference's order.  One lane runs it; the elements are
 // packed keys (weight << RG_KEY_BITS | chain index) so that a comparison is two independent LDS reads and a swap two stores.
 #define RG_KEY_BITS 13   // chain indices < 8192 (RgHuge::CCAP)
+// asymmetric_flt_seed (memchain.c:138-149) for the seed of `ln` bases at reference position rb (forward-reverse space) whose read bases are q[0, ln): a
+// reference T under a read C or a reference A under a read G.  The reference bases come 32 at a time (one unaligned 8-byte load of pac: a chance
+// match of 19-22 bases is one load); a seed lies on one strand, the reverse one read backwards and complemented
+__device__ __forceinline__ int rg_seed_conv_test(const DevIndex &ix, long long rb, int ln, const uint8_t *q)
+{
+	const long long l_pac = ix.l_pac;
+	int bad = 0;
+	const bool rev = rb >= l_pac;
+	const long long f0 = rev ? (l_pac << 1) - rb - ln : rb;   // forward coordinate of the seed's lowest base
+	for (int done = 0; done < ln; ) {
+		const long long f = f0 + done;
+		unsigned long long w;
+		__builtin_memcpy(&w, ix.pac + (f >> 2), 8);   // (pac is padded: upload_ref)
+		const int k0 = (int)(f & 3);
+		int m = 32 - k0; if (m > ln - done) m = ln - done;
+		for (int k = k0; k < k0 + m; ++k) {
+			const int b = (int)(w >> (((k >> 2) << 3) + ((~k & 3) << 1))) & 3;
+			const int at = done + (k - k0);   // position along the forward strand
+			const int i = rev ? ln - 1 - at : at, r = rev ? 3 - b : b, qq = q[i];
+			bad |= (r == 3 && qq == 1) || (r == 0 && qq == 2);
+		}
+		done += m;
+	}
+	return bad;
+}
+
 __device__ void rg_introsort_keys(unsigned int *a, int n, int *stk)
 {
 #define LT(x, y) (((x) >> RG_KEY_BITS) > ((y) >> RG_KEY_BITS))
@@ -711,13 +737,27 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		const int big = mine.x2 > (unsigned long long)P.max_occ;
 		const int lk = big ? P.max_occ : (int)mine.x2;   // what k_occ looked up ahead
 		long long incl = lk;
+		if (P.max_occ <= 1 << 24) incl = wave_scan_sum_incl(lk);   // (64 intervals of at most max_occ: the sum fits; DPP instead of twelve ds_bpermute)
+		else {
 #pragma unroll
-		for (int off = 1; off < 64; off <<= 1) {
-			const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
-			if (lane >= off) incl += o;
+			for (int off = 1; off < 64; off <<= 1) {
+				const long long o = (long long)((unsigned long long)(unsigned)__shfl_up((int)(incl >> 32), off) << 32 | (unsigned)__shfl_up((int)incl, off));
+				if (lane >= off) incl += o;
+			}
 		}
 		// the other keys come 64 at a time with one coalesced load and are handed round with v_readlane
 		int rank = 0;
+		constexpr bool K32 = Store::ICAP <= 1024 && DP::QCAP < 2048;   // begin (11 bits), end (11) and the list index (10) as ONE 32-bit key: unique, a readlane and a compare per pair
+		if (K32) {
+			const unsigned int mykey = i < n_iv ? ((unsigned int)(mine.info >> 32) << 21 | ((unsigned int)mine.info & 0x7ffu) << 10 | (unsigned int)i) : 0xffffffffu;
+			for (int cb = 0; cb < n_iv; cb += 64) {
+				const int kk = cb + lane;
+				unsigned int okey = mykey;
+				if (cb != base) { const unsigned long long oinfo = kk < n_iv ? src[kk].info : ~0ull; okey = kk < n_iv ? ((unsigned int)(oinfo >> 32) << 21 | ((unsigned int)oinfo & 0x7ffu) << 10 | (unsigned int)kk) : 0xffffffffu; }
+				const int lim = n_iv - cb < 64 ? n_iv - cb : 64;
+				for (int j = 0; j < lim; ++j) rank += (unsigned int)__builtin_amdgcn_readlane((int)okey, j) < mykey;
+			}
+		} else
 		for (int cb = 0; cb < n_iv; cb += 64) {
 			const int kk = cb + lane;
 			const unsigned long long oinfo = kk < n_iv ? src[kk].info : ~0ull;
@@ -815,26 +855,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	// was a quarter of this kernel's time on a genome where most seeds are chance matches).
 	for (int o = lane; o < tot; o += 64) {
 		if (S.s_rid[o] < 0) continue;
-		const long long rb = S.s_rbeg[o]; const int qb = S.s_qbeg[o], ln = S.s_len[o];
-		// the seed's reference bases come 32 at a time (one unaligned 8-byte load of pac: a chance match of 19-22 bases is one load, where a
-		// load per base was twenty dependent trips to the same line); a seed lies on one strand, the reverse one read backwards and complemented
-		int bad = 0;
-		const bool rev = rb >= l_pac;
-		const long long f0 = rev ? (l_pac << 1) - rb - ln : rb;   // forward coordinate of the seed's lowest base
-		for (int done = 0; done < ln; ) {
-			const long long f = f0 + done;
-			unsigned long long w;
-			__builtin_memcpy(&w, ix.pac + (f >> 2), 8);   // (pac is padded: upload_ref)
-			const int k0 = (int)(f & 3);
-			int m = 32 - k0; if (m > ln - done) m = ln - done;
-			for (int k = k0; k < k0 + m; ++k) {
-				const int b = (int)(w >> (((k >> 2) << 3) + ((~k & 3) << 1))) & 3;
-				const int at = done + (k - k0);   // position along the forward strand
-				const int i = rev ? ln - 1 - at : at, r = rev ? 3 - b : b, q = D.q[qb + i];
-				bad |= (r == 3 && q == 1) || (r == 0 && q == 2);
-			}
-			done += m;
-		}
+		const int bad = rg_seed_conv_test(ix, S.s_rbeg[o], (int)S.s_len[o], D.q + S.s_qbeg[o]);
 		if (bad) S.s_extra[o] |= 2;
 	}
 	WAVE_SYNC();

@@ -332,10 +332,10 @@ static void to_read(const bsx_fq_t *f, bsx_read_t *s, int has_bc)
 	if (l > 2 && s->name[l - 2] == '/' && isdigit((unsigned char)s->name[l - 1])) s->name[l - 2] = 0;
 	s->comment = f->comment.n ? strdup(f->comment.a) : 0;
 	if (has_bc) { /* name_..._BARCODE_UMI (bis_kseq2bseq1, bwa.c:766-815): the last two '_' fields */
-		char *tmp = strdup(s->name), *tok, *bc = 0, *umi = 0;
-		tok = strtok(tmp, "_");
-		bc = strtok(NULL, "_"); umi = strtok(NULL, "_");
-		while ((tok = strtok(NULL, "_")) != NULL) { bc = umi; umi = tok; }
+		char *tmp = strdup(s->name), *tok, *bc = 0, *umi = 0, *sv = 0;   /* (strtok_r: the two input files are parsed by two threads) */
+		tok = strtok_r(tmp, "_", &sv);
+		bc = strtok_r(NULL, "_", &sv); umi = strtok_r(NULL, "_", &sv);
+		while ((tok = strtok_r(NULL, "_", &sv)) != NULL) { bc = umi; umi = tok; }
 		s->barcode = bc ? strdup(bc) : 0; s->umi = umi ? strdup(umi) : 0;
 		free(tmp);
 	}

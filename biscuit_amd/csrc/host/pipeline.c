@@ -345,6 +345,14 @@ static int merge_score_fn(void *ud_, const reg_t *a, const reg_t *b, int w, int 
 
 typedef struct { chunk_t *C; merge_ud_t *ud; int *pending; } merge_par_t;
 
+/* a region as the device left it (bsx_region_t, 56 bytes) into the host's record */
+static inline void reg_from_device(reg_t *r, const bsx_region_t *d)
+{
+	memset(r, 0, sizeof(*r));
+	r->rb = d->rb; r->re = d->re; r->qb = d->qb; r->qe = d->qe; r->rid = d->rid; r->score = d->score; r->truesc = d->truesc;
+	r->w = d->w; r->seedcov = d->seedcov; r->seedlen0 = d->seedlen0; r->frac_rep = d->frac_rep; r->bss = d->bss; r->parent = d->parent;
+}
+
 static void regs_copy(reg_v *dst, const reg_v *src)
 {
 	dst->n = src->n; dst->n_pri = src->n_pri;
@@ -363,14 +371,14 @@ static void merge_worker(void *data, long i, int tid)
 	if (!P->pending[i]) return;
 	if (C->dd_n && C->dd_n[i] >= 0) { /* sorted and de-duplicated on the device: what is left of the concatenation, in order */
 		const uint8_t *ix = C->dd_idx + (size_t)i * (size_t)C->dd_cap;
-		int t, kk, m = C->dd_n[i]; size_t tot = 0;
-		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += C->tasks[t].regs.n;
+		int t, kk, m = C->dd_n[i]; size_t tot = 0;   /* (every strand search of such a read finished on the device: dreg_n >= 0) */
+		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += (size_t)C->dreg_n[t];
 		if (regs->m < (size_t)m) { regs->a = (reg_t*)bsx_crealloc(regs->a, 0, sizeof(reg_t) * ((size_t)m + 2)); regs->m = (size_t)m + 2; }
 		regs->n = (size_t)m; regs->n_pri = 0;
 		for (kk = 0; kk < m; ++kk) {
 			size_t li = ix[kk];
-			for (t = C->read_task0[i]; li >= C->tasks[t].regs.n; ++t) li -= C->tasks[t].regs.n;
-			regs->a[kk] = C->tasks[t].regs.a[li];
+			for (t = C->read_task0[i]; li >= (size_t)C->dreg_n[t]; ++t) li -= (size_t)C->dreg_n[t];
+			reg_from_device(&regs->a[kk], &C->dregs[C->dreg_off[t] + (int64_t)li]);
 			regs->a[kk].n_comp = tot > 1 ? 1 : 0;   /* mem_alnreg.c:114,118 */
 		}
 	} else { /* here: (re)start from the regions of the read's strand searches, concatenated in call order */
@@ -962,12 +970,13 @@ static void adopt_worker(void *data, long t, int tid)
 	(void)tid;
 	if (n < 0) return;
 	T->done = 1;
+	/* a read whose regions were sorted and de-duplicated on the device takes the survivors straight from the downloaded block
+	 * (merge_worker): nine million regions a chunk come down, a third of them are left, and a list per strand search was two
+	 * million allocations and 1.4 GB of writes */
+	if (C->dd_n && C->n > 0 && C->dd_n[t / (C->n_tasks / C->n)] >= 0) return;
 	for (k = 0; k < n; ++k) {
-		const bsx_region_t *d = &C->dregs[C->dreg_off[t] + k];
 		reg_t r;
-		memset(&r, 0, sizeof(r));
-		r.rb = d->rb; r.re = d->re; r.qb = d->qb; r.qe = d->qe; r.rid = d->rid; r.score = d->score; r.truesc = d->truesc;
-		r.w = d->w; r.seedcov = d->seedcov; r.seedlen0 = d->seedlen0; r.frac_rep = d->frac_rep; r.bss = d->bss; r.parent = d->parent;
+		reg_from_device(&r, &C->dregs[C->dreg_off[t] + k]);
 		bsx_cvec_push(T->regs, r);
 	}
 }
