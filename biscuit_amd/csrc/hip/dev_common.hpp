@@ -49,7 +49,6 @@ struct RegParams {
 	uint32_t max_chain_extend;
 	float mask_level, drop_ratio;
 	int32_t prof;          // count wave cycles per stage (tracing only: the counters are contended atomics)
-	int32_t knobs;         // $BSX_RG_KNOBS (A/B runs): bit 0 = the chain filter's sort swap by swap (round-4 form), bit 1 = its overlap loop chain by chain
 	int32_t walk_on;       // the HBM tiers walk an over-represented interval past max_occ themselves (0: such strand searches are left to the caller)
 	int32_t gap_cap;       // cal_max_gap is tabulated up to this query length (set by each kernel to the size of its table)
 	int32_t flt_len;       // flt_tab has entries for read lengths 0..flt_len

@@ -216,125 +216,7 @@ __device__ void rg_introsort_keys(unsigned int *a, int n, int *stk)
 #undef SWP
 }
 
-// The same sort by the whole wavefront, keys in registers (position p in lane p & 63 of v[p >> 6]): EXACTLY klib's sequence of swaps
-// (ksort.h:138-216 -- median-of-three introsort on the runs longer than 16, then one insertion pass over the whole array), because the order
-// of chains of equal weight is part of the result and a strand search against an hg38-sized genome has a hundred chains of weight 19-22.
-// One lane walking the keys in LDS spent a quarter of the larger LDS tier's cycles here (two dependent LDS trips per comparison); in
-// registers a scan "do ++i while (a[i] < pivot)" is a compare, a ballot and a count of trailing zeros, a swap two v_readlane and two
-// v_writelane, and an insertion a population count plus a one-lane shift of the run it passes (DPP).  Up to 64 * NS keys; returns false
-// (nothing sorted: v is scratch) when the depth limit would send klib into its comb sort -- the caller then runs the one-lane form.
-template <int NS>
-__device__ __forceinline__ unsigned int rgw_get(const unsigned int (&v)[NS], int p)
-{
-	unsigned int r = 0;
-#pragma unroll
-	for (int s = 0; s < NS; ++s) if (s == (p >> 6)) r = (unsigned int)__builtin_amdgcn_readlane((int)v[s], p & 63);
-	return r;
-}
-template <int NS>
-__device__ __forceinline__ void rgw_set(unsigned int (&v)[NS], int p, unsigned int x, int lane)
-{
-#pragma unroll
-	for (int s = 0; s < NS; ++s) if (s == (p >> 6) && lane == (p & 63)) v[s] = x;
-}
-template <int NS>
-__device__ __forceinline__ bool rg_introsort_wave(unsigned int (&v)[NS], int n, int *stk, int lane)
-{
-#define WGT(x) ((x) >> RG_KEY_BITS)
-	if (n < 2) return true;
-	if (n == 2) { const unsigned int a0 = rgw_get(v, 0), a1 = rgw_get(v, 1); if (WGT(a1) > WGT(a0)) { rgw_set(v, 0, a1, lane); rgw_set(v, 1, a0, lane); } return true; }
-	int d, s = 0, t = n - 1, top = 0;
-	int *stk_l = stk, *stk_r = stk + 16, *stk_d = stk + 32;
-	for (d = 2; (1 << d) < n; ++d);
-	d <<= 1;
-	for (;;) {
-		if (s < t) {
-			if (--d == 0) return false;
-			int i = s, j = t, k = i + ((j - i) >> 1) + 1;
-			{
-				const unsigned int ak = WGT(rgw_get(v, k)), ai = WGT(rgw_get(v, i)), aj = WGT(rgw_get(v, j));
-				// LT(x, y) = weight(x) > weight(y)
-				if (ak > ai) { if (ak > aj) k = j; }
-				else k = aj > ai ? i : j;
-			}
-			const unsigned int rp = rgw_get(v, k), wp = WGT(rp);
-			if (k != t) { const unsigned int at = rgw_get(v, t); rgw_set(v, k, at, lane); rgw_set(v, t, rp, lane); }
-			for (;;) {
-				{ // do ++i; while (LT(a[i], rp)): the next position whose weight is <= the pivot's (a[t] is the pivot: it stops there at the latest)
-					const int from = i + 1;
-					int found = -1;
-#pragma unroll
-					for (int q = 0; q < NS; ++q) {
-						if (found < 0 && q >= (from >> 6)) {
-							unsigned long long m = __ballot(WGT(v[q]) <= wp);
-							if (q == (from >> 6)) m &= ~0ull << (from & 63);
-							if (m) found = q * 64 + (int)__builtin_ctzll(m);
-						}
-					}
-					i = found;
-				}
-				{ // do --j; while (i <= j && LT(rp, a[j])): the last position in [i, j) whose weight is >= the pivot's, or i - 1
-					const int last = j - 1;
-					int found = i - 1; bool got = false;
-#pragma unroll
-					for (int q = NS - 1; q >= 0; --q) {
-						if (!got && last >= i && q <= (last >> 6) && q >= (i >> 6)) {
-							unsigned long long m = __ballot(WGT(v[q]) >= wp);
-							if (q == (last >> 6)) m &= (2ull << (last & 63)) - 1;
-							if (q == (i >> 6)) m &= ~0ull << (i & 63);
-							if (m) { found = q * 64 + 63 - (int)__builtin_clzll(m); got = true; }
-						}
-					}
-					j = found;
-				}
-				if (j <= i) break;
-				{ const unsigned int xi = rgw_get(v, i), xj = rgw_get(v, j); rgw_set(v, i, xj, lane); rgw_set(v, j, xi, lane); }
-			}
-			{ const unsigned int xi = rgw_get(v, i), xt = rgw_get(v, t); rgw_set(v, i, xt, lane); rgw_set(v, t, xi, lane); }
-			if (i - s > t - i) {
-				if (i - s > 16) { if (lane == 0) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; } ++top; }
-				s = t - i > 16 ? i + 1 : t;
-			} else {
-				if (t - i > 16) { if (lane == 0) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; } ++top; }
-				t = i - s > 16 ? i - 1 : s;
-			}
-		} else {
-			if (top == 0) break;
-			--top;
-			WAVE_SYNC();
-			s = uni(stk_l[top]); t = uni(stk_r[top]); d = uni(stk_d[top]);
-		}
-	}
-	// the insertion pass: a[i] moves left past every predecessor of smaller weight; the positions before it are in order by then, so it
-	// lands behind the last one whose weight is >= its own, and the run it passes moves up one position
-	for (int i = 1; i < n; ++i) {
-		const unsigned int x = rgw_get(v, i), wx = WGT(x);
-		if (!(wx > WGT(rgw_get(v, i - 1)))) continue;
-		int q = 0;
-#pragma unroll
-		for (int c = 0; c < NS; ++c) {
-			if (c * 64 < i) {
-				unsigned long long m = __ballot(WGT(v[c]) >= wx);
-				if (c == (i >> 6)) m &= (1ull << (i & 63)) - 1;
-				q += __popcll(m);
-			}
-		}
-#pragma unroll
-		for (int c = NS - 1; c >= 0; --c) {
-			if (c >= (q >> 6) && c <= (i >> 6)) {
-				const unsigned int carry = c > 0 ? (unsigned int)__builtin_amdgcn_readlane((int)v[c > 0 ? c - 1 : 0], 63) : 0u;
-				const unsigned int sh = (unsigned int)wave_prev((int)v[c], (int)carry);
-				const int pos = c * 64 + lane;
-				v[c] = (pos > q && pos <= i) ? sh : v[c];
-			}
-		}
-		rgw_set(v, q, x, lane);
-	}
-	return true;
-#undef WGT
-}
-
-// The same sort with every partition made AT ONCE (round 4, second form).  klib's partition loop (ksort.h:212-217) is Hoare's: i stops at the
+// The same sort by the whole wavefront with every partition made AT ONCE (round 4).  klib's partition loop (ksort.h:212-217) is Hoare's: i stops at the
 // positions whose weight is <= the pivot's ("L stops", the pivot at a[t] among them), j at those in (s, t) whose weight is >= it ("R
 // stops"), and round k swaps the k-th L stop from the left with the k-th R stop from the right while the first lies below the second -- the
 // swaps never touch what later rounds scan, so which positions swap, and with whom, follows from the two stop masks of the ORIGINAL segment:
@@ -1130,16 +1012,9 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		WAVE_SYNC();
 		bool sorted = false;
 		constexpr int SORT_MS = Store::CCAP <= 64 ? 1 : Store::CCAP <= 128 ? 2 : 4;
-		if (!Store::NODES && n <= 64 * SORT_MS && !(P.knobs & 1)) { // every partition at once (rg_introsort_par): the second half of srt[] holds the partners' lists
+		if (!Store::NODES && n <= 64 * SORT_MS) { // every partition at once (rg_introsort_par): the second half of srt[] holds the partners' lists
 			rg_introsort_par<SORT_MS>(keys, n, keys + Store::SCAP, keys + Store::SCAP + Store::SCAP / 2, D.H, lane);
 			sorted = true;
-		} else
-		if (n <= 64) { // by the wave, a key per lane (exactly klib's permutation); its depth-limit case and longer lists: one lane over LDS.
-			// (Measured with two and four register slots for up to 256 keys: every slot is a compare, a ballot and a branch more in every scan and
-			// access, and the larger LDS tier got slower -- sort 199 G -> 269 G wave cycles per chunk -- where the one-slot form halves the first tier's.)
-			unsigned int kv[1] = { lane < n ? keys[lane] : 0u };
-			sorted = rg_introsort_wave<1>(kv, n, D.H, lane);
-			if (sorted) { WAVE_SYNC(); if (lane < n) keys[lane] = kv[0]; }
 		}
 		WAVE_SYNC();
 		if (!sorted && lane == 0) rg_introsort_keys(keys, n, D.H);
@@ -1149,19 +1024,13 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		RG_STAGE(4);
 		if (n > 0 && !Store::NODES) {
 			// The overlap filter (mem_chain_flt, memchain.c:430-470) with the KEPT chains' numbers in registers: kept chain k lives in lane
-			// k & 63 of register set k >> 6, in the order it was kept (= sorted order), so "the first kept chain that drops chain i" is
-			// the lowest lane that says so, and a chain is tested against as many register sets as the kept list fills -- one, for all
-			// but the reads inside repeats (a kilobase read has 800 chains and keeps a few dozen).  Chain i's own numbers come from LDS.
+			// k & 63 of register set k >> 6, in the order it was kept
 			constexpr int NH = (Store::CCAP + 63) / 64;
-			int kb[NH], ke[NH], kw[NH], ka[NH], kpos[NH], kst[NH], kfi[NH];
+			int kb[NH], kw[NH], kpos[NH], kst[NH], kfi[NH];
 #pragma unroll
-			for (int h = 0; h < NH; ++h) { kb[h] = ke[h] = kw[h] = ka[h] = 0; kpos[h] = -1; kst[h] = 0; kfi[h] = -1; }
+			for (int h = 0; h < NH; ++h) { kb[h] = kw[h] = 0; kpos[h] = -1; kst[h] = 0; kfi[h] = -1; }
 			int n_kept = 1;
 			{
-				const RgChain c0 = rg_chain(S, (int)uni(S.ord[0]));
-				if (lane == 0) { kb[0] = c0.first_q; ke[0] = c0.last_q + c0.last_len; kw[0] = c0.w; ka[0] = c0.is_alt; kpos[0] = 0; kst[0] = 3; }
-			}
-			if (!(P.knobs & 2)) {
 				// A LANE PER CANDIDATE, 64 chains of the sorted order at a time, the kept list walked entry by entry (round 4): what chain i does to
 				// a kept chain k, and k to i, depends on the two alone, and i meets the kept chains in the order they were kept.  So every lane
 				// first tests its chain against the list as it stands (a drop ends the lane); then the lowest lane left is the next kept chain,
@@ -1265,36 +1134,6 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				}
 #pragma unroll
 				for (int h = 0; h < NH; ++h) { kpos[h] = km[h] & 0xfff; kst[h] = (km[h] >> 12) & 3; kfi[h] = (km[h] >> 16) - 1; }
-			} else
-			for (int i = 1; i < n; ++i) {
-				const RgChain ci = rg_chain(S, (int)uni(S.ord[i]));
-				const int ib = uni((int)ci.first_q), ie = uni((int)ci.last_q + (int)ci.last_len), iw = uni((int)ci.w), ia = uni((int)ci.is_alt);
-				int r[NH];
-				int stop = 0x7fffffff;
-#pragma unroll
-				for (int h = 0; h < NH; ++h) {
-					r[h] = 0;
-					if (h * 64 < n_kept) {
-						r[h] = (lane + 64 * h < n_kept) ? rg_flt_vals(P, ib, ie, iw, ia, kb[h], ke[h], kw[h], ka[h]) : 0;
-						const unsigned long long d = __ballot(r[h] & 2);
-						if (d && stop == 0x7fffffff) stop = 64 * h + __ffsll((long long)d) - 1;
-					}
-				}
-				int large = 0;
-#pragma unroll
-				for (int h = 0; h < NH; ++h) {
-					if (h * 64 < n_kept) {
-						const int hit = (r[h] & 1) && lane + 64 * h <= stop;
-						if (hit && kfi[h] < 0) kfi[h] = i;
-						if (__ballot(hit)) large = 1;
-					}
-				}
-				if (stop == 0x7fffffff) { // kept: the next entry of the list
-					const int sl = n_kept & 63, hi = n_kept >> 6;
-#pragma unroll
-					for (int h = 0; h < NH; ++h) if (h == hi && lane == sl) { kb[h] = ib; ke[h] = ie; kw[h] = iw; ka[h] = ia; kpos[h] = i; kst[h] = large ? 2 : 3; kfi[h] = -1; }
-					++n_kept;
-				}
 			}
 			// kept flags by sorted position (PCAP: lst is free here), then the first chain each kept one shadows (chn->first, memchain.c:455-460)
 			for (int j = lane; j < n; j += 64) { if (Store::PCAP) S.lst[j] = 0; else S.ch[S.ord[j]].kept = 0; }
@@ -1312,7 +1151,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 			// no chain light enough for the heaviest one to drop it (memchain.c:449): then none is dropped by anybody, every chain is kept, and
 			// the pair tests would only tell kept chains apart (2 for 3, `first`), which nothing reads unless max_chain_extend is in force
 			bool all_kept = false;
-			if (!(P.knobs & 2) && P.max_chain_extend >= (unsigned int)n) {
+			if (P.max_chain_extend >= (unsigned int)n) {
 				const int w0 = (int)(uni((int)keys[0]) >> RG_KEY_BITS), wl = (int)(uni((int)keys[n - 1]) >> RG_KEY_BITS);
 				all_kept = !((float)wl < (float)w0 * P.drop_ratio && w0 - wl >= P.min_seed_len << 1);
 				if (all_kept) { for (int j = lane; j < n; j += 64) S.ch[S.ord[j]].kept = 3; WAVE_SYNC(); }

@@ -601,7 +601,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.a = opt->a; R.w = opt->w; R.o_del = opt->o_del; R.e_del = opt->e_del; R.o_ins = opt->o_ins; R.e_ins = opt->e_ins;
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
-	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0; R.knobs = getenv("BSX_RG_KNOBS") ? atoi(getenv("BSX_RG_KNOBS")) : 0;
+	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
 	R.gap_cap = 0;
 	{ static const int walk = getenv("BSX_WALK_PAST_MAX_OCC") ? atoi(getenv("BSX_WALK_PAST_MAX_OCC")) : 1; R.walk_on = walk; }
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated

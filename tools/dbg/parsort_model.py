@@ -10,7 +10,31 @@ def lt(a, b):          # flt_lt: heavier first
     return a[0] > b[0]
 
 
-def klib_introsort(a):
+def klib_combsort(a, s, t):
+    """ks_combsort (ksort.h:162-183) over a[s..t]"""
+    m = t - s + 1
+    gap = m
+    while True:
+        if gap > 2:
+            gap = int(gap / 1.2473309501039786540366528676643)
+            if gap == 9 or gap == 10:
+                gap = 11
+        swapped = False
+        for i in range(0, m - gap):
+            if lt(a[s + i + gap], a[s + i]):
+                a[s + i], a[s + i + gap] = a[s + i + gap], a[s + i]
+                swapped = True
+        if not (swapped or gap > 2):
+            break
+    if gap != 1:
+        for i in range(s + 1, t + 1):
+            j = i
+            while j > s and lt(a[j], a[j - 1]):
+                a[j], a[j - 1] = a[j - 1], a[j]
+                j -= 1
+
+
+def klib_introsort(a, comb=False):
     n = len(a)
     if n < 1:
         return True
@@ -28,7 +52,11 @@ def klib_introsort(a):
         if s < t:
             d -= 1
             if d == 0:
-                return False      # comb sort: not modelled (the device falls back to the one-lane form)
+                if not comb:
+                    return False      # (the depth limit: klib goes into its comb sort)
+                klib_combsort(a, s, t)
+                t = s
+                continue
             i, j = s, t
             k = i + ((j - i) >> 1) + 1
             if lt(a[k], a[i]):
@@ -98,7 +126,7 @@ def par_partition(a, s, t):
     return i
 
 
-def par_introsort(a):
+def par_introsort(a, comb=False):
     n = len(a)
     if n < 2:
         return True
@@ -116,7 +144,11 @@ def par_introsort(a):
         if s < t:
             d -= 1
             if d == 0:
-                return False
+                if not comb:
+                    return False
+                klib_combsort(a, s, t)    # (one lane, on the array as the partitions so far left it)
+                t = s
+                continue
             i, j = s, t
             k = i + ((j - i) >> 1) + 1
             if lt(a[k], a[i]):
