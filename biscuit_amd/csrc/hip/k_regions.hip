@@ -1781,9 +1781,10 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 {
 	__shared__ RgSmall lds[RG_WPB];
 	__shared__ DPT dp[RG_WPB];
+	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	const int *gap_tab = nullptr;   // (cal_max_gap is read by the chain-to-region loop, which this tier leaves to k_c2r: its kilobyte was two workgroups per CU)
-	P.gap_cap = 0;
+	P.gap_cap = DPT::QCAP;
+	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
@@ -1876,9 +1877,11 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 {
 	__shared__ Store lds[WPB];
 	__shared__ DPT dp[WPB];
+	constexpr int GAPCAP = DPT::QCAP > RG_QCAP ? RG_QCAP : DPT::QCAP;   // (LDS bounds this launch: longer lengths are computed)
+	__shared__ int gap_tab[GAPCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	const int *gap_tab = nullptr;   // (as in k_regions: this tier stops before the loop that reads cal_max_gap)
-	P.gap_cap = 0;
+	P.gap_cap = GAPCAP;
+	for (int q = threadIdx.x; q <= GAPCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
