@@ -267,13 +267,45 @@ def main():
     ctr = dev.counters()
     ktimes = [dev.kernel_time(k) for k in range(8)]
     alone = None
+    region_launch_ms = None
     ref_blocks_per_read, ref_seed_ms = None, None
     tab_touch = [ctr[0] + ctr[1], dev.seed_table()[0], dev.seed_table()[1]]   # FM blocks and table entries the seeding kernel read in the timed region
     if not args.no_pipeline:
         for k in range(8):
             dev.kernel_time(k, reset=True)
         extra = gen(777, pairs_per_step)
-        B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(standalone)")
+        # the region launches of this chunk one by one ($BSX_TIERS: HIP events between them, printed by the library): the last HBM tier is a
+        # handful of strand searches -- reads inside tandem repeats, a wavefront each -- and lasts as long as the longest of them, so
+        # "regions_tiers23" of one chunk says little about the tiers that carry the load without the split
+        import tempfile
+        tier_txt = ""
+        os.environ["BSX_TIERS"] = "1"
+        sys.stderr.flush()
+        saved_fd, tf = os.dup(2), tempfile.TemporaryFile()
+        os.dup2(tf.fileno(), 2)
+        try:
+            B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(standalone)")
+        finally:
+            os.dup2(saved_fd, 2)
+            os.close(saved_fd)
+            os.environ.pop("BSX_TIERS", None)
+            tf.seek(0)
+            tier_txt = tf.read().decode(errors="replace")
+            tf.close()
+            sys.stderr.write(tier_txt)
+        region_launch_ms = None
+        for line in tier_txt.splitlines():
+            if "region launches (ms):" in line:
+                try:
+                    region_launch_ms = {}
+                    for part in line.split("region launches (ms):", 1)[1].split("|"):
+                        part = part.strip()
+                        if part:
+                            name, ms = part.rsplit(" ", 1)
+                            region_launch_ms[name.strip()] = float(ms)
+                except ValueError:
+                    region_launch_ms = None
+                break
         alone = [dev.kernel_time(k) for k in range(8)]
         # SURVEY 8(d)'s algorithmic bytes are the REFERENCE algorithm's FM-block touches (bwt_occ4 / bwt_2occ4 calls of bwt_smem1a and
         # bwt_seed_strategy1: deterministic integers for a given input).  The seeding kernel of the timed region does not make them all (it
@@ -401,6 +433,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(8)},
             "kernel_ms_per_step_standalone": ({names[k]: round(alone[k][0], 3) for k in range(8)} if alone else None),
+            "region_launch_ms_standalone": region_launch_ms if alone else None,   # tier 1 | tier 1b | extensions ahead | chains -> regions | tier 2 | tier 3 of the same chunk
             "strand_searches_per_step": phase_tot.get("n_tasks", 0) // max(1, phase_tot.get("_chunks", 1)), "strand_searches_chained_on_host_per_step": phase_tot.get("n_host_tasks", 0) // max(1, phase_tot.get("_chunks", 1)),
             "host_phase_s_per_chunk": {k: round(v / max(1, phase_tot.get("_chunks", 1)), 4) for k, v in phase_tot.items() if k.startswith("t_")},
             "push_loop_s_per_step": {"ring_wait": round(loop_s[0] / args.steps, 4), "in_stream_push": round(loop_s[1] / args.steps, 4)}, "sam_consumer_s_per_step": round(retire_s[0] / args.steps, 4),
@@ -432,7 +465,7 @@ def main():
                 pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
                 sub = json.loads(pr.stdout.decode().strip().split("\n")[-1])
                 out["hg38_like_genome"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "roofline", "roofline_whole_path", "cpu_baseline", "kernel_ms_per_step",
-                                                                  "kernel_ms_per_step_standalone", "strand_searches_chained_on_host_per_step", "host_phase_s_per_chunk", "host_cpu_s_per_step")}
+                                                                  "kernel_ms_per_step_standalone", "region_launch_ms_standalone", "strand_searches_chained_on_host_per_step", "host_phase_s_per_chunk", "host_cpu_s_per_step")}
                 out["hg38_like_genome"]["workload"] = sub["config"]["workload"]
             except Exception as e:      # the headline line must not depend on it
                 out["hg38_like_genome"] = {"error": repr(e)[:300]}
@@ -444,7 +477,7 @@ def main():
                 try:
                     pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
                     sub = json.loads(pr.stdout.decode().strip().split("\n")[-1])
-                    out["long_reads"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms_per_step", "kernel_ms_per_step_standalone",
+                    out["long_reads"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms_per_step", "kernel_ms_per_step_standalone", "region_launch_ms_standalone",
                                                                  "strand_searches_chained_on_host_per_step", "host_cpu_s_per_step")}
                     out["long_reads"]["workload"] = sub["config"]["workload"]
                 except Exception as e:
