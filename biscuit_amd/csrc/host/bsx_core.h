@@ -146,6 +146,7 @@ BSX_API int  bsx_bt_traverse(const bsx_btree_t *t, int32_t *ids);
 /* ---------- thread pool (kt_for equivalent; results never depend on scheduling) ---------- */
 typedef void (*bsx_for_fn)(void *data, long i, int tid);
 BSX_API void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n);
+void *bsx_par_calloc(int n_threads, size_t n, size_t size);   /* calloc whose zeroing is shared by the worker pool (per-chunk tables of 50-70 MB: a serial memset was 20 ms of every back half) */
 /* worker threads for host stages: $BSX_HOST_THREADS if set, else opt->n_threads (-@ also fixes the chunk size) */
 BSX_API int bsx_host_threads(const bsx_opt_t *opt);
 

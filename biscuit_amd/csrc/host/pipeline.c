@@ -468,7 +468,7 @@ static int merge_regions(chunk_t *C)
 	merge_par_t P;
 	merge_aux_t A;
 	P.C = C;
-	P.ud = (merge_ud_t*)calloc(n ? n : 1, sizeof(merge_ud_t));
+	P.ud = (merge_ud_t*)bsx_par_calloc(C->nt, (size_t)n, sizeof(merge_ud_t));
 	P.pending = (int*)malloc(sizeof(int) * (n ? n : 1));
 	A.P = &P; A.cnt = (int*)malloc(sizeof(int) * ((size_t)n + 1)); A.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n + 1));
 	bsx_parallel_for(C->nt, merge_init_worker, &P, n);
@@ -656,7 +656,7 @@ static int mate_rescue(chunk_t *C)
 {
 	int np = C->n >> 1, rc = BSX_OK, round;
 	double t_batch = 0, t_all = now_s();
-	msw_pair_t *M = (msw_pair_t*)calloc(np ? np : 1, sizeof(msw_pair_t));
+	msw_pair_t *M = (msw_pair_t*)bsx_par_calloc(C->nt, (size_t)np, sizeof(msw_pair_t));
 	msw_par_t P;
 	g_msw_prof = getenv("BSX_PHASES") != 0;
 	P.C = C; P.M = M;
@@ -790,7 +790,7 @@ static void finish_worker(void *data, long k, int tid)
 	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]], F->tags ? &F->tags[k] : 0, F->tags ? F->md + F->tags[k].md_off : 0);
 }
 
-typedef struct { chunk_t *C; samctx_t *ctx; int per; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg; } plan_par_t;
+typedef struct { chunk_t *C; samctx_t *ctx; int per; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg, *todo; } plan_par_t;
 static void plan_count_worker(void *data, long u, int tid)
 {
 	plan_par_t *Q = (plan_par_t*)data;
@@ -814,7 +814,9 @@ static void plan_jobs_worker(void *data, long u, int tid)
 			int gi = Q->ctx[u].want[w].a[k];
 			bsx_setsam_job(C->opt, C->idx, &C->reads[ri], C->roff[ri], &regs->a[gi], &Q->jobs[at]);
 			Q->jobs[at].cigar_cap = 8;   /* most CIGARs are 1-3 operations; one that does not fit is redone with the room it asks for */
+			Q->jobs[at].cigar_off = (uint32_t)(at * 8);   /* (the first round's pool layout: every job's eight words one behind the other) */
 			Q->jread[at] = ri; Q->jreg[at] = gi;
+			if (Q->todo) Q->todo[at] = (int)at;
 		}
 	}
 }
@@ -833,7 +835,7 @@ static void plan_free_worker(void *data, long u, int tid)
 static int emit_sam(chunk_t *C)
 {
 	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, rc = BSX_OK, round;
-	samctx_t *ctx = (samctx_t*)calloc(n_units ? n_units : 1, sizeof(samctx_t));
+	samctx_t *ctx = (samctx_t*)bsx_par_calloc(C->nt, (size_t)n_units, sizeof(samctx_t));
 	out_par_t P;
 	plan_par_t Q;
 	BSX_VEC(int) todo;
@@ -853,9 +855,9 @@ static int emit_sam(chunk_t *C)
 	n_jobs = prefix_counts(n_units, Q.cnt, Q.off);
 	Q.jobs = (bsx_glb_job_t*)malloc(sizeof(bsx_glb_job_t) * (size_t)(n_jobs ? n_jobs : 1));
 	Q.jread = (int*)malloc(sizeof(int) * (size_t)(n_jobs ? n_jobs : 1)); Q.jreg = (int*)malloc(sizeof(int) * (size_t)(n_jobs ? n_jobs : 1));
-	bsx_parallel_for(C->nt, plan_jobs_worker, &Q, n_units);
 	bsx_vec_reserve(todo, (size_t)n_jobs + 1);
-	for (k = 0; k < (size_t)n_jobs; ++k) todo.a[k] = (int)k;
+	Q.todo = todo.a;   /* filled by the workers, each job its own index: the first round is every job */
+	bsx_parallel_for(C->nt, plan_jobs_worker, &Q, n_units);
 	todo.n = (size_t)n_jobs;
 	for (round = 0; round < 8 && todo.n && rc == BSX_OK; ++round) { /* a CIGAR that does not fit is redone with the room it asked for */
 		/* the first round is every job, in place (a million 48-byte records are not copied); a later one the few whose CIGAR did not fit */
@@ -863,7 +865,7 @@ static int emit_sam(chunk_t *C)
 		bsx_glb_res_t *sres = (bsx_glb_res_t*)malloc(sizeof(*sres) * todo.n);
 		bsx_glb_tag_t *tags = C->be->global_batch_tags ? (bsx_glb_tag_t*)malloc(sizeof(*tags) * todo.n) : 0;
 		size_t off = 0, nt = 0;
-		if (round == 0) for (k = 0; k < todo.n; ++k) { sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
+		if (round == 0) off = todo.n * 8;   /* (cigar_off set with the jobs) */
 		else for (k = 0; k < todo.n; ++k) { sub[k] = Q.jobs[todo.a[k]]; sub[k].cigar_off = (uint32_t)off; off += sub[k].cigar_cap; }
 		if (off > pool_len) { pool_len = off; pool = (uint32_t*)realloc(pool, pool_len * 4 + 4); }
 		{

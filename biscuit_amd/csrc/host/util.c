@@ -455,6 +455,26 @@ void bsx_parallel_for(int n_threads, bsx_for_fn fn, void *data, long n)
 	pthread_mutex_unlock(&g_pool.mu);
 }
 
+typedef struct { char *p; size_t bytes; } zero_par_t;
+#define ZERO_BLOCK ((size_t)4 << 20)
+static void zero_worker(void *data, long b, int tid)
+{
+	zero_par_t *Z = (zero_par_t*)data;
+	size_t at = (size_t)b * ZERO_BLOCK, len = Z->bytes - at < ZERO_BLOCK ? Z->bytes - at : ZERO_BLOCK;
+	(void)tid;
+	memset(Z->p + at, 0, len);
+}
+void *bsx_par_calloc(int n_threads, size_t n, size_t size)
+{
+	zero_par_t Z;
+	Z.bytes = (n ? n : 1) * size;
+	Z.p = (char*)malloc(Z.bytes);
+	if (!Z.p) return 0;
+	if (Z.bytes < 4 * ZERO_BLOCK || n_threads < 2) memset(Z.p, 0, Z.bytes);
+	else bsx_parallel_for(n_threads, zero_worker, &Z, (long)((Z.bytes + ZERO_BLOCK - 1) / ZERO_BLOCK));
+	return Z.p;
+}
+
 /* The host stages allocate millions of small records per chunk from many threads.  With glibc's
  * defaults every arena grows and shrinks in small steps, and each step is an mprotect/munmap that
  * takes the process-wide mmap lock against all page faults of the other workers.  Growing in large
