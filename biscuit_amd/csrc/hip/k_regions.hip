@@ -82,15 +82,25 @@ typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;
 // slab, exporting: for the repeat reads that outgrow the LDS tiers but have no tied chain starts
 typedef RgStore<4096, 8192, 8192, 8192, 8192, unsigned short, short> RgHuge;   // reads inside tandem repeats: thousands of short seeds
 #define RG_WIN 768       // reference window of a chain kept in LDS while its seeds are extended (longer windows: extension reads HBM)
+// $BSX_PHASES: where a strand search's wave cycles go.  The sums live in the wave's LDS and every lane writes them alike (uniform values): no
+// divergent region inside the stages.  Round 5: `if (P.prof) { ...; if (lane == 0) atomicAdd(&counters[..], ..); }` ahead of the (not inlined)
+// call of rg_export made the compiler place a copy of the lane index for the call AHEAD of the s_or_b64 that restores EXEC at the end of the
+// lane-0 region -- 63 lanes entered rg_export with a stale lane index and exported garbage (tools/dbg/exec_join_check.py looks for that shape
+// in the assembly; tests/test_isa_exec_join.py).  Flushed to counters[32 + k] once, when the wave leaves the kernel.
+#define RG_NPF 16            // 0-7 stage cycles, 8 extensions, 9 extension rows
+#define RG_PF_ZERO(D) do { if (P.prof) { (D).pf[lane & (RG_NPF - 1)] = 0; WAVE_SYNC(); } } while (0)
+#define RG_PF_ADD(D, k, v) do { const unsigned long long s_ = (D).pf[k] + (unsigned long long)(v); (D).pf[k] = s_; } while (0)
+#define RG_PF_FLUSH(D) do { if (P.prof) { WAVE_SYNC(); if (lane < RG_NPF) { const unsigned long long v_ = (D).pf[lane]; if (v_) atomicAdd(&counters[32 + lane], v_); } } } while (0)
 struct RgDp {            // per-wave LDS scratch
 	static const int QCAP = RG_QCAP;
+	unsigned long long pf[RG_NPF];
 	int32_t H[64], E[64];        // the one-lane passes (introsort stack, tree traversal stack)
 	uint8_t q[RG_QCAP];          // the read
 	uint8_t win[RG_WIN];         // reference bases [rmax0, rmax1) of the chain being extended, one byte each
 };
-struct RgDpLite { static const int QCAP = RG_QCAP; int32_t H[64], E[64]; uint8_t q[RG_QCAP]; uint8_t win[4]; };   // the LDS tiers stop before the extensions: no window
+struct RgDpLite { static const int QCAP = RG_QCAP; unsigned long long pf[RG_NPF]; int32_t H[64], E[64]; uint8_t q[RG_QCAP]; uint8_t win[4]; };   // the LDS tiers stop before the extensions: no window
 #define RG_QCAP_LONG 1024   // the launches for chunks with longer reads (a read of a kilobase; anything longer is chained by the caller)
-struct RgDpLiteL { static const int QCAP = RG_QCAP_LONG; int32_t H[64], E[64]; uint8_t q[RG_QCAP_LONG]; uint8_t win[4]; };
+struct RgDpLiteL { static const int QCAP = RG_QCAP_LONG; unsigned long long pf[RG_NPF]; int32_t H[64], E[64]; uint8_t q[RG_QCAP_LONG]; uint8_t win[4]; };
 
 // wave-uniform values live in scalar registers: say so for what comes out of LDS, shuffles and reductions
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -546,7 +556,7 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 	RgXHdr *H = (RgXHdr*)(X.base + at);
 	RgXChain *XC = (RgXChain*)(H + 1);
 	RgXSeed *XS = (RgXSeed*)(XC + n_surv);
-	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->flt = flt; H->has_ext = ext; H->pad = 0; }
+	if (lane == 0) { H->n_chains = n_surv; H->n_seeds = n_sd; H->frac_rep = frac_rep; H->flt = flt; H->has_ext = ext; H->pad = Store::SCAP; }   // (pad: which tier's tables made the record, for the debug checks)
 	int so = 0;
 	for (int ci = 0; ci < n_surv; ++ci) {
 		const int c = uni(S.ord[ci]);
@@ -588,10 +598,10 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	typedef typename Store::idx_t idx_t;
 	const long long l_pac = ix.l_pac;
 	const uint8_t *query = reads + qoff;
-	// per-stage wave cycles into counters[32 + stage] (P.prof, set under $BSX_PHASES): where a strand search's time goes
+	// per-stage wave cycles (P.prof, set under $BSX_PHASES) into the wave's sums D.pf, see RG_PF_ADD
 	long long pf_t = P.prof ? (long long)__builtin_readcyclecounter() : 0;
 	unsigned int pf_ext = 0, pf_rows = 0;
-#define RG_STAGE(k) do { if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + (k)], (unsigned long long)(now_ - pf_t)); pf_t = now_; } } while (0)
+#define RG_STAGE(k) do { if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); RG_PF_ADD(D, k, now_ - pf_t); pf_t = now_; } } while (0)
 	if (lane == 0) {
 		S.n_chains = 0; S.n_regs = 0;
 		if (Store::NODES) { S.n_nodes = 0; S.root = rg_bt_alloc(S, 0); }
@@ -1389,7 +1399,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 	}
 	RG_STAGE(6);
-	if (P.prof && lane == 0) { atomicAdd(&counters[40], (unsigned long long)pf_ext); atomicAdd(&counters[41], (unsigned long long)pf_rows); }
+	if (P.prof) { RG_PF_ADD(D, 8, pf_ext); RG_PF_ADD(D, 9, pf_rows); }
 	return 0;
 }
 
@@ -1425,6 +1435,7 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 template <int QC, int WC, int XSD>
 struct RgC2rT {
 	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
+	unsigned long long pf[RG_NPF];
 	bsx_region_t regs[RG_XREGS];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
 	RgXExt xe[RG_XCBLK];     // and, when the record has them, the extensions made ahead of this launch (k_ext4.hip)
@@ -1586,7 +1597,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						const int prev = R.score;
 						aw = P.w << i;
 						J.w = aw;
-						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + 6], (unsigned long long)(now_ - pf_t)); pf_t = now_; }
+						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); RG_PF_ADD(W, 6, now_ - pf_t); pf_t = now_; }
 						// rows in registers, 64 entries per lane slot: as few slots as the query needs (a row's cost grows with them)
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
@@ -1596,7 +1607,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
 						R.score = res.score;
-						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) atomicAdd(&counters[32 + 7], (unsigned long long)(now_ - pf_t)); pf_t = now_; }
+						if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); RG_PF_ADD(W, 7, now_ - pf_t); pf_t = now_; }
 						++pf_ext; pf_rows += (unsigned int)(res.tle > res.gtle ? res.tle : res.gtle);
 						if (R.score == prev || res.max_off < (aw >> 1) + (aw >> 2)) break;
 					}
@@ -1627,7 +1638,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 			}
 		}
 	}
-	if (P.prof && lane == 0) { atomicAdd(&counters[32 + 6], (unsigned long long)((long long)__builtin_readcyclecounter() - pf_t)); atomicAdd(&counters[40], (unsigned long long)pf_ext); atomicAdd(&counters[41], (unsigned long long)pf_rows); }
+	if (P.prof) { RG_PF_ADD(W, 6, (long long)__builtin_readcyclecounter() - pf_t); RG_PF_ADD(W, 8, pf_ext); RG_PF_ADD(W, 9, pf_rows); }
 	return 0;
 }
 
@@ -1737,6 +1748,7 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 	__syncthreads();
 	const int lane = wave_lane();
 	WT &W = lds[threadIdx.x >> 6];
+	RG_PF_ZERO(W);
 	const int n = (int)*X.xcount;
 	// a wave takes `quota` strand searches and leaves (the launch covers the worst case): workgroups with a bounded life let the
 	// back half's short high-priority batches (k_sw, k_global) of an older chunk get compute units while this one runs
@@ -1765,8 +1777,29 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 		}
 		WAVE_SYNC();
 	}
+	RG_PF_FLUSH(W);
 }
 
+// Debug builds of the LDS tiers (tools/dbg/lds_variants.sh; never the product's): RG_DBG 1 = guard words around every LDS object of the
+// workgroup, checked when it ends (tests/test_gpu_lds_guards.py); 2 = the wave's tables filled with 0xff before every strand search (an
+// answer that changes with the fill reads LDS it did not write)
+#ifndef RG_DBG
+#define RG_DBG 0
+#endif
+#if RG_DBG == 2
+#define RG_DBG_FILL(S, D) do { WAVE_SYNC(); for (int i_ = lane; i_ < (int)(sizeof(S) / 4); i_ += 64) ((int*)&(S))[i_] = -1; \
+		for (int i_ = (int)(sizeof((D).pf) / 4) + lane; i_ < (int)(sizeof(D) / 4); i_ += 64) ((int*)&(D))[i_] = -1; WAVE_SYNC(); } while (0)
+#else
+#define RG_DBG_FILL(S, D) do { } while (0)
+#endif
+#if RG_DBG == 1
+#define RG_GUARD_WORD(q) ((int)0xC0DE0000 + (q))
+#define RG_DBG_GUARDS(name) do { __syncthreads(); for (int q_ = threadIdx.x; q_ < 64; q_ += blockDim.x) { const int w_ = RG_GUARD_WORD(q_); \
+		if (DL.c0[q_] != w_ || DL.c1[q_] != w_ || DL.c2[q_] != w_ || DL.c3[q_] != w_) \
+			printf("LDS GUARD %s block %d word %d: %08x %08x %08x %08x\n", name, (int)blockIdx.x, q_, DL.c0[q_], DL.c1[q_], DL.c2[q_], DL.c3[q_]); } } while (0)
+#else
+#define RG_DBG_GUARDS(name) do { } while (0)
+#endif
 // first tier: tables in LDS.  Tasks declined for table size (or for tied chain starts) go on retry_list for the second tier.
 #ifndef RG_WPB
 #define RG_WPB 1     // waves per workgroup of the LDS tiers, as C2R_WPB
@@ -1779,12 +1812,18 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
           unsigned int *task_cursor, int *retry_list, unsigned int *retry_count, int quota, unsigned long long *counters,
           const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, RgXPool X)
 {
+#if RG_DBG == 1
+	struct DbgLds { int c0[64]; RgSmall lds[RG_WPB]; int c1[64]; DPT dp[RG_WPB]; int c2[64]; long long ctg_lds[RG_CTG_LDS + 1]; int c3[64]; };
+	__shared__ DbgLds DL;
+	RgSmall *lds = DL.lds; DPT *dp = DL.dp; long long *ctg_lds = DL.ctg_lds;
+	for (int q = threadIdx.x; q < 64; q += blockDim.x) { DL.c0[q] = DL.c1[q] = DL.c2[q] = DL.c3[q] = RG_GUARD_WORD(q); }
+#else
 	__shared__ RgSmall lds[RG_WPB];
 	__shared__ DPT dp[RG_WPB];
-	__shared__ int gap_tab[DPT::QCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	P.gap_cap = DPT::QCAP;
-	for (int q = threadIdx.x; q <= DPT::QCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+#endif
+	const int *gap_tab = nullptr;   // (cal_max_gap is read by the chain-to-region loop, which this tier leaves to k_c2r: its table was a kilobyte of LDS per workgroup)
+	P.gap_cap = -1;
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
@@ -1805,11 +1844,14 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
+		RG_DBG_FILL(S, D);
 		int status = rg_task<RgSmall, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;   // exported: k_c2r makes and publishes its regions
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;   // (10: the HBM tiers walk an over-represented interval further)
 	}
+	RG_PF_FLUSH(D);
+	RG_DBG_GUARDS("k_regions");
 }
 
 // second and third tier: the same code over per-wave tables in HBM, for the strand searches of repeat-rich reads.
@@ -1875,13 +1917,18 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
               const int *list, const unsigned int *count, unsigned int *cursor, int *next_list, unsigned int *next_count,
               unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, RgXPool X, int quota)
 {
+#if RG_DBG == 1
+	struct DbgLds { int c0[64]; Store lds[WPB]; int c1[64]; DPT dp[WPB]; int c2[64]; long long ctg_lds[RG_CTG_LDS + 1]; int c3[64]; };
+	__shared__ DbgLds DL;
+	Store *lds = DL.lds; DPT *dp = DL.dp; long long *ctg_lds = DL.ctg_lds;
+	for (int q = threadIdx.x; q < 64; q += blockDim.x) { DL.c0[q] = DL.c1[q] = DL.c2[q] = DL.c3[q] = RG_GUARD_WORD(q); }
+#else
 	__shared__ Store lds[WPB];
 	__shared__ DPT dp[WPB];
-	constexpr int GAPCAP = DPT::QCAP > RG_QCAP ? RG_QCAP : DPT::QCAP;   // (LDS bounds this launch: longer lengths are computed)
-	__shared__ int gap_tab[GAPCAP + 1];
 	__shared__ long long ctg_lds[RG_CTG_LDS + 1];
-	P.gap_cap = GAPCAP;
-	for (int q = threadIdx.x; q <= GAPCAP; q += blockDim.x) gap_tab[q] = rg_cal_max_gap(P, q);
+#endif
+	const int *gap_tab = nullptr;   // (as in k_regions: this tier stops before the loop that reads cal_max_gap)
+	P.gap_cap = -1;
 	if (ix.n_seqs <= RG_CTG_LDS) for (int q = threadIdx.x; q <= ix.n_seqs; q += blockDim.x) ctg_lds[q] = ix.ctg_off[q];
 	const long long *ctg_tab = ix.n_seqs <= RG_CTG_LDS ? (const long long*)ctg_lds : (const long long*)ix.ctg_off;
 	__syncthreads();
@@ -1898,11 +1945,14 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
+		RG_DBG_FILL(S, D);
 		int status = rg_task<Store, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
+	RG_PF_FLUSH(D);
+	RG_DBG_GUARDS("k_regions_mid");
 }
 
 // ---- K3 for the whole chunk ahead of the region kernels: the LF walks are pure pointer chasing, and run an order of

@@ -33,5 +33,5 @@ __device__ __forceinline__ int rg_cal_max_gap(const RegParams &P, int qlen)   //
 	return l < P.w << 1 ? l : P.w << 1;
 }
 // cal_max_gap for every length a read of this kernel can ask about, tabulated once per workgroup (two double divisions each)
-__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (unsigned)qlen <= (unsigned)P.gap_cap ? tab[qlen] : rg_cal_max_gap(P, qlen); }
+__device__ __forceinline__ int rg_gap(const int *tab, const RegParams &P, int qlen) { return (qlen >= 0 && qlen <= P.gap_cap) ? tab[qlen] : rg_cal_max_gap(P, qlen); }   // (gap_cap < 0: the kernel keeps no table)
 #endif

@@ -602,7 +602,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
-	R.gap_cap = 0;
+	R.gap_cap = -1;
 	{ static const int walk = getenv("BSX_WALK_PAST_MAX_OCC") ? atoi(getenv("BSX_WALK_PAST_MAX_OCC")) : 1; R.walk_on = walk; }
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
 	// here because the rule goes through log() and the float / double conversions of the reference's expression.
@@ -778,6 +778,49 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			TIER_MARK("tier 3 (exports)");
 			if (any_flt) launch_seedsw(st, (int)std::min<int64_t>((nT + 3) / 4, (int64_t)d->n_cu * 32), d->ix, L.sc, R, d_reads, T, XP, k32 + 5, ctr);
 			TIER_MARK("seed filter");
+#ifdef BSX_DEBUG_XCHECK
+			if (main_seq) { // debug builds (tools/dbg/lds_variants.sh): every exported record looked at before k_c2r reads it
+				unsigned long long used = 0; unsigned int xn = 0;
+				HIPCHK(hipStreamSynchronize(st));
+				D2H(st, &used, XP.cursor, 8); D2H(st, &xn, XP.xcount, 4);
+				HIPCHK(hipStreamSynchronize(st));
+				fprintf(stderr, "[xcheck] %u records, %llu bytes of %llu\n", xn, used, XP.cap);
+				if (used > XP.cap) used = XP.cap;
+				std::vector<unsigned char> a((size_t)used);
+				std::vector<long long> xo((size_t)nT); std::vector<int> xl((size_t)xn);
+				D2H(st, a.data(), XP.base, (size_t)used); D2H(st, xo.data(), XP.xoff, (size_t)nT * 8); D2H(st, xl.data(), XP.xlist, (size_t)xn * 4);
+				HIPCHK(hipStreamSynchronize(st));
+				std::vector<std::pair<long long, long long>> span;
+				long n_bad = 0;
+				for (unsigned int k = 0; k < xn; ++k) {
+					const int t = xl[k];
+					if (t < 0 || t >= nT) { fprintf(stderr, "[xcheck] list entry %u names task %d\n", k, t); ++n_bad; continue; }
+					const long long o = xo[t];
+					if (o < 0 || (unsigned long long)o + 24 > used) { fprintf(stderr, "[xcheck] task %d offset %lld\n", t, o); ++n_bad; continue; }
+					const int *H = (const int*)(a.data() + o);
+					const int nk = H[0], nsd = H[1], has = H[4], tier = H[5];
+					const long long bytes = 24 + (long long)nk * 24 + (long long)nsd * 16 + (has ? (long long)nk * 48 : 0);
+					span.push_back(std::make_pair(o, o + bytes));
+					bool bad = nk <= 0 || nsd < nk || (unsigned long long)(o + bytes) > used;
+					long long so_expect = 0;
+					for (int c = 0; c < nk && !bad; ++c) {
+						const unsigned char *xc = a.data() + o + 24 + (size_t)c * 24;
+						const long long pos = *(const long long*)xc; const int rid = *(const int*)(xc + 8), so = *(const int*)(xc + 12);
+						const int nm = *(const unsigned short*)(xc + 16), ne = *(const unsigned short*)(xc + 18);
+						if (rid < 0 || rid >= d->ix.n_seqs || pos < 0 || pos >= 2 * d->ix.l_pac || so < so_expect || so + nm + ne > nsd) {
+							fprintf(stderr, "[xcheck] task %d (len %d, tier tables %d) record at %lld: %d chains %d seeds; chain %d: pos %lld rid %d seed_off %d (expected %lld) main %d extra %d\n",
+							        t, T == d_tasks ? tasks[t].len : -1, tier, o, nk, nsd, c, pos, rid, so, so_expect, nm, ne);
+							bad = true;
+						}
+						so_expect = so + nm + ne;   // (k_seedsw shortens a main list in place and moves the backup list up behind it: offsets stay those of the export)
+					}
+					if (bad) { ++n_bad; if (nk <= 0 || nsd < nk) fprintf(stderr, "[xcheck] task %d (tier tables %d) record at %lld: %d chains %d seeds %lld bytes\n", t, tier, o, nk, nsd, bytes); }
+				}
+				std::sort(span.begin(), span.end());
+				for (size_t k = 1; k < span.size(); ++k) if (span[k].first < span[k - 1].second) { fprintf(stderr, "[xcheck] records overlap: [%lld, %lld) and [%lld, %lld)\n", span[k - 1].first, span[k - 1].second, span[k].first, span[k].second); ++n_bad; }
+				fprintf(stderr, "[xcheck] %ld bad\n", n_bad);
+			}
+#endif
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, nullptr, nullptr, ctr, c2r_quota, long_reads);
 			TIER_MARK("chains -> regions");
 			return BSX_OK;

@@ -600,6 +600,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 loop_done:
 		bsx_fq_scan_close(scan);
 	}
+	if (bsx_fq_error(f1) || bsx_fq_error(f2)) { fprintf(stderr, "[E::%s] damaged or truncated compressed input: the SAM is incomplete\n", "main_align"); rc = 1; }
 	if (fflush(stdout) != 0 || ferror(stdout)) g_write_error = 1;
 	if (g_write_error) { fprintf(stderr, "[E::%s] failed to write the output: the SAM is incomplete\n", "main_align"); rc = 1; }
 cleanup:

@@ -8,11 +8,11 @@
 #include <zlib.h>
 #include <ctype.h>
 #include <pthread.h>
+#include <sys/stat.h>
 #include "bsx_core.h"
 #include "fastq.h"
 
 const uint8_t *bsx_nt4_table(void);
-int bsx_fq_plain_file(const char *fn);
 
 /* ---- where a reader gets its bytes.  A plain regular file is read in place (offsets into it mean something: the chunk scan and
  * bsx_fq_seek).  Compressed or piped input is inflated AHEAD of the parser by threads of its own (with the aligner on
@@ -30,7 +30,7 @@ typedef struct fq_src {
 	gzFile gz; FILE *fp;
 	src_slot_t ring[SRC_RING];
 	int64_t head, tail, next_job;   /* consumer's slot, producer's next slot, next compressed slot a worker takes */
-	int eof, stop, failed, head_pos;
+	int eof, stop, failed, reported, head_pos;
 	pthread_mutex_t mu; pthread_cond_t cv;
 	pthread_t th_read, th_work[8]; int n_work;
 } fq_src_t;
@@ -39,7 +39,7 @@ struct bsx_fq {
 	gzFile fp;
 	fq_src_t *src;
 	unsigned char *buf;
-	int begin, end, is_eof, last_char;
+	int begin, end, is_eof, last_char, failed;
 	int64_t base;        /* file offset of buf[0] (plain files: the chunk scan and bsx_fq_seek) */
 	int64_t last_off;    /* where last_char was read */
 	BSX_VEC(char) name, comment, seq, qual;
@@ -61,7 +61,12 @@ static void *src_gz_main(void *arg)   /* mode 1: the one thread that inflates */
 		if (!sl->data) { sl->data = (unsigned char*)malloc(SRC_SLOT); sl->cap = SRC_SLOT; }
 		n = gzread(S->gz, sl->data, SRC_SLOT);
 		pthread_mutex_lock(&S->mu);
-		if (n <= 0) { S->eof = 1; if (n < 0) S->failed = 1; pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu); return 0; }
+		if (n <= 0) { /* the end, or damage: a truncated stream reads as 0 bytes with Z_BUF_ERROR set */
+			int errnum = Z_OK;
+			(void)gzerror(S->gz, &errnum);
+			S->eof = 1; if (n < 0 || errnum < 0) S->failed = 1;
+			pthread_cond_broadcast(&S->cv); pthread_mutex_unlock(&S->mu); return 0;
+		}
 		sl->n = n; sl->state = 3; ++S->tail;
 		pthread_cond_broadcast(&S->cv);
 		pthread_mutex_unlock(&S->mu);
@@ -120,8 +125,14 @@ static void *src_bgzf_work_main(void *arg)   /* mode 2: a worker inflates the ne
 		inflateReset(&z);
 		z.next_in = sl->comp; z.avail_in = (unsigned)sl->ncomp; z.next_out = sl->data; z.avail_out = 65536;
 		ok = inflate(&z, Z_FINISH) == Z_STREAM_END;
+		if (ok) { /* the member's trailer: CRC32 and ISIZE of what it inflates to (RFC 1952) */
+			const unsigned char *t = sl->comp + sl->ncomp;
+			const unsigned long crc = (unsigned long)t[0] | (unsigned long)t[1] << 8 | (unsigned long)t[2] << 16 | (unsigned long)t[3] << 24;
+			const unsigned long isz = (unsigned long)t[4] | (unsigned long)t[5] << 8 | (unsigned long)t[6] << 16 | (unsigned long)t[7] << 24;
+			ok = isz == z.total_out && crc == crc32(crc32(0L, Z_NULL, 0), sl->data, (uInt)z.total_out);
+		}
 		pthread_mutex_lock(&S->mu);
-		sl->n = ok ? (int)z.total_out : 0;
+		sl->n = ok ? (int)z.total_out : -1;   /* -1: the stream ends here (src_read), whatever lies behind the damage */
 		if (!ok) S->failed = 1;
 		sl->state = 3;
 		pthread_cond_broadcast(&S->cv);
@@ -130,7 +141,11 @@ static void *src_bgzf_work_main(void *arg)   /* mode 2: a worker inflates the ne
 	inflateEnd(&z);
 	return 0;
 }
-/* the next bytes of the stream, up to cap of them; 0 at its end */
+static void src_report(fq_src_t *S)
+{
+	if (S->failed && !S->reported) { S->reported = 1; fprintf(stderr, "[E::%s] the compressed input is damaged or truncated: the reads behind the damage are not aligned\n", "fastq"); }
+}
+/* the next bytes of the stream, up to cap of them; 0 at its end (or at the first damaged block: bsx_fq_error tells the two apart) */
 static int src_read(fq_src_t *S, unsigned char *dst, int cap)
 {
 	int got = 0;
@@ -141,10 +156,11 @@ static int src_read(fq_src_t *S, unsigned char *dst, int cap)
 		for (;;) {
 			sl = &S->ring[S->head % SRC_RING];
 			if (S->head < S->tail && sl->state == 3) break;
-			if (S->head >= S->tail && S->eof) { pthread_mutex_unlock(&S->mu); if (S->failed) fprintf(stderr, "[E::%s] the compressed input is damaged or truncated\n", "fastq"); return 0; }
+			if (S->head >= S->tail && S->eof) { pthread_mutex_unlock(&S->mu); src_report(S); return 0; }
 			pthread_cond_wait(&S->cv, &S->mu);
 		}
 		pthread_mutex_unlock(&S->mu);
+		if (sl->n < 0) { src_report(S); return 0; }   /* a damaged block: nothing behind it is handed on (the slot is never released: every later call ends here) */
 		k = sl->n - S->head_pos; k = k < cap ? k : cap;
 		if (k > 0) { memcpy(dst, sl->data + S->head_pos, (size_t)k); S->head_pos += k; got = k; }
 		if (S->head_pos >= sl->n) {
@@ -156,26 +172,36 @@ static int src_read(fq_src_t *S, unsigned char *dst, int cap)
 	}
 	return got;
 }
+/* What kind of input a name is, decided WITHOUT reading from it unless it is a regular file: a FIFO or a process substitution
+ * (`align ref <(zcat r1.gz) <(zcat r2.gz)`) gives every byte once, so it is opened exactly once, by the reader that keeps it (zlib's gzopen
+ * tells gzip from plain text itself).  0: plain regular file, 1: regular gzip file, 2: regular BGZF file, 3: anything else (pipes, devices,
+ * standard input), -1: cannot be opened. */
+static int src_kind(const char *fn)
+{
+	struct stat st;
+	FILE *fp;
+	unsigned char hdr[18];
+	int kind = 0;
+	if (strcmp(fn, "-") == 0) return 3;
+	if (stat(fn, &st) != 0) return -1;
+	if (!S_ISREG(st.st_mode)) return 3;
+	if ((fp = fopen(fn, "rb")) == 0) return -1;
+	if (fread(hdr, 1, 2, fp) == 2 && hdr[0] == 0x1f && hdr[1] == 0x8b) { rewind(fp); kind = bgzf_block_size(fp, hdr) > 0 ? 2 : 1; }
+	fclose(fp);
+	return kind;
+}
 static fq_src_t *src_open(const char *fn)
 {
 	const char *e = getenv("BSX_INFLATE_THREADS");
-	int nw = e ? atoi(e) : 3, is_gz = 0, is_bgzf = 0, i;
+	int nw = e ? atoi(e) : 3, i;
+	const int kind = src_kind(fn);
 	fq_src_t *S;
-	if (nw <= 0) return 0;
-	if (strcmp(fn, "-") != 0) {
-		FILE *fp = fopen(fn, "rb");
-		unsigned char hdr[18];
-		if (!fp) return 0;
-		if (fread(hdr, 1, 2, fp) == 2 && hdr[0] == 0x1f && hdr[1] == 0x8b) { is_gz = 1; rewind(fp); is_bgzf = bgzf_block_size(fp, hdr) > 0; }
-		else if (bsx_fq_plain_file(fn)) { fclose(fp); return 0; }   /* a plain regular file: read in place */
-		fclose(fp);
-	}
-	(void)is_gz;
+	if (nw <= 0 || kind <= 0) return 0;   /* a plain regular file is read in place (and a name that cannot be opened fails in bsx_fq_open) */
 	S = (fq_src_t*)calloc(1, sizeof(*S));
 	pthread_mutex_init(&S->mu, 0); pthread_cond_init(&S->cv, 0);
-	if (is_bgzf) {
+	if (kind == 2) {
 		S->mode = 2;
-		S->fp = fopen(fn, "rb");
+		if ((S->fp = fopen(fn, "rb")) == 0) { free(S); return 0; }
 		S->n_work = nw < 8 ? nw : 8;
 		pthread_create(&S->th_read, 0, src_bgzf_read_main, S);
 		for (i = 0; i < S->n_work; ++i) pthread_create(&S->th_work[i], 0, src_bgzf_work_main, S);
@@ -226,7 +252,16 @@ void bsx_fq_close(bsx_fq_t *f)
 	free(f);
 }
 
-static inline int fq_more(bsx_fq_t *f) { return f->src ? src_read(f->src, f->buf, FQ_BUFSZ) : gzread(f->fp, f->buf, FQ_BUFSZ); }
+static inline int fq_more(bsx_fq_t *f)
+{
+	int n, errnum = Z_OK;
+	if (f->src) return src_read(f->src, f->buf, FQ_BUFSZ);
+	n = gzread(f->fp, f->buf, FQ_BUFSZ);
+	if (n <= 0) { (void)gzerror(f->fp, &errnum); if ((n < 0 || errnum < 0) && !f->failed) { f->failed = 1; fprintf(stderr, "[E::%s] the input is damaged or truncated: the reads behind the damage are not aligned\n", "fastq"); } }
+	return n;
+}
+/* non-zero once the reader has met damaged or truncated compressed input: what it returned as "end of file" was not one */
+int bsx_fq_error(const bsx_fq_t *f) { return f ? (f->failed || (f->src && f->src->failed)) : 0; }
 static inline int fq_getc(bsx_fq_t *f)
 {
 	if (f->is_eof && f->begin >= f->end) return -1;
@@ -534,16 +569,7 @@ static int64_t fq_next_off(const bsx_fq_t *f) { return f->last_char ? f->last_of
 
 int bsx_fq_plain_file(const char *fn)   /* a regular, uncompressed file: offsets into it mean something */
 {
-	unsigned char m[2] = {0, 0};
-	FILE *fp;
-	size_t k;
-	if (strcmp(fn, "-") == 0) return 0;
-	if ((fp = fopen(fn, "rb")) == 0) return 0;
-	if (fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return 0; }   /* pipes, sockets */
-	rewind(fp);
-	k = fread(m, 1, 2, fp);
-	fclose(fp);
-	return !(k == 2 && m[0] == 0x1f && m[1] == 0x8b);
+	return src_kind(fn) == 0;   /* (never opens a pipe: its bytes come once, and closing a FIFO's read end can kill its writer) */
 }
 int bsx_fq_seek(bsx_fq_t *f, int64_t off)
 {
@@ -641,11 +667,12 @@ int bsx_fq_skip_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size)
 	int n = 0, l;
 	while ((l = fq_scan(f1, &o)) >= 0) {
 		int l2 = 0;
-		if (f2 && (l2 = fq_scan(f2, &o)) < 0) break;
+		if (f2 && (l2 = fq_scan(f2, &o)) < 0) { fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bsx_fq_read_chunk"); break; }   /* (what the parsing ranks say) */
 		size += l; ++n;
 		if (f2) { size += l2; ++n; }
 		if (size >= chunk_size && (n & 1) == 0) break;
 	}
+	if (size == 0 && f2 && fq_scan(f2, &o) >= 0) fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", "bsx_fq_read_chunk");
 	return n;
 }
 

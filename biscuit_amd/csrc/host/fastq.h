@@ -5,6 +5,7 @@
 typedef struct bsx_fq bsx_fq_t;
 bsx_fq_t *bsx_fq_open(const char *fn);
 void bsx_fq_close(bsx_fq_t *f);
+int bsx_fq_error(const bsx_fq_t *f);   /* damaged or truncated compressed input was met: the end of input the reader reported was not one */
 /* bis_bseq_read (lib/aln/bwa.c:817-850): interleaves f1/f2 when f2 != NULL; NULL at end of input */
 bsx_read_t *bsx_fq_read_chunk(bsx_fq_t *f1, bsx_fq_t *f2, int chunk_size, int has_bc, int *n);
 void bsx_read_free(bsx_read_t *s);
