@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- paired-end reads aligned per second through the MI355X `biscuit align` hot path.
 
+Since round 5 the headline workload is the hg38-LIKE synthetic genome (BASELINE's metric is quoted "vs hg38": the repeat families of a
+real genome are where max_occ binds, strand searches have thousands of seeds and a read has dozens of regions); the clean genome of rounds
+1-4, 1 kb single-end reads (configs[4]) and the command line end to end are sub-records of the same JSON line.
+
 A step = one chunk (10 Mbp x threads of 2x150 bp reads, the reference's chunk size, align.c:576)
 pushed through bsx_process_seqs (== mem_process_seqs): all five HIP kernels + the host stages
 between them, ending in SAM text.  The index is resident in HBM before timing starts; reads are in
@@ -26,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
@@ -37,9 +41,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one chunk at a time through bsx_process_seqs (no overlap of consecutive chunks)")
     ap.add_argument("--no-long-reads", action="store_true", help="skip the third, short measurement on 1 kb single-end reads (BASELINE configs[4] shape; own subprocess)")
-    ap.add_argument("--no-hard-genome", action="store_true", help="skip the second, shorter measurement on the hg38-like genome (run after the headline one, in a subprocess)")
-    ap.add_argument("--genome-profile", choices=["clean", "hg38-like"], default="clean",
-                    help="clean: i.i.d. bases + 5 %% planted repeats (the workload of rounds 1-2); hg38-like: + interspersed repeat families with up to a million copies, ~43 %% repeats (csrc/host/sim.c)")
+    ap.add_argument("--no-hard-genome", action="store_true", help="skip the second, shorter measurement on the other genome profile (run after the headline one, in a subprocess)")
+    ap.add_argument("--genome-profile", choices=["clean", "hg38-like"], default="hg38-like",
+                    help="hg38-like (the headline since round 5: BASELINE's metric is quoted vs hg38): i.i.d. bases + interspersed repeat families with up to a million copies, ~43 %% repeats (csrc/host/sim.c); clean: i.i.d. bases + 5 %% planted repeats (the headline of rounds 1-4, now the sub-record clean_genome)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the cli_end_to_end sub-record (FASTQ text in -> SAM text out through biscuit_align, tools/cli_e2e.py)")
+    ap.add_argument("--sub", action="store_true", help="(internal) this run is a sub-record of another: no sub-records of its own")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,6 +150,7 @@ def main():
         dev.kernel_time(k, reset=True)
     dev.counters(reset=True)
     dev.seed_table(reset=True)
+    dev.region_work(reset=True)
     phase_tot = {}
     # the gather of the records to rank 0 (below) is part of the timed region; its connections are made here, as part of the warm-up
     import numpy as np
@@ -258,14 +265,19 @@ def main():
         dist.all_reduce(c)   # "gather" of per-GPU record counts over RCCL
         tot_reads = int(c.item())
 
-    # rooflines of the two HBM-bound kernels, both random 64-byte gathers over the FM index:
-    #   k_seed (K1+K2): 64 B per FM block touched by bwt_extend (two blocks unless k and l share one)
-    #   k_occ  (K3):    64 B per LF step of bwt_sa + 8 B per SA sample + 16 B per occurrence (rank in, position out)
-    # Durations are HIP-event times on the launch stream over the timed region.  With chunks pipelined, kernels of
-    # different chunks share the device, so a launch lasts longer than it would alone; one extra chunk is therefore
-    # run unpipelined after the timed region and its event times are reported next to the live ones.
+    # ---- rooflines.  One byte definition throughout: the bytes a kernel family has to move for this input (its ALGORITHMIC bytes, stated per
+    # unit in DESIGN.md section 4), over HIP-event launch times on the launch stream in the timed region.  With chunks pipelined, kernels of
+    # different chunks share the device, so a launch lasts longer than it would alone; one extra chunk is therefore run unpipelined after
+    # the timed region and its event times are reported next to the live ones (*_standalone).
+    #   region family (K3's consumers: C1+C2+K4+C4 -- k_regions, k_regions_mid, k_x4prep/k_extl/k_ext4, k_c2r, k_regions_slab): per strand search
+    #       the read (l_query B) + 32 B per SA interval + 8 B per seed occurrence; per region 56 B written + the read again and the packed
+    #       reference window of its two extensions (l_query + ceil((l_query + 2 w) / 4) B)
+    #   k_seedt (K1+K2): 64 B per FM block the kernel touches + a 64-byte line per entry of the table of k-mer intervals it reads.  (The
+    #       reference algorithm touches four times as many blocks for the same reads: `reference_equivalent`, counted by k_seed.)
+    #   k_occ (K3): 64 B per LF step of bwt_sa + 8 B per SA sample + 16 B per occurrence (rank in, position out)
     ctr = dev.counters()
     ktimes = [dev.kernel_time(k) for k in range(8)]
+    rwork = dev.region_work()
     alone = None
     region_launch_ms = None
     ref_blocks_per_read, ref_seed_ms = None, None
@@ -307,10 +319,9 @@ def main():
                     region_launch_ms = None
                 break
         alone = [dev.kernel_time(k) for k in range(8)]
-        # SURVEY 8(d)'s algorithmic bytes are the REFERENCE algorithm's FM-block touches (bwt_occ4 / bwt_2occ4 calls of bwt_smem1a and
-        # bwt_seed_strategy1: deterministic integers for a given input).  The seeding kernel of the timed region does not make them all (it
-        # reads most intervals from its table of k-mer intervals), so they are counted here, after the timed region, by the same chunk
-        # through the kernel that walks the FM index step by step as the reference does (k_seed.hip, $BSX_SEED_FORM=classic).
+        # The reference algorithm's FM-block touches for these reads (bwt_occ4 / bwt_2occ4 calls of bwt_smem1a and bwt_seed_strategy1:
+        # deterministic integers for a given input) are counted here, after the timed region, by the same chunk through the kernel
+        # that walks the FM index step by step as the reference does (k_seed.hip, $BSX_SEED_FORM=classic).
         os.environ["BSX_SEED_FORM"] = "classic"
         try:
             dev.counters(reset=True)
@@ -322,13 +333,14 @@ def main():
             os.environ.pop("BSX_SEED_FORM", None)
         L.bsx_sim_free_reads(extra, n_reads)
 
-    # Counter passes cannot run inside this process (rocprofv3 --pmc wraps a command): HBM traffic and instruction counts per
-    # launch come from the committed passes of THIS command at THIS genome size (profiles/*_pmc_<Mbp>mbp.json, written by
-    # tools/profile_round.sh + tools/summarize_profiles.py), and are only quoted when the workload is the profiled one.
+    # Counter passes cannot run inside this process (rocprofv3 --pmc wraps a command): HBM traffic and instruction counts per launch come
+    # from the committed passes of THIS command on THIS genome (profiles/*_pmc_<Mbp>mbp_<profile>.json, written by tools/profile_round.sh +
+    # tools/summarize_profiles.py), and are only quoted when the workload is the profiled one.
     pmc = {}
     import glob
-    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%dmbp.json" % int(round(args.genome_mbp)))))
-    if cand and args.read_len == 150 and threads == 16 and args.genome_profile == "clean":
+    prof_tag = "hg38like" if args.genome_profile == "hg38-like" else "clean"
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%dmbp_%s.json" % (int(round(args.genome_mbp)), prof_tag))))
+    if cand and args.read_len == 150 and threads == 16 and not args.single_end:
         with open(cand[-1]) as f:
             tj = json.load(f)
         if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
@@ -338,76 +350,71 @@ def main():
     GATHER_CEILING = 3500.0   # GB/s: dependent random 64-B block reads over a 3.1 GB table, four lanes per block, measured on this GPU
                               # with tools/ubench/gather64.hip (profiles/r02_gather64.txt); one lane per block: 2.7 TB/s
 
-    def roof_of(name, k, alg_bytes, extra, pmc_key=None):
-        # one chunk-wide launch (sequence) per step: the launch count of slot k also holds the few small batches of the host path
-        ms, launches = ktimes[k][0], args.steps
-        if not ktimes[k][1] or ms <= 0:
+    def hbm_roof(name, slots, alg_bytes, extra, pmc_key=None):
+        # alg_bytes: over the whole timed region; one chunk-wide launch (sequence) per step
+        ms, launches = sum(ktimes[k][0] for k in slots), args.steps
+        if not ktimes[slots[0]][1] or ms <= 0:
             return None
         ach = alg_bytes / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(ach / PEAK_HBM, 5),
-             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3),
-             "random_64B_gather_ceiling": GATHER_CEILING, "frac_of_gather_ceiling": round(ach / GATHER_CEILING, 4)}
-        if alone and alone[k][1]:
-            r["avg_launch_ms_standalone"] = round(alone[k][0], 3)   # the one extra chunk
-            r["achieved_standalone"] = round(alg_bytes / launches / (alone[k][0] * 1e-3) / 1e9, 2)
+             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3)}
+        if alone and alone[slots[0]][1]:
+            ms1 = sum(alone[k][0] for k in slots)
+            r["avg_launch_ms_standalone"] = round(ms1, 3)   # the one extra chunk
+            r["achieved_standalone"] = round(alg_bytes / launches / (ms1 * 1e-3) / 1e9, 2)
             r["frac_standalone"] = round(r["achieved_standalone"] / PEAK_HBM, 5)
         p = pmc.get(pmc_key or "", {})
         if p.get("FETCH_SIZE_KiB") is not None and p.get("WRITE_SIZE_KiB") is not None:
             r["traffic"] = 1024.0 * (p["FETCH_SIZE_KiB"] + p["WRITE_SIZE_KiB"])
-            r["traffic_source"] = "FETCH_SIZE + WRITE_SIZE of %s (separate rocprofv3 --pmc passes of this command at this genome size)" % pmc["_file"]
+            r["traffic_source"] = "FETCH_SIZE + WRITE_SIZE of %s (separate rocprofv3 --pmc passes of this command on this genome, one chunk)" % pmc["_file"]
         r.update(extra)
         return r
 
-    # k_seedt (K1+K2): `achieved` = the reference algorithm's FM-block bytes for these reads (counted above) over the launch time, as SURVEY 8(d)
-    # defines it; what the kernel itself moved (the FM blocks it did touch + a 64-byte line per table entry read) is reported beside it
+    steps_reads = float(n_reads * args.steps)
+    # -- the region family: what dominates the step
+    win_bytes = args.read_len + (args.read_len + 2 * opt.w + 3) // 4
+    reg_bytes = rwork[4] + 32.0 * rwork[1] + 8.0 * rwork[2] + (56.0 + win_bytes) * rwork[3]
+    issue = None
+    p_ = pmc.get("k_regions", {})
+    if p_.get("SQ_INSTS_SALU") is not None and p_.get("SQ_INSTS_VALU") is not None and alone and alone[5][1]:
+        t_ = (alone[5][0] + alone[6][0]) * 1e-3
+        # one scalar instruction per CU per cycle, one wave64 VALU instruction per SIMD per two cycles (256 CUs x 4 SIMDs, 2.4 GHz)
+        issue = {"salu_inst_per_chunk": p_["SQ_INSTS_SALU"], "valu_inst_per_chunk": p_["SQ_INSTS_VALU"],
+                 "frac_salu_issue_peak": round(p_["SQ_INSTS_SALU"] / t_ / (256 * 2.4e9), 4), "frac_valu_issue_peak": round(p_["SQ_INSTS_VALU"] * 2 / t_ / (1024 * 2.4e9), 4),
+                 "over": "the stand-alone chunk's %.0f ms" % (t_ * 1e3), "counter_source": pmc["_file"]}
+    roof = hbm_roof("region family (C1+C2+K4+C4): k_regions + k_regions_mid (chaining, chain filter; tables in LDS), k_x4prep/k_extl/k_ext4 (extensions ahead), k_c2r (chains -> regions), k_regions_slab x2 (HBM slabs)",
+                    [5, 6], reg_bytes,
+                    {"per_read": {"strand_searches": rwork[0] / steps_reads, "sa_intervals": rwork[1] / steps_reads, "seed_occurrences": rwork[2] / steps_reads, "regions": rwork[3] / steps_reads},
+                     "algorithmic_bytes_are": "per strand search the read + 32 B per SA interval + 8 B per seed occurrence; per region 56 B written + %d B (the read and the packed reference window of its extensions)" % win_bytes,
+                     "issue": issue,
+                     "what_bounds_it": "neither bytes nor, by the counters, instruction issue: latency and divergence -- a wavefront per strand search walks dependent LDS / HBM round trips (chaining, the chain filter), and a DP row of an extension is a dependent chain of DPP steps; see DESIGN.md section 4"},
+                    "k_regions")
+    # -- seeding
     touched = 64.0 * (ctr[0] + ctr[1]) + 64.0 * (tab_touch[1] if tab_touch else 0)
-    alg = 64.0 * ref_blocks_per_read * n_reads * args.steps if ref_blocks_per_read else 64.0 * (ctr[0] + ctr[1])
-    roof = roof_of("k_seedt (K1+K2 SMEM seeding over the table of k-mer intervals + dependent random 64-B FM-block gathers)", 0, alg,
-                   {"fm_block_touches_per_read": (ref_blocks_per_read if ref_blocks_per_read else (ctr[0] + ctr[1]) / float(n_reads * args.steps)),
-                    "algorithmic_bytes_are": "the reference algorithm's bwt_occ4/bwt_2occ4 touches for these reads (SURVEY 8(d)), counted on one chunk by the kernel that walks the FM index as the reference does (BSX_SEED_FORM=classic, after the timed region)" if ref_blocks_per_read else "the blocks this kernel touched",
-                    "kernel_touches_per_read": {"fm_blocks": (ctr[0] + ctr[1]) / float(n_reads * args.steps), "table_entries": (tab_touch[1] / float(n_reads * args.steps)) if tab_touch else 0.0,
-                                                "table_depth": tab_touch[2] if tab_touch else 0},
-                    "bytes_touched_per_launch": touched / args.steps,
-                    "achieved_touched": round(touched / (ktimes[0][0] * 1e-3) / 1e9, 2) if ktimes[0][0] > 0 else None,
-                    "frac_touched": round(touched / (ktimes[0][0] * 1e-3) / 1e9 / PEAK_HBM, 5) if ktimes[0][0] > 0 else None,
-                    "kernel_without_table_ms_standalone": round(ref_seed_ms, 3) if ref_seed_ms else None,
-                    "what_bounds_it": "vector and scalar issue of the per-lane state machine (a lane per strand search, persistent lanes, three waves per SIMD at 168 VGPRs): a trip of the wave loop is one request per lane -- an FM extension (one or two dependent random 64-B blocks, fetched by the wave as a whole) or a 16-byte table entry -- and about half its cycles are the machine that decides the next request; the table (18 levels, 2 x 9.3 GB) removes three of four FM-block touches of the reference algorithm, so the kernel runs far above the rate at which it could fetch the reference's bytes; see DESIGN.md"}, "k_seed")
-    roof_other = roof_of("k_occ (K3 suffix-array lookups of the whole chunk)", 1, 64.0 * ctr[2] + 24.0 * ctr[3],
-                         {"lf_steps_per_read": ctr[2] / float(n_reads * args.steps), "sa_lookups_per_read": ctr[3] / float(n_reads * args.steps)}, "k_occ")
-
-    # The region kernels (C1+C2+K4+C4: chaining, chain filter, extension) take the most device time and touch ~1.5 KB per strand
-    # search: they are bound by instruction issue.  Roofline against the issue rates: one scalar instruction per CU per cycle,
-    # one wave64 VALU instruction per SIMD per two cycles (256 CUs x 4 SIMDs, 2.4 GHz).
-    def issue_roof():
-        ms = ktimes[5][0] + ktimes[6][0]
-        launches = ktimes[5][1]
-        if not launches or ms <= 0:
-            return None
-        r = {"bound": "issue", "kernel": "k_regions, all tiers (C1+C2+K4+C4)", "avg_ms_per_chunk": round(ms / launches, 3),
-             "peak_salu_ginst_per_s": 256 * 2.4, "peak_valu_ginst_per_s": 1024 * 2.4 / 2, "salu_inst_per_chunk": None, "valu_inst_per_chunk": None,
-             "frac_salu": None, "frac_valu": None}
-        if alone and alone[5][1]:
-            r["avg_ms_per_chunk_standalone"] = round((alone[5][0] + alone[6][0]) / alone[5][1], 3)
-        p = pmc.get("k_regions", {})
-        if p.get("SQ_INSTS_SALU") is not None and p.get("SQ_INSTS_VALU") is not None:
-            t = (r.get("avg_ms_per_chunk_standalone") or r["avg_ms_per_chunk"]) * 1e-3
-            r["salu_inst_per_chunk"], r["valu_inst_per_chunk"] = p["SQ_INSTS_SALU"], p["SQ_INSTS_VALU"]
-            r["frac_salu"] = round(p["SQ_INSTS_SALU"] / t / (256 * 2.4e9), 4)
-            r["frac_valu"] = round(p["SQ_INSTS_VALU"] * 2 / t / (1024 * 2.4e9), 4)
-            r["counter_source"] = pmc["_file"]
-        return r
-    roof_regions = issue_roof()
-
-    # the whole path against the HBM peak: the algorithmic bytes of the two HBM-bound kernel families over the whole step (everything
-    # else the step does -- chaining, extension, the host back half -- moves a few KB per read)
+    ref_eq = None
+    if ref_blocks_per_read and ktimes[0][0] > 0:
+        rb_ = 64.0 * ref_blocks_per_read * n_reads * args.steps
+        ref_eq = {"fm_block_touches_per_read": ref_blocks_per_read, "bytes_per_launch": rb_ / args.steps, "rate": round(rb_ / (ktimes[0][0] * 1e-3) / 1e9, 2), "unit": "GB/s",
+                  "frac_of_hbm_peak": round(rb_ / (ktimes[0][0] * 1e-3) / 1e9 / PEAK_HBM, 5),
+                  "meaning": "the rate at which the kernel gets through the REFERENCE algorithm's FM-block touches for these reads (bwt_occ4/bwt_2occ4 of bwt_smem1a and bwt_seed_strategy1, SURVEY 8(d); counted on one chunk by k_seed, BSX_SEED_FORM=classic, after the timed region) -- not bytes moved: the table of k-mer intervals replaces three of four of them",
+                  "kernel_without_table_ms_standalone": round(ref_seed_ms, 3) if ref_seed_ms else None}
+    roof_seed = hbm_roof("k_seedt (K1+K2: SMEM seeding over the table of k-mer intervals + dependent random 64-B FM-block gathers)", [0], touched,
+                         {"kernel_touches_per_read": {"fm_blocks": (ctr[0] + ctr[1]) / steps_reads, "table_entries": (tab_touch[1] / steps_reads) if tab_touch else 0.0, "table_depth": tab_touch[2] if tab_touch else 0},
+                          "random_64B_gather_ceiling": GATHER_CEILING, "frac_of_gather_ceiling": round(touched / (ktimes[0][0] * 1e-3) / 1e9 / GATHER_CEILING, 4) if ktimes[0][0] > 0 else None,
+                          "reference_equivalent": ref_eq,
+                          "what_bounds_it": "vector and scalar issue of the per-lane state machine (a lane per strand search, persistent lanes, three waves per SIMD at 168 VGPRs): a trip of the wave loop is one request per lane -- an FM extension (one or two dependent random 64-B blocks, fetched by the wave as a whole) or a 16-byte table entry -- and about half its cycles are the machine that decides the next request; see DESIGN.md"}, "k_seed")
+    roof_occ = hbm_roof("k_occ_expand + k_occ (K3: suffix-array lookups of the whole chunk)", [1], 64.0 * ctr[2] + 24.0 * ctr[3],
+                        {"lf_steps_per_read": ctr[2] / steps_reads, "sa_lookups_per_read": ctr[3] / steps_reads}, "k_occ")
+    # -- the whole path against the HBM peak: the same bytes, all families, over the step's wall time
     whole = None
-    if roof and roof_other:
-        wb = (64.0 * (ctr[0] + ctr[1]) + 64.0 * ctr[2] + 24.0 * ctr[3]) * world   # this rank's counters; ranks do the same work
+    if roof and roof_seed and roof_occ:
+        wb = (touched + 64.0 * ctr[2] + 24.0 * ctr[3] + reg_bytes) * world   # this rank's counters; ranks do the same work
         whole = {"bound": "hbm", "algorithmic_bytes_per_step": wb / args.steps, "ms_per_step": round(1e3 * tmax / args.steps, 2),
-                 "achieved": round(wb / tmax / 1e9, 2), "peak": PEAK_HBM * world, "unit": "GB/s", "frac": round(wb / tmax / 1e9 / (PEAK_HBM * world), 5)}
+                 "achieved": round(wb / tmax / 1e9, 2), "peak": PEAK_HBM * world, "unit": "GB/s", "frac": round(wb / tmax / 1e9 / (PEAK_HBM * world), 5),
+                 "bytes_are": "seeding (FM blocks and table lines touched) + K3 + the region family, as in the three rooflines above; mate rescue (K5) and CIGARs (K6) move a few hundred bytes per job"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(L, B, idx, opt, args, ncores)
+        cpu = cpu_baseline(L, B, idx, dev, opt, args, ncores)
 
     repeats = ("with hg38-like repeat content (SINE/LINE/LTR-like families of up to a million copies, satellite arrays: ~43 % repeats)"
                if args.genome_profile == "hg38-like" else "with repeat families (5 % planted repeats of 1-5 copies)")
@@ -426,9 +433,9 @@ def main():
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 2 * 8) + n_bases / 4),
                        "seed_table_bytes_in_hbm": int(2 * 16 * sum(3 ** l for l in range(1, (tab_touch[2] if tab_touch else 0) + 1)))},
             "roofline": roof,
-            "roofline_second_kernel": roof_other,
+            "roofline_seeding": roof_seed,
+            "roofline_sa_lookup": roof_occ,
             "roofline_whole_path": whole,
-            "roofline_regions": roof_regions,
             "record_gather": {"chunks_received_by_rank0": gathered[0], "bytes_received_by_rank0": gathered[1], "in_timed_region": True},
             "cpu_baseline": cpu,
             "kernel_ms_per_step": {names[k]: round(ktimes[k][0] / args.steps, 3) for k in range(8)},
@@ -443,45 +450,49 @@ def main():
             "sam_bytes_per_read": round(sam_bytes / float(n_reads * args.steps), 1),
             "genome_and_index_build_s": round(t_build, 1), "device": dev.name,
             "hbm_bytes_free_of_total_after_the_run": list(hbm_free),
-            "hg38_like_genome": None,
         }
-    dev_name = dev.name
     if not args.no_pipeline:
         L.bsx_stream_close(stream)
     for c in list.__iter__(chunks):
         L.bsx_sim_free_reads(c, n_reads)
     if rank == 0:
-        # The same measurement, shorter, on the genome with hg38's repeat content (a workload where max_occ binds, strand searches have
-        # thousands of seeds and a read has dozens of regions), in a process of its own after this one has given the device back: the
-        # headline value stays the clean genome of rounds 1-2, this one says what the repeat families of a real genome cost.
-        if world == 1 and args.genome_profile == "clean" and not args.no_hard_genome and not args.no_pipeline:
+        # Sub-records, each in a process of its own after this one has given the device back (the headline line must not depend on them):
+        #   clean_genome     the same measurement, shorter, on the genome of rounds 1-4's headline (i.i.d. bases + 5 % planted repeats)
+        #   long_reads       BASELINE configs[4] shape (1 kb single-end reads), with its own roofline and CPU baseline
+        #   cli_end_to_end   SURVEY 8(d)'s second number: FASTQ text in -> SAM text out through the command line (tools/cli_e2e.py)
+        if world == 1 and not args.sub and not args.no_pipeline:
             dev.close()
             idx.close()
-            cmd = [sys.executable, os.path.abspath(__file__), "--genome-profile", "hg38-like", "--genome-mbp", str(args.genome_mbp), "--threads", str(threads),
-                   "--read-len", str(args.read_len), "--steps", str(max(2, min(6, args.steps))), "--warmup", "2", "--cpu-sample-pairs", str(max(1000, args.cpu_sample_pairs // 5))]
-            if args.no_cpu_baseline:
-                cmd.append("--no-cpu-baseline")
-            try:
-                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
-                sub = json.loads(pr.stdout.decode().strip().split("\n")[-1])
-                out["hg38_like_genome"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "roofline", "roofline_whole_path", "cpu_baseline", "kernel_ms_per_step",
-                                                                  "kernel_ms_per_step_standalone", "region_launch_ms_standalone", "strand_searches_chained_on_host_per_step", "host_phase_s_per_chunk", "host_cpu_s_per_step")}
-                out["hg38_like_genome"]["workload"] = sub["config"]["workload"]
-            except Exception as e:      # the headline line must not depend on it
-                out["hg38_like_genome"] = {"error": repr(e)[:300]}
-            # BASELINE configs[4] shape (single-end reads of 1 kb, clean genome of the same size): the long-read kernels, timed the same way
-            # (a chunk is 160 Mbp of reads: 160 k of them)
-            if not args.no_long_reads:
-                cmd = [sys.executable, os.path.abspath(__file__), "--genome-mbp", str(args.genome_mbp), "--threads", str(threads), "--single-end", "--read-len", "1000",
-                       "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-hard-genome", "--no-long-reads"]
+            keep = ("value", "unit", "steps", "warmup", "ms_per_step", "roofline", "roofline_seeding", "roofline_whole_path", "cpu_baseline", "kernel_ms_per_step",
+                    "kernel_ms_per_step_standalone", "region_launch_ms_standalone", "strand_searches_chained_on_host_per_step", "host_phase_s_per_chunk", "host_cpu_s_per_step",
+                    "push_loop_s_per_step", "host_cores_busy_per_gpu")
+
+            def sub_run(key, extra_args, timeout):
+                cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--genome-mbp", str(args.genome_mbp), "--threads", str(threads)] + extra_args
+                if args.no_cpu_baseline:
+                    cmd.append("--no-cpu-baseline")
                 try:
-                    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
                     sub = json.loads(pr.stdout.decode().strip().split("\n")[-1])
-                    out["long_reads"] = {k: sub.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "kernel_ms_per_step", "kernel_ms_per_step_standalone", "region_launch_ms_standalone",
-                                                                 "strand_searches_chained_on_host_per_step", "host_cpu_s_per_step")}
-                    out["long_reads"]["workload"] = sub["config"]["workload"]
+                    out[key] = {k: sub.get(k) for k in keep}
+                    out[key]["workload"] = sub["config"]["workload"]
                 except Exception as e:
-                    out["long_reads"] = {"error": repr(e)[:300]}
+                    out[key] = {"error": repr(e)[:300]}
+            if not args.no_hard_genome:
+                other = "clean" if args.genome_profile == "hg38-like" else "hg38-like"
+                sub_run("clean_genome" if other == "clean" else "hg38_like_genome",
+                        ["--genome-profile", other, "--read-len", str(args.read_len), "--steps", str(max(2, min(8 if other == "clean" else 4, args.steps))), "--warmup", "2",
+                         "--cpu-sample-pairs", str(max(1000, args.cpu_sample_pairs // 5))], 1500)
+            if not args.no_long_reads:
+                # (a chunk is 160 Mbp of reads: 160 k of them; the CPU baseline's sample is 6 000 reads)
+                sub_run("long_reads", ["--genome-profile", "clean", "--single-end", "--read-len", "1000", "--steps", "3", "--warmup", "1", "--cpu-sample-pairs", "3000"], 1200)
+            if not args.no_cli:
+                try:
+                    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_e2e.py"), "--genome-mbp", str(args.genome_mbp), "--profile", "1" if args.genome_profile == "hg38-like" else "0",
+                                         "--threads", str(threads), "--chunks", "2,6", "--out", "/dev/null", "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+                    out["cli_end_to_end"] = json.loads(pr.stdout.decode().strip().split("\n")[-1])
+                except Exception as e:
+                    out["cli_end_to_end"] = {"error": repr(e)[:300]}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -511,7 +522,7 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(L, B, idx, opt, args, ncores):
+def cpu_baseline(L, B, idx, dev, opt, args, ncores):
     """The CPU path on a bounded sample of the same workload, all usable host cores: this repository's C host pipeline (the reference's
     memchain.c / mem_alnreg.c / mem_pair.c / mem_alnreg_format.c cannot be built offline: un-vendored headers) over
     the REFERENCE'S OWN kernels -- oracle/_ref/libbiscuit_ref.so = lib/aln/bwt.c and ksw.c (SSE2 ksw_u8/ksw_i16 included) compiled where
@@ -524,28 +535,48 @@ def cpu_baseline(L, B, idx, opt, args, ncores):
     L.bsx_process_seqs_backend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
     L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
 
-    def run(port, pairs):
+    import zlib
+
+    def sam_crc(p, n):   # the records' SAM text, read by read
+        reads = C.cast(p, C.POINTER(B.Read))
+        crc, nb = 0, 0
+        for i in range(n):
+            t = C.string_at(reads[i].sam) if reads[i].sam else b""
+            crc = zlib.crc32(t, crc)
+            nb += len(t)
+        return crc, nb
+
+    def run(port, pairs, check_hip=False):
         p = C.c_void_p()
         B.check(L.bsx_sim_pairs(idx.h, pairs, args.read_len, 999, args.read_len if args.single_end else 200, args.read_len + 400 if args.single_end else 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
         be = port.backend()
         t0 = time.time()
         B.check(L.bsx_process_seqs_backend(C.byref(be), C.byref(o), idx.h, 0, pairs * 2, p, None), "cpu baseline")
         dt = time.time() - t0
+        same = None
+        if check_hip:   # the same reads through the HIP path: the two SAM texts must be the same bytes
+            want = sam_crc(p, pairs * 2)
+            L.bsx_sim_reset_reads(p, pairs * 2)
+            B.check(L.bsx_process_seqs(dev.h, C.byref(o), idx.h, 0, pairs * 2, p, None), "process_seqs(the CPU sample through HIP)")
+            got = sam_crc(p, pairs * 2)
+            same = {"sam_identical": want == got, "sam_crc32_cpu": "%08x" % want[0], "sam_crc32_hip": "%08x" % got[0], "sam_bytes": want[1]}
         L.bsx_sim_free_reads(p, pairs * 2)
-        return pairs * 2 / dt, dt
+        return pairs * 2 / dt, dt, same
 
     out = None
     ref = oracle_lib.Port(idx, n_threads=ncores)
     if ref.use_reference_kernels():
-        v, dt = run(ref, n_pairs)
+        v, dt, same = run(ref, n_pairs, check_hip=True)
         out = {"value": round(v, 1), "unit": "reads/s", "cores": ncores, "kind": "port",
                "kernels": "the reference's own (oracle/_ref: lib/aln/bwt.c, ksw.c compiled where they lie) under this repository's C host pipeline",
-               "sample": "%d pairs of the same workload, one chunk, %.1f s" % (n_pairs, dt)}
+               "sample": "%d %s of the same workload, one chunk, %.1f s" % (n_pairs * (2 if args.single_end else 1), "reads" if args.single_end else "pairs", dt)}
+        out.update(same)
     small = max(1000, n_pairs // 4) if out else n_pairs
-    v2, dt2 = run(oracle_lib.Port(idx, n_threads=ncores), small)
+    v2, dt2, same2 = run(oracle_lib.Port(idx, n_threads=ncores), small, check_hip=out is None)
     if out is None:
         out = {"value": round(v2, 1), "unit": "reads/s", "cores": ncores, "kind": "port", "kernels": "scalar C restatement (oracle/port.c); oracle/_ref is absent",
                "sample": "%d pairs of the same workload, one chunk, %.1f s" % (small, dt2)}
+        out.update(same2)
     else:
         out["scalar_restatement_kernels"] = {"value": round(v2, 1), "sample": "%d pairs, %.1f s" % (small, dt2),
                                              "slowdown_vs_reference_kernels": round(out["value"] / v2, 2)}

@@ -213,6 +213,12 @@ class Device(Batches):
         B.check(B.lib().bsx_device_counters(self.h, c, int(reset)), "bsx_device_counters")
         return list(c)
 
+    def region_work(self, reset=False):
+        """[strand searches, SA intervals, occurrences looked up, regions written, read bases] of the region kernels since the last reset"""
+        w = (C.c_uint64 * 5)()
+        B.check(B.lib().bsx_device_region_work(self.h, w, int(reset)), "bsx_device_region_work")
+        return list(w)
+
     def seed_table(self, reset=False):
         """(table entries read by the seeding kernel since the last reset, depth K of the resident table of k-mer intervals; 0 = none)"""
         n, k = C.c_uint64(), C.c_int()

@@ -1830,6 +1830,7 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 	const int lane = wave_lane();
 	RgSmall &S = lds[threadIdx.x >> 6];
 	DPT &D = dp[threadIdx.x >> 6];
+	RG_PF_ZERO(D);
 	// each wave takes `quota` tasks and leaves (bounded workgroup life, see k_seed); the launch covers all tasks
 	for (int taken = 0; taken < quota; ++taken) {
 		int t = 0;
@@ -1875,6 +1876,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 	const int lane = wave_lane();
 	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
 	DPT &D = dp[threadIdx.x >> 6];
+	RG_PF_ZERO(D);
 	const int n = (int)*count;
 	for (;;) {
 		int i = 0;
@@ -1903,6 +1905,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
+	RG_PF_FLUSH(D);
 }
 
 // Between the first tier and the HBM tiers: the same tables four times larger, still in LDS (two waves per workgroup, three
@@ -1935,6 +1938,7 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 	const int lane = wave_lane();
 	Store &S = lds[threadIdx.x >> 6];
 	DPT &D = dp[threadIdx.x >> 6];
+	RG_PF_ZERO(D);
 	const int n = (int)*count;
 	for (int taken = 0; taken < quota; ++taken) {   // bounded workgroup life, as in k_c2r
 		int i = 0;

@@ -51,6 +51,7 @@ struct Lane {
 	} rs;
 	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint64_t work[5] = {0, 0, 0, 0, 0};   // the region kernels' work since the last reset: strand searches, SA intervals, occurrences, regions, read bases
 };
 
 struct bsx_device {
@@ -435,6 +436,14 @@ extern "C" BSX_API int bsx_device_seed_table(bsx_device_t *d, uint64_t *lookups,
 	}
 	if (lookups) *lookups = tot;
 	if (depth) *depth = d->has_index ? d->ix.tab.K : 0;
+	return BSX_OK;
+}
+
+extern "C" BSX_API int bsx_device_region_work(bsx_device_t *d, uint64_t w[5], int reset)
+{
+	if (!d || !w) return BSX_E_ARG;
+	for (int k = 0; k < 5; ++k) w[k] = 0;
+	for (int l = 0; l < BSX_LANES; ++l) for (int k = 0; k < 5; ++k) { w[k] += d->lane[l].work[k]; if (reset) d->lane[l].work[k] = 0; }
 	return BSX_OK;
 }
 
@@ -906,7 +915,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		std::vector<int> s_n((size_t)n);
 		HIPCHK(hipEventSynchronize(L.ev1));
 		D2H(L.st2, s_n.data(), d_n, (size_t)n * 4);
-		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i);
+		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i); else L.work[1] += (uint64_t)s_n[i];
 		if (redo.size() > 262144) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
@@ -979,6 +988,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	D2H(L.st, out_n, r_n, (size_t)n * 4);
 	D2H(L.st, &used, ctr + 6, 8);
 	if (used > regs_cap) used = regs_cap;
+	{ // work of the chunk (bsx_device_region_work)
+		unsigned long long n_occ = 0;
+		D2H(L.st, &n_occ, ctr + 11, 8);
+		L.work[0] += (uint64_t)n; L.work[2] += n_occ < pos_cap ? n_occ : pos_cap; L.work[3] += used;
+		for (int64_t i = 0; i < n; ++i) L.work[4] += (uint64_t)(tasks[i].len > 0 ? tasks[i].len : 0);
+	}
 	for (int64_t i = 0; i < n; ++i) out_off[i] = h_off[i];
 	L.rs.used_main = used; L.rs.regs_cap = regs_cap;
 	for (size_t j = 0; j < redo.size(); ++j) out_n[redo[j]] = BSX_REGIONS_PENDING;   // lane_regions_finish fills these in

@@ -8,6 +8,7 @@
 BSX_API void *bsx_hook_fq_open(const char *fn) { return bsx_fq_open(fn); }
 BSX_API int bsx_hook_fq_seek(void *f, int64_t off) { return bsx_fq_seek((bsx_fq_t*)f, off); }
 BSX_API void bsx_hook_fq_close(void *f) { bsx_fq_close((bsx_fq_t*)f); }
+BSX_API int bsx_hook_fq_error(void *f) { return bsx_fq_error((const bsx_fq_t*)f); }
 BSX_API int bsx_hook_fq_skip_chunk(void *f1, void *f2, int chunk_size) { return bsx_fq_skip_chunk((bsx_fq_t*)f1, (bsx_fq_t*)f2, chunk_size); }
 BSX_API bsx_read_t *bsx_hook_fq_chunk(void *f1, void *f2, int chunk_size, int has_bc, int *n) { return bsx_fq_read_chunk((bsx_fq_t*)f1, (bsx_fq_t*)f2, chunk_size, has_bc, n); }
 BSX_API void bsx_hook_reads_free(bsx_read_t *r, int n) { int i; if (!r) return; for (i = 0; i < n; ++i) bsx_read_free(&r[i]); free(r); }

@@ -299,6 +299,10 @@ int bsx_global_batch_tags(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *job
  * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and
  * from the region kernels), c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
+/* what the region kernels (bsx_regions_batch: K3 + C1 + C2 + K4 + C4) were given and made since the last reset, summed over the chunks:
+ * w[0] strand searches, w[1] SA intervals read (32 B each), w[2] seed occurrences whose position was looked up (8 B each),
+ * w[3] alignment regions written (56 B each), w[4] read bases of the strand searches -- the terms of the family's algorithmic bytes */
+int bsx_device_region_work(bsx_device_t *dev, uint64_t w[5], int reset);
 /* the seeding kernel's table of k-mer intervals: entries read since the last reset, depth K of the resident table (0: none) */
 int bsx_device_seed_table(bsx_device_t *dev, uint64_t *lookups, int *depth, int reset);
 /* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since

@@ -348,3 +348,146 @@ def test_skip_chunk_counts_what_the_reader_reads(tmp_path):
                 k += 1
             assert k == len(want)
             L.bsx_hook_fq_close(f1); L.bsx_hook_fq_close(f2)
+
+
+def _read_names(path):
+    L = B.lib()
+    L.bsx_hook_fq_open.restype = C.c_void_p
+    L.bsx_hook_fq_open.argtypes = [C.c_char_p]
+    L.bsx_hook_fq_close.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_error.argtypes = [C.c_void_p]
+    L.bsx_hook_fq_chunk.restype = C.POINTER(B.Read)
+    L.bsx_hook_fq_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    f = L.bsx_hook_fq_open(path.encode())
+    assert f
+    names = []
+    while True:
+        n = C.c_int()
+        r = L.bsx_hook_fq_chunk(f, None, 10 ** 6, 0, C.byref(n))
+        if not r or n.value == 0:
+            break
+        names += [r[i].name.decode() for i in range(n.value)]
+        L.bsx_sim_free_reads(r, n.value)
+    err = L.bsx_hook_fq_error(f)
+    L.bsx_hook_fq_close(f)
+    return names, err
+
+
+def test_pipes_are_opened_once(tmp_path, monkeypatch):
+    """`align ref <(zcat r1.gz) <(zcat r2.gz)`: a FIFO gives every byte once.  The reader must not sniff it with one handle and read it with
+    another (round 4: 921 of 1000 reads of a piped plain file, none of a piped gzip file, no error).  Plain and gzipped text through a named
+    FIFO and through /dev/fd/N, with and without the inflate threads."""
+    import os
+    import threading
+    rng = random.Random(21)
+    text = make_text(rng, 1000)
+    open(str(tmp_path / "plain.fq"), "w").write(text)
+    want, err0 = _read_names(str(tmp_path / "plain.fq"))   # (names as the reader trims them, bwa.c:58-63)
+    assert len(want) == 1000 == len(kseq_records(text)) and err0 == 0
+    payloads = {"plain": text.encode(), "gzip": gzip.compress(text.encode())}
+    bg = str(tmp_path / "x.bgz")
+    write_bgzf(bg, text.encode())
+    payloads["bgzf"] = open(bg, "rb").read()
+    for threads in ("3", "0"):
+        monkeypatch.setenv("BSX_INFLATE_THREADS", threads)
+        for kind, data in payloads.items():
+            fifo = str(tmp_path / ("fifo_%s_%s" % (kind, threads)))
+            os.mkfifo(fifo)
+
+            def feed(path=fifo, data=data):
+                with open(path, "wb") as w:
+                    w.write(data)
+            t = threading.Thread(target=feed)
+            t.start()
+            names, err = _read_names(fifo)
+            t.join()
+            assert names == want and err == 0, (kind, threads, len(names))
+            # an inherited descriptor of a pipe, named the way a shell's process substitution names it
+            rd, wr = os.pipe()
+            t = threading.Thread(target=lambda wr=wr, data=data: (os.write(wr, data[:1]), os.write(wr, data[1:]), os.close(wr)))
+            t.start()
+            names, err = _read_names("/dev/fd/%d" % rd)
+            t.join()
+            os.close(rd)
+            assert names == want and err == 0, (kind, threads, "fd")
+
+
+def test_damaged_compressed_input_ends_the_stream_and_is_reported(tmp_path, monkeypatch):
+    """One flipped byte in the middle of a BGZF file (round 4: the block was skipped and reading went on behind it -- with paired files every
+    later R1 met the wrong R2 -- and the exit code stayed 0): the stream ends AT the damage, the reader says so (bsx_fq_error), and a block
+    whose CRC32 or ISIZE disagree with what it inflates to counts as damaged.  Truncated files likewise, for every way of reading."""
+    rng = random.Random(22)
+    text = make_text(rng, 4000)
+    open(str(tmp_path / "plain.fq"), "w").write(text)
+    want, _ = _read_names(str(tmp_path / "plain.fq"))
+    assert len(want) == 4000
+    bg = str(tmp_path / "a.fq.gz")
+    write_bgzf(bg, text.encode(), block=20000)
+    raw = bytearray(open(bg, "rb").read())
+    # where the blocks start
+    offs, o = [], 0
+    while o < len(raw):
+        offs.append(o)
+        o += (raw[o + 16] | raw[o + 17] << 8) + 1
+    assert len(offs) > 6
+    k = len(offs) // 2
+    monkeypatch.setenv("BSX_INFLATE_THREADS", "3")
+    # (a) a byte of the deflate stream, (b) the CRC32, (c) the ISIZE of block k
+    for what, at in (("stream", offs[k] + 18 + 40), ("crc", offs[k + 1] - 8), ("isize", offs[k + 1] - 4)):
+        bad = bytearray(raw)
+        bad[at] ^= 0x5a
+        p = str(tmp_path / ("bad_%s.fq.gz" % what))
+        open(p, "wb").write(bytes(bad))
+        names, err = _read_names(p)
+        assert err != 0, what
+        assert 0 < len(names) < len(want) and names == want[:len(names)], (what, len(names))   # a prefix: nothing from behind the damage
+        # the text of the blocks before k holds at least len(names) - 1 whole records
+        assert len(names) <= sum(1 for _ in kseq_records(text[:20000 * k + 20000]))
+    names, err = _read_names(bg)
+    assert names == want and err == 0
+    # truncation: BGZF workers, the gzread thread (plain gzip), and no threads at all
+    gz = str(tmp_path / "b.fq.gz")
+    open(gz, "wb").write(gzip.compress(text.encode()))
+    for src, threads in ((bg, "3"), (gz, "3"), (gz, "0"), (bg, "0")):
+        monkeypatch.setenv("BSX_INFLATE_THREADS", threads)
+        cut = str(tmp_path / "cut.fq.gz")
+        data = open(src, "rb").read()
+        open(cut, "wb").write(data[:len(data) * 2 // 3])
+        names, err = _read_names(cut)
+        assert err != 0 and 0 < len(names) < len(want) and names == want[:len(names)], (src, threads, err, len(names))
+
+
+def test_command_line_fails_on_damaged_input(tmp_path):
+    """the CLI (cli.c, here over the CPU restatement of the kernels: oracle_align) turns the reader's sticky error into exit code 1"""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import simdata
+    from biscuit_amd.api import Index
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpu = os.path.join(root, "oracle", "oracle_align")
+    d = str(tmp_path)
+    contigs = simdata.make_genome(60000, seed=5, n_contigs=1)
+    simdata.write_genome(d + "/g.fa", contigs)
+    Index.build(d + "/g.fa", d + "/g").close()
+    simdata.write_fastq(d + "/ok.fq", simdata.make_single(contigs, 400, 100, 3))
+    text = open(d + "/ok.fq").read()
+    write_bgzf(d + "/ok.fq.gz", text.encode(), block=8000)
+    raw = bytearray(open(d + "/ok.fq.gz", "rb").read())
+    first = (raw[16] | raw[17] << 8) + 1
+    raw[first + 18 + 30] ^= 0x33   # inside the second block
+    open(d + "/bad.fq.gz", "wb").write(bytes(raw))
+    ok = subprocess.run([cpu, "-@", "2", "g", "ok.fq.gz"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    bad = subprocess.run([cpu, "-@", "2", "g", "bad.fq.gz"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert ok.returncode == 0 and ok.stdout.count(b"\n") > 400
+    assert bad.returncode == 1 and b"damaged" in bad.stderr, (bad.returncode, bad.stderr[-600:])
+    n_ok = sum(1 for l in ok.stdout.split(b"\n") if l and not l.startswith(b"@"))
+    n_bad = sum(1 for l in bad.stdout.split(b"\n") if l and not l.startswith(b"@"))
+    assert 0 < n_bad < n_ok
+    # and the everyday invocation with a process substitution gives the whole SAM
+    ps = subprocess.run(["bash", "-c", "%s -@ 2 g <(zcat ok.fq.gz)" % cpu], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert ps.returncode == 0
+    strip = lambda b: [l for l in b.split(b"\n") if not l.startswith(b"@PG")]
+    assert strip(ps.stdout) == strip(ok.stdout)

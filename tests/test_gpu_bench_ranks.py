@@ -26,3 +26,25 @@ def test_two_rank_bench_line():
     assert g["in_timed_region"] and g["chunks_received_by_rank0"] == 6 and g["bytes_received_by_rank0"] > 6 * 1000000
     # whole-job rate: both ranks' reads over the slowest rank's time
     assert abs(d["value"] - 2 * d["config"]["reads_per_step_per_gpu"] * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
+
+
+def test_single_rank_bench_line_small():
+    """the default command's line at a small genome: the contract keys, the rooflines' byte definitions, and the CPU baseline's sample
+    through both paths with identical SAM (bench.py, cpu_baseline.sam_identical)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--genome-mbp", "8", "--cpu-sample-pairs", "3000",
+           "--no-long-reads", "--no-cli", "--no-hard-genome"]
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "hg38-like" in d["config"]["workload"] and d["n_gpus"] == 1 and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
+    assert r["per_read"]["regions"] > 0.5 and r["per_read"]["strand_searches"] == 2.0
+    s = d["roofline_seeding"]
+    assert 0 < s["frac"] < 1 and s["reference_equivalent"]["fm_block_touches_per_read"] > s["kernel_touches_per_read"]["fm_blocks"]
+    w = d["roofline_whole_path"]
+    assert w["algorithmic_bytes_per_step"] >= r["algorithmic_bytes_per_launch"] + s["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["sam_identical"] is True and c["sam_crc32_cpu"] == c["sam_crc32_hip"] and c["cores"] >= 1 and c["value"] > 0

@@ -3,6 +3,7 @@
 next to the in-memory bench: python tools/cli_e2e.py [--genome-mbp 128] [--chunks 6]"""
 import argparse
 import ctypes as C
+import json
 import os
 import subprocess
 import sys
@@ -12,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--genome-mbp", type=float, default=128)
-ap.add_argument("--chunks", type=int, default=6)
+ap.add_argument("--chunks", default="6", help="chunks of reads in the FASTQ files; two numbers a,b: two runs, and the steady-state rate from their difference")
+ap.add_argument("--profile", type=int, default=0, help="0: the clean synthetic genome, 1: the hg38-like one (csrc/host/sim.c)")
+ap.add_argument("--json", action="store_true", help="one JSON line (bench.py's cli_end_to_end sub-record)")
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--out", default=None, help="where the SAM goes (default: a file in the work directory; /dev/null isolates the aligner from the write)")
 a = ap.parse_args()
@@ -20,14 +23,14 @@ from biscuit_amd import _lib as B
 from biscuit_amd.api import Index, Device
 L = B.lib()
 n_bases = int(a.genome_mbp * 1e6)
-work = "/tmp/bsx_bench_%d" % n_bases
+work = "/tmp/bsx_bench_%d_p%d" % (n_bases, a.profile)
 base = work + "/g"
 t_build = None
 if not os.path.exists(base + ".dau.sa"):
     os.makedirs(work, exist_ok=True)
     tb = time.time()
     if n_bases > 1_000_000_000:   # past the host builder's 32-bit suffix sorter: both indices on the device, then the seven files
-        g = Index.synthetic(n_bases, seed=2024, n_contigs=24)
+        g = Index.synthetic(n_bases, seed=2024, n_contigs=24, profile=a.profile)
         dev = Device(0)
         dev.build_index(g, fill_host=True)
         g.save(base)
@@ -42,22 +45,35 @@ L.bsx_sim_write_fastq.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_char_p,
 L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
 pairs = 10000000 * a.threads // 300
 fq1, fq2 = work + "/e2e_1.fq", work + "/e2e_2.fq"
-for k in range(a.chunks):
-    p = C.c_void_p()
-    B.check(L.bsx_sim_pairs(idx.h, pairs, 150, 4000 + k, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
-    B.check(L.bsx_sim_write_fastq(p, 2 * pairs, fq1.encode(), fq2.encode(), 1 if k else 0), "write_fastq")
-    L.bsx_sim_free_reads(p, 2 * pairs)
-idx.close()
+runs = []
 env = dict(os.environ, BSX_HOST_THREADS=str(a.threads))
-t0 = time.time()
-outp = a.out or (work + "/e2e.sam")
-with open(outp, "wb") as out:
-    p = subprocess.run([os.path.join(ROOT, "biscuit_amd", "biscuit_align"), "-@", str(a.threads), base, fq1, fq2], stdout=out, stderr=subprocess.PIPE, env=env)
-dt = time.time() - t0
-assert p.returncode == 0, p.stderr.decode()[-2000:]
-if os.environ.get("E2E_STDERR"):
-    open(os.environ["E2E_STDERR"], "wb").write(p.stderr)
-n = 2 * pairs * a.chunks
-print({"cli_end_to_end_reads_per_s": round(n / dt, 1), "reads": n, "seconds": round(dt, 2), "sam_bytes": os.path.getsize(outp), "out": outp,
-       "genome_mbp": a.genome_mbp, "genome_and_index_files_s": t_build, "stderr_tail": p.stderr.decode()[-600:],
-       "includes": "index load + upload, FASTQ parse, alignment, SAM text to a file"})
+written = 0
+for n_chunks in sorted(int(x) for x in a.chunks.split(",")):
+    for k in range(written, n_chunks):   # the longer run's files continue the shorter one's
+        p = C.c_void_p()
+        B.check(L.bsx_sim_pairs(idx.h, pairs, 150, 4000 + k, 200, 500, 0.005, 0.0, C.byref(p)), "sim_pairs")
+        B.check(L.bsx_sim_write_fastq(p, 2 * pairs, fq1.encode(), fq2.encode(), 1 if k else 0), "write_fastq")
+        L.bsx_sim_free_reads(p, 2 * pairs)
+    written = n_chunks
+    t0 = time.time()
+    outp = a.out or (work + "/e2e.sam")
+    with open(outp, "wb") as out:
+        p = subprocess.run([os.path.join(ROOT, "biscuit_amd", "biscuit_align"), "-@", str(a.threads), base, fq1, fq2], stdout=out, stderr=subprocess.PIPE, env=env)
+    dt = time.time() - t0
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    if os.environ.get("E2E_STDERR"):
+        open(os.environ["E2E_STDERR"], "wb").write(p.stderr)
+    runs.append({"chunks": n_chunks, "reads": 2 * pairs * n_chunks, "seconds": round(dt, 2), "reads_per_s_whole_process": round(2 * pairs * n_chunks / dt, 1)})
+idx.close()
+res = {"metric": "reads/s through the command line: FASTQ text in -> SAM text out (biscuit_align -@ %d <index files> r1.fq r2.fq > %s)" % (a.threads, a.out or "file"),
+       "runs": runs, "genome_mbp": a.genome_mbp, "genome_profile": "hg38-like" if a.profile else "clean", "genome_and_index_files_s": t_build,
+       "includes": "index files -> host -> HBM, dense SA sample and table of k-mer intervals rebuilt on the device, FASTQ parse, alignment, SAM text written"}
+if len(runs) >= 2 and runs[-1]["reads"] > runs[0]["reads"]:
+    d_reads, d_s = runs[-1]["reads"] - runs[0]["reads"], runs[-1]["seconds"] - runs[0]["seconds"]
+    res["steady_state_reads_per_s"] = round(d_reads / max(1e-9, d_s), 1)
+    res["steady_state_s_per_chunk"] = round(d_s / (runs[-1]["chunks"] - runs[0]["chunks"]), 3)
+    res["start_up_s"] = round(runs[0]["seconds"] - runs[0]["chunks"] * d_s / (runs[-1]["chunks"] - runs[0]["chunks"]), 2)
+    res["value"], res["unit"] = res["steady_state_reads_per_s"], "reads/s"
+else:
+    res["value"], res["unit"] = runs[-1]["reads_per_s_whole_process"], "reads/s"
+print(json.dumps(res) if a.json else res)

@@ -89,6 +89,7 @@ def pick(agg, kernel):
 fs, ws, hm = pmc_dir("FETCH_SIZE"), pmc_dir("WRITE_SIZE"), pmc_dir("TCC_HIT_sum_TCC_MISS_sum")
 ins = pmc_dir("SQ_WAVES_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS")
 mbp = int(round(float(os.environ.get("GENOME_MBP", "3100"))))
+gprof = os.environ.get("GENOME_PROFILE", "hg38-like")   # the profile the passes ran on (tools/profile_round.sh)
 if fs and ws:
     traffic = {}
     for kern in ("k_seed", "k_occ", "k_regions"):
@@ -96,7 +97,7 @@ if fs and ws:
         def pk(agg, kern=kern):
             tot = collections.defaultdict(float)
             for k, v in agg.items():
-                if k == kern or k.startswith(kern + "<") or (kern == "k_seed" and k.startswith("k_seedt")) or (kern == "k_regions" and k.startswith(("k_regions", "k_c2r", "k_ext_", "k_ext4", "k_extl", "k_x4prep"))):
+                if k == kern or k.startswith(kern + "<") or (kern == "k_seed" and (k.startswith("k_seedt<") or k.startswith("k_seedt_pack"))) or (kern == "k_regions" and k.startswith(("k_regions", "k_c2r", "k_ext_", "k_ext4", "k_extl", "k_x4prep"))):
                     for c, x in v.items():
                         tot[c] += x
             return tot
@@ -107,13 +108,13 @@ if fs and ws:
         if ins:
             for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
                 traffic[kern][c] = pk(ins).get(c, 0.0)
-    traffic["_note"] = ("rocprofv3 --pmc passes (one counter group per run, with --kernel-trace only) of `python bench.py --genome-mbp %d --steps 1 --warmup 0 "
-                        "--no-cpu-baseline --no-pipeline` (one chunk of 1,066,666 reads; tools/profile_round.sh), summed over the dispatches of each kernel "
+    traffic["_note"] = ("rocprofv3 --pmc passes (one counter group per run, with --kernel-trace only) of `python bench.py --genome-profile " + gprof + " --genome-mbp %d --steps 1 --warmup 0 "
+                        "--no-cpu-baseline --no-pipeline --sub` (one chunk of 1,066,666 reads; tools/profile_round.sh), summed over the dispatches of each kernel "
                         "family.  FETCH_SIZE calibration on this access pattern (r01): k_occ reads exactly one 64-byte FM block per LF step; its FETCH_SIZE "
                         "was 0.88 x that byte count at a 7 %% L2 hit rate, i.e. for 64-byte gathers FETCH_SIZE is within a few percent of the bytes that "
                         "miss L2 (not the 1/2 the guide measured for wide coalesced streams)." % mbp)
     traffic["_reads_per_chunk"] = 1066666
-    json.dump(traffic, open(os.path.join(out, "%s_pmc_%dmbp.json" % (tag, mbp)), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, "%s_pmc_%dmbp_%s.json" % (tag, mbp, "hg38like" if gprof == "hg38-like" else "clean")), "w"), indent=1)
 
 kt = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
 if kt:
