@@ -489,7 +489,7 @@ def main():
             if not args.no_cli:
                 try:
                     pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_e2e.py"), "--genome-mbp", str(args.genome_mbp), "--profile", "1" if args.genome_profile == "hg38-like" else "0",
-                                         "--threads", str(threads), "--chunks", "2,6", "--out", "/dev/null", "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+                                         "--threads", str(threads), "--chunks", "7", "--out", "/dev/null", "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
                     out["cli_end_to_end"] = json.loads(pr.stdout.decode().strip().split("\n")[-1])
                 except Exception as e:
                     out["cli_end_to_end"] = {"error": repr(e)[:300]}

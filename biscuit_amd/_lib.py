@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbiscuit_amd.so")
+LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "libbiscuit_amd.so")   # ($BSX_LIB_PATH: a debug build of the same library, tools/dbg/)
 
 
 class Opt(C.Structure):  # bsx_opt_t == mem_opt_t (lib/aln/bwamem.h:54-124)

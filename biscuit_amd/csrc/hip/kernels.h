@@ -35,6 +35,8 @@ void launch_global_hbm(hipStream_t st, const DevIndex &ix, const DevScoring &sc,
                        bsx_glb_tag_t *tags, char *md_pool, unsigned long long md_cap, unsigned long long *md_cursor, void *rows);   // one wave per workgroup
 void launch_sw(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int nc);
+void launch_swl(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_sw_job_t *jobs, const int *order,
+                long long n, bsx_sw_res_t *res, unsigned long long *bscratch, int bcap, int blocks, int slen_max);   // k_swl.hip: byte-sized jobs, four to a wavefront
 void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_glb_job_t *jobs, const int *order,
                    long long n, bsx_glb_res_t *res, uint32_t *pool, uint8_t *zscratch, size_t zstride, int qcap, int nc, int blocks, int wpb,
                    bsx_glb_tag_t *tags = nullptr, char *md_pool = nullptr, unsigned long long md_cap = 0, unsigned long long *md_cursor = nullptr, int tcap = 0);

@@ -1238,37 +1238,58 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
-	std::vector<int> order[3];   // by padded query length: up to 256, 1024, 3072 columns
-	int max_tlen = 1;
+	// byte-sized jobs (KSW_XBYTE, queries of up to 256 columns: mate rescue of ordinary reads) go four to a wavefront through the striped
+	// kernel (k_swl.hip), ordered by stripe count and then by target length, longest first, so that the four jobs of a wavefront are alike;
+	// the others a wavefront each (k_sw.hip), by padded query length: up to 256, 1024, 3072 columns
+	std::vector<int> order[4];
+	int max_tlen = 1, slen_max = 1;
+	static const bool use_swl = !(getenv("BSX_SWL") && atoi(getenv("BSX_SWL")) == 0);   // ($BSX_SWL=0, tests: every job through the wave-per-job kernel)
+	std::vector<int> key;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_sw_job_t &j = jobs[i];
 		if (j.qlen <= 0 || j.tlen < 0) { fprintf(stderr, "[bsx-hip] sw job %lld: invalid\n", (long long)i); return BSX_E_ARG; }
 		const int p = (j.xtra & BSX_KSW_XBYTE) ? 16 : 8, Q = (j.qlen + p - 1) / p * p;
 		if (Q > 3072) { fprintf(stderr, "[bsx-hip] sw job %lld: query %d beyond kernel limit (3072)\n", (long long)i, j.qlen); return BSX_E_ARG; }
-		order[Q <= 256 ? 0 : Q <= 1024 ? 1 : 2].push_back((int)i);
 		max_tlen = std::max(max_tlen, j.tlen);
+		if (use_swl && p == 16 && Q <= 256) { order[3].push_back((int)i); slen_max = std::max(slen_max, Q / 16); }
+		else order[Q <= 256 ? 0 : Q <= 1024 ? 1 : 2].push_back((int)i);
+	}
+	if (order[3].size() > 4) { // counting sort by (stripes, target length descending)
+		const int NK = 17 * 2048;
+		std::vector<int> cnt((size_t)NK + 1, 0), sorted(order[3].size());
+		auto keyof = [&](int i) { const bsx_sw_job_t &j = jobs[i]; return ((j.qlen + 15) >> 4) * 2048 + (2047 - std::min(j.tlen, 2047)); };
+		for (int i : order[3]) ++cnt[(size_t)keyof(i) + 1];
+		for (int x = 0; x < NK; ++x) cnt[(size_t)x + 1] += cnt[(size_t)x];
+		for (int i : order[3]) sorted[(size_t)cnt[(size_t)keyof(i)]++] = i;
+		order[3].swap(sorted);
 	}
 	int rc;
 	const int blocks_cap = d->n_cu * 8;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_sw_job_t))) != BSX_OK) return rc;
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
-	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;
+	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;   // b[] of every job in flight: four jobs to a wave in k_swl
 	static const bool tr_sw = getenv("BSX_PHASES") != nullptr;
 	const double ts0 = tr_sw ? bsx_now_s() : 0;
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t));
 	size_t off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
 		H2D(L.st_hi, (int*)L.aux.p + off, order[c].data(), order[c].size() * 4);
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev0, L.st_hi));
 	off = 0;
-	for (int c = 0; c < 3; ++c) if (!order[c].empty()) {
+	for (int c = 0; c < 4; ++c) if (!order[c].empty()) {
 		const long long m = (long long)order[c].size();
-		const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
-		launch_sw(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
-		          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : c == 1 ? 16 : 48);
+		if (c == 3) {
+			const int blocks = (int)std::min<long long>((m + 15) / 16, blocks_cap);
+			launch_swl(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
+			           (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, slen_max);
+		} else {
+			const int blocks = (int)std::min<long long>((m + 3) / 4, blocks_cap);
+			launch_sw(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.jobs.p, (const int*)L.aux.p + off, m,
+			          (bsx_sw_res_t*)L.res.p, (unsigned long long*)L.scratch.p, max_tlen, blocks, c == 0 ? 4 : c == 1 ? 16 : 48);
+		}
 		off += order[c].size();
 	}
 	HIPCHK(hipEventRecord(L.ev1, L.st_hi));

@@ -48,6 +48,7 @@ fq1, fq2 = work + "/e2e_1.fq", work + "/e2e_2.fq"
 runs = []
 env = dict(os.environ, BSX_HOST_THREADS=str(a.threads))
 written = 0
+import threading
 for n_chunks in sorted(int(x) for x in a.chunks.split(",")):
     for k in range(written, n_chunks):   # the longer run's files continue the shorter one's
         p = C.c_void_p()
@@ -55,25 +56,37 @@ for n_chunks in sorted(int(x) for x in a.chunks.split(",")):
         B.check(L.bsx_sim_write_fastq(p, 2 * pairs, fq1.encode(), fq2.encode(), 1 if k else 0), "write_fastq")
         L.bsx_sim_free_reads(p, 2 * pairs)
     written = n_chunks
-    t0 = time.time()
     outp = a.out or (work + "/e2e.sam")
-    with open(outp, "wb") as out:
-        p = subprocess.run([os.path.join(ROOT, "biscuit_amd", "biscuit_align"), "-@", str(a.threads), base, fq1, fq2], stdout=out, stderr=subprocess.PIPE, env=env)
+    done_at, err_lines = [], []
+    t0 = time.time()
+    with open(outp, "wb") as sam:
+        pr = subprocess.Popen([os.path.join(ROOT, "biscuit_amd", "biscuit_align"), "-@", str(a.threads), base, fq1, fq2], stdout=sam, stderr=subprocess.PIPE, env=env)
+
+        def watch():   # when each chunk's SAM is complete: the command line says so on stderr ([M::bsx_process_seqs] Processed ...)
+            for line in pr.stderr:
+                err_lines.append(line)
+                if b"Processed" in line:
+                    done_at.append(time.time() - t0)
+        th = threading.Thread(target=watch)
+        th.start()
+        rc = pr.wait()
+        th.join()
     dt = time.time() - t0
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert rc == 0, b"".join(err_lines)[-2000:].decode(errors="replace")
     if os.environ.get("E2E_STDERR"):
-        open(os.environ["E2E_STDERR"], "wb").write(p.stderr)
-    runs.append({"chunks": n_chunks, "reads": 2 * pairs * n_chunks, "seconds": round(dt, 2), "reads_per_s_whole_process": round(2 * pairs * n_chunks / dt, 1)})
+        open(os.environ["E2E_STDERR"], "wb").write(b"".join(err_lines))
+    r = {"chunks": n_chunks, "reads": 2 * pairs * n_chunks, "seconds": round(dt, 2), "reads_per_s_whole_process": round(2 * pairs * n_chunks / dt, 1),
+         "chunk_done_at_s": [round(x, 2) for x in done_at]}
+    if len(done_at) >= 3:   # chunks complete at the stream's rate once the pipeline is full: first completion to last
+        r["steady_state_s_per_chunk"] = round((done_at[-1] - done_at[0]) / (len(done_at) - 1), 3)
+        r["steady_state_reads_per_s"] = round(2 * pairs / max(1e-9, r["steady_state_s_per_chunk"]), 1)
+        r["start_up_and_fill_s"] = round(done_at[0], 2)
+    runs.append(r)
 idx.close()
 res = {"metric": "reads/s through the command line: FASTQ text in -> SAM text out (biscuit_align -@ %d <index files> r1.fq r2.fq > %s)" % (a.threads, a.out or "file"),
        "runs": runs, "genome_mbp": a.genome_mbp, "genome_profile": "hg38-like" if a.profile else "clean", "genome_and_index_files_s": t_build,
-       "includes": "index files -> host -> HBM, dense SA sample and table of k-mer intervals rebuilt on the device, FASTQ parse, alignment, SAM text written"}
-if len(runs) >= 2 and runs[-1]["reads"] > runs[0]["reads"]:
-    d_reads, d_s = runs[-1]["reads"] - runs[0]["reads"], runs[-1]["seconds"] - runs[0]["seconds"]
-    res["steady_state_reads_per_s"] = round(d_reads / max(1e-9, d_s), 1)
-    res["steady_state_s_per_chunk"] = round(d_s / (runs[-1]["chunks"] - runs[0]["chunks"]), 3)
-    res["start_up_s"] = round(runs[0]["seconds"] - runs[0]["chunks"] * d_s / (runs[-1]["chunks"] - runs[0]["chunks"]), 2)
-    res["value"], res["unit"] = res["steady_state_reads_per_s"], "reads/s"
-else:
-    res["value"], res["unit"] = runs[-1]["reads_per_s_whole_process"], "reads/s"
+       "includes": "index files -> host -> HBM, dense SA sample and table of k-mer intervals rebuilt on the device, FASTQ parse, alignment, SAM text written",
+       "steady_state_is": "the time from the first chunk's SAM being complete to the last one's, per chunk (the start-up -- index load and upload, pipeline fill -- is reported beside it)"}
+best = runs[-1]
+res["value"], res["unit"] = best.get("steady_state_reads_per_s", best["reads_per_s_whole_process"]), "reads/s"
 print(json.dumps(res) if a.json else res)
