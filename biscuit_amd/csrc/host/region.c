@@ -512,3 +512,26 @@ int bsx_approx_mapq_se(const bsx_opt_t *opt, const reg_t *a)
 	mapq = (int)(mapq * (1. - a->frac_rep) + .499);
 	return mapq;
 }
+
+/* ---- test hooks (tests/test_oracle_golden.py): the functions above that restate header-inline functions of the reference, against the
+ * reference's own, recorded in tests/golden/ref_vectors.npz.  a / b: rid, rb, re, qb, qe of a region */
+static void hook_mk_pair(bsx_refmeta_t *ref, reg_t r[2], int64_t l_pac, const int64_t a[5], const int64_t b[5])
+{
+	memset(ref, 0, sizeof(*ref)); memset(r, 0, 2 * sizeof(reg_t));
+	ref->l_pac = l_pac;
+	r[0].rid = (int)a[0]; r[0].rb = a[1]; r[0].re = a[2]; r[0].qb = (int)a[3]; r[0].qe = (int)a[4];
+	r[1].rid = (int)b[0]; r[1].rb = b[1]; r[1].re = b[2]; r[1].qb = (int)b[3]; r[1].qe = (int)b[4];
+}
+BSX_API int bsx_hook_infer_isize(int64_t pos1, int64_t pos2, int isrev1, int isrev2, int len1, int len2, int64_t *isize)
+{ return infer_isize(pos1, pos2, isrev1, isrev2, len1, len2, isize); }
+BSX_API int bsx_hook_reg_isize(int64_t l_pac, const int64_t a[5], const int64_t b[5], int64_t *isize)
+{ bsx_refmeta_t ref; reg_t r[2]; hook_mk_pair(&ref, r, l_pac, a, b); return bsx_reg_isize(&ref, &r[0], &r[1], isize); }
+BSX_API int bsx_hook_region_depos(int64_t l_pac, int64_t contig_offset, int64_t rb, int64_t re)
+{
+	bsx_refmeta_t ref; bsx_ann_t ann; reg_t r;
+	memset(&ref, 0, sizeof(ref)); memset(&ann, 0, sizeof(ann)); memset(&r, 0, sizeof(r));
+	ref.l_pac = l_pac; ref.n_seqs = 1; ref.anns = &ann; ann.offset = contig_offset;
+	r.rid = 0; r.rb = rb; r.re = re;
+	return region_depos(&ref, &r);
+}
+BSX_API int64_t bsx_hook_depos(int64_t l_pac, int64_t pos, int *is_rev) { return bsx_depos(l_pac, pos, is_rev); }

@@ -593,3 +593,24 @@ BSX_API int bsx_hook_setsam_finish(const bsx_opt_t *opt, const bsx_index_t *idx,
 	bsx_cfree(rec.cigar);
 	return k;
 }
+
+/* ---- test hooks (tests/test_oracle_golden.py): restated header-inline functions against the reference's own (ref_vectors.npz) */
+BSX_API int bsx_hook_get_rlen(int n_cigar, const uint32_t *cigar) { return get_rlen(n_cigar, cigar); }
+BSX_API int bsx_hook_get_pri_idx(double XA_drop_ratio, int n, const int *score, const int *secondary_all, int i)
+{
+	reg_t *a = (reg_t*)calloc((size_t)n, sizeof(reg_t));
+	int k, r;
+	for (k = 0; k < n; ++k) { a[k].score = score[k]; a[k].secondary_all = secondary_all[k]; }
+	r = get_pri_idx(XA_drop_ratio, a, i);
+	free(a);
+	return r;
+}
+BSX_API int bsx_hook_is_proper_pair(int64_t l_pac, const int64_t a[5], const int64_t b[5], int low, int high)
+{
+	bsx_refmeta_t ref; reg_t r[2]; bsx_pestat_t pes;
+	memset(&ref, 0, sizeof(ref)); memset(r, 0, sizeof(r)); memset(&pes, 0, sizeof(pes));
+	ref.l_pac = l_pac; pes.low = low; pes.high = high;
+	r[0].rid = (int)a[0]; r[0].rb = a[1]; r[0].re = a[2]; r[0].qb = (int)a[3]; r[0].qe = (int)a[4];
+	r[1].rid = (int)b[0]; r[1].rb = b[1]; r[1].re = b[2]; r[1].qb = (int)b[3]; r[1].qe = (int)b[4];
+	return is_proper_pair(&ref, &r[0], &r[1], &pes);
+}

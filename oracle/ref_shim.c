@@ -217,6 +217,47 @@ API void ref_bsconvert(int l, const uint8_t *seq, int parent, uint8_t *out)
 }
 /* infer_bw (bwamem.h:192) */
 API int ref_infer_bw(int l1, int l2, int score, int a, int q, int r) { return infer_bw(l1, l2, score, a, q, r); }
+/* ---- the header-inline functions of the pairing / formatting code (mem_alnreg.h, bwamem.h, bntseq.h): the .c files around them do
+ * not build here, these do -- each forward builds the reference's own structs from plain arguments and calls the inline function */
+/* mem_infer_isize (mem_alnreg.h:75-83) */
+API int ref_infer_isize(int64_t pos1, int64_t pos2, int isrev1, int isrev2, int len1, int len2, int64_t *isize)
+{ return mem_infer_isize(pos1, pos2, isrev1, isrev2, len1, len2, isize); }
+static void ref_mk_pair(bntseq_t *bns, mem_alnreg_t r[2], int64_t l_pac, const int64_t a[5], const int64_t b[5])   /* rid, rb, re, qb, qe */
+{
+	memset(bns, 0, sizeof(*bns)); memset(r, 0, 2 * sizeof(mem_alnreg_t));
+	bns->l_pac = l_pac;
+	r[0].rid = (int)a[0]; r[0].rb = a[1]; r[0].re = a[2]; r[0].qb = (int)a[3]; r[0].qe = (int)a[4];
+	r[1].rid = (int)b[0]; r[1].rb = b[1]; r[1].re = b[2]; r[1].qb = (int)b[3]; r[1].qe = (int)b[4];
+}
+/* mem_alnreg_isize (mem_alnreg.h:86-93) */
+API int ref_alnreg_isize(int64_t l_pac, const int64_t a[5], const int64_t b[5], int64_t *isize)
+{ bntseq_t bns; mem_alnreg_t r[2]; ref_mk_pair(&bns, r, l_pac, a, b); return mem_alnreg_isize(&bns, &r[0], &r[1], isize); }
+/* is_proper_pair (mem_alnreg.h:95-100) */
+API int ref_is_proper_pair(int64_t l_pac, const int64_t a[5], const int64_t b[5], int low, int high)
+{ bntseq_t bns; mem_alnreg_t r[2]; mem_pestat_t pes; ref_mk_pair(&bns, r, l_pac, a, b); memset(&pes, 0, sizeof(pes)); pes.low = low; pes.high = high; return is_proper_pair(&bns, &r[0], &r[1], pes); }
+/* get_pri_idx (mem_alnreg.h:127-131) over n regions given by score and secondary_all */
+API int ref_get_pri_idx(double XA_drop_ratio, int n, const int *score, const int *secondary_all, int i)
+{
+	mem_alnreg_t *a = (mem_alnreg_t*)calloc((size_t)n, sizeof(mem_alnreg_t));
+	int k, r;
+	for (k = 0; k < n; ++k) { a[k].score = score[k]; a[k].secondary_all = secondary_all[k]; }
+	r = get_pri_idx(XA_drop_ratio, a, i);
+	free(a);
+	return r;
+}
+/* region_depos (mem_alnreg.h:139-144): position of a region on its contig, forward strand */
+API int ref_region_depos(int64_t l_pac, int64_t contig_offset, int64_t rb, int64_t re, int *is_rev)
+{
+	bntseq_t bns; bntann1_t ann; mem_alnreg_t r;
+	memset(&bns, 0, sizeof(bns)); memset(&ann, 0, sizeof(ann)); memset(&r, 0, sizeof(r));
+	bns.l_pac = l_pac; bns.n_seqs = 1; bns.anns = &ann; ann.offset = contig_offset;
+	r.rid = 0; r.rb = rb; r.re = re;
+	return region_depos(&bns, &r, is_rev);
+}
+/* get_rlen (bwamem.h:200-208) */
+API int ref_get_rlen(int n_cigar, const uint32_t *cigar) { return get_rlen(n_cigar, cigar); }
+/* bns_depos (bntseq.h:92-94) */
+API int64_t ref_bns_depos(int64_t l_pac, int64_t pos, int *is_rev) { bntseq_t bns; memset(&bns, 0, sizeof(bns)); bns.l_pac = l_pac; return bns_depos(&bns, pos, is_rev); }
 /* hash_64 (utils.h:107) */
 API uint64_t ref_hash_64(uint64_t k) { return hash_64(k); }
 

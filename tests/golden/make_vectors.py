@@ -390,5 +390,77 @@ for n1, n2 in NAME_OK:
     R.ref_check_paired_read_names(n1.encode(), n2.encode())      # returns: accepted by the reference
 out["names_ok"] = np.frombuffer("\x1e".join("\x1f".join(p) for p in NAME_OK).encode(), np.uint8)
 
+# ---- the header-inline functions of the pairing / formatting code (mem_alnreg.h:75-144, bwamem.h:200, bntseq.h:92): a generator of its
+# own, so that the vectors above stay what they were
+prng = np.random.default_rng(5150)
+i64p, i32p, u32p = C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_uint32)
+L_PAC = 1000000
+R.ref_infer_isize.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, i64p]
+R.ref_alnreg_isize.argtypes = [C.c_int64, i64p, i64p, i64p]
+R.ref_is_proper_pair.argtypes = [C.c_int64, i64p, i64p, C.c_int, C.c_int]
+R.ref_get_pri_idx.argtypes = [C.c_double, C.c_int, i32p, i32p, C.c_int]
+R.ref_region_depos.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32p]
+R.ref_get_rlen.argtypes = [C.c_int, u32p]
+R.ref_bns_depos.argtypes = [C.c_int64, C.c_int64, i32p]
+R.ref_bns_depos.restype = C.c_int64
+rows = []
+for _ in range(400):   # pos1 pos2 isrev1 isrev2 len1 len2 -> ok isize
+    a = [int(prng.integers(0, 2 * L_PAC)), int(prng.integers(0, 2 * L_PAC)), int(prng.integers(0, 2)), int(prng.integers(0, 2)), int(prng.integers(1, 300)), int(prng.integers(1, 300))]
+    iz = C.c_int64(-12345)
+    ok = R.ref_infer_isize(*a, C.byref(iz))
+    rows.append(a + [ok, iz.value if ok else 0])
+out["isize_infer"] = np.array(rows, np.int64)
+rows = []
+for k in range(1200):   # two regions (rid rb re qb qe) around the strand boundary, often close to each other, + low high -> ok isize proper
+    def reg(near=None):
+        ln = int(prng.integers(20, 200))
+        if near is not None and prng.random() < 0.7:   # a mate within a kilobase on the other strand (mirror image), or the same
+            mid = (2 * L_PAC - 1 - near) if prng.random() < 0.8 else near
+            rb = int(np.clip(mid + prng.integers(-900, 900), 0, 2 * L_PAC - 1))
+        else:
+            rb = int(prng.integers(0, 2 * L_PAC)) if k % 7 else int(L_PAC + prng.integers(-3, 4))
+        qb = int(prng.integers(0, 40))
+        return [int(prng.integers(0, 3)) if prng.random() < 0.2 else 1, rb, rb + ln, qb, qb + ln]
+    a = reg(); b = reg(a[1])
+    low, high = int(prng.integers(-50, 300)), int(prng.integers(300, 1200))
+    aa, bb = np.array(a, np.int64), np.array(b, np.int64)
+    iz = C.c_int64(-12345)
+    ok = R.ref_alnreg_isize(L_PAC, P(aa, i64p), P(bb, i64p), C.byref(iz))
+    pp = R.ref_is_proper_pair(L_PAC, P(aa, i64p), P(bb, i64p), low, high)
+    rows.append(a + b + [low, high, ok, iz.value if ok else 0, pp])
+out["isize_pair"] = np.array(rows, np.int64)
+assert 50 < sum(r[-1] for r in rows) < 1150 and 100 < sum(r[-3] for r in rows)   # both answers occur often
+rows = []
+for _ in range(300):   # XA_drop_ratio, i, then 8 scores and 8 secondary_all -> index
+    n = 8
+    sc = prng.integers(20, 150, n).astype(np.int32)
+    sa = prng.integers(-1, n, n).astype(np.int32)
+    ratio = float(np.float32(prng.choice([0.8, 0.5, 1.0, 0.95])))   # the option is a float (mem_opt_t.XA_drop_ratio) widened to the function's double
+    if _ % 3 == 0:   # borderline: a[i].score == a[k].score * ratio up to rounding
+        sa[:] = 0; sc[0] = 100; sc[1:] = [80, 50, 95, 81, 79, 100, 49]
+    i = int(prng.integers(0, n))
+    r = R.ref_get_pri_idx(ratio, n, P(sc, i32p), P(sa, i32p), i)
+    rows.append([ratio, i] + [float(x) for x in sc] + [float(x) for x in sa] + [r])
+out["pri_idx"] = np.array(rows, np.float64)
+rows = []
+for _ in range(300):   # l_pac offset rb re -> pos is_rev ; and bns_depos of rb
+    off = int(prng.integers(0, L_PAC // 2))
+    ln = int(prng.integers(1, 300))
+    fwd = prng.random() < 0.5
+    rb = int(prng.integers(off, L_PAC - ln)) if fwd else int(prng.integers(L_PAC, 2 * L_PAC - off - ln))
+    isr, isr2 = C.c_int(-1), C.c_int(-1)
+    pos = R.ref_region_depos(L_PAC, off, rb, rb + ln, C.byref(isr))
+    dp = R.ref_bns_depos(L_PAC, rb, C.byref(isr2))
+    rows.append([L_PAC, off, rb, rb + ln, pos, isr.value, dp, isr2.value])
+out["region_depos"] = np.array(rows, np.int64)
+cg, cgo = [], []
+for _ in range(200):   # CIGARs (op in the low 4 bits: M I D S H and N) -> reference length
+    n = int(prng.integers(0, 9))
+    c = (prng.integers(1, 200, n).astype(np.uint32) << 4) | prng.integers(0, 6, n).astype(np.uint32)
+    cg.append(c)
+    cgo.append(R.ref_get_rlen(n, P(np.ascontiguousarray(c), u32p)) if n else R.ref_get_rlen(0, None))
+out["rlen_cigar"], out["rlen_cigar_off"] = ragged(cg, np.uint32)
+out["rlen_out"] = np.array(cgo, np.int32)
+
 np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
 print("wrote", os.path.join(HERE, "ref_vectors.npz"), os.path.getsize(os.path.join(HERE, "ref_vectors.npz")), "bytes")

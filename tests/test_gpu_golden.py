@@ -106,6 +106,50 @@ def test_sw_kernel_vs_reference_vectors(V, tmp_path):
     dev.close()
 
 
+def test_global_kernel_vs_reference_vectors(V, tmp_path):
+    """k_global (K6) against ksw_global2 outputs recorded from the reference (gl_score / gl_cigar): the kernel folds the band set-up of
+    bis_bwa_gen_cigar2 in (bwa.c:325-333: w = max(min((max_gap + |d| + 1) >> 1, w_), |d| + 3)), so the vectors used are the ones whose
+    recorded band is the band that rule gives when it is passed as w_."""
+    idx, start = _genome_of_targets(str(tmp_path), "gl", V["gl_t"], V["gl_toff"])
+    dev = Device(0); dev.upload_index(idx)
+    qo, to, co = V["gl_qoff"], V["gl_toff"], V["gl_coff"]
+    dev.set_reads(V["gl_q"])
+    par = V["gl_par"]
+    groups = {}
+    for i in range(len(par)):
+        if start[i] < 0 or (V["gl_q"][qo[i]:qo[i + 1]] > 3).any():
+            continue
+        a, b, which, od, ed, oi, ei, w, wc = [int(x) for x in par[i]]
+        lq, lt = int(qo[i + 1] - qo[i]), int(to[i + 1] - to[i])
+        max_ins = int(float(((lq + 1) >> 1) * a - oi) / ei + 1.)
+        max_del = int(float(((lq + 1) >> 1) * a - od) / ed + 1.)
+        max_gap = max(max_ins, max_del, 1)
+        if w > (max_gap + abs(lt - lq) + 1) >> 1:
+            continue    # bis_bwa_gen_cigar2 would narrow this band
+        groups.setdefault((a, b, od, ed, oi, ei), []).append(i)
+    n = n_cig = 0
+    for key, ids in groups.items():
+        dev.set_opt(_opt(key[0], key[1], key[2:6]))
+        jobs = np.zeros(len(ids), dtype=GLB_DT)
+        cig_off = 0
+        for k, i in enumerate(ids):
+            a, b, which, od, ed, oi, ei, w, wc = [int(x) for x in par[i]]
+            cap = int(co[i + 1] - co[i]) + 8
+            jobs[k] = (start[i], qo[i], qo[i + 1] - qo[i], to[i + 1] - to[i], w, 1 << 20, 0, 1, cig_off, cap, 1, 1, 1 if which == 1 else 0, wc)
+            cig_off += cap
+        res, pool = dev.global_(jobs, cig_off)
+        for k, i in enumerate(ids):
+            assert int(res[k]["score"]) == int(V["gl_score"][i]), (key, i, res[k], V["gl_score"][i])
+            if int(par[i][8]):
+                nc = int(res[k]["n_cigar"])
+                off = int(jobs[k]["cigar_off"])
+                assert list(pool[off:off + nc]) == list(V["gl_cigar"][co[i]:co[i + 1]]), (key, i)
+                n_cig += 1
+        n += len(ids)
+    assert n > 120 and n_cig > 80, (n, n_cig)
+    dev.close()
+
+
 def test_fm_kernels_vs_reference_vectors(V, tmp_path):
     """K1-K3 on the committed 24 kb genome against vectors recorded from the real reference: the seeding kernel's interval
     lists == the lists the reference's bwt_smem1a / bwt_seed_strategy1 give when driven as mem_collect_intv drives them

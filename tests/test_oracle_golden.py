@@ -274,3 +274,62 @@ def test_read_clipping_vs_reference(V):
         assert L.bsx_hook_pair_names_ok(n1.encode(), n2.encode()) == 1
     for n1, n2 in (("r1", "r3"), ("a/1", "b/2"), ("x2", "x1")):
         assert L.bsx_hook_pair_names_ok(n1.encode(), n2.encode()) == 0
+
+
+def test_header_inline_functions_of_the_pairing_code(V):
+    """mem_infer_isize / mem_alnreg_isize / is_proper_pair / get_pri_idx / region_depos (mem_alnreg.h:75-144), get_rlen (bwamem.h:200) and
+    bns_depos (bntseq.h:92): the reference's own inline functions (compiled through oracle/ref_shim.c, recorded in ref_vectors.npz)
+    against the product's restatements in region.c / sam.c and against oracle/backhalf.py, which the end-to-end oracle uses."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import backhalf
+    import e2e
+    L = B.lib()
+    i64p = C.POINTER(C.c_int64)
+    L.bsx_hook_infer_isize.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, i64p]
+    L.bsx_hook_reg_isize.argtypes = [C.c_int64, i64p, i64p, i64p]
+    L.bsx_hook_is_proper_pair.argtypes = [C.c_int64, i64p, i64p, C.c_int, C.c_int]
+    L.bsx_hook_get_pri_idx.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.bsx_hook_region_depos.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    L.bsx_hook_depos.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int)]
+    L.bsx_hook_depos.restype = C.c_int64
+    L.bsx_hook_get_rlen.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    l_pac = 1000000
+    for r in V["isize_infer"]:
+        p1, p2, r1, r2, l1, l2, ok, isz = [int(x) for x in r]
+        iz = C.c_int64(0)
+        assert L.bsx_hook_infer_isize(p1, p2, r1, r2, l1, l2, C.byref(iz)) == ok and (not ok or iz.value == isz)
+        got = backhalf.infer_isize(p1, p2, r1, r2, l1, l2)
+        assert (got is not None) == bool(ok) and (not ok or got == isz)
+    n_ok = n_pp = 0
+    for r in V["isize_pair"]:
+        a, b = np.array(r[0:5], np.int64), np.array(r[5:10], np.int64)
+        low, high, ok, isz, pp = [int(x) for x in r[10:15]]
+        iz = C.c_int64(0)
+        assert L.bsx_hook_reg_isize(l_pac, a.ctypes.data_as(i64p), b.ctypes.data_as(i64p), C.byref(iz)) == ok and (not ok or iz.value == isz), r
+        assert L.bsx_hook_is_proper_pair(l_pac, a.ctypes.data_as(i64p), b.ctypes.data_as(i64p), low, high) == pp, r
+        d1 = dict(rid=int(a[0]), rb=int(a[1]), re=int(a[2]), qb=int(a[3]), qe=int(a[4]))
+        d2 = dict(rid=int(b[0]), rb=int(b[1]), re=int(b[2]), qb=int(b[3]), qe=int(b[4]))
+        got = backhalf.alnreg_isize(l_pac, d1, d2)
+        assert (got is not None) == bool(ok) and (not ok or got == isz), r
+        assert int(got is not None and low <= got <= high) == pp
+        n_ok += ok; n_pp += pp
+    assert n_ok > 100 and n_pp > 50
+    for r in V["pri_idx"]:
+        ratio, i = float(r[0]), int(r[1])
+        sc = np.array(r[2:10], np.int32); sa = np.array(r[10:18], np.int32)
+        want = int(r[18])
+        assert L.bsx_hook_get_pri_idx(ratio, 8, sc.ctypes.data_as(C.POINTER(C.c_int)), sa.ctypes.data_as(C.POINTER(C.c_int)), i) == want
+        regs = [dict(score=int(sc[k]), secondary_all=int(sa[k])) for k in range(8)]
+        assert backhalf._pri_idx(dict(XA_drop_ratio=ratio), regs, i) == want and e2e._pri_idx(dict(XA_drop_ratio=ratio), regs, i) == want
+    for r in V["region_depos"]:
+        lp, off, rb, re, pos, isr, dp, isr2 = [int(x) for x in r]
+        assert L.bsx_hook_region_depos(lp, off, rb, re) == pos
+        assert backhalf.region_depos(lp, [off], dict(rid=0, rb=rb, re=re)) == pos
+        fl = C.c_int(-1)
+        assert L.bsx_hook_depos(lp, rb, C.byref(fl)) == dp and fl.value == isr2
+    cg, co = V["rlen_cigar"], V["rlen_cigar_off"]
+    for i, want in enumerate(V["rlen_out"]):
+        c = np.ascontiguousarray(cg[co[i]:co[i + 1]], np.uint32)
+        assert L.bsx_hook_get_rlen(len(c), c.ctypes.data_as(C.POINTER(C.c_uint32))) == int(want)
+        assert backhalf.get_rlen([int(x) for x in c]) == int(want) and e2e.get_rlen([int(x) for x in c]) == int(want)
