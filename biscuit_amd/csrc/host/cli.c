@@ -18,6 +18,31 @@ BSX_API char *bsx_pg_line = 0;
  * identical to the single-process run once the chunks are written back in order.  The launcher
  * (biscuit_amd/multi_gpu.py) installs an emit hook and gathers the text over RCCL. */
 BSX_API int bsx_shard_rank = 0, bsx_shard_world = 1;
+/* 0: the chunks of the input are dealt to the ranks (chunk k to rank k % world).  1: every rank takes every chunk and aligns its own
+ * slice of the chunk's pairs (for inputs with fewer chunks than GPUs); the insert-size statistics are those of the whole
+ * chunk (bsx_pes_hist_hook, region.c), the slices leave in rank order as chunks k * world + rank of the gather */
+BSX_API int bsx_shard_mode = 0;
+void bsx_pestat_sync_empty(const bsx_opt_t *opt);
+void bsx_chunk_slice_offset(int64_t first);
+extern void (*bsx_pes_hist_hook)(void *ud, int64_t *hist, int n_bins);
+#define CHUNK_WORLD (bsx_shard_mode ? 1 : bsx_shard_world)
+#define CHUNK_RANK (bsx_shard_mode ? 0 : bsx_shard_rank)
+/* this rank's slice of a chunk (within-chunk sharding): reads [*a, *a + return) of n, whole pairs */
+static int shard_slice(int n, int is_pe, int *a)
+{
+	const int unit = is_pe ? 2 : 1, U = n / unit;
+	const int ua = (int)((int64_t)U * bsx_shard_rank / bsx_shard_world), ub = (int)((int64_t)U * (bsx_shard_rank + 1) / bsx_shard_world);
+	*a = ua * unit;
+	return (ub - ua) * unit;
+}
+/* keep reads [a, a + m) of the chunk, release the others */
+static void shard_trim(bsx_read_t *seqs, int n, int a, int m)
+{
+	int i;
+	for (i = 0; i < a; ++i) bsx_read_free(&seqs[i]);
+	for (i = a + m; i < n; ++i) bsx_read_free(&seqs[i]);
+	if (a > 0 && m > 0) memmove(seqs, seqs + a, (size_t)m * sizeof(bsx_read_t));
+}
 BSX_API void (*bsx_emit_hook)(void *ud, int64_t chunk, const char *text, size_t len) = 0;
 BSX_API void *bsx_emit_ud = 0;   /* "@PG\t..." set by the program entry, printed after the header lines */
 
@@ -204,7 +229,7 @@ static volatile int g_write_error = 0;   /* a write to stdout failed (the refere
 static bsx_fq_scan_t *shard_scan_start(const char *fn1, const char *fn2, int chunk)
 {
 	bsx_fq_scan_t *s;
-	if (bsx_shard_world <= 1 || getenv("BSX_NO_CHUNK_SCAN")) return 0;
+	if (CHUNK_WORLD <= 1 || getenv("BSX_NO_CHUNK_SCAN")) return 0;
 	s = bsx_fq_scan_start(fn1, fn2, chunk);
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] rank %d of %d: %s\n", "main_align", bsx_shard_rank, bsx_shard_world,
 	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank inflates all of it, parses its own chunks and walks the others without building records");
@@ -218,7 +243,7 @@ static void *reader_main(void *arg)
 	bsx_fq_scan_t *scan = shard_scan_start(R->fn1, R->fn2, R->chunk);
 	/* several ranks over input that cannot be sought in (compressed, piped): the chunks of the other ranks are walked without building
 	 * their records (bsx_fq_skip_chunk); this rank's own are parsed in place, the inflate threads of fastq.c running ahead of both */
-	const int skip_mode = !scan && bsx_shard_world > 1 && !getenv("BSX_NO_CHUNK_SKIP");
+	const int skip_mode = !scan && CHUNK_WORLD > 1 && !getenv("BSX_NO_CHUNK_SKIP");
 	int64_t n_before = 0;
 	bsx_fq_pair_t *P = (scan || skip_mode) ? 0 : bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
 	if (scan) idx = bsx_shard_rank;
@@ -482,16 +507,31 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				int64_t size = 0;
 				for (i = 0; i < r.n; ++i) size += r.seqs[i].l_seq;
 				if (r.n_before >= 0) n_processed = r.n_before;   /* the reader skipped the chunks of the other ranks */
-				if (bsx_shard_world > 1 && r.idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
+				if (CHUNK_WORLD > 1 && r.idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
 					n_processed += r.n;
 					for (i = 0; i < r.n; ++i) bsx_read_free(&r.seqs[i]);
 					free(r.seqs);
 					continue;
 				}
 				if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", r.n, (long)size);
+				if (bsx_shard_mode && bsx_shard_world > 1) { /* this rank's slice of the chunk */
+					int a = 0, m = shard_slice(r.n, (opt->flag & BSX_F_PE) != 0, &a);
+					const int n_all = r.n, short_chunk = r.n / ((opt->flag & BSX_F_PE) ? 2 : 1) < bsx_shard_world;
+					shard_trim(r.seqs, r.n, a, m);
+					r.n = m; r.idx = r.idx * bsx_shard_world + bsx_shard_rank;
+					/* a chunk with fewer pairs than ranks leaves some slices empty: every rank brings its pipeline to this chunk first, so that
+					 * the exchange of the insert-size histograms is everybody's next one */
+					if (short_chunk) { rc = bsx_stream_flush(stream); while (rc == BSX_OK && n_pend) { chunk_rec_t d; d.seqs = pend[0].seqs; d.n = pend[0].n; d.idx = pend[0].idx; d.ok = 1; d.n_before = -1; cq_put(&out_q, d); for (i = 1; i < n_pend; ++i) pend[i - 1] = pend[i]; --n_pend; } }
+					if (rc == BSX_OK && m > 0) { bsx_chunk_slice_offset(a); rc = bsx_stream_push(stream, n_processed + a, m, r.seqs); }
+					if (rc == BSX_OK && short_chunk) { rc = bsx_stream_flush(stream); if (m == 0 && (opt->flag & BSX_F_PE) && !pes0) bsx_pestat_sync_empty(opt); }
+					if (m > 0 && !short_chunk) { pend[n_pend].seqs = r.seqs; pend[n_pend].n = m; pend[n_pend].idx = r.idx; ++n_pend; }
+					else { chunk_rec_t d; d.seqs = r.seqs; d.n = m; d.idx = r.idx; d.ok = rc == BSX_OK; d.n_before = -1; cq_put(&out_q, d); }   /* (done, or empty: straight to the writer) */
+					n_processed += n_all;
+				} else {
 				rc = bsx_stream_push(stream, n_processed, r.n, r.seqs);
 				pend[n_pend].seqs = r.seqs; pend[n_pend].n = r.n; pend[n_pend].idx = r.idx; ++n_pend;
 				n_processed += r.n;
+				}
 				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; R.stop = 1; break; }
 				if (g_write_error) { rc = 1; R.stop = 1; break; }
 				while (n_pend > depth - 1) { /* the push completed the oldest chunk in flight */
@@ -537,13 +577,13 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 				if (chunk_idx < 0) scan = shard_scan_start(argv[optind + 1], f2 ? argv[optind + 2] : 0, chunk);
 				if (scan) { /* straight to this rank's next chunk (see reader_main) */
 					bsx_fq_chunkpos_t cp;
-					const int64_t k = chunk_idx < 0 ? bsx_shard_rank : chunk_idx + bsx_shard_world;
+					const int64_t k = chunk_idx < 0 ? CHUNK_RANK : chunk_idx + CHUNK_WORLD;
 					if (!bsx_fq_scan_get(scan, k, &cp)) break;
 					if (bsx_fq_seek(f1, cp.off1) != 0 || (f2 && bsx_fq_seek(f2, cp.off2) != 0)) { fprintf(stderr, "[E::%s] cannot seek in the input\n", "main_align"); rc = 1; break; }
 					chunk_idx = k - 1;
 					n_processed = cp.n_before;
 				}
-				if (!scan && bsx_shard_world > 1 && (chunk_idx + 1) % bsx_shard_world != bsx_shard_rank && !getenv("BSX_NO_CHUNK_SKIP")) {
+				if (!scan && CHUNK_WORLD > 1 && (chunk_idx + 1) % bsx_shard_world != bsx_shard_rank && !getenv("BSX_NO_CHUNK_SKIP")) {
 					/* another rank's chunk of input that cannot be sought in: walked, not parsed (bsx_fq_skip_chunk) */
 					const int ns = bsx_fq_skip_chunk(f1, f2, chunk);
 					if (ns == 0) break;
@@ -556,13 +596,28 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 			}
 			for (i = 0; i < n; ++i) size += seqs[i].l_seq;
 			++chunk_idx;
-			if (bsx_shard_world > 1 && chunk_idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
+			if (CHUNK_WORLD > 1 && chunk_idx % bsx_shard_world != bsx_shard_rank) { /* another rank's chunk */
 				n_processed += n;
 				for (i = 0; i < n; ++i) bsx_read_free(&seqs[i]);
 				free(seqs);
 				continue;
 			}
 			if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] read %d sequences (%ld bp)...\n", "process", n, (long)size);
+			if (bsx_shard_mode && bsx_shard_world > 1) { /* within-chunk sharding without the stream (a backend without one): slice, align, emit */
+				int a = 0, m = shard_slice(n, (opt->flag & BSX_F_PE) != 0, &a);
+				const int n_all = n;
+				if (opt->flag & BSX_F_SMARTPE) { fprintf(stderr, "[E::%s] -p cannot be combined with ranks sharing a chunk\n", "main_align"); rc = 1; break; }
+				if (stream) { rc = bsx_stream_flush(stream); for (i = 0; i < n_pend; ++i) emit_chunk(pend[i].seqs, pend[i].n, pend[i].idx, rc == 0); n_pend = 0; }
+				shard_trim(seqs, n, a, m);
+				if (rc == 0 && m > 0) { bsx_chunk_slice_offset(a); rc = process(ud, opt, idx, n_processed + a, m, seqs, pes0); }
+				else if (rc == 0 && (opt->flag & BSX_F_PE) && !pes0) bsx_pestat_sync_empty(opt);
+				if (rc != BSX_OK) { fprintf(stderr, "[E::%s] alignment failed: %s\n", "main_align", bsx_strerror(rc)); rc = 1; }
+				n_processed += n_all;
+				emit_chunk(seqs, m, chunk_idx * bsx_shard_world + bsx_shard_rank, rc == 0);
+				if (g_write_error) rc = 1;
+				if (rc) break;
+				continue;
+			}
 			if (opt->flag & BSX_F_SMARTPE) { /* -p: split into single and paired reads (align.c:108-146) */
 				bsx_read_t *sep[2]; int m[2];
 				bsx_opt_t tmp = *opt;

@@ -93,6 +93,7 @@ typedef struct {
 	const bsx_index_t *idx;
 	int n, is_pe, nt;
 	int64_t n_processed;
+	int64_t local0;      /* these reads are a slice of a chunk (several GPUs sharing it): the index of the first one within the chunk */
 	bsx_read_t *reads;
 	uint32_t *roff;
 	/* tasks */
@@ -747,8 +748,8 @@ static void out_worker(void *data, long u, int tid)
 		if (!P->final_pass) { /* plan on a scratch copy */
 			reg_v tmp[2];
 			memset(tmp, 0, sizeof(tmp));
-			bsx_mark_primary(C->opt, &pair[0], u << 1 | 0);   /* ids are chunk-local for PE (bwamem.c:408,413) */
-			bsx_mark_primary(C->opt, &pair[1], u << 1 | 1);
+			bsx_mark_primary(C->opt, &pair[0], (C->local0 + (u << 1)) | 0);   /* ids are chunk-local for PE (bwamem.c:408,413): local0 = where a slice starts in its chunk */
+			bsx_mark_primary(C->opt, &pair[1], (C->local0 + (u << 1)) | 1);
 			reset_flags(&pair[0]); reset_flags(&pair[1]);
 			regs_copy(&tmp[0], &pair[0]); regs_copy(&tmp[1], &pair[1]);
 			ctx->plan = 1;
@@ -987,12 +988,19 @@ static void release_regs_worker(void *data, long i, int tid) { (void)tid; bsx_cf
 /* ------------------------------------------------------------------ the chunk */
 #define FCHECK(x) do { rc = (x); if (rc != BSX_OK) return rc; } while (0)
 
+/* The next chunk handed to bsx_process_seqs / bsx_stream_push by this thread is a slice of a larger chunk, starting at read `first` of
+ * it (an even number for pairs): the reference hashes a pair's regions by the pair's index WITHIN the chunk (bwamem.c:408,413), the one
+ * place where a read's position in its chunk enters the result besides the insert-size statistics. */
+static __thread int64_t g_next_local0 = 0;
+BSX_API void bsx_chunk_slice_offset(int64_t first) { g_next_local0 = first; }
+
 static chunk_t *chunk_new(const bsx_backend_t *be, const bsx_opt_t *opt, const bsx_index_t *idx, int64_t n_processed, int n,
                           bsx_read_t *reads, const bsx_pestat_t *pes0)
 {
 	chunk_t *C = (chunk_t*)calloc(1, sizeof(chunk_t));
 	C->be_copy = *be; C->be = &C->be_copy;
 	C->opt = opt; C->idx = idx; C->n = n; C->reads = reads; C->n_processed = n_processed; C->nt = bsx_host_threads(opt);
+	C->local0 = g_next_local0; g_next_local0 = 0;
 	C->is_pe = (opt->flag & BSX_F_PE) ? 1 : 0;
 	if (pes0) { C->pes0_copy = *pes0; C->pes0 = &C->pes0_copy; }
 	C->arena_set = -1;

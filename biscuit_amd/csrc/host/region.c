@@ -358,6 +358,18 @@ static void pes_worker(void *data, long i, int tid)   /* the pair's insert size 
 /* mem_pestat.  The reference sorts the insert sizes and walks the sorted array; they are integers in
  * [-max_ins, max_ins], so a histogram gives the same sorted sequence, and the sums below are taken over it
  * value by value in ascending order exactly as the reference's loops do. */
+BSX_API void (*bsx_pes_hist_hook)(void *ud, int64_t *hist, int n_bins) = 0;
+BSX_API void *bsx_pes_hist_ud = 0;
+/* a rank whose slice of a chunk is empty still takes part in the exchange */
+BSX_API void bsx_pestat_sync_empty(const bsx_opt_t *opt)
+{
+	int nb = 2 * opt->max_ins + 1;
+	int64_t *hist;
+	if (!bsx_pes_hist_hook || opt->max_ins < 0) return;
+	hist = (int64_t*)calloc((size_t)nb, sizeof(int64_t));
+	bsx_pes_hist_hook(bsx_pes_hist_ud, hist, nb);
+	free(hist);
+}
 bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, const reg_v *regs)
 {
 	bsx_pestat_t pes;
@@ -372,6 +384,10 @@ bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, c
 	hist = (int64_t*)calloc((size_t)nb, sizeof(int64_t));
 	for (i = 0; i < np; ++i) if (P.is[i] != PES_NONE) { ++hist[P.is[i] + opt->max_ins]; ++tot; }
 	free(P.is);
+	/* Several GPUs sharing one chunk (each aligns a slice of its pairs, cli.c): mem_pestat is the one step of a chunk that looks at all
+	 * of its pairs (bwamem.c:464-467), and everything it computes is a function of the histogram of insert sizes -- so the ranks add their
+	 * histograms (an all-reduce of 2 * max_ins + 1 counts through the hook) and each gets the statistics of the whole chunk. */
+	if (bsx_pes_hist_hook) { bsx_pes_hist_hook(bsx_pes_hist_ud, hist, nb); for (i = 0, tot = 0; i < nb; ++i) tot += hist[i]; }
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] # candidate unique pairs: %ld\n", "mem_pestat", (long)tot);
 	if (tot < MIN_DIR_CNT) {
 		fprintf(stderr, "[M:%s] There are not enough pairs for insert size inference\n", "mem_pestat");

@@ -1,7 +1,7 @@
 """Multi-GPU `biscuit align`: one process per GPU, chunks of the input are the shard unit.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        -m biscuit_amd.multi_gpu [--out FILE] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
+        -m biscuit_amd.multi_gpu [--out FILE] [--shard chunks|pairs] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
 
 Every rank cuts the input into the reference's chunks (10 Mbp x -@, align.c:576) and aligns chunks
 r, r+N, ... on its own GPU against its own HBM-resident copy of the index.  The chunk rule is cumulative, so over plain files a
@@ -12,6 +12,12 @@ each other (per-chunk insert-size statistics), so the SAM equals the single-GPU 
 (biscuit_amd/gather.py: sizes, then exactly the payload, point to point -> RCCL over xGMI), overlapped
 with the alignment of the following chunks; rank 0 writes chunks in input order as they arrive, and no
 rank ever holds more than a few chunks of output.
+
+--shard pairs (for inputs with fewer chunks than GPUs -- BASELINE configs[1] is two chunks at -@ 16): every rank takes
+every chunk and aligns its own slice of the chunk's pairs.  The one step of a chunk that looks at all of its pairs is mem_pestat
+(bwamem.c:464-467), and what it computes is a function of the histogram of insert sizes: the ranks add their histograms (an all-reduce
+of 2 * max_ins + 1 counters per chunk, csrc/host/region.c: bsx_pes_hist_hook) and each gets the statistics of the whole chunk, so the
+SAM is again the single-GPU one.  The slices leave in rank order as chunks k * world + rank of the same gather.
 
 `main(argv, entry=..., use_gpu=...)`: `entry` is the C entry point with the signature of bsx_align_main.
 The product always runs bsx_align_main (HIP; no CPU path exists in this package); tests inject another
@@ -26,11 +32,16 @@ import threading
 def main(argv=None, entry=None, use_gpu=True):
     argv = list(sys.argv[1:] if argv is None else argv)
     out_path = None   # SAM goes to stdout unless --out FILE (libraries such as gloo also print to stdout)
+    shard = "chunks"
     if "--" in argv:
         k = argv.index("--")
         head, argv = argv[:k], argv[k + 1:]
         if "--out" in head:
             out_path = head[head.index("--out") + 1]
+        if "--shard" in head:
+            shard = head[head.index("--shard") + 1]
+            if shard not in ("chunks", "pairs"):
+                raise SystemExit("--shard chunks|pairs")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -48,17 +59,34 @@ def main(argv=None, entry=None, use_gpu=True):
 
     from . import _lib as B
     L = B.lib()
+    failed = [0]      # an output or hook failure on this rank: the rounds go on (the other ranks are inside collectives), the exit status says so
     if entry is None:
         entry = L.bsx_align_main
     C.c_int.in_dll(L, "bsx_shard_rank").value = rank
     C.c_int.in_dll(L, "bsx_shard_world").value = world
+    C.c_int.in_dll(L, "bsx_shard_mode").value = 1 if (shard == "pairs" and world > 1) else 0
+    pes_hook = None
+    if shard == "pairs" and world > 1:
+        # the insert-size histograms of a chunk's slices, added over the ranks: 80 KB per chunk, from the aligner's own thread while the
+        # gather's collectives run on another -- so on a communicator of its own, and on the host (gloo) in GPU runs too
+        pes_group = dist.new_group(backend="gloo")
+        PES = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.c_int)
+
+        def pes_sum(ud, hist, nb):
+            try:
+                a = np.ctypeslib.as_array(hist, shape=(nb,))
+                t = torch.from_numpy(a)       # shares the C buffer: the sum lands in place
+                dist.all_reduce(t, group=pes_group)
+            except Exception as e:
+                failed[0] = 1
+                sys.stderr.write("[E::multi_gpu] adding the insert-size histograms failed: %r\n" % (e,))
+        pes_hook = PES(pes_sum)
+        C.c_void_p.in_dll(L, "bsx_pes_hist_hook").value = C.cast(pes_hook, C.c_void_p).value
 
     out = None
     if rank == 0:
         out = open(out_path, "wb") if out_path else sys.stdout.buffer
     written = [0]
-
-    failed = [0]      # an output or hook failure on this rank: the rounds go on (the other ranks are inside collectives), the exit status says so
 
     def sink(idx, buf):
         if failed[0]:

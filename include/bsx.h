@@ -299,6 +299,16 @@ int bsx_global_batch_tags(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *job
  * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and
  * from the region kernels), c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
+/* Several GPUs sharing ONE chunk: each process aligns a slice of the chunk's pairs.  Two things tie a read to its chunk:
+ * mem_pestat (bwamem.c:464-467), whose result is a function of the chunk's histogram of insert sizes -- bsx_pes_hist_hook, when set, is
+ * called with this process's histogram (2 * max_ins + 1 counters) and must return the sum over all processes in place (an all-reduce;
+ * bsx_pestat_sync_empty: the call of a process whose slice is empty) -- and the pair's index within the chunk, which seeds the hash that
+ * breaks ties between equal hits (bwamem.c:408,413): bsx_chunk_slice_offset(first) says where the NEXT chunk this thread passes to
+ * bsx_process_seqs / bsx_stream_push starts within its chunk.  n_processed is the global index of the slice's first read, as always. */
+extern void (*bsx_pes_hist_hook)(void *ud, int64_t *hist, int n_bins);
+extern void *bsx_pes_hist_ud;
+void bsx_pestat_sync_empty(const bsx_opt_t *opt);
+void bsx_chunk_slice_offset(int64_t first);
 /* what the region kernels (bsx_regions_batch: K3 + C1 + C2 + K4 + C4) were given and made since the last reset, summed over the chunks:
  * w[0] strand searches, w[1] SA intervals read (32 B each), w[2] seed occurrences whose position was looked up (8 B each),
  * w[3] alignment regions written (56 B each), w[4] read bases of the strand searches -- the terms of the family's algorithmic bytes */

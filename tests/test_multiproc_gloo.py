@@ -55,3 +55,37 @@ def test_two_ranks_equal_one(tmp_path, pe):
         assert gz.returncode == 0, gz.stderr.decode()[-3000:]
         assert strip_pg(open(d + "/gz.sam", "rb").read()) == a
         assert gz.stderr.count(b"walks the others without building records") == 2
+
+
+@pytest.mark.parametrize("pe,n_ranks", [(True, 2), (False, 2), (True, 3)])
+def test_ranks_sharing_each_chunk_equal_one(tmp_path, pe, n_ranks):
+    """--shard pairs: every rank aligns its slice of every chunk, the insert-size histograms are added over the ranks
+    (bsx_pes_hist_hook), the slices leave in rank order.  Same SAM as one process -- with several chunks, with ONE chunk (fewer chunks
+    than ranks: what chunk sharding cannot spread), and with a last chunk of fewer pairs than ranks (empty slices)."""
+    d = str(tmp_path)
+    contigs = simdata.make_genome(200000, seed=6, n_contigs=2)
+    simdata.write_genome(d + "/g.fa", contigs)
+    Index.build(d + "/g.fa", d + "/g").close()
+    port = 29560 + (4 if pe else 0) + n_ranks * 8
+    for tag, n_pairs, chunk in (("multi", 2001, "100000"), ("single", 900, "10000000")):
+        # 2001 pairs of 2 x 100 at 100 kbp per chunk: 500 pairs a chunk, the last chunk is ONE pair (empty slices on the other ranks)
+        pairs = simdata.make_pairs(contigs, n_pairs, 100, 3, frag=(150, 300), sub=0.01, indel=0.003)
+        simdata.write_fastq(d + "/%s_1.fq" % tag, [(n, a) for n, a, b in pairs])
+        simdata.write_fastq(d + "/%s_2.fq" % tag, [(n, b) for n, a, b in pairs])
+        files = ["%s_1.fq" % tag, "%s_2.fq" % tag] if pe else ["%s_1.fq" % tag]
+        env = dict(os.environ, BSX_CHUNK_SIZE=chunk, PYTHONPATH=ROOT)
+        one = subprocess.run([os.path.join(ROOT, "oracle", "oracle_align"), "-@", "1", "g"] + files, cwd=d, env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert one.returncode == 0, one.stderr.decode()[-2000:]
+        n_chunks = one.stderr.count(b"sequences (")
+        assert (n_chunks >= 3) if tag == "multi" else (n_chunks == 1)
+        port += 1
+        many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+                               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/many.sam", "--shard", "pairs",
+                               "--", "-@", "1", "g"] + files, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert many.returncode == 0, many.stderr.decode()[-3000:]
+        a, b = strip_pg(one.stdout), strip_pg(open(d + "/many.sam", "rb").read())
+        assert a.count(b"\n") > (800 if pe else 400)
+        assert a == b, tag
+        # every rank read every chunk (nobody skipped), and with pairs every rank took part in every chunk's statistics
+        assert many.stderr.count(b"sequences (") == n_chunks * n_ranks, many.stderr.decode()[-2000:]
