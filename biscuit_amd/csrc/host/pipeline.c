@@ -93,6 +93,7 @@ typedef struct {
 	const bsx_index_t *idx;
 	int n, is_pe, nt;
 	int64_t n_processed;
+	int64_t seq;         /* order of the chunks pushed through streams ($BSX_STREAM_WHOLE_CHUNK: back halves start in this order) */
 	int64_t local0;      /* these reads are a slice of a chunk (several GPUs sharing it): the index of the first one within the chunk */
 	bsx_read_t *reads;
 	uint32_t *roff;
@@ -1338,7 +1339,12 @@ struct bsx_stream {
 	int64_t n_pushed;
 };
 
-static int g_whole_chunk_threads = -1;   /* $BSX_STREAM_WHOLE_CHUNK: the chunk's thread runs its back half too */
+static int g_whole_chunk_threads = -1;   /* $BSX_STREAM_WHOLE_CHUNK=N: the chunk's own thread runs its back half too, at most N back halves at a time (0: the pushing thread runs them, one by one) */
+static pthread_mutex_t g_back_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_back_cv = PTHREAD_COND_INITIALIZER;
+static int g_back_running = 0;
+static int64_t g_back_next = 0, g_back_seq = 0;   /* chunk sequence numbers of the streams of this process */
+extern void (*bsx_pes_hist_hook)(void *ud, int64_t *hist, int n_bins);
 
 static void *front_thread(void *arg)
 {
@@ -1348,7 +1354,25 @@ static void *front_thread(void *arg)
 	/* With the back half on the chunk's own thread as well, back halves of consecutive chunks overlap each other: one
 	 * chunk's serial stretches and waits for its K5/K6 batches are filled with the other's parallel loops (the worker
 	 * pool serves several loops at once).  Chunks still complete in order: the stream joins the threads in order. */
-	if (g_whole_chunk_threads && C->rc == BSX_OK) { C->rc = chunk_back(C); C->back_done = 1; }
+	if (g_whole_chunk_threads && C->rc == BSX_OK && !bsx_pes_hist_hook) {   /* (ranks sharing a chunk exchange histograms in chunk order: back halves stay on the pushing thread) */
+		/* at most g_whole_chunk_threads back halves at a time, started in chunk order */
+		pthread_mutex_lock(&g_back_mu);
+		while (g_back_running >= g_whole_chunk_threads || g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu);
+		++g_back_running; ++g_back_next;
+		pthread_cond_broadcast(&g_back_cv);
+		pthread_mutex_unlock(&g_back_mu);
+		C->rc = chunk_back(C); C->back_done = 1;
+		pthread_mutex_lock(&g_back_mu);
+		--g_back_running;
+		pthread_cond_broadcast(&g_back_cv);
+		pthread_mutex_unlock(&g_back_mu);
+	} else if (g_whole_chunk_threads && !bsx_pes_hist_hook) { /* a failed front half: its turn passes */
+		pthread_mutex_lock(&g_back_mu);
+		while (g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu);
+		++g_back_next;
+		pthread_cond_broadcast(&g_back_cv);
+		pthread_mutex_unlock(&g_back_mu);
+	}
 	bsx_arenas_bind(-1);
 	return 0;
 }
@@ -1409,8 +1433,9 @@ BSX_API int bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_rea
 	if (n > 0) {
 		chunk_t *C = chunk_new(&s->be[s->n_pushed % s->depth], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
 		++s->n_pushed;
+		pthread_mutex_lock(&g_back_mu); C->seq = g_back_seq++; pthread_mutex_unlock(&g_back_mu);
 		if (pthread_create(&C->th, 0, front_thread, C) == 0) C->th_live = 1;
-		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); }
+		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); if (g_whole_chunk_threads && !bsx_pes_hist_hook) { pthread_mutex_lock(&g_back_mu); while (g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu); ++g_back_next; pthread_cond_broadcast(&g_back_cv); pthread_mutex_unlock(&g_back_mu); } }
 		s->q[s->n_q++] = C;
 	}
 	while (s->n_q > (n > 0 ? s->depth - 1 : 0) && rc == BSX_OK) { /* complete the oldest: its lane is the next push's */
