@@ -301,8 +301,62 @@ __device__ __forceinline__ int rg_par_partition(unsigned int *a, unsigned int *t
 	WAVE_SYNC();
 	return i;
 }
-template <int MS>   // register slots of 64 keys: n <= 64 * MS
-__device__ __forceinline__ void rg_introsort_par(unsigned int *a, int n, unsigned int *tmpL, unsigned int *tmpR, int *stk, int lane)
+// The same partition for a segment of any length (the kilobase-read tiers: a strand search on the strand its read does not come from has
+// ~800 chains of weight 19-22), 64 positions at a time: a first sweep counts the stops of every block (cnt[0..31] L stops, cnt[32..63] R
+// stops), a second one numbers them (L stops from the left, R stops from the right), decides who takes part and lists the partners, a third
+// one puts the partners in place.  kk: which pair a position belongs to, kept in LDS between the sweeps (a short per position).
+__device__ __forceinline__ int rg_par_partition_blk(unsigned int *a, unsigned int *tmpL, unsigned int *tmpR, short *kk, int *cnt, int s, int t, unsigned int rp, int lane)
+{
+	const unsigned int wp = rp >> RG_KEY_BITS;
+	const int len = t - s + 1, nb = (len + 63) >> 6;
+	int tot_r = 0;
+	for (int c = 0; c < nb; ++c) {
+		const int r = c * 64 + lane;
+		const bool in = r >= 1 && r < len;
+		const unsigned int w = (in ? a[s + r] : 0u) >> RG_KEY_BITS;
+		const int nl = __popcll(__ballot(in && w <= wp)), nr = __popcll(__ballot(in && r < len - 1 && w >= wp));
+		if (lane == 0) { cnt[c] = nl; cnt[32 + c] = nr; }
+		tot_r += nr;
+	}
+	WAVE_SYNC();
+	int l_before = 0, r_after = tot_r, first_free = 0x7fffffff, low_r = 0x7fffffff;
+	for (int c = 0; c < nb; ++c) {
+		const int r = c * 64 + lane;
+		const bool in = r >= 1 && r < len;
+		const unsigned int x = in ? a[s + r] : 0u, w = x >> RG_KEY_BITS;
+		const unsigned long long Lm = __ballot(in && w <= wp), Rm = __ballot(in && r < len - 1 && w >= wp);
+		const int rc = uni(cnt[32 + c]);
+		r_after -= rc;                                  // R stops in the blocks above this one
+		const int is_l = (int)((Lm >> lane) & 1), is_r = (int)((Rm >> lane) & 1);
+		const int l_lt = l_before + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(Lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)Lm, 0u));
+		const int r_lt = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(Rm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)Rm, 0u));
+		const int k_l = l_lt + 1, r_gt = r_after + rc - r_lt - is_r, k_r = r_gt + 1;
+		const bool pl = is_l && r_gt >= k_l, pr = is_r && l_lt >= k_r;
+		if (pl) tmpL[k_l - 1] = x;
+		if (pr) tmpR[k_r - 1] = x;
+		if (r < len) kk[r] = (short)(pl ? k_l : pr ? -k_r : 0);
+		const unsigned long long fm = Lm & ~__ballot(pl), rm = __ballot(pr);
+		if (fm && first_free == 0x7fffffff) first_free = c * 64 + (int)__builtin_ctzll(fm);
+		if (rm && low_r == 0x7fffffff) low_r = c * 64 + (int)__builtin_ctzll(rm);
+		l_before += uni(cnt[c]);
+	}
+	WAVE_SYNC();
+	for (int c = 0; c < nb; ++c) {
+		const int r = c * 64 + lane;
+		if (r < len) {
+			const int k = kk[r];
+			if (k > 0) a[s + r] = tmpR[k - 1];
+			else if (k < 0) a[s + r] = tmpL[-k - 1];
+		}
+	}
+	const int i = s + (first_free < low_r ? first_free : low_r);
+	WAVE_SYNC();
+	if (i != t && lane == 0) { const unsigned int v = a[i]; a[t] = v; a[i] = rp; }
+	WAVE_SYNC();
+	return i;
+}
+template <int MS>   // register slots of 64 keys: n <= 64 * MS; MS > 4: kk (n shorts) and cnt (64 ints) are LDS scratch for the partitions of long segments
+__device__ __forceinline__ void rg_introsort_par(unsigned int *a, int n, unsigned int *tmpL, unsigned int *tmpR, int *stk, int lane, short *kk = nullptr, int *cnt = nullptr)
 {
 #define WGT(x) ((x) >> RG_KEY_BITS)
 	if (n < 2) return;
@@ -325,7 +379,8 @@ __device__ __forceinline__ void rg_introsort_par(unsigned int *a, int n, unsigne
 			int i;
 			if (len <= 64) i = rg_par_partition<1>(a, tmpL, tmpR, s, t, rp, lane);
 			else if (MS <= 2 || len <= 128) i = rg_par_partition<2>(a, tmpL, tmpR, s, t, rp, lane);
-			else i = rg_par_partition<MS <= 2 ? 2 : 4>(a, tmpL, tmpR, s, t, rp, lane);
+			else if (MS <= 4 || len <= 256) i = rg_par_partition<MS <= 2 ? 2 : 4>(a, tmpL, tmpR, s, t, rp, lane);
+			else i = rg_par_partition_blk(a, tmpL, tmpR, kk, cnt, s, t, rp, lane);
 			if (i - s > t - i) {
 				if (i - s > 16) { if (lane == 0) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; } ++top; }
 				s = t - i > 16 ? i + 1 : t;
@@ -347,7 +402,7 @@ __device__ __forceinline__ void rg_introsort_par(unsigned int *a, int n, unsigne
 	for (int c = 0; c < MS; ++c) {
 		const int p = c * 64 + lane;
 		x[c] = (c * 64 < n && p < n) ? a[p] : 0u;
-		u[c] = p < n ? (WGT(x[c]) << 9 | (unsigned int)(256 - p)) : 0u;   // unique, heavier and earlier = larger; 0: no key
+		u[c] = p < n ? (MS <= 4 ? (WGT(x[c]) << 9 | (unsigned int)(256 - p)) : (WGT(x[c]) << 11 | (unsigned int)(2047 - p))) : 0u;   // unique, heavier and earlier = larger; 0: no key
 		rk[c] = 0;
 	}
 #pragma unroll
@@ -1021,9 +1076,10 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 		WAVE_SYNC();
 		bool sorted = false;
-		constexpr int SORT_MS = Store::CCAP <= 64 ? 1 : Store::CCAP <= 128 ? 2 : 4;
+		constexpr int SORT_MS = Store::CCAP <= 64 ? 1 : Store::CCAP <= 128 ? 2 : Store::CCAP <= 256 ? 4 : (Store::CCAP + 63) / 64;
 		if (!Store::NODES && n <= 64 * SORT_MS) { // every partition at once (rg_introsort_par): the second half of srt[] holds the partners' lists
-			rg_introsort_par<SORT_MS>(keys, n, keys + Store::SCAP, keys + Store::SCAP + Store::SCAP / 2, D.H, lane);
+			// (the kilobase-read tiers: lst[] is free until the kept flags are written, E[] is the tree traversal's stack, which these tiers do not have)
+			rg_introsort_par<SORT_MS>(keys, n, keys + Store::SCAP, keys + Store::SCAP + Store::SCAP / 2, D.H, lane, (short*)S.lst, D.E);
 			sorted = true;
 		}
 		WAVE_SYNC();
