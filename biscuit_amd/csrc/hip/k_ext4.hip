@@ -517,7 +517,7 @@ void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &s
 	hipLaunchKernelGGL(k_x4prep, dim3(std::max(1, pgrid)), dim3(64 * X4P_WPB), 0, st, ix, P, tasks, X, (X4Job*)jobs, jcap, ctr32);
 	const int use_l = getenv("BSX_XL") ? atoi(getenv("BSX_XL")) : 1;   // 0: the narrow queue through k_ext4 too
 	if (use_l) launch_extl(st, n_cu, ix, sc, P, reads, jobs, jcap, ctr32, X.base, n_tasks * 4, prof);
-	static const int wpc = getenv("BSX_X4_WG_PER_CU") ? std::max(1, atoi(getenv("BSX_X4_WG_PER_CU"))) : 3;   // (three waves per SIMD at 167 VGPRs)
+	const int wpc = 3;   // (three waves per SIMD at 167 VGPRs)
 	const int grid = (int)std::max<long long>(1, std::min<long long>((n_tasks * 4 + 15) / 16, (long long)n_cu * wpc));
 	hipLaunchKernelGGL((k_ext4<10, true>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, (const void*)jobs, (void*)nullptr, X.base, (const unsigned int*)ctr32, jcap, ctr32 + 1, prof, use_l ? 0 : 1);
 }

@@ -337,7 +337,7 @@ k_extl(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, void *jobs
 void launch_extl(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, void *jobs, unsigned int jcap,
                  unsigned int *ctr32, unsigned char *xbase, long long n_upper, unsigned long long *prof)
 {
-	static const int wpc = getenv("BSX_XL_WAVES_PER_CU") ? std::max(1, atoi(getenv("BSX_XL_WAVES_PER_CU"))) : 4 * XL_OCC;
+	const int wpc = 4 * XL_OCC;
 	const int grid = (int)std::max<long long>(1, std::min<long long>((n_upper + 63) / 64, (long long)n_cu * wpc));
 	hipLaunchKernelGGL(k_extl<true>, dim3(grid), dim3(64), 0, st, ix, sc, P, reads, jobs, (void*)nullptr, jcap, ctr32, xbase, prof);
 }

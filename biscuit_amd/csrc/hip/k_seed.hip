@@ -286,11 +286,11 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
                  int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof, uint32_t *qpack, unsigned long long direct_off)
 {
 	// 165 VGPRs and 11 KB of LDS per wave: three waves per SIMD
-	// the full state machine runs every (cold_mask + 1)-th trip, or when more than cold_lanes lanes wait for it ($BSX_SEED_COLD_EVERY, a power of two,
-	// $BSX_SEED_COLD_LANES).  The launch does not care (tools/seed_cold.sh: 208.2-209.8 ms from every 2nd trip / 16 lanes to every 16th / 32): what
+	// the full state machine runs every (cold_mask + 1)-th trip, or when more than cold_lanes lanes wait for it (measured in round 3,
+	// the launch does not care: 208.2-209.8 ms from every 2nd trip / 16 lanes to every 16th / 32): what
 	// bounds it is the vector issue of the trips themselves -- 820 wave64 instructions at four cycles each on a 16-wide SIMD, three waves deep
-	static const unsigned int cold_mask = (getenv("BSX_SEED_COLD_EVERY") ? (unsigned int)atoi(getenv("BSX_SEED_COLD_EVERY")) : 4u) - 1u;
-	static const int cold_lanes = getenv("BSX_SEED_COLD_LANES") ? atoi(getenv("BSX_SEED_COLD_LANES")) : 24;
+	const unsigned int cold_mask = 4u - 1u;
+	const int cold_lanes = 24;
 	// the table form (k_seedt.hip) whenever the index has its table; $BSX_SEED_FORM=classic (or a number: the forms below) keeps this kernel
 	const bool classic = getenv("BSX_SEED_FORM") != nullptr;   // (read per launch: the tests switch it)
 	if (!classic) {

@@ -251,9 +251,9 @@ void launch_seedt(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *r
                   int quota, unsigned int *slab_busy, int n_slabs, int trip_budget, int prof, uint32_t *qpack, unsigned long long direct_off)
 {
 	// lanes whose strand search is done wait for company before the wave publishes and hands out new ones: every (cold_mask + 1)-th trip, or
-	// when more than cold_lanes wait ($BSX_SEED_COLD_EVERY, a power of two; $BSX_SEED_COLD_LANES; read per launch: tools/seedt_sweep.py)
-	const unsigned int cold_mask = (getenv("BSX_SEED_COLD_EVERY") ? (unsigned int)atoi(getenv("BSX_SEED_COLD_EVERY")) : 8u) - 1u;
-	const int cold_lanes = getenv("BSX_SEED_COLD_LANES") ? atoi(getenv("BSX_SEED_COLD_LANES")) : 16;
+	// when more than cold_lanes wait (every 8th trip / 16 lanes: swept in round 4)
+	const unsigned int cold_mask = 8u - 1u;
+	const int cold_lanes = 16;
 	if (qpack) {
 		const long long nw = (long long)n_tasks * SEEDT_WPT;
 		hipLaunchKernelGGL(k_seedt_pack, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, reads, tasks, n_tasks, qpack);

@@ -84,8 +84,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 	if (ordinal < 0 || ordinal >= n) return BSX_E_ARG;
 	HIPCHK(hipSetDevice(ordinal));
 	// host threads that wait for the device sleep instead of polling: a chunk stream has half a dozen threads waiting at any time (front
-	// halves, K5/K6 batches), and on a 16-core quota their polling was a third of the host's CPU time ($BSX_BLOCKING_SYNC=0: the runtime's default)
-	if (!(getenv("BSX_BLOCKING_SYNC") && atoi(getenv("BSX_BLOCKING_SYNC")) == 0)) { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
+	// halves, K5/K6 batches), and on a 16-core quota their polling was a third of the host's CPU time (the runtime's default polls)
+	if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
 	bsx_device *d = new bsx_device();
 	d->ordinal = ordinal;
 	hipDeviceProp_t prop;
@@ -346,8 +346,7 @@ static void copy_by_kernel(hipStream_t st, void *dst, const void *src, size_t n)
 static int xfer(Lane &L, hipStream_t st, void *dst, const void *src, size_t n, bool h2d)
 {
 	if (n == 0) return BSX_OK;
-	static const bool zc_on = !(getenv("BSX_COPY_KERNELS") && atoi(getenv("BSX_COPY_KERNELS")) == 0);
-	const bool zc = zc_on && st == L.st_hi;
+	const bool zc = st == L.st_hi;   // the back half's small batches move with a kernel on their own stream, not through the copy engines (round 4)
 	if (!zc && n < ((size_t)256 << 10)) {
 		HIPCHK(hipMemcpyAsync(dst, src, n, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
@@ -612,7 +611,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
 	R.gap_cap = -1;
-	{ static const int walk = getenv("BSX_WALK_PAST_MAX_OCC") ? atoi(getenv("BSX_WALK_PAST_MAX_OCC")) : 1; R.walk_on = walk; }
+	R.walk_on = 1;
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
 	// here because the rule goes through log() and the float / double conversions of the reference's expression.
 	bool any_flt = false;
@@ -656,16 +655,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;   // (the kernel scales it per 256 bases of read)
 	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
 	const int n_slabs = d->n_cu * 16;
-	// quota 0 = persistent waves: their number can be capped ($BSX_SEED_WAVES_PER_CU) to study how the kernel reacts to fewer
-	// gathers in flight on a given box
-	const int seed_wpc = getenv("BSX_SEED_WAVES_PER_CU") ? std::max(1, std::min(16, atoi(getenv("BSX_SEED_WAVES_PER_CU")))) : 16;
+	const int seed_wpc = 16;   // quota 0 = persistent waves, sixteen per CU
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
 	                          : (int)((std::min<int64_t>((n + 63) / 64, (int64_t)d->n_cu * seed_wpc) + 3) / 4);
 	const size_t lanes = (size_t)n_slabs * 64, scratch_bytes = lanes * ((size_t)mem_cap * 32 + (size_t)list_cap * 16);   // as in lane_seed_batch
 	// the HBM tiers: workgroups of four waves over per-wave slabs; they are bound by the latency of their slabs, so what counts is waves in flight:
 	// three workgroups per CU for the first (its kernel is held to 168 VGPRs for that and spills: 710 -> 578 ms per chunk on the hg38-like genome
 	// all the same), one per CU for the second (1.3 MB of slab a wave; 222 -> 167 ms: a launch lasts as long as its largest strand search)
-	const int big_grid = d->n_cu * (getenv("BSX_SLAB_GRID_PER_CU") ? std::max(1, std::min(6, atoi(getenv("BSX_SLAB_GRID_PER_CU")))) : 3), huge_grid = getenv("BSX_SLAB3_GRID_X2") ? std::max(1, d->n_cu * atoi(getenv("BSX_SLAB3_GRID_X2")) / 2) : d->n_cu;
+	const int big_grid = d->n_cu * 3, huge_grid = d->n_cu;
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
@@ -841,44 +838,6 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (XP.ext) {
 			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
-			if (main_seq && getenv("BSX_XL_CHECK")) { // $BSX_XL_CHECK (tools/dbg/xlchk.sh): the records as k_extl + k_ext4 left them against k_ext4 alone, record by record
-				unsigned long long used = 0; unsigned int xn = 0;
-				HIPCHK(hipStreamSynchronize(st));
-				D2H(st, &used, XP.cursor, 8); D2H(st, &xn, XP.xcount, 4);
-				if (used > XP.cap) used = XP.cap;
-				std::vector<unsigned char> a((size_t)used), b((size_t)used);
-				std::vector<long long> xo((size_t)nT); std::vector<int> xl((size_t)xn);
-				D2H(st, a.data(), XP.base, (size_t)used); D2H(st, xo.data(), XP.xoff, (size_t)nT * 8); D2H(st, xl.data(), XP.xlist, (size_t)xn * 4);
-				setenv("BSX_XL", "0", 1);
-				launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, nullptr);
-				unsetenv("BSX_XL");
-				HIPCHK(hipStreamSynchronize(st));
-				D2H(st, b.data(), XP.base, (size_t)used);
-				long n_diff = 0, n_tot = 0;
-				for (unsigned int k = 0; k < xn; ++k) {
-					const int t = xl[k];
-					const int *H = (const int*)(a.data() + xo[t]);
-					const int nk = H[0], nsd = H[1], has = H[4];
-					if (!has) continue;
-					const size_t eo = (size_t)xo[t] + 24 + (size_t)nk * 24 + (size_t)nsd * 16;
-					for (int c = 0; c < nk; ++c) {
-						const long long *ea = (const long long*)(a.data() + eo + (size_t)c * 48), *eb = (const long long*)(b.data() + eo + (size_t)c * 48);
-						++n_tot;
-						if (memcmp(ea, eb, 48) != 0) {
-							if (n_diff++ < 12) {
-								const int *ia = (const int*)ea, *ib = (const int*)eb;
-								const long long *sd = (const long long*)(a.data() + xo[t] + 24 + (size_t)nk * 24);
-								const int *ch = (const int*)(a.data() + xo[t] + 24 + (size_t)c * 24);
-								const int so = ch[3];
-								const short *sq = (const short*)(sd + 2 * (so + ia[10]) + 1);
-								fprintf(stderr, "[xl_check] task %d (len %d) chain %d seed rbeg %lld qbeg %d len %d | xl: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d | x4: rb %lld re %lld qb %d qe %d score %d truesc %d aw %d %d si %d st %d\n",
-								        t, tasks[t].len, c, sd[2 * (so + ia[10])], (int)sq[0], (int)sq[1], ea[0], ea[1], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], eb[0], eb[1], ib[4], ib[5], ib[6], ib[7], ib[8], ib[9], ib[10], ib[11]);
-							}
-						}
-					}
-				}
-				fprintf(stderr, "[xl_check] %ld of %ld chain records differ\n", n_diff, n_tot);
-			}
 		}
 		launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
 		if (main_seq && chain == 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
@@ -1183,7 +1142,7 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	// The host chaining path calls this once per round of its strand searches' extensions -- a thousand rounds of a few hundred jobs for
 	// the reads inside satellite arrays of a repeat-rich genome -- while the front-half kernels of other chunks fill the device.
 	// $BSX_HOSTPATH_STREAM=1 puts the rounds on the lane's high-priority stream: measured, no difference (3.36-3.60 against 3.52 s per chunk).
-	static const int hp_hi = getenv("BSX_HOSTPATH_STREAM") ? atoi(getenv("BSX_HOSTPATH_STREAM")) : 0;
+	const int hp_hi = 0;
 	hipStream_t S = hp_hi ? L.st_hi : L.st;
 	// the last class: queries of any length, rows in HBM (reads of tens of kilobases).  What remains out of reach is a band of more
 	// than 2048 columns, i.e. -w above 511 -- a limit of the option, not of the data
@@ -1243,7 +1202,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	// the others a wavefront each (k_sw.hip), by padded query length: up to 256, 1024, 3072 columns
 	std::vector<int> order[4];
 	int max_tlen = 1, slen_max = 1;
-	static const bool use_swl = !(getenv("BSX_SWL") && atoi(getenv("BSX_SWL")) == 0);   // ($BSX_SWL=0, tests: every job through the wave-per-job kernel)
+	const bool use_swl = true;
 	std::vector<int> key;
 	for (int64_t i = 0; i < n; ++i) {
 		const bsx_sw_job_t &j = jobs[i];

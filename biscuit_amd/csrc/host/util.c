@@ -347,7 +347,6 @@ void *bsx_arena_alloc(bsx_arena_t *a, size_t n)
 int bsx_arenas_begin(int n_threads)
 {
 	int i, set;
-	if (getenv("BSX_NO_ARENA")) return -1;
 	pthread_mutex_lock(&g_arena_mu);
 	for (;;) {
 		for (set = 0; set < ARENA_SETS; ++set) if (!g_set_busy[set]) break;
@@ -399,7 +398,7 @@ static void *pf_worker(void *arg)
 	int id = (int)(intptr_t)arg;   /* participates as tid id+1 */
 	/* the workers yield to the threads that feed the device (the front half of the next chunk, the HIP runtime's
 	 * own threads) when there are fewer cores than runnable threads */
-	{ const char *e = getenv("BSX_WORKER_NICE"); int nv = e ? atoi(e) : 5; if (nv > 0) setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nv); }
+	setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 5);
 	pthread_mutex_lock(&g_pool.mu);
 	for (;;) {
 		pf_job_t *J = 0;
@@ -481,7 +480,6 @@ void *bsx_par_calloc(int n_threads, size_t n, size_t size)
  * steps and never trimming keeps the memory of one chunk for the next one. */
 __attribute__((constructor)) static void bsx_tune_malloc(void)
 {
-	if (getenv("BSX_NO_MALLOC_TUNING")) return;
 	mallopt(M_TOP_PAD, 64 << 20);
 	mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
 	mallopt(M_MMAP_THRESHOLD, 1 << 30);
