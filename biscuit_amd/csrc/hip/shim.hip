@@ -194,16 +194,36 @@ static int upload_ref(bsx_device_t *d, const bsx_index_t *idx)
 
 // The table of k-mer intervals of both converted indices (seed_tab.hpp), built from the indices now resident: K levels, K chosen from the
 // text's size (18 for an hg38-sized genome: 2 x 9.3 GB), $BSX_SEED_TAB_K overrides (0: no table, every seeding step an FM extension).
+// What the index's optional structures may take of the device's memory: the chunks in flight need room too (their buffers grow with the chunk:
+// ~25 GB a lane for 1 M reads against an hg38-sized genome), so a third of the device (at most 64 GB) is left alone.  On a 288 GB part
+// nothing changes; on a smaller one the table loses levels and the suffix-array sample gets sparser instead of the upload failing.
+static size_t hbm_budget(void)
+{
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return ~(size_t)0; }
+	const size_t keep = std::min<size_t>(tot / 3, (size_t)64 << 30);
+	return fr > keep ? fr - keep : 0;
+}
 static int build_seed_tables(bsx_device_t *d)
 {
 	int K = seed_tab_depth(d->ix.fmi[0].seq_len);
+	const int K_want = K;
 	if (const char *e = getenv("BSX_SEED_TAB_K")) { K = atoi(e); if (K < 2) K = 0; if (K > 19) K = 19; }
 	d->ix.tab.K = 0; d->ix.tab.t[0] = d->ix.tab.t[1] = nullptr; d->ix.tab.pad_ = 0;
-	if (K < 2) { d->seedtab[0].release(); d->seedtab[1].release(); return BSX_OK; }
+	d->seedtab[0].release(); d->seedtab[1].release();
+	while (K >= 2 && 2 * (size_t)seed_tab_entries(K) * sizeof(SeedEnt) > hbm_budget()) --K;   // a level is a third of the table
 	Lane &L = d->lane[0];
+	for (; K >= 2; --K) { // (and one level fewer when the reservation fails all the same)
+		int rc = BSX_OK;
+		for (int i = 0; i < 2 && rc == BSX_OK; ++i) rc = d->seedtab[i].reserve_exact((size_t)seed_tab_entries(K) * sizeof(SeedEnt));
+		if (rc == BSX_OK) break;
+		d->seedtab[0].release(); d->seedtab[1].release();
+		(void)hipGetLastError();
+	}
+	if (K != K_want && !getenv("BSX_SEED_TAB_K")) fprintf(stderr, "[W::%s] device memory: table of k-mer intervals with %d levels instead of %d%s\n", "bsx-hip", K < 2 ? 0 : K, K_want, K < 2 ? " (none: every seeding step is an FM extension)" : "");
+	if (K < 2) { d->seedtab[0].release(); d->seedtab[1].release(); return BSX_OK; }
 	for (int i = 0; i < 2; ++i) {
 		int rc;
-		if ((rc = d->seedtab[i].reserve_exact((size_t)seed_tab_entries(K) * sizeof(SeedEnt))) != BSX_OK) return rc;
 		if ((rc = seedtab_build(L.st, d->ix, i, K, d->seedtab[i].p)) != BSX_OK) return rc;
 	}
 	HIPCHK(hipStreamSynchronize(L.st));
@@ -240,6 +260,11 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 		const char *e = getenv("BSX_DEVICE_SA_INTV");
 		int want = e ? atoi(e) : BSX_DEVICE_SA_INTV_DEFAULT;
 		const int file_intv = (int)d->ix.fmi[0].sa_mask + 1;
+		if (want >= 1 && (want & (want - 1)) == 0) { // sparser when the device is short of memory (hbm_budget), down to the files' own sample
+			const int asked = want;
+			while (want < file_intv && 2 * ((size_t)(d->ix.fmi[0].seq_len / (unsigned)want) + 1) * 8 > hbm_budget()) want <<= 1;
+			if (want != asked) fprintf(stderr, "[W::%s] device memory: suffix-array sample every %d ranks instead of every %d\n", "bsx-hip", want < file_intv ? want : file_intv, asked);
+		}
 		if (want >= 1 && want < file_intv && (want & (want - 1)) == 0 && d->ix.fmi[1].sa_mask == d->ix.fmi[0].sa_mask) {
 			DevBuf dense[2];
 			Lane &L = d->lane[0];
