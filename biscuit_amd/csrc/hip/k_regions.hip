@@ -77,6 +77,8 @@ typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;          
 // LDS, 62 KB per wave, two workgroups of one wave per CU -- every table access of the HBM tiers below is a memory round trip
 typedef RgStore<640, 1152, 1152, 0, 0, unsigned short, short, 160> RgLongS;   // 49 KB: three workgroups per CU; four fifths of the kilobase reads' strand searches fit
 typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongB;   // 62 KB, two per CU: most of the rest
+// ordinary reads inside repeat families (an hg38-like genome: 7 % of the strand searches outgrow RgMid): 23 KB per wave, six workgroups of one wave per CU
+typedef RgStore<256, 512, 512, 0, 0, unsigned short, short, 96> RgMid2;
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;
 // the same capacity chained as the LDS tiers do it (pieces, chain starts in registers, records for multi-seed chains only), tables in an HBM
 // slab, exporting: for the repeat reads that outgrow the LDS tiers but have no tied chain starts
@@ -1488,11 +1490,11 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 #define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
 #define RG_XREGS 64      // regions of one strand search (a lane each in the containment test); a read inside a high-copy repeat has dozens
 #define RG_XCBLK 16      // chain records staged at a time
-template <int QC, int WC, int XSD>
+template <int QC, int WC, int XSD, int XRG = RG_XREGS>
 struct RgC2rT {
-	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
+	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
 	unsigned long long pf[RG_NPF];
-	bsx_region_t regs[RG_XREGS];
+	bsx_region_t regs[XRG];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
 	RgXExt xe[RG_XCBLK];     // and, when the record has them, the extensions made ahead of this launch (k_ext4.hip)
 	RgXSeed sd[XSD];         // a window [sd_lo, sd_hi) over the record's seeds: the current chain's lists lie inside it
@@ -1506,7 +1508,8 @@ struct RgC2rT {
 	uint8_t qrow[QC > RG_QCAP ? QC : 4];
 };
 typedef RgC2rT<RG_QCAP, RG_WIN, RG_XSEEDS> RgC2r;
-typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
+typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;
+typedef RgC2rT<RG_QCAP, RG_WIN, 256, 256> RgC2rB;   // reads inside repeat families: up to 256 regions of a strand search, 256 seeds of a chain (22 KB: seven waves per CU); for what k_c2r<RgC2r> declines   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
 
 template <typename WT>
 __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, int l_query, int parent, uint32_t qoff,
@@ -1585,10 +1588,11 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(W.n_regs);
-				{ // a lane per region made so far (nr <= RG_XREGS <= 64): the reference's loop stops at the first region that passes
+				u = nr;
+				for (int rbase = 0; rbase < nr && u == nr; rbase += 64) { // a lane per region made so far, 64 at a time: the reference's loop stops at the first region that passes
 					bool hit = false;
-					if (lane < nr) {
-						const bsx_region_t &rg = W.regs[lane];
+					if (rbase + lane < nr) {
+						const bsx_region_t &rg = W.regs[rbase + lane];
 						if (!(s_rbeg < rg.rb || s_rbeg + s_len > rg.re || s_qbeg < rg.qb || s_qbeg + s_len > rg.qe) && !(s_len - rg.seedlen0 > .1 * l_query)) {
 							int qd = s_qbeg - rg.qb; long long rd = s_rbeg - rg.rb;
 							int max_gap = rg_gap(gap, P, (int)(qd < rd ? qd : rd));
@@ -1601,7 +1605,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						}
 					}
 					const unsigned long long hm = __ballot(hit);
-					u = hm ? (int)__builtin_ctzll(hm) : nr;
+					if (hm) u = rbase + (int)__builtin_ctzll(hm);
 				}
 				if (u < nr) { // is there a later seed of the list (in sorted order) that may lead to a different alignment?  A lane per seed
 					bool any = false;
@@ -1687,7 +1691,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 				}
 				R.seedcov = uni(wave_sum_i32(cov));
 				R.w = aw0 > aw1 ? aw0 : aw1; R.seedlen0 = s_len; R.frac_rep = frac_rep;
-				if (uni(W.n_regs) == RG_XREGS) return 6;
+				if (uni(W.n_regs) == WT::XREGS) return 6;
 				WAVE_SYNC();
 				if (lane == 0) { W.regs[W.n_regs] = R; ++W.n_regs; }
 				WAVE_SYNC();
@@ -2132,6 +2136,9 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
 	if (long_reads == 3)   // kilobase reads, the larger of the two table sizes
 		hipLaunchKernelGGL((k_regions_mid<RgLongB, RgDpLiteL, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
+	else if (long_reads == 4)   // reads of ordinary length: twice RgMid's tables, the tier behind it
+		hipLaunchKernelGGL((k_regions_mid<RgMid2, RgDpLite, 1, 2>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
+		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
 	else if (long_reads == 2)   // the larger tables for reads of ordinary length (the tier behind k_regions_mid<RgMid>)
 		hipLaunchKernelGGL((k_regions_mid<RgLongB, RgDpLite, 1, 1>), dim3(grid * 2), dim3(64), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, next_list, next_count, counters, pos_off, pos, X, quota);
@@ -2147,7 +2154,9 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
                 unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads)
 {
 	RgXPool X = rgx_pool(&XA);
-	if (long_reads)
+	if (long_reads == 2)   // ordinary reads with many regions or long seed lists: the strand searches k_c2r<RgC2r> declined (X names them)
+		hipLaunchKernelGGL((k_c2r<RgC2rB, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	else if (long_reads)
 		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
 	else
 	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);

@@ -694,7 +694,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.qpack.reserve(seedt_pack_bytes(n))) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 29 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 33 + 64)) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 6 * regions_slab_bytes(2))) != BSX_OK) return rc;   // (the exporting form runs three workgroups per CU)
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
@@ -718,6 +718,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int *retry_m = (int*)((char*)L.regmeta.p + (size_t)n * 20);
 	int *retry_l = (int*)((char*)L.regmeta.p + (size_t)n * 24);
 	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 28;
+	int *retry_c = (int*)((char*)L.regmeta.p + (((size_t)n * 29 + 3) & ~(size_t)3));   // what the first chains -> regions launch declines (ordinary chunks)
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
 	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
@@ -734,6 +735,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	L.rb_tasks = n;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
+	HIPCHK(hipMemsetAsync(ctr + 20, 0, 8, L.st));   // (count and cursor of the second chains -> regions launch)
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)(ctr + 4) + 1), (int)(uint32_t)(direct_n >> 32), 1, L.st));
 	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 3;   // 0: none, 1: seeding, 2: seeding and regions, 3: the same but the HBM tiers (a few long strand searches on a few waves) hold nobody back (measured A/B on one box, 16 chunks: 1.76 / 1.81 M reads/s with 2, 2.00 / 1.89 M with 3)
@@ -771,7 +773,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
-	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c) -> int {
+	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c, int *rc_list, unsigned int *rc32) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
@@ -795,6 +797,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (use_mid && long_reads) { // kilobase reads: a second LDS tier with larger tables (two workgroups per CU) for what outgrows the first (three)
 			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 3);
+			to2 = rl; n2c = l_count;
+			TIER_MARK("tier 1c");
+		}
+		static const bool use_1c = !(getenv("BSX_TIER1C") && atoi(getenv("BSX_TIER1C")) == 0);   // ($BSX_TIER1C=0: the tier sequence of rounds 2-4, for the A/B)
+		const bool tier1c = use_mid && !long_reads && !export_all && use_1c;
+		if (tier1c) { // ordinary reads inside repeat families: an LDS tier with twice the tables behind the first two (round 5)
+			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                   (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rm, k32 + 10, l_cursor, rl, l_count, ctr, posoffs, d_pos, XP, mid_quota, 4);
 			to2 = rl; n2c = l_count;
 			TIER_MARK("tier 1c");
 		}
@@ -864,6 +874,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
 		}
+		if (tier1c) { // ... and what the chains -> regions launch declines (more than 64 regions, lists of more than 128 seeds) gets a second one with larger tables
+			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rc_list, rc32, ctr, c2r_quota);
+			RgXPoolArg XB2 = XP;
+			XB2.xlist = rc_list; XB2.xcount = rc32;
+			launch_c2r(st, d->n_cu * 2, d->ix, L.sc, R, d_reads, T, XB2, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rc32 + 1, to2, n2c, ctr, 1 << 30, 2);   // (few strand searches, long ones: persistent waves)
+		} else
 		launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
 		if (main_seq && chain == 3) { // the HBM tiers (a few long strand searches on a few waves) do not hold the next chunk's region launches back
 			std::lock_guard<std::mutex> g(d->chain_mu);
@@ -879,7 +895,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16))) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16), retry_c, (unsigned int*)(ctr + 20))) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -918,25 +934,25 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[redo[j]];
 			// device side, per re-seeded strand search: task | interval offset | region offset | position offset | export offset | interval
 			// count | region count | three tier lists | export list | tier class
-			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 16 + 4 + 1) + 1024)) != BSX_OK) return rc;
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 1) + 1024)) != BSX_OK) return rc;
 			if ((rc = L.rs.hres.reserve(n2 * 12 + 64)) != BSX_OK) return rc;
 			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
 			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; long long *posoff2 = roff2 + n2; long long *xoff2 = posoff2 + n2;
-			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *rl2 = rb2 + n2, *xlist2 = rl2 + n2;
-			unsigned char *cls2 = (unsigned char*)(xlist2 + n2);
+			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *rl2 = rb2 + n2, *xlist2 = rl2 + n2, *rc2l = xlist2 + n2;
+			unsigned char *cls2 = (unsigned char*)(rc2l + n2);
 			// its own cursors (u64 slots 96.. of the lane's counter block): u32 [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3
 			// count [4] tier-3 cursor [7] seed task cursor [10] count of what the larger LDS tier hands on [11] its cursor; slot 102: exported
 			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
 			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemsetAsync(ctr + 96, 0, 64, L.st2));
+			HIPCHK(hipMemsetAsync(ctr + 96, 0, 72, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18))) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18), rc2l, (unsigned int*)(ctr + 104))) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
@@ -988,8 +1004,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		unsigned int hc[12]; unsigned long long hu[12];
 		D2H(L.st, hc, c32, sizeof(hc));
 		D2H(L.st, hu, ctr, sizeof(hu));
-		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, left tier 2: %u | every tier exports: %d\n",
-		        (long long)n, hu[4], hu[11], hc[1], hc[10], hc[3], export_all ? 1 : 0);
+		unsigned long long hu20 = 0;
+		D2H(L.st, &hu20, ctr + 20, 8);
+		fprintf(stderr, "[M::regions_batch] %lld strand searches: %llu intervals, %llu occurrences looked up ahead | left tier 1: %u, left tier 1b: %u, reached tier 2: %u, left tier 2: %u | second chains -> regions launch: %u | every tier exports: %d\n",
+		        (long long)n, hu[4], hu[11], hc[1], hc[10], long_reads || export_all ? hc[6] : hc[6] ? hc[6] : hc[10], hc[3], (unsigned int)hu20, export_all ? 1 : 0);
 		unsigned long long sp[8];
 		D2H(L.st, sp, ctr + 48, sizeof(sp));
 		HIPCHK(hipMemsetAsync(ctr + 48, 0, sizeof(sp), L.st));
