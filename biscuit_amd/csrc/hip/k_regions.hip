@@ -1710,12 +1710,288 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 #include "sw_pass.hpp"
 #define RG_SHORT_EXT 50
 #define RG_SHORT_LEN 200
-__global__ void __launch_bounds__(64, 4)
-k_seedsw(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X, unsigned int *cursor, unsigned long long *counters)
+// Round 5: the alignments of a chunk's seeds are one batch.  A kilobase read has a few dozen seeds to score on its own strand (and the other
+// strand's chance seeds as well), 16 M jobs of <= 199 x 199 cells per chunk; a wavefront per strand search with a wavefront per
+// alignment (the form of rounds 3-4: 730 ms per chunk) spends two wave-wide prefix scans per row.  Now:
+//   k_seedsw_prep   a wavefront per strand search, a lane per seed: the window of mem_seed_sw, the seed's job appended to the chunk's list;
+//                   the seed remembers its job's number (bit 31 of its score field) until the scores are in
+//   k_swl16         ksw_i16 (ksw.c:232-334) as Farrar's striped kernel itself, the 8 word lanes of its SSE register being 8 lanes of the
+//                   wavefront: EIGHT jobs to a wave (k_swl.hip does the same for ksw_u8 with 16 lanes); score only
+//   k_seedsw_apply  a wavefront per strand search: seeds below the threshold leave their lists, the lists are compacted in place
+struct SswJob { long long rb; uint32_t qoff; short qlen, tlen; };   // qoff: bit 31 = the strand's matrix (parent)
+#define SSW_PENDING 0x80000000u
+#define SSW_BLK 1024u
+#define SSW_NOROOM 0x3fffffffu   // the job list was full: k_seedsw_apply aligns the seed itself
+
+// the window of mem_seed_sw (memchain.c:501-535) for a seed: false = no alignment is made (the seed keeps len * a)
+__device__ __forceinline__ bool ssw_window(const DevIndex &ix, int l_query, long long s_rbeg, int s_qbeg, int s_len, int &qb_, int &qlen_, long long &rb_, int &tlen_)
+{
+	const long long l_pac = ix.l_pac;
+	if (s_len >= RG_SHORT_LEN) return false;
+	int qb = s_qbeg, qe = s_qbeg + s_len;
+	long long rb = s_rbeg, re = s_rbeg + s_len;
+	const long long mid = (rb + re) >> 1;
+	qb -= RG_SHORT_EXT; qb = qb > 0 ? qb : 0;
+	qe += RG_SHORT_EXT; qe = qe < l_query ? qe : l_query;
+	rb -= RG_SHORT_EXT; rb = rb > 0 ? rb : 0;
+	re += RG_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+	if (qe - qb >= RG_SHORT_LEN || re - rb >= RG_SHORT_LEN) return false;
+	// bns_fetch_seq (bntseq.c:415-437): the span is cut to the contig of its middle
+	const int is_rev = mid >= l_pac;
+	const int rid = rg_pos2rid(ix, (const long long*)ix.ctg_off, rg_depos(l_pac, mid));
+	long long far_beg = ix.ctg_off[rid], far_end = ix.ctg_off[rid + 1];
+	if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+	rb = rb > far_beg ? rb : far_beg; re = re < far_end ? re : far_end;
+	qb_ = qb; qlen_ = qe - qb; rb_ = rb; tlen_ = (int)(re - rb);
+	return qlen_ > 0 && tlen_ > 0;
+}
+
+// A kilobase read's strand search exports hundreds of chains of one or two seeds (chance 19-mers) and a few long ones: chains of up to
+// SSW_SHORT seeds get a lane each, 64 chains at a time; the long ones a wavefront, 64 seeds at a time.
+#define SSW_SHORT 8
+struct SswAlloc { unsigned int at, left; };   // the wave's block of job numbers (one atomic on the chunk's counter per SSW_BLK jobs)
+__device__ __forceinline__ unsigned int ssw_take(SswAlloc &A, bool want, SswJob *jobs, unsigned int job_cap, unsigned int *job_count, int lane)
+{   // a job number for every lane that wants one (wave-uniform control flow); what a block leaves is filled with empty jobs
+	const unsigned long long m = __ballot(want);
+	if (m == 0) return 0;
+	const unsigned int cnt = (unsigned int)__popcll(m);
+	if (cnt > A.left) {
+		SswJob Z; Z.rb = 0; Z.qoff = 0; Z.qlen = 0; Z.tlen = 0;
+		for (unsigned int z = lane; z < A.left; z += 64) if (A.at + z < job_cap) jobs[A.at + z] = Z;
+		unsigned int at = 0;
+		if (lane == 0) at = atomicAdd(job_count, (unsigned int)SSW_BLK);
+		A.at = (unsigned int)uni((int)__shfl((int)at, 0)); A.left = SSW_BLK;
+	}
+	const unsigned int id = A.at + (unsigned int)__popcll(m & ((1ull << lane) - 1));
+	A.at += cnt; A.left -= cnt;
+	return id;
+}
+__device__ __forceinline__ void ssw_prep_seed(const DevIndex &ix, SswAlloc &A, bool have, RgXSeed *slot, int l_query, uint32_t qoff, int parent,
+                                              SswJob *jobs, unsigned int job_cap, unsigned int *job_count, int lane)
+{
+	bool want = false;
+	int qb = 0, qlen = 0, tlen = 0; long long rb = 0;
+	RgXSeed sd; sd.rbeg = 0; sd.qbeg = sd.len = 0; sd.sb = 0;
+	if (have) { sd = *slot; want = ssw_window(ix, l_query, sd.rbeg, sd.qbeg, sd.len, qb, qlen, rb, tlen); }
+	const unsigned int id = ssw_take(A, want, jobs, job_cap, job_count, lane);
+	if (want) {
+		if (id < job_cap) {
+			SswJob J; J.rb = rb; J.qoff = (qoff + (uint32_t)qb) | (parent ? 0x80000000u : 0u); J.qlen = (short)qlen; J.tlen = (short)tlen;
+			jobs[id] = J;
+			slot->sb = (int)(SSW_PENDING | id << 1 | (unsigned int)XS_BAD(sd));
+		} else slot->sb = (int)(SSW_PENDING | SSW_NOROOM << 1 | (unsigned int)XS_BAD(sd));
+	}
+}
+
+__global__ void __launch_bounds__(64, 8)
+k_seedsw_prep(DevIndex ix, const bsx_seed_task_t *tasks, RgXPool X, unsigned int *cursor, SswJob *jobs, unsigned int job_cap, unsigned int *job_count)
 {
 	const int lane = wave_lane();
 	const int n = (int)*X.xcount;
-	const long long l_pac = ix.l_pac;
+	SswAlloc A; A.at = 0; A.left = 0;
+	for (;;) {
+		int i = 0;
+		if (lane == 0) i = (int)atomicAdd(cursor, 1u);
+		i = uni(__shfl(i, 0));
+		if (i >= n) break;
+		const int t = uni(X.xlist[i]);
+		RgXHdr *H = (RgXHdr*)(X.base + uni64(X.xoff[t]));
+		if (uni(H->flt) == RG_NOFLT) continue;
+		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent);
+		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
+		const int nk = uni(H->n_chains);
+		RgXChain *XC = (RgXChain*)(H + 1);
+		RgXSeed *XS = (RgXSeed*)(XC + nk);
+		for (int cbase = 0; cbase < nk; cbase += 64) {
+			const int c = cbase + lane;
+			int seed_off = 0, n_main = 0;
+			if (c < nk) { seed_off = XC[c].seed_off; n_main = (int)XC[c].n_main; }
+			const bool shortc = n_main <= SSW_SHORT;
+			const int rounds = wave_max_i32(shortc ? n_main : 0);
+			for (int j = 0; j < rounds; ++j)
+				ssw_prep_seed(ix, A, shortc && j < n_main, XS + seed_off + j, l_query, qoff, parent, jobs, job_cap, job_count, lane);
+			unsigned long long longs = __ballot(!shortc);
+			while (longs) {
+				const int src = __ffsll((long long)longs) - 1;
+				longs &= longs - 1;
+				const int so = uni(__shfl(seed_off, src)), nm = uni(__shfl(n_main, src));
+				for (int base = 0; base < nm; base += 64)
+					ssw_prep_seed(ix, A, base + lane < nm, XS + so + base + lane, l_query, qoff, parent, jobs, job_cap, job_count, lane);
+			}
+		}
+	}
+	SswJob Z; Z.rb = 0; Z.qoff = 0; Z.qlen = 0; Z.tlen = 0;
+	for (unsigned int z = lane; z < A.left; z += 64) if (A.at + z < job_cap) jobs[A.at + z] = Z;
+}
+
+// ---- ksw_i16 (ksw.c:232-334), score only, SIXTEEN jobs to a wavefront.  A job is 8 lanes -- the 8 words of the SSE register (k_swl.hip does
+// the same for ksw_u8 with 16 lanes) -- and every lane carries two jobs, one in each half of its 32-bit registers (v_pk_add_u16 / v_pk_sub_u16
+// clamp / v_pk_max_i16: the SSE instructions themselves, two jobs at a time).
+//   * all 16 jobs run with the stripe count of the longest query among them.  The local-alignment matrix does not depend on how its columns are
+//     dealt to stripes, and the padding columns behind a query (profile 0, as ksw_qinit pads its last stripe) cannot raise the maximum: what
+//     reaches them came from a cell that was counted already.
+//   * the query profile is kept biased (score + bias as an unsigned byte, four target bases to a register); a row's scores for both jobs come
+//     from one v_perm_b32.  h = max(0, h + s) instead of h + s: the next instruction is a maximum with E and F, which are >= 0.
+//   * E and F floor at 0 as in ksw_i16 (_mm_subs_epu16); the scores fit 15 bits (199 columns x an int8 match score)
+//   * the lazy-F loop (ksw.c:285-295) is what it converges to: F carried in from the job's lower lanes by a prefix maximum over the lanes'
+//     last F values (k_swl.hip, swl_row, has the argument)
+#define SSW_SL 25   // stripes: ceil(199 / 8)
+typedef unsigned short ssw_u2 __attribute__((ext_vector_type(2)));
+typedef short ssw_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ssw_u2, a) + __builtin_bit_cast(ssw_u2, b)); }
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(ssw_u2, a), __builtin_bit_cast(ssw_u2, b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ssw_s2, a), __builtin_bit_cast(ssw_s2, b))); }
+__device__ __forceinline__ uint32_t pk_dup(int v) { return (uint32_t)(v & 0xffff) * 0x10001u; }
+__device__ __forceinline__ uint32_t ssw8_or(uint32_t v)   // OR over the job's 8 lanes
+{
+	v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+	v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+	v |= (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror: the other quad of the 8
+	return v;
+}
+__device__ __forceinline__ uint32_t ssw8_pkmax(uint32_t v)
+{
+	v = pk_max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+	v = pk_max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+	v = pk_max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+	return v;
+}
+// the lane's column of every stripe against target bases 0..3, biased.  lut: the register for each read base (0..4, then the padding column's),
+// the two matrices one behind the other
+__device__ __forceinline__ void ssw_profile(uint32_t (&prof)[SSW_SL], const uint8_t *reads, const uint32_t *lut, uint32_t qoff, int qlen, int slen, int k)
+{
+	int q[SSW_SL];
+#pragma unroll
+	for (int j = 0; j < SSW_SL; ++j) {
+		const int c = j + k * slen;   // word k of stripe j is query column j + k * slen (ksw.c:100-107)
+		q[j] = reads[(size_t)qoff + (c < qlen ? c : 0)];   // (all the loads in flight together)
+		q[j] = (j < slen && c < qlen && q[j] < 5) ? q[j] : 5;
+	}
+#pragma unroll
+	for (int j = 0; j < SSW_SL; ++j) prof[j] = lut[q[j]];
+}
+template<bool UNI>   // UNI: deletions and insertions cost the same
+__global__ void __launch_bounds__(256)
+k_swl16(DevIndex ix, DevScoring sc, const uint8_t *reads, const SswJob *jobs, const unsigned int *job_count, unsigned int job_cap, int *scores)
+{
+	const int lane = wave_lane(), g = lane >> 3, k = lane & 7;
+	unsigned int n = *job_count; if (n > job_cap) n = job_cap;
+	const long long wave_id = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+	int bias = 0;
+	for (int i = 0; i < 25; ++i) { bias = (int)sc.ctmat[i] < -bias ? -(int)sc.ctmat[i] : bias; bias = (int)sc.gamat[i] < -bias ? -(int)sc.gamat[i] : bias; }
+	__shared__ uint32_t lut[16];   // [0..5] gamat (parent 0), [8..13] ctmat
+	if (threadIdx.x < 16) {
+		const int q = threadIdx.x & 7;
+		const int8_t *mat = threadIdx.x >> 3 ? sc.ctmat : sc.gamat;
+		lut[threadIdx.x] = q > 4 ? (uint32_t)bias * 0x01010101u
+		                         : ((uint32_t)(uint8_t)(mat[q] + bias) | (uint32_t)(uint8_t)(mat[5 + q] + bias) << 8 | (uint32_t)(uint8_t)(mat[10 + q] + bias) << 16 | (uint32_t)(uint8_t)(mat[15 + q] + bias) << 24);
+	}
+	__syncthreads();
+	const uint32_t biasv = pk_dup(bias), oe_delv = pk_dup(sc.o_del + sc.e_del), oe_insv = pk_dup(sc.o_ins + sc.e_ins), e_delv = pk_dup(sc.e_del), e_insv = pk_dup(sc.e_ins);
+	for (long long q16 = wave_id; q16 * 16 < (long long)n; q16 += n_waves) {
+		const long long jA = q16 * 16 + (g << 1), jB = jA + 1;
+		const bool vA = jA < (long long)n, vB = jB < (long long)n;
+		const SswJob JA = jobs[vA ? jA : 0], JB = jobs[vB ? jB : 0];
+		const int qlenA = vA ? (int)JA.qlen : 0, tlenA = vA ? (int)JA.tlen : 0, qlenB = vB ? (int)JB.qlen : 0, tlenB = vB ? (int)JB.tlen : 0;
+		const int slen = uni(wave_max_i32(((qlenA > qlenB ? qlenA : qlenB) + 7) >> 3));
+		const int rows = uni(wave_max_i32(tlenA > tlenB ? tlenA : tlenB));
+		if (slen == 0 || slen > SSW_SL) { if (k == 0) { if (vA) scores[jA] = 0; if (vB) scores[jB] = 0; } continue; }   // (empty jobs: what a wave left of its block)
+		uint32_t H[SSW_SL], E[SSW_SL], profA[SSW_SL], profB[SSW_SL];
+		ssw_profile(profA, reads, lut + ((JA.qoff >> 31) << 3), JA.qoff & 0x7fffffffu, qlenA, slen, k);
+		ssw_profile(profB, reads, lut + ((JB.qoff >> 31) << 3), JB.qoff & 0x7fffffffu, qlenB, slen, k);
+#pragma unroll
+		for (int j = 0; j < SSW_SL; ++j) H[j] = E[j] = 0;
+		const uint32_t col0ev = pk_dup(k * slen * sc.e_ins), col1ev = pk_dup(k ? (k - 1) * slen * sc.e_ins : 0);
+		uint32_t gmaxv = 0, hlast = 0;
+		unsigned int twA = 0, twB = 0;   // the target bases of 8 rows, two bits each, the same in the job's 8 lanes
+		for (int i = 0; i < rows; ++i) {
+			if ((i & 7) == 0) {
+				const int ii = i + k;
+				twA = ssw8_or(ii < tlenA ? (unsigned int)dev_ref_base(ix.pac, ix.l_pac, JA.rb + ii) << (k << 1) : 0u);
+				twB = ssw8_or(ii < tlenB ? (unsigned int)dev_ref_base(ix.pac, ix.l_pac, JB.rb + ii) << (k << 1) : 0u);
+			}
+			const int sh = (i & 7) << 1;
+			const uint32_t sel = ((twA >> sh) & 3u) | 0x0c000c00u | (4u + ((twB >> sh) & 3u)) << 16;   // byte 0: job A's score, byte 2: job B's, bytes 1 and 3: zero
+			const uint32_t livem = (i < tlenA ? 0xffffu : 0u) | (i < tlenB ? 0xffff0000u : 0u);
+			// the striped main loop (ksw.c:268-284)
+			uint32_t f = 0, mxv = 0;
+			const int hs = __builtin_amdgcn_update_dpp(0, (int)hlast, DPP_ROW_SHR(1), 0xf, 0xf, false);
+			uint32_t h = k ? (uint32_t)hs : 0u;   // _mm_slli_si128(H[slen - 1], 2)
+#pragma unroll
+			for (int j = 0; j < SSW_SL; ++j) {
+				if (j >= slen) { hlast = H[j > 0 ? j - 1 : 0]; break; }
+				h = pk_subs(pk_add(h, __builtin_amdgcn_perm(profB[j], profA[j], sel)), biasv);
+				uint32_t e = E[j];
+				h = pk_max(h, e);
+				h = pk_max(h, f);
+				mxv = pk_max(mxv, h);
+				const uint32_t hold = H[j];
+				H[j] = h;
+				const uint32_t t = pk_subs(h, oe_delv);
+				E[j] = pk_max(pk_subs(e, e_delv), t);
+				const uint32_t t2 = UNI ? t : pk_subs(h, oe_insv);
+				f = pk_max(pk_subs(f, e_insv), t2);
+				h = hold;
+			}
+			if (slen == SSW_SL) hlast = H[SSW_SL - 1];
+			// f is now F of the column behind the lane's last one -- the next lane's first (what `f = _mm_slli_si128(f, 2)` hands on); through a
+			// whole lane it decays by slen * e_ins: lane k's first column gets max over k' < k of f(k') - (k - 1 - k') * slen * e_ins
+			uint32_t gl = pk_add(f, col0ev);
+			uint32_t t;
+			t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gl, DPP_ROW_SHR(1), 0xf, 0xf, false); gl = pk_max(gl, k >= 1 ? t : 0u);
+			t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gl, DPP_ROW_SHR(2), 0xf, 0xf, false); gl = pk_max(gl, k >= 2 ? t : 0u);
+			t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gl, DPP_ROW_SHR(4), 0xf, 0xf, false); gl = pk_max(gl, k >= 4 ? t : 0u);
+			t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gl, DPP_ROW_SHR(1), 0xf, 0xf, false);
+			uint32_t v = pk_subs(k >= 1 ? t : 0u, col1ev);
+			if (__ballot(v != 0) != 0) {
+#pragma unroll
+				for (int j = 0; j < SSW_SL; ++j) {
+					if (j >= slen) { hlast = H[j > 0 ? j - 1 : 0]; break; }
+					H[j] = pk_max(H[j], v); v = pk_subs(v, e_insv);
+				}
+				if (slen == SSW_SL) hlast = H[SSW_SL - 1];
+			}
+			gmaxv = pk_max(gmaxv, mxv & livem);
+		}
+		gmaxv = ssw8_pkmax(gmaxv);
+		if (k == 0) { if (vA) scores[jA] = (int)(gmaxv & 0xffffu); if (vB) scores[jB] = (int)(gmaxv >> 16); }
+	}
+}
+
+// one seed's score for k_seedsw_apply: from the batch, or -- no room in the chunk's job list -- aligned here, a wavefront for the one
+// alignment (the form of rounds 3-4).  Wave-uniform control flow; `have`: this lane holds a seed.
+__device__ __forceinline__ int ssw_score_of(const DevIndex &ix, const DevScoring &sc, const int8_t *mat, const uint8_t *reads, uint32_t qoff, int l_query,
+                                            bool have, const RgXSeed &sd, const int *scores, unsigned int &n_sw, int lane)
+{
+	const unsigned int sbu = (unsigned int)sd.sb;
+	const bool pending = have && (sbu & SSW_PENDING);
+	const unsigned int id = (sbu >> 1) & 0x3fffffffu;
+	int score = -1;
+	if (pending && id != SSW_NOROOM) score = scores[id];
+	unsigned long long todo = __ballot(pending && id == SSW_NOROOM);
+	while (todo) {
+		const int src = __ffsll((long long)todo) - 1;
+		todo &= todo - 1;
+		const long long s_rbeg = uni64(__shfl((long long)sd.rbeg, src)); const int s_qbeg = uni(__shfl((int)sd.qbeg, src)), s_len1 = uni(__shfl((int)sd.len, src));
+		int qb, qlen, tlen; long long rb; int sc1 = -1;
+		if (ssw_window(ix, l_query, s_rbeg, s_qbeg, s_len1, qb, qlen, rb, tlen)) {
+			const int Q = ((qlen + 7) >> 3) << 3;
+#define SEEDSW_RUN(NC_) do { int qv[NC_]; _Pragma("unroll") for (int c = 0; c < NC_; ++c) { const int jj = (c << 6) + lane; qv[c] = jj < qlen ? (int)reads[(size_t)qoff + qb + jj] : 5; } \
+				const SwPass r = sw_pass<NC_>(ix, mat, 0, qlen, qv, tlen, rb, 1, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, 0, nullptr, lane); sc1 = uni(r.score); } while (0)
+			if (Q <= 128) SEEDSW_RUN(2); else if (Q <= 192) SEEDSW_RUN(3); else SEEDSW_RUN(4);
+		}
+		if (lane == src) score = sc1;
+	}
+	n_sw += (unsigned int)__popcll(__ballot(pending));
+	return score;
+}
+
+__global__ void __launch_bounds__(64, 4)
+k_seedsw_apply(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X, unsigned int *cursor, const int *scores, unsigned long long *counters)
+{
+	const int lane = wave_lane();
+	const int n = (int)*X.xcount;
 	unsigned int n_sw = 0;
 	for (;;) {
 		int i = 0;
@@ -1732,57 +2008,61 @@ k_seedsw(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bs
 		const int nk = uni(H->n_chains);
 		RgXChain *XC = (RgXChain*)(H + 1);
 		RgXSeed *XS = (RgXSeed*)(XC + nk);
-		for (int ci = 0; ci < nk; ++ci) {
-			const int seed_off = uni(XC[ci].seed_off), n_main = uni((int)XC[ci].n_main), n_extra = uni((int)XC[ci].n_extra);
+		for (int cbase = 0; cbase < nk; cbase += 64) {
+			const int c = cbase + lane;
+			int seed_off = 0, n_main = 0, n_extra = 0;
+			if (c < nk) { seed_off = XC[c].seed_off; n_main = (int)XC[c].n_main; n_extra = (int)XC[c].n_extra; }
+			const bool shortc = n_main <= SSW_SHORT;
+			// short chains: a lane each, its seeds one after the other (nobody else touches the chain's lists)
+			const int rounds = wave_max_i32(shortc ? n_main : 0);
 			int k = 0;
-			for (int j = 0; j < n_main; ++j) {
-				RgXSeed sd = XS[seed_off + j];
-				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
-				int score = -1;
-				if (s_len < RG_SHORT_LEN) {
-					int qb = s_qbeg, qe = s_qbeg + s_len;
-					long long rb = s_rbeg, re = s_rbeg + s_len;
-					const long long mid = (rb + re) >> 1;
-					qb -= RG_SHORT_EXT; qb = qb > 0 ? qb : 0;
-					qe += RG_SHORT_EXT; qe = qe < l_query ? qe : l_query;
-					rb -= RG_SHORT_EXT; rb = rb > 0 ? rb : 0;
-					re += RG_SHORT_EXT; re = re < l_pac << 1 ? re : l_pac << 1;
-					if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
-					if (!(qe - qb >= RG_SHORT_LEN || re - rb >= RG_SHORT_LEN)) {
-						// bns_fetch_seq (bntseq.c:415-437): the span is cut to the contig of its middle
-						const int is_rev = mid >= l_pac;
-						const int rid = rg_pos2rid(ix, (const long long*)ix.ctg_off, rg_depos(l_pac, mid));
-						long long far_beg = ix.ctg_off[rid], far_end = ix.ctg_off[rid + 1];
-						if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
-						rb = rb > far_beg ? rb : far_beg; re = re < far_end ? re : far_end;
-						const int qlen = qe - qb, tlen = (int)(re - rb);
-						if (qlen > 0 && tlen > 0) {
-							// as many 64-column register slots as the padded query needs (a seed of 19 with its 2 x 50 bases: two)
-							const int Q = ((qlen + 7) >> 3) << 3;
-#define SEEDSW_RUN(NC_) do { int qv[NC_]; _Pragma("unroll") for (int c = 0; c < NC_; ++c) { const int jj = (c << 6) + lane; qv[c] = jj < qlen ? (int)reads[(size_t)qoff + qb + jj] : 5; } \
-								const SwPass r = sw_pass<NC_>(ix, mat, 0, qlen, qv, tlen, rb, 1, -1, sc.o_del, sc.e_del, sc.o_ins, sc.e_ins, 0, nullptr, lane); score = uni(r.score); } while (0)
-							if (Q <= 128) SEEDSW_RUN(2); else if (Q <= 192) SEEDSW_RUN(3); else SEEDSW_RUN(4);
-							++n_sw;
-						}
-					}
-				}
-				if (score < 0 || score >= flt) {
-					sd.sb = (score < 0 ? s_len * P.a : score) << 1 | XS_BAD(sd);
-					if (lane == 0) XS[seed_off + k] = sd;   // k <= j: behind every entry still to be read
+			for (int j = 0; j < rounds; ++j) {
+				const bool have = shortc && j < n_main;
+				RgXSeed sd; sd.rbeg = 0; sd.qbeg = sd.len = 0; sd.sb = 0;
+				if (have) sd = XS[seed_off + j];
+				const int score = ssw_score_of(ix, sc, mat, reads, qoff, l_query, have, sd, scores, n_sw, lane);
+				if (have && (score < 0 || score >= flt)) {
+					sd.sb = (score < 0 ? (int)sd.len * P.a : score) << 1 | (int)((unsigned int)sd.sb & 1u);
+					XS[seed_off + k] = sd;   // k <= j
 					++k;
 				}
 			}
-			if (k != n_main) {
-				const int shift = n_main - k;
-				for (int base = 0; base < n_extra; base += 64) { // the backup list moves up behind the shortened main list (targets never pass the sources of a later round)
-					const int e = base + lane;
-					RgXSeed v; v.rbeg = 0; v.qbeg = v.len = 0; v.sb = 0;
-					if (e < n_extra) v = XS[seed_off + n_main + e];
+			if (shortc && c < nk && k != n_main) {
+				for (int e = 0; e < n_extra; ++e) XS[seed_off + k + e] = XS[seed_off + n_main + e];   // the backup list moves up behind the shortened main list
+				XC[c].n_main = (unsigned short)k;
+			}
+			// long chains: a wavefront each, 64 seeds at a time -- what stays moves down behind what stayed before
+			unsigned long long longs = __ballot(!shortc);
+			while (longs) {
+				const int src = __ffsll((long long)longs) - 1;
+				longs &= longs - 1;
+				const int so = uni(__shfl(seed_off, src)), nm = uni(__shfl(n_main, src)), ne = uni(__shfl(n_extra, src));
+				int kk = 0;
+				for (int base = 0; base < nm; base += 64) {
+					const int j = base + lane;
+					RgXSeed sd; sd.rbeg = 0; sd.qbeg = sd.len = 0; sd.sb = 0;
+					if (j < nm) sd = XS[so + j];
+					const int score = ssw_score_of(ix, sc, mat, reads, qoff, l_query, j < nm, sd, scores, n_sw, lane);
+					const bool keep = j < nm && (score < 0 || score >= flt);
+					const unsigned long long km = __ballot(keep);
+					sd.sb = (score < 0 ? (int)sd.len * P.a : score) << 1 | (int)((unsigned int)sd.sb & 1u);
+					WAVE_SYNC();   // every lane has read its seed before any is written (kk + rank <= j)
+					if (keep) XS[so + kk + __popcll(km & ((1ull << lane) - 1))] = sd;
 					WAVE_SYNC();
-					if (e < n_extra) XS[seed_off + n_main + e - shift] = v;
-					WAVE_SYNC();
+					kk += __popcll(km);
 				}
-				if (lane == 0) XC[ci].n_main = (unsigned short)k;
+				if (kk != nm) {
+					const int shift = nm - kk;
+					for (int base = 0; base < ne; base += 64) { // (targets never pass the sources of a later round)
+						const int e = base + lane;
+						RgXSeed v; v.rbeg = 0; v.qbeg = v.len = 0; v.sb = 0;
+						if (e < ne) v = XS[so + nm + e];
+						WAVE_SYNC();
+						if (e < ne) XS[so + nm + e - shift] = v;
+						WAVE_SYNC();
+					}
+					if (lane == 0) XC[src + cbase].n_main = (unsigned short)kk;
+				}
 			}
 		}
 	}
@@ -2182,10 +2462,16 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
 		hipLaunchKernelGGL((k_regions_slab<RgHuge, false, RgDp>), dim3(grid), dim3(256), 0, st, ix, sc, P, reads, tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, list, count, cursor, (RgHuge*)slabs, next_list, next_count, counters, pos_off, pos, X);
 }
-void launch_seedsw(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
-                   const RgXPoolArg &XA, unsigned int *cursor, unsigned long long *counters)
-{
+size_t seedsw_job_bytes(void) { return sizeof(SswJob) + sizeof(int); }   // a job and its score
+void launch_seedsw(hipStream_t st, int grid, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                   const RgXPoolArg &XA, unsigned int *cursor, unsigned int *count_cursor, void *jobs, unsigned int job_cap, unsigned long long *counters)
+{   // cursor: k_seedsw_prep's; count_cursor: [0] the job count [1] k_seedsw_apply's cursor (zeroed by the caller)
 	RgXPool X = rgx_pool(&XA);
-	hipLaunchKernelGGL(k_seedsw, dim3(grid), dim3(64), 0, st, ix, sc, P, reads, tasks, X, cursor, counters);
+	SswJob *J = (SswJob*)jobs;
+	int *scores = (int*)(J + job_cap);
+	hipLaunchKernelGGL(k_seedsw_prep, dim3(grid), dim3(64), 0, st, ix, tasks, X, cursor, J, job_cap, count_cursor);
+	if (sc.o_del == sc.o_ins && sc.e_del == sc.e_ins) hipLaunchKernelGGL(k_swl16<true>, dim3(n_cu * 8), dim3(256), 0, st, ix, sc, reads, (const SswJob*)J, (const unsigned int*)count_cursor, job_cap, scores);
+	else hipLaunchKernelGGL(k_swl16<false>, dim3(n_cu * 8), dim3(256), 0, st, ix, sc, reads, (const SswJob*)J, (const unsigned int*)count_cursor, job_cap, scores);
+	hipLaunchKernelGGL(k_seedsw_apply, dim3(grid), dim3(64), 0, st, ix, sc, P, reads, tasks, X, count_cursor + 1, (const int*)scores, counters);
 }
 int regions_long_max_query(void) { return RG_QCAP_LONG; }

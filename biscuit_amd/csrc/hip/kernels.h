@@ -82,8 +82,9 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                 unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads = 0);   // next_list may be null (long reads: what outgrows the tables is left to the caller)
 // C3 between the tiers and launch_c2r: the seed-SW filter of the exported strand searches it applies to (mem_flt_chained_seeds, memchain.c:537-568)
-void launch_seedsw(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
-                   const RgXPoolArg &X, unsigned int *cursor, unsigned long long *counters);
+void launch_seedsw(hipStream_t st, int grid, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
+                   const RgXPoolArg &XA, unsigned int *cursor, unsigned int *count_cursor, void *jobs, unsigned int job_cap, unsigned long long *counters);
+size_t seedsw_job_bytes(void);
 int regions_long_max_query(void);
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,

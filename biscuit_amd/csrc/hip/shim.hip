@@ -33,7 +33,7 @@ struct Lane {
 	DevBuf qpack;            // the chunk's reads as base-3 digits for the seeding kernel (k_seedt.hip)
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
 	int flt_key[3] = {-1, -1, -1};   // what fltab was made for
-	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd;
+	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd, sswjobs;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -711,6 +711,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	static const int use_x4 = getenv("BSX_X4") ? atoi(getenv("BSX_X4")) : 1;
 	const unsigned long long x4_cap = (unsigned long long)n * 12 * lf + (1u << 20);
 	if (use_x4 && !export_all && (rc = L.x4jobs.reserve((size_t)x4_cap * x4_job_bytes())) != BSX_OK) return rc;
+	// the seed filter's alignments (reads of 700 bases and more: memchain.c:501-535) are one batch per chunk: a few dozen per strand search
+	// ($BSX_SSW_CAP, tests: a list too short for the chunk -- what finds no room in it is aligned a wavefront at a time)
+	const unsigned long long ssw_cap = !any_flt ? 0 : getenv("BSX_SSW_CAP") ? std::max(8ull, strtoull(getenv("BSX_SSW_CAP"), 0, 10))
+	                                   : std::min<unsigned long long>((unsigned long long)n * 24 * lf + (1u << 20), 0x3ffffff0ull);
+	if (any_flt && (rc = L.sswjobs.reserve((size_t)ssw_cap * seedsw_job_bytes())) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
 	long long *d_off = (long long*)L.aux.p; int *d_n = (int*)((char*)L.aux.p + (size_t)n * 8);
 	long long *r_off = (long long*)L.regmeta.p; int *r_n = (int*)((char*)L.regmeta.p + (size_t)n * 8);
@@ -773,7 +778,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
-	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c, int *rc_list, unsigned int *rc32) -> int {
+	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c, int *rc_list, unsigned int *rc32, unsigned int *ssw32) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
@@ -817,7 +822,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos, &XP);
 			TIER_MARK("tier 3 (exports)");
-			if (any_flt) launch_seedsw(st, (int)std::min<int64_t>((nT + 3) / 4, (int64_t)d->n_cu * 32), d->ix, L.sc, R, d_reads, T, XP, k32 + 5, ctr);
+			if (any_flt) { // (the side stream's run comes after the main one's on the device -- it waits for the tiers -- and may use the same job list)
+				// ssw32: [0] job count [1] the third launch's cursor; k32[5]: the first launch's
+				launch_seedsw(st, (int)std::min<int64_t>(nT, (int64_t)d->n_cu * 32), d->n_cu, d->ix, L.sc, R, d_reads, T, XP, k32 + 5, ssw32, L.sswjobs.p, (unsigned int)ssw_cap, ctr);
+			}
 			TIER_MARK("seed filter");
 #ifdef BSX_DEBUG_XCHECK
 			if (main_seq) { // debug builds (tools/dbg/lds_variants.sh): every exported record looked at before k_c2r reads it
@@ -895,7 +903,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16), retry_c, (unsigned int*)(ctr + 20))) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16), retry_c, (unsigned int*)(ctr + 20), (unsigned int*)(ctr + 15))) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -945,14 +953,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
 			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
-			HIPCHK(hipMemsetAsync(ctr + 96, 0, 72, L.st2));
+			HIPCHK(hipMemsetAsync(ctr + 96, 0, 80, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18), rc2l, (unsigned int*)(ctr + 104))) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18), rc2l, (unsigned int*)(ctr + 104), (unsigned int*)(ctr + 105))) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));
@@ -1033,6 +1041,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)pf[k];
 		if (tot > 0) fprintf(stderr, "[M::regions_batch] wave cycles by stage (all tiers): intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% chain prologues+seed tests %.1f%% extension %.1f%% | %.0f M cycles, %llu extensions, %llu rows\n",
 		        100 * pf[0] / tot, 100 * pf[1] / tot, 100 * pf[2] / tot, 100 * pf[3] / tot, 100 * pf[4] / tot, 100 * pf[5] / tot, 100 * pf[6] / tot, 100 * pf[7] / tot, tot * 1e-6, pf[8], pf[9]);
+		if (pf[10]) fprintf(stderr, "[M::regions_batch] seed filter: %llu alignments\n", pf[10]);
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts_out);
 	if (trace) fprintf(stderr, "[M::regions_batch] entry to kernels enqueued %.0f ms | tiers done to regions downloaded %.0f ms (%llu regions)\n",

@@ -88,6 +88,16 @@ def test_occurrence_table_overflow(data):
         assert run(HIP, args, data, env={"BSX_POS_CAP": cap}) == want, cap
 
 
+def test_seed_filter_job_list_overflow(data):
+    """the seed filter's alignments go through a chunk-wide job list (k_seedsw_prep -> k_swl16 -> k_seedsw_apply); seeds that find no
+    room in it are aligned a wavefront at a time by the last of the three.  Same SAM with no room, little room and room for all."""
+    for ci in (10, 13):
+        args = CASES[ci][1]
+        want = run(CPU, args, data)
+        for cap in (None, "8", "3000"):
+            assert run(HIP, args, data, env={"BSX_SSW_CAP": cap} if cap else None) == want, (CASES[ci][0], cap)
+
+
 def _on_device(stderr):
     import re
     m = re.findall(r"\[M::regions\] on device (\d+) \| declined: (.*)", stderr)

@@ -20,3 +20,9 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INS
 	[ -n "$(find "$OUT/pmc_$name" -name "*counter_collection.csv" 2>/dev/null | head -1)" ] || echo "pmc group $grp: no counter file" >> "$OUT/errors.txt"
 done
 find "$OUT" -name "*.csv" | head -50 > "$OUT/files.txt"
+# gpurun brings back at most 64 MiB: the summaries are made here, the raw traces (tens of MB each) stay behind
+cd "$ROOT"
+PROFILES_OUT="$OUT/summary" GENOME_PROFILE=$GP python tools/summarize_profiles.py "$OUT" "$TAG" > "$OUT/summarize.log" 2>&1
+find "$OUT" -name "*.csv" -size +1M -delete
+find "$OUT" -name "*.db" -delete
+du -sh "$OUT" >> "$OUT/summarize.log"

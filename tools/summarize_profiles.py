@@ -10,7 +10,8 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[-1]
 extra = sys.argv[2] if len(sys.argv) > 3 else None
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+out = os.environ.get("PROFILES_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")   # ($PROFILES_OUT: on the GPU box, into gpurun_out/)
+os.makedirs(out, exist_ok=True)
 for name in ("bench_kernel_stats.csv", "bench_domain_stats.csv"):
     p = os.path.join(src, "trace", name)
     if os.path.exists(p):
