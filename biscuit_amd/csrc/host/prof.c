@@ -13,14 +13,20 @@
 #include "bsx_core.h"
 
 #define PROF_MAX (1 << 22)
-static void **g_pc; static volatile long g_n; static const char *g_path;
+static void **g_pc, **g_ra; static volatile long g_n; static const char *g_path;
+static char *g_lo, *g_hi;   /* this library, roughly: 64 MB from its base is enough to tell it from libc */
 
 static void on_prof(int sig, siginfo_t *si, void *uc_)
 {
 	ucontext_t *uc = (ucontext_t*)uc_;
 	long k = __sync_fetch_and_add(&g_n, 1);
 	(void)sig; (void)si;
-	if (k < PROF_MAX) g_pc[k] = (void*)uc->uc_mcontext.gregs[REG_RIP];
+	if (k < PROF_MAX) {
+		g_pc[k] = (void*)uc->uc_mcontext.gregs[REG_RIP];
+		/* a sample outside this library (memcpy, memset ...: leaf routines that push nothing): the word on top of the stack is the return
+		 * address into whoever called it -- a guess, kept only if it points back into this library */
+		g_ra[k] = ((char*)g_pc[k] < g_lo || (char*)g_pc[k] >= g_hi) ? *(void**)uc->uc_mcontext.gregs[REG_RSP] : 0;
+	}
 }
 static int cmp_ptr(const void *a, const void *b) { const void *x = *(void* const*)a, *y = *(void* const*)b; return x < y ? -1 : x > y; }
 /* "count offset object" per distinct address (offset inside its shared object: tools/prof_symbols.py turns them into functions with nm) */
@@ -31,6 +37,7 @@ static void prof_dump(void)
 	memset(&off, 0, sizeof(off));
 	setitimer(ITIMER_PROF, &off, 0);
 	if (!g_path || n == 0) return;
+	for (i = 0; i < n; ++i) if (g_ra[i] && (char*)g_ra[i] >= g_lo && (char*)g_ra[i] < g_hi) g_pc[i] = (void*)((unsigned long)g_ra[i] | 1ul << 62);   /* marked: "called from" */
 	qsort(g_pc, (size_t)n, sizeof(void*), cmp_ptr);
 	f = fopen(g_path, "w");
 	if (!f) return;
@@ -38,8 +45,10 @@ static void prof_dump(void)
 	for (i = 0; i < n; ) {
 		long j = i; Dl_info di; const char *fl = "?"; unsigned long base = 0;
 		while (j < n && g_pc[j] == g_pc[i]) ++j;
-		if (dladdr(g_pc[i], &di) && di.dli_fname) { fl = di.dli_fname; base = (unsigned long)di.dli_fbase; }
-		fprintf(f, "%ld %lx %s\n", j - i, (unsigned long)g_pc[i] - base, fl);
+		const int from = (int)((unsigned long)g_pc[i] >> 62 & 1);
+		void *pc = (void*)((unsigned long)g_pc[i] & ~(1ul << 62));
+		if (dladdr(pc, &di) && di.dli_fname) { fl = di.dli_fname; base = (unsigned long)di.dli_fbase; }
+		fprintf(f, "%ld %lx %s%s\n", j - i, (unsigned long)pc - base, from ? "libc<-" : "", fl);
 		i = j;
 	}
 	fclose(f);
@@ -49,7 +58,8 @@ __attribute__((constructor)) static void prof_init(void)
 	struct sigaction sa; struct itimerval it;
 	g_path = getenv("BSX_PROF_SAMPLE");
 	if (!g_path || !*g_path) { g_path = 0; return; }
-	g_pc = (void**)malloc(sizeof(void*) * PROF_MAX);
+	g_pc = (void**)malloc(sizeof(void*) * PROF_MAX); g_ra = (void**)malloc(sizeof(void*) * PROF_MAX);
+	{ Dl_info di; if (dladdr((void*)prof_dump, &di) && di.dli_fbase) { g_lo = (char*)di.dli_fbase; g_hi = g_lo + (64l << 20); } }
 	memset(&sa, 0, sizeof(sa));
 	sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
 	sigaction(SIGPROF, &sa, 0);

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <limits.h>
 #include "align_types.h"
+#include "sort_tmpl.h"
 
 #define PATCH_MAX_R_BW 0.05f       /* mem_alnreg.c:51-52 */
 #define PATCH_MIN_SC_RATIO 0.90f
@@ -24,12 +25,10 @@ static int reg_score_lt(const void *a_, const void *b_)                         
  * repeat-rich genome that was most of the host's time.) */
 typedef struct { int64_t re; int idx; } prox_re_t;
 typedef struct { int64_t rb; int score, qb, idx; } prox_sc_t;
-static int prox_re_lt(const void *a, const void *b) { return ((const prox_re_t*)a)->re < ((const prox_re_t*)b)->re; }
-static int prox_sc_lt(const void *a_, const void *b_)
-{
-	const prox_sc_t *a = (const prox_sc_t*)a_, *b = (const prox_sc_t*)b_;
-	return a->score > b->score || (a->score == b->score && (a->rb < b->rb || (a->rb == b->rb && a->qb < b->qb)));
-}
+#define PROX_RE_LT(a, b) ((a)->re < (b)->re)
+#define PROX_SC_LT(a, b) ((a)->score > (b)->score || ((a)->score == (b)->score && ((a)->rb < (b)->rb || ((a)->rb == (b)->rb && (a)->qb < (b)->qb))))
+BSX_SORT_DEFINE(sort_prox_re, prox_re_t, PROX_RE_LT)
+BSX_SORT_DEFINE(sort_prox_sc, prox_sc_t, PROX_SC_LT)
 static void regs_sort(reg_v *regs, int by_score)
 {
 	size_t n = regs->n, i;
@@ -43,7 +42,7 @@ static void regs_sort(reg_v *regs, int by_score)
 	px = n * w <= sizeof(stackbuf) ? stackbuf : (char*)malloc(n * w);
 	if (by_score) { prox_sc_t *q = (prox_sc_t*)px; for (i = 0; i < n; ++i) { q[i].rb = regs->a[i].rb; q[i].score = regs->a[i].score; q[i].qb = regs->a[i].qb; q[i].idx = (int)i; } }
 	else { prox_re_t *q = (prox_re_t*)px; for (i = 0; i < n; ++i) { q[i].re = regs->a[i].re; q[i].idx = (int)i; } }
-	bsx_introsort(px, n, w, by_score ? prox_sc_lt : prox_re_lt);
+	if (by_score) sort_prox_sc(n, (prox_sc_t*)px); else sort_prox_re(n, (prox_re_t*)px);
 	for (i = 0; i < n; ++i) if ((by_score ? ((prox_sc_t*)px)[i].idx : ((prox_re_t*)px)[i].idx) != (int)i) { moved = 1; break; }
 	if (moved) {
 		tmp = (reg_t*)malloc(sizeof(reg_t) * n);
@@ -135,14 +134,13 @@ void bsx_regs_sort_dedup(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int can
  * break (equal ends, or equal (score, start, query start) with the new region): with ties the outcome depends on klib's introsort
  * and on the order it starts from, so those calls go through bsx_regs_sort_dedup on the list as the reference would hold it. */
 void bsx_regs_inc_free(bsx_regs_inc_t *st) { free(st->ord); st->ord = 0; st->valid = st->m = 0; }
-static int inc_re_cmp(const void *a, const void *b) { const prox_re_t *x = (const prox_re_t*)a, *y = (const prox_re_t*)b; return x->re < y->re ? -1 : x->re > y->re; }
 static void inc_rebuild(reg_v *regs, bsx_regs_inc_t *st)
 {
 	size_t n = regs->n, i;
 	prox_re_t *px = (prox_re_t*)malloc(sizeof(prox_re_t) * (n ? n : 1));
 	if (st->m < (int)n + 8) { st->m = (int)n * 2 + 16; st->ord = (int*)realloc(st->ord, sizeof(int) * (size_t)st->m); }
 	for (i = 0; i < n; ++i) { px[i].re = regs->a[i].re; px[i].idx = (int)i; }
-	qsort(px, n, sizeof(prox_re_t), inc_re_cmp);
+	sort_prox_re(n, px);   /* (ties make the state invalid: their order does not matter) */
 	st->valid = 1;
 	for (i = 0; i < n; ++i) { st->ord[i] = px[i].idx; if (i && px[i].re == px[i - 1].re) st->valid = 0; }
 	/* (the list comes out of mem_sort_deduplicate: in the second sort's order, identical (score, rb, qb) already removed) */
@@ -220,6 +218,33 @@ static int reg_hash_lt2(const void *a_, const void *b_)  /* alnreg_hlt2: is_alt,
 	return a->is_alt < b->is_alt || (a->is_alt == b->is_alt && (a->score > b->score || (a->score == b->score && a->hash < b->hash)));
 }
 
+/* ... on proxies as well (regs_sort above has the argument): the keys and the record's index */
+typedef struct { uint64_t hash; int score, is_alt, idx; } prox_h_t;
+#define PROX_H_LT(a, b) ((a)->score > (b)->score || ((a)->score == (b)->score && ((a)->is_alt < (b)->is_alt || ((a)->is_alt == (b)->is_alt && (a)->hash < (b)->hash))))
+#define PROX_H_LT2(a, b) ((a)->is_alt < (b)->is_alt || ((a)->is_alt == (b)->is_alt && ((a)->score > (b)->score || ((a)->score == (b)->score && (a)->hash < (b)->hash))))
+BSX_SORT_DEFINE(sort_prox_h, prox_h_t, PROX_H_LT)
+BSX_SORT_DEFINE(sort_prox_h2, prox_h_t, PROX_H_LT2)
+static void regs_sort_hash(reg_v *regs, int second)
+{
+	size_t n = regs->n, i;
+	prox_h_t stackbuf[128], *px;
+	reg_t *tmp;
+	int moved = 0;
+	if (n < 2) return;
+	if (n < 4) { bsx_introsort(regs->a, n, sizeof(reg_t), second ? reg_hash_lt2 : reg_hash_lt); return; }
+	px = n <= sizeof(stackbuf) / sizeof(stackbuf[0]) ? stackbuf : (prox_h_t*)malloc(n * sizeof(prox_h_t));
+	for (i = 0; i < n; ++i) { px[i].hash = regs->a[i].hash; px[i].score = regs->a[i].score; px[i].is_alt = regs->a[i].is_alt; px[i].idx = (int)i; }
+	if (second) sort_prox_h2(n, px); else sort_prox_h(n, px);
+	for (i = 0; i < n; ++i) if (px[i].idx != (int)i) { moved = 1; break; }
+	if (moved) {
+		tmp = (reg_t*)malloc(sizeof(reg_t) * n);
+		for (i = 0; i < n; ++i) tmp[i] = regs->a[px[i].idx];
+		memcpy(regs->a, tmp, sizeof(reg_t) * n);
+		free(tmp);
+	}
+	if (px != stackbuf) free(px);
+}
+
 typedef BSX_VEC(int) int_v;
 
 /* mem_mark_primary_se_core, mem_alnreg.c:252-288 */
@@ -266,7 +291,7 @@ void bsx_mark_primary(const bsx_opt_t *opt, reg_v *regs, int64_t id)
 		p->hash = bsx_hash64((uint64_t)(id + i));
 		if (!p->is_alt) ++regs->n_pri;
 	}
-	bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_hash_lt);
+	regs_sort_hash(regs, 0);
 	bsx_vec_init(z);
 	mark_core(opt, (int)regs->n, regs, &z);
 	for (i = 0; (size_t)i < regs->n; ++i) {
@@ -276,7 +301,7 @@ void bsx_mark_primary(const bsx_opt_t *opt, reg_v *regs, int64_t id)
 	}
 	if (regs->n_pri > 0 && regs->n_pri < regs->n) {
 		bsx_vec_reserve(z, regs->n);
-		bsx_introsort(regs->a, regs->n, sizeof(reg_t), reg_hash_lt2);
+		regs_sort_hash(regs, 1);
 		for (i = 0; (size_t)i < regs->n; ++i) z.a[regs->a[i].secondary_all] = i;
 		for (i = 0; (size_t)i < regs->n; ++i) {
 			if (regs->a[i].secondary >= 0) {
@@ -430,11 +455,9 @@ bsx_pestat_t bsx_pestat(const bsx_opt_t *opt, const bsx_refmeta_t *ref, int n, c
 /* ------------------------------------------------------------------ pairing */
 typedef struct { uint64_t x, y; } pair64_t;
 typedef struct { uint64_t x, y, z; } trio64_t;
-static int pair64_lt(const void *a_, const void *b_)   /* utils.c:46: the 192-bit sort ignores z */
-{
-	const pair64_t *a = (const pair64_t*)a_, *b = (const pair64_t*)b_;
-	return a->x < b->x || (a->x == b->x && a->y < b->y);
-}
+#define PAIR64_LT(a, b) ((a)->x < (b)->x || ((a)->x == (b)->x && (a)->y < (b)->y))   /* utils.c:46: the 192-bit sort ignores z */
+BSX_SORT_DEFINE(sort_pair64, pair64_t, PAIR64_LT)
+BSX_SORT_DEFINE(sort_trio64, trio64_t, PAIR64_LT)
 
 static int region_depos(const bsx_refmeta_t *ref, const reg_t *reg)   /* mem_alnreg.h:135-140 */
 {
@@ -462,7 +485,7 @@ void bsx_pair(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const bsx_pestat_t
 			bsx_vec_push(v, key);
 		}
 	}
-	bsx_introsort(v.a, v.n, sizeof(trio64_t), pair64_lt);
+	sort_trio64(v.n, v.a);
 	for (i = 0; (size_t)i < v.n; ++i) {
 		for (k = i - 1; k >= 0; --k) {
 			int64_t is = 0;
@@ -485,7 +508,7 @@ void bsx_pair(const bsx_opt_t *opt, const bsx_refmeta_t *ref, const bsx_pestat_t
 	}
 	if (pp.n) {
 		int tmp;
-		bsx_introsort(pp.a, pp.n, sizeof(pair64_t), pair64_lt);
+		sort_pair64(pp.n, pp.a);
 		i = (int)(pp.a[pp.n - 1].y >> 32);
 		k = (int)(pp.a[pp.n - 1].y << 32 >> 32);
 		z[v.a[i].y & 1] = (int)(v.a[i].y << 32 >> 34);

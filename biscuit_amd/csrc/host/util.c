@@ -13,6 +13,7 @@
 #include <unistd.h>
 #include <malloc.h>
 #include "bsx_core.h"
+#include "sort_tmpl.h"
 
 BSX_API int bsx_verbose = 3;
 
@@ -129,10 +130,11 @@ done:
 	if (S.tmp != buf) free(S.tmp);
 }
 
-static int lt_u64(const void *a, const void *b) { return *(const uint64_t*)a < *(const uint64_t*)b; }
-static int lt_i64(const void *a, const void *b) { return *(const int64_t*)a < *(const int64_t*)b; }
-void bsx_introsort_u64(size_t n, uint64_t *a) { bsx_introsort(a, n, 8, lt_u64); }
-void bsx_introsort_i64(size_t n, int64_t *a) { bsx_introsort(a, n, 8, lt_i64); }
+#define LT_VAL(a, b) (*(a) < *(b))
+BSX_SORT_DEFINE(sort_u64, uint64_t, LT_VAL)
+BSX_SORT_DEFINE(sort_i64, int64_t, LT_VAL)
+void bsx_introsort_u64(size_t n, uint64_t *a) { sort_u64(n, a); }
+void bsx_introsort_i64(size_t n, int64_t *a) { sort_i64(n, a); }
 
 /* ------------------------------------------------------------------------------------------
  * B-tree, minimum degree 3 (the value kbtree.h:75 derives for 72-byte keys in 512-byte nodes),

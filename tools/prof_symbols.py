@@ -27,6 +27,9 @@ def main():
         n, off, obj = l.split(None, 2)
         n, off, obj = int(n), int(off, 16), obj.strip()
         tot += n
+        via = ""
+        if obj.startswith("libc<-"):   # a sample in a system library whose return address points into this repository's code
+            obj = obj[6:]; via = "libc called from "
         base = os.path.basename(obj)
         local = {"libbiscuit_amd.so": "biscuit_amd/libbiscuit_amd.so", "liboracle_port.so": "oracle/liboracle_port.so"}.get(base)
         if not local and os.path.exists(obj) and len(sys.argv) > 3 and sys.argv[3] in base:
@@ -44,7 +47,7 @@ def main():
                     tabs[base] = (a, nmn)
             a, nm = tabs[base]
             i = bisect.bisect_right(a, off) - 1
-            by[(nm[i] if i >= 0 else "?") + " [" + base + "]"] += n
+            by[via + (nm[i] if i >= 0 else "?") + " [" + base + "]"] += n
         else:
             by["[" + base + "]"] += n
     print("%d samples (ms of CPU)" % tot)
