@@ -25,7 +25,12 @@ static void on_prof(int sig, siginfo_t *si, void *uc_)
 		g_pc[k] = (void*)uc->uc_mcontext.gregs[REG_RIP];
 		/* a sample outside this library (memcpy, memset ...: leaf routines that push nothing): the word on top of the stack is the return
 		 * address into whoever called it -- a guess, kept only if it points back into this library */
-		g_ra[k] = ((char*)g_pc[k] < g_lo || (char*)g_pc[k] >= g_hi) ? *(void**)uc->uc_mcontext.gregs[REG_RSP] : 0;
+		g_ra[k] = 0;
+		if ((char*)g_pc[k] < g_lo || (char*)g_pc[k] >= g_hi) { /* the nearest word up the stack that points into this library (stale words can mislead: a guess) */
+			void **sp = (void**)uc->uc_mcontext.gregs[REG_RSP];
+			int w;
+			for (w = 0; w < 96; ++w) if ((char*)sp[w] >= g_lo && (char*)sp[w] < g_hi) { g_ra[k] = sp[w]; break; }
+		}
 	}
 }
 static int cmp_ptr(const void *a, const void *b) { const void *x = *(void* const*)a, *y = *(void* const*)b; return x < y ? -1 : x > y; }
