@@ -2217,6 +2217,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 	Store &S = slabs[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)];
 	DPT &D = dp[threadIdx.x >> 6];
 	RG_PF_ZERO(D);
+	unsigned long long wave_cyc = 0;
 	const int n = (int)*count;
 	for (;;) {
 		int i = 0;
@@ -2227,6 +2228,7 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 		const int l_query = uni(tasks[t].len), parent = uni(tasks[t].parent), n_iv = uni(task_n[t]);
 		const uint32_t qoff = (uint32_t)uni((int)tasks[t].qoff);
 		const long long po = pos ? uni64(pos_off[t]) : -1;
+		const long long tk0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
 		// status 10: an over-represented interval has to be walked past its first max_occ occurrences; again with eight times as many of it, ...
 		int bi[4], bl[4], nb = 0, status;
 		for (;;) {
@@ -2241,11 +2243,17 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 			else bl[j] <<= 3;
 			WAVE_SYNC();
 		}
+		if (P.prof && lane == 0) { // $BSX_PHASES: the longest strand search of the launch, their sum and number, the busiest wave
+			const unsigned long long dt = (unsigned long long)((long long)__builtin_readcyclecounter() - tk0);
+			unsigned long long *c = counters + (Store::SCAP > 1024 ? 114 : 110);
+			atomicMax(c, dt); atomicAdd(c + 1, dt); atomicAdd(c + 2, 1ull); wave_cyc += dt;
+		}
 		if (status == 11) continue;   // exported (XSPLIT: chunks with long reads, whose chains go through k_seedsw and k_c2r)
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
 		if (next_list && (status == 8 || status == 2 || status == 3 || status == 4 || status == 6) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
 	}
 	RG_PF_FLUSH(D);
+	if (P.prof && lane == 0 && wave_cyc) atomicMax(counters + (Store::SCAP > 1024 ? 117 : 113), wave_cyc);
 }
 
 // Between the first tier and the HBM tiers: the same tables four times larger, still in LDS (two waves per workgroup, three

@@ -1042,6 +1042,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (tot > 0) fprintf(stderr, "[M::regions_batch] wave cycles by stage (all tiers): intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% chain prologues+seed tests %.1f%% extension %.1f%% | %.0f M cycles, %llu extensions, %llu rows\n",
 		        100 * pf[0] / tot, 100 * pf[1] / tot, 100 * pf[2] / tot, 100 * pf[3] / tot, 100 * pf[4] / tot, 100 * pf[5] / tot, 100 * pf[6] / tot, 100 * pf[7] / tot, tot * 1e-6, pf[8], pf[9]);
 		if (pf[10]) fprintf(stderr, "[M::regions_batch] seed filter: %llu alignments\n", pf[10]);
+		{ // the HBM tiers: how long their strand searches take (a wave each)
+			unsigned long long tk[8];
+			D2H(L.st, tk, ctr + 110, sizeof(tk));
+			HIPCHK(hipMemsetAsync(ctr + 110, 0, sizeof(tk), L.st));
+			for (int k = 0; k < 2; ++k) if (tk[4 * k + 2])
+				fprintf(stderr, "[M::regions_batch] tier %d: %llu strand searches, %.2f M cycles each on average, the longest %.1f M, the busiest wave %.1f M, all of them %.0f M\n",
+				        2 + k, tk[4 * k + 2], 1e-6 * tk[4 * k + 1] / tk[4 * k + 2], 1e-6 * tk[4 * k], 1e-6 * tk[4 * k + 3], 1e-6 * tk[4 * k + 1]);
+		}
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts_out);
 	if (trace) fprintf(stderr, "[M::regions_batch] entry to kernels enqueued %.0f ms | tiers done to regions downloaded %.0f ms (%llu regions)\n",
