@@ -9,6 +9,9 @@ carries chunks r*world .. r*world+world-1, one per rank at most:
        link into rank 0, so the round's transfers run side by side instead of one after the other,
     3. rank 0 hands the round's chunks to `sink` in input order and drops them; the device-to-host copies of the later
        senders' chunks (a side stream, pinned buffers) overlap the sink of the earlier ones.
+With `direct_path` (the launcher's --out FILE; one node, one file system) no payload moves at all: step 1 carries the sizes to everybody,
+every rank derives the offset of its own chunk in the output (header + the chunks before it) and writes it there itself (os.pwrite),
+so rank 0 is not the funnel of eight ranks' SAM text.
 It ends with the first round in which some rank has no chunk (round-robin dealing: no later chunk exists).
 Producers (the aligner's writer thread) hand chunks in through `submit`, which blocks once `max_pending`
 chunks wait: host memory of a rank is bounded by a few chunks whatever the input size, rank 0 writes as it
@@ -23,7 +26,7 @@ _EOF = object()
 
 
 class ChunkGather:
-    def __init__(self, rank, world, device, sink, max_pending=3):
+    def __init__(self, rank, world, device, sink, max_pending=3, direct_path=None):
         """device: torch.device the collectives run on (cuda:N under RCCL, cpu under gloo);
         sink(chunk_index, buffer) is called on rank 0 only, in increasing chunk order."""
         self.rank, self.world, self.device, self.sink = rank, world, device, sink
@@ -37,6 +40,9 @@ class ChunkGather:
         import os
         self._sequential = bool(os.environ.get("BSX_GATHER_SEQUENTIAL"))   # one receive at a time (the form of rounds 1-2)
         self._copy_stream = None
+        self.direct_path = direct_path if world > 1 else None   # every rank writes its own chunks into this file at their offsets
+        self.header = b""             # rank 0, direct form: the SAM header (set by the producer before its first chunk)
+        self.bytes_written = 0        # direct form: bytes this rank wrote itself
         self._dead = False            # set when the gather has ended: late producers (another rank failed) are not blocked
 
     # ---- producer side -------------------------------------------------------------------------------------------
@@ -137,6 +143,8 @@ class ChunkGather:
         """gather until the input ends; returns the number of chunks seen (all ranks return the same)"""
         r = 0
         n_chunks = 0
+        if self.direct_path is not None:
+            return self._run_direct()
         while True:
             mine = self._next_own(r * self.world + self.rank)
             n = len(mine) if mine is not None else 0
@@ -220,4 +228,48 @@ class ChunkGather:
             if not all(has for has, _ in metas):
                 break
         self._dead = True
+        return n_chunks
+
+    def _run_direct(self):
+        """the rounds of run() with the sizes alone: every rank writes its own chunk at header + (bytes of all chunks before it)"""
+        import os
+        r = 0
+        n_chunks = 0
+        base = 0
+        fd = -1
+        try:
+            while True:
+                mine = self._next_own(r * self.world + self.rank)
+                n = len(mine) if mine is not None else 0
+                hdr = 0
+                if r == 0 and self.rank == 0:   # the file exists, with its header, before anybody learns the header's length
+                    fd = os.open(self.direct_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                    hdr = len(self.header)
+                    if hdr:
+                        os.pwrite(fd, bytes(self.header), 0)
+                meta = torch.tensor([1 if mine is not None else 0, n, hdr], dtype=torch.int64, device=self.device)
+                metas = [torch.zeros(3, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+                dist.all_gather(metas, meta)
+                metas = [(int(m[0]), int(m[1]), int(m[2])) for m in torch.stack(metas).cpu()]
+                if r == 0:
+                    base = metas[0][2]
+                    if self.rank != 0:
+                        fd = os.open(self.direct_path, os.O_WRONLY)
+                off = base + sum(nb for has, nb, _ in metas[:self.rank] if has)
+                if mine is not None and n:
+                    view = memoryview(mine)
+                    done = 0
+                    while done < n:
+                        done += os.pwrite(fd, view[done:], off + done)
+                    self.bytes_written += n
+                base += sum(nb for has, nb, _ in metas if has)
+                n_chunks += sum(1 for has, _, _ in metas if has)
+                self.rounds += 1
+                r += 1
+                if not all(has for has, _, _ in metas):
+                    break
+        finally:
+            self._dead = True
+            if fd >= 0:
+                os.close(fd)
         return n_chunks

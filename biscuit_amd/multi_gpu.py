@@ -1,7 +1,7 @@
 """Multi-GPU `biscuit align`: one process per GPU, chunks of the input are the shard unit.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
-        -m biscuit_amd.multi_gpu [--out FILE] [--shard chunks|pairs] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
+        -m biscuit_amd.multi_gpu [--out FILE [--via-rank0]] [--shard chunks|pairs] -- [biscuit align options] <index base> <in1.fq> [in2.fq]
 
 Every rank cuts the input into the reference's chunks (10 Mbp x -@, align.c:576) and aligns chunks
 r, r+N, ... on its own GPU against its own HBM-resident copy of the index.  The chunk rule is cumulative, so over plain files a
@@ -11,7 +11,9 @@ each other (per-chunk insert-size statistics), so the SAM equals the single-GPU 
 -@.  The only communication is the streaming gather of the per-chunk SAM text to rank 0
 (biscuit_amd/gather.py: sizes, then exactly the payload, point to point -> RCCL over xGMI), overlapped
 with the alignment of the following chunks; rank 0 writes chunks in input order as they arrive, and no
-rank ever holds more than a few chunks of output.
+rank ever holds more than a few chunks of output.  With --out FILE (one node: the ranks see the same file) nothing but the chunks' sizes is
+exchanged: every rank writes its own chunks into the file at their offsets (gather.py, the direct form), so rank 0 is not the funnel of
+eight ranks' SAM text; --via-rank0 keeps the gather for such a file too.
 
 --shard pairs (for inputs with fewer chunks than GPUs -- BASELINE configs[1] is two chunks at -@ 16): every rank takes
 every chunk and aligns its own slice of the chunk's pairs.  The one step of a chunk that looks at all of its pairs is mem_pestat
@@ -33,11 +35,13 @@ def main(argv=None, entry=None, use_gpu=True):
     argv = list(sys.argv[1:] if argv is None else argv)
     out_path = None   # SAM goes to stdout unless --out FILE (libraries such as gloo also print to stdout)
     shard = "chunks"
+    via_rank0 = False
     if "--" in argv:
         k = argv.index("--")
         head, argv = argv[:k], argv[k + 1:]
         if "--out" in head:
             out_path = head[head.index("--out") + 1]
+        via_rank0 = "--via-rank0" in head
         if "--shard" in head:
             shard = head[head.index("--shard") + 1]
             if shard not in ("chunks", "pairs"):
@@ -83,8 +87,9 @@ def main(argv=None, entry=None, use_gpu=True):
         pes_hook = PES(pes_sum)
         C.c_void_p.in_dll(L, "bsx_pes_hist_hook").value = C.cast(pes_hook, C.c_void_p).value
 
+    direct = out_path if (out_path and world > 1 and not via_rank0) else None
     out = None
-    if rank == 0:
+    if rank == 0 and not direct:
         out = open(out_path, "wb") if out_path else sys.stdout.buffer
     written = [0]
 
@@ -99,7 +104,7 @@ def main(argv=None, entry=None, use_gpu=True):
             sys.stderr.write("[E::multi_gpu] writing the SAM failed: %r\n" % (e,))
 
     dev = torch.device("cuda", local_rank) if (use_gpu and world > 1) else torch.device("cpu")
-    G = ChunkGather(rank, world, dev, sink)
+    G = ChunkGather(rank, world, dev, sink, direct_path=direct)
     HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t)
 
     def emit(ud, idx, text, n):
@@ -107,7 +112,10 @@ def main(argv=None, entry=None, use_gpu=True):
         try:
             data = np.ctypeslib.as_array(C.cast(text, C.POINTER(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint8)
             if idx < 0:
-                out.write(data)
+                if direct:
+                    G.header = data.tobytes()   # (rank 0 only; before its first chunk: the gather's thread writes it at offset 0)
+                else:
+                    out.write(data)
                 return
         except Exception as e:     # (an exception must not leave a ctypes callback: it would only be printed)
             failed[0] = 1
@@ -138,7 +146,7 @@ def main(argv=None, entry=None, use_gpu=True):
         t = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rc = int(t.item())
-    if rank == 0:
+    if rank == 0 and out is not None:
         out.flush()
         if out_path:
             out.close()

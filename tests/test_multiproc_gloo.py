@@ -42,6 +42,7 @@ def test_two_ranks_equal_one(tmp_path, pe):
     # plain files: each rank found its chunks through the boundary scan and parsed nothing else
     assert two.stderr.count(b"this rank parses its own chunks only") == 2, two.stderr.decode()[-2000:]
     if pe:
+        # (the run above wrote its file in the direct form -- every rank its own chunks at their offsets; this one gathers to rank 0)
         # compressed input has no offsets to seek to: every rank inflates everything, parses its own chunks and walks the other rank's
         # without building records (bsx_fq_skip_chunk); same SAM
         import gzip
@@ -50,7 +51,7 @@ def test_two_ranks_equal_one(tmp_path, pe):
             with open(d + "/" + f, "rb") as fi, gzip.open(d + "/" + f + ".gz", "wb") as fo:
                 shutil.copyfileobj(fi, fo)
         gz = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                             "--master-port", "29533", os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/gz.sam", "--", "-@", "1", "g"] + [f + ".gz" for f in files],
+                             "--master-port", "29533", os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/gz.sam", "--via-rank0", "--", "-@", "1", "g"] + [f + ".gz" for f in files],
                             cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert gz.returncode == 0, gz.stderr.decode()[-3000:]
         assert strip_pg(open(d + "/gz.sam", "rb").read()) == a
@@ -81,8 +82,8 @@ def test_ranks_sharing_each_chunk_equal_one(tmp_path, pe, n_ranks):
         assert (n_chunks >= 3) if tag == "multi" else (n_chunks == 1)
         port += 1
         many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-                               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/many.sam", "--shard", "pairs",
-                               "--", "-@", "1", "g"] + files, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_entry_cpu.py"), "--out", d + "/many.sam", "--shard", "pairs"]
+                              + (["--via-rank0"] if n_ranks == 3 else []) + ["--", "-@", "1", "g"] + files, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert many.returncode == 0, many.stderr.decode()[-3000:]
         a, b = strip_pg(one.stdout), strip_pg(open(d + "/many.sam", "rb").read())
         assert a.count(b"\n") > (800 if pe else 400)
