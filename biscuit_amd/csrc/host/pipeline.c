@@ -1193,6 +1193,15 @@ static int chunk_front(chunk_t *C)
 			C->dd_idx = (uint8_t*)bsx_big_get(C->arena_set, 11, (size_t)C->dd_cap * ((size_t)n + 1));
 			rc = be->regions_dedup(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx);
 			if (rc != BSX_OK) goto out;
+			if (getenv("BSX_PHASES")) { /* what the device's sort + de-duplication leaves of the regions that came down */
+				int64_t kept = 0, held = 0, left_all = 0, left_reads = 0; int per = C->n_tasks / (n ? n : 1), i, k;
+				for (i = 0; i < n; ++i) {
+					int64_t all = 0;
+					for (k = 0; k < per; ++k) if (C->dreg_n[i * per + k] > 0) all += C->dreg_n[i * per + k];
+					if (C->dd_n[i] >= 0) { kept += C->dd_n[i]; held += all; } else { left_all += all; ++left_reads; }
+				}
+				fprintf(stderr, "[M::regions] device de-duplication: %lld of %lld regions kept; %lld regions of %lld reads left to the host's\n", (long long)kept, (long long)held, (long long)left_all, (long long)left_reads);
+			}
 		}
 		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, adopting the regions %.3f s\n", ta - t0, now_s() - ta); }
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
