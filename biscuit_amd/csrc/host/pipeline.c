@@ -1142,7 +1142,7 @@ static int chunk_front(chunk_t *C)
 	int rc = BSX_OK, i, t, n = C->n, nt = C->nt, n_reseed = 0;
 	bsx_intv_t *decl_intv = 0; int64_t decl_cap = 0, *decl_off = 0;
 	size_t tot = 0;
-	double t0;
+	double t0, t_batch_end = 0;
 
 	C->arena_set = bsx_arenas_begin(nt);
 	/* clipping + chunk read buffer + strand searches in the reference's call order (bwamem.c:325-333,352-372) */
@@ -1185,6 +1185,7 @@ static int chunk_front(chunk_t *C)
 		C->dregs = (bsx_region_t*)bsx_big_get(C->arena_set, 8, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		decl_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)C->n_tasks + 1));
 		rc = be->regions_batch(be->ctx, opt, C->n_tasks, C->stasks, &C->dregs, &C->dregs_cap, C->dreg_off, C->dreg_n, &decl_intv, &decl_cap, decl_off);
+		t_batch_end = now_s();
 		bsx_big_update(C->arena_set, 8, C->dregs, sizeof(bsx_region_t) * (size_t)C->dregs_cap);
 		if (rc != BSX_OK) goto out;
 		if (be->regions_dedup && C->n_tasks == n * (C->n_tasks / (n ? n : 1))) { /* C5 of every read whose strand searches all finished on the device */
@@ -1203,7 +1204,7 @@ static int chunk_front(chunk_t *C)
 				fprintf(stderr, "[M::regions] device de-duplication: %lld of %lld regions kept; %lld regions of %lld reads left to the host's\n", (long long)kept, (long long)held, (long long)left_all, (long long)left_reads);
 			}
 		}
-		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, adopting the regions %.3f s\n", ta - t0, now_s() - ta); }
+		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, device de-duplication %.3f s, adopting the regions %.3f s\n", t_batch_end - t0, ta - t_batch_end, now_s() - ta); }
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
 		n_reseed = C->n_host;

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include <ucontext.h>
 #include "bsx_core.h"
 
@@ -63,6 +64,11 @@ __attribute__((constructor)) static void prof_init(void)
 	struct sigaction sa; struct itimerval it;
 	g_path = getenv("BSX_PROF_SAMPLE");
 	if (!g_path || !*g_path) { g_path = 0; return; }
+	if (strstr(g_path, "%d")) { /* a file per process (a launcher and the command line it starts both load this library) */
+		static char per_pid[1024];
+		snprintf(per_pid, sizeof(per_pid), g_path, (int)getpid());
+		g_path = per_pid;
+	}
 	g_pc = (void**)malloc(sizeof(void*) * PROF_MAX); g_ra = (void**)malloc(sizeof(void*) * PROF_MAX);
 	{ Dl_info di; if (dladdr((void*)prof_dump, &di) && di.dli_fbase) { g_lo = (char*)di.dli_fbase; g_hi = g_lo + (64l << 20); } }
 	memset(&sa, 0, sizeof(sa));

@@ -46,7 +46,8 @@ L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
 pairs = 10000000 * a.threads // 300
 fq1, fq2 = work + "/e2e_1.fq", work + "/e2e_2.fq"
 runs = []
-env = dict(os.environ, BSX_HOST_THREADS=str(a.threads))
+env = dict(os.environ)
+env.setdefault("BSX_HOST_THREADS", str(a.threads))
 written = 0
 import threading
 for n_chunks in sorted(int(x) for x in a.chunks.split(",")):
