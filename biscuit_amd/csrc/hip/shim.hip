@@ -349,6 +349,13 @@ extern "C" BSX_API int bsx_device_set_opt(bsx_device_t *d, const bsx_opt_t *o) {
 // the copy engines: those serve every stream first come first served, and behind another chunk's region download (half a gigabyte) a
 // one-megabyte copy waited half a second (measured: "download 0.656 s" of a 15 ms K5 batch).  A kernel on the batch's own stream moves the
 // bytes between the lane's pinned halves (mapped into the device's address space) and HBM instead.
+// the strand searches seeded again inside the main launch sequence: their new lists replace the first pass's in the chunk's offset / count arrays
+__global__ void __launch_bounds__(256)
+k_patch_lists(const int *which, int n, const long long *off2, const int *cnt2, long long *off, int *cnt)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n) { off[which[j]] = off2[j]; cnt[which[j]] = cnt2[j]; }
+}
 __global__ void __launch_bounds__(256)
 k_copy_bytes(const unsigned char *src, unsigned char *dst, size_t n)
 {
@@ -760,6 +767,43 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipEventRecord(L.ev_seed_done, L.st));
 		d->chain_seed = L.ev_seed_done;
 	}
+	// Strand searches whose interval list overflowed are seeded again with lists eight times as long.  A few of them (reads inside tandem
+	// repeats: ~300 k dependent FM steps on one lane, tens of milliseconds) go to the side stream and through a tier sequence of their own
+	// while the main one runs (below).  MANY of them -- an hg38-like genome: 4 % of the strand searches, reads inside young copies of a repeat
+	// family, 23 ms for 43 k -- are seeded again right here and rejoin the chunk's one tier sequence (round 5): the second sequence could only
+	// start when the first had ended (shared slabs and export lists), and the front half waited for it as long again as for the first
+	// whenever the chunks in flight were in step (the command line's steady state: 8.5 s front halves).  The price is a host round trip
+	// between seeding and the suffix-array lookups for every chunk (the counts, 8 MB).
+	std::vector<int> first_n;   // the first pass's counts (negative: overflowed)
+	bool merged = false;
+	const long merge_min = getenv("BSX_REDO_MERGE_MIN") ? atol(getenv("BSX_REDO_MERGE_MIN")) : 4096;   // (tests: 1 = always merged, a huge number = never)
+	if (merge_min >= 0) {
+		first_n.resize((size_t)n);
+		HIPCHK(hipEventSynchronize(L.ev1));
+		D2H(L.st, first_n.data(), d_n, (size_t)n * 4);
+		std::vector<int> which;
+		for (int64_t i = 0; i < n; ++i) if (first_n[i] < 0) which.push_back((int)i);
+		const size_t n2 = which.size();
+		const int g2 = (int)((n2 + 255) / 256);
+		const long long cap2 = std::max<long long>((long long)mem_cap * 8, 1024);
+		const size_t scratch2 = (size_t)g2 * 256 * ((size_t)cap2 * 32 + (size_t)list_cap * 16);
+		if ((long)n2 >= merge_min && n2 > 0 && n2 <= 262144 && g2 * 4 <= n_slabs && scratch2 <= ((size_t)24 << 30)) {
+			if ((rc = L.scratch2.reserve(scratch2)) != BSX_OK) return rc;
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 4 + 4) + 1024)) != BSX_OK) return rc;
+			L.rs.sub.resize(n2);
+			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[which[j]];
+			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
+			long long *off2 = (long long*)(t2 + n2); int *cnt2 = (int*)(off2 + n2); int *which_d = cnt2 + n2;
+			H2D(L.st, t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t));
+			H2D(L.st, which_d, which.data(), n2 * sizeof(int));
+			HIPCHK(hipMemsetAsync(ctr + 99, 0, 8, L.st));   // (u32 [7] of the second sequence's cursors: its seed task cursor)
+			launch_seed(L.st, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
+			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);
+			hipLaunchKernelGGL(k_patch_lists, dim3((unsigned int)((n2 + 255) / 256)), dim3(256), 0, L.st, (const int*)which_d, (int)n2, (const long long*)off2, (const int*)cnt2, d_off, d_n);
+			merged = true;
+			if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_batch] %zu strand searches seeded again inside the main sequence\n", n2);
+		}
+	}
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
 	if (chain >= 2) {
@@ -920,11 +964,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	std::vector<int64_t> redo;            // task indices
 	{
-		std::vector<int> s_n((size_t)n);
-		HIPCHK(hipEventSynchronize(L.ev1));
-		D2H(L.st2, s_n.data(), d_n, (size_t)n * 4);
+		std::vector<int> s_n;
+		if (!first_n.empty()) s_n.swap(first_n);
+		else { s_n.resize((size_t)n); HIPCHK(hipEventSynchronize(L.ev1)); D2H(L.st2, s_n.data(), d_n, (size_t)n * 4); }
 		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i); else L.work[1] += (uint64_t)s_n[i];
-		if (redo.size() > 262144) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller
+		if (redo.size() > 262144 || merged) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller; merged: they are in the main sequence
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	L.rs.active = false;
@@ -1090,6 +1134,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			else D2H(L.st, dst, (const bsx_intv_t*)L.out.p + s_off[i], sizeof(bsx_intv_t) * (size_t)cnt);
 			if (cnt > 1) std::sort(dst, dst + cnt, intv_info_lt);
 		}
+	}
+	if (trace) { // one line per call, with the lane: lines of chunks in flight together interleave
+		struct timespec te; clock_gettime(CLOCK_MONOTONIC, &te);
+#define MS_(a, b) (((b).tv_sec - (a).tv_sec) * 1e3 + ((b).tv_nsec - (a).tv_nsec) * 1e-6)
+		fprintf(stderr, "[M::regions_batch] lane %d from %.3f: %.0f ms = enqueue %.0f + seeding awaited %.0f + second pass enqueued %.0f + tiers awaited %.0f + counts and regions down %.0f + the rest %.0f\n",
+		        lane, ts_in.tv_sec % 1000 + ts_in.tv_nsec * 1e-9, MS_(ts_in, te), MS_(ts_in, ts0), MS_(ts0, ts1), MS_(ts1, ts2), MS_(ts2, ts3), MS_(ts3, ts_out), MS_(ts_out, te));
+#undef MS_
 	}
 	return BSX_OK;
 }

@@ -180,22 +180,27 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
             # strand searches whose interval lists overflow are seeded again on a side stream with longer lists; a short
             # first-pass list sends ordinary reads down that path, collected before the front half returns or (async) by
             # regions_finish at the start of the back half
+            # -- or, when there are many of them (round 5), seeded again inside the chunk's one launch sequence ($BSX_REDO_MERGE_MIN: from how many)
             os.environ["BSX_SEED_MEM_CAP"] = "28"
-            for asy in ("0", "1"):
+            for merge_min, asy in (("1000000000", "0"), ("1000000000", "1"), ("1", "0")):
                 os.environ["BSX_ASYNC_REDO"] = asy
+                os.environ["BSX_REDO_MERGE_MIN"] = merge_min
                 B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
                 L.bsx_last_phase_stats(C.byref(ps))
-                assert crc() == a, (max_occ, asy)
+                assert crc() == a, (max_occ, merge_min, asy)
                 assert ps.n_host_tasks * 5 < ps.n_tasks
                 if asy == "1":
                     assert ps.n_redo_tasks > 0
+                if merge_min == "1":
+                    assert ps.n_redo_tasks == 0
                 L.bsx_sim_reset_reads(p, 2 * n_pairs)
             os.environ.pop("BSX_SEED_MEM_CAP", None)
             os.environ.pop("BSX_ASYNC_REDO", None)
+            os.environ.pop("BSX_REDO_MERGE_MIN", None)
             seen.add(a)
         assert len(seen) == 2   # the cap does change the alignments
     finally:
-        for k in ("BSX_HOST_CHAIN", "BSX_SEED_MEM_CAP", "BSX_ASYNC_REDO"):
+        for k in ("BSX_HOST_CHAIN", "BSX_SEED_MEM_CAP", "BSX_ASYNC_REDO", "BSX_REDO_MERGE_MIN"):
             os.environ.pop(k, None)
         L.bsx_sim_free_reads(p, 2 * n_pairs)
         dev.close()

@@ -7,6 +7,6 @@ for cfg in "$@"; do
 	i=$((i + 1))
 	env $cfg BSX_PHASES=1 E2E_STDERR=/root/repo/gpurun_out/cli_diag.err timeout 1500 python tools/cli_e2e.py --genome-mbp 3100 --profile 1 --chunks ${CHUNKS:-10} --out /dev/null --json > gpurun_out/cli_diag_$i.json 2> gpurun_out/cli_diag_$i.log
 	echo "== $cfg" > gpurun_out/cli_diag_$i.txt
-	grep "M::stream\|M::main\|seed kernel done\|tiers done to regions\|M::regions\] regions_batch\|region launches" gpurun_out/cli_diag.err | cut -c1-260 >> gpurun_out/cli_diag_$i.txt
+	grep "M::stream\|M::main\|lane [0-9] from\|M::regions\] regions_batch" gpurun_out/cli_diag.err | cut -c1-260 >> gpurun_out/cli_diag_$i.txt
 	rm -f gpurun_out/cli_diag.err
 done
