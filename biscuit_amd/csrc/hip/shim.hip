@@ -24,7 +24,7 @@ struct Lane {
 	hipStream_t st = nullptr;      // front-half kernels (low priority)
 	hipEvent_t ev_seed_done = nullptr, ev_regions_done = nullptr;   // what the next chunk's launches of the same stage wait for
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr, ev5 = nullptr, ev6 = nullptr;   // (ev5, ev6: around the second seeding pass inside the main sequence)
 	hipEvent_t tier_ev[12] = {};   // $BSX_PHASES: between the region launches
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
@@ -117,6 +117,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipEventCreateWithFlags(&L.ev_seed_done, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.ev_regions_done, hipEventDisableTiming));
 		HIPCHK(hipEventCreate(&L.ev4));
+		HIPCHK(hipEventCreate(&L.ev5));
+		HIPCHK(hipEventCreate(&L.ev6));
 		HIPCHK(hipEventCreateWithFlags(&L.rs.ev, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.rs.ev_tiers, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.pev[0], hipEventDisableTiming));
@@ -158,6 +160,8 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.st2) (void)hipStreamDestroy(L.st2);
 		if (L.ev3) (void)hipEventDestroy(L.ev3);
 		if (L.ev4) (void)hipEventDestroy(L.ev4);
+		if (L.ev5) (void)hipEventDestroy(L.ev5);
+		if (L.ev6) (void)hipEventDestroy(L.ev6);
 		for (int k = 0; k < 12; ++k) if (L.tier_ev[k]) { (void)hipEventDestroy(L.tier_ev[k]); L.tier_ev[k] = nullptr; }
 		if (L.rs.ev) (void)hipEventDestroy(L.rs.ev);
 		if (L.rs.ev_tiers) (void)hipEventDestroy(L.rs.ev_tiers);
@@ -797,13 +801,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			H2D(L.st, t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t));
 			H2D(L.st, which_d, which.data(), n2 * sizeof(int));
 			HIPCHK(hipMemsetAsync(ctr + 99, 0, 8, L.st));   // (u32 [7] of the second sequence's cursors: its seed task cursor)
+			HIPCHK(hipEventRecord(L.ev5, L.st));
 			launch_seed(L.st, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);
 			hipLaunchKernelGGL(k_patch_lists, dim3((unsigned int)((n2 + 255) / 256)), dim3(256), 0, L.st, (const int*)which_d, (int)n2, (const long long*)off2, (const int*)cnt2, d_off, d_n);
+			HIPCHK(hipEventRecord(L.ev6, L.st));
 			merged = true;
 			if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_batch] %zu strand searches seeded again inside the main sequence\n", n2);
 		}
 	}
+	if (!merged) { HIPCHK(hipEventRecord(L.ev5, L.st)); HIPCHK(hipEventRecord(L.ev6, L.st)); }
 	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
 	if (chain >= 2) {
@@ -1026,8 +1033,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		                   (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6, redo.size(), (ts2.tv_sec - ts0.tv_sec) * 1e3 + (ts2.tv_nsec - ts0.tv_nsec) * 1e-6,
 		                   (ts3.tv_sec - ts0.tv_sec) * 1e3 + (ts3.tv_nsec - ts0.tv_nsec) * 1e-6);
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
-		float ms3 = 0;
-		HIPCHK(hipEventElapsedTime(&ms3, L.ev1, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
+		float ms3 = 0, ms_again = 0;
+		HIPCHK(hipEventElapsedTime(&ms_again, L.ev5, L.ev6));   // the second seeding pass, when it ran inside this sequence
+		ms0 += ms_again;
+		HIPCHK(hipEventElapsedTime(&ms3, L.ev6, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
 		L.k_ms[1] += ms3; L.k_launch[1] += 1;
 		HIPCHK(hipEventElapsedTime(&ms1, L.ev4, L.ev3));   // the first region tier alone
 		HIPCHK(hipEventElapsedTime(&ms2, L.ev3, L.ev2));   // tiers 2 and 3 and the wait for re-seeded strand searches
