@@ -423,7 +423,7 @@ def main():
                 "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
                 "built on the GPU at start-up), biscuit align defaults (-b 0)") % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9)
     if rank == 0:
-        names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_host_path_batches"]
+        names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_again_and_host_path_batches"]   # (the last: the second seeding pass inside the chunk's sequence + K1/K2 batches of the host path)
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),

@@ -779,6 +779,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// whenever the chunks in flight were in step (the command line's steady state: 8.5 s front halves).  The price is a host round trip
 	// between seeding and the suffix-array lookups for every chunk (the counts, 8 MB).
 	std::vector<int> first_n;   // the first pass's counts (negative: overflowed)
+	std::vector<int> merged_which; const int *merged_cnt = nullptr;   // the strand searches of the second pass inside this sequence, and where their new counts are
 	bool merged = false;
 	const long merge_min = getenv("BSX_REDO_MERGE_MIN") ? atol(getenv("BSX_REDO_MERGE_MIN")) : 4096;   // (tests: 1 = always merged, a huge number = never)
 	if (merge_min >= 0) {
@@ -802,11 +803,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			H2D(L.st, which_d, which.data(), n2 * sizeof(int));
 			HIPCHK(hipMemsetAsync(ctr + 99, 0, 8, L.st));   // (u32 [7] of the second sequence's cursors: its seed task cursor)
 			HIPCHK(hipEventRecord(L.ev5, L.st));
+			// (with a budget of its own, eight times the first pass's: the launch lasts as long as its slowest lane, and the handful of reads
+			// inside tandem repeats -- hundreds of thousands of dependent FM steps -- made it 90-170 ms for 23 ms of work; they go on to the
+			// side stream below like the few of a clean genome)
 			launch_seed(L.st, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);
+			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, trip_budget * 8, 0, (uint32_t*)L.qpack.p);
 			hipLaunchKernelGGL(k_patch_lists, dim3((unsigned int)((n2 + 255) / 256)), dim3(256), 0, L.st, (const int*)which_d, (int)n2, (const long long*)off2, (const int*)cnt2, d_off, d_n);
 			HIPCHK(hipEventRecord(L.ev6, L.st));
-			merged = true;
+			merged = true; merged_which.swap(which); merged_cnt = cnt2;
 			if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_batch] %zu strand searches seeded again inside the main sequence\n", n2);
 		}
 	}
@@ -975,7 +979,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (!first_n.empty()) s_n.swap(first_n);
 		else { s_n.resize((size_t)n); HIPCHK(hipEventSynchronize(L.ev1)); D2H(L.st2, s_n.data(), d_n, (size_t)n * 4); }
 		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i); else L.work[1] += (uint64_t)s_n[i];
-		if (redo.size() > 262144 || merged) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller; merged: they are in the main sequence
+		if (merged) { // they are in the main sequence, but for those that the second pass gave up on as well (its budget, its list)
+			std::vector<int> c2(merged_which.size());
+			HIPCHK(hipEventSynchronize(L.ev6));
+			D2H(L.st2, c2.data(), merged_cnt, c2.size() * 4);
+			redo.clear();
+			for (size_t j = 0; j < c2.size(); ++j) if (c2[j] < 0) redo.push_back(merged_which[j]); else L.work[1] += (uint64_t)c2[j];
+		}
+		if (redo.size() > 262144) redo.clear();   // (one slab per four waves of the second pass: n_slabs bounds it) leave them to the caller
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts1);
 	L.rs.active = false;
@@ -1035,7 +1046,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
 		float ms3 = 0, ms_again = 0;
 		HIPCHK(hipEventElapsedTime(&ms_again, L.ev5, L.ev6));   // the second seeding pass, when it ran inside this sequence
-		ms0 += ms_again;
+		if (merged) { L.k_ms[7] += ms_again; L.k_launch[7] += 1; }   // (slot 7: seeding outside the chunk-wide launch)
 		HIPCHK(hipEventElapsedTime(&ms3, L.ev6, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
 		L.k_ms[1] += ms3; L.k_launch[1] += 1;
 		HIPCHK(hipEventElapsedTime(&ms1, L.ev4, L.ev3));   // the first region tier alone

@@ -317,7 +317,7 @@ int bsx_device_region_work(bsx_device_t *dev, uint64_t w[5], int reset);
 int bsx_device_seed_table(bsx_device_t *dev, uint64_t *lookups, int *depth, int reset);
 /* average GPU time (ms, HIP events on the launch stream) and launch count of each kernel since
  * the last reset: k = 0 seed (the chunk-wide launch of bsx_regions_batch), 1 sa, 2 extend, 3 sw, 4 global, 5 regions (first tier),
- * 6 regions (tiers 1b, 2 and 3), 7 seed (bsx_seed_batch launches: the strand searches the host chains) */
+ * 6 regions (tiers 1b, 2 and 3), 7 seed outside the chunk-wide launch (the second seeding pass inside a chunk's sequence; bsx_seed_batch launches: the strand searches the host chains) */
 int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *launches, int reset);
 
 /* ------------------------------------------------------------------------------------------
