@@ -1,6 +1,7 @@
 /* hooks.c -- small exported entry points used by the Python plumbing (multi-GPU launcher, tests):
  * flat wrappers over internal host functions, no logic of their own. */
 #include "align_types.h"
+#include "sort_tmpl.h"
 #include "hook_types.h"
 #include "fastq.h"
 
@@ -25,6 +26,12 @@ typedef struct { int64_t key, id; } kv_t;
 static int kv_lt(const void *a, const void *b) { return ((const kv_t*)a)->key < ((const kv_t*)b)->key; }
 static int kv_gt(const void *a, const void *b) { return ((const kv_t*)a)->key > ((const kv_t*)b)->key; }
 BSX_API void bsx_hook_sort_kv(int64_t n, int64_t *kv, int desc) { bsx_introsort(kv, (size_t)n, sizeof(kv_t), desc ? kv_gt : kv_lt); }
+/* the same through sort_tmpl.h (the introsort compiled per element type that the back half's sorts use) */
+#define KV_LT(a, b) ((a)->key < (b)->key)
+#define KV_GT(a, b) ((a)->key > (b)->key)
+BSX_SORT_DEFINE(sort_kv_asc, kv_t, KV_LT)
+BSX_SORT_DEFINE(sort_kv_desc, kv_t, KV_GT)
+BSX_API void bsx_hook_sort_kv_typed(int64_t n, int64_t *kv, int desc) { if (desc) sort_kv_desc((size_t)n, (kv_t*)kv); else sort_kv_asc((size_t)n, (kv_t*)kv); }
 
 BSX_API int bsx_hook_mapq(int a, int b, int min_seed_len, float coef_len, int coef_fac, int score, int sub, int csub, int sub_n,
                           int qb, int qe, int64_t rb, int64_t re, int seedcov, float frac_rep)

@@ -64,16 +64,18 @@ def test_hash_and_mapq(V):
 
 
 def test_introsort_permutation(V):
-    """the exact permutation of klib's unstable introsort (incl. comb-sort fallback), asc and desc"""
+    """the exact permutation of klib's unstable introsort (incl. comb-sort fallback), asc and desc: the generic form (a comparison callback) and
+    the one compiled per element type (sort_tmpl.h: what the back half's sorts run)"""
     L = B.lib()
     off = V["sort_off"]
     for i in range(len(off) - 1):
         keys = V["sort_keys"][off[i]:off[i + 1]]
         n = len(keys)
         for desc, want in ((0, V["sort_perm_asc"]), (1, V["sort_perm_desc"])):
-            kv = np.stack([keys, np.arange(n, dtype=np.int64)], 1).copy()
-            L.bsx_hook_sort_kv(C.c_int64(n), kv.ctypes.data_as(C.c_void_p), desc)
-            assert (kv[:, 1] == want[off[i]:off[i + 1]]).all(), (i, n, desc)
+            for fn in (L.bsx_hook_sort_kv, L.bsx_hook_sort_kv_typed):
+                kv = np.stack([keys, np.arange(n, dtype=np.int64)], 1).copy()
+                fn(C.c_int64(n), kv.ctypes.data_as(C.c_void_p), desc)
+                assert (kv[:, 1] == want[off[i]:off[i + 1]]).all(), (i, n, desc)
 
 
 def test_btree_lookup_and_order(V):
