@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("BSX_BENCH_GENOME_MBP", "3100")))
+    ap.add_argument("--genome-mbp", type=float, default=None, help="size of the synthetic genome (default 3100, or $BSX_BENCH_GENOME_MBP); when NOT given, $BISCUIT_HG38_INDEX / $BISCUIT_HG38_FA switch the headline record to the real genome (SURVEY 8(d) config 2)")
     ap.add_argument("--threads", type=int, default=16, help="-@ of the run: fixes the chunk size (10 Mbp x threads), like the reference")
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads for the host stages; 0 = cores / ranks, capped at 64")
     ap.add_argument("--read-len", type=int, default=150)
@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the cli_end_to_end sub-record (FASTQ text in -> SAM text out through biscuit_align, tools/cli_e2e.py)")
     ap.add_argument("--sub", action="store_true", help="(internal) this run is a sub-record of another: no sub-records of its own")
     args = ap.parse_args()
+    genome_given = args.genome_mbp is not None or "BSX_BENCH_GENOME_MBP" in os.environ
+    if args.genome_mbp is None:
+        args.genome_mbp = float(os.environ.get("BSX_BENCH_GENOME_MBP", "3100"))
+    synth_mbp = args.genome_mbp   # (the sub-records stay on the synthetic genomes)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,10 +91,27 @@ def main():
     # genome takes ~5 s to generate and ~13 s to index), resident in HBM from then on.  Rank 0 of a single-GPU run also
     # takes the file-format arrays back to the host: the CPU baseline needs them.
     t0 = time.time()
-    idx = Index.synthetic(n_bases, seed=2024, n_contigs=24 if n_bases >= 1_000_000_000 else 8, profile=1 if args.genome_profile == "hg38-like" else 0)
     dev = Device(local_rank)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    dev.build_index(idx, fill_host=want_cpu)
+    # "vs hg38 index (pre-built files at $BISCUIT_HG38_INDEX; if absent, a synthetic 3.1 Gbp genome ...)".  The real
+    # genome when the box has it -- $BISCUIT_HG38_INDEX = the <base> of a `biscuit index` file set (<base>.{par,dau}.{bwt,sa} +
+    # <base>.bis.{ann,amb,pac}), or $BISCUIT_HG38_FA = the FASTA, indexed on the GPU at start-up -- and only for the headline record; the
+    # reads are simulated from whichever genome is resident (bsx_sim_pairs reads the index's pac).
+    real_genome = None
+    if args.genome_profile == "hg38-like" and not args.single_end and not genome_given and not args.sub:
+        real_genome = real_genome_source()
+    if real_genome and real_genome[0] == "index":
+        idx = Index(real_genome[1])
+        dev.upload_index(idx)
+    elif real_genome:
+        idx = Index.from_fasta(real_genome[1])
+        dev.build_index(idx, fill_host=want_cpu)
+    else:
+        idx = Index.synthetic(n_bases, seed=2024, n_contigs=24 if n_bases >= 1_000_000_000 else 8, profile=1 if args.genome_profile == "hg38-like" else 0)
+        dev.build_index(idx, fill_host=want_cpu)
+    if real_genome:
+        n_bases = int(idx.l_pac)
+        args.genome_mbp = n_bases / 1e6
     t_build = time.time() - t0
     barrier()
 
@@ -148,6 +169,7 @@ def main():
         L.bsx_sim_reset_reads(chunks[s_], n_reads)   # drop the warm-up chunks' SAM text
     for k in range(8):
         dev.kernel_time(k, reset=True)
+    dev.seed_passes(reset=True)
     dev.counters(reset=True)
     dev.seed_table(reset=True)
     dev.region_work(reset=True)
@@ -275,23 +297,26 @@ def main():
     #   k_seedt (K1+K2): 64 B per FM block the kernel touches + a 64-byte line per entry of the table of k-mer intervals it reads.  (The
     #       reference algorithm touches four times as many blocks for the same reads: `reference_equivalent`, counted by k_seed.)
     #   k_occ (K3): 64 B per LF step of bwt_sa + 8 B per SA sample + 16 B per occurrence (rank in, position out)
+    seed_p1, seed_p2, seed_ms = dev.seed_passes()   # FM blocks / table entries / HIP-event ms of each seeding pass, counted apart
     ctr = dev.counters()
     ktimes = [dev.kernel_time(k) for k in range(8)]
     rwork = dev.region_work()
     alone = None
+    alone_seed_ms = None
     region_launch_ms = None
     ref_blocks_per_read, ref_seed_ms = None, None
     tab_touch = [ctr[0] + ctr[1], dev.seed_table()[0], dev.seed_table()[1]]   # FM blocks and table entries the seeding kernel read in the timed region
     if not args.no_pipeline:
         for k in range(8):
             dev.kernel_time(k, reset=True)
+        dev.seed_passes(reset=True)
         extra = gen(777, pairs_per_step)
-        # the region launches of this chunk one by one ($BSX_TIERS: HIP events between them, printed by the library): the last HBM tier is a
+        # the region launches of this chunk one by one (the setting `tiers`: HIP events between them, printed by the library): the last HBM tier is a
         # handful of strand searches -- reads inside tandem repeats, a wavefront each -- and lasts as long as the longest of them, so
         # "regions_tiers23" of one chunk says little about the tiers that carry the load without the split
         import tempfile
         tier_txt = ""
-        os.environ["BSX_TIERS"] = "1"
+        B.tune("tiers", "1")
         sys.stderr.flush()
         saved_fd, tf = os.dup(2), tempfile.TemporaryFile()
         os.dup2(tf.fileno(), 2)
@@ -300,7 +325,7 @@ def main():
         finally:
             os.dup2(saved_fd, 2)
             os.close(saved_fd)
-            os.environ.pop("BSX_TIERS", None)
+            B.tune("tiers", None)
             tf.seek(0)
             tier_txt = tf.read().decode(errors="replace")
             tf.close()
@@ -319,10 +344,11 @@ def main():
                     region_launch_ms = None
                 break
         alone = [dev.kernel_time(k) for k in range(8)]
+        alone_seed_ms = dev.seed_passes()[2]   # [first pass, second pass] of the stand-alone chunk
         # The reference algorithm's FM-block touches for these reads (bwt_occ4 / bwt_2occ4 calls of bwt_smem1a and bwt_seed_strategy1:
         # deterministic integers for a given input) are counted here, after the timed region, by the same chunk through the kernel
-        # that walks the FM index step by step as the reference does (k_seed.hip, $BSX_SEED_FORM=classic).
-        os.environ["BSX_SEED_FORM"] = "classic"
+        # that walks the FM index step by step as the reference does (k_seed.hip, the setting seed_form=classic).
+        B.tune("seed_form", "classic")
         try:
             dev.counters(reset=True)
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, n_processed, n_reads, extra, None), "process_seqs(reference block count)")
@@ -330,7 +356,7 @@ def main():
             ref_blocks_per_read = (rc_[0] + rc_[1]) / float(n_reads)
             ref_seed_ms = dev.kernel_time(0)[0] - alone[0][0]
         finally:
-            os.environ.pop("BSX_SEED_FORM", None)
+            B.tune("seed_form", None)
         L.bsx_sim_free_reads(extra, n_reads)
 
     # Counter passes cannot run inside this process (rocprofv3 --pmc wraps a command): HBM traffic and instruction counts per launch come
@@ -340,7 +366,7 @@ def main():
     import glob
     prof_tag = "hg38like" if args.genome_profile == "hg38-like" else "clean"
     cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%dmbp_%s.json" % (int(round(args.genome_mbp)), prof_tag))))
-    if cand and args.read_len == 150 and threads == 16 and not args.single_end:
+    if cand and args.read_len == 150 and threads == 16 and not args.single_end and not real_genome:
         with open(cand[-1]) as f:
             tj = json.load(f)
         if tj.get("_reads_per_chunk") == n_reads:   # per launch = per chunk
@@ -350,23 +376,40 @@ def main():
     GATHER_CEILING = 3500.0   # GB/s: dependent random 64-B block reads over a 3.1 GB table, four lanes per block, measured on this GPU
                               # with tools/ubench/gather64.hip (profiles/r02_gather64.txt); one lane per block: 2.7 TB/s
 
-    def hbm_roof(name, slots, alg_bytes, extra, pmc_key=None):
-        # alg_bytes: over the whole timed region; one chunk-wide launch (sequence) per step
-        ms, launches = sum(ktimes[k][0] for k in slots), args.steps
-        if not ktimes[slots[0]][1] or ms <= 0:
+    # the kernel trace of this command committed under profiles/ (tools/profile_round.sh + tools/summarize_profiles.py): each family's kernel
+    # durations summed per chunk, pipelined and for the stand-alone chunk -- what a reader of profiles/*_kernel_stats.csv recomputes
+    trace_ms = {}
+    cand_t = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_family_ms_%dmbp_%s.json" % (int(round(args.genome_mbp)), prof_tag))))
+    if cand_t and args.read_len == 150 and threads == 16 and not args.single_end and not real_genome:
+        with open(cand_t[-1]) as f:
+            trace_ms = json.load(f)
+        trace_ms["_file"] = os.path.relpath(cand_t[-1], ROOT)
+    SPAN = ("HIP-event span on the chunk's launch stream inside the timed region, averaged over the steps: with %d chunks in flight the span of a launch "
+            "sequence includes the time it shared the device with (or waited behind) the other chunks' kernels -- NOT exclusive kernel time; the "
+            "stand-alone chunk's span (one chunk alone on the device, after the timed region) and the trace's summed kernel durations are beside it" % depth)
+
+    def hbm_roof(name, ms, alg_bytes, extra, pmc_key=None, ms_alone=None, trace_key=None):
+        # alg_bytes and ms: over the whole timed region; one launch (sequence) per step
+        launches = args.steps
+        if ms <= 0:
             return None
         ach = alg_bytes / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_HBM, "unit": "GB/s", "frac": round(ach / PEAK_HBM, 5),
-             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3)}
-        if alone and alone[slots[0]][1]:
-            ms1 = sum(alone[k][0] for k in slots)
-            r["avg_launch_ms_standalone"] = round(ms1, 3)   # the one extra chunk
-            r["achieved_standalone"] = round(alg_bytes / launches / (ms1 * 1e-3) / 1e9, 2)
+             "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_ms": round(ms / launches, 3), "avg_launch_ms_is": SPAN}
+        if ms_alone:
+            r["avg_launch_ms_standalone"] = round(ms_alone, 3)   # the one extra chunk
+            r["achieved_standalone"] = round(alg_bytes / launches / (ms_alone * 1e-3) / 1e9, 2)
             r["frac_standalone"] = round(r["achieved_standalone"] / PEAK_HBM, 5)
+        t_ = trace_ms.get(trace_key or "", None)
+        if t_:
+            # (rocprofv3 --kernel-trace of this command: the family's kernel durations summed, per chunk)
+            r["kernel_ms_sum_from_trace"] = {"pipelined_per_chunk": t_.get("pipelined_ms_per_chunk"), "chunks": t_.get("chunks"), "by_kernel": t_.get("by_kernel"), "source": trace_ms["_file"]}
+            if t_.get("pipelined_ms_per_chunk"):
+                r["frac_over_trace_kernel_ms"] = round(alg_bytes / launches / (t_["pipelined_ms_per_chunk"] * 1e-3) / 1e9 / PEAK_HBM, 5)
         p = pmc.get(pmc_key or "", {})
         if p.get("FETCH_SIZE_KiB") is not None and p.get("WRITE_SIZE_KiB") is not None:
             r["traffic"] = 1024.0 * (p["FETCH_SIZE_KiB"] + p["WRITE_SIZE_KiB"])
-            r["traffic_source"] = "FETCH_SIZE + WRITE_SIZE of %s (separate rocprofv3 --pmc passes of this command on this genome, one chunk)" % pmc["_file"]
+            r["traffic_source"] = "FETCH_SIZE + WRITE_SIZE of %s (separate rocprofv3 --pmc passes of this command on this genome, one chunk: every dispatch of the family in that chunk, i.e. the same launches the bytes above are counted over)" % pmc["_file"]
         r.update(extra)
         return r
 
@@ -383,28 +426,45 @@ def main():
                  "frac_salu_issue_peak": round(p_["SQ_INSTS_SALU"] / t_ / (256 * 2.4e9), 4), "frac_valu_issue_peak": round(p_["SQ_INSTS_VALU"] * 2 / t_ / (1024 * 2.4e9), 4),
                  "over": "the stand-alone chunk's %.0f ms" % (t_ * 1e3), "counter_source": pmc["_file"]}
     roof = hbm_roof("region family (C1+C2+K4+C4): k_regions + k_regions_mid (chaining, chain filter; tables in LDS), k_x4prep/k_extl/k_ext4 (extensions ahead), k_c2r (chains -> regions), k_regions_slab x2 (HBM slabs)",
-                    [5, 6], reg_bytes,
+                    ktimes[5][0] + ktimes[6][0], reg_bytes,
                     {"per_read": {"strand_searches": rwork[0] / steps_reads, "sa_intervals": rwork[1] / steps_reads, "seed_occurrences": rwork[2] / steps_reads, "regions": rwork[3] / steps_reads},
                      "algorithmic_bytes_are": "per strand search the read + 32 B per SA interval + 8 B per seed occurrence; per region 56 B written + %d B (the read and the packed reference window of its extensions)" % win_bytes,
                      "issue": issue,
                      "what_bounds_it": "neither bytes nor, by the counters, instruction issue: latency and divergence -- a wavefront per strand search walks dependent LDS / HBM round trips (chaining, the chain filter), and a DP row of an extension is a dependent chain of DPP steps; see DESIGN.md section 4"},
-                    "k_regions")
-    # -- seeding
-    touched = 64.0 * (ctr[0] + ctr[1]) + 64.0 * (tab_touch[1] if tab_touch else 0)
+                    "k_regions", ms_alone=(alone[5][0] + alone[6][0]) if alone and alone[5][1] else None, trace_key="region_family")
+    # -- seeding: BOTH passes (the chunk-wide launch and, on a repeat-rich genome, the launch over the strand searches seeded again inside the
+    # chunk's sequence), each pass's own bytes over its own time, and the two together: bytes of both over the time of both
+    b1 = 64.0 * (seed_p1[0] + seed_p1[1])   # first pass: FM blocks + table lines
+    b2 = 64.0 * (seed_p2[0] + seed_p2[1])   # second pass
+    touched = b1 + b2
+    seed_ms_both = seed_ms[0] + seed_ms[1]
     ref_eq = None
-    if ref_blocks_per_read and ktimes[0][0] > 0:
+    if ref_blocks_per_read and seed_ms_both > 0:
         rb_ = 64.0 * ref_blocks_per_read * n_reads * args.steps
-        ref_eq = {"fm_block_touches_per_read": ref_blocks_per_read, "bytes_per_launch": rb_ / args.steps, "rate": round(rb_ / (ktimes[0][0] * 1e-3) / 1e9, 2), "unit": "GB/s",
-                  "frac_of_hbm_peak": round(rb_ / (ktimes[0][0] * 1e-3) / 1e9 / PEAK_HBM, 5),
-                  "meaning": "the rate at which the kernel gets through the REFERENCE algorithm's FM-block touches for these reads (bwt_occ4/bwt_2occ4 of bwt_smem1a and bwt_seed_strategy1, SURVEY 8(d); counted on one chunk by k_seed, BSX_SEED_FORM=classic, after the timed region) -- not bytes moved: the table of k-mer intervals replaces three of four of them",
+        ref_eq = {"fm_block_touches_per_read": ref_blocks_per_read, "bytes_per_launch": rb_ / args.steps, "rate": round(rb_ / (seed_ms_both * 1e-3) / 1e9, 2), "unit": "GB/s",
+                  "frac_of_hbm_peak": round(rb_ / (seed_ms_both * 1e-3) / 1e9 / PEAK_HBM, 5),
+                  "meaning": "the rate at which the kernel (both passes' time) gets through the REFERENCE algorithm's FM-block touches for these reads (bwt_occ4/bwt_2occ4 of bwt_smem1a and bwt_seed_strategy1, SURVEY 8(d); counted on one chunk by k_seed, seed_form=classic, after the timed region) -- not bytes moved: the table of k-mer intervals replaces three of four of them",
                   "kernel_without_table_ms_standalone": round(ref_seed_ms, 3) if ref_seed_ms else None}
-    roof_seed = hbm_roof("k_seedt (K1+K2: SMEM seeding over the table of k-mer intervals + dependent random 64-B FM-block gathers)", [0], touched,
-                         {"kernel_touches_per_read": {"fm_blocks": (ctr[0] + ctr[1]) / steps_reads, "table_entries": (tab_touch[1] / steps_reads) if tab_touch else 0.0, "table_depth": tab_touch[2] if tab_touch else 0},
-                          "random_64B_gather_ceiling": GATHER_CEILING, "frac_of_gather_ceiling": round(touched / (ktimes[0][0] * 1e-3) / 1e9 / GATHER_CEILING, 4) if ktimes[0][0] > 0 else None,
+
+    def pass_rec(b, ms, fm, tab, extra=None):
+        if ms <= 0:
+            return None
+        r = {"algorithmic_bytes_per_launch": b / args.steps, "avg_launch_ms": round(ms / args.steps, 3), "achieved": round(b / (ms * 1e-3) / 1e9, 2),
+             "frac": round(b / (ms * 1e-3) / 1e9 / PEAK_HBM, 5), "fm_blocks_per_read": fm / steps_reads, "table_entries_per_read": tab / steps_reads}
+        r.update(extra or {})
+        return r
+    roof_seed = hbm_roof("k_seedt (K1+K2: SMEM seeding over the table of k-mer intervals + dependent random 64-B FM-block gathers), both passes of a chunk", seed_ms_both, touched,
+                         {"kernel_touches_per_read": {"fm_blocks": (seed_p1[0] + seed_p2[0]) / steps_reads, "table_entries": (seed_p1[1] + seed_p2[1]) / steps_reads, "table_depth": tab_touch[2] if tab_touch else 0},
+                          "first_pass": pass_rec(b1, seed_ms[0], seed_p1[0], seed_p1[1], {"what": "the chunk-wide launch: every strand search, a lane each"}),
+                          "second_pass": pass_rec(b2, seed_ms[1], seed_p2[0], seed_p2[1], {"what": "the strand searches whose lists or budget overflowed, seeded again inside the chunk's sequence with lists eight times as long",
+                                                                                           "strand_searches_per_chunk": seed_p2[3] / max(1, seed_p2[2])}),
+                          "random_64B_gather_ceiling": GATHER_CEILING, "frac_of_gather_ceiling": round(touched / (seed_ms_both * 1e-3) / 1e9 / GATHER_CEILING, 4) if seed_ms_both > 0 else None,
                           "reference_equivalent": ref_eq,
-                          "what_bounds_it": "vector and scalar issue of the per-lane state machine (a lane per strand search, persistent lanes, three waves per SIMD at 168 VGPRs): a trip of the wave loop is one request per lane -- an FM extension (one or two dependent random 64-B blocks, fetched by the wave as a whole) or a 16-byte table entry -- and about half its cycles are the machine that decides the next request; see DESIGN.md"}, "k_seed")
-    roof_occ = hbm_roof("k_occ_expand + k_occ (K3: suffix-array lookups of the whole chunk)", [1], 64.0 * ctr[2] + 24.0 * ctr[3],
-                        {"lf_steps_per_read": ctr[2] / steps_reads, "sa_lookups_per_read": ctr[3] / steps_reads}, "k_occ")
+                          "what_bounds_it": "vector and scalar issue of the per-lane state machine (a lane per strand search, persistent lanes, three waves per SIMD at 168 VGPRs): a trip of the wave loop is one request per lane -- an FM extension (one or two dependent random 64-B blocks, fetched by the wave as a whole) or a 16-byte table entry -- and about half its cycles are the machine that decides the next request; the second pass is a few hundred waves bound by the dependent FM steps of their longest strand searches; see DESIGN.md"},
+                         "k_seed", ms_alone=(alone_seed_ms[0] + alone_seed_ms[1]) if alone_seed_ms and alone_seed_ms[0] > 0 else None, trace_key="seeding")
+    roof_occ = hbm_roof("k_occ_expand + k_occ (K3: suffix-array lookups of the whole chunk)", ktimes[1][0], 64.0 * ctr[2] + 24.0 * ctr[3],
+                        {"lf_steps_per_read": ctr[2] / steps_reads, "sa_lookups_per_read": ctr[3] / steps_reads}, "k_occ",
+                        ms_alone=alone[1][0] if alone and alone[1][1] else None, trace_key="sa_lookup")
     # -- the whole path against the HBM peak: the same bytes, all families, over the step's wall time
     whole = None
     if roof and roof_seed and roof_occ:
@@ -412,22 +472,42 @@ def main():
         whole = {"bound": "hbm", "algorithmic_bytes_per_step": wb / args.steps, "ms_per_step": round(1e3 * tmax / args.steps, 2),
                  "achieved": round(wb / tmax / 1e9, 2), "peak": PEAK_HBM * world, "unit": "GB/s", "frac": round(wb / tmax / 1e9 / (PEAK_HBM * world), 5),
                  "bytes_are": "seeding (FM blocks and table lines touched) + K3 + the region family, as in the three rooflines above; mate rescue (K5) and CIGARs (K6) move a few hundred bytes per job"}
+        if ref_blocks_per_read:
+            # SURVEY 8(d)'s own per-read figure -- what the REFERENCE algorithm moves for these reads:
+            #   B(read) = 64 (N_occ4 + N_2occ4_fast + N_occ) + 8 N_sa + sum over windows ceil(ref_bases / 4) + 2 l_seq + sam_bytes
+            # N_occ4 + N_2occ4_fast: counted exactly (k_seed, the reference's own sequence of bwt_extend calls, one chunk after the timed region);
+            # N_sa: counted exactly (one bwt_sa per seed occurrence kept); N_occ: bwt_sa's LF steps at the FILES' 1-in-32 sample = 31 per lookup in
+            # expectation (a walk ends at a sampled rank with probability 1/32 per step; the device's own sample is every 2nd rank and its measured
+            # mean is 1.0); windows: the two extension windows of every region (K5 / K6 windows, a few hundred bytes per job, are left out).
+            n_sa = ctr[3] / steps_reads
+            regions_pr = rwork[3] / steps_reads
+            sam_pr = sam_bytes / steps_reads
+            terms = {"fm_blocks_seeding": 64.0 * ref_blocks_per_read, "fm_blocks_bwt_sa_expected": 64.0 * 31.0 * n_sa, "sa_words": 8.0 * n_sa,
+                     "reference_windows": float((win_bytes - args.read_len) * regions_pr), "read_in_and_out": 2.0 * args.read_len, "sam_text": sam_pr}
+            b_read = sum(terms.values())
+            whole["reference_equivalent"] = {"bytes_per_read": round(b_read, 1), "terms_bytes_per_read": {k: round(v, 1) for k, v in terms.items()},
+                                             "rate": round(b_read * tot_reads / tmax / 1e9, 2), "unit": "GB/s", "frac_of_hbm_peak": round(b_read * tot_reads / tmax / 1e9 / (PEAK_HBM * world), 5),
+                                             "meaning": "SURVEY 8(d)'s B(read), the bytes the reference algorithm touches for these reads, over this run's wall time: the rate at which the path gets through the reference's memory work -- not bytes this implementation moves (the table of k-mer intervals and the dense suffix-array sample replace most of them)"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(L, B, idx, dev, opt, args, ncores)
 
     repeats = ("with hg38-like repeat content (SINE/LINE/LTR-like families of up to a million copies, satellite arrays: ~43 % repeats)"
                if args.genome_profile == "hg38-like" else "with repeat families (5 % planted repeats of 1-5 copies)")
+    if real_genome:
+        repeats = "-- THE REAL GENOME: %s" % real_genome[2]
     workload = (("BASELINE configs[4] shape: 1x%d bp synthetic directional bisulfite single-end reads vs" if args.single_end else "BASELINE configs[1] shape: 2x%d bp synthetic directional bisulfite pairs vs")
-                + " a SYNTHETIC %.0f Mbp genome %s "
-                "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
-                "built on the GPU at start-up), biscuit align defaults (-b 0)") % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9)
+                + (" a %.0f Mbp genome %s (two FM indices of %.2f G symbols each), biscuit align defaults (-b 0)" if real_genome else
+                   " a SYNTHETIC %.0f Mbp genome %s "
+                   "(hg38 itself is not available offline; SURVEY 8(d) config 2 fallback: an hg38-sized synthetic genome, two FM indices of %.2f G symbols each, "
+                   "built on the GPU at start-up; $BISCUIT_HG38_INDEX / $BISCUIT_HG38_FA switch this record to the real genome), biscuit align defaults (-b 0)")) % (args.read_len, args.genome_mbp, repeats, 2 * n_bases / 1e9)
     if rank == 0:
         names = ["seed", "occ", "extend", "sw", "global", "regions_tier1", "regions_tiers23", "seed_again_and_host_path_batches"]   # (the last: the second seeding pass inside the chunk's sequence + K1/K2 batches of the host path)
         out = {
             "metric": "paired-end reads aligned/sec", "value": round(tot_reads / tmax, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tmax / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "data": ("real genome (%s), synthetic reads" % real_genome[2]) if real_genome else "synthetic",
             "config": {"workload": workload,
                        "reads_per_step_per_gpu": n_reads, "chunk_threads(-@)": threads, "host_threads_per_gpu": host_threads, "host_cores_usable": ncores, "parallelism": ("chunk-sharded x%d" % world) + (" (CODE-PATH CHECK: all ranks on one GPU, gloo; not a measurement)" if share_gpu else ""), "chunk_pipeline_depth": depth,
                        "index_bytes_in_hbm": int(2 * (n_bases * 2 / 128 * 64 + n_bases * 2 / 2 * 8) + n_bases / 4),
@@ -468,7 +548,7 @@ def main():
                     "push_loop_s_per_step", "host_cores_busy_per_gpu")
 
             def sub_run(key, extra_args, timeout):
-                cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--genome-mbp", str(args.genome_mbp), "--threads", str(threads)] + extra_args
+                cmd = [sys.executable, os.path.abspath(__file__), "--sub", "--genome-mbp", str(synth_mbp), "--threads", str(threads)] + extra_args
                 if args.no_cpu_baseline:
                     cmd.append("--no-cpu-baseline")
                 try:
@@ -488,14 +568,35 @@ def main():
                 sub_run("long_reads", ["--genome-profile", "clean", "--single-end", "--read-len", "1000", "--steps", "3", "--warmup", "1", "--cpu-sample-pairs", "3000"], 1200)
             if not args.no_cli:
                 try:
-                    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_e2e.py"), "--genome-mbp", str(args.genome_mbp), "--profile", "1" if args.genome_profile == "hg38-like" else "0",
+                    pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_e2e.py"), "--genome-mbp", str(synth_mbp), "--profile", "1" if args.genome_profile == "hg38-like" else "0",
                                          "--threads", str(threads), "--chunks", "7", "--out", "/dev/null", "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
                     out["cli_end_to_end"] = json.loads(pr.stdout.decode().strip().split("\n")[-1])
                 except Exception as e:
                     out["cli_end_to_end"] = {"error": repr(e)[:300]}
+        # the driver's record keeps the top level of this line: the sub-records' headline values are repeated there
+        for key, top in (("clean_genome", "clean_genome_reads_s"), ("long_reads", "long_reads_s"), ("cli_end_to_end", "cli_reads_s"), ("hg38_like_genome", "hg38_like_genome_reads_s")):
+            if isinstance(out.get(key), dict) and out[key].get("value") is not None:
+                out[top] = out[key]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def real_genome_source():
+    """the hg38 BISCUIT index at $BISCUIT_HG38_INDEX (the <base> of the seven files), else the FASTA at $BISCUIT_HG38_FA
+    (indexed on the GPU at start-up); None when neither is usable -- the synthetic hg38-sized genome is the stated fallback."""
+    base = os.environ.get("BISCUIT_HG38_INDEX")
+    if base:
+        need = [base + e for e in (".par.bwt", ".par.sa", ".dau.bwt", ".dau.sa", ".bis.ann", ".bis.amb", ".bis.pac")]
+        if all(os.path.exists(f) for f in need):
+            return ("index", base, "index files %s.*" % base)
+        sys.stderr.write("[bench] $BISCUIT_HG38_INDEX=%s: not a complete index file set (%s missing); falling back\n" % (base, ", ".join(os.path.basename(f) for f in need if not os.path.exists(f))))
+    fa = os.environ.get("BISCUIT_HG38_FA")
+    if fa:
+        if os.path.exists(fa):
+            return ("fasta", fa, "FASTA %s, indexed on the GPU at start-up" % fa)
+        sys.stderr.write("[bench] $BISCUIT_HG38_FA=%s does not exist; falling back\n" % fa)
+    return None
 
 
 def effective_cores():

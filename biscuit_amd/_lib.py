@@ -118,6 +118,45 @@ def lib():
     return _lib
 
 
+def tune(name, value=None):
+    """a setting of the library (csrc/host/tune.c has the table): value None = back to the default"""
+    L = lib()
+    L.bsx_tune_set.argtypes = [C.c_char_p, C.c_char_p]
+    check(L.bsx_tune_set(name.encode(), None if value is None else str(value).encode()), "bsx_tune_set(%s)" % name)
+
+
+def tune_names():
+    L = lib()
+    L.bsx_tune_name.restype = C.c_char_p
+    out, i = [], 0
+    while True:
+        n = L.bsx_tune_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def tune_env(settings):
+    """An environment for a child process from a dict of settings: names of the library's table (with or without the BSX_ prefix of the
+    environment variables they were until round 5, any case) go into ONE variable, $BSX_TUNE="name=value,..."; everything else -- real
+    environment variables such as BSX_STREAM_DEPTH -- passes through unchanged."""
+    names = set(tune_names())
+    env, tuned = {}, []
+    for k, v in (settings or {}).items():
+        if k == "BSX_TUNE":
+            tuned.append(str(v))
+            continue
+        low = k[4:].lower() if k.upper().startswith("BSX_") else k.lower()
+        if low in names and k not in ("BSX_PHASES",):
+            tuned.append("%s=%s" % (low, v))
+        else:
+            env[k] = str(v)
+    if tuned:
+        env["BSX_TUNE"] = ",".join(tuned)
+    return env
+
+
 class BsxError(RuntimeError):
     pass
 

@@ -213,6 +213,14 @@ class Device(Batches):
         B.check(B.lib().bsx_device_counters(self.h, c, int(reset)), "bsx_device_counters")
         return list(c)
 
+    def seed_passes(self, reset=False):
+        """([FM blocks, table entries] of the first seeding pass, [FM blocks, table entries, launches, strand searches] of the second pass
+        inside the chunk's sequence, [ms first pass, ms second pass]) since the last reset; read before counters()/seed_table() with reset"""
+        w = (C.c_uint64 * 6)()
+        ms = (C.c_double * 2)()
+        B.check(B.lib().bsx_device_seed_passes(self.h, w, ms, int(reset)), "bsx_device_seed_passes")
+        return list(w[:2]), list(w[2:]), list(ms)
+
     def region_work(self, reset=False):
         """[strand searches, SA intervals, occurrences looked up, regions written, read bases] of the region kernels since the last reset"""
         w = (C.c_uint64 * 5)()

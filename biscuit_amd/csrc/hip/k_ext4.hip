@@ -25,6 +25,7 @@
 #include "dev_common.hpp"
 #include "wave.hpp"
 #include "kernels.h"
+#include "tune.h"
 #include "rgx.hpp"
 #include "x4.hpp"
 
@@ -515,7 +516,7 @@ void launch_x4(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &s
 	const int pgrid = (int)((n_tasks + 64 * X4P_WPB - 1) / (64 * X4P_WPB));
 	(void)hipMemsetAsync(ctr32, 0, 16, st);
 	hipLaunchKernelGGL(k_x4prep, dim3(std::max(1, pgrid)), dim3(64 * X4P_WPB), 0, st, ix, P, tasks, X, (X4Job*)jobs, jcap, ctr32);
-	const int use_l = getenv("BSX_XL") ? atoi(getenv("BSX_XL")) : 1;   // 0: the narrow queue through k_ext4 too
+	const int use_l = (int)bsx_tune_long("xl", 1);   // 0: the narrow queue through k_ext4 too
 	if (use_l) launch_extl(st, n_cu, ix, sc, P, reads, jobs, jcap, ctr32, X.base, n_tasks * 4, prof);
 	const int wpc = 3;   // (three waves per SIMD at 167 VGPRs)
 	const int grid = (int)std::max<long long>(1, std::min<long long>((n_tasks * 4 + 15) / 16, (long long)n_cu * wpc));

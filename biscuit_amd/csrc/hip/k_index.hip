@@ -27,6 +27,7 @@
 // Sorting and scanning use rocPRIM's device primitives (plain library sorts, as rocBLAS would be for a plain GEMM);
 // everything specific to the index is written here.  Ranks and positions are 64-bit throughout.
 #include <hip/hip_runtime.h>
+#include "tune.h"
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -339,7 +340,7 @@ int bsx_ix_build_fmi(hipStream_t st, int n_cu, const uint8_t *d_pac, int64_t l_p
 	const double t_begin = ix_now();
 	const u64 n_words = ((n + 31) >> 5) + 2;
 	// batch / slice size: bounded so that the temporaries stay a small part of HBM
-	u64 batch_cap = getenv("BSX_INDEX_BATCH") ? strtoull(getenv("BSX_INDEX_BATCH"), 0, 10) : ((u64)256 << 20);
+	u64 batch_cap = bsx_tune_is_set("index_batch") ? strtoull(bsx_tune_str("index_batch"), 0, 10) : ((u64)256 << 20);
 	if (batch_cap < 1024) batch_cap = 1024;
 
 	DevBuf T, SA, ISA, small, hist;

@@ -17,6 +17,7 @@
 #include "dev_common.hpp"
 #include "wave.hpp"
 #include "kernels.h"
+#include "tune.h"
 #include "ext_dp.hpp"
 #include "rgx.hpp"
 
@@ -2399,7 +2400,7 @@ void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScori
                     const long long *pos_off, const unsigned long long *pos, const unsigned char *cls, const RgXPoolArg &XA, int long_reads)
 {
 	RgXPool X = rgx_pool(&XA);
-	static const int occ = getenv("BSX_REGIONS_OCC") ? atoi(getenv("BSX_REGIONS_OCC")) : 5;   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
+	const int occ = (int)bsx_tune_long("regions_occ", 5);   // waves per SIMD the register allocation targets (the tables in LDS allow five workgroups per CU)
 	if (long_reads)
 		hipLaunchKernelGGL((k_regions<3, RgDpLiteL>), dim3(grid * (4 / RG_WPB)), dim3(64 * RG_WPB), 0, st, ix, sc, P, reads, tasks, n_tasks, seeds_dense, task_off, task_n,
 		                   out, out_cap, out_cursor, reg_off, reg_n, task_cursor, retry_list, retry_count, quota, counters, pos_off, pos, cls, X);
@@ -2477,6 +2478,18 @@ void launch_seedsw(hipStream_t st, int grid, int n_cu, const DevIndex &ix, const
 	RgXPool X = rgx_pool(&XA);
 	SswJob *J = (SswJob*)jobs;
 	int *scores = (int*)(J + job_cap);
+	{ // k_swl16 keeps two jobs' scores in the 16-bit halves of a register (wrapping adds, signed 16-bit maxima) and its profile as biased bytes:
+	  // exact while the largest score of a job -- at most 199 columns of the matrix's maximum -- plus the bias and the gap terms added to it
+	  // stays below 2^15, and a biased matrix entry fits a byte.  Scoring options beyond that (an -A in the hundreds) leave the job list empty:
+	  // every seed then takes the no-room path of k_seedsw_apply (sw_pass: a wavefront per alignment in 32-bit arithmetic), which is exact.
+		int mx = 0, bias = 0;
+		for (int i = 0; i < 25; ++i) {
+			mx = sc.ctmat[i] > mx ? sc.ctmat[i] : mx; mx = sc.gamat[i] > mx ? sc.gamat[i] : mx;
+			bias = -(int)sc.ctmat[i] > bias ? -(int)sc.ctmat[i] : bias; bias = -(int)sc.gamat[i] > bias ? -(int)sc.gamat[i] : bias;
+		}
+		const int oe = (sc.o_del + sc.e_del > sc.o_ins + sc.e_ins ? sc.o_del + sc.e_del : sc.o_ins + sc.e_ins), e = sc.e_del > sc.e_ins ? sc.e_del : sc.e_ins;
+		if (199LL * mx + 7LL * 25 * e + 2LL * oe + bias >= 32768 || mx + bias > 255 || oe >= 32768) job_cap = 0;
+	}
 	hipLaunchKernelGGL(k_seedsw_prep, dim3(grid), dim3(64), 0, st, ix, tasks, X, cursor, J, job_cap, count_cursor);
 	if (sc.o_del == sc.o_ins && sc.e_del == sc.e_ins) hipLaunchKernelGGL(k_swl16<true>, dim3(n_cu * 8), dim3(256), 0, st, ix, sc, reads, (const SswJob*)J, (const unsigned int*)count_cursor, job_cap, scores);
 	else hipLaunchKernelGGL(k_swl16<false>, dim3(n_cu * 8), dim3(256), 0, st, ix, sc, reads, (const SswJob*)J, (const unsigned int*)count_cursor, job_cap, scores);

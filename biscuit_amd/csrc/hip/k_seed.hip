@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "seed_core.hpp"
 #include "kernels.h"
+#include "tune.h"
 
 #include "wave.hpp"
 
@@ -150,7 +151,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	L.state = SD_DONE;
 	L.n_slow = L.n_fast = 0;
 	int task = -1, retired = 0, taken = 0, trips = 0, budget = 0;
-	uint32_t tot_slow = 0, tot_fast = 0;
+	uint32_t tot_slow = 0, tot_fast = 0, tot_over = 0;
 
 	unsigned int trip = 0;
 	// $BSX_PHASES: where a wave's cycles go (u64 slots 48..: wave cycles, in the full machine, publishing, trips, full-machine passes)
@@ -183,6 +184,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 						}
 						task_off[task] = (long long)base;
 						task_n[task] = L.overflow ? -n - 1 : n;   // any negative count: seed this strand search again
+						tot_over += L.overflow ? 1u : 0u;
 						tot_slow += L.n_slow; tot_fast += L.n_fast;
 						task = -1;
 						if (prof) pc_pub += clock64() - pc_p0;
@@ -236,7 +238,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 		}
 	}
 	// work counters for the algorithmic-bytes model: slow path = two 64-B blocks, fast = one
-	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); }
+	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); tot_over += __shfl_down(tot_over, off); }
 	if (prof) {
 		long long pub = pc_pub;
 		for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(pub, off); pub = pub > o ? pub : o; }
@@ -247,6 +249,7 @@ k_seed(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_ta
 	}
 	if ((threadIdx.x & 63) == 0) {
 		atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast);
+		if (tot_over) atomicAdd(&counters[119], (unsigned long long)tot_over);   // strand searches left with a negative count (k_seedt.hip)
 		__threadfence();
 		atomicExch(&slab_busy[slab], 0u);
 	}
@@ -292,7 +295,7 @@ void launch_seed(hipStream_t st, int grid, const DevIndex &ix, const uint8_t *re
 	const unsigned int cold_mask = 4u - 1u;
 	const int cold_lanes = 24;
 	// the table form (k_seedt.hip) whenever the index has its table; $BSX_SEED_FORM=classic (or a number: the forms below) keeps this kernel
-	const bool classic = getenv("BSX_SEED_FORM") != nullptr;   // (read per launch: the tests switch it)
+	const bool classic = bsx_tune_is_set("seed_form");   // (a setting of the library: the tests and bench.py switch it between calls)
 	if (!classic) {
 		launch_seedt(st, grid, ix, reads, tasks, n_tasks, P, scratch, list_cap, mem_cap, out, out_cap, out_cursor, task_off, task_n, task_cursor, counters,
 		             quota, slab_busy, n_slabs, trip_budget, prof, qpack, direct_off);

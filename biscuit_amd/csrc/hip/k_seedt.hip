@@ -159,7 +159,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 	L.ik.x0 = L.ik.x1 = L.ik.x2 = L.ik.info = 0; L.ext_back = L.ext_c = L.ext_which = 0; L.tab_idx = 0;
 	L.mem_n = 0; L.overflow = 0; L.pw = 0; L.key = 0; L.ka = L.kb = 0;
 	int task = -1, retired = 0, taken = 0, trips = 0, budget = 0;
-	uint32_t tot_slow = 0, tot_fast = 0, tot_look = 0;
+	uint32_t tot_slow = 0, tot_fast = 0, tot_look = 0, tot_over = 0;   // (tot_over: strand searches this lane left with a negative count)
 	unsigned int trip = 0;
 	long long pc_t0 = prof ? clock64() : 0, pc_cold = 0, pc_hot = 0, pc_fetch = 0, pc_post = 0; unsigned int pc_cold_n = 0;
 	unsigned long long pc_req = 0;
@@ -181,6 +181,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 				}
 				task_off[task] = (long long)base;
 				task_n[task] = L.overflow ? -n - 1 : n;   // any negative count: seed this strand search again
+				tot_over += L.overflow ? 1u : 0u;
 				tot_slow += L.n_slow; tot_fast += L.n_fast; tot_look += L.n_look;
 				task = -1;
 			}
@@ -198,6 +199,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 				budget = trip_budget * ((L.len + 255) >> 8);
 				if (L.len < P.min_seed_len || L.len + 1 > list_cap) { // too short to seed (memchain.c:279) / cannot fit: an empty result
 					task_off[t] = 0; task_n[t] = L.len + 1 > list_cap ? -1 : 0;
+					tot_over += L.len + 1 > list_cap ? 1u : 0u;
 					task = -1;
 					continue;
 				}
@@ -231,7 +233,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 		}
 		if (prof) pc_post += clock64() - pc_p0;
 	}
-	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); tot_look += __shfl_down(tot_look, off); }
+	for (int off = 32; off > 0; off >>= 1) { tot_slow += __shfl_down(tot_slow, off); tot_fast += __shfl_down(tot_fast, off); tot_look += __shfl_down(tot_look, off); tot_over += __shfl_down(tot_over, off); }
 	if ((threadIdx.x & 63) == 0) {
 		if (prof) {
 			atomicAdd(&counters[48], (unsigned long long)(clock64() - pc_t0)); atomicAdd(&counters[49], (unsigned long long)pc_cold);
@@ -240,6 +242,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 			atomicAdd(&counters[124], pc_req);
 		}
 		atomicAdd(&counters[0], 2ull * tot_slow); atomicAdd(&counters[1], (unsigned long long)tot_fast); atomicAdd(&counters[120], (unsigned long long)tot_look);
+		if (tot_over) atomicAdd(&counters[119], (unsigned long long)tot_over);   // what the caller has to seed again: read back instead of every count
 		__threadfence();
 		atomicExch(&slab_busy[slab], 0u);
 	}

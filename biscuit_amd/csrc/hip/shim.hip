@@ -14,6 +14,7 @@
 #include "devbuf.hpp"
 #include "kernels.h"
 #include "index_build.h"
+#include "tune.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[bsx-hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return BSX_E_NODEVICE; } } while (0)
 
@@ -52,7 +53,15 @@ struct Lane {
 	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t work[5] = {0, 0, 0, 0, 0};   // the region kernels' work since the last reset: strand searches, SA intervals, occurrences, regions, read bases
+	long last_overflow = -1;   // strand searches the first seeding pass of this lane's last chunk left to the second (-1: no chunk yet)
+	double seed2_ms = 0; int64_t seed2_launches = 0; uint64_t seed2_tasks = 0;   // the second seeding pass inside the chunk's sequence (its own launch, its own counters: SEED2_CTR)
 };
+// The seeding launches of a chunk count their FM blocks and table entries in blocks of their own, so that each pass's bytes can be put over
+// that pass's time (bsx_device_seed_passes): u64 slots [0], [1], [120] of the lane's counter block for the chunk-wide first pass (and the batch
+// form), the same three at SEED2_CTR for the second pass inside the sequence, at SEED3_CTR for the few seeded again on the side stream.
+#define SEED2_CTR 256
+#define SEED3_CTR 384
+#define SMALL_BYTES 4096
 
 struct bsx_device {
 	int ordinal = 0;
@@ -99,7 +108,7 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		// The front-half streams leave a few compute units alone (one in every `reserve`): workgroups of k_seed live for tens of
 		// milliseconds and are not preempted, so without free CUs the short high-priority batches of the back half (K5, K6)
 		// would queue behind them no matter their priority.
-		static const int reserve = getenv("BSX_RESERVE_CU_EVERY") ? atoi(getenv("BSX_RESERVE_CU_EVERY")) : 8;
+		const int reserve = (int)bsx_tune_long("reserve_cu_every", 8);
 		bool masked = false;
 		if (reserve >= 2 && d->n_cu >= 16) {
 			std::vector<uint32_t> mask((size_t)(d->n_cu + 31) / 32, 0u);
@@ -128,8 +137,8 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		HIPCHK(hipEventCreate(&L.ev0));
 		HIPCHK(hipEventCreate(&L.ev1));
 		HIPCHK(hipEventCreate(&L.ev2));
-		if (L.small.reserve(1024) != BSX_OK) return BSX_E_NOMEM;   // u64 slots 32..47: per-stage cycle counts of the region kernels ($BSX_PHASES)
-		HIPCHK(hipMemset(L.small.p, 0, 1024));
+		if (L.small.reserve(SMALL_BYTES) != BSX_OK) return BSX_E_NOMEM;   // u64 slots 32..47: per-stage cycle counts of the region kernels ($BSX_PHASES)
+		HIPCHK(hipMemset(L.small.p, 0, SMALL_BYTES));
 	}
 	memset(&d->ix, 0, sizeof(d->ix));
 	for (int l = 0; l < BSX_LANES; ++l) memset(&d->lane[l].sc, 0, sizeof(DevScoring));
@@ -212,7 +221,7 @@ static int build_seed_tables(bsx_device_t *d)
 {
 	int K = seed_tab_depth(d->ix.fmi[0].seq_len);
 	const int K_want = K;
-	if (const char *e = getenv("BSX_SEED_TAB_K")) { K = atoi(e); if (K < 2) K = 0; if (K > 19) K = 19; }
+	if (const char *e = bsx_tune_str("seed_tab_k")) { K = atoi(e); if (K < 2) K = 0; if (K > 19) K = 19; }
 	d->ix.tab.K = 0; d->ix.tab.t[0] = d->ix.tab.t[1] = nullptr; d->ix.tab.pad_ = 0;
 	d->seedtab[0].release(); d->seedtab[1].release();
 	while (K >= 2 && 2 * (size_t)seed_tab_entries(K) * sizeof(SeedEnt) > hbm_budget()) --K;   // a level is a third of the table
@@ -224,7 +233,7 @@ static int build_seed_tables(bsx_device_t *d)
 		d->seedtab[0].release(); d->seedtab[1].release();
 		(void)hipGetLastError();
 	}
-	if (K != K_want && !getenv("BSX_SEED_TAB_K")) fprintf(stderr, "[W::%s] device memory: table of k-mer intervals with %d levels instead of %d%s\n", "bsx-hip", K < 2 ? 0 : K, K_want, K < 2 ? " (none: every seeding step is an FM extension)" : "");
+	if (K != K_want && !bsx_tune_is_set("seed_tab_k")) fprintf(stderr, "[W::%s] device memory: table of k-mer intervals with %d levels instead of %d%s\n", "bsx-hip", K < 2 ? 0 : K, K_want, K < 2 ? " (none: every seeding step is an FM extension)" : "");
 	if (K < 2) { d->seedtab[0].release(); d->seedtab[1].release(); return BSX_OK; }
 	for (int i = 0; i < 2; ++i) {
 		int rc;
@@ -261,7 +270,7 @@ extern "C" BSX_API int bsx_device_upload_index(bsx_device_t *d, const bsx_index_
 	int rc;
 	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
 	{ // denser suffix-array sample for the device (the files' 1-in-32 stays what the loader and the host see)
-		const char *e = getenv("BSX_DEVICE_SA_INTV");
+		const char *e = bsx_tune_str("device_sa_intv");
 		int want = e ? atoi(e) : BSX_DEVICE_SA_INTV_DEFAULT;
 		const int file_intv = (int)d->ix.fmi[0].sa_mask + 1;
 		if (want >= 1 && (want & (want - 1)) == 0) { // sparser when the device is short of memory (hbm_budget), down to the files' own sample
@@ -300,7 +309,7 @@ extern "C" BSX_API int bsx_device_build_index(bsx_device_t *d, bsx_index_t *idx,
 	HIPCHK(hipSetDevice(d->ordinal));
 	int rc;
 	if ((rc = upload_ref(d, idx)) != BSX_OK) return rc;
-	const char *e = getenv("BSX_DEVICE_SA_INTV");
+	const char *e = bsx_tune_str("device_sa_intv");
 	int dense = e ? atoi(e) : BSX_DEVICE_SA_INTV_DEFAULT;
 	if (dense < 1 || dense > 32 || (dense & (dense - 1))) dense = BSX_DEVICE_SA_INTV_DEFAULT;
 	Lane &L = d->lane[0];
@@ -453,6 +462,12 @@ extern "C" BSX_API int bsx_device_counters(bsx_device_t *d, uint64_t c[4], int r
 		HIPCHK(hipMemcpy(t, d->lane[l].small.p, 32, hipMemcpyDeviceToHost));
 		for (int k = 0; k < 4; ++k) c[k] += t[k];
 		if (reset) HIPCHK(hipMemset(d->lane[l].small.p, 0, 32));
+		for (int b = 0; b < 2; ++b) { // the later seeding passes' FM blocks (counted apart: bsx_device_seed_passes)
+			char *p = (char*)d->lane[l].small.p + (size_t)(b ? SEED3_CTR : SEED2_CTR) * 8;
+			HIPCHK(hipMemcpy(t, p, 16, hipMemcpyDeviceToHost));
+			c[0] += t[0]; c[1] += t[1];
+			if (reset) HIPCHK(hipMemset(p, 0, 16));
+		}
 	}
 	return BSX_OK;
 }
@@ -464,13 +479,41 @@ extern "C" BSX_API int bsx_device_seed_table(bsx_device_t *d, uint64_t *lookups,
 	HIPCHK(hipSetDevice(d->ordinal));
 	uint64_t tot = 0;
 	for (int l = 0; l < BSX_LANES; ++l) {
-		uint64_t t = 0;
-		HIPCHK(hipMemcpy(&t, (char*)d->lane[l].small.p + 120 * 8, 8, hipMemcpyDeviceToHost));
-		tot += t;
-		if (reset) HIPCHK(hipMemset((char*)d->lane[l].small.p + 120 * 8, 0, 8));
+		static const int at[3] = {120, SEED2_CTR + 120, SEED3_CTR + 120};
+		for (int b = 0; b < 3; ++b) {
+			uint64_t t = 0;
+			HIPCHK(hipMemcpy(&t, (char*)d->lane[l].small.p + (size_t)at[b] * 8, 8, hipMemcpyDeviceToHost));
+			tot += t;
+			if (reset) HIPCHK(hipMemset((char*)d->lane[l].small.p + (size_t)at[b] * 8, 0, 8));
+		}
 	}
 	if (lookups) *lookups = tot;
 	if (depth) *depth = d->has_index ? d->ix.tab.K : 0;
+	return BSX_OK;
+}
+
+// The seeding passes of bsx_regions_batch one by one since the last reset (call it BEFORE bsx_device_counters / _seed_table with reset, which
+// zero the same blocks): w[0], w[1] FM blocks and table entries read by the chunk-wide first pass (and by bsx_seed_batch launches), w[2], w[3]
+// by the second pass inside the chunk's sequence, w[4] its launches, w[5] its strand searches; ms[0], ms[1]: their summed HIP-event times.
+extern "C" BSX_API int bsx_device_seed_passes(bsx_device_t *d, uint64_t w[6], double ms[2], int reset)
+{
+	if (!d || !w || !ms) return BSX_E_ARG;
+	HIPCHK(hipSetDevice(d->ordinal));
+	for (int k = 0; k < 6; ++k) w[k] = 0;
+	ms[0] = ms[1] = 0;
+	for (int l = 0; l < BSX_LANES; ++l) {
+		Lane &L = d->lane[l];
+		uint64_t t[2], u = 0;
+		HIPCHK(hipMemcpy(t, L.small.p, 16, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&u, (char*)L.small.p + 120 * 8, 8, hipMemcpyDeviceToHost));
+		w[0] += t[0] + t[1]; w[1] += u;
+		HIPCHK(hipMemcpy(t, (char*)L.small.p + SEED2_CTR * 8, 16, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&u, (char*)L.small.p + (SEED2_CTR + 120) * 8, 8, hipMemcpyDeviceToHost));
+		w[2] += t[0] + t[1]; w[3] += u;
+		w[4] += (uint64_t)L.seed2_launches; w[5] += L.seed2_tasks;
+		ms[0] += L.k_ms[0]; ms[1] += L.seed2_ms;
+		if (reset) { L.seed2_ms = 0; L.seed2_launches = 0; L.seed2_tasks = 0; }
+	}
 	return BSX_OK;
 }
 
@@ -645,7 +688,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.a = opt->a; R.w = opt->w; R.o_del = opt->o_del; R.e_del = opt->e_del; R.o_ins = opt->o_ins; R.e_ins = opt->e_ins;
 	R.pen_clip5 = opt->pen_clip5; R.pen_clip3 = opt->pen_clip3; R.min_seed_len = opt->min_seed_len; R.min_chain_weight = opt->min_chain_weight;
 	R.max_chain_gap = opt->max_chain_gap; R.max_occ = opt->max_occ; R.bsstrand = opt->bsstrand; R.max_chain_extend = (uint32_t)opt->max_chain_extend;
-	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = getenv("BSX_PHASES") ? 1 : 0;
+	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = bsx_phases() ? 1 : 0;
 	R.gap_cap = -1;
 	R.walk_on = 1;
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
@@ -674,22 +717,22 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const bool export_all = long_reads || any_flt;
 
 	// $BSX_SEED_MEM_CAP (tests): a short first-pass list, so that ordinary reads take the seeded-again path too
-	const int mem_cap = getenv("BSX_SEED_MEM_CAP") ? std::max(4, atoi(getenv("BSX_SEED_MEM_CAP"))) : std::max(64, max_len), list_cap = max_len + 2;
+	const int mem_cap = bsx_tune_is_set("seed_mem_cap") ? std::max(4, (int)bsx_tune_long("seed_mem_cap", 64)) : std::max(64, max_len), list_cap = max_len + 2;
 	// room for the interval lists (32 B each) and regions (56 B each) of the whole chunk; repeat-rich genomes average
 	// dozens of intervals per strand search, and HBM is not the scarce resource here
 	const unsigned long long lf = (unsigned long long)std::max(1, (max_len + 149) / 150);   // pools are sized per 150 bases of read
 	// the interval lists: strand search t's own stretch of mem_cap entries (k_seedt writes them where they stay), then room for the lists of the
 	// strand searches seeded again with longer lists, which go one behind the other from the cursor
-	const bool seed_direct = !(getenv("BSX_SEED_DIRECT") && atoi(getenv("BSX_SEED_DIRECT")) == 0) && !getenv("BSX_SEED_FORM")
+	const bool seed_direct = bsx_tune_long("seed_direct", 1) != 0 && !bsx_tune_is_set("seed_form")
 	                         && (unsigned long long)n * (unsigned long long)mem_cap <= (768ull << 20);   // (24 GB of lists: a chunk of short reads with one very long one keeps the lists one behind the other)   // ($BSX_SEED_DIRECT=0: one list behind the other, copied there when a strand search is done)
 	const unsigned long long direct_n = seed_direct ? (unsigned long long)n * (unsigned long long)mem_cap : 0;
 	const unsigned long long dense_cap = direct_n + (unsigned long long)n * (seed_direct ? 16 : 96) * lf + (1u << 20), regs_cap = (unsigned long long)n * 24 + 65536;   // (a read inside a repeat family has dozens of regions: 6 per strand search overflowed on an hg38-like genome)
 	// workgroups with a bounded life (a few tasks per lane / wave), many more of them than fit on the chip
-	const int seed_quota = getenv("BSX_SEED_QUOTA") ? atoi(getenv("BSX_SEED_QUOTA")) : (getenv("BSX_SEED_FORM") ? 1 : 0);   // strand searches per lane, 0 = lanes take them until none is left.  The table form (k_seedt.hip) runs persistent lanes: a lane that is done takes the next strand search in the same trip (measured at hg38 scale: 68 ms against 97 with one per lane and 86 with four); the kernel without the table does best with one (292 ms against 335 with two and 359 persistent: its lanes then move through the seeding passes together)
+	const int seed_quota = (int)bsx_tune_long("seed_quota", bsx_tune_is_set("seed_form") ? 1 : 0);   // strand searches per lane, 0 = lanes take them until none is left.  The table form (k_seedt.hip) runs persistent lanes: a lane that is done takes the next strand search in the same trip (measured at hg38 scale: 68 ms against 97 with one per lane and 86 with four); the kernel without the table does best with one (292 ms against 335 with two and 359 persistent: its lanes then move through the seeding passes together)
 	// extensions after which the first seeding pass hands a strand search to the second one (0: never)
 	// (4096 for reads of 150 bases, which need ~1.2 k; in proportion for longer ones)
-	const int trip_budget = getenv("BSX_SEED_TRIP_BUDGET") ? std::max(0, atoi(getenv("BSX_SEED_TRIP_BUDGET"))) : 4096;   // (the kernel scales it per 256 bases of read)
-	static const int reg_quota = getenv("BSX_REGIONS_QUOTA") ? std::max(1, atoi(getenv("BSX_REGIONS_QUOTA"))) : 16;
+	const int trip_budget = std::max(0, (int)bsx_tune_long("seed_trip_budget", 4096));   // (the kernel scales it per 256 bases of read)
+	const int reg_quota = std::max(1, (int)bsx_tune_long("regions_quota", 16));
 	const int n_slabs = d->n_cu * 16;
 	const int seed_wpc = 16;   // quota 0 = persistent waves, sixteen per CU
 	int grid = seed_quota > 0 ? (int)((n + 256LL * seed_quota - 1) / (256LL * seed_quota))
@@ -710,7 +753,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
 	// copies there), a few dozen against small ones.  $BSX_POS_CAP (tests): a cap small enough for strand searches to find no room.
-	const unsigned long long pos_cap = getenv("BSX_POS_CAP") ? strtoull(getenv("BSX_POS_CAP"), 0, 10) : (unsigned long long)n * 384 * lf + (1u << 20);
+	const unsigned long long pos_cap = bsx_tune_is_set("pos_cap") ? strtoull(bsx_tune_str("pos_cap"), 0, 10) : (unsigned long long)n * 384 * lf + (1u << 20);
 	if ((rc = L.pos.reserve((size_t)pos_cap * 8)) != BSX_OK) return rc;
 	if ((rc = L.posoff.reserve((size_t)n * 8 + 64)) != BSX_OK) return rc;
 	// what the LDS tiers export for the chains -> regions launch: ~0.5 KB per strand search (a task that finds no room goes to the next tier)
@@ -719,12 +762,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.xmeta.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	// the extensions of the exported chains' best seeds are made ahead of chains -> regions, four to a wavefront (k_ext4.hip); $BSX_X4=0: all
 	// of them inline in k_c2r (the tests compare the two).  Not for chunks whose lists the seed-SW filter rewrites after the export.
-	static const int use_x4 = getenv("BSX_X4") ? atoi(getenv("BSX_X4")) : 1;
+	const int use_x4 = (int)bsx_tune_long("x4", 1);
 	const unsigned long long x4_cap = (unsigned long long)n * 12 * lf + (1u << 20);
 	if (use_x4 && !export_all && (rc = L.x4jobs.reserve((size_t)x4_cap * x4_job_bytes())) != BSX_OK) return rc;
 	// the seed filter's alignments (reads of 700 bases and more: memchain.c:501-535) are one batch per chunk: a few dozen per strand search
 	// ($BSX_SSW_CAP, tests: a list too short for the chunk -- what finds no room in it is aligned a wavefront at a time)
-	const unsigned long long ssw_cap = !any_flt ? 0 : getenv("BSX_SSW_CAP") ? std::max(8ull, strtoull(getenv("BSX_SSW_CAP"), 0, 10))
+	const unsigned long long ssw_cap = !any_flt ? 0 : bsx_tune_is_set("ssw_cap") ? std::max(8ull, strtoull(bsx_tune_str("ssw_cap"), 0, 10))
 	                                   : std::min<unsigned long long>((unsigned long long)n * 24 * lf + (1u << 20), 0x3ffffff0ull);
 	if (any_flt && (rc = L.sswjobs.reserve((size_t)ssw_cap * seedsw_job_bytes())) != BSX_OK) return rc;
 	unsigned long long *d_pos = (unsigned long long*)L.pos.p; long long *d_posoff = (long long*)L.posoff.p;
@@ -752,9 +795,10 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipMemsetAsync(ctr + 20, 0, 8, L.st));   // (count and cursor of the second chains -> regions launch)
+	HIPCHK(hipMemsetAsync(ctr + 119, 0, 8, L.st));  // (the first seeding pass's count of strand searches to be seeded again)
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)(ctr + 4) + 1), (int)(uint32_t)(direct_n >> 32), 1, L.st));
-	static const int chain = getenv("BSX_CHAIN_STAGES") ? atoi(getenv("BSX_CHAIN_STAGES")) : 3;   // 0: none, 1: seeding, 2: seeding and regions, 3: the same but the HBM tiers (a few long strand searches on a few waves) hold nobody back (measured A/B on one box, 16 chunks: 1.76 / 1.81 M reads/s with 2, 2.00 / 1.89 M with 3)
+	const int chain = (int)bsx_tune_long("chain_stages", 3);   // 0: none, 1: seeding, 2: seeding and regions, 3: the same but the HBM tiers (a few long strand searches on a few waves) hold nobody back (measured A/B on one box, 16 chunks: 1.76 / 1.81 M reads/s with 2, 2.00 / 1.89 M with 3)
 	if (chain >= 1) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		if (d->chain_seed && d->chain_seed != L.ev_seed_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_seed, 0));
@@ -781,10 +825,19 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	std::vector<int> first_n;   // the first pass's counts (negative: overflowed)
 	std::vector<int> merged_which; const int *merged_cnt = nullptr;   // the strand searches of the second pass inside this sequence, and where their new counts are
 	bool merged = false;
-	const long merge_min = getenv("BSX_REDO_MERGE_MIN") ? atol(getenv("BSX_REDO_MERGE_MIN")) : 4096;   // (tests: 1 = always merged, a huge number = never)
-	if (merge_min >= 0) {
-		first_n.resize((size_t)n);
+	const long merge_min = bsx_tune_long("redo_merge_min", 4096);   // (tests: 1 = always merged, a huge number or a negative one = never)
+	// Whether there are that many is the kernel's own count (counters[119]: 8 bytes back, not every strand search's count), and the host waits
+	// for it only when the lane's last chunk came anywhere near the threshold: on a clean genome, where a few dozen overflow, nothing stands
+	// between a chunk's seeding and its suffix-array lookups after the lane's first chunk.
+	unsigned long long n_over = 0;
+	const bool may_merge = merge_min >= 0 && merge_min <= (long)n;
+	if (may_merge && (L.last_overflow < 0 || L.last_overflow >= merge_min / 4)) {
 		HIPCHK(hipEventSynchronize(L.ev1));
+		D2H(L.st, &n_over, ctr + 119, 8);
+		L.last_overflow = (long)n_over;
+	}
+	if (may_merge && (long)n_over >= merge_min) {
+		first_n.resize((size_t)n);
 		D2H(L.st, first_n.data(), d_n, (size_t)n * 4);
 		std::vector<int> which;
 		for (int64_t i = 0; i < n; ++i) if (first_n[i] < 0) which.push_back((int)i);
@@ -807,11 +860,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// inside tandem repeats -- hundreds of thousands of dependent FM steps -- made it 90-170 ms for 23 ms of work; they go on to the
 			// side stream below like the few of a clean genome)
 			launch_seed(L.st, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, trip_budget * 8, 0, (uint32_t*)L.qpack.p);
+			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr + SEED2_CTR, 0, (unsigned int*)L.slabflags.p, g2 * 4, trip_budget * 8, 0, (uint32_t*)L.qpack.p);
 			hipLaunchKernelGGL(k_patch_lists, dim3((unsigned int)((n2 + 255) / 256)), dim3(256), 0, L.st, (const int*)which_d, (int)n2, (const long long*)off2, (const int*)cnt2, d_off, d_n);
 			HIPCHK(hipEventRecord(L.ev6, L.st));
 			merged = true; merged_which.swap(which); merged_cnt = cnt2;
-			if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_batch] %zu strand searches seeded again inside the main sequence\n", n2);
+			if (bsx_phases()) fprintf(stderr, "[M::regions_batch] %zu strand searches seeded again inside the main sequence\n", n2);
 		}
 	}
 	if (!merged) { HIPCHK(hipEventRecord(L.ev5, L.st)); HIPCHK(hipEventRecord(L.ev6, L.st)); }
@@ -822,14 +875,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (d->chain_regions && d->chain_regions != L.ev_regions_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_regions, 0));
 	}
 	// tier 1 -> retry_a -> LDS tier with larger tables -> retry_m -> tier 2 (HBM slabs) -> retry_b -> tier 3
-	static const int use_mid = getenv("BSX_REGIONS_MID") ? atoi(getenv("BSX_REGIONS_MID")) : 1;
+	const int use_mid = (int)bsx_tune_long("regions_mid", 1);
 	// strand searches a wave of the larger LDS tier / of the chains -> regions launch takes before it leaves (bounded workgroup life)
-	static const int mid_quota = getenv("BSX_MID_QUOTA") ? std::max(1, atoi(getenv("BSX_MID_QUOTA"))) : 8;
-	static const int c2r_quota = getenv("BSX_C2R_QUOTA") ? std::max(1, atoi(getenv("BSX_C2R_QUOTA"))) : 16;
+	const int mid_quota = std::max(1, (int)bsx_tune_long("mid_quota", 8));
+	const int c2r_quota = std::max(1, (int)bsx_tune_long("c2r_quota", 16));
 	// The tier sequence over a task list (the chunk's, and once more the re-seeded strand searches' on the side stream).  k32: u32 cursors and
 	// counts ([0] tier-1 cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor [5] k_seedsw's cursor [10] what the
 	// larger LDS tier hands on [11] its cursor); xc32: exported count | k_c2r's cursor.
-	const bool trace_tiers = getenv("BSX_PHASES") != nullptr || getenv("BSX_TIERS") != nullptr;   // $BSX_TIERS: the launch times alone (no cycle counters in the kernels)
+	const bool trace_tiers = bsx_phases() != 0 || bsx_tune_long("tiers", 0) != 0;   // $BSX_TIERS: the launch times alone (no cycle counters in the kernels)
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
@@ -838,7 +891,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
 		// $BSX_PHASES=2: the stage counters read (and zeroed) after every launch of the main sequence: where each tier's wave cycles go
-		const bool per_tier = getenv("BSX_PHASES") && atoi(getenv("BSX_PHASES")) == 2;
+		const bool per_tier = bsx_phases() == 2;
 #define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; \
 		if (per_tier) { unsigned long long pf_[8]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
 			double tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) tot_ += (double)pf_[k_]; \
@@ -860,7 +913,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			to2 = rl; n2c = l_count;
 			TIER_MARK("tier 1c");
 		}
-		static const bool use_1c = !(getenv("BSX_TIER1C") && atoi(getenv("BSX_TIER1C")) == 0);   // ($BSX_TIER1C=0: the tier sequence of rounds 2-4, for the A/B)
+		const bool use_1c = bsx_tune_long("tier1c", 1) != 0;   // ($BSX_TIER1C=0: the tier sequence of rounds 2-4, for the A/B)
 		const bool tier1c = use_mid && !long_reads && !export_all && use_1c;
 		if (tier1c) { // ordinary reads inside repeat families: an LDS tier with twice the tables behind the first two (round 5)
 			launch_regions_mid(st, (int)((nT + 2LL * mid_quota - 1) / (2LL * mid_quota)), d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
@@ -970,7 +1023,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// on one lane) are seeded again on the side stream with much longer lists and go through the third tier as well.  None of
 	// that is waited for here: everything is enqueued, and lane_regions_finish collects the result when the caller gets to the
 	// chunk's back half.
-	const bool trace = getenv("BSX_PHASES") != nullptr;
+	const bool trace = bsx_phases() != 0;
 	struct timespec ts0, ts1, ts2, ts3;
 	clock_gettime(CLOCK_MONOTONIC, &ts0);
 	std::vector<int64_t> redo;            // task indices
@@ -979,6 +1032,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (!first_n.empty()) s_n.swap(first_n);
 		else { s_n.resize((size_t)n); HIPCHK(hipEventSynchronize(L.ev1)); D2H(L.st2, s_n.data(), d_n, (size_t)n * 4); }
 		for (int64_t i = 0; i < n; ++i) if (s_n[i] < 0) redo.push_back(i); else L.work[1] += (uint64_t)s_n[i];
+		L.last_overflow = (long)redo.size();
 		if (merged) { // they are in the main sequence, but for those that the second pass gave up on as well (its budget, its list)
 			std::vector<int> c2(merged_which.size());
 			HIPCHK(hipEventSynchronize(L.ev6));
@@ -1017,7 +1071,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
 			HIPCHK(hipMemsetAsync(ctr + 96, 0, 80, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, q32 + 7, ctr, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
+			            off2, cnt2, q32 + 7, ctr + SEED3_CTR, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
@@ -1046,7 +1100,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
 		float ms3 = 0, ms_again = 0;
 		HIPCHK(hipEventElapsedTime(&ms_again, L.ev5, L.ev6));   // the second seeding pass, when it ran inside this sequence
-		if (merged) { L.k_ms[7] += ms_again; L.k_launch[7] += 1; }   // (slot 7: seeding outside the chunk-wide launch)
+		if (merged) { L.k_ms[7] += ms_again; L.k_launch[7] += 1; L.seed2_ms += ms_again; L.seed2_launches += 1; L.seed2_tasks += (uint64_t)merged_which.size(); }   // (slot 7: seeding outside the chunk-wide launch)
 		HIPCHK(hipEventElapsedTime(&ms3, L.ev6, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
 		L.k_ms[1] += ms3; L.k_launch[1] += 1;
 		HIPCHK(hipEventElapsedTime(&ms1, L.ev4, L.ev3));   // the first region tier alone
@@ -1177,7 +1231,7 @@ static int lane_regions_finish(bsx_device_t *d, int lane, bsx_region_t **out, in
 	clock_gettime(CLOCK_MONOTONIC, &ta);
 	HIPCHK(hipEventSynchronize(L.rs.ev));
 	clock_gettime(CLOCK_MONOTONIC, &tb);
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions_finish] waited %.0f ms for %zu strand searches seeded again\n", (tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6, L.rs.tasks.size());
+	if (bsx_phases()) fprintf(stderr, "[M::regions_finish] waited %.0f ms for %zu strand searches seeded again\n", (tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6, L.rs.tasks.size());
 	HIPCHK(hipGetLastError());
 	const size_t n2 = L.rs.tasks.size();
 	const long long *roff = (const long long*)L.rs.hres.p;
@@ -1208,7 +1262,7 @@ static int lane_regions_finish(bsx_device_t *d, int lane, bsx_region_t **out, in
 		out_off[i] = used; out_n[i] = rn[j];
 		used += rn[j];
 	}
-	if (getenv("BSX_PHASES")) {
+	if (bsx_phases()) {
 		fprintf(stderr, "[M::regions_finish] left to the caller after the second pass, by reason:");
 		for (int k = 1; k < 16; ++k) if (hist[k]) fprintf(stderr, " %d: %ld", k, hist[k]);
 		fprintf(stderr, "\n");
@@ -1248,7 +1302,7 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
 	HIPCHK(hipSetDevice(d->ordinal));
-	if (getenv("BSX_EXT4")) { // tests: the batch through the quarter-wave kernel of the regions path (k_ext4.hip); jobs it declines fail the call
+	if (bsx_tune_is_set("ext4")) { // tests: the batch through the quarter-wave kernel of the regions path (k_ext4.hip); jobs it declines fail the call
 		int rc, max_q = 0;
 		for (int64_t i = 0; i < n; ++i) max_q = std::max(max_q, jobs[i].qlen);
 		if (max_q > x4_max_query(16) || n > 0x7fffffff) return BSX_E_ARG;
@@ -1258,7 +1312,7 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
 		launch_ext4_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p, max_q);
-		if (atoi(getenv("BSX_EXT4")) == 2) { // then the lane-per-job kernel (k_extl.hip) over the same jobs: its answers replace the others'
+		if (bsx_tune_long("ext4", 0) == 2) { // then the lane-per-job kernel (k_extl.hip) over the same jobs: its answers replace the others'
 			HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
 			launch_extl_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p);
 			unsigned int c[4]; D2H(L.st, c, L.aux.p, 16);
@@ -1359,7 +1413,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	if ((rc = L.res.reserve((size_t)n * sizeof(bsx_sw_res_t))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 4 + 64)) != BSX_OK) return rc;
 	if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * 4 * (size_t)max_tlen * 8)) != BSX_OK) return rc;   // b[] of every job in flight: four jobs to a wave in k_swl
-	static const bool tr_sw = getenv("BSX_PHASES") != nullptr;
+	const bool tr_sw = bsx_phases() != 0;
 	const double ts0 = tr_sw ? bsx_now_s() : 0;
 	H2D(L.st_hi, L.jobs.p, jobs, (size_t)n * sizeof(bsx_sw_job_t));
 	size_t off = 0;
@@ -1555,7 +1609,7 @@ static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_tas
 {
 	// The handful of strand searches seeded again (tandem repeats) are done by the time the region tiers are, so by default they are
 	// collected before returning; $BSX_ASYNC_REDO=1 leaves them pending for regions_finish at the start of the chunk's back half.
-	const int async_redo = getenv("BSX_ASYNC_REDO") ? atoi(getenv("BSX_ASYNC_REDO")) : 0;
+	const int async_redo = (int)bsx_tune_long("async_redo", 0);
 	int rc = lane_regions_batch(LR(c), o, n, t, out, cap, off, cnt, di, dc, doff);
 	if (rc == BSX_OK && !async_redo) rc = lane_regions_finish(LR(c), out, cap, off, cnt);
 	return rc;
@@ -1578,9 +1632,9 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	out->ctx = r; out->name = "hip-gfx950";
 	out->set_opt = be_set_opt; out->set_reads = be_set_reads; out->seed_batch = be_seed; out->sa_batch = be_sa;
 	out->extend_batch = be_ext; out->sw_batch = be_sw; out->global_batch = be_glb; out->global_batch_tags = be_glb_tags;
-	out->regions_batch = getenv("BSX_HOST_CHAIN") ? nullptr : be_regions;
+	out->regions_batch = bsx_tune_long("host_chain", 0) ? nullptr : be_regions;
 	out->regions_finish = out->regions_batch ? be_regions_finish : nullptr;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
-	out->regions_dedup = out->regions_batch && !getenv("BSX_HOST_DEDUP") ? be_dedup : nullptr;   // BSX_HOST_DEDUP=1: C5 on the host for every read (A/B checks)
+	out->regions_dedup = out->regions_batch && !bsx_tune_long("host_dedup", 0) ? be_dedup : nullptr;   // BSX_HOST_DEDUP=1: C5 on the host for every read (A/B checks)
 	out->dedup_cap = dedup_cap();
 	return BSX_OK;
 }

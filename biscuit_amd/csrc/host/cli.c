@@ -7,6 +7,7 @@
 #include <getopt.h>
 #include <pthread.h>
 #include "bsx_core.h"
+#include "tune.h"
 #include "fastq.h"
 #include "pipeline.h"
 
@@ -229,7 +230,7 @@ static volatile int g_write_error = 0;   /* a write to stdout failed (the refere
 static bsx_fq_scan_t *shard_scan_start(const char *fn1, const char *fn2, int chunk)
 {
 	bsx_fq_scan_t *s;
-	if (CHUNK_WORLD <= 1 || getenv("BSX_NO_CHUNK_SCAN")) return 0;
+	if (CHUNK_WORLD <= 1 || bsx_tune_long("no_chunk_scan", 0)) return 0;
 	s = bsx_fq_scan_start(fn1, fn2, chunk);
 	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] rank %d of %d: %s\n", "main_align", bsx_shard_rank, bsx_shard_world,
 	                              s ? "chunk boundaries by a scan of the input, this rank parses its own chunks only" : "compressed or piped input: this rank inflates all of it, parses its own chunks and walks the others without building records");
@@ -243,7 +244,7 @@ static void *reader_main(void *arg)
 	bsx_fq_scan_t *scan = shard_scan_start(R->fn1, R->fn2, R->chunk);
 	/* several ranks over input that cannot be sought in (compressed, piped): the chunks of the other ranks are walked without building
 	 * their records (bsx_fq_skip_chunk); this rank's own are parsed in place, the inflate threads of fastq.c running ahead of both */
-	const int skip_mode = !scan && CHUNK_WORLD > 1 && !getenv("BSX_NO_CHUNK_SKIP");
+	const int skip_mode = !scan && CHUNK_WORLD > 1 && !bsx_tune_long("no_chunk_skip", 0);
 	int64_t n_before = 0;
 	bsx_fq_pair_t *P = (scan || skip_mode) ? 0 : bsx_fq_pair_open(R->f1, R->f2, R->has_bc);
 	if (scan) idx = bsx_shard_rank;
@@ -583,7 +584,7 @@ BSX_API int bsx_align_main_with(int argc, char **argv, process_fn process, void 
 					chunk_idx = k - 1;
 					n_processed = cp.n_before;
 				}
-				if (!scan && CHUNK_WORLD > 1 && (chunk_idx + 1) % bsx_shard_world != bsx_shard_rank && !getenv("BSX_NO_CHUNK_SKIP")) {
+				if (!scan && CHUNK_WORLD > 1 && (chunk_idx + 1) % bsx_shard_world != bsx_shard_rank && !bsx_tune_long("no_chunk_skip", 0)) {
 					/* another rank's chunk of input that cannot be sought in: walked, not parsed (bsx_fq_skip_chunk) */
 					const int ns = bsx_fq_skip_chunk(f1, f2, chunk);
 					if (ns == 0) break;

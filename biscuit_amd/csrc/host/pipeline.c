@@ -20,6 +20,7 @@
 #include <pthread.h>
 #include <sys/time.h>
 #include "align_types.h"
+#include "tune.h"
 #include "pipeline.h"
 
 static double now_s(void) { struct timeval tv; gettimeofday(&tv, 0); return tv.tv_sec + tv.tv_usec * 1e-6; }
@@ -94,6 +95,7 @@ typedef struct {
 	int n, is_pe, nt;
 	int64_t n_processed;
 	int64_t seq;         /* order of the chunks pushed through streams ($BSX_STREAM_WHOLE_CHUNK: back halves start in this order) */
+	int ordered;         /* decided once, when the chunk is pushed: its back half runs on its own thread, in its turn (seq is its ticket) */
 	int64_t local0;      /* these reads are a slice of a chunk (several GPUs sharing it): the index of the first one within the chunk */
 	bsx_read_t *reads;
 	uint32_t *roff;
@@ -318,7 +320,7 @@ static int extension_rounds(chunk_t *C)
 		else bsx_parallel_for(C->nt, consume_worker, &P, nj);
 		tc += now_s() - tx;
 	}
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::extend] advance %.3f gather %.3f batch %.3f consume %.3f (%ld jobs, %ld rounds)\n", ta, tg, tb, tc, (long)C->st.n_ext_jobs, (long)C->st.n_ext_rounds);
+	if (bsx_phases()) fprintf(stderr, "[M::extend] advance %.3f gather %.3f batch %.3f consume %.3f (%ld jobs, %ld rounds)\n", ta, tg, tb, tc, (long)C->st.n_ext_jobs, (long)C->st.n_ext_rounds);
 	free(jobs); free(res); free(owner); free(active);
 	return rc;
 }
@@ -660,7 +662,7 @@ static int mate_rescue(chunk_t *C)
 	double t_batch = 0, t_all = now_s();
 	msw_pair_t *M = (msw_pair_t*)bsx_par_calloc(C->nt, (size_t)np, sizeof(msw_pair_t));
 	msw_par_t P;
-	g_msw_prof = getenv("BSX_PHASES") != 0;
+	g_msw_prof = bsx_phases() != 0;
 	P.C = C; P.M = M;
 	P.cnt = (int*)malloc(sizeof(int) * ((size_t)np + 1)); P.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)np + 1));
 	bsx_parallel_for(C->nt, msw_init_worker, &P, np);
@@ -682,7 +684,7 @@ static int mate_rescue(chunk_t *C)
 		if (rc != BSX_OK) break;
 	}
 	bsx_parallel_for(C->nt, msw_free_worker, &P, np);
-	if (getenv("BSX_PHASES")) {
+	if (bsx_phases()) {
 		fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host | thread-seconds: %.2f in the per-pair passes, %.2f of them in %ld list sorts (%.1f regions each)\n",
 		        round, t_batch, now_s() - t_all - t_batch, g_msw_replay_ns * 1e-9, g_msw_ns * 1e-9, (long)g_msw_calls, g_msw_calls ? (double)g_msw_elems / g_msw_calls : 0.0);
 		g_msw_replay_ns = g_msw_ns = g_msw_calls = g_msw_elems = 0;
@@ -892,7 +894,7 @@ static int emit_sam(chunk_t *C)
 		free(sres); free(tags);
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
+	if (bsx_phases()) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
 	C->st.t_cigar += now_s() - t0; t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
@@ -1040,7 +1042,7 @@ static int host_path(chunk_t *C, int n_reseed, const bsx_intv_t *decl_intv, cons
 		for (t = n_reseed; t <= C->n_host; ++t) C->intv_off[t] = base + decl_off[t - n_reseed];
 	}
 	C->st.t_seed += now_s() - t0; C->st.n_intv += C->intv_off[C->n_host];
-	if (getenv("BSX_PHASES") && be->regions_batch)
+	if (bsx_phases() && be->regions_batch)
 		for (t = 0; t < C->n_host && t < 80; ++t) {
 			int64_t k, occ = 0, big = 0;
 			for (k = C->intv_off[t]; k < C->intv_off[t + 1]; ++k) { occ += (int64_t)(C->intv[k].x[2] < (uint64_t)opt->max_occ ? C->intv[k].x[2] : (uint64_t)opt->max_occ); big += C->intv[k].x[2] > (uint64_t)opt->max_occ; }
@@ -1194,7 +1196,7 @@ static int chunk_front(chunk_t *C)
 			C->dd_idx = (uint8_t*)bsx_big_get(C->arena_set, 11, (size_t)C->dd_cap * ((size_t)n + 1));
 			rc = be->regions_dedup(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx);
 			if (rc != BSX_OK) goto out;
-			if (getenv("BSX_PHASES")) { /* what the device's sort + de-duplication leaves of the regions that came down */
+			if (bsx_phases()) { /* what the device's sort + de-duplication leaves of the regions that came down */
 				int64_t kept = 0, held = 0, left_all = 0, left_reads = 0; int per = C->n_tasks / (n ? n : 1), i, k;
 				for (i = 0; i < n; ++i) {
 					int64_t all = 0;
@@ -1204,13 +1206,13 @@ static int chunk_front(chunk_t *C)
 				fprintf(stderr, "[M::regions] device de-duplication: %lld of %lld regions kept; %lld regions of %lld reads left to the host's\n", (long long)kept, (long long)held, (long long)left_all, (long long)left_reads);
 			}
 		}
-		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] regions_batch %.3f s, device de-duplication %.3f s, adopting the regions %.3f s\n", t_batch_end - t0, ta - t_batch_end, now_s() - ta); }
+		{ double ta = now_s(); bsx_parallel_for(nt, adopt_worker, C, C->n_tasks); if (bsx_phases()) fprintf(stderr, "[M::regions] regions_batch %.3f s, device de-duplication %.3f s, adopting the regions %.3f s\n", t_batch_end - t0, ta - t_batch_end, now_s() - ta); }
 		/* host list: first the strand searches that must be seeded again, then the ones whose intervals came back */
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
 		n_reseed = C->n_host;
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] < -1 && C->dreg_n[t] != BSX_REGIONS_PENDING) C->hmap[C->n_host++] = t;
 		for (t = 0; t < C->n_tasks; ++t) if (C->dreg_n[t] == BSX_REGIONS_PENDING) ++C->n_pending;
-		if (getenv("BSX_PHASES")) {
+		if (bsx_phases()) {
 			long h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 			for (t = 0; t < C->n_tasks; ++t) ++h[C->dreg_n[t] >= 0 ? 0 : C->dreg_n[t] == BSX_REGIONS_PENDING ? 1 : (-C->dreg_n[t] < 9 ? -C->dreg_n[t] : 9)];
 			fprintf(stderr, "[M::regions] on device %ld | declined: seeding overflow %ld, read length %ld, intervals %ld, occurrences %ld, chains %ld, tied starts %ld, band %ld, regions %ld, output %ld\n",
@@ -1246,7 +1248,7 @@ static int finish_pending(chunk_t *C)
 			else if (C->dreg_n[t] == -1) C->hmap[C->n_host++] = t;
 			else rc = BSX_E_ARG;
 		}
-		if (getenv("BSX_PHASES")) fprintf(stderr, "[M::regions] seeded again on the device: %d strand searches, %d of them left to the host\n", n_list, C->n_host);
+		if (bsx_phases()) fprintf(stderr, "[M::regions] seeded again on the device: %d strand searches, %d of them left to the host\n", n_list, C->n_host);
 		C->st.n_host_tasks += C->n_host;
 		if (rc == BSX_OK) rc = host_path(C, C->n_host, 0, 0);
 	}
@@ -1301,7 +1303,7 @@ static void chunk_free(chunk_t *C)
 	if (bsx_verbose >= 3) {
 		const bsx_phase_stats_t *S = &C->st;
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f real sec (%s)\n", "bsx_process_seqs", C->n, S->t_total, C->be->name ? C->be->name : "?");
-		if (getenv("BSX_PHASES"))
+		if (bsx_phases())
 			fprintf(stderr, "[M::phases] regions %.3f (host tasks %ld) seed %.3f sa %.3f chain %.3f extend %.3f (%ld jobs, %ld rounds) merge %.3f pestat %.3f matesw %.3f primary %.3f cigar %.3f sam %.3f | tasks %ld intv %ld sa %ld sw %ld glb %ld\n",
 				S->t_regions, (long)S->n_host_tasks, S->t_seed, S->t_sa, S->t_chain, S->t_extend, (long)S->n_ext_jobs, (long)S->n_ext_rounds, S->t_merge, S->t_pestat,
 				S->t_matesw, S->t_primary, S->t_cigar, S->t_sam, (long)S->n_tasks, (long)S->n_intv, (long)S->n_sa, (long)S->n_sw_jobs, (long)S->n_glb_jobs);
@@ -1364,7 +1366,7 @@ static void *front_thread(void *arg)
 	/* With the back half on the chunk's own thread as well, back halves of consecutive chunks overlap each other: one
 	 * chunk's serial stretches and waits for its K5/K6 batches are filled with the other's parallel loops (the worker
 	 * pool serves several loops at once).  Chunks still complete in order: the stream joins the threads in order. */
-	if (g_whole_chunk_threads && C->rc == BSX_OK && !bsx_pes_hist_hook) {   /* (ranks sharing a chunk exchange histograms in chunk order: back halves stay on the pushing thread) */
+	if (C->ordered && C->rc == BSX_OK) {   /* (ranks sharing a chunk exchange histograms in chunk order: back halves stay on the pushing thread -- decided at push time) */
 		/* at most g_whole_chunk_threads back halves at a time, started in chunk order */
 		pthread_mutex_lock(&g_back_mu);
 		while (g_back_running >= g_whole_chunk_threads || g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu);
@@ -1376,7 +1378,7 @@ static void *front_thread(void *arg)
 		--g_back_running;
 		pthread_cond_broadcast(&g_back_cv);
 		pthread_mutex_unlock(&g_back_mu);
-	} else if (g_whole_chunk_threads && !bsx_pes_hist_hook) { /* a failed front half: its turn passes */
+	} else if (C->ordered) { /* a failed front half: its turn passes */
 		pthread_mutex_lock(&g_back_mu);
 		while (g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu);
 		++g_back_next;
@@ -1393,7 +1395,7 @@ BSX_API int bsx_stream_open_backends(int depth, const bsx_backend_t *be, const b
 	bsx_stream_t *s;
 	int i;
 	if (!be || !opt || !idx || !out || depth < 1 || depth > STREAM_MAX_DEPTH) return BSX_E_ARG;
-	if (g_whole_chunk_threads < 0) { const char *e = getenv("BSX_STREAM_WHOLE_CHUNK"); g_whole_chunk_threads = e ? atoi(e) : 0; }
+	g_whole_chunk_threads = (int)bsx_tune_long("stream_whole_chunk", 0);
 	s = (bsx_stream_t*)calloc(1, sizeof(*s));
 	for (i = 0; i < depth; ++i) s->be[i] = be[i];
 	s->depth = depth; s->opt = opt; s->idx = idx;
@@ -1427,7 +1429,7 @@ static int chunk_finish(chunk_t *C)
 	rc = C->rc;
 	if (rc == BSX_OK && !C->back_done) rc = chunk_back(C);
 	t2 = now_s();
-	if (getenv("BSX_PHASES")) fprintf(stderr, "[M::stream] chunk begun at %.3f: front half %.3f s (prep %.3f, device pass %.3f), waited %.3f s for it from %.3f, back half %.3f s until %.3f\n",
+	if (bsx_phases()) fprintf(stderr, "[M::stream] chunk begun at %.3f: front half %.3f s (prep %.3f, device pass %.3f), waited %.3f s for it from %.3f, back half %.3f s until %.3f\n",
 	                                  C->t_begin, C->t_front_end - C->t_begin, C->st.t_prep, C->st.t_regions, t1 - t0, t0, t2 - t1, t2);
 	chunk_free(C);
 	return rc;
@@ -1443,9 +1445,12 @@ BSX_API int bsx_stream_push(bsx_stream_t *s, int64_t n_processed, int n, bsx_rea
 	if (n > 0) {
 		chunk_t *C = chunk_new(&s->be[s->n_pushed % s->depth], s->opt, s->idx, n_processed, n, reads, s->has_pes0 ? &s->pes0 : 0);
 		++s->n_pushed;
-		pthread_mutex_lock(&g_back_mu); C->seq = g_back_seq++; pthread_mutex_unlock(&g_back_mu);
+		/* a ticket only for the chunks that take a turn: a chunk pushed while the histogram hook is set (or without $BSX_STREAM_WHOLE_CHUNK)
+		 * never advances g_back_next, so handing it a number would leave every later ordered chunk waiting for a turn that never comes */
+		C->ordered = g_whole_chunk_threads > 0 && !bsx_pes_hist_hook;
+		if (C->ordered) { pthread_mutex_lock(&g_back_mu); C->seq = g_back_seq++; pthread_mutex_unlock(&g_back_mu); }
 		if (pthread_create(&C->th, 0, front_thread, C) == 0) C->th_live = 1;
-		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); if (g_whole_chunk_threads && !bsx_pes_hist_hook) { pthread_mutex_lock(&g_back_mu); while (g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu); ++g_back_next; pthread_cond_broadcast(&g_back_cv); pthread_mutex_unlock(&g_back_mu); } }
+		else { C->rc = chunk_front(C); bsx_arenas_bind(-1); if (C->ordered) { pthread_mutex_lock(&g_back_mu); while (g_back_next != C->seq) pthread_cond_wait(&g_back_cv, &g_back_mu); ++g_back_next; pthread_cond_broadcast(&g_back_cv); pthread_mutex_unlock(&g_back_mu); } }
 		s->q[s->n_q++] = C;
 	}
 	while (s->n_q > (n > 0 ? s->depth - 1 : 0) && rc == BSX_OK) { /* complete the oldest: its lane is the next push's */

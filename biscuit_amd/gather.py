@@ -44,6 +44,7 @@ class ChunkGather:
         self.header = b""             # rank 0, direct form: the SAM header (set by the producer before its first chunk)
         self.bytes_written = 0        # direct form: bytes this rank wrote itself
         self._dead = False            # set when the gather has ended: late producers (another rank failed) are not blocked
+        self.failed = False           # direct form: this rank could not open / write the file; it still takes part in every round
 
     # ---- producer side -------------------------------------------------------------------------------------------
     def submit(self, chunk_index, data):
@@ -231,22 +232,33 @@ class ChunkGather:
         return n_chunks
 
     def _run_direct(self):
-        """the rounds of run() with the sizes alone: every rank writes its own chunk at header + (bytes of all chunks before it)"""
+        """the rounds of run() with the sizes alone: every rank writes its own chunk at header + (bytes of all chunks before it).
+        A rank that cannot open or write the file (ENOSPC, a target that is not seekable ...) says so once, sets `failed` and keeps taking
+        part in the size exchanges: the other ranks are inside the same collectives, and the launcher's MAX-reduced exit status reports it."""
         import os
+        import sys
         r = 0
         n_chunks = 0
         base = 0
         fd = -1
+
+        def fail(what, e):
+            if not self.failed:
+                sys.stderr.write("[E::gather] rank %d: %s %s failed: %r\n" % (self.rank, what, self.direct_path, e))
+            self.failed = True
         try:
             while True:
                 mine = self._next_own(r * self.world + self.rank)
                 n = len(mine) if mine is not None else 0
                 hdr = 0
                 if r == 0 and self.rank == 0:   # the file exists, with its header, before anybody learns the header's length
-                    fd = os.open(self.direct_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
                     hdr = len(self.header)
-                    if hdr:
-                        os.pwrite(fd, bytes(self.header), 0)
+                    try:
+                        fd = os.open(self.direct_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                        if hdr:
+                            os.pwrite(fd, bytes(self.header), 0)
+                    except OSError as e:
+                        fail("opening", e)
                 meta = torch.tensor([1 if mine is not None else 0, n, hdr], dtype=torch.int64, device=self.device)
                 metas = [torch.zeros(3, dtype=torch.int64, device=self.device) for _ in range(self.world)]
                 dist.all_gather(metas, meta)
@@ -254,14 +266,20 @@ class ChunkGather:
                 if r == 0:
                     base = metas[0][2]
                     if self.rank != 0:
-                        fd = os.open(self.direct_path, os.O_WRONLY)
+                        try:
+                            fd = os.open(self.direct_path, os.O_WRONLY)
+                        except OSError as e:
+                            fail("opening", e)
                 off = base + sum(nb for has, nb, _ in metas[:self.rank] if has)
-                if mine is not None and n:
+                if mine is not None and n and not self.failed:
                     view = memoryview(mine)
                     done = 0
-                    while done < n:
-                        done += os.pwrite(fd, view[done:], off + done)
-                    self.bytes_written += n
+                    try:
+                        while done < n:
+                            done += os.pwrite(fd, view[done:], off + done)
+                        self.bytes_written += n
+                    except OSError as e:
+                        fail("writing", e)
                 base += sum(nb for has, nb, _ in metas if has)
                 n_chunks += sum(1 for has, _, _ in metas if has)
                 self.rounds += 1
@@ -271,5 +289,29 @@ class ChunkGather:
         finally:
             self._dead = True
             if fd >= 0:
-                os.close(fd)
+                try:
+                    os.close(fd)
+                except OSError as e:
+                    fail("closing", e)
         return n_chunks
+
+
+def direct_output_ok(path, world, env=None):
+    """May every rank write its own chunks into `path` (ChunkGather(direct_path=...))?  Only when all ranks are on one node -- they must see
+    the same file -- and the target is (or will be created as) a regular file: pwrite() at offsets needs a seekable file, which /dev/stdout,
+    a FIFO or a character device is not.  The answer is the same on every rank of a one-node job."""
+    import os
+    import stat
+    env = os.environ if env is None else env
+    try:
+        if int(env.get("LOCAL_WORLD_SIZE", "0")) != int(world):
+            return False
+    except ValueError:
+        return False
+    try:
+        st = os.stat(path)
+    except FileNotFoundError:
+        return os.path.isdir(os.path.dirname(os.path.abspath(path)))
+    except OSError:
+        return False
+    return stat.S_ISREG(st.st_mode)

@@ -87,7 +87,11 @@ def main(argv=None, entry=None, use_gpu=True):
         pes_hook = PES(pes_sum)
         C.c_void_p.in_dll(L, "bsx_pes_hist_hook").value = C.cast(pes_hook, C.c_void_p).value
 
-    direct = out_path if (out_path and world > 1 and not via_rank0) else None
+    # every rank writing its own chunks needs one node (one file system) and a seekable regular file: anything else goes through rank 0
+    from .gather import direct_output_ok
+    direct = out_path if (out_path and world > 1 and not via_rank0 and direct_output_ok(out_path, world)) else None
+    if out_path and world > 1 and not via_rank0 and not direct and rank == 0:
+        sys.stderr.write("[M::multi_gpu] %s: not a regular file on a single node -- the records go through rank 0\n" % out_path)
     out = None
     if rank == 0 and not direct:
         out = open(out_path, "wb") if out_path else sys.stdout.buffer
@@ -141,7 +145,7 @@ def main(argv=None, entry=None, use_gpu=True):
     th.start()
     G.run()
     th.join()
-    rc = rc_box[0] or failed[0]
+    rc = rc_box[0] or failed[0] or (1 if G.failed else 0)
     if world > 1:
         t = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -295,10 +295,27 @@ typedef struct bsx_glb_tag {
 int bsx_global_batch_tags(bsx_device_t *dev, int64_t n, const bsx_glb_job_t *jobs, bsx_glb_res_t *res,
                           uint32_t *cigar_pool, size_t cigar_pool_len, bsx_glb_tag_t *tags, char **md, int64_t *md_cap);
 
+/* Settings of the library that never change its output (launch shapes, table sizes, which of two equivalent paths runs: what the tests and
+ * the A/B tools switch).  One registry (csrc/host/tune.c has the table of names): bsx_tune_set(name, value) between calls of the library
+ * (value NULL: back to the default; BSX_E_ARG for an unknown name), or "$BSX_TUNE=name=value,name=value" for a whole process.  bsx_phases():
+ * the diagnostic level ($BSX_PHASES or the setting "phases"). */
+int bsx_tune_set(const char *name, const char *value);
+const char *bsx_tune_str(const char *name);
+long bsx_tune_long(const char *name, long dflt);
+int bsx_tune_is_set(const char *name);
+int bsx_phases(void);
+const char *bsx_tune_name(int i);
+const char *bsx_tune_doc(int i);
+
 /* device-side work counters of the last seed/sa batch (algorithmic-bytes model):
  * c[0]=bwt_occ4 calls, c[1]=same-block bwt_2occ4 calls, c[2]=bwt_occ calls (inside bwt_sa, from k_sa and
  * from the region kernels), c[3]=bwt_sa calls */
 int bsx_device_counters(bsx_device_t *dev, uint64_t c[4], int reset);
+/* the seeding passes of bsx_regions_batch one by one, since the last reset (read it BEFORE bsx_device_counters / bsx_device_seed_table with
+ * reset: they zero the same counters): w[0], w[1] = 64-byte FM blocks and table entries read by the chunk-wide first pass (and bsx_seed_batch
+ * launches), w[2], w[3] = by the second pass over the strand searches seeded again inside a chunk's launch sequence, w[4] = its launches,
+ * w[5] = its strand searches; ms[0], ms[1] = the two passes' summed HIP-event times.  (Each pass's bytes over that pass's time: bench.py) */
+int bsx_device_seed_passes(bsx_device_t *dev, uint64_t w[6], double ms[2], int reset);
 /* Several GPUs sharing ONE chunk: each process aligns a slice of the chunk's pairs.  Two things tie a read to its chunk:
  * mem_pestat (bwamem.c:464-467), whose result is a function of the chunk's histogram of insert sizes -- bsx_pes_hist_hook, when set, is
  * called with this process's histogram (2 * max_ins + 1 counters) and must return the sum over all processes in place (an all-reduce;

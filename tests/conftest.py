@@ -34,3 +34,17 @@ def device(small_index):
     dev = Device(0)   # raises loudly when there is no HIP device
     dev.upload_index(small_index)
     return dev
+
+
+@pytest.fixture
+def tune():
+    """set settings of the library (biscuit_amd/csrc/host/tune.c) for the length of a test: tune(name, value)"""
+    from biscuit_amd import _lib as B
+    names = []
+
+    def set_(name, value):
+        names.append(name)
+        B.tune(name, value)
+    yield set_
+    for n in names:
+        B.tune(n, None)

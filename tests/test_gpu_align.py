@@ -14,8 +14,9 @@ CPU = os.path.join(ROOT, "oracle", "oracle_align")
 
 
 def run(exe, args, cwd, env=None, want_stderr=False):
+    from biscuit_amd._lib import tune_env
     e = dict(os.environ)
-    e.update(env or {})
+    e.update(tune_env(env or {}))   # the library's settings (BSX_POS_CAP -> pos_cap ...) travel in one variable, $BSX_TUNE
     p = subprocess.run([exe] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=e)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     sam = b"\n".join(l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG"))
@@ -64,6 +65,9 @@ CASES = [
     # options the device chaining/extension pass reads: occurrence cap, chain filter knobs, strand restriction, band, clip penalties
     ("pe150_chain_knobs", ["-@", "4", "-c", "12", "-D", "0.3", "-W", "25", "-m", "30", "-G", "4000", "g", "b1.fq", "b2.fq"]),
     ("se150_bsstrand_band", ["-@", "4", "-f", "1", "-w", "12", "-L", "0,9", "-r", "1.2", "-y", "30", "g", "b1.fq"]),
+    # scores beyond the packed 16-bit seed filter's range (199 columns x 170 > 2^15): launch_seedsw leaves its job list empty and every
+    # seed of the filter is aligned in 32-bit arithmetic
+    ("long_1kb_big_scores", ["-@", "4", "-A", "170", "g", "long.fq"]),
 ]
 
 
@@ -160,7 +164,7 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
         seen = set()
         for max_occ in (500, 8):   # 8: most repeat seeds are over-represented, the first-max_occ visiting rule (memchain.c:325-326) runs on the device
             opt.max_occ = max_occ
-            os.environ.pop("BSX_HOST_CHAIN", None)
+            B.tune("host_chain", None)
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
             ps = B.PhaseStats()
             L.bsx_last_phase_stats(C.byref(ps))
@@ -170,21 +174,21 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
             assert ps.n_host_tasks < 200, (max_occ, ps.n_host_tasks)
             a = crc()
             L.bsx_sim_reset_reads(p, 2 * n_pairs)
-            os.environ["BSX_HOST_CHAIN"] = "1"
+            B.tune("host_chain", "1")
             B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
             L.bsx_last_phase_stats(C.byref(ps))
             assert ps.n_host_tasks == ps.n_tasks
             assert crc() == a, max_occ
             L.bsx_sim_reset_reads(p, 2 * n_pairs)
-            os.environ.pop("BSX_HOST_CHAIN", None)
+            B.tune("host_chain", None)
             # strand searches whose interval lists overflow are seeded again on a side stream with longer lists; a short
             # first-pass list sends ordinary reads down that path, collected before the front half returns or (async) by
             # regions_finish at the start of the back half
-            # -- or, when there are many of them (round 5), seeded again inside the chunk's one launch sequence ($BSX_REDO_MERGE_MIN: from how many)
-            os.environ["BSX_SEED_MEM_CAP"] = "28"
+            # -- or, when there are many of them (round 5), seeded again inside the chunk's one launch sequence (the setting redo_merge_min: from how many)
+            B.tune("seed_mem_cap", "28")
             for merge_min, asy in (("1000000000", "0"), ("1000000000", "1"), ("1", "0")):
-                os.environ["BSX_ASYNC_REDO"] = asy
-                os.environ["BSX_REDO_MERGE_MIN"] = merge_min
+                B.tune("async_redo", asy)
+                B.tune("redo_merge_min", merge_min)
                 B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "process_seqs")
                 L.bsx_last_phase_stats(C.byref(ps))
                 assert crc() == a, (max_occ, merge_min, asy)
@@ -194,14 +198,14 @@ def test_device_regions_equal_host_chaining_repeat_rich(tmp_path):
                 if merge_min == "1":
                     assert ps.n_redo_tasks == 0
                 L.bsx_sim_reset_reads(p, 2 * n_pairs)
-            os.environ.pop("BSX_SEED_MEM_CAP", None)
-            os.environ.pop("BSX_ASYNC_REDO", None)
-            os.environ.pop("BSX_REDO_MERGE_MIN", None)
+            B.tune("seed_mem_cap", None)
+            B.tune("async_redo", None)
+            B.tune("redo_merge_min", None)
             seen.add(a)
         assert len(seen) == 2   # the cap does change the alignments
     finally:
-        for k in ("BSX_HOST_CHAIN", "BSX_SEED_MEM_CAP", "BSX_ASYNC_REDO", "BSX_REDO_MERGE_MIN"):
-            os.environ.pop(k, None)
+        for k in ("host_chain", "seed_mem_cap", "async_redo", "redo_merge_min"):
+            B.tune(k, None)
         L.bsx_sim_free_reads(p, 2 * n_pairs)
         dev.close()
         idx.close()

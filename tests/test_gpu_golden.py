@@ -44,12 +44,12 @@ def _opt(a, b, gp, zdrop=100):
 
 
 @pytest.mark.parametrize("form", ["wavefront_per_job", "quarter_wave_per_job", "lane_per_job"])
-def test_extend_kernel_vs_reference_vectors(V, tmp_path, form, monkeypatch):
+def test_extend_kernel_vs_reference_vectors(V, tmp_path, form, tune):
     """ksw_extend2 vectors recorded from the reference against k_extend (a wavefront per job, rows in LDS) and against k_ext4
     (k_ext4.hip: a row of 16 lanes per job, the form the regions path runs; it holds queries up to 255 bases)"""
     quarter = form != "wavefront_per_job"
     if quarter:      # "2": then k_extl (a lane per job) over the same jobs, its answers replacing k_ext4's
-        monkeypatch.setenv("BSX_EXT4", "1" if form == "quarter_wave_per_job" else "2")
+        tune("ext4", "1" if form == "quarter_wave_per_job" else "2")
     idx, start = _genome_of_targets(str(tmp_path), "ext", V["ext_t"], V["ext_toff"])
     dev = Device(0); dev.upload_index(idx)
     qo = V["ext_qoff"]

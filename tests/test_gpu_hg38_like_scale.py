@@ -50,7 +50,7 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
     opt.n_threads = 16
     opt.flag |= 0x10 | 0x2
     opt.max_occ = max_occ
-    os.environ["BSX_PHASES"] = "1"
+    B.tune("phases", "1")
     try:
         capfd.readouterr()
         hip, cpu = _run_both(hard, opt, p, n)
@@ -64,7 +64,7 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
         mapped = np.mean([not (int(s.split(b"\t")[1]) & 4) for s in hip])
         assert mapped > 0.9, mapped
     finally:
-        os.environ.pop("BSX_PHASES", None)
+        B.tune("phases", None)
         L.bsx_sim_free_reads(p, n)
 
 

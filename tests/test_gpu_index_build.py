@@ -2,7 +2,7 @@
 against the host builder (SA-IS, csrc/host/index.c), whose files the reference's own bwt_restore_*/bwt_cal_sa/is_bwt
 accept and reproduce (tests/test_oracle_vs_ref.py).  BWT and suffix array of a text are unique: the seven files must be
 byte-identical.  Genomes are chosen to reach every branch of the sorter: several batches and slices (small
-$BSX_INDEX_BATCH), many doubling rounds (long exact repeats, tandem repeats, homopolymers), ties that run into the end
+the setting index_batch), many doubling rounds (long exact repeats, tandem repeats, homopolymers), ties that run into the end
 of the text (the sentinel rule), N runs, several contigs."""
 import filecmp
 import os
@@ -17,10 +17,11 @@ FILES = [".par.bwt", ".par.sa", ".dau.bwt", ".dau.sa", ".bis.pac", ".bis.ann", "
 
 
 def _both(tmp, fasta, env=None):
+    from biscuit_amd import _lib as B_
     old = {}
-    for k, v in (env or {}).items():
-        old[k] = os.environ.get(k)
-        os.environ[k] = v
+    for k, v in (env or {}).items():   # settings of the library (csrc/host/tune.c), for the length of the call
+        old[k] = None
+        B_.tune(k, v)
     try:
         Index.build(fasta, tmp + "/host").close()
         idx = Index.from_fasta(fasta)
@@ -30,11 +31,8 @@ def _both(tmp, fasta, env=None):
         dev.close()
         idx.close()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in old:
+            B_.tune(k, None)
     for ext in FILES:
         assert filecmp.cmp(tmp + "/host" + ext, tmp + "/dev" + ext, shallow=False), "file %s differs" % ext
 
@@ -46,7 +44,7 @@ def test_golden_fasta(tmp_path):
 def test_repeats_and_n_runs_many_batches(tmp_path):
     d = str(tmp_path)
     simdata.write_genome(d + "/g.fa", simdata.make_genome(1500000, seed=77, n_contigs=3))
-    _both(d, d + "/g.fa", {"BSX_INDEX_BATCH": "50000"})   # dozens of batches in round 0, slices in the later rounds
+    _both(d, d + "/g.fa", {"index_batch": "50000"})   # dozens of batches in round 0, slices in the later rounds
 
 
 def _write(fa, contigs):
@@ -68,7 +66,7 @@ def test_deep_repeats_and_sentinel_ties(tmp_path):
     c2 = "G" * 77 + rnd(1000) + "GATTACA" * 1500 + rnd(500) + "C" * 2100 + "T" * 31
     d = str(tmp_path)
     _write(d + "/g.fa", [("c1", c1), ("c2", c2)])
-    _both(d, d + "/g.fa", {"BSX_INDEX_BATCH": "30000"})
+    _both(d, d + "/g.fa", {"index_batch": "30000"})
     _both(d, d + "/g.fa")
 
 

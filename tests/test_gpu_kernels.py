@@ -69,23 +69,23 @@ def test_seed_and_sa_match_oracle(small_index, port, device):
     assert depth >= 8 and looks > 0 and dc[0] + dc[1] < 0.7 * (pc[0] + pc[1]), (pc, dc, looks, depth)
     # the same lists from every table depth (0: none, every step an FM extension) and from the kernel without the table,
     # whose FM-block touches are the reference's own (the algorithmic-bytes figure of SURVEY 8(d))
-    import os
+    from biscuit_amd import _lib as B_
     try:
         for k in (0, 2, 5, depth - 1):
-            os.environ["BSX_SEED_TAB_K"] = str(k)
+            B_.tune("seed_tab_k", k)
             device.upload_index(small_index)
             assert device.seed_table()[1] == k
             di, do = device.seed(opt, tasks)
             assert (po == do).all() and (pi == di).all(), k
-        os.environ["BSX_SEED_FORM"] = "classic"
+        B_.tune("seed_form", "classic")
         device.counters(reset=True)
         di, do = device.seed(opt, tasks)
         assert (po == do).all() and (pi == di).all()
         dc = device.counters()
         assert pc[0] == dc[0] and pc[1] == dc[1], (pc, dc)
     finally:
-        os.environ.pop("BSX_SEED_TAB_K", None)
-        os.environ.pop("BSX_SEED_FORM", None)
+        B_.tune("seed_tab_k", None)
+        B_.tune("seed_form", None)
         device.upload_index(small_index)
     assert device.seed_table()[1] == depth
     # K3 on every occurrence the chaining step would look up (capped like memchain.c:325)
@@ -141,9 +141,9 @@ def _rand_ext_jobs(small_index, seqs, offs, rng, n, long_band=False):
 
 
 @pytest.mark.parametrize("form", ["wavefront_per_job", "quarter_wave_per_job", "lane_per_job"])
-def test_extend_matches_oracle(small_index, port, device, form, monkeypatch):
+def test_extend_matches_oracle(small_index, port, device, form, tune):
     if form != "wavefront_per_job":      # the rows of 16 lanes the regions path extends with (k_ext4.hip), on plain jobs; "2": then the lane-per-job
-        monkeypatch.setenv("BSX_EXT4", "1" if form == "quarter_wave_per_job" else "2")   # kernel (k_extl.hip) over the same jobs, its answers replacing the others'
+        tune("ext4", "1" if form == "quarter_wave_per_job" else "2")   # kernel (k_extl.hip) over the same jobs, its answers replacing the others'
     opt = default_opt()
     rng = np.random.default_rng(11)
     seqs = _reads(small_index, n_pairs=200, read_len=150, seed=12)
@@ -184,14 +184,14 @@ def test_extend_matches_oracle(small_index, port, device, form, monkeypatch):
 
 
 @pytest.mark.parametrize("form", ["quarter_wave_per_job", "lane_per_job"])
-def test_extend_narrow_jobs_quarter_wave(small_index, port, device, monkeypatch, form, capfd):
+def test_extend_narrow_jobs_quarter_wave(small_index, port, device, tune, form, capfd):
     """k_ext4 (k_ext4.hip: a row of 16 lanes per job) on the jobs the regions path is full of -- extensions from chance matches of
     19..26 bases: scores that decay, bands of a dozen columns, queries of any length, both directions and strands, targets on either side of
     the forward-reverse boundary, a few real continuations (the read's own locus) that run past the 48 rows of reference bases a row holds --
     against the CPU restatement job by job.  lane_per_job: k_extl (k_extl.hip: a lane per job, the row a window of 64 columns in registers), which
     has to answer most of them itself."""
     import re
-    monkeypatch.setenv("BSX_EXT4", "1" if form == "quarter_wave_per_job" else "2")
+    tune("ext4", "1" if form == "quarter_wave_per_job" else "2")
     opt = default_opt()
     rng = np.random.default_rng(77)
     seqs = _reads(small_index, n_pairs=300, read_len=150, seed=13)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone kernel times of one unpipelined chunk of the bench workload under different environments, the index built once:
-   python tools/chunk_ab.py [--genome-mbp 3100] [--profile 0|1] "" "BSX_SEED_DIRECT=0" ...   (knobs read per call only)"""
+   python tools/chunk_ab.py [--genome-mbp 3100] [--profile 0|1] "" "seed_direct=0" "tier1c=0 x4=0" ...   (settings of the library, csrc/host/tune.c; anything else is set as an environment variable)"""
 import argparse
 import ctypes as C
 import os
@@ -43,8 +43,13 @@ def main():
     import time
     for cfg in a.cfgs:
         kv = dict(x.split("=", 1) for x in cfg.split())
-        for k, v in kv.items():
-            os.environ[k] = v
+        names = set(B.tune_names())
+        for k, v in kv.items():   # a setting of the library (name or the BSX_NAME it was as an environment variable), else a real environment variable
+            low = k[4:].lower() if k.startswith("BSX_") else k.lower()
+            if low in names:
+                B.tune(low, v)
+            else:
+                os.environ[k] = v
         for k in range(8):
             dev.kernel_time(k, reset=True)
         t0 = time.time()
@@ -61,7 +66,11 @@ def main():
         dt = (time.time() - t0) / a.reps
         print("%-50s %s | chunk %.0f ms" % (cfg or "(defaults)", " ".join("%s %.1f" % (names[k], dev.kernel_time(k)[0] / a.reps) for k in range(8)), dt * 1e3) + (" | sam crc %08x" % crc if crc is not None else ""), flush=True)
         for k in kv:
-            os.environ.pop(k, None)
+            low = k[4:].lower() if k.startswith("BSX_") else k.lower()
+            if low in names:
+                B.tune(low, None)
+            else:
+                os.environ.pop(k, None)
 
 
 if __name__ == "__main__":

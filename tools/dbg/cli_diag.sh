@@ -1,6 +1,6 @@
 #!/bin/bash
 # the command line on the hg38-like genome with the stream's per-chunk phase lines: where a chunk's time goes between FASTQ text and SAM text
-# usage: tools/dbg/cli_diag.sh "" "BSX_STREAM_WHOLE_CHUNK=2" ...   (one run per configuration, same files)
+# usage: tools/dbg/cli_diag.sh "" "BSX_TUNE=stream_whole_chunk=2" ...   (one run per configuration, same files)
 cd /root/repo
 i=0
 for cfg in "$@"; do

@@ -15,7 +15,7 @@ def run(env):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     return [l for l in p.stdout.decode().split("\n") if not l.startswith("@")], p.stderr.decode()
 a, ea = run({"BSX_PHASES": "1"})
-b, eb = run({"BSX_HOST_CHAIN": "1"})
+b, eb = run({"BSX_TUNE": "host_chain=1"})
 print([l for l in ea.split("\n") if "M::regions]" in l][:3])
 nd = 0
 for x, y in zip(a, b):

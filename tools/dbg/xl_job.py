@@ -4,6 +4,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
 import simdata, oracle_lib
 from biscuit_amd.api import Index, Device, default_opt, EXT_DT
+from biscuit_amd import _lib as B
 d = "/tmp/xlchk"
 contigs = simdata.make_genome(1000000, seed=21, n_contigs=3)
 p100 = simdata.make_pairs(contigs, 5000, 100, 1, frag=(180, 320), sub=0.005)
@@ -26,7 +27,7 @@ for par in (0, 1):
     right = np.array([(rbeg + ln, offs[k] + qb + ln, 100 - qb - ln, 100 - qb - ln + gap(100 - qb - ln), int(pl[k]["score"]), 100, 10, 1, 1, par, 0) for k, (t, rbeg, qb, ln) in enumerate(cases)], dtype=EXT_DT)
     pr = port.extend(right)
     for mode in ("1", "2"):
-        os.environ["BSX_EXT4"] = mode
+        B.tune("ext4", mode)
         dl, dr = dev.extend(left), dev.extend(right)
         print("parent", par, "mode", mode, "left bad", int((pl != dl).sum()), "right bad", int((pr != dr).sum()))
         for i in np.nonzero(pr != dr)[0][:4]:

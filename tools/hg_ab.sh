@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of environment settings on the headline workload (hg38-like genome, pipelined stream): tools/hg_ab.sh "" "BSX_STREAM_WHOLE_CHUNK=1" ...
+# A/B of settings on the headline workload (hg38-like genome, pipelined stream): tools/hg_ab.sh "" "BSX_TUNE=stream_whole_chunk=1" "BSX_TUNE=tier1c=0,x4=0 BSX_STREAM_DEPTH=5" ...
+# (the library's settings travel in $BSX_TUNE, csrc/host/tune.c; BSX_STREAM_DEPTH / BSX_HOST_THREADS are environment variables of their own)
 # One bench process per configuration (index built each time: ~30 s); prints reads/s, ms per step, the push thread's time and the host's CPU seconds.
 cd "$(dirname "$0")/.."
 for cfg in "$@"; do

@@ -32,11 +32,9 @@ def crc():
     return c
 out = []
 for host, asy, hdd in ((0, 1, 0), (0, 0, 0), (0, 0, 1), (1, 0, 0)):
-    if host: os.environ["BSX_HOST_CHAIN"] = "1"
-    else: os.environ.pop("BSX_HOST_CHAIN", None)
-    if hdd: os.environ["BSX_HOST_DEDUP"] = "1"
-    else: os.environ.pop("BSX_HOST_DEDUP", None)
-    os.environ["BSX_ASYNC_REDO"] = str(asy)
+    B.tune("host_chain", "1" if host else None)
+    B.tune("host_dedup", "1" if hdd else None)
+    B.tune("async_redo", str(asy))
     t = time.time()
     B.check(L.bsx_process_seqs(dev.h, C.byref(opt), idx.h, 0, 2 * n_pairs, p, None), "ps")
     dt = time.time() - t
