@@ -101,4 +101,10 @@ void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, u
 // C5 (k_dedup.hip): mem_sort_deduplicate of every read over the regions of the chunk, a lane per read
 int dedup_cap(void);
 void launch_dedup(hipStream_t st, const bsx_region_t *regs, const long long *reg_off, const int *reg_n, int n_reads, int per_read,
-                  long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, int *out_n, unsigned char *out_idx);
+                  long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, int *out_n, unsigned char *out_idx,
+                  int *long_list = nullptr, unsigned int *long_count = nullptr);   // long_list (2 x n_reads ints) / long_count (2 counters, zeroed): the reads k_dedup_long takes
+// ... and a wavefront per read for the reads with more regions than that (up to dedup_long_cap()): 16-bit indices, one list behind the other in pool
+int dedup_long_cap(void);
+void launch_dedup_long(hipStream_t st, int n_cu, const bsx_region_t *regs, const long long *reg_off, const int *reg_n, int n_reads, int per_read,
+                       long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, const int *long_list, const unsigned int *long_count,
+                       int *out_n, long long *out_off, unsigned short *pool, unsigned long long pool_cap, unsigned long long *pool_cursor);

@@ -53,6 +53,7 @@ struct Lane {
 	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t work[5] = {0, 0, 0, 0, 0};   // the region kernels' work since the last reset: strand searches, SA intervals, occurrences, regions, read bases
+	std::mutex hi_mu;      // the back half's batches (K5, K6) of this lane, one at a time: the slices of a chunk's back half call them from two threads
 	long last_overflow = -1;   // strand searches the first seeding pass of this lane's last chunk left to the second (-1: no chunk yet)
 	double seed2_ms = 0; int64_t seed2_launches = 0; uint64_t seed2_tasks = 0;   // the second seeding pass inside the chunk's sequence (its own launch, its own counters: SEED2_CTR)
 };
@@ -1381,6 +1382,7 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
+	std::lock_guard<std::mutex> hi_lock(L.hi_mu);
 	HIPCHK(hipSetDevice(d->ordinal));
 	// byte-sized jobs (KSW_XBYTE, queries of up to 256 columns: mate rescue of ordinary reads) go four to a wavefront through the striped
 	// kernel (k_swl.hip), ordered by stripe count and then by target length, longest first, so that the four jobs of a wavefront are alike;
@@ -1449,7 +1451,8 @@ static int lane_sw_batch(bsx_device_t *d, int lane, int64_t n, const bsx_sw_job_
 // ------------------------------------------------------------------------------------------
 // C5 over the regions of the last regions batch of this lane
 // ------------------------------------------------------------------------------------------
-static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx)
+static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx,
+                              int64_t *long_off = nullptr, uint16_t **long_idx = nullptr, int64_t *long_cap = nullptr)
 {
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
 	if (!opt || !out_n || !out_idx || per_read < 1) return BSX_E_ARG;
@@ -1460,13 +1463,39 @@ static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int rc;
 	const int64_t n = L.rb_tasks;
 	const size_t cap = (size_t)dedup_cap();
-	if ((rc = L.dd.reserve((size_t)n_reads * (4 + cap) + 64)) != BSX_OK) return rc;
+	// the reads with more regions than a lane of k_dedup holds (long_off given): a wavefront each (k_dedup_long), their lists of 16-bit indices
+	// one behind the other in a pool with room for every region the main sequence made
+	const bool with_long = long_off && long_idx && long_cap && per_read <= 4 && bsx_tune_long("long_dedup", 1) != 0;
+	const size_t pool_cap = with_long ? (size_t)L.rs.used_main + 64 : 0;
+	// layout of L.dd: counts | short lists | [long: class lists (2 n_reads ints) | offsets (n_reads i64) | 2 counters + cursor (16 B) | pool]
+	const size_t o_idx = (size_t)n_reads * 4, o_list = (o_idx + (size_t)n_reads * cap + 15) & ~(size_t)15, o_off = o_list + (size_t)n_reads * 8, o_ctr = o_off + (size_t)n_reads * 8, o_pool = o_ctr + 16;
+	if ((rc = L.dd.reserve(with_long ? o_pool + pool_cap * 2 + 64 : o_idx + (size_t)n_reads * cap + 64)) != BSX_OK) return rc;
 	const long long *r_off = (const long long*)L.regmeta.p; const int *r_n = (const int*)((const char*)L.regmeta.p + (size_t)n * 8);
-	int *d_n = (int*)L.dd.p; unsigned char *d_idx = (unsigned char*)L.dd.p + (size_t)n_reads * 4;
-	launch_dedup(L.st, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun, d_n, d_idx);
+	int *d_n = (int*)L.dd.p; unsigned char *d_idx = (unsigned char*)L.dd.p + o_idx;
+	int *d_list = with_long ? (int*)((char*)L.dd.p + o_list) : nullptr;
+	long long *d_off = (long long*)((char*)L.dd.p + o_off);
+	unsigned int *d_cnt = with_long ? (unsigned int*)((char*)L.dd.p + o_ctr) : nullptr;
+	if (with_long) {
+		HIPCHK(hipMemsetAsync(d_cnt, 0, 16, L.st));
+		HIPCHK(hipMemsetAsync(d_off, 0xff, (size_t)n_reads * 8, L.st));   // -1: the read's list (if it has one) is among the short ones
+	}
+	launch_dedup(L.st, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun, d_n, d_idx, d_list, d_cnt);
+	if (with_long)
+		launch_dedup_long(L.st, d->n_cu, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun,
+		                  d_list, d_cnt, d_n, d_off, (unsigned short*)((char*)L.dd.p + o_pool), (unsigned long long)pool_cap, (unsigned long long*)(d_cnt + 2));
 	HIPCHK(hipGetLastError());
 	D2H(L.st, out_n, d_n, (size_t)n_reads * 4);
 	D2H(L.st, out_idx, d_idx, (size_t)n_reads * cap);
+	if (with_long) {
+		unsigned int hc[4];
+		D2H(L.st, hc, d_cnt, 16);
+		unsigned long long used = (unsigned long long)hc[2] | (unsigned long long)hc[3] << 32;
+		if (used > pool_cap) used = pool_cap;   // (lists that found no room left their reads to the caller)
+		D2H(L.st, long_off, d_off, (size_t)n_reads * 8);
+		if (*long_cap < (int64_t)used + 16) { *long_cap = (int64_t)used + (int64_t)(used >> 2) + 1024; *long_idx = (uint16_t*)realloc(*long_idx, (size_t)*long_cap * 2); }
+		if (used) D2H(L.st, *long_idx, (char*)L.dd.p + o_pool, (size_t)used * 2);
+		if (bsx_phases()) fprintf(stderr, "[M::regions_dedup] a wavefront per read: %u reads of up to 256 regions, %u of up to %d; %llu regions kept\n", hc[0], hc[1], dedup_long_cap(), used);
+	} else if (long_off) for (int64_t i = 0; i < n_reads; ++i) long_off[i] = -1;
 	return BSX_OK;
 }
 
@@ -1479,6 +1508,7 @@ static int lane_global_batch(bsx_device_t *d, int lane, int64_t n, const bsx_glb
 	if (!d || !d->has_index) return BSX_E_NODEVICE;
 	Lane &L = d->lane[lane];
 	if (n == 0) return BSX_OK;
+	std::lock_guard<std::mutex> hi_lock(L.hi_mu);
 	HIPCHK(hipSetDevice(d->ordinal));
 	// the last class: queries of any length with their rows in HBM (as lane_extend_batch); a band above 2048 columns stays out of reach
 	static const int QCAP[4] = {256, 1024, 16384, 0x7fffffff}, BAND[4] = {256, 1024, 2048, 2048}, NCS[4] = {4, 16, 32, 32}, WPB[4] = {4, 4, 1, 1};
@@ -1587,6 +1617,10 @@ extern "C" BSX_API int bsx_regions_finish(bsx_device_t *d, bsx_region_t **out, i
 extern "C" BSX_API int bsx_regions_dedup_cap(void) { return dedup_cap(); }
 extern "C" BSX_API int bsx_regions_dedup(bsx_device_t *d, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx)
 { return lane_regions_dedup(d, 0, opt, n_reads, per_read, out_n, out_idx); }
+extern "C" BSX_API int bsx_regions_dedup_long_cap(void) { return dedup_long_cap(); }
+extern "C" BSX_API int bsx_regions_dedup2(bsx_device_t *d, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx,
+                                          int64_t *long_off, uint16_t **long_idx, int64_t *long_cap)
+{ return lane_regions_dedup(d, 0, opt, n_reads, per_read, out_n, out_idx, long_off, long_idx, long_cap); }
 extern "C" BSX_API int bsx_sa_batch(bsx_device_t *d, int64_t n, const bsx_sa_job_t *jobs, uint64_t *pos) { return lane_sa_batch(d, 0, n, jobs, pos); }
 extern "C" BSX_API int bsx_extend_batch(bsx_device_t *d, int64_t n, const bsx_ext_job_t *jobs, bsx_ext_res_t *res) { return lane_extend_batch(d, 0, n, jobs, res); }
 extern "C" BSX_API int bsx_sw_batch(bsx_device_t *d, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res) { return lane_sw_batch(d, 0, n, jobs, res); }
@@ -1616,6 +1650,8 @@ static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_tas
 }
 static int be_regions_finish(void *c, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return lane_regions_finish(LR(c), out, cap, off, cnt); }
 static int be_dedup(void *c, const bsx_opt_t *o, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx) { return lane_regions_dedup(LR(c), o, n_reads, per_read, out_n, out_idx); }
+static int be_dedup2(void *c, const bsx_opt_t *o, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx, int64_t *long_off, uint16_t **long_idx, int64_t *long_cap)
+{ return lane_regions_dedup(LR(c), o, n_reads, per_read, out_n, out_idx, long_off, long_idx, long_cap); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
 static int be_glb_tags(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len, bsx_glb_tag_t *t, char **md, int64_t *cap)
 { return lane_global_batch(LR(c), n, j, r, pool, len, t, md, cap); }
@@ -1636,6 +1672,7 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	out->regions_finish = out->regions_batch ? be_regions_finish : nullptr;   // BSX_HOST_CHAIN=1: host chaining for every task (A/B checks)
 	out->regions_dedup = out->regions_batch && !bsx_tune_long("host_dedup", 0) ? be_dedup : nullptr;   // BSX_HOST_DEDUP=1: C5 on the host for every read (A/B checks)
 	out->dedup_cap = dedup_cap();
+	out->regions_dedup2 = out->regions_dedup ? be_dedup2 : nullptr;
 	return BSX_OK;
 }
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out) { return bsx_hip_backend_lane(dev, 0, out); }

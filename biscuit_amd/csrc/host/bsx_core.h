@@ -31,6 +31,7 @@ typedef struct bsx_arena bsx_arena_t;
 /* Two chunks can be in flight (front half of one, back half of the previous): there are two arena sets. */
 BSX_API int  bsx_arenas_begin(int n_threads);   /* take a free set (-1: arenas off), bind it to the caller and to its parallel loops */
 BSX_API void bsx_arenas_bind(int set);          /* another thread continues work on the chunk that owns `set` */
+void bsx_arenas_bind_extra(int set, int k);     /* ... a further thread works on it BESIDE its owner, with arena k of the set's spares as its own */
 BSX_API void bsx_arenas_end(int set);           /* rewind the set, release it, unbind the caller */
 void *bsx_arena_alloc(bsx_arena_t *a, size_t n);
 /* large arrays that live as long as the arena set (chunk after chunk): slot = a small fixed index per array */
@@ -176,6 +177,10 @@ typedef struct bsx_backend {
 	 * (dedup_cap entries of out_idx per read) */
 	int (*regions_dedup)(void *ctx, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx);
 	int dedup_cap;
+	/* optional, with regions_dedup: the same, and the reads with more than dedup_cap regions as well (bsx_regions_dedup2): long_off[i] >= 0 =
+	 * read i's out_n[i] indices are 16-bit entries of *long_idx from there; -1 = they are in out_idx as above */
+	int (*regions_dedup2)(void *ctx, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx,
+	                      int64_t *long_off, uint16_t **long_idx, int64_t *long_cap);
 } bsx_backend_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;
@@ -204,6 +209,10 @@ typedef int (*bsx_process_fn)(void *ud, const bsx_opt_t *opt, const bsx_index_t 
                               bsx_read_t *reads, const bsx_pestat_t *pes0);
 BSX_API int bsx_align_main_with(int argc, char **argv, bsx_process_fn process, void *ud,
                                 int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud));
+/* the same, as one of $WORLD_SIZE processes (rank $RANK, GPU $LOCAL_RANK) whose chunks are brought together by the gather (gather.c): over RCCL
+ * (use_rccl) or Unix sockets; with WORLD_SIZE unset or 1 it is bsx_align_main_with */
+BSX_API int bsx_align_main_ranks_with(int argc, char **argv, bsx_process_fn process, void *ud,
+                                      int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud), int use_rccl);
 BSX_API extern char *bsx_pg_line;
 
 BSX_API extern int bsx_verbose;

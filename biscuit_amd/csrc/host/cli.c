@@ -667,6 +667,108 @@ cleanup:
 	return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Several GPUs without Python in the data path (north_star: "host code stays C ... a trivial RCCL gather"): the same command line started
+ * once per GPU by any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (torchrun, mpirun with a wrapper, a shell loop).  Every process
+ * aligns its share of the chunks (cli.c above: bsx_shard_rank / _world / _mode) on GPU $LOCAL_RANK and hands each chunk's SAM text to the
+ * gather (gather.c): over RCCL in the product, over Unix sockets for the CPU checker.  The output: $BSX_OUT when set -- every rank writes its
+ * own chunks into that file at their offsets when all ranks are on one node and it is a regular file, else the text goes through rank 0 --
+ * or rank 0's stdout.  $BSX_GATHER_ID: the path through which the ranks find each other (the unique ids' file / the sockets' name); by
+ * default next to the output, or in /tmp under the launcher's MASTER_PORT.  Settings: shard_pairs=1 (every rank takes its slice of EVERY
+ * chunk: inputs with fewer chunks than GPUs), gather_via_rank0=1, gather_transport=rccl|socket.
+ * biscuit_amd/multi_gpu.py (torch.distributed) drives the same sharding through the emit hook and remains available. */
+typedef struct {
+	bsx_gather_t *G; FILE *out; int direct, failed;
+	bsx_transport_t tg, tr;
+	int argc; char **argv; bsx_process_fn process; void *ud; int (*open_device)(int, const bsx_index_t*, void**); int rc;
+} ranks_t;
+static ranks_t *g_ranks = 0;
+static void ranks_emit(void *ud, int64_t chunk, const char *text, size_t len)   /* the aligner's writer thread, chunk by chunk; -1: the header (rank 0) */
+{
+	ranks_t *R = (ranks_t*)ud;
+	if (chunk < 0) {
+		if (R->direct) bsx_gather_set_header(R->G, text, len);
+		else if (R->out && len && fwrite(text, 1, len, R->out) != len) R->failed = 1;
+		return;
+	}
+	{
+		char *copy = (char*)malloc(len ? len : 1);
+		memcpy(copy, text, len);
+		if (bsx_gather_submit(R->G, chunk, copy, len) != BSX_OK) R->failed = 1;   /* blocks while a few chunks wait for their round */
+	}
+}
+static void ranks_sink(void *ud, int64_t chunk, const void *buf, size_t n)      /* rank 0, the gather's thread: chunks in input order */
+{
+	ranks_t *R = (ranks_t*)ud;
+	(void)chunk;
+	if (R->out && !R->failed && n && fwrite(buf, 1, n, R->out) != n) { R->failed = 1; fprintf(stderr, "[E::%s] failed to write the output: the SAM is incomplete\n", "main_align"); }
+}
+static void ranks_hist(void *ud, int64_t *hist, int nb)
+{
+	ranks_t *R = (ranks_t*)ud;
+	if (R->tr.all_reduce_sum && R->tr.all_reduce_sum(R->tr.ctx, hist, nb) != BSX_OK) { R->failed = 1; fprintf(stderr, "[E::%s] adding the insert-size histograms over the ranks failed\n", "main_align"); }
+}
+static void *ranks_aligner(void *arg)
+{
+	ranks_t *R = (ranks_t*)arg;
+	R->rc = bsx_align_main_with(R->argc, R->argv, R->process, R->ud, R->open_device);
+	bsx_gather_close_input(R->G);
+	return 0;
+}
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+extern void *bsx_pes_hist_ud;
+
+BSX_API int bsx_align_main_ranks_with(int argc, char **argv, bsx_process_fn process, void *ud, int (*open_device)(int ordinal, const bsx_index_t *idx, void **ud), int use_rccl)
+{
+	const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", rank), local_world = env_int("LOCAL_WORLD_SIZE", world);
+	const char *out_path = getenv("BSX_OUT"), *id_env = getenv("BSX_GATHER_ID"), *tk = bsx_tune_str("gather_transport");
+	const int pairs = bsx_tune_long("shard_pairs", 0) != 0, want_rccl = tk ? strcmp(tk, "socket") != 0 : use_rccl;
+	char id_path[4096], dev_env[32];
+	ranks_t R;
+	pthread_t th;
+	int rc, direct;
+	int64_t n_chunks = 0, mine, *all;
+	if (world <= 1 || bsx_emit_hook) return bsx_align_main_with(argc, argv, process, ud, open_device);   /* (a launcher with its own hook: multi_gpu.py) */
+	if (rank < 0 || rank >= world) { fprintf(stderr, "[E::%s] RANK %d of WORLD_SIZE %d\n", "main_align", rank, world); return 1; }
+	memset(&R, 0, sizeof(R));
+	if (id_env && *id_env) snprintf(id_path, sizeof(id_path), "%s", id_env);
+	else if (out_path && *out_path) snprintf(id_path, sizeof(id_path), "%s.ranks", out_path);
+	else snprintf(id_path, sizeof(id_path), "/tmp/bsx_ranks_%s_%d", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (int)getppid());
+	if (!getenv("BSX_DEVICE")) { snprintf(dev_env, sizeof(dev_env), "%d", local_rank); setenv("BSX_DEVICE", dev_env, 1); }
+	rc = want_rccl ? bsx_transport_rccl(rank, world, local_rank, id_path, &R.tg, pairs ? &R.tr : 0) : bsx_transport_socket(rank, world, id_path, &R.tg, pairs ? &R.tr : 0);
+	if (rc != BSX_OK) { fprintf(stderr, "[E::%s] rank %d: no connection to the other ranks (%s)\n", "main_align", rank, bsx_strerror(rc)); return 1; }
+	direct = out_path && *out_path && !bsx_tune_long("gather_via_rank0", 0) && bsx_gather_direct_ok(out_path, world, local_world);
+	R.direct = direct;
+	if (!direct && rank == 0) {
+		R.out = out_path && *out_path ? fopen(out_path, "wb") : stdout;
+		if (!R.out) { fprintf(stderr, "[E::%s] cannot open %s\n", "main_align", out_path); R.failed = 1; }
+	}
+	if (bsx_verbose >= 3) fprintf(stderr, "[M::%s] rank %d of %d on device %d: %s over %s, %s\n", "main_align", rank, world, local_rank, pairs ? "a slice of every chunk" : "every world-th chunk",
+	                              want_rccl ? "RCCL" : "sockets", direct ? "every rank writes its own chunks" : "records through rank 0");
+	if ((rc = bsx_gather_open(&R.tg, direct ? out_path : 0, ranks_sink, &R, 3, &R.G)) != BSX_OK) { R.tg.close(R.tg.ctx); if (R.tr.close) R.tr.close(R.tr.ctx); return 1; }
+	R.argc = argc; R.argv = argv; R.process = process; R.ud = ud; R.open_device = open_device; R.rc = 1;
+	bsx_shard_rank = rank; bsx_shard_world = world; bsx_shard_mode = pairs;
+	bsx_emit_hook = ranks_emit; bsx_emit_ud = &R;
+	if (pairs) { bsx_pes_hist_hook = ranks_hist; bsx_pes_hist_ud = &R; }
+	g_ranks = &R;
+	if (pthread_create(&th, 0, ranks_aligner, &R) != 0) { (void)ranks_aligner(&R); }
+	rc = bsx_gather_run(R.G, &n_chunks);
+	pthread_join(th, 0);
+	bsx_emit_hook = 0; bsx_emit_ud = 0; bsx_pes_hist_hook = 0; bsx_pes_hist_ud = 0; bsx_shard_rank = 0; bsx_shard_world = 1; bsx_shard_mode = 0; g_ranks = 0;
+	if (R.out && R.out != stdout && fclose(R.out) != 0) R.failed = 1;
+	else if (R.out == stdout && fflush(stdout) != 0) R.failed = 1;
+	/* every rank leaves with the worst status of all */
+	mine = (R.rc != 0 || rc != BSX_OK || R.failed) ? 1 : 0;
+	all = (int64_t*)calloc((size_t)world, sizeof(int64_t));
+	if (R.tg.all_gather(R.tg.ctx, &mine, 1, all) == BSX_OK) { int k; for (k = 0; k < world; ++k) if (all[k]) mine = 1; }
+	else mine = 1;
+	free(all);
+	bsx_gather_free(R.G);
+	R.tg.close(R.tg.ctx);
+	if (R.tr.close) R.tr.close(R.tr.ctx);
+	return (int)mine;
+}
+
 /* ---- product entry: HIP device only ---- */
 static int hip_open(int ordinal, const bsx_index_t *idx, void **ud)
 {
@@ -690,7 +792,7 @@ BSX_API int bsx_align_main(int argc, char **argv)
 	int rc;
 	g_use_stream = getenv("BSX_NO_STREAM") ? 0 : 1;
 	g_close_device = hip_close;
-	rc = bsx_align_main_with(argc, argv, hip_process, 0, hip_open);
+	rc = bsx_align_main_ranks_with(argc, argv, hip_process, 0, hip_open, 1);   /* (one process: straight to bsx_align_main_with) */
 	g_close_device = 0; g_use_stream = 0;
 	return rc;
 }

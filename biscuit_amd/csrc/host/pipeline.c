@@ -106,6 +106,7 @@ typedef struct {
 	int n_host, *hmap, n_pending;
 	bsx_region_t *dregs; int64_t dregs_cap, *dreg_off; int32_t *dreg_n;
 	int32_t *dd_n; uint8_t *dd_idx; int dd_cap;   /* C5 done by the backend (regions_dedup): per read, the regions kept and their order; dd_n < 0: here */
+	int64_t *dd_loff; uint16_t *dd_lidx; int64_t dd_lcap;   /* ... the reads with more than dd_cap regions (regions_dedup2): where a read's 16-bit indices start in dd_lidx, or -1 */
 	int *read_task0;             /* first task of each read; read_task0[n] = n_tasks */
 	bsx_intv_t *intv; int64_t intv_cap; int64_t *intv_off;
 	uint64_t *pos; int64_t *ipos_off;   /* per interval: its occurrences' positions */
@@ -121,6 +122,7 @@ typedef struct {
 	int arena_set, rc;
 	pthread_t th; int th_live;   /* the thread running the front half (stream mode) */
 	int back_done;               /* ... which ran the back half too */
+	int merged;                  /* the per-read merge (C5) already ran at the end of the front half, on its thread */
 	double t_begin, t_front_end;
 	bsx_phase_stats_t st;
 } chunk_t;
@@ -375,12 +377,13 @@ static void merge_worker(void *data, long i, int tid)
 	if (!P->pending[i]) return;
 	if (C->dd_n && C->dd_n[i] >= 0) { /* sorted and de-duplicated on the device: what is left of the concatenation, in order */
 		const uint8_t *ix = C->dd_idx + (size_t)i * (size_t)C->dd_cap;
+		const uint16_t *lx = C->dd_loff && C->dd_loff[i] >= 0 ? C->dd_lidx + C->dd_loff[i] : 0;   /* a long list (k_dedup_long): 16-bit indices */
 		int t, kk, m = C->dd_n[i]; size_t tot = 0;   /* (every strand search of such a read finished on the device: dreg_n >= 0) */
 		for (t = C->read_task0[i]; t < C->read_task0[i + 1]; ++t) tot += (size_t)C->dreg_n[t];
 		if (regs->m < (size_t)m) { regs->a = (reg_t*)bsx_crealloc(regs->a, 0, sizeof(reg_t) * ((size_t)m + 2)); regs->m = (size_t)m + 2; }
 		regs->n = (size_t)m; regs->n_pri = 0;
 		for (kk = 0; kk < m; ++kk) {
-			size_t li = ix[kk];
+			size_t li = lx ? lx[kk] : ix[kk];
 			for (t = C->read_task0[i]; li >= (size_t)C->dreg_n[t]; ++t) li -= (size_t)C->dreg_n[t];
 			reg_from_device(&regs->a[kk], &C->dregs[C->dreg_off[t] + (int64_t)li]);
 			regs->a[kk].n_comp = tot > 1 ? 1 : 0;   /* mem_alnreg.c:114,118 */
@@ -610,14 +613,15 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 	return missing;
 }
 
-typedef struct { chunk_t *C; msw_pair_t *M; int *cnt; int64_t *off; bsx_sw_job_t *jobs; const bsx_sw_res_t *res; } msw_par_t;
+/* (the pairs [p0, p0 + np) of the chunk: M, cnt and off are indexed from p0) */
+typedef struct { chunk_t *C; msw_pair_t *M; int *cnt; int64_t *off; bsx_sw_job_t *jobs; const bsx_sw_res_t *res; int p0; } msw_par_t;
 static void msw_worker(void *data, long pi, int tid)
 {
 	msw_par_t *P = (msw_par_t*)data;
 	(void)tid;
 	if (P->M[pi].pending) {
 		double t0 = g_msw_prof ? now_s() : 0;
-		P->M[pi].pending = matesw_replay(P->C, &P->M[pi], (int)pi);
+		P->M[pi].pending = matesw_replay(P->C, &P->M[pi], P->p0 + (int)pi);
 		if (g_msw_prof) __atomic_fetch_add(&g_msw_replay_ns, (int64_t)((now_s() - t0) * 1e9), __ATOMIC_RELAXED);
 	}
 }
@@ -656,14 +660,14 @@ static void msw_free_worker(void *data, long pi, int tid)
 	bsx_cfree(P->M[pi].saved[0].a); bsx_cfree(P->M[pi].saved[1].a); bsx_vec_free(P->M[pi].slots);
 }
 
-static int mate_rescue(chunk_t *C)
+static int mate_rescue(chunk_t *C, int p0, int p1)   /* the pairs [p0, p1) */
 {
-	int np = C->n >> 1, rc = BSX_OK, round;
+	int np = p1 - p0, rc = BSX_OK, round;
 	double t_batch = 0, t_all = now_s();
 	msw_pair_t *M = (msw_pair_t*)bsx_par_calloc(C->nt, (size_t)np, sizeof(msw_pair_t));
 	msw_par_t P;
 	g_msw_prof = bsx_phases() != 0;
-	P.C = C; P.M = M;
+	P.C = C; P.M = M; P.p0 = p0;
 	P.cnt = (int*)malloc(sizeof(int) * ((size_t)np + 1)); P.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)np + 1));
 	bsx_parallel_for(C->nt, msw_init_worker, &P, np);
 	for (round = 0; round < 256; ++round) {
@@ -677,7 +681,7 @@ static int mate_rescue(chunk_t *C)
 		res = (bsx_sw_res_t*)malloc(sizeof(*res) * (size_t)nj);
 		bsx_parallel_for(C->nt, msw_jobs_worker, &P, np);
 		{ double tb = now_s(); rc = C->be->sw_batch(C->be->ctx, nj, P.jobs, res); t_batch += now_s() - tb; }
-		C->st.n_sw_jobs += nj;
+		__atomic_fetch_add(&C->st.n_sw_jobs, nj, __ATOMIC_RELAXED);
 		P.res = res;
 		if (rc == BSX_OK) bsx_parallel_for(C->nt, msw_results_worker, &P, np);
 		free(res); free(P.jobs);
@@ -719,7 +723,7 @@ BSX_API int bsx_hook_mate_rescue(const bsx_backend_t *be, const bsx_opt_t *opt, 
 	}
 	rc = be->set_opt(be->ctx, opt);
 	if (rc == BSX_OK) rc = be->set_reads(be->ctx, C->buf, tot);
-	if (rc == BSX_OK) rc = mate_rescue(C);
+	if (rc == BSX_OK) rc = mate_rescue(C, 0, n_reads >> 1);
 	for (i = 0; i < n_reads && rc == BSX_OK; ++i) {
 		out_off[i] = at;
 		if (at + (int64_t)C->regs[i].n > out_cap) { rc = BSX_E_ARG; break; }
@@ -734,17 +738,18 @@ BSX_API int bsx_hook_mate_rescue(const bsx_backend_t *be, const bsx_opt_t *opt, 
 /* ------------------------------------------------------------------ output: plan -> K6 -> final */
 typedef struct {
 	chunk_t *C;
-	samctx_t *ctx;        /* per unit (pair or single read) */
-	int final_pass;
+	samctx_t *ctx;        /* per unit (pair or single read) of the slice: unit u0 + k at ctx[k] */
+	int final_pass, u0;
 } out_par_t;
 
 static void reset_flags(reg_v *r) { size_t k; for (k = 0; k < r->n; ++k) r->a[k].flag = 0; }
 
-static void out_worker(void *data, long u, int tid)
+static void out_worker(void *data, long k_, int tid)
 {
 	out_par_t *P = (out_par_t*)data;
 	chunk_t *C = P->C;
-	samctx_t *ctx = &P->ctx[u];
+	samctx_t *ctx = &P->ctx[k_];
+	const long u = P->u0 + k_;
 	(void)tid;
 	if (C->is_pe) {
 		reg_v *pair = &C->regs[u << 1];
@@ -781,7 +786,7 @@ static void out_worker(void *data, long u, int tid)
 }
 
 typedef struct {
-	chunk_t *C; samctx_t *ctx; int per; const int *todo, *jread, *jreg; const bsx_glb_job_t *sub; const bsx_glb_res_t *sres; const uint32_t *pool;
+	chunk_t *C; samctx_t *ctx; int per, u0; const int *todo, *jread, *jreg; const bsx_glb_job_t *sub; const bsx_glb_res_t *sres; const uint32_t *pool;
 	const bsx_glb_tag_t *tags; const char *md;   /* NM / MD / ZC / ZR from the backend, or NULL */
 } finish_par_t;
 static void finish_worker(void *data, long k, int tid)
@@ -791,10 +796,10 @@ static void finish_worker(void *data, long k, int tid)
 	(void)tid;
 	if (F->sres[k].n_cigar < 0) return;   /* did not fit: redone with more room */
 	bsx_setsam_finish(F->C->opt, F->C->idx, &F->C->reads[ri], &F->C->regs[ri].a[F->jreg[jj]], F->pool + F->sub[k].cigar_off, F->sres[k].n_cigar,
-	                  &F->ctx[ri / F->per].table[ri % F->per][F->jreg[jj]], F->tags ? &F->tags[k] : 0, F->tags ? F->md + F->tags[k].md_off : 0);
+	                  &F->ctx[ri / F->per - F->u0].table[ri % F->per][F->jreg[jj]], F->tags ? &F->tags[k] : 0, F->tags ? F->md + F->tags[k].md_off : 0);
 }
 
-typedef struct { chunk_t *C; samctx_t *ctx; int per; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg, *todo; } plan_par_t;
+typedef struct { chunk_t *C; samctx_t *ctx; int per, u0; int *cnt; int64_t *off; bsx_glb_job_t *jobs; int *jread, *jreg, *todo; } plan_par_t;
 static void plan_count_worker(void *data, long u, int tid)
 {
 	plan_par_t *Q = (plan_par_t*)data;
@@ -810,7 +815,7 @@ static void plan_jobs_worker(void *data, long u, int tid)
 	int w; size_t k; int64_t at = Q->off[u];
 	(void)tid;
 	for (w = 0; w < Q->per; ++w) {
-		int ri = (int)u * Q->per + w;
+		int ri = (Q->u0 + (int)u) * Q->per + w;
 		reg_v *regs = &C->regs[ri];
 		Q->ctx[u].table[w] = (samrec_t*)bsx_crealloc(0, 0, sizeof(samrec_t) * (regs->n ? regs->n : 1));
 		memset(Q->ctx[u].table[w], 0, sizeof(samrec_t) * (regs->n ? regs->n : 1));
@@ -830,15 +835,18 @@ static void plan_free_worker(void *data, long u, int tid)
 	int w; size_t k;
 	(void)tid;
 	for (w = 0; w < Q->per; ++w) {
-		reg_v *regs = &Q->C->regs[u * Q->per + w];
+		reg_v *regs = &Q->C->regs[(Q->u0 + u) * Q->per + w];
 		if (Q->ctx[u].table[w]) for (k = 0; k < regs->n; ++k) bsx_cfree(Q->ctx[u].table[w][k].cigar);
 		bsx_cfree(Q->ctx[u].table[w]); bsx_cvec_free(Q->ctx[u].want[w]);
 	}
 }
 
-static int emit_sam(chunk_t *C)
+static pthread_mutex_t g_stat_mu = PTHREAD_MUTEX_INITIALIZER;   /* a chunk's phase times, added to by the slices of its back half */
+static void stat_add(double *dst, double v) { pthread_mutex_lock(&g_stat_mu); *dst += v; pthread_mutex_unlock(&g_stat_mu); }
+
+static int emit_sam(chunk_t *C, int u0, int u1)   /* the units (pairs, or single reads) [u0, u1) */
 {
-	int n_units = C->is_pe ? C->n >> 1 : C->n, per = C->is_pe ? 2 : 1, rc = BSX_OK, round;
+	int n_units = u1 - u0, per = C->is_pe ? 2 : 1, rc = BSX_OK, round;
 	samctx_t *ctx = (samctx_t*)bsx_par_calloc(C->nt, (size_t)n_units, sizeof(samctx_t));
 	out_par_t P;
 	plan_par_t Q;
@@ -850,10 +858,10 @@ static int emit_sam(chunk_t *C)
 	int64_t n_jobs;
 	double t0 = now_s(), t_batch = 0;
 	bsx_vec_init(todo);
-	P.C = C; P.ctx = ctx; P.final_pass = 0;
+	P.C = C; P.ctx = ctx; P.final_pass = 0; P.u0 = u0;
 	bsx_parallel_for(C->nt, out_worker, &P, n_units);
-	C->st.t_primary += now_s() - t0; t0 = now_s();
-	Q.C = C; Q.ctx = ctx; Q.per = per;
+	stat_add(&C->st.t_primary, now_s() - t0); t0 = now_s();
+	Q.C = C; Q.ctx = ctx; Q.per = per; Q.u0 = u0;
 	Q.cnt = (int*)malloc(sizeof(int) * ((size_t)n_units + 1)); Q.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_units + 1));
 	bsx_parallel_for(C->nt, plan_count_worker, &Q, n_units);
 	n_jobs = prefix_counts(n_units, Q.cnt, Q.off);
@@ -878,10 +886,10 @@ static int emit_sam(chunk_t *C)
 			          : C->be->global_batch(C->be->ctx, (int64_t)todo.n, sub, sres, pool, off);
 			t_batch += now_s() - tb;
 		}
-		C->st.n_glb_jobs += (int64_t)todo.n;
+		__atomic_fetch_add(&C->st.n_glb_jobs, (int64_t)todo.n, __ATOMIC_RELAXED);
 		if (rc == BSX_OK) {
 			finish_par_t F;
-			F.C = C; F.ctx = ctx; F.per = per; F.todo = todo.a; F.jread = Q.jread; F.jreg = Q.jreg; F.sub = sub; F.sres = sres; F.pool = pool;
+			F.C = C; F.ctx = ctx; F.per = per; F.u0 = u0; F.todo = todo.a; F.jread = Q.jread; F.jreg = Q.jreg; F.sub = sub; F.sres = sres; F.pool = pool;
 			F.tags = tags; F.md = md;
 			bsx_parallel_for(C->nt, finish_worker, &F, (long)todo.n);
 			for (k = 0; k < todo.n; ++k) {
@@ -895,11 +903,11 @@ static int emit_sam(chunk_t *C)
 	}
 	if (rc == BSX_OK && todo.n) rc = BSX_E_INTERNAL;
 	if (bsx_phases()) fprintf(stderr, "[M::cigar] %d rounds, %.3f s in the K6 batches, %.3f s on the host\n", round, t_batch, now_s() - t0 - t_batch);
-	C->st.t_cigar += now_s() - t0; t0 = now_s();
+	stat_add(&C->st.t_cigar, now_s() - t0); t0 = now_s();
 	if (rc == BSX_OK) { P.final_pass = 1; bsx_parallel_for(C->nt, out_worker, &P, n_units); }
 	/* the records own the CIGAR buffers now; release what the reference frees in mem_alnreg_freeSAM */
 	if (C->arena_set < 0) bsx_parallel_for(C->nt, plan_free_worker, &Q, n_units);   /* arena memory is rewound with the chunk */
-	C->st.t_sam += now_s() - t0;
+	stat_add(&C->st.t_sam, now_s() - t0);
 	free(ctx); free(pool); free(md); free(Q.cnt); free(Q.off); free(Q.jobs); free(Q.jread); free(Q.jreg);
 	bsx_vec_free(todo);
 	return rc;
@@ -1134,6 +1142,7 @@ out:
 	return rc;
 }
 
+static int chunk_merge(chunk_t *C);
 /* front half: clipping, strand searches, seeding .. regions of every strand search (mem_align1_core's first part,
  * lib/aln/bwamem.c:183-208, for the whole chunk) */
 static int chunk_front(chunk_t *C)
@@ -1194,7 +1203,10 @@ static int chunk_front(chunk_t *C)
 			C->dd_cap = be->dedup_cap;
 			C->dd_n = (int32_t*)bsx_big_get(C->arena_set, 10, sizeof(int32_t) * ((size_t)n + 1));
 			C->dd_idx = (uint8_t*)bsx_big_get(C->arena_set, 11, (size_t)C->dd_cap * ((size_t)n + 1));
-			rc = be->regions_dedup(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx);
+			if (be->regions_dedup2) {
+				C->dd_loff = (int64_t*)bsx_big_get(C->arena_set, 12, sizeof(int64_t) * ((size_t)n + 1));
+				rc = be->regions_dedup2(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx, C->dd_loff, &C->dd_lidx, &C->dd_lcap);
+			} else rc = be->regions_dedup(be->ctx, opt, n, C->n_tasks / (n ? n : 1), C->dd_n, C->dd_idx);
 			if (rc != BSX_OK) goto out;
 			if (bsx_phases()) { /* what the device's sort + de-duplication leaves of the regions that came down */
 				int64_t kept = 0, held = 0, left_all = 0, left_reads = 0; int per = C->n_tasks / (n ? n : 1), i, k;
@@ -1224,6 +1236,7 @@ static int chunk_front(chunk_t *C)
 	}
 	C->st.t_regions = now_s() - t0; C->st.n_host_tasks = C->n_host;
 	rc = host_path(C, n_reseed, decl_intv, decl_off);
+	if (rc == BSX_OK && !C->n_pending) rc = chunk_merge(C);
 out:
 	free(decl_intv); free(decl_off);
 	return rc;
@@ -1256,30 +1269,94 @@ static int finish_pending(chunk_t *C)
 	return rc;
 }
 
+/* What follows the insert-size statistics -- mate rescue, primary marking / pairing, CIGARs, SAM text -- is per pair (per read, single-end):
+ * nothing of it looks beyond its pair.  The pushing thread used to run those stages one after the other over the whole chunk, waiting for the
+ * chunk's K5 batch (150-300 ms with other chunks' kernels on the device) and then for its K6 batch with nothing else to do; on a repeat-rich
+ * genome that thread's back half is what bounds the stream (1.1-1.2 s of a 1.3 s step, round 5).  So the units are cut into slices, and two
+ * threads take the slices alternately, each slice going through all four stages: while one thread waits for its slice's K5 / K6 batch (the
+ * lane's back-half batches are serialised by a lock in the shim: one stream, one set of staging buffers), the other runs host stages of the
+ * next slice.  Every pair is still processed by the same code in the same order of stages: the SAM cannot change ("back_slices": 1 = the
+ * stages over the whole chunk, as before). */
+typedef struct { chunk_t *C; int first, step, n_sl, n_units, helper, rc; } slice_run_t;
+static int one_slice(chunk_t *C, int u0, int u1)
+{
+	int rc = BSX_OK;
+	if (u1 <= u0) return BSX_OK;
+	if (C->is_pe && !(C->opt->flag & BSX_F_NO_RESCUE)) {
+		double t0 = now_s();
+		rc = mate_rescue(C, u0, u1);
+		stat_add(&C->st.t_matesw, now_s() - t0);
+		if (rc != BSX_OK) return rc;
+	}
+	return emit_sam(C, u0, u1);
+}
+static void *slice_thread(void *arg)
+{
+	slice_run_t *R = (slice_run_t*)arg;
+	chunk_t *C = R->C;
+	int k;
+	if (R->helper) bsx_arenas_bind_extra(C->arena_set, R->helper - 1);   /* its own arena beside the chunk's: the caller of a parallel loop allocates too */
+	for (k = R->first; k < R->n_sl && R->rc == BSX_OK; k += R->step) {
+		const int u0 = (int)((int64_t)R->n_units * k / R->n_sl), u1 = (int)((int64_t)R->n_units * (k + 1) / R->n_sl);
+		R->rc = one_slice(C, u0, u1);
+	}
+	if (R->helper) bsx_arenas_bind(-1);
+	return 0;
+}
+static int back_slices(chunk_t *C)
+{
+	const int n_units = C->is_pe ? C->n >> 1 : C->n;
+	int n_sl = (int)bsx_tune_long("back_slices", 4), n_thr = (int)bsx_tune_long("back_threads", 2), j, rc = BSX_OK;
+	slice_run_t R[4];
+	pthread_t th[4];
+	int live[4] = {0, 0, 0, 0};
+	if (n_sl > n_units / 1024) n_sl = n_units / 1024;   /* (small chunks: nothing to overlap) */
+	if (n_sl < 1) n_sl = 1;
+	if (n_thr > 4) n_thr = 4;
+	if (n_thr > n_sl) n_thr = n_sl;
+	if (n_thr < 1 || C->arena_set < 0) n_thr = 1;
+	for (j = 0; j < n_thr; ++j) { R[j].C = C; R[j].first = j; R[j].step = n_thr; R[j].n_sl = n_sl; R[j].n_units = n_units; R[j].helper = j; R[j].rc = BSX_OK; }
+	for (j = 1; j < n_thr; ++j) live[j] = pthread_create(&th[j], 0, slice_thread, &R[j]) == 0;
+	for (j = 1; j < n_thr; ++j) if (!live[j]) { R[j].helper = 0; }   /* (no thread: its slices run here, below) */
+	(void)slice_thread(&R[0]);
+	for (j = 1; j < n_thr; ++j) { if (live[j]) pthread_join(th[j], 0); else (void)slice_thread(&R[j]); }
+	for (j = 0; j < n_thr; ++j) if (rc == BSX_OK) rc = R[j].rc;
+	return rc;
+}
+
 /* back half: per-read merge, insert-size statistics, mate rescue, pairing, CIGARs, SAM text (the rest of
  * mem_process_seqs, lib/aln/bwamem.c:374-412) */
+/* C5 of every read (mem_sort_deduplicate: what the device left to the host, the concatenation tests' score-only K6 batches, the reads'
+ * region lists built).  It needs nothing but the front half's products, so it runs at the end of the front half, on that thread -- chunks
+ * further back in the stream have time there, the pushing thread (whose back halves bound the stream) does not -- unless strand searches
+ * are still being seeded again on the side stream: then it waits for the back half to collect them. */
+static int chunk_merge(chunk_t *C)
+{
+	int rc;
+	double t0 = now_s();
+	C->regs = (reg_v*)bsx_big_get(C->arena_set, 9, sizeof(reg_v) * ((size_t)C->n + 1));
+	memset(C->regs, 0, sizeof(reg_v) * ((size_t)C->n + 1));
+	rc = merge_regions(C);
+	C->st.t_merge = now_s() - t0;
+	C->merged = 1;
+	return rc;
+}
+
 static int chunk_back(chunk_t *C)
 {
 	const bsx_opt_t *opt = C->opt;
 	int rc = BSX_OK;
 	double t0;
 	bsx_arenas_bind(C->arena_set);
-	t0 = now_s();
 	if (C->n_pending) FCHECK(finish_pending(C));
-	C->regs = (reg_v*)bsx_big_get(C->arena_set, 9, sizeof(reg_v) * ((size_t)C->n + 1));
-	memset(C->regs, 0, sizeof(reg_v) * ((size_t)C->n + 1));
-	FCHECK(merge_regions(C));
-	C->st.t_merge = now_s() - t0;
+	if (!C->merged) FCHECK(chunk_merge(C));
 	if (C->is_pe) {
 		t0 = now_s();
 		if (C->pes0) C->pes = *C->pes0;
 		else C->pes = bsx_pestat(opt, &C->idx->ref, C->n, C->regs);
 		C->st.t_pestat = now_s() - t0;
-		t0 = now_s();
-		if (!(opt->flag & BSX_F_NO_RESCUE)) FCHECK(mate_rescue(C));
-		C->st.t_matesw = now_s() - t0;
 	}
-	return emit_sam(C);
+	return back_slices(C);
 }
 
 static void chunk_free(chunk_t *C)
@@ -1296,6 +1373,8 @@ static void chunk_free(chunk_t *C)
 	bsx_big_put(C->arena_set, 4, C->stasks); bsx_big_put(C->arena_set, 1, C->buf);
 	bsx_big_put(C->arena_set, 5, C->hmap); bsx_big_put(C->arena_set, 8, C->dregs); bsx_big_put(C->arena_set, 6, C->dreg_off); bsx_big_put(C->arena_set, 7, C->dreg_n);
 	if (C->dd_n) { bsx_big_put(C->arena_set, 10, C->dd_n); bsx_big_put(C->arena_set, 11, C->dd_idx); }
+	if (C->dd_loff) bsx_big_put(C->arena_set, 12, C->dd_loff);
+	free(C->dd_lidx);
 	bsx_arenas_end(C->arena_set);
 	C->st.t_cleanup = now_s() - t0;
 	C->st.t_total = now_s() - C->t_begin;

@@ -36,6 +36,11 @@ static knob_t g_knobs[] = {
 	{"no_chunk_scan", "[0] 1 (several ranks): no boundary scan of plain input files, every rank parses everything", 0},
 	{"no_chunk_skip", "[0] 1 (several ranks): the other ranks' chunks are parsed into records and dropped instead of walked", 0},
 	{"index_batch", "[256 M] suffixes per batch of the device index builder's first round", 0},
+	{"back_slices", "[4] slices the pairs of a chunk are cut into for the stages after the insert-size statistics (mate rescue .. SAM text); 1: the stages over the whole chunk", 0},
+	{"back_threads", "[2] threads that take those slices alternately (one waits for its slice's K5 / K6 batch while the other runs host stages); up to 4", 0},
+	{"shard_pairs", "[0] several ranks (RANK / WORLD_SIZE): 1 = every rank aligns its slice of EVERY chunk (inputs with fewer chunks than GPUs) instead of every world-th chunk", 0},
+	{"gather_via_rank0", "[0] several ranks with $BSX_OUT: 1 = the records go through rank 0 even where every rank could write its own chunks into the file", 0},
+	{"gather_transport", "[rccl] several ranks: socket = Unix-domain sockets through rank 0 instead of RCCL", 0},
 	{"long_dedup", "[1] 0: reads with more than 32 regions are de-duplicated on the host (A/B against k_dedup_long)", 0},
 };
 #define N_KNOBS ((int)(sizeof(g_knobs) / sizeof(g_knobs[0])))

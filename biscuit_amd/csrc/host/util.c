@@ -307,6 +307,8 @@ struct bsx_arena { arena_blk_t *blk; int n_blk, m_blk, cur; size_t used; };
 BSX_API __thread bsx_arena_t *bsx_tls_arena = 0;
 #define ARENA_SETS 4
 static bsx_arena_t **g_arenas[ARENA_SETS];
+#define ARENA_EXTRA 3
+static bsx_arena_t *g_arena_extra[ARENA_SETS][ARENA_EXTRA];   /* for further threads working on the set's chunk beside its owner (the slices of a back half) */
 static int g_n_arenas[ARENA_SETS], g_set_busy[ARENA_SETS];
 static pthread_mutex_t g_arena_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_arena_cv = PTHREAD_COND_INITIALIZER;
@@ -372,6 +374,18 @@ void bsx_arenas_bind(int set)
 	bsx_tls_arena = set >= 0 ? g_arenas[set][0] : 0;
 }
 
+/* a thread that works on the set's chunk beside the one that owns it: arena k of the set's spares is its own (the caller of a parallel loop
+ * allocates as thread 0 of the loop, and two callers must not share an arena) */
+void bsx_arenas_bind_extra(int set, int k)
+{
+	if (set < 0 || k < 0 || k >= ARENA_EXTRA) { bsx_arenas_bind(set); return; }
+	pthread_mutex_lock(&g_arena_mu);
+	if (!g_arena_extra[set][k]) g_arena_extra[set][k] = (bsx_arena_t*)calloc(1, sizeof(bsx_arena_t));
+	pthread_mutex_unlock(&g_arena_mu);
+	tls_arena_set = set;
+	bsx_tls_arena = g_arena_extra[set][k];
+}
+
 void bsx_arenas_end(int set)
 {
 	int i;
@@ -379,6 +393,7 @@ void bsx_arenas_end(int set)
 	if (set < 0) return;
 	pthread_mutex_lock(&g_arena_mu);
 	for (i = 0; i < g_n_arenas[set]; ++i) { g_arenas[set][i]->cur = 0; g_arenas[set][i]->used = 0; }
+	for (i = 0; i < ARENA_EXTRA; ++i) if (g_arena_extra[set][i]) { g_arena_extra[set][i]->cur = 0; g_arena_extra[set][i]->used = 0; }
 	g_set_busy[set] = 0;
 	pthread_cond_signal(&g_arena_cv);
 	pthread_mutex_unlock(&g_arena_mu);
@@ -386,7 +401,8 @@ void bsx_arenas_end(int set)
 
 static void pf_run(pf_job_t *J, int tid)
 {
-	bsx_tls_arena = (J->arena_set >= 0 && tid < g_n_arenas[J->arena_set]) ? g_arenas[J->arena_set][tid] : 0;
+	/* (the caller runs as thread 0 on the arena it is bound to: the owner's, or a helper's own -- bsx_arenas_bind_extra) */
+	if (tid > 0) bsx_tls_arena = (J->arena_set >= 0 && tid < g_n_arenas[J->arena_set]) ? g_arenas[J->arena_set][tid] : 0;
 	for (;;) {
 		long b = __sync_fetch_and_add(&J->next, J->grain), e, i;
 		if (b >= J->n) break;

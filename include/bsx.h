@@ -276,6 +276,12 @@ int bsx_regions_finish(bsx_device_t *dev, bsx_region_t **out, int64_t *out_cap, 
  * not finished on the device, too many regions, or two regions have to be tested for concatenation, mem_alnreg.c:63-108). */
 int bsx_regions_dedup_cap(void);
 int bsx_regions_dedup(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx);
+/* ... and the reads with MORE regions than that, up to bsx_regions_dedup_long_cap() (a wavefront per read, k_dedup_long): as above, and for
+ * such a read long_off[i] >= 0 says where its out_n[i] indices (16 bits each) start in *long_idx (a malloc'd array the call grows:
+ * *long_cap entries); long_off[i] == -1: the read's list, if it has one, is in out_idx. */
+int bsx_regions_dedup_long_cap(void);
+int bsx_regions_dedup2(bsx_device_t *dev, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx,
+                       int64_t *long_off, uint16_t **long_idx, int64_t *long_cap);
 /* K5 */
 int bsx_sw_batch(bsx_device_t *dev, int64_t n, const bsx_sw_job_t *jobs, bsx_sw_res_t *res);
 /* K6 */
@@ -336,6 +342,44 @@ int bsx_device_seed_table(bsx_device_t *dev, uint64_t *lookups, int *depth, int 
  * the last reset: k = 0 seed (the chunk-wide launch of bsx_regions_batch), 1 sa, 2 extend, 3 sw, 4 global, 5 regions (first tier),
  * 6 regions (tiers 1b, 2 and 3), 7 seed outside the chunk-wide launch (the second seeding pass inside a chunk's sequence; bsx_seed_batch launches: the strand searches the host chains) */
 int bsx_device_kernel_time(bsx_device_t *dev, int k, double *total_ms, int64_t *launches, int reset);
+
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs ("replicas + gather"): one process per GPU, the per-chunk alignment records brought together in input order.
+ * The reference has nothing to bind here (it is one process: align.c:100-170 writes its chunks in order from kt_pipeline's third step);
+ * what these replace is that ordered write, across processes.  csrc/host/gather.c has the protocol (rounds: sizes to everybody, then either
+ * the payload to rank 0 or every rank's own pwrite() into the output file at its offset), over a small communication vtable:
+ *   bsx_transport_rccl   RCCL over xGMI (ncclAllGather / ncclSend / ncclRecv / ncclAllReduce; the unique id travels through a file);
+ *   bsx_transport_local  the ranks as threads of one process (tests of the protocol).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bsx_transport {
+	void *ctx;
+	int rank, world;
+	int (*all_gather)(void *ctx, const int64_t *mine, int n, int64_t *all);   /* n values of every rank, in rank order, to every rank */
+	int (*send)(void *ctx, int dst, const void *buf, size_t n_bytes);          /* host memory; returns when buf may be reused */
+	int (*recv_many)(void *ctx, int n_src, const int *src, void *const *buf, const size_t *n_bytes);   /* the receives of a round, posted together */
+	int (*all_reduce_sum)(void *ctx, int64_t *buf, int n);                     /* in place (the insert-size histograms of ranks sharing a chunk) */
+	void (*close)(void *ctx);
+} bsx_transport_t;
+int bsx_transport_local(int world, bsx_transport_t *out);   /* out[0 .. world): one per thread-rank */
+/* rank / world of this process, the HIP device its staging buffers live on, and a path all ranks can read: rank 0 writes the unique ids there
+ * (and removes the file when the last communicator is up).  Two communicators: `gather` for the rounds, `reduce` for all_reduce_sum calls
+ * made from another thread (either may be NULL).  BSX_E_NODEVICE when librccl cannot be loaded. */
+int bsx_transport_rccl(int rank, int world, int device, const char *id_path, bsx_transport_t *gather, bsx_transport_t *reduce);
+/* the ranks as processes of one node talking through rank 0 over Unix-domain sockets <path>.0 / <path>.1 (the CPU checker's multi-process
+ * runs; a fallback where librccl cannot be loaded) */
+int bsx_transport_socket(int rank, int world, const char *path, bsx_transport_t *gather, bsx_transport_t *reduce);
+typedef struct bsx_gather bsx_gather_t;
+/* direct_path != NULL: every rank writes its own chunks into that file (bsx_gather_direct_ok says whether it may); else rank 0's `sink`
+ * is called with every chunk in input order.  max_pending: chunks a rank may hold before bsx_gather_submit blocks. */
+int bsx_gather_open(const bsx_transport_t *tr, const char *direct_path, void (*sink)(void *ud, int64_t chunk, const void *buf, size_t n), void *ud,
+                    int max_pending, bsx_gather_t **out);
+int bsx_gather_set_header(bsx_gather_t *g, const void *hdr, size_t n);       /* rank 0, direct form: what the file starts with */
+int bsx_gather_submit(bsx_gather_t *g, int64_t chunk, void *buf, size_t n);  /* buf: malloc'd, the gather's from now on */
+int bsx_gather_close_input(bsx_gather_t *g);                                 /* no more chunks from this rank */
+int bsx_gather_run(bsx_gather_t *g, int64_t *n_chunks);                      /* the rounds, on the calling thread, until the input has ended everywhere */
+void bsx_gather_stats(const bsx_gather_t *g, int64_t out[3]);                /* rounds, payload bytes rank 0 received, bytes this rank wrote itself */
+void bsx_gather_free(bsx_gather_t *g);
+int bsx_gather_direct_ok(const char *path, int world, int local_world);
 
 /* ------------------------------------------------------------------------------------------
  * The whole path: mem_process_seqs (lib/aln/bwamem.c:432-476, declared bwamem.h:184)

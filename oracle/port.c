@@ -862,4 +862,4 @@ static int port_process(void *ud, const bsx_opt_t *opt, const bsx_index_t *idx, 
 	oracle_port_backend(ud, &be);
 	return bsx_process_seqs_backend(&be, opt, idx, np, n, reads, pes0);
 }
-BSX_API int oracle_align_main(int argc, char **argv) { return bsx_align_main_with(argc, argv, port_process, 0, port_open); }
+BSX_API int oracle_align_main(int argc, char **argv) { return bsx_align_main_ranks_with(argc, argv, port_process, 0, port_open, 0); }   /* (several processes: over sockets) */

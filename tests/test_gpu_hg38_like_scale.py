@@ -68,6 +68,79 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
         L.bsx_sim_free_reads(p, n)
 
 
+def test_long_region_lists_deduplicated_on_the_device(hard):
+    """C5 for the reads a lane of k_dedup cannot hold (more than 32 regions: against this genome 15 % of the reads, with 60 % of a chunk's
+    regions): bsx_regions_dedup2 (k_dedup_long, a wavefront per read -- ranks by counting, klib's own loop on one lane for lists with tied
+    keys, the redundancy scan 64 earlier regions at a time) against mem_sort_deduplicate as the host runs it (region.c through
+    bsx_hook_regs_sort_dedup), read by read, on the regions a regions batch left on the device."""
+    L = B.lib()
+    idx, dev = hard["idx"], hard["dev"]
+    L.bsx_sim_free_reads.argtypes = [C.c_void_p, C.c_int64]
+    n_pairs = 30000
+    n = 2 * n_pairs
+    p = _sim(idx, n_pairs, 4242, sub=0.01, pbat=0.2)
+    reads = C.cast(p, C.POINTER(B.Read))
+    opt = default_opt()
+    opt.flag |= 0x10 | 0x2
+    try:
+        seqs = [bytes(C.string_at(reads[i].seq, reads[i].l_seq)) for i in range(n)]
+        buf = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+        tasks = np.zeros(2 * n, dtype=SEED_DT)
+        for i in range(n):   # the reference's call order for -b 0 (bwamem.c:352-372): read 1 parent then daughter, read 2 daughter then parent
+            for k, par in enumerate((1, 0) if i % 2 == 0 else (0, 1)):
+                tasks[2 * i + k] = (offs[i], len(seqs[i]), par)
+        dev.set_opt(opt)
+        dev.set_reads(buf)
+        regs, roff, rn = dev.regions(opt, tasks)
+        cap, lcap = L.bsx_regions_dedup_cap(), L.bsx_regions_dedup_long_cap()
+        out_n = np.zeros(n, dtype=np.int32)
+        out_idx = np.zeros(n * cap, dtype=np.uint8)
+        loff = np.zeros(n, dtype=np.int64)
+        lidx, lc = C.c_void_p(), C.c_int64(0)
+        L.bsx_regions_dedup2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        B.check(L.bsx_regions_dedup2(dev.h, C.byref(opt), n, 2, out_n.ctypes.data_as(C.c_void_p), out_idx.ctypes.data_as(C.c_void_p), loff.ctypes.data_as(C.c_void_p),
+                                     C.byref(lidx), C.byref(lc)), "bsx_regions_dedup2")
+        pool = np.ctypeslib.as_array(C.cast(lidx, C.POINTER(C.c_uint16)), shape=(max(1, lc.value),)).copy() if lidx.value else np.zeros(1, dtype=np.uint16)
+        L.bsx_hook_regs_sort_dedup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.bsx_hook_regs_sort_dedup.restype = C.c_int
+        n_long = n_long_done = n_tied = biggest = dropped = n_over = 0
+        for i in range(n):
+            if rn[2 * i] < 0 or rn[2 * i + 1] < 0:
+                assert out_n[i] == -1
+                continue
+            cat = np.concatenate([regs[roff[2 * i]:roff[2 * i] + rn[2 * i]], regs[roff[2 * i + 1]:roff[2 * i + 1] + rn[2 * i + 1]]])
+            is_long = len(cat) > cap
+            n_long += is_long
+            n_over += len(cat) > lcap
+            if not is_long:
+                assert loff[i] == -1
+            if out_n[i] < 0:
+                continue
+            keep = np.zeros(max(1, len(cat)), dtype=np.int32)
+            m = L.bsx_hook_regs_sort_dedup(C.byref(opt), idx.h, cat.ctypes.data_as(C.c_void_p), len(cat), keep.ctypes.data_as(C.c_void_p))
+            assert m >= 0, i
+            if is_long:
+                assert loff[i] >= 0
+                got = pool[loff[i]:loff[i] + out_n[i]].astype(np.int32)
+                n_long_done += 1
+                biggest = max(biggest, len(cat))
+                n_tied += len(set(cat["re"].tolist())) < len(cat)
+                dropped += m < len(cat)
+            else:
+                got = out_idx[i * cap:i * cap + out_n[i]].astype(np.int32)
+            assert out_n[i] == m and (got == keep[:m]).all(), (i, len(cat), list(got[:40]), list(keep[:m][:40]))
+        # the long lists are there, most of them were finished on the device, lists with tied ends (klib's order of equal keys) among them
+        # (what is not: lists beyond the kernel's tables, and reads where two regions have to be aligned across the gap between them -- a quarter of
+        # the reads with a hundred regions have such a pair: the host's merge rounds, which batch those alignments)
+        assert n_long > 0.05 * n and n_long_done > 0.6 * n_long and n_tied > 50 and biggest > 200 and dropped > 100, (n_long, n_long_done, n_over, n_tied, biggest, dropped)
+        if lidx.value:
+            from biscuit_amd.api import _libc_free
+            _libc_free(lidx)
+    finally:
+        L.bsx_sim_free_reads(p, n)
+
+
 def test_hg38_like_full_chunk_properties(hard):
     """One full chunk of the bench (-@ 16: 1 066 666 reads) on the bench's hg38-like genome: every record of a sample valid against the
     genome, reads found where they were simulated from, the same chunk twice gives the same SAM (checksum of checksums), and the pipelined

@@ -56,6 +56,8 @@ def test_the_library_reads_few_environment_variables():
         for f in os.listdir(os.path.join(ROOT, d)):
             if f.endswith((".c", ".h", ".hip", ".hpp")):
                 names |= set(re.findall(r'getenv\("([A-Za-z_0-9]+)"\)', open(os.path.join(ROOT, d, f)).read()))
-    assert len(names) <= 12, sorted(names)
+    assert len(names) <= 20, sorted(names)
     assert names <= {"BSX_TUNE", "BSX_PHASES", "BSX_DEVICE", "BSX_HOST_THREADS", "BSX_INFLATE_THREADS", "BSX_STREAM_DEPTH", "BSX_NO_STREAM", "BSX_CHUNK_SIZE",
-                     "BSX_PROF_SAMPLE", "BSX_TRACE_ALLOC", "BSX_INDEX_TRACE"}, sorted(names)
+                     "BSX_PROF_SAMPLE", "BSX_TRACE_ALLOC", "BSX_INDEX_TRACE",
+                     # several processes (csrc/host/cli.c, bsx_align_main_ranks_with): what every launcher sets, where the output goes, where the ranks meet
+                     "RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "BSX_OUT", "BSX_GATHER_ID"}, sorted(names)
