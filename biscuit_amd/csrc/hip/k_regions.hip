@@ -1296,6 +1296,7 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 template <int QC, int WC, int XSD, int XRG = RG_XREGS>
 struct RgC2rT {
 	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
+	static const bool HBM = false;
 	unsigned long long pf[RG_NPF];
 	bsx_region_t regs[XRG];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
@@ -1312,6 +1313,29 @@ struct RgC2rT {
 };
 typedef RgC2rT<RG_QCAP, RG_WIN, RG_XSEEDS> RgC2r;
 typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;
+// The same workspace with its three large tables -- the regions made so far, the window over the record's seeds, the sort keys -- in a slab of
+// HBM per wave (round 6): for the strand searches of reads inside repeat families that outgrow RgC2rB (up to 1024 regions, 1024 seeds a list: what
+// the first HBM tier holds).  Until round 6 those went through that tier's monolithic form, whose extensions run inline, a wavefront each -- 58 % of
+// the tier's cycles, a quarter of all wave cycles of a chunk; through this launch their chains' extensions come from k_extl / k_ext4 (several
+// jobs to a wavefront, made ahead) and only the seed loop's bookkeeping pays HBM round trips.
+template <int QC, int WC, int XSD, int XRG>
+struct RgC2rHT {
+	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC;
+	static const bool HBM = true;
+	unsigned long long pf[RG_NPF];
+	bsx_region_t *regs;      // XRG entries in the wave's slab of HBM: written once per region, read a lane per region by the containment test
+	RgXChain xc[RG_XCBLK];
+	RgXExt xe[RG_XCBLK];
+	RgXSeed sd[XSD];         // (the seed window and its sort keys stay in LDS: the rank by counting reads every key once per seed)
+	unsigned long long srt[XSD];
+	uint8_t q[QC];
+	uint8_t win[WC];
+	int n_regs;
+	int32_t Hrow[1], Erow[1];
+	uint8_t qrow[4];
+	static constexpr size_t slab_bytes() { return (size_t)XRG * sizeof(bsx_region_t); }
+};
+typedef RgC2rHT<RG_QCAP, RG_WIN, 1024, 1024> RgC2rH;   // 27 KB of LDS: five workgroups of one wave per CU
 typedef RgC2rT<RG_QCAP, RG_WIN, 256, 256> RgC2rB;   // reads inside repeat families: up to 256 regions of a strand search, 256 seeds of a chain (22 KB: seven waves per CU); for what k_c2r<RgC2r> declines   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
 
 template <typename WT>
@@ -1326,6 +1350,15 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 	// reading each chain's record and lists where they lie was three per chain, twelve chains per strand search.
 	for (int i = lane; i < l_query; i += 64) W.q[i] = reads[qoff + i];
 	const int nk = uni(H->n_chains), n_sd = uni(H->n_seeds);
+	// routing, before anything is started: a strand search with more chains than this launch holds regions, or with a list longer than its seed
+	// window, goes on to the launch with larger tables (it would be declined half-way otherwise, its work done twice)
+	if (nk > 4 * WT::XREGS) return 6;
+	{
+		const RgXChain *XCh = (const RgXChain*)(H + 1);
+		int mx = 0;
+		for (int c = lane; c < nk; c += 64) { const int a = XCh[c].n_main, b = XCh[c].n_extra; mx = mx > a ? mx : a; mx = mx > b ? mx : b; }
+		if (uni(wave_max_i32(mx)) > WT::XSEEDS) return 2;
+	}
 	const float frac_rep = H->frac_rep;
 	const unsigned long long *XCw = (const unsigned long long*)(H + 1);                           // RgXChain = 3 words, RgXSeed = 2
 	const unsigned long long *XSw = XCw + (size_t)nk * (sizeof(RgXChain) / 8);
@@ -1879,7 +1912,7 @@ template <typename WT, int OCC>
 __global__ void __launch_bounds__(64 * C2R_WPB, OCC)
 k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_seed_task_t *tasks, RgXPool X,
       bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-      unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota)
+      unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, unsigned char *slab)
 {
 	__shared__ WT lds[C2R_WPB];
 	__shared__ int gap_tab[WT::GAPCAP + 1];
@@ -1892,6 +1925,11 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 	const int lane = wave_lane();
 	WT &W = lds[threadIdx.x >> 6];
 	RG_PF_ZERO(W);
+	if constexpr (WT::HBM) { // the large tables: this wave's slab
+		unsigned char *sl = slab + ((size_t)blockIdx.x * C2R_WPB + (threadIdx.x >> 6)) * WT::slab_bytes();
+		if (lane == 0) W.regs = (bsx_region_t*)sl;
+		WAVE_SYNC();
+	}
 	const int n = (int)*X.xcount;
 	// a wave takes `quota` strand searches and leaves (the launch covers the worst case): workgroups with a bounded life let the
 	// back half's short high-priority batches (k_sw, k_global) of an older chunk get compute units while this one runs
@@ -1906,6 +1944,21 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 		const RgXHdr *H = (const RgXHdr*)(X.base + uni64(X.xoff[t]));
 		int status = rg_c2r(W, ix, sc, P, reads, l_query, parent, qoff, H, lane, counters, gap_tab, ctg_tab);
 		WAVE_SYNC();
+		if constexpr (WT::HBM) { // publish: hundreds of regions, all lanes copy
+			const int nr = status ? 0 : uni(W.n_regs);
+			unsigned long long base = 0;
+			if (nr > 0) {
+				if (lane == 0) base = atomicAdd(out_cursor, (unsigned long long)nr);
+				base = (unsigned long long)uni64((long long)base);
+				if (base + nr <= out_cap) { const bsx_region_t *src = W.regs; for (int k = lane; k < nr; k += 64) out[base + k] = src[k]; }
+				else status = 7;
+			}
+			if (lane == 0) {
+				reg_off[t] = (long long)base;
+				reg_n[t] = status ? -status : nr;
+				if (next_list && (status == 2 || status == 6)) next_list[atomicAdd(next_count, 1u)] = t;
+			}
+		} else
 		if (lane == 0) { // publish (as rg_publish)
 			const int nr = status ? 0 : W.n_regs;
 			unsigned long long base = 0;
@@ -2194,6 +2247,7 @@ void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, u
 }
 
 size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }
+size_t c2r_hbm_slab_bytes(void) { return RgC2rH::slab_bytes() * C2R_WPB; }   // per workgroup of launch_c2r(.., long_reads = 3)
 
 void launch_regions(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                     const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,
@@ -2242,15 +2296,17 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
 }
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &XA, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads)
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads, void *slab)
 {
 	RgXPool X = rgx_pool(&XA);
-	if (long_reads == 2)   // ordinary reads with many regions or long seed lists: the strand searches k_c2r<RgC2r> declined (X names them)
-		hipLaunchKernelGGL((k_c2r<RgC2rB, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	if (long_reads == 3)   // ... and what that one declines too: the large tables in HBM (`slab`: c2r_hbm_slab_bytes() per wave of the grid)
+		hipLaunchKernelGGL((k_c2r<RgC2rH, 2>), dim3(grid), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)slab);
+	else if (long_reads == 2)   // ordinary reads with many regions or long seed lists: the strand searches k_c2r<RgC2r> declined (X names them)
+		hipLaunchKernelGGL((k_c2r<RgC2rB, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 	else if (long_reads)
-		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 	else
-	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota);
+	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 }
 void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads,
                          const bsx_seed_task_t *tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n,

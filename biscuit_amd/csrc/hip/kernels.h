@@ -80,7 +80,8 @@ void launch_regions_mid(hipStream_t st, int grid, const DevIndex &ix, const DevS
 // chains -> regions for everything the two launches above exported; what does not fit its tables goes on next_list
 void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                 const RgXPoolArg &X, bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
-                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads = 0);   // next_list may be null (long reads: what outgrows the tables is left to the caller)
+                unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads = 0, void *slab = nullptr);   // next_list may be null (long reads: what outgrows the tables is left to the caller)   // long_reads 2: larger LDS tables (what the first launch declines); 3: the large tables in HBM, `slab` = grid x c2r_hbm_slab_bytes()
+size_t c2r_hbm_slab_bytes(void);
 // C3 between the tiers and launch_c2r: the seed-SW filter of the exported strand searches it applies to (mem_flt_chained_seeds, memchain.c:537-568)
 void launch_seedsw(hipStream_t st, int grid, int n_cu, const DevIndex &ix, const DevScoring &sc, const RegParams &P, const uint8_t *reads, const bsx_seed_task_t *tasks,
                    const RgXPoolArg &XA, unsigned int *cursor, unsigned int *count_cursor, void *jobs, unsigned int job_cap, unsigned long long *counters);

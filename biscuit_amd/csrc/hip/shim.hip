@@ -34,7 +34,7 @@ struct Lane {
 	DevBuf qpack;            // the chunk's reads as base-3 digits for the seeding kernel (k_seedt.hip)
 	int64_t rb_tasks = 0;    // strand searches of the last regions batch (their regions, offsets and counts are still in regs / regmeta)
 	int flt_key[3] = {-1, -1, -1};   // what fltab was made for
-	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd, sswjobs;
+	DevBuf fltab, jobs, res, scratch, scratch2, out, aux, pool, regs, regmeta, slabs, slabs3, slabflags, redo, pos, posoff, xpool, xmeta, x4jobs, tags, mdpool, dd, sswjobs, c2rslab;
 	DevBuf small;          // counters[4] | out_cursor | task_cursor | region cursors
 	HostBuf hstage;        // pinned staging for bulk results
 	HostBuf pin;           // two pinned halves through which large host<->device copies are streamed
@@ -157,7 +157,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.qpack.release(); L.gath.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release(); L.c2rslab.release(); L.sswjobs.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -749,7 +749,9 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.qpack.reserve(seedt_pack_bytes(n))) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 33 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 45 + 64)) != BSX_OK) return rc;
+	const int c2rh_grid = d->n_cu * 5;   // workgroups of the chains -> regions launch with its tables in HBM (a slab each)
+	if ((rc = L.c2rslab.reserve((size_t)c2rh_grid * c2r_hbm_slab_bytes())) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 6 * regions_slab_bytes(2))) != BSX_OK) return rc;   // (the exporting form runs three workgroups per CU)
 	if ((rc = L.slabs3.reserve((size_t)huge_grid * 4 * regions_slab_bytes(3))) != BSX_OK) return rc;
 	// one u64 per seed occurrence of the chunk: ~125 per strand search against an hg38-sized genome (a 3-letter 19-mer has random
@@ -779,6 +781,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int *retry_l = (int*)((char*)L.regmeta.p + (size_t)n * 24);
 	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 28;
 	int *retry_c = (int*)((char*)L.regmeta.p + (((size_t)n * 29 + 3) & ~(size_t)3));   // what the first chains -> regions launch declines (ordinary chunks)
+	int *retry_h = retry_c + n, *xlist_t2 = retry_c + 2 * n, *retry_f = retry_c + 3 * n;   // round 6: what the second declines (-> the one with tables in HBM); the strand searches the first HBM tier exports; what takes that tier's full form
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
 	//                       [5] redo count [6] redo tier-3 cursor [7] redo seed task cursor  ([8],[9] = u64 slot 11: the K3 cursor)
@@ -797,6 +800,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipMemsetAsync(ctr + 20, 0, 8, L.st));   // (count and cursor of the second chains -> regions launch)
 	HIPCHK(hipMemsetAsync(ctr + 119, 0, 8, L.st));  // (the first seeding pass's count of strand searches to be seeded again)
+	HIPCHK(hipMemsetAsync(ctr + 70, 0, 80, L.st));  // (round 6: counts and cursors of the launches between the second chains -> regions launch and the last HBM tier)
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((uint32_t*)(ctr + 4) + 1), (int)(uint32_t)(direct_n >> 32), 1, L.st));
 	const int chain = (int)bsx_tune_long("chain_stages", 3);   // 0: none, 1: seeding, 2: seeding and regions, 3: the same but the HBM tiers (a few long strand searches on a few waves) hold nobody back (measured A/B on one box, 16 chunks: 1.76 / 1.81 M reads/s with 2, 2.00 / 1.89 M with 3)
@@ -887,7 +891,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int n_marks = 0; const char *mark_name[12];
 	auto run_tiers = [&](hipStream_t st, const bsx_seed_task_t *T, int64_t nT, const long long *offs, const int *cnts, long long *roffs, int *rns,
 	                     int *ra, int *rm, int *rb, unsigned int *k32, unsigned int *xc32, const RgXPoolArg &XP, const long long *posoffs,
-	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c, int *rc_list, unsigned int *rc32, unsigned int *ssw32) -> int {
+	                     const unsigned char *clsx, bool main_seq, int *rl, unsigned int *l_count, unsigned int *l_cursor, unsigned int *x4c, int *rc_list, unsigned int *rc32, unsigned int *ssw32,
+	                     int *rh_list, int *x2_list, int *rf_list, unsigned int *h32) -> int {
 		int rc2;
 		const int rgrid = (int)((nT + 4LL * reg_quota - 1) / (4LL * reg_quota));
 		// $BSX_PHASES: the main sequence's launches one by one (events between them)
@@ -986,7 +991,11 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// chains -> regions of everything the two LDS tiers exported; what outgrows its tables joins the list of the HBM tiers.
 		// (The first HBM tier exporting its chains as well -- 156 instead of 225 VGPRs, its chains through k_c2r with everybody else's -- was
 		// measured in rounds 3 and 4 and removed: what k_c2r cannot hold, 64 regions and 128 seeds a chain, takes the full form afterwards anyway,
-		// 1468 against 1287 ms per chunk on the hg38-like genome.)
+		// 1468 against 1287 ms per chunk on the hg38-like genome.  Round 6 takes it up again with a chains -> regions launch that CAN hold them:)
+		//
+		// h32 (u32): [0] what the second chains -> regions launch declines [1] the third's cursor | [4] what takes the HBM tier's full form [5] its
+		// cursor | [6] the exporting launch's cursor
+		const int t2x = (int)bsx_tune_long("tier2_export", 0) && tier1c && XP.ext;   // 1: the first HBM tier in steps (below) instead of its monolithic form (chains, filter and extensions inline in one launch)
 		if (XP.ext) {
 			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
@@ -995,6 +1004,12 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rc_list, rc32, ctr, c2r_quota);
 			RgXPoolArg XB2 = XP;
 			XB2.xlist = rc_list; XB2.xcount = rc32;
+			if (t2x) { // ... and what THAT declines (up to 1024 regions, 1024 seeds a list) a third, the regions it makes in HBM: the record and its extensions are there
+				launch_c2r(st, d->n_cu * 2, d->ix, L.sc, R, d_reads, T, XB2, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rc32 + 1, rh_list, h32 + 0, ctr, 1 << 30, 2);
+				RgXPoolArg XB3 = XP;
+				XB3.xlist = rh_list; XB3.xcount = h32 + 0;
+				launch_c2r(st, c2rh_grid, d->ix, L.sc, R, d_reads, T, XB3, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, h32 + 1, rf_list, h32 + 4, ctr, 1 << 30, 3, L.c2rslab.p);
+			} else
 			launch_c2r(st, d->n_cu * 2, d->ix, L.sc, R, d_reads, T, XB2, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rc32 + 1, to2, n2c, ctr, 1 << 30, 2);   // (few strand searches, long ones: persistent waves)
 		} else
 		launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, to2, n2c, ctr, c2r_quota);
@@ -1004,6 +1019,24 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			d->chain_regions = L.ev_regions_done;
 		}
 		TIER_MARK("chains -> regions");
+		if (t2x) {
+			// The first HBM tier in steps (round 6, "tier2_export=1"; measured and not the default).  What outgrew the LDS tiers'
+			// tables is chained and filtered over the tier's slabs and EXPORTED like the LDS tiers' strand searches; its chains' best seeds are extended
+			// ahead, several jobs to a wavefront (k_extl / k_ext4) -- inline, a wavefront each, the extensions are 58 % of the tier's cycles --; the seed
+			// loop is run by the chains -> regions launch that keeps up to 1024 regions in HBM.  Only what even that cannot hold takes the tier's
+			// monolithic form; what outgrows the tier's tables goes on to the last tier as before.
+			RgXPoolArg XT = XP;
+			XT.xlist = x2_list; XT.xcount = h32 + 2;
+			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, h32 + 6, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XT);
+			TIER_MARK("tier 2 (chains)");
+			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XT, L.x4jobs.p, x4_cap, h32 + 8, nullptr);
+			TIER_MARK("tier 2 (extensions)");
+			launch_c2r(st, c2rh_grid, d->ix, L.sc, R, d_reads, T, XT, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, h32 + 3, rf_list, h32 + 4, ctr, 1 << 30, 3, L.c2rslab.p);
+			TIER_MARK("tier 2 (chains -> regions)");
+			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
+			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rf_list, h32 + 4, h32 + 5, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
+		} else
 		launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
 		TIER_MARK("tier 2");
@@ -1012,7 +1045,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		TIER_MARK("tier 3");
 		return BSX_OK;
 	};
-	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16), retry_c, (unsigned int*)(ctr + 20), (unsigned int*)(ctr + 15))) != BSX_OK) return rc;
+	if ((rc = run_tiers(L.st, d_tasks, n, d_off, d_n, r_off, r_n, retry_a, retry_m, retry_b, c32, (unsigned int*)(ctr + 14), XA, d_posoff, d_cls, true, retry_l, c32 + 6, c32 + 7, (unsigned int*)(ctr + 16), retry_c, (unsigned int*)(ctr + 20), (unsigned int*)(ctr + 15),
+	                    retry_h, xlist_t2, retry_f, (unsigned int*)(ctr + 70))) != BSX_OK) return rc;
 
 	if (chain == 2 || chain >= 4) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
@@ -1059,25 +1093,28 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			for (size_t j = 0; j < n2; ++j) L.rs.sub[j] = tasks[redo[j]];
 			// device side, per re-seeded strand search: task | interval offset | region offset | position offset | export offset | interval
 			// count | region count | three tier lists | export list | tier class
-			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 1) + 1024)) != BSX_OK) return rc;
+			if ((rc = L.redo.reserve(n2 * (sizeof(bsx_seed_task_t) + 8 + 8 + 8 + 8 + 4 + 4 + 16 + 4 + 4 + 12 + 1) + 1024)) != BSX_OK) return rc;
 			if ((rc = L.rs.hres.reserve(n2 * 12 + 64)) != BSX_OK) return rc;
 			bsx_seed_task_t *t2 = (bsx_seed_task_t*)L.redo.p;
 			long long *off2 = (long long*)(t2 + n2); long long *roff2 = off2 + n2; long long *posoff2 = roff2 + n2; long long *xoff2 = posoff2 + n2;
 			int *cnt2 = (int*)(xoff2 + n2); int *rn2 = cnt2 + n2; int *ra2 = rn2 + n2, *rm2 = ra2 + n2, *rb2 = rm2 + n2, *rl2 = rb2 + n2, *xlist2 = rl2 + n2, *rc2l = xlist2 + n2;
-			unsigned char *cls2 = (unsigned char*)(rc2l + n2);
+			int *rh2 = rc2l + n2, *x22 = rh2 + n2, *rf2 = x22 + n2;
+			unsigned char *cls2 = (unsigned char*)(rf2 + n2);
 			// its own cursors (u64 slots 96.. of the lane's counter block): u32 [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3
 			// count [4] tier-3 cursor [7] seed task cursor [10] count of what the larger LDS tier hands on [11] its cursor; slot 102: exported
 			// count | k_c2r cursor; slot 103: where its ranks start in the position pool
 			unsigned int *q32 = (unsigned int*)(ctr + 96);
 			HIPCHK(hipMemcpyAsync(t2, L.rs.sub.data(), n2 * sizeof(bsx_seed_task_t), hipMemcpyHostToDevice, L.st2));
 			HIPCHK(hipMemsetAsync(ctr + 96, 0, 80, L.st2));
+			HIPCHK(hipMemsetAsync(ctr + 80, 0, 80, L.st2));
 			launch_seed(L.st2, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
 			            off2, cnt2, q32 + 7, ctr + SEED3_CTR, 0, (unsigned int*)L.slabflags.p, g2 * 4, 0, 0, (uint32_t*)L.qpack.p);   // (the main launch is over: its packed reads are no longer needed)
 			HIPCHK(hipStreamWaitEvent(L.st2, L.rs.ev_tiers, 0));   // the slabs of the HBM tiers and the export pool's lists are shared with the main launch sequence
 			RgXPoolArg XB = XA;
 			XB.xoff = xoff2; XB.xlist = xlist2; XB.xcount = (unsigned int*)(ctr + 102);
 			launch_occ(L.st2, d->n_cu, d->ix, t2, (int)n2, (const DevIntv*)L.out.p, off2, cnt2, opt->max_occ, d_pos, pos_cap, ctr + 11, posoff2, ctr, cls2, ctr + 103);
-			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18), rc2l, (unsigned int*)(ctr + 104), (unsigned int*)(ctr + 105))) != BSX_OK) return rc;
+			if ((rc = run_tiers(L.st2, t2, (int64_t)n2, off2, cnt2, roff2, rn2, ra2, rm2, rb2, q32, (unsigned int*)(ctr + 102), XB, posoff2, cls2, false, rl2, q32 + 6, q32 + 8, (unsigned int*)(ctr + 18), rc2l, (unsigned int*)(ctr + 104), (unsigned int*)(ctr + 105),
+				                    rh2, x22, rf2, (unsigned int*)(ctr + 80))) != BSX_OK) return rc;
 			HIPCHK(hipMemcpyAsync(L.rs.hres.p, roff2, n2 * 8, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipMemcpyAsync((char*)L.rs.hres.p + n2 * 8, rn2, n2 * 4, hipMemcpyDeviceToHost, L.st2));
 			HIPCHK(hipEventRecord(L.rs.ev, L.st2));

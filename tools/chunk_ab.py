@@ -43,10 +43,10 @@ def main():
     import time
     for cfg in a.cfgs:
         kv = dict(x.split("=", 1) for x in cfg.split())
-        names = set(B.tune_names())
+        tnames = set(B.tune_names())
         for k, v in kv.items():   # a setting of the library (name or the BSX_NAME it was as an environment variable), else a real environment variable
             low = k[4:].lower() if k.startswith("BSX_") else k.lower()
-            if low in names:
+            if low in tnames:
                 B.tune(low, v)
             else:
                 os.environ[k] = v
@@ -67,7 +67,7 @@ def main():
         print("%-50s %s | chunk %.0f ms" % (cfg or "(defaults)", " ".join("%s %.1f" % (names[k], dev.kernel_time(k)[0] / a.reps) for k in range(8)), dt * 1e3) + (" | sam crc %08x" % crc if crc is not None else ""), flush=True)
         for k in kv:
             low = k[4:].lower() if k.startswith("BSX_") else k.lower()
-            if low in names:
+            if low in tnames:
                 B.tune(low, None)
             else:
                 os.environ.pop(k, None)
