@@ -1320,7 +1320,7 @@ typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;
 // jobs to a wavefront, made ahead) and only the seed loop's bookkeeping pays HBM round trips.
 template <int QC, int WC, int XSD, int XRG>
 struct RgC2rHT {
-	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC;
+	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;
 	static const bool HBM = true;
 	unsigned long long pf[RG_NPF];
 	bsx_region_t *regs;      // XRG entries in the wave's slab of HBM: written once per region, read a lane per region by the containment test
@@ -1331,11 +1331,12 @@ struct RgC2rHT {
 	uint8_t q[QC];
 	uint8_t win[WC];
 	int n_regs;
-	int32_t Hrow[1], Erow[1];
-	uint8_t qrow[4];
+	int32_t Hrow[QC > RG_QCAP ? QC + 2 : 1], Erow[QC > RG_QCAP ? QC + 2 : 1];   // (long reads: the extension's rows in LDS, as in RgC2rT)
+	uint8_t qrow[QC > RG_QCAP ? QC : 4];
 	static constexpr size_t slab_bytes() { return (size_t)XRG * sizeof(bsx_region_t); }
 };
 typedef RgC2rHT<RG_QCAP, RG_WIN, 1024, 1024> RgC2rH;   // 27 KB of LDS: five workgroups of one wave per CU
+typedef RgC2rHT<RG_QCAP_LONG, 1536, 1024, 1024> RgC2rHL;   // reads up to a kilobase: what k_c2r<RgC2rL> declines (64 regions, 256 seeds a list) -- chained on the host until round 6
 typedef RgC2rT<RG_QCAP, RG_WIN, 256, 256> RgC2rB;   // reads inside repeat families: up to 256 regions of a strand search, 256 seeds of a chain (22 KB: seven waves per CU); for what k_c2r<RgC2r> declines   // reads up to a kilobase: a chain's window is the read plus its two gaps, a true chain has a few hundred seeds
 
 template <typename WT>
@@ -2299,7 +2300,9 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
                 unsigned int *cursor, int *next_list, unsigned int *next_count, unsigned long long *counters, int quota, int long_reads, void *slab)
 {
 	RgXPool X = rgx_pool(&XA);
-	if (long_reads == 3)   // ... and what that one declines too: the large tables in HBM (`slab`: c2r_hbm_slab_bytes() per wave of the grid)
+	if (long_reads == 4)   // chunks with long reads: what k_c2r<RgC2rL> declines
+		hipLaunchKernelGGL((k_c2r<RgC2rHL, 1>), dim3(grid), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)slab);
+	else if (long_reads == 3)   // ... and what that one declines too: the large tables in HBM (`slab`: c2r_hbm_slab_bytes() per wave of the grid)
 		hipLaunchKernelGGL((k_c2r<RgC2rH, 2>), dim3(grid), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)slab);
 	else if (long_reads == 2)   // ordinary reads with many regions or long seed lists: the strand searches k_c2r<RgC2r> declined (X names them)
 		hipLaunchKernelGGL((k_c2r<RgC2rB, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);

@@ -984,7 +984,14 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 				fprintf(stderr, "[xcheck] %ld bad\n", n_bad);
 			}
 #endif
-			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, nullptr, nullptr, ctr, c2r_quota, long_reads);
+			// (what outgrows the launch's tables -- 64 regions of a strand search, 256 seeds of a list -- gets a second one with up to 1024 of each, the
+			// regions in HBM; round 6: those were forty strand searches per chunk of kilobase reads chained on the host, a second of its time each chunk)
+			launch_c2r(st, c2r_grid, d->ix, L.sc, R, d_reads, T, XP, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, xc32 + 1, rh_list, h32 + 0, ctr, c2r_quota, long_reads);
+			{
+				RgXPoolArg XB3 = XP;
+				XB3.xlist = rh_list; XB3.xcount = h32 + 0;
+				launch_c2r(st, d->n_cu * 2, d->ix, L.sc, R, d_reads, T, XB3, (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, h32 + 1, nullptr, nullptr, ctr, 1 << 30, 4, L.c2rslab.p);
+			}
 			TIER_MARK("chains -> regions");
 			return BSX_OK;
 		}
