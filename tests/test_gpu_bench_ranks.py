@@ -48,3 +48,31 @@ def test_single_rank_bench_line_small():
     assert w["algorithmic_bytes_per_step"] >= r["algorithmic_bytes_per_launch"] + s["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["sam_identical"] is True and c["sam_crc32_cpu"] == c["sam_crc32_hip"] and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_real_genome_hook(tmp_path):
+    """"vs hg38 index (pre-built files at $BISCUIT_HG38_INDEX; if absent, a synthetic 3.1 Gbp genome ...)".  bench.py takes
+    the real genome when the box has it -- index files at $BISCUIT_HG38_INDEX, or the FASTA at $BISCUIT_HG38_FA indexed on the GPU -- and says so
+    in `data` and `config.workload`; with neither (or an incomplete file set) it falls back and says that.  A small genome stands in for hg38."""
+    import simdata
+    from biscuit_amd.api import Index
+    d = str(tmp_path)
+    simdata.write_genome(d + "/g.fa", simdata.make_genome(3000000, seed=31, n_contigs=3))
+    Index.build(d + "/g.fa", d + "/g").close()
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--threads", "1", "--cpu-sample-pairs", "1000",
+            "--no-long-reads", "--no-cli", "--no-hard-genome"]
+    env = {k: v for k, v in os.environ.items() if k not in ("BISCUIT_HG38_INDEX", "BISCUIT_HG38_FA", "BSX_BENCH_GENOME_MBP")}
+    for how, e in (("index", {"BISCUIT_HG38_INDEX": d + "/g"}), ("fasta", {"BISCUIT_HG38_FA": d + "/g.fa"})):
+        p = subprocess.run(base, cwd=ROOT, env=dict(env, **e), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+        assert r["data"].startswith("real genome") and "synthetic reads" in r["data"], r["data"]
+        assert "THE REAL GENOME" in r["config"]["workload"] and "SYNTHETIC" not in r["config"]["workload"]
+        assert r["value"] > 0 and r["cpu_baseline"]["sam_identical"] is True
+        assert abs(r["config"]["index_bytes_in_hbm"] / (2 * (3e6 * 2 / 128 * 64 + 3e6 * 2 / 2 * 8) + 3e6 / 4) - 1) < 0.01   # the 3 Mbp genome is what is resident
+    # an incomplete file set is reported and the synthetic genome takes over (a --genome-mbp given on the command line never looks at the hook)
+    os.remove(d + "/g.dau.sa")
+    p = subprocess.run(base + ["--no-cpu-baseline", "--genome-mbp", "8"], cwd=ROOT, env=dict(env, BISCUIT_HG38_INDEX=d + "/g"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert r["data"] == "synthetic" and "SYNTHETIC 8 Mbp" in r["config"]["workload"]
