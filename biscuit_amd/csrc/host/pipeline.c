@@ -505,8 +505,8 @@ static int merge_regions(chunk_t *C)
 typedef struct { int i, j; bsx_sw_job_t job; bsx_sw_res_t res; int have; } msw_slot_t;
 typedef struct {
 	reg_v saved[2]; int have_saved;
-	BSX_VEC(msw_slot_t) slots;
-	int pending;
+	BSX_VEC(msw_slot_t) slots;   /* in the order the candidates (i, j) are visited: every pass visits them in that order */
+	int pending, cur;            /* cur: where the pass's next candidate is expected in slots */
 } msw_pair_t;
 
 static int g_msw_prof = 0;                       /* $BSX_PHASES: where mate rescue's host time goes */
@@ -532,7 +532,10 @@ static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const re
 	if (l_ms <= 0) return 0;   /* a mate clipped away entirely: ksw_align2 of an empty query scores 0 and reports no start (ksw.c:343-365), so nothing is added */
 	parent = reg->bss ^ (reg->rb < l_pac);
 	xtra = BSX_KSW_XSUBO | BSX_KSW_XSTART | (l_ms * opt->a < 250 ? BSX_KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
-	for (k = 0; k < M->slots.n; ++k) if (M->slots.a[k].i == i && M->slots.a[k].j == j) { slot = &M->slots.a[k]; break; }
+	/* (a pass asks for its candidates' slots in the order an earlier pass made them: the next one is almost always the one wanted -- the search
+	 * over all slots of the pair was 5 000 comparisons a pair for a read inside a repeat family) */
+	if ((size_t)M->cur < M->slots.n && M->slots.a[M->cur].i == i && M->slots.a[M->cur].j == j) slot = &M->slots.a[M->cur++];
+	else for (k = 0; k < M->slots.n; ++k) if (M->slots.a[k].i == i && M->slots.a[k].j == j) { slot = &M->slots.a[k]; M->cur = (int)k + 1; break; }
 	if (!slot) {
 		msw_slot_t s;
 		memset(&s, 0, sizeof(s));
@@ -590,9 +593,12 @@ static int matesw_replay(chunk_t *C, msw_pair_t *M, int pi)
 		else { regs_copy(&pair[0], &M->saved[0]); regs_copy(&pair[1], &M->saved[1]); }
 	}
 	memset(good, 0, sizeof(good));
+	M->cur = 0;
 	for (i = 0; i < 2; ++i) {
 		good[i].a = small[i]; good[i].m = 8;
-		for (j = 0; j < pair[i].n; ++j)
+		/* (the reference copies every region within pen_unpaired of the best and then looks at the first max_matesw of the copies: only those
+		 * are copied here -- a read inside a repeat family has two hundred) */
+		for (j = 0; j < pair[i].n && (int)good[i].n < opt->max_matesw; ++j)
 			if (pair[i].a[j].score >= pair[i].a[0].score - opt->pen_unpaired) {
 				if (good[i].n == good[i].m) {
 					reg_t *na = (reg_t*)malloc(sizeof(reg_t) * (good[i].m << 1));
