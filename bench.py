@@ -565,7 +565,7 @@ def main():
                          "--cpu-sample-pairs", str(max(1000, args.cpu_sample_pairs // 5))], 1500)
             if not args.no_long_reads:
                 # (a chunk is 160 Mbp of reads: 160 k of them; the CPU baseline's sample is 6 000 reads)
-                sub_run("long_reads", ["--genome-profile", "clean", "--single-end", "--read-len", "1000", "--steps", "3", "--warmup", "1", "--cpu-sample-pairs", "3000"], 1200)
+                sub_run("long_reads", ["--genome-profile", "clean", "--single-end", "--read-len", "1000", "--steps", "6", "--warmup", "2", "--cpu-sample-pairs", "3000"], 1200)   # (three steps were a fill and a drain: 61-75 k reads/s from box to box)
             if not args.no_cli:
                 try:
                     pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_e2e.py"), "--genome-mbp", str(synth_mbp), "--profile", "1" if args.genome_profile == "hg38-like" else "0",
