@@ -88,7 +88,7 @@ class GlbTag(C.Structure):
 
 class Backend(C.Structure):  # bsx_backend_t (csrc/host/bsx_core.h)
     _fields_ = [("ctx", C.c_void_p), ("name", C.c_char_p)] + [(n, C.c_void_p) for n in
-                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "global_batch_tags", "regions_batch", "regions_finish", "regions_dedup")] + [("dedup_cap", C.c_int), ("regions_dedup2", C.c_void_p)]
+                ("set_opt", "set_reads", "seed_batch", "sa_batch", "extend_batch", "sw_batch", "global_batch", "global_batch_tags", "regions_batch", "regions_finish", "regions_dedup")] + [("dedup_cap", C.c_int), ("regions_dedup2", C.c_void_p), ("msw_plan", C.c_void_p)]
 
 
 class PhaseStats(C.Structure):

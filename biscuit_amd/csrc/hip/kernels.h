@@ -109,3 +109,11 @@ int dedup_long_cap(void);
 void launch_dedup_long(hipStream_t st, int n_cu, const bsx_region_t *regs, const long long *reg_off, const int *reg_n, int n_reads, int per_read,
                        long long l_pac, int max_chain_gap, int opt_w, float mask_level_redun, const int *long_list, const unsigned int *long_count,
                        int *out_n, long long *out_off, unsigned short *pool, unsigned long long pool_cap, unsigned long long *pool_cursor);
+
+// mate rescue's plan on the device (k_msw.hip): candidates -> jobs (binned for k_swl) + a record per pair
+size_t msw_pair_bytes(void);
+int msw_hist_bins(void);
+void launch_msw_plan(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_region_t *regs, const long long *r_off, const int *r_n,
+                     const int *dd_n, const unsigned char *dd_idx, const long long *dd_off, const unsigned short *dd_pool, int dd_cap, int per_read,
+                     const unsigned int *roff, int low, int high, int pen_unpaired, int max_matesw, int min_seed_len, int a, int p0, int n_pairs,
+                     bsx_sw_job_t *jobs, unsigned int job_cap, unsigned int *job_count, unsigned int *hist, void *table, int *order);

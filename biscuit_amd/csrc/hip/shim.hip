@@ -53,6 +53,9 @@ struct Lane {
 	double k_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int64_t k_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	uint64_t work[5] = {0, 0, 0, 0, 0};   // the region kernels' work since the last reset: strand searches, SA intervals, occurrences, regions, read bases
+	// what the last de-duplication of this lane left in `dd` (k_msw.hip reads the reads' lists from there): layout and validity
+	struct { bool valid = false; int64_t n_reads = 0; int per_read = 0; size_t o_idx = 0, o_off = 0, o_pool = 0; bool with_long = false; } ddl;
+	DevBuf msw_jobs, msw_res, msw_meta, msw_roff; int64_t msw_token = -1;
 	std::mutex hi_mu;      // the back half's batches (K5, K6) of this lane, one at a time: the slices of a chunk's back half call them from two threads
 	long last_overflow = -1;   // strand searches the first seeding pass of this lane's last chunk left to the second (-1: no chunk yet)
 	double seed2_ms = 0; int64_t seed2_launches = 0; uint64_t seed2_tasks = 0;   // the second seeding pass inside the chunk's sequence (its own launch, its own counters: SEED2_CTR)
@@ -157,7 +160,7 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 	for (int l = 0; l < BSX_LANES; ++l) {
 		Lane &L = d->lane[l];
 		L.reads.release(); L.qpack.release(); L.gath.release(); L.jobs.release(); L.res.release(); L.scratch.release(); L.scratch2.release(); L.out.release(); L.aux.release(); L.pool.release();
-		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release(); L.c2rslab.release(); L.sswjobs.release();
+		L.small.release(); L.hstage.release(); L.regs.release(); L.regmeta.release(); L.slabs.release(); L.slabflags.release(); L.slabs3.release(); L.redo.release(); L.pin.release(); L.pos.release(); L.posoff.release(); L.xpool.release(); L.xmeta.release(); L.x4jobs.release(); L.fltab.release(); L.flt_key[0] = -1; L.tags.release(); L.mdpool.release(); L.dd.release(); L.c2rslab.release(); L.sswjobs.release(); L.msw_jobs.release(); L.msw_res.release(); L.msw_meta.release(); L.msw_roff.release();
 		if (L.pev[0]) (void)hipEventDestroy(L.pev[0]);
 		if (L.pev[1]) (void)hipEventDestroy(L.pev[1]);
 		if (L.ev0) (void)hipEventDestroy(L.ev0);
@@ -796,6 +799,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	const uint8_t *d_reads = (const uint8_t*)L.reads.p;
 	const bsx_seed_task_t *d_tasks = (const bsx_seed_task_t*)L.jobs.p;
 	L.rb_tasks = n;
+	L.ddl.valid = false;
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipMemsetAsync(ctr + 20, 0, 8, L.st));   // (count and cursor of the second chains -> regions launch)
@@ -1523,6 +1527,7 @@ static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipMemsetAsync(d_cnt, 0, 16, L.st));
 		HIPCHK(hipMemsetAsync(d_off, 0xff, (size_t)n_reads * 8, L.st));   // -1: the read's list (if it has one) is among the short ones
 	}
+	L.ddl.valid = true; L.ddl.n_reads = n_reads; L.ddl.per_read = per_read; L.ddl.o_idx = o_idx; L.ddl.o_off = o_off; L.ddl.o_pool = o_pool; L.ddl.with_long = with_long;
 	launch_dedup(L.st, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun, d_n, d_idx, d_list, d_cnt);
 	if (with_long)
 		launch_dedup_long(L.st, d->n_cu, (const bsx_region_t*)L.regs.p, r_off, r_n, (int)n_reads, per_read, (long long)d->ix.l_pac, opt->max_chain_gap, opt->w, opt->mask_level_redun,
@@ -1540,6 +1545,71 @@ static int lane_regions_dedup(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (used) D2H(L.st, *long_idx, (char*)L.dd.p + o_pool, (size_t)used * 2);
 		if (bsx_phases()) fprintf(stderr, "[M::regions_dedup] a wavefront per read: %u reads of up to 256 regions, %u of up to %d; %llu regions kept\n", hc[0], hc[1], dedup_long_cap(), used);
 	} else if (long_off) for (int64_t i = 0; i < n_reads; ++i) long_off[i] = -1;
+	return BSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// mate rescue's plan + its K5 batch on the device (k_msw.hip), for the pairs [p0, p1) of the chunk whose reads the lane last de-duplicated.
+// Returns BSX_OK and *n_jobs >= 0, or *n_jobs = -1 when the plan does not apply (the caller plans on the host as before): no
+// de-duplication state for these reads, reads too long for the byte-sized kernel, more than 64 candidates a read.
+// ------------------------------------------------------------------------------------------
+static int lane_msw_plan(bsx_device_t *d, int lane, const bsx_opt_t *opt, const bsx_pestat_t *pes, int64_t token, int64_t n_reads, int per_read,
+                         const uint32_t *roff, int max_len, int p0, int p1, void *table, bsx_sw_res_t **res, int64_t *res_cap, int64_t *n_jobs)
+{
+	if (!d || !d->has_index) return BSX_E_NODEVICE;
+	Lane &L = d->lane[lane];
+	*n_jobs = -1;
+	if (p1 <= p0) { *n_jobs = 0; return BSX_OK; }
+	if (!bsx_tune_long("msw_plan", 0)) return BSX_OK;   // (built, bit-identical, measured slower than the host's plan pass: off unless asked for -- DESIGN.md section 4)
+	if (!L.ddl.valid || L.ddl.n_reads != n_reads || L.ddl.per_read != per_read || n_reads * per_read != L.rb_tasks) return BSX_OK;
+	if (max_len <= 0 || max_len > 256 || (long long)max_len * opt->a >= 250 || opt->max_matesw > 64 || opt->max_matesw < 1 || (opt->flag & BSX_F_SELF_OVLP)) return BSX_OK;
+	std::lock_guard<std::mutex> hi_lock(L.hi_mu);
+	HIPCHK(hipSetDevice(d->ordinal));
+	int rc;
+	const int np = p1 - p0, MM = opt->max_matesw;
+	const size_t job_cap = (size_t)np * 2 * (size_t)MM;
+	const size_t tb = (size_t)np * msw_pair_bytes(), o_hist = (tb + 255) & ~(size_t)255, o_cnt = o_hist + (size_t)msw_hist_bins() * 4, o_ord = o_cnt + 256;
+	if ((rc = L.msw_jobs.reserve(job_cap * sizeof(bsx_sw_job_t) + 64)) != BSX_OK) return rc;
+	if ((rc = L.msw_res.reserve(job_cap * sizeof(bsx_sw_res_t) + 64)) != BSX_OK) return rc;
+	if ((rc = L.msw_meta.reserve(o_ord + job_cap * 4 + 64)) != BSX_OK) return rc;
+	if (L.msw_token != token) { // the chunk's read offsets, once per chunk
+		if ((rc = L.msw_roff.reserve(((size_t)n_reads + 1) * 4)) != BSX_OK) return rc;
+		H2D(L.st_hi, L.msw_roff.p, roff, ((size_t)n_reads + 1) * 4);
+		L.msw_token = token;
+	}
+	char *M = (char*)L.msw_meta.p;
+	unsigned int *d_hist = (unsigned int*)(M + o_hist), *d_cnt = (unsigned int*)(M + o_cnt);
+	int *d_ord = (int*)(M + o_ord);
+	HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)msw_hist_bins() * 4 + 256, L.st_hi));
+	const int64_t n = L.rb_tasks;
+	const long long *r_off = (const long long*)L.regmeta.p; const int *r_n = (const int*)((const char*)L.regmeta.p + (size_t)n * 8);
+	const char *DD = (const char*)L.dd.p;
+	launch_msw_plan(L.st_hi, d->n_cu, d->ix, (const bsx_region_t*)L.regs.p, r_off, r_n, (const int*)DD, (const unsigned char*)DD + L.ddl.o_idx,
+	                L.ddl.with_long ? (const long long*)(DD + L.ddl.o_off) : nullptr, L.ddl.with_long ? (const unsigned short*)(DD + L.ddl.o_pool) : nullptr, dedup_cap(), per_read,
+	                (const unsigned int*)L.msw_roff.p, pes->low, pes->high, opt->pen_unpaired, MM, opt->min_seed_len, opt->a, p0, np,
+	                (bsx_sw_job_t*)L.msw_jobs.p, (unsigned int)std::min<size_t>(job_cap, 0xfffffff0u), d_cnt, d_hist, M, d_ord);
+	unsigned int nj = 0;
+	D2H(L.st_hi, &nj, d_cnt, 4);
+	if ((size_t)nj > job_cap) nj = (unsigned int)job_cap;
+	if (nj) {
+		const int blocks_cap = d->n_cu * 8;
+		long long bound = (long long)pes->high - (long long)pes->low + max_len + 8;   // no window is longer: re - rb <= high - low + l_ms
+		if (bound < 1) bound = 1;
+		if (bound > (1 << 20)) { *n_jobs = -1; return BSX_OK; }                       // (absurd insert-size bounds: the host's path sizes its scratch from the jobs)
+		if ((rc = L.scratch.reserve((size_t)blocks_cap * 4 * 4 * (size_t)bound * 8)) != BSX_OK) return rc;
+		const int blocks = (int)std::min<long long>(((long long)nj + 15) / 16, blocks_cap);
+		HIPCHK(hipEventRecord(L.ev0, L.st_hi));
+		launch_swl(L.st_hi, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_sw_job_t*)L.msw_jobs.p, (const int*)d_ord, (long long)nj,
+		           (bsx_sw_res_t*)L.msw_res.p, (unsigned long long*)L.scratch.p, (int)bound, blocks, (max_len + 15) / 16);
+		HIPCHK(hipEventRecord(L.ev1, L.st_hi));
+		if ((rc = finish_timed(L, 3)) != BSX_OK) return rc;
+		if (*res_cap < (int64_t)nj) { *res_cap = (int64_t)nj + (nj >> 2) + 1024; *res = (bsx_sw_res_t*)realloc(*res, sizeof(bsx_sw_res_t) * (size_t)*res_cap); }
+		D2H(L.st_hi, *res, L.msw_res.p, (size_t)nj * sizeof(bsx_sw_res_t));
+	}
+	D2H(L.st_hi, table, M, tb);
+	HIPCHK(hipGetLastError());
+	*n_jobs = (int64_t)nj;
+	if (bsx_phases()) fprintf(stderr, "[M::msw_plan] pairs %d..%d: %u alignments planned and run on the device\n", p0, p1, nj);
 	return BSX_OK;
 }
 
@@ -1694,6 +1764,9 @@ static int be_regions(void *c, const bsx_opt_t *o, int64_t n, const bsx_seed_tas
 }
 static int be_regions_finish(void *c, bsx_region_t **out, int64_t *cap, int64_t *off, int32_t *cnt) { return lane_regions_finish(LR(c), out, cap, off, cnt); }
 static int be_dedup(void *c, const bsx_opt_t *o, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx) { return lane_regions_dedup(LR(c), o, n_reads, per_read, out_n, out_idx); }
+static int be_msw_plan(void *c, const bsx_opt_t *o, const bsx_pestat_t *pes, int64_t token, int64_t n_reads, int per_read, const uint32_t *roff, int max_len,
+                       int p0, int p1, void *table, bsx_sw_res_t **res, int64_t *res_cap, int64_t *n_jobs)
+{ return lane_msw_plan(LR(c), o, pes, token, n_reads, per_read, roff, max_len, p0, p1, table, res, res_cap, n_jobs); }
 static int be_dedup2(void *c, const bsx_opt_t *o, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx, int64_t *long_off, uint16_t **long_idx, int64_t *long_cap)
 { return lane_regions_dedup(LR(c), o, n_reads, per_read, out_n, out_idx, long_off, long_idx, long_cap); }
 static int be_glb(void *c, int64_t n, const bsx_glb_job_t *j, bsx_glb_res_t *r, uint32_t *pool, size_t len) { return lane_global_batch(LR(c), n, j, r, pool, len); }
@@ -1717,6 +1790,7 @@ extern "C" int bsx_hip_backend_lane(bsx_device_t *dev, int lane, bsx_backend_t *
 	out->regions_dedup = out->regions_batch && !bsx_tune_long("host_dedup", 0) ? be_dedup : nullptr;   // BSX_HOST_DEDUP=1: C5 on the host for every read (A/B checks)
 	out->dedup_cap = dedup_cap();
 	out->regions_dedup2 = out->regions_dedup ? be_dedup2 : nullptr;
+	out->msw_plan = out->regions_dedup ? be_msw_plan : nullptr;
 	return BSX_OK;
 }
 extern "C" int bsx_hip_backend(bsx_device_t *dev, bsx_backend_t *out) { return bsx_hip_backend_lane(dev, 0, out); }

@@ -181,7 +181,15 @@ typedef struct bsx_backend {
 	 * read i's out_n[i] indices are 16-bit entries of *long_idx from there; -1 = they are in out_idx as above */
 	int (*regions_dedup2)(void *ctx, const bsx_opt_t *opt, int64_t n_reads, int per_read, int32_t *out_n, uint8_t *out_idx,
 	                      int64_t *long_off, uint16_t **long_idx, int64_t *long_cap);
+	/* optional, with regions_dedup: mate rescue's plan pass (mem_alnreg.c:385-419: which candidates of the pairs [p0, p1) need an alignment, over
+	 * which window) and its K5 batch, on the lists the de-duplication left on the device.  table: a bsx_msw_pair_t per pair; *n_jobs = -1: not
+	 * applicable, plan on the host.  token: changes with the chunk (the reads' offsets roff[0 .. n_reads] are uploaded once per chunk) */
+	int (*msw_plan)(void *ctx, const bsx_opt_t *opt, const bsx_pestat_t *pes, int64_t token, int64_t n_reads, int per_read, const uint32_t *roff, int max_len,
+	                int p0, int p1, void *table, bsx_sw_res_t **res, int64_t *res_cap, int64_t *n_jobs);
 } bsx_backend_t;
+/* what msw_plan says about a pair: base = its first job in res (-1: the pair is left to the host's own plan), n_c[i] = candidates of read i it
+ * looked at, mask[i] = which of them have a job (bit j: candidate j), in job order: read 0's, then read 1's */
+typedef struct { int32_t base, n_c[2], pad; uint64_t mask[2]; } bsx_msw_pair_t;
 
 /* mem_process_seqs equivalent over an arbitrary backend (the product passes the HIP backend;
  * tests may pass the CPU restatement that lives under oracle/) */

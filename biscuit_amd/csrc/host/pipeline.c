@@ -123,6 +123,7 @@ typedef struct {
 	pthread_t th; int th_live;   /* the thread running the front half (stream mode) */
 	int back_done;               /* ... which ran the back half too */
 	int merged;                  /* the per-read merge (C5) already ran at the end of the front half, on its thread */
+	int64_t token; int max_len;  /* a number of its own (the backend keeps per-chunk uploads by it); the longest clipped read */
 	double t_begin, t_front_end;
 	bsx_phase_stats_t st;
 } chunk_t;
@@ -534,6 +535,7 @@ static int matesw_core(chunk_t *C, msw_pair_t *M, int pi, int i, int j, const re
 	xtra = BSX_KSW_XSUBO | BSX_KSW_XSTART | (l_ms * opt->a < 250 ? BSX_KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
 	/* (a pass asks for its candidates' slots in the order an earlier pass made them: the next one is almost always the one wanted -- the search
 	 * over all slots of the pair was 5 000 comparisons a pair for a read inside a repeat family) */
+	while ((size_t)M->cur < M->slots.n && (M->slots.a[M->cur].i < i || (M->slots.a[M->cur].i == i && M->slots.a[M->cur].j < j))) ++M->cur;   /* (slots of candidates this pass skipped) */
 	if ((size_t)M->cur < M->slots.n && M->slots.a[M->cur].i == i && M->slots.a[M->cur].j == j) slot = &M->slots.a[M->cur++];
 	else for (k = 0; k < M->slots.n; ++k) if (M->slots.a[k].i == i && M->slots.a[k].j == j) { slot = &M->slots.a[k]; M->cur = (int)k + 1; break; }
 	if (!slot) {
@@ -666,16 +668,55 @@ static void msw_free_worker(void *data, long pi, int tid)
 	bsx_cfree(P->M[pi].saved[0].a); bsx_cfree(P->M[pi].saved[1].a); bsx_vec_free(P->M[pi].slots);
 }
 
+/* the device's plan (k_msw.hip) into the pairs' slots: every alignment the first pass would have asked for is there with its result, in the
+ * order the replay visits its candidates */
+typedef struct { msw_pair_t *M; const bsx_msw_pair_t *tab; const bsx_sw_res_t *res; } msw_fill_t;
+static void msw_fill_worker(void *data, long k, int tid)
+{
+	msw_fill_t *F = (msw_fill_t*)data;
+	const bsx_msw_pair_t *T = &F->tab[k];
+	int i, at = T->base;
+	(void)tid;
+	if (at < 0) return;   /* (left to the host's own plan: the first pass collects as before) */
+	for (i = 0; i < 2; ++i) {
+		uint64_t m = T->mask[i];
+		while (m) {
+			msw_slot_t s;
+			memset(&s, 0, sizeof(s));
+			s.i = i; s.j = __builtin_ctzll(m); s.have = 1; s.res = F->res[at++];
+			bsx_vec_push(F->M[k].slots, s);
+			m &= m - 1;
+		}
+	}
+}
+
 static int mate_rescue(chunk_t *C, int p0, int p1)   /* the pairs [p0, p1) */
 {
 	int np = p1 - p0, rc = BSX_OK, round;
 	double t_batch = 0, t_all = now_s();
+	int64_t n_planned = -1, n_later = 0; long n_pairs_host = 0;   /* ($BSX_PHASES) */
 	msw_pair_t *M = (msw_pair_t*)bsx_par_calloc(C->nt, (size_t)np, sizeof(msw_pair_t));
 	msw_par_t P;
 	g_msw_prof = bsx_phases() != 0;
 	P.C = C; P.M = M; P.p0 = p0;
 	P.cnt = (int*)malloc(sizeof(int) * ((size_t)np + 1)); P.off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)np + 1));
 	bsx_parallel_for(C->nt, msw_init_worker, &P, np);
+	if (C->be->msw_plan && C->dd_n && C->n > 0 && np > 0) { /* the plan pass and its K5 batch on the device, where the lists are */
+		bsx_msw_pair_t *tab = (bsx_msw_pair_t*)malloc(sizeof(bsx_msw_pair_t) * (size_t)np);
+		bsx_sw_res_t *pres = 0; int64_t pcap = 0, nj = -1;
+		double tb = now_s();
+		rc = C->be->msw_plan(C->be->ctx, C->opt, &C->pes, C->token, C->n, C->n_tasks / C->n, C->roff, C->max_len, p0, p1, tab, &pres, &pcap, &nj);
+		t_batch += now_s() - tb;
+		if (rc == BSX_OK && nj >= 0) {
+			msw_fill_t F; F.M = M; F.tab = tab; F.res = pres;
+			bsx_parallel_for(C->nt, msw_fill_worker, &F, np);
+			__atomic_fetch_add(&C->st.n_sw_jobs, nj, __ATOMIC_RELAXED);
+			n_planned = nj;
+			if (g_msw_prof) { long k; for (k = 0; k < np; ++k) n_pairs_host += tab[k].base < 0; }
+		}
+		free(tab); free(pres);
+		if (rc != BSX_OK) { free(M); free(P.cnt); free(P.off); return rc; }
+	}
 	for (round = 0; round < 256; ++round) {
 		bsx_sw_res_t *res;
 		int64_t nj;
@@ -683,6 +724,7 @@ static int mate_rescue(chunk_t *C, int p0, int p1)   /* the pairs [p0, p1) */
 		bsx_parallel_for(C->nt, msw_count_worker, &P, np);
 		nj = prefix_counts(np, P.cnt, P.off);
 		if (nj == 0) break;
+		n_later += nj;
 		P.jobs = (bsx_sw_job_t*)malloc(sizeof(bsx_sw_job_t) * (size_t)nj);
 		res = (bsx_sw_res_t*)malloc(sizeof(*res) * (size_t)nj);
 		bsx_parallel_for(C->nt, msw_jobs_worker, &P, np);
@@ -695,8 +737,9 @@ static int mate_rescue(chunk_t *C, int p0, int p1)   /* the pairs [p0, p1) */
 	}
 	bsx_parallel_for(C->nt, msw_free_worker, &P, np);
 	if (bsx_phases()) {
-		fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host | thread-seconds: %.2f in the per-pair passes, %.2f of them in %ld list sorts (%.1f regions each)\n",
-		        round, t_batch, now_s() - t_all - t_batch, g_msw_replay_ns * 1e-9, g_msw_ns * 1e-9, (long)g_msw_calls, g_msw_calls ? (double)g_msw_elems / g_msw_calls : 0.0);
+		fprintf(stderr, "[M::matesw] %d rounds, %.3f s in the K5 batches, %.3f s on the host | thread-seconds: %.2f in the per-pair passes, %.2f of them in %ld list sorts (%.1f regions each) | planned on the device: %lld alignments (%ld of %d pairs left to the host's plan), asked for by the replay afterwards: %lld\n",
+		        round, t_batch, now_s() - t_all - t_batch, g_msw_replay_ns * 1e-9, g_msw_ns * 1e-9, (long)g_msw_calls, g_msw_calls ? (double)g_msw_elems / g_msw_calls : 0.0,
+		        (long long)n_planned, n_pairs_host, np, (long long)n_later);
 		g_msw_replay_ns = g_msw_ns = g_msw_calls = g_msw_elems = 0;
 	}
 	free(M); free(P.cnt); free(P.off);
@@ -1022,6 +1065,7 @@ static chunk_t *chunk_new(const bsx_backend_t *be, const bsx_opt_t *opt, const b
 	if (pes0) { C->pes0_copy = *pes0; C->pes0 = &C->pes0_copy; }
 	C->arena_set = -1;
 	C->t_begin = now_s();
+	{ static int64_t g_token = 0; C->token = __atomic_add_fetch(&g_token, 1, __ATOMIC_RELAXED); }
 	return C;
 }
 
@@ -1172,7 +1216,7 @@ static int chunk_front(chunk_t *C)
 			}
 	bsx_parallel_for(nt, clip_worker, C, n);
 	C->roff = (uint32_t*)bsx_big_get(C->arena_set, 0, sizeof(uint32_t) * ((size_t)n + 1));
-	for (i = 0; i < n; ++i) { C->roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; }
+	for (i = 0; i < n; ++i) { C->roff[i] = (uint32_t)tot; tot += (size_t)reads[i].l_seq; if (reads[i].l_seq > C->max_len) C->max_len = reads[i].l_seq; }
 	C->roff[n] = (uint32_t)tot;
 	if (tot >= 0xffff0000ull) return BSX_E_ARG;
 	C->buf = (uint8_t*)bsx_big_get(C->arena_set, 1, tot + 16);

@@ -42,6 +42,7 @@ static knob_t g_knobs[] = {
 	{"gather_via_rank0", "[0] several ranks with $BSX_OUT: 1 = the records go through rank 0 even where every rank could write its own chunks into the file", 0},
 	{"gather_transport", "[rccl] several ranks: socket = Unix-domain sockets through rank 0 instead of RCCL", 0},
 	{"tier2_export", "[0] 1: the first HBM tier of the region kernels in steps -- chains exported, their best seeds extended ahead (k_extl / k_ext4), the seed loop by a chains -> regions launch with its regions in HBM -- instead of its monolithic form (same SAM; measured slower, DESIGN.md section 4)", 0},
+	{"msw_plan", "[0] 1: mate rescue's plan pass (which candidates need an alignment, over which window) by k_msw_plan over the lists on the device, its K5 batch run from device memory, instead of by the host's first replay pass (same SAM; measured slower, DESIGN.md section 4)", 0},
 	{"long_dedup", "[1] 0: reads with more than 32 regions are de-duplicated on the host (A/B against k_dedup_long)", 0},
 };
 #define N_KNOBS ((int)(sizeof(g_knobs) / sizeof(g_knobs[0])))

@@ -299,7 +299,9 @@ def test_cli_many_chunks_through_the_stream(data):
     {"BSX_SEED_QUOTA": "0", "BSX_REGIONS_QUOTA": "1", "BSX_STREAM_DEPTH": "4"},   # persistent seeding waves, one task per region wave
     {"BSX_REGIONS_MID": "0", "BSX_SEED_TRIP_BUDGET": "200"},        # no LDS tier between the first and the HBM tiers; most strand searches handed to the second seeding pass
     {"BSX_HOST_DEDUP": "1"},                                        # C5 (mem_sort_deduplicate) of every read on the host instead of by k_dedup
-], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget", "host_dedup"])
+    {"msw_plan": "1", "back_slices": "3"},                          # mate rescue's plan pass by k_msw_plan on the device, its K5 batch from device memory
+    {"tier2_export": "1", "long_dedup": "0", "back_slices": "1", "back_threads": "1"},   # the first HBM tier in steps; long lists de-duplicated on the host; the back half unsliced
+], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget", "host_dedup", "msw_plan", "tier2x_nolongdedup_noslices"])
 def test_device_tuning_knobs_do_not_change_the_output(data, env):
     """Launch shapes, occupancy targets, the device-side suffix-array sample and the pipeline depth are performance knobs:
     the SAM must be byte-identical whatever they are set to."""

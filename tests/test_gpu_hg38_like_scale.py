@@ -63,13 +63,13 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
         assert m and int(m.group(2)) > 0, err[-600:]              # strand searches reached the HBM tiers
         mapped = np.mean([not (int(s.split(b"\t")[1]) & 4) for s in hip])
         assert mapped > 0.9, mapped
-        # the first HBM tier in steps (tier2_export=1: its chains exported, extended ahead, the seed loop with its regions in HBM) and the reads with
-        # long region lists left to the host's de-duplication (long_dedup=0): other routes through the device, the same SAM
+        # the first HBM tier in steps (tier2_export=1: its chains exported, extended ahead, the seed loop with its regions in HBM), the reads with
+        # long region lists left to the host's de-duplication (long_dedup=0), mate rescue planned on the device (msw_plan=1): other routes, the same SAM
         L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
         r = C.cast(p, C.POINTER(B.Read))
-        for name in ("tier2_export", "long_dedup"):
-            B.tune(name, "1" if name == "tier2_export" else "0")
+        for name in ("tier2_export", "long_dedup", "msw_plan"):   # (msw_plan=1: mate rescue's plan pass and its K5 batch on the device, k_msw.hip)
+            B.tune(name, "0" if name == "long_dedup" else "1")
             try:
                 capfd.readouterr()
                 B.check(L.bsx_process_seqs(hard["dev"].h, C.byref(opt), hard["idx"].h, 0, n, p, None), "process_seqs(%s)" % name)
@@ -81,6 +81,8 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
             assert other == hip, name
             if name == "tier2_export":
                 assert "tier 2 (chains -> regions)" in err2, err2[-800:]
+            if name == "msw_plan":
+                assert "alignments planned and run on the device" in err2, err2[-800:]
     finally:
         B.tune("phases", None)
         L.bsx_sim_free_reads(p, n)

@@ -182,7 +182,7 @@ if kt:
             g.write("| %s | %d | %.1f | %.1f | %.1f |\n" % (k, len(v), sum(v) / len(v), min(v), max(v)))
 
 # --- each kernel family's durations in the pipelined trace, per chunk: what bench.py quotes beside its HIP-event spans
-# (`kernel_ms_sum_from_trace`).  Chunks in the trace = launches of k_occ (one per chunk: warm-up, timed, stand-alone and the classic-seeding chunk).
+# (`kernel_ms_sum_from_trace`).  Chunks in the trace = launches of k_dedup (one per chunk: warm-up, timed, stand-alone and the classic-seeding chunk).
 if kt:
     fam = {"seeding": ("k_seedt<", "k_seedt_pack"), "sa_lookup": ("k_occ",),
            "region_family": ("k_regions", "k_c2r", "k_ext4", "k_extl", "k_x4prep", "k_seedsw", "k_swl16"),
@@ -193,7 +193,7 @@ if kt:
     for r in csv.DictReader(open(kt[0])):
         nm = short(r["Kernel_Name"])
         ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-        if nm == "k_occ":
+        if nm == "k_dedup":   # one launch per chunk (k_occ also runs for the few strand searches seeded again on the side stream)
             chunks += 1
         for f_, pre in fam.items():
             if any(nm == p_ or nm.startswith(p_) for p_ in pre) and not (f_ == "sa_lookup" and not nm.startswith("k_occ")):
@@ -206,5 +206,5 @@ if kt:
             fj[f_] = {"chunks": chunks, "pipelined_ms_per_chunk": round(sum(d_.values()) / chunks, 2),
                       "by_kernel": {k: {"ms_per_chunk": round(v / chunks, 2), "launches": calls[k]} for k, v in sorted(d_.items(), key=lambda kv: -kv[1])}}
         fj["_note"] = ("rocprofv3 --kernel-trace of the default pipelined bench command (tools/profile_round.sh): kernel durations summed per family and divided by the "
-                       "chunks in the trace (k_occ launches: warm-up + timed + the stand-alone chunk + the classic-seeding chunk, which adds no k_seedt time).")
+                       "chunks in the trace (k_dedup launches: warm-up + timed + the stand-alone chunk + the classic-seeding chunk, which adds no k_seedt time).")
         json.dump(fj, open(os.path.join(out, "%s_family_ms_%dmbp_%s.json" % (tag, mbp, "hg38like" if gprof == "hg38-like" else "clean")), "w"), indent=1)
