@@ -56,7 +56,7 @@ k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Jo
 		const int t = X.xlist[i0 + lane];
 		const unsigned long long at = (unsigned long long)X.xoff[t];
 		const RgXHdr *H = (const RgXHdr*)(X.base + at);
-		nk = H->has_ext ? H->n_chains : 0;
+		nk = H->has_ext ? H->n_chains : 0;   // (has_ext 2: a slot and a job per SEED of the main lists, below)
 		s_rec[wv][lane] = at;
 		s_qoff[wv][lane] = tasks[t].qoff;
 		s_lq[wv][lane] = tasks[t].len << 1 | (tasks[t].parent & 1);
@@ -67,28 +67,33 @@ k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Jo
 	WAVE_SYNC();
 	for (int b = 0; b < tot; b += 64) {
 		const int j = b + lane;
-		bool job = false;
-		X4Job J;
+		// the lane's chain: its window, and which of its seeds get a job -- the one the loop reaches first (has_ext 1), or every seed of the main
+		// list that passes asymmetric_flt_seed (has_ext 2); then the jobs, one per lane per round
+		int n_it = 0, mode = 0, best = -1, ci = 0, l_query = 0, parent = 0, s = 0;
+		long long rmax0 = 0, rmax1 = 0;
+		const RgXSeed *XS = nullptr; RgXExt *XE = nullptr; RgXChain c; c.pos = 0; c.rid = 0; c.seed_off = 0; c.n_main = c.n_extra = 0; c.pad = 0;
+		RgXExt xe0; xe0.rb = xe0.re = 0; xe0.qb = xe0.qe = 0; xe0.score = xe0.truesc = -1; xe0.aw0 = xe0.aw1 = P.w; xe0.si = -1; xe0.status = 0;
 		if (j < tot) {
 			int lo = 0, hi = 63;   // first s with s_pre[s] > j
 			while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pre[wv][mid] > j) hi = mid; else lo = mid + 1; }
-			const int s = lo;
+			s = lo;
 			const unsigned long long at = s_rec[wv][s];
 			const RgXHdr *H = (const RgXHdr*)(X.base + at);
 			const int nch = H->n_chains, n_sd = H->n_seeds;
-			const int ci = j - (s_pre[wv][s] - nch);
-			const int l_query = s_lq[wv][s] >> 1, parent = s_lq[wv][s] & 1;
+			mode = H->has_ext;
+			ci = j - (s_pre[wv][s] - nch);
+			l_query = s_lq[wv][s] >> 1; parent = s_lq[wv][s] & 1;
 			const RgXChain *XC = (const RgXChain*)(H + 1);
-			const RgXSeed *XS = (const RgXSeed*)(XC + nch);
-			RgXExt *XE = (RgXExt*)(XS + n_sd);
-			const RgXChain c = XC[ci];
-			RgXExt xe; xe.rb = xe.re = 0; xe.qb = xe.qe = 0; xe.score = xe.truesc = -1; xe.aw0 = xe.aw1 = P.w; xe.si = -1; xe.status = 0;
+			XS = (const RgXSeed*)(XC + nch);
+			XE = (RgXExt*)(XS + n_sd);
+			c = XC[ci];
 			const int n_main = c.n_main;
-			if (n_main > 0 && n_main <= X4_XSEEDS && c.n_extra <= X4_XSEEDS && l_query <= X4_GAPCAP) {
+			const int cap = mode == 2 ? 1024 : X4_XSEEDS;   // (k_c2r's own limits: lists it hands on are not worth extending for)
+			if (n_main > 0 && n_main <= cap && c.n_extra <= cap && l_query <= X4_GAPCAP) {
 				// mem_chain_reference_span (memchain.c:585-605) over the main list + bns_fetch_seq's contig clamp, as k_c2r does it;
 				// the seed mem_chain2region1's loop reaches first: the largest (score, index) among those that pass asymmetric_flt_seed
-				long long rmax0 = l_pac << 1, rmax1 = 0;
-				int best = -1; long long bkey = -1;
+				rmax0 = l_pac << 1; rmax1 = 0;
+				long long bkey = -1;
 				for (int o = 0; o < n_main; ++o) {
 					const RgXSeed sd = XS[c.seed_off + o];
 					const long long bb = sd.rbeg - (sd.qbeg + rg_gap(gap_tab, P, sd.qbeg));
@@ -106,21 +111,36 @@ k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Jo
 						if (is_rev) { const long long tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
 						rmax0 = rmax0 > far_beg ? rmax0 : far_beg; rmax1 = rmax1 < far_end ? rmax1 : far_end;
 					}
-					const RgXSeed sd = XS[c.seed_off + best];
-					xe.si = best;
-					if (sd.qbeg == 0 && sd.qbeg + sd.len == l_query) { // the seed spans the read: no extension on either side (memchain.c:617,674)
-						xe.score = xe.truesc = sd.len * P.a; xe.qb = 0; xe.rb = sd.rbeg; xe.qe = l_query; xe.re = sd.rbeg + sd.len;
-						xe.status = 1;
-					} else {
-						job = true;
-						J.s_rbeg = sd.rbeg; J.rmax0 = rmax0; J.rmax1 = rmax1;
-						J.ext_at = (unsigned long long)((unsigned char*)(XE + ci) - X.base);
-						J.qoff = s_qoff[wv][s]; J.l_query = (short)l_query; J.s_qbeg = sd.qbeg; J.s_len = sd.len; J.parent = (unsigned char)parent; J.pad = 0;
-						J.si = best;
-					}
+					n_it = mode == 2 ? n_main : 1;
 				}
 			}
-			XE[ci] = xe;
+			if (n_it == 0) { // nothing to extend ahead: the slots say so
+				if (mode == 2) { for (int o = 0; o < n_main; ++o) XE[c.seed_off + o] = xe0; }
+				else XE[ci] = xe0;
+			}
+		}
+		for (int it = 0; __ballot(it < n_it) != 0ull; ++it) {
+		bool job = false;
+		X4Job J;
+		if (it < n_it) {
+			const int o = mode == 2 ? it : best;
+			const RgXSeed sd = XS[c.seed_off + o];
+			RgXExt *slot = mode == 2 ? XE + c.seed_off + o : XE + ci;
+			RgXExt xe = xe0;
+			if (!XS_BAD(sd)) {
+				xe.si = o;
+				if (sd.qbeg == 0 && sd.qbeg + sd.len == l_query) { // the seed spans the read: no extension on either side (memchain.c:617,674)
+					xe.score = xe.truesc = sd.len * P.a; xe.qb = 0; xe.rb = sd.rbeg; xe.qe = l_query; xe.re = sd.rbeg + sd.len;
+					xe.status = 1;
+				} else {
+					job = true;
+					J.s_rbeg = sd.rbeg; J.rmax0 = rmax0; J.rmax1 = rmax1;
+					J.ext_at = (unsigned long long)((unsigned char*)slot - X.base);
+					J.qoff = s_qoff[wv][s]; J.l_query = (short)l_query; J.s_qbeg = sd.qbeg; J.s_len = sd.len; J.parent = (unsigned char)parent; J.pad = 0;
+					J.si = o;
+				}
+			}
+			*slot = xe;
 		}
 		// Two queues, each in its half of the pool: a seed of fewer than X4_NARROW bases is nearly always a chance match whose extensions
 		// stay inside a band of a dozen columns and die within thirty rows; the others (the read's own locus) run for as many rows as the
@@ -135,6 +155,7 @@ k_x4prep(DevIndex ix, RegParams P, const bsx_seed_task_t *tasks, RgXPool X, X4Jo
 				const unsigned int at = base + (unsigned int)__popcll(jm & ((1ull << lane) - 1));
 				if (job && narrow == (q == 1) && at < jcap / 2) jobs[(size_t)q * (jcap / 2) + at] = J;   // no room: the chain keeps status 0 and k_c2r extends it inline
 			}
+		}
 		}
 	}
 }

@@ -407,8 +407,11 @@ __device__ int rg_export(Store &S, int t, int tot, float frac_rep, const RgXPool
 		WAVE_SYNC();
 	}
 	if (n_surv == 0) return 0;
-	const int ext = X.ext && flt == RG_NOFLT;   // room for the extensions made ahead of k_c2r (k_ext4.hip); the seed-SW filter rewrites the lists after the export
-	const unsigned long long bytes = sizeof(RgXHdr) + (unsigned long long)n_surv * sizeof(RgXChain) + (unsigned long long)n_sd * sizeof(RgXSeed) + (ext ? (unsigned long long)n_surv * sizeof(RgXExt) : 0ull);
+	// room for the extensions made ahead of k_c2r (k_ext4.hip); the seed-SW filter rewrites the lists after the export.  X.ext = 1: a slot per chain (the
+	// seed the loop reaches first); 2: a slot per seed (every seed of every main list is extended ahead: the HBM tiers' strand searches, where the
+	// loop skips one seed in fourteen)
+	const int ext = flt == RG_NOFLT ? X.ext : 0;
+	const unsigned long long bytes = sizeof(RgXHdr) + (unsigned long long)n_surv * sizeof(RgXChain) + (unsigned long long)n_sd * sizeof(RgXSeed) + (ext ? (unsigned long long)(ext == 2 ? n_sd : n_surv) * sizeof(RgXExt) : 0ull);
 	unsigned long long at = 0;
 	if (lane == 0) at = atomicAdd(X.cursor, bytes);
 	at = (unsigned long long)uni64((long long)at);
@@ -1086,6 +1089,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 	}
 	// ---- E. chains -> regions (mem_chain2region, memchain.c:873-904)
 	const int nk = uni(S.n_chains), ns = tot;
+	unsigned int pf_seen = 0, pf_skip = 0, pf_inl = 0;
 	for (int ci = 0; ci < nk; ++ci) {
 		const int c = uni(S.ord[ci]);
 		const RgChain chn = S.ch[c];
@@ -1153,6 +1157,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 				const int o = uni(S.lst[si]);
 				if (uni(S.s_extra[o]) & 2) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested for every seed after stage B
 				const long long s_rbeg = uni64(S.s_rbeg[o]); const int s_qbeg = uni(S.s_qbeg[o]), s_len = uni(S.s_len[o]);
+				++pf_seen;
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(S.n_regs);
@@ -1189,8 +1194,9 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 						}
 						any = __ballot(alt) != 0;
 					}
-					if (!any) { WAVE_SYNC(); if (lane == 0) S.srt[k] = 0; WAVE_SYNC(); continue; }
+					if (!any) { ++pf_skip; WAVE_SYNC(); if (lane == 0) S.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
+				++pf_inl;
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths
 				if (win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
@@ -1260,7 +1266,7 @@ __device__ int rg_task(Store &S, DP &D, const DevIndex &ix, const DevScoring &sc
 		}
 	}
 	RG_STAGE(6);
-	if (P.prof) { RG_PF_ADD(D, 8, pf_ext); RG_PF_ADD(D, 9, pf_rows); }
+	if (P.prof) { RG_PF_ADD(D, 8, pf_ext); RG_PF_ADD(D, 9, pf_rows); RG_PF_ADD(D, 11, pf_seen); RG_PF_ADD(D, 12, pf_skip); RG_PF_ADD(D, 14, pf_inl); }
 	return 0;
 }
 
@@ -1345,7 +1351,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 {
 	const long long l_pac = ix.l_pac;
 	long long pf_t = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-	unsigned int pf_ext = 0, pf_rows = 0;
+	unsigned int pf_ext = 0, pf_rows = 0, pf_seen = 0, pf_skip = 0, pf_cached = 0, pf_inl = 0;
 	// The exported record (header, chains in processing order, their seeds in the same order) is staged through LDS a block of
 	// chains and a window of seeds at a time: two round trips to HBM per strand search (header + read, then chains + seeds) where
 	// reading each chain's record and lists where they lie was three per chain, twelve chains per strand search.
@@ -1369,7 +1375,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 	int xc_lo = 0, sd_lo = 0, sd_hi = 0;
 #define C2R_STAGE_CHAINS(from) do { const int n_ = (nk - (from) < RG_XCBLK ? nk - (from) : RG_XCBLK) * (int)(sizeof(RgXChain) / 8); \
 		for (int i_ = lane; i_ < n_; i_ += 64) ((unsigned long long*)W.xc)[i_] = XCw[(size_t)(from) * (sizeof(RgXChain) / 8) + i_]; \
-		if (has_ext) for (int i_ = lane; i_ < n_ * 2; i_ += 64) ((unsigned long long*)W.xe)[i_] = XEw[(size_t)(from) * (sizeof(RgXExt) / 8) + i_]; xc_lo = (from); } while (0)
+		if (has_ext == 1) for (int i_ = lane; i_ < n_ * 2; i_ += 64) ((unsigned long long*)W.xe)[i_] = XEw[(size_t)(from) * (sizeof(RgXExt) / 8) + i_]; xc_lo = (from); } while (0)
 #define C2R_STAGE_SEEDS(from) do { const int m_ = n_sd - (from) < WT::XSEEDS ? n_sd - (from) : WT::XSEEDS; \
 		for (int i_ = lane; i_ < m_ * 2; i_ += 64) ((unsigned long long*)W.sd)[i_] = XSw[(size_t)(from) * 2 + i_]; sd_lo = (from); sd_hi = (from) + m_; } while (0)
 	C2R_STAGE_CHAINS(0);
@@ -1422,6 +1428,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 				const RgXSeed sd = Lsd[si];
 				if (uni(XS_BAD(sd))) continue;   // asymmetric_flt_seed (memchain.c:138-149), tested by the tier that exported the seed
 				const long long s_rbeg = uni64(sd.rbeg); const int s_qbeg = uni((int)sd.qbeg), s_len = uni((int)sd.len);
+				++pf_seen;
 				// contained in a region of this strand search? (memchain.c:761-819)
 				int u;
 				const int nr = uni(W.n_regs);
@@ -1458,12 +1465,21 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						}
 						any = __ballot(alt) != 0;
 					}
-					if (!any) { WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
+					if (!any) { ++pf_skip; WAVE_SYNC(); if (lane == 0) W.srt[k] = 0; WAVE_SYNC(); continue; }
 				}
 				// extension (memchain.c:613-730): left then right, each with up to MAX_BAND_TRY band widths -- taken from the record when this
 				// is the seed k_ext4 extended ahead of the loop (the first one the loop reaches in a chain's main list)
-				const RgXExt &xe = W.xe[ci - xc_lo];
+				RgXExt xe = W.xe[ci - xc_lo];
+				if (has_ext == 2 && pass == 0) { // a slot per seed, where the extension kernels left it: one 48-byte read, six lanes
+					const unsigned long long *xp = XEw + (size_t)(l0 + si) * (sizeof(RgXExt) / 8);
+					const unsigned long long v = lane < (int)(sizeof(RgXExt) / 8) ? xp[lane] : 0ull;
+					unsigned long long w6[sizeof(RgXExt) / 8];
+#pragma unroll
+					for (int q = 0; q < (int)(sizeof(RgXExt) / 8); ++q) w6[q] = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), q) << 32 | (unsigned)__builtin_amdgcn_readlane((int)v, q);
+					memcpy(&xe, w6, sizeof(xe));
+				}
 				const bool cached = has_ext && pass == 0 && uni(xe.status) == 1 && uni(xe.si) == si;
+				if (cached) ++pf_cached; else ++pf_inl;
 				if (!cached && win_ok == 0) { // the chain's reference window (bns_fetch_seq, memchain.c:889) into LDS, once, when a seed of it is first extended
 					const int span = (int)(rmax1 - rmax0);
 					if (span > 0 && span <= WT::WINCAP) {
@@ -1535,7 +1551,8 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 			}
 		}
 	}
-	if (P.prof) { RG_PF_ADD(W, 6, (long long)__builtin_readcyclecounter() - pf_t); RG_PF_ADD(W, 8, pf_ext); RG_PF_ADD(W, 9, pf_rows); }
+	if (P.prof) { RG_PF_ADD(W, 6, (long long)__builtin_readcyclecounter() - pf_t); RG_PF_ADD(W, 8, pf_ext); RG_PF_ADD(W, 9, pf_rows);
+	              RG_PF_ADD(W, 11, pf_seen); RG_PF_ADD(W, 12, pf_skip); RG_PF_ADD(W, 13, pf_cached); RG_PF_ADD(W, 14, pf_inl); }
 	return 0;
 }
 
@@ -2034,8 +2051,9 @@ k_regions(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const b
 		if (lane == 0) t = (int)atomicAdd(task_cursor, 1u);
 		t = uni(__shfl(t, 0));
 		if (t >= n_tasks) break;
-		if (cls && uni(cls[t]) != 0) { // larger than this tier's tables: straight to the next one
-			if (lane == 0) retry_list[atomicAdd(retry_count, 1u)] = t;
+		const int cl = cls ? uni((int)cls[t]) : 0;
+		if (cl != 0) { // larger than this tier's tables: straight to the next one (3: the last HBM tier has it already, launch_occ's early list)
+			if (lane == 0 && cl != 3) retry_list[atomicAdd(retry_count, 1u)] = t;
 			--taken;   // costs nothing: the quota counts strand searches done here
 			continue;
 		}
@@ -2104,6 +2122,12 @@ k_regions_slab(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, co
 			const unsigned long long dt = (unsigned long long)((long long)__builtin_readcyclecounter() - tk0);
 			unsigned long long *c = counters + (Store::SCAP > 1024 ? 114 : 110);
 			atomicMax(c, dt); atomicAdd(c + 1, dt); atomicAdd(c + 2, 1ull); wave_cyc += dt;
+			if (Store::SCAP > 1024) { // the last tier: its strand searches by duration (powers of two of 2^16 cycles), and what the longest one looked like
+				const unsigned long long b = dt >> 16;
+				atomicAdd(counters + 130 + (b ? 64 - __builtin_clzll(b) : 0), 1ull);
+				const unsigned long long nk_ = (unsigned long long)(S.n_chains < 0 ? 0 : S.n_chains > 16383 ? 16383 : S.n_chains), nr_ = (unsigned long long)(S.n_regs < 0 ? 0 : S.n_regs > 16383 ? 16383 : S.n_regs);
+				atomicMax(counters + 128, (dt >> 14) << 38 | (unsigned long long)(n_iv > 4095 ? 4095 : n_iv) << 26 | (nk_ & 8191) << 13 | (nr_ & 8191));
+			}
 		}
 		if (status == 11) continue;   // exported (XSPLIT: chunks with long reads, whose chains go through k_seedsw and k_c2r)
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
@@ -2171,7 +2195,8 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 #define OCC_MAX_PER_TASK 8192   // = RgHuge::SCAP: nothing on the device visits more
 __global__ void __launch_bounds__(256)
 k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ,
-             unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off, unsigned char *cls)
+             unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off, unsigned char *cls,
+             int *early_list, unsigned int *early_count)
 {
 	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (t >= n_tasks) return;
@@ -2185,6 +2210,9 @@ k_occ_expand(const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_den
 		// which tier's tables hold this strand search: decided here, where the sizes are known, so that the first tier does not start
 		// what it would have to give up (chains and regions can still outgrow a tier: that is found out along the way)
 		tier = (n_iv <= RgSmall::ICAP && tot <= (unsigned long long)RgSmall::SCAP) ? 0 : (n_iv <= RgMid::ICAP && tot <= (unsigned long long)RgMid::SCAP) ? 1 : 2;
+		// what only the last HBM tier's tables hold (rg_task's own tests, statuses 8 and 2, of every tier before it) is listed for it here: that
+		// launch -- a couple of thousand strand searches, as long as its longest -- then runs beside the other tiers instead of behind them
+		if (early_list && (n_iv > RgBig::ICAP || tot > (unsigned long long)RgBig::SCAP)) { tier = 3; early_list[atomicAdd(early_count, 1u)] = t; }
 		if (!over && tot > 0 && tot <= OCC_MAX_PER_TASK) {
 			const unsigned long long base = atomicAdd(cursor, tot);
 			if (base + tot <= desc_cap) {
@@ -2225,10 +2253,10 @@ k_occ(DevIndex ix, unsigned long long *desc, unsigned long long desc_cap, const 
 
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters, unsigned char *cls, unsigned long long *start)
+                unsigned long long *counters, unsigned char *cls, unsigned long long *start, int *early_list, unsigned int *early_count)
 {
 	if (start) (void)hipMemcpyAsync(start, cursor, 8, hipMemcpyDeviceToDevice, st);   // a later launch over the same pool: only the ranks it adds
-	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off, cls);
+	hipLaunchKernelGGL(k_occ_expand, dim3((n_tasks + 255) / 256), dim3(256), 0, st, tasks, n_tasks, seeds_dense, task_off, task_n, max_occ, desc, desc_cap, cursor, pos_off, cls, early_list, early_count);
 	hipLaunchKernelGGL(k_occ, dim3(n_cu * 32), dim3(256), 0, st, ix, desc, desc_cap, cursor, counters, (const unsigned long long*)start);
 }
 
@@ -2245,6 +2273,38 @@ k_sa_dense(DevIndex ix, int parent, unsigned int intv, unsigned long long n, uns
 void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out)
 {
 	hipLaunchKernelGGL(k_sa_dense, dim3(n_cu * 32), dim3(256), 0, st, ix, parent, intv, n, out);
+}
+
+// The last HBM tier lasts as long as its longest strand search: a couple of thousand of them on a thousand waves, 40 ms each on average and 190 ms
+// the longest -- when that one is taken off the cursor late, the launch is its 190 ms behind everything before it.  So the list is put in order of
+// decreasing size first (the occurrences the strand search will visit, what k_occ_expand counted): longest first, the short ones fill in behind.
+// One workgroup; ranks by counting (n is a few thousand).  Lists longer than the table are left as they are: they are bound by throughput anyway.
+#define ORDER_CAP 6144
+__global__ void __launch_bounds__(1024)
+k_order_list(int *list, const unsigned int *count, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ)
+{
+	__shared__ unsigned int cost[ORDER_CAP];
+	__shared__ int task[ORDER_CAP];
+	const int n = (int)*count;
+	if (n < 2 || n > ORDER_CAP) return;
+	for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+		const int t = list[i], n_iv = task_n[t];
+		const DevIntv *src = seeds_dense + task_off[t];
+		unsigned long long tot = 0;
+		for (int k = 0; k < n_iv; ++k) { const unsigned long long x2 = src[k].x2; tot += x2 > (unsigned long long)max_occ ? (unsigned long long)max_occ : x2; }
+		cost[i] = tot > 0xffffffffull ? 0xffffffffu : (unsigned int)tot; task[i] = t;
+	}
+	__syncthreads();
+	for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) {
+		const unsigned int c = cost[i];
+		int r = 0;
+		for (int j = 0; j < n; ++j) { const unsigned int cj = cost[j]; r += (cj > c || (cj == c && j < i)) ? 1 : 0; }
+		list[r] = task[i];
+	}
+}
+void launch_order_list(hipStream_t st, int *list, const unsigned int *count, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ)
+{
+	hipLaunchKernelGGL(k_order_list, dim3(1), dim3(1024), 0, st, list, count, seeds_dense, task_off, task_n, max_occ);
 }
 
 size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }

@@ -161,6 +161,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 	int task = -1, retired = 0, taken = 0, trips = 0, budget = 0;
 	uint32_t tot_slow = 0, tot_fast = 0, tot_look = 0, tot_over = 0;   // (tot_over: strand searches this lane left with a negative count)
 	unsigned int trip = 0;
+	const int hist = prof & 2; prof &= 1;
 	long long pc_t0 = prof ? clock64() : 0, pc_cold = 0, pc_hot = 0, pc_fetch = 0, pc_post = 0; unsigned int pc_cold_n = 0;
 	unsigned long long pc_req = 0;
 	for (;;) {
@@ -182,6 +183,7 @@ k_seedt(DevIndex ix, const uint8_t *reads, const bsx_seed_task_t *tasks, int n_t
 				task_off[task] = (long long)base;
 				task_n[task] = L.overflow ? -n - 1 : n;   // any negative count: seed this strand search again
 				tot_over += L.overflow ? 1u : 0u;
+				if (hist) atomicAdd(&counters[60 + (trips > 0 ? 32 - __clz(trips) : 0)], 1ull);   // ($BSX_PHASES: requests per strand search of the second pass, by power of two)
 				tot_slow += L.n_slow; tot_fast += L.n_fast; tot_look += L.n_look;
 				task = -1;
 			}

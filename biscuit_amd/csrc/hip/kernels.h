@@ -92,11 +92,13 @@ void launch_regions_slab(hipStream_t st, int tier, int grid, const DevIndex &ix,
                          bsx_region_t *out, unsigned long long out_cap, unsigned long long *out_cursor, long long *reg_off, int *reg_n,
                          const int *list, const unsigned int *count, unsigned int *cursor, void *slabs, int *next_list, unsigned int *next_count,
                          unsigned long long *counters, const long long *pos_off, const unsigned long long *pos, const RgXPoolArg *X = nullptr);   // X: export the chains (as the LDS tiers do) instead of making the regions
+// a tier's list put in order of decreasing size (occurrences to visit), longest strand search first: what a launch that lasts as long as its longest one wants
+void launch_order_list(hipStream_t st, int *list, const unsigned int *count, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ);
 // K3 ahead of the region kernels: SA ranks of all occurrences of all strand searches listed into desc (pos_off[t] = where task
 // t's start, -1 = none listed), then turned into reference positions in place.  pos_off/pos feed launch_regions*.
 void launch_occ(hipStream_t st, int n_cu, const DevIndex &ix, const bsx_seed_task_t *tasks, int n_tasks, const DevIntv *seeds_dense, const long long *task_off,
                 const int *task_n, int max_occ, unsigned long long *desc, unsigned long long desc_cap, unsigned long long *cursor, long long *pos_off,
-                unsigned long long *counters, unsigned char *cls, unsigned long long *start = nullptr);   // start: an 8-byte device slot; set = only the ranks this call adds to the pool are walked   // cls[t]: the first tier whose interval/occurrence tables hold task t
+                unsigned long long *counters, unsigned char *cls, unsigned long long *start = nullptr, int *early_list = nullptr, unsigned int *early_count = nullptr);   // early_list: the strand searches only the last HBM tier's tables hold are listed there (cls 3; the first tier then skips them)   // start: an 8-byte device slot; set = only the ranks this call adds to the pool are walked   // cls[t]: the first tier whose interval/occurrence tables hold task t
 // out[j] = SA[j * intv] for j < n, from the (sparser) samples ix currently holds: the denser suffix-array sample kept in HBM
 void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, unsigned int intv, unsigned long long n, unsigned long long *out);
 // C5 (k_dedup.hip): mem_sort_deduplicate of every read over the regions of the chunk, a lane per read

@@ -27,6 +27,10 @@ struct Lane {
 	hipStream_t st_hi = nullptr;   // back-half kernels (K5, K6): high priority, so that they get compute units while another chunk's front half runs
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr, ev4 = nullptr, ev5 = nullptr, ev6 = nullptr;   // (ev5, ev6: around the second seeding pass inside the main sequence)
 	hipEvent_t tier_ev[12] = {};   // $BSX_PHASES: between the region launches
+	hipStream_t st_cp = nullptr;   // unmasked: the front half's small copies (xfer)
+	hipEvent_t ev_cp = nullptr;
+	hipStream_t st3 = nullptr;     // the last HBM tier of what is known to need it when the occurrences are counted: beside the chunk's other tiers
+	hipEvent_t ev_t3a = nullptr, ev_t3b = nullptr;
 	hipStream_t st2 = nullptr;     // side stream of the front half: seeding redone with larger lists while the region kernels run
 	DevScoring sc;         // set by set_opt on this lane; read by every launch of this lane
 	DevBuf reads; size_t n_reads = 0;
@@ -112,20 +116,33 @@ extern "C" BSX_API int bsx_device_open(int ordinal, bsx_device_t **out)
 		// The front-half streams leave a few compute units alone (one in every `reserve`): workgroups of k_seed live for tens of
 		// milliseconds and are not preempted, so without free CUs the short high-priority batches of the back half (K5, K6)
 		// would queue behind them no matter their priority.
-		const int reserve = (int)bsx_tune_long("reserve_cu_every", 8);
+		const int reserve = (int)bsx_tune_long("reserve_cu_every", 0);   // (0 since round 6: with the CUs that are left free spread over every XCD -- below -- the back half's batches start at once and everything else gets slower by more: 735 k reads/s against 776 k without a mask and 757-780 k with the old one)
 		bool masked = false;
 		if (reserve >= 2 && d->n_cu >= 16) {
 			std::vector<uint32_t> mask((size_t)(d->n_cu + 31) / 32, 0u);
-			for (int cu = 0; cu < d->n_cu; ++cu) if (cu % reserve != reserve - 1) mask[cu >> 5] |= 1u << (cu & 31);
+			// Which CUs a mask bit stands for (tools/ubench/mask_probe.hip, round 6): bit i is CU i / 32 of shader engine (i / 8) % 4 of XCD i % 8 -- consecutive
+			// bits go round the XCDs, then the shader engines.  Workgroups go round the XCDs as well, and a kernel is done when its last workgroup is:
+			// the CUs left free must be in EVERY XCD.  Rounds 4-6 cleared every `reserve`-th bit -- with 8, all of XCD 7 and nothing of the others, and
+			// a batch of the back half waited a workgroup's lifetime of whatever filled the other seven (the probe: 21 ms against 0.05 ms).  Now the TOP
+			// n_cu / reserve bits (whole rows of 32: one CU of every shader engine of every XCD per row) are the ones left out.
+			int n_free = d->n_cu / reserve;
+			if (d->n_cu >= 64) n_free = (n_free + 31) / 32 * 32;
+			if (n_free >= d->n_cu) n_free = d->n_cu / 2;
+			for (int cu = 0; cu < d->n_cu - n_free; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
 			masked = hipExtStreamCreateWithCUMask(&L.st, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
-			         hipExtStreamCreateWithCUMask(&L.st2, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-			if (!masked) { (void)hipGetLastError(); if (L.st) { (void)hipStreamDestroy(L.st); L.st = nullptr; } if (L.st2) { (void)hipStreamDestroy(L.st2); L.st2 = nullptr; } }
+			         hipExtStreamCreateWithCUMask(&L.st2, (uint32_t)mask.size(), mask.data()) == hipSuccess &&
+			         hipExtStreamCreateWithCUMask(&L.st3, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+			if (!masked) { (void)hipGetLastError(); if (L.st) { (void)hipStreamDestroy(L.st); L.st = nullptr; } if (L.st2) { (void)hipStreamDestroy(L.st2); L.st2 = nullptr; } if (L.st3) { (void)hipStreamDestroy(L.st3); L.st3 = nullptr; } }
 		}
 		if (!masked) {
 			HIPCHK(hipStreamCreateWithPriority(&L.st, hipStreamNonBlocking, lo));
 			HIPCHK(hipStreamCreateWithPriority(&L.st2, hipStreamNonBlocking, lo));
+			HIPCHK(hipStreamCreateWithPriority(&L.st3, hipStreamNonBlocking, lo));
 		}
+		HIPCHK(hipEventCreate(&L.ev_t3a));
+		HIPCHK(hipEventCreate(&L.ev_t3b));
 		HIPCHK(hipStreamCreateWithPriority(&L.st_hi, hipStreamNonBlocking, hi));
+		if (masked && bsx_tune_long("small_copies_unmasked", 1)) { HIPCHK(hipStreamCreateWithPriority(&L.st_cp, hipStreamNonBlocking, hi)); HIPCHK(hipEventCreateWithFlags(&L.ev_cp, hipEventDisableTiming)); }
 		HIPCHK(hipEventCreate(&L.ev3));
 		HIPCHK(hipEventCreateWithFlags(&L.ev_seed_done, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&L.ev_regions_done, hipEventDisableTiming));
@@ -171,6 +188,11 @@ extern "C" BSX_API void bsx_device_close(bsx_device_t *d)
 		if (L.st) (void)hipStreamDestroy(L.st);
 		if (L.st_hi) (void)hipStreamDestroy(L.st_hi);
 		if (L.st2) (void)hipStreamDestroy(L.st2);
+		if (L.st3) (void)hipStreamDestroy(L.st3);
+		if (L.st_cp) (void)hipStreamDestroy(L.st_cp);
+		if (L.ev_cp) (void)hipEventDestroy(L.ev_cp);
+		if (L.ev_t3a) (void)hipEventDestroy(L.ev_t3a);
+		if (L.ev_t3b) (void)hipEventDestroy(L.ev_t3b);
 		if (L.ev3) (void)hipEventDestroy(L.ev3);
 		if (L.ev4) (void)hipEventDestroy(L.ev4);
 		if (L.ev5) (void)hipEventDestroy(L.ev5);
@@ -397,8 +419,14 @@ static int xfer(Lane &L, hipStream_t st, void *dst, const void *src, size_t n, b
 	if (n == 0) return BSX_OK;
 	const bool zc = st == L.st_hi;   // the back half's small batches move with a kernel on their own stream, not through the copy engines (round 4)
 	if (!zc && n < ((size_t)256 << 10)) {
-		HIPCHK(hipMemcpyAsync(dst, src, n, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
-		HIPCHK(hipStreamSynchronize(st));
+		// A small copy is a kernel of the runtime's (__amd_rocclr_copyBuffer: 1 400 of them per chunk in the trace), and on a front-half stream it is
+		// dispatched to that stream's CUs only: with other chunks' long-lived workgroups on all of them it waits for one to leave -- tens of milliseconds
+		// for eight bytes, at every point where the host reads a count.  It goes to the lane's unmasked stream instead, behind an event of `st`: the
+		// CUs the front-half streams leave alone are in every XCD (bsx_device_open), so it runs at once.
+		hipStream_t cs = L.st_cp && (st == L.st || st == L.st2 || st == L.st3) ? L.st_cp : st;
+		if (cs != st) { HIPCHK(hipEventRecord(L.ev_cp, st)); HIPCHK(hipStreamWaitEvent(cs, L.ev_cp, 0)); }
+		HIPCHK(hipMemcpyAsync(dst, src, n, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, cs));
+		HIPCHK(hipStreamSynchronize(cs));
 		return BSX_OK;
 	}
 	int rc;
@@ -745,14 +773,16 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	// the HBM tiers: workgroups of four waves over per-wave slabs; they are bound by the latency of their slabs, so what counts is waves in flight:
 	// three workgroups per CU for the first (its kernel is held to 168 VGPRs for that and spills: 710 -> 578 ms per chunk on the hg38-like genome
 	// all the same), one per CU for the second (1.3 MB of slab a wave; 222 -> 167 ms: a launch lasts as long as its largest strand search)
-	const int big_grid = d->n_cu * 3, huge_grid = d->n_cu;
+	// (the last tier: one workgroup of four waves per CU, or two -- "tier3_wgs"; its list longest strand search first -- "tier3_order")
+	const int big_grid = d->n_cu * 3, huge_grid = d->n_cu * std::max(1, std::min(3, (int)bsx_tune_long("tier3_wgs", 2)));
+	const bool order3 = bsx_tune_long("tier3_order", 1) != 0;
 	if ((rc = L.scratch.reserve(scratch_bytes)) != BSX_OK) return rc;
 	if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_seed_task_t))) != BSX_OK) return rc;
 	if ((rc = L.out.reserve((size_t)dense_cap * sizeof(DevIntv))) != BSX_OK) return rc;
 	if ((rc = L.aux.reserve((size_t)n * 12 + 64)) != BSX_OK) return rc;
 	if ((rc = L.qpack.reserve(seedt_pack_bytes(n))) != BSX_OK) return rc;
 	if ((rc = L.regs.reserve((size_t)regs_cap * sizeof(bsx_region_t))) != BSX_OK) return rc;
-	if ((rc = L.regmeta.reserve((size_t)n * 45 + 64)) != BSX_OK) return rc;
+	if ((rc = L.regmeta.reserve((size_t)n * 49 + 64)) != BSX_OK) return rc;
 	const int c2rh_grid = d->n_cu * 5;   // workgroups of the chains -> regions launch with its tables in HBM (a slab each)
 	if ((rc = L.c2rslab.reserve((size_t)c2rh_grid * c2r_hbm_slab_bytes())) != BSX_OK) return rc;
 	if ((rc = L.slabs.reserve((size_t)big_grid * 6 * regions_slab_bytes(2))) != BSX_OK) return rc;   // (the exporting form runs three workgroups per CU)
@@ -784,6 +814,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	int *retry_l = (int*)((char*)L.regmeta.p + (size_t)n * 24);
 	unsigned char *d_cls = (unsigned char*)L.regmeta.p + (size_t)n * 28;
 	int *retry_c = (int*)((char*)L.regmeta.p + (((size_t)n * 29 + 3) & ~(size_t)3));   // what the first chains -> regions launch declines (ordinary chunks)
+	int *retry_e = retry_c + 4 * n;   // what launch_occ lists for the last HBM tier ahead of everything else (u32 count and cursor: slot 22)
 	int *retry_h = retry_c + n, *xlist_t2 = retry_c + 2 * n, *retry_f = retry_c + 3 * n;   // round 6: what the second declines (-> the one with tables in HBM); the strand searches the first HBM tier exports; what takes that tier's full form
 	// counters (u64 slots of L.small): [4] interval cursor  [5] seed task cursor  [6] region cursor
 	// u32 view from slot 7: [0] tier-1 task cursor [1] tier-2 count [2] tier-2 cursor [3] tier-3 count [4] tier-3 cursor
@@ -803,6 +834,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	H2D(L.st, L.jobs.p, tasks, (size_t)n * sizeof(bsx_seed_task_t));
 	HIPCHK(hipMemsetAsync(ctr + 4, 0, 96, L.st));
 	HIPCHK(hipMemsetAsync(ctr + 20, 0, 8, L.st));   // (count and cursor of the second chains -> regions launch)
+	HIPCHK(hipMemsetAsync(ctr + 22, 0, 8, L.st));   // (count and cursor of the early launch of the last HBM tier)
 	HIPCHK(hipMemsetAsync(ctr + 119, 0, 8, L.st));  // (the first seeding pass's count of strand searches to be seeded again)
 	HIPCHK(hipMemsetAsync(ctr + 70, 0, 80, L.st));  // (round 6: counts and cursors of the launches between the second chains -> regions launch and the last HBM tier)
 	HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ctr + 4), (int)(uint32_t)direct_n, 1, L.st));            // the cursor starts behind the strand searches' own stretches
@@ -834,6 +866,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	std::vector<int> first_n;   // the first pass's counts (negative: overflowed)
 	std::vector<int> merged_which; const int *merged_cnt = nullptr;   // the strand searches of the second pass inside this sequence, and where their new counts are
 	bool merged = false;
+	const int budget2_mul = std::max(1, (int)bsx_tune_long("seed_budget2", 8));   // the second pass's budget, in first-pass budgets
 	const long merge_min = bsx_tune_long("redo_merge_min", 4096);   // (tests: 1 = always merged, a huge number or a negative one = never)
 	// Whether there are that many is the kernel's own count (counters[119]: 8 bytes back, not every strand search's count), and the host waits
 	// for it only when the lane's last chunk came anywhere near the threshold: on a clean genome, where a few dozen overflow, nothing stands
@@ -869,7 +902,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// inside tandem repeats -- hundreds of thousands of dependent FM steps -- made it 90-170 ms for 23 ms of work; they go on to the
 			// side stream below like the few of a clean genome)
 			launch_seed(L.st, g2, d->ix, d_reads, t2, (int)n2, P, (DevIntv*)L.scratch2.p, list_cap, (int)cap2, (DevIntv*)L.out.p, dense_cap, ctr + 4,
-			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr + SEED2_CTR, 0, (unsigned int*)L.slabflags.p, g2 * 4, trip_budget * 8, 0, (uint32_t*)L.qpack.p);
+			            off2, cnt2, (unsigned int*)(ctr + 96) + 7, ctr + SEED2_CTR, 0, (unsigned int*)L.slabflags.p, g2 * 4, trip_budget * budget2_mul, bsx_phases() ? 2 : 0, (uint32_t*)L.qpack.p);
 			hipLaunchKernelGGL(k_patch_lists, dim3((unsigned int)((n2 + 255) / 256)), dim3(256), 0, L.st, (const int*)which_d, (int)n2, (const long long*)off2, (const int*)cnt2, d_off, d_n);
 			HIPCHK(hipEventRecord(L.ev6, L.st));
 			merged = true; merged_which.swap(which); merged_cnt = cnt2;
@@ -877,8 +910,23 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		}
 	}
 	if (!merged) { HIPCHK(hipEventRecord(L.ev5, L.st)); HIPCHK(hipEventRecord(L.ev6, L.st)); }
-	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls);
+	// The last HBM tier beside the others (round 6): its launch lasts as long as its longest strand search -- 190 ms for a read inside a tandem repeat,
+	// on a device it leaves almost empty -- and what it takes is known as soon as the occurrences are counted (more intervals or occurrences than the
+	// tier before it holds).  launch_occ lists those, the first tier skips them, and the launch goes to a stream of its own right behind the
+	// suffix-array lookups; what the first HBM tier hands on later (a strand search that grew along the way) gets the launch at the end as before.
+	// Not with the exporting tiers (kilobase reads, the seed filter), and not under phases=2 (the stage counters are read tier by tier).
+	const bool early3 = bsx_tune_long("tier3_early", 1) != 0 && !export_all && !long_reads && bsx_phases() != 2 && L.st3;
+	launch_occ(L.st, d->n_cu, d->ix, d_tasks, (int)n, (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ, d_pos, pos_cap, ctr + 11, d_posoff, ctr, d_cls, nullptr,
+	           early3 ? retry_e : nullptr, early3 ? (unsigned int*)(ctr + 22) : nullptr);
 	HIPCHK(hipEventRecord(L.ev4, L.st));
+	if (early3) {
+		HIPCHK(hipStreamWaitEvent(L.st3, L.ev4, 0));
+		HIPCHK(hipEventRecord(L.ev_t3a, L.st3));
+		if (order3) launch_order_list(L.st3, retry_e, (unsigned int*)(ctr + 22), (const DevIntv*)L.out.p, d_off, d_n, opt->max_occ);
+		launch_regions_slab(L.st3, 3, huge_grid, d->ix, L.sc, R, d_reads, d_tasks, (const DevIntv*)L.out.p, d_off, d_n,
+		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, r_off, r_n, retry_e, (unsigned int*)(ctr + 22), (unsigned int*)(ctr + 22) + 1, L.slabs3.p, nullptr, nullptr, ctr, d_posoff, d_pos);
+		HIPCHK(hipEventRecord(L.ev_t3b, L.st3));
+	}
 	if (chain >= 2) {
 		std::lock_guard<std::mutex> g(d->chain_mu);
 		if (d->chain_regions && d->chain_regions != L.ev_regions_done) HIPCHK(hipStreamWaitEvent(L.st, d->chain_regions, 0));
@@ -903,7 +951,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		// $BSX_PHASES=2: the stage counters read (and zeroed) after every launch of the main sequence: where each tier's wave cycles go
 		const bool per_tier = bsx_phases() == 2;
 #define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; \
-		if (per_tier) { unsigned long long pf_[8]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
+		if (per_tier) { unsigned long long pf_[16]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
+			if (pf_[11]) fprintf(stderr, "[M::regions_batch] %s: seed loops: %llu seeds reached, %llu skipped as contained, %llu took the extension made ahead, %llu extended in place (%llu extensions, %llu rows)\n", name_, pf_[11], pf_[12], pf_[13], pf_[14], pf_[8], pf_[9]); \
 			double tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) tot_ += (double)pf_[k_]; \
 			if (tot_ > 0) fprintf(stderr, "[M::regions_batch] %s: intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% prologues+seed tests %.1f%% extension %.1f%% of %.0f M wave cycles\n", name_, \
 			                      100 * pf_[0] / tot_, 100 * pf_[1] / tot_, 100 * pf_[2] / tot_, 100 * pf_[3] / tot_, 100 * pf_[4] / tot_, 100 * pf_[5] / tot_, 100 * pf_[6] / tot_, 100 * pf_[7] / tot_, tot_ * 1e-6); } } } while (0)
@@ -1006,7 +1055,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		//
 		// h32 (u32): [0] what the second chains -> regions launch declines [1] the third's cursor | [4] what takes the HBM tier's full form [5] its
 		// cursor | [6] the exporting launch's cursor
-		const int t2x = (int)bsx_tune_long("tier2_export", 0) && tier1c && XP.ext;   // 1: the first HBM tier in steps (below) instead of its monolithic form (chains, filter and extensions inline in one launch)
+		const int t2x = tier1c && XP.ext ? (int)bsx_tune_long("tier2_export", 0) : 0;   // 1: the first HBM tier in steps (below) instead of its monolithic form (chains, filter and extensions inline in one launch)
 		if (XP.ext) {
 			launch_x4(st, d->n_cu, d->ix, L.sc, R, d_reads, T, (long long)nT, XP, L.x4jobs.p, x4_cap, x4c, R.prof ? ctr + 56 : nullptr);
 			TIER_MARK("extensions");
@@ -1038,6 +1087,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			// monolithic form; what outgrows the tier's tables goes on to the last tier as before.
 			RgXPoolArg XT = XP;
 			XT.xlist = x2_list; XT.xcount = h32 + 2;
+			if (t2x >= 2) XT.ext = 2;   // every seed of every main list extended ahead (a slot per seed): the seed loops of these strand searches skip one seed in fourteen
 			launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 			                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, h32 + 6, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos, &XT);
 			TIER_MARK("tier 2 (chains)");
@@ -1051,6 +1101,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		launch_regions_slab(st, 2, big_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, to2, n2c, k32 + 2, L.slabs.p, rb, k32 + 3, ctr, posoffs, d_pos);
 		TIER_MARK("tier 2");
+		if (main_seq && early3) HIPCHK(hipStreamWaitEvent(st, L.ev_t3b, 0));   // (the early launch: it shares the tier's slabs, and everything behind this point waits for its regions)
+		if (order3) launch_order_list(st, rb, k32 + 3, (const DevIntv*)L.out.p, offs, cnts, opt->max_occ);
 		launch_regions_slab(st, 3, huge_grid, d->ix, L.sc, R, d_reads, T, (const DevIntv*)L.out.p, offs, cnts,
 		                    (bsx_region_t*)L.regs.p, regs_cap, ctr + 6, roffs, rns, rb, k32 + 3, k32 + 4, L.slabs3.p, nullptr, nullptr, ctr, posoffs, d_pos);
 		TIER_MARK("tier 3");
@@ -1141,6 +1193,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (trace_tiers && n_marks > 1) {
 			fprintf(stderr, "[M::regions_batch] region launches (ms):");
 			for (int k = 1; k < n_marks; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, L.tier_ev[k - 1], L.tier_ev[k]) == hipSuccess) fprintf(stderr, " %s %.1f |", mark_name[k], ms); }
+			if (early3) { float ms = 0; unsigned int ne = 0; D2H(L.st, &ne, ctr + 22, 4); if (hipEventElapsedTime(&ms, L.ev_t3a, L.ev_t3b) == hipSuccess) fprintf(stderr, " tier 3 beside them (%u strand searches) %.1f |", ne, ms); }
 			fprintf(stderr, "\n");
 		}
 		if (trace) fprintf(stderr, "[M::regions_batch] seed kernel done +%.0f ms | redo of %zu strand searches enqueued +%.0f ms | all region tiers done +%.0f ms\n",
@@ -1149,6 +1202,13 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		HIPCHK(hipEventElapsedTime(&ms0, L.ev0, L.ev1));
 		float ms3 = 0, ms_again = 0;
 		HIPCHK(hipEventElapsedTime(&ms_again, L.ev5, L.ev6));   // the second seeding pass, when it ran inside this sequence
+		if (merged && trace) { // requests per strand search of the second pass, by power of two (k_seedt, prof & 2)
+			unsigned long long hh[20];
+			HIPCHK(hipMemcpy(hh, ctr + SEED2_CTR + 60, sizeof(hh), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + SEED2_CTR + 60, 0, sizeof(hh)));
+			fprintf(stderr, "[M::regions_batch] second seeding pass %.1f ms (budget %d requests); strand searches by requests made, < 2^k:", ms_again, trip_budget * budget2_mul);
+			for (int k = 0; k < 20; ++k) if (hh[k]) fprintf(stderr, " k=%d: %llu |", k, hh[k]);
+			fprintf(stderr, "\n");
+		}
 		if (merged) { L.k_ms[7] += ms_again; L.k_launch[7] += 1; L.seed2_ms += ms_again; L.seed2_launches += 1; L.seed2_tasks += (uint64_t)merged_which.size(); }   // (slot 7: seeding outside the chunk-wide launch)
 		HIPCHK(hipEventElapsedTime(&ms3, L.ev6, L.ev4));   // K3 for the chunk (k_occ_expand + k_occ)
 		L.k_ms[1] += ms3; L.k_launch[1] += 1;
@@ -1209,6 +1269,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		if (tot > 0) fprintf(stderr, "[M::regions_batch] wave cycles by stage (all tiers): intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% chain prologues+seed tests %.1f%% extension %.1f%% | %.0f M cycles, %llu extensions, %llu rows\n",
 		        100 * pf[0] / tot, 100 * pf[1] / tot, 100 * pf[2] / tot, 100 * pf[3] / tot, 100 * pf[4] / tot, 100 * pf[5] / tot, 100 * pf[6] / tot, 100 * pf[7] / tot, tot * 1e-6, pf[8], pf[9]);
 		if (pf[10]) fprintf(stderr, "[M::regions_batch] seed filter: %llu alignments\n", pf[10]);
+		if (pf[11]) fprintf(stderr, "[M::regions_batch] seed loops (mem_chain2region1): %llu seeds reached, %llu skipped as contained, %llu took the extension made ahead, %llu extended in place\n", pf[11], pf[12], pf[13], pf[14]);
 		{ // the HBM tiers: how long their strand searches take (a wave each)
 			unsigned long long tk[8];
 			D2H(L.st, tk, ctr + 110, sizeof(tk));
@@ -1216,6 +1277,15 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 			for (int k = 0; k < 2; ++k) if (tk[4 * k + 2])
 				fprintf(stderr, "[M::regions_batch] tier %d: %llu strand searches, %.2f M cycles each on average, the longest %.1f M, the busiest wave %.1f M, all of them %.0f M\n",
 				        2 + k, tk[4 * k + 2], 1e-6 * tk[4 * k + 1] / tk[4 * k + 2], 1e-6 * tk[4 * k], 1e-6 * tk[4 * k + 3], 1e-6 * tk[4 * k + 1]);
+			unsigned long long th[24];
+			D2H(L.st, th, ctr + 128, sizeof(th));
+			HIPCHK(hipMemsetAsync(ctr + 128, 0, sizeof(th), L.st));
+			if (th[0]) {
+				fprintf(stderr, "[M::regions_batch] tier 3: the longest strand search: %.1f M cycles, %llu intervals, %llu chains kept, %llu regions | strand searches by duration, < 2^k x 65536 cycles:",
+				        (double)(th[0] >> 36) * 4096e-6, (th[0] >> 24) & 4095, (th[0] >> 14) & 16383, th[0] & 16383);
+				for (int k = 0; k < 22; ++k) if (th[2 + k]) fprintf(stderr, " k=%d: %llu |", k, th[2 + k]);
+				fprintf(stderr, "\n");
+			}
 		}
 	}
 	clock_gettime(CLOCK_MONOTONIC, &ts_out);

@@ -13,6 +13,10 @@ static knob_t g_knobs[] = {
 	{"seed_mem_cap", "[max(64, longest read)] entries of a strand search's first-pass interval list (tests: short lists, so that ordinary reads are seeded again)", 0},
 	{"seed_direct", "[1] 0: interval lists copied behind each other instead of written where they stay", 0},
 	{"seed_quota", "[0 = persistent lanes; 1 for seed_form=classic] strand searches a lane of the seeding kernel takes", 0},
+	{"tier3_early", "[1] the last HBM tier's launch for what is known to need it when the occurrences are counted: on a stream of its own beside the other tiers; 0: behind them", 0},
+	{"tier3_order", "[1] the last HBM tier takes its strand searches longest first (by occurrences to visit); 0: in the order the tier before handed them on", 0},
+	{"tier3_wgs", "[2] workgroups of four waves per CU in the last HBM tier's launch (1..3)", 0},
+	{"seed_budget2", "[8] the second seeding pass's budget in first-pass budgets; what exceeds it is seeded a third time on the side stream, without one", 0},
 	{"seed_trip_budget", "[4096] FM extensions (per 256 bases of read) after which the first seeding pass hands a strand search to the second; 0: never", 0},
 	{"redo_merge_min", "[4096] from how many overflowed strand searches the second seeding pass runs inside the chunk's launch sequence (1: always; negative or huge: never)", 0},
 	{"async_redo", "[0] 1: bsx_process_seqs collects the strand searches seeded again on the side stream only in the back half", 0},
@@ -29,7 +33,8 @@ static knob_t g_knobs[] = {
 	{"xl", "[1] 0: the narrow extension jobs through k_ext4 as well (no lane-per-job kernel)", 0},
 	{"ext4", "[off] tests: bsx_extend_batch through the quarter-wave kernel (1) / then the lane-per-job kernel (2) of the regions path", 0},
 	{"chain_stages", "[3] how consecutive chunks' front halves are chained on the device: 0 none, 1 seeding, 2 seeding and regions, 3 the same but the HBM tiers hold nobody back, 4 strictly one after the other", 0},
-	{"reserve_cu_every", "[8] the front-half streams leave every n-th compute unit to the back half's short batches; < 2: none", 0},
+	{"small_copies_unmasked", "[1] the front half's copies of less than 256 KB go through the lane's unmasked stream (the CUs the front-half streams leave alone); 0: through the stream they are ordered on", 0},
+	{"reserve_cu_every", "[0] n >= 2: the front-half streams leave one compute unit in n (of every shader engine of every XCD) to the back half's short batches; < 2: none", 0},
 	{"host_chain", "[0] 1: every strand search chained on the host over the batch kernels (A/B against the region kernels)", 0},
 	{"host_dedup", "[0] 1: mem_sort_deduplicate of every read on the host (A/B against k_dedup)", 0},
 	{"stream_whole_chunk", "[0] N: a chunk's own thread runs its back half too, at most N at a time", 0},
@@ -41,7 +46,7 @@ static knob_t g_knobs[] = {
 	{"shard_pairs", "[0] several ranks (RANK / WORLD_SIZE): 1 = every rank aligns its slice of EVERY chunk (inputs with fewer chunks than GPUs) instead of every world-th chunk", 0},
 	{"gather_via_rank0", "[0] several ranks with $BSX_OUT: 1 = the records go through rank 0 even where every rank could write its own chunks into the file", 0},
 	{"gather_transport", "[rccl] several ranks: socket = Unix-domain sockets through rank 0 instead of RCCL", 0},
-	{"tier2_export", "[0] 1: the first HBM tier of the region kernels in steps -- chains exported, their best seeds extended ahead (k_extl / k_ext4), the seed loop by a chains -> regions launch with its regions in HBM -- instead of its monolithic form (same SAM; measured slower, DESIGN.md section 4)", 0},
+	{"tier2_export", "[0] the first HBM tier of the region kernels in steps -- chains exported, seeds extended ahead (k_extl / k_ext4; 1: every chain's best seed, 2: every seed of every main list), the seed loop by a chains -> regions launch with its regions in HBM -- instead of its monolithic form (same SAM; measured no faster, DESIGN.md section 4)", 0},
 	{"msw_plan", "[0] 1: mate rescue's plan pass (which candidates need an alignment, over which window) by k_msw_plan over the lists on the device, its K5 batch run from device memory, instead of by the host's first replay pass (same SAM; measured slower, DESIGN.md section 4)", 0},
 	{"long_dedup", "[1] 0: reads with more than 32 regions are de-duplicated on the host (A/B against k_dedup_long)", 0},
 };

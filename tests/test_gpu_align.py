@@ -301,7 +301,10 @@ def test_cli_many_chunks_through_the_stream(data):
     {"BSX_HOST_DEDUP": "1"},                                        # C5 (mem_sort_deduplicate) of every read on the host instead of by k_dedup
     {"msw_plan": "1", "back_slices": "3"},                          # mate rescue's plan pass by k_msw_plan on the device, its K5 batch from device memory
     {"tier2_export": "1", "long_dedup": "0", "back_slices": "1", "back_threads": "1"},   # the first HBM tier in steps; long lists de-duplicated on the host; the back half unsliced
-], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget", "host_dedup", "msw_plan", "tier2x_nolongdedup_noslices"])
+    {"tier2_export": "2", "tier3_early": "0", "tier3_order": "0", "tier3_wgs": "1", "seed_budget2": "1"},   # ... with every seed extended ahead; the last HBM tier behind the others, in list order; a short second seeding pass
+    {"reserve_cu_every": "8", "BSX_STREAM_DEPTH": "4"},             # CU-masked front-half streams (a CU of every shader engine left out), the small copies through the unmasked stream
+    {"reserve_cu_every": "4", "small_copies_unmasked": "0"},
+], ids=["sa32", "sa1", "occ", "noreserve_depth1", "quotas_depth4", "nomid_budget", "host_dedup", "msw_plan", "tier2x_nolongdedup_noslices", "tier2x_all_seeds_tier3_late", "cu_mask8", "cu_mask4"])
 def test_device_tuning_knobs_do_not_change_the_output(data, env):
     """Launch shapes, occupancy targets, the device-side suffix-array sample and the pipeline depth are performance knobs:
     the SAM must be byte-identical whatever they are set to."""

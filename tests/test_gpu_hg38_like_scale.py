@@ -68,8 +68,10 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
         L.bsx_process_seqs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.bsx_sim_reset_reads.argtypes = [C.c_void_p, C.c_int64]
         r = C.cast(p, C.POINTER(B.Read))
-        for name in ("tier2_export", "long_dedup", "msw_plan"):   # (msw_plan=1: mate rescue's plan pass and its K5 batch on the device, k_msw.hip)
-            B.tune(name, "0" if name == "long_dedup" else "1")
+        # (tier2_export=2: every seed of the exported main lists extended ahead; tier3_early=0: the last HBM tier behind the others instead of beside them;
+        # msw_plan=1: mate rescue's plan pass and its K5 batch on the device, k_msw.hip)
+        for name, val in (("tier2_export", "1"), ("tier2_export", "2"), ("long_dedup", "0"), ("msw_plan", "1"), ("tier3_early", "0")):
+            B.tune(name, val)
             try:
                 capfd.readouterr()
                 B.check(L.bsx_process_seqs(hard["dev"].h, C.byref(opt), hard["idx"].h, 0, n, p, None), "process_seqs(%s)" % name)
@@ -78,9 +80,11 @@ def test_hg38_like_sam_identical(hard, max_occ, capfd):
                 L.bsx_sim_reset_reads(p, n)
             finally:
                 B.tune(name, None)
-            assert other == hip, name
+            assert other == hip, (name, val)
             if name == "tier2_export":
                 assert "tier 2 (chains -> regions)" in err2, err2[-800:]
+            if name == "tier3_early":
+                assert "tier 3 beside them" not in err2 and "tier 3 beside them" in err, err2[-800:]
             if name == "msw_plan":
                 assert "alignments planned and run on the device" in err2, err2[-800:]
     finally:
