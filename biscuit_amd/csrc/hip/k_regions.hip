@@ -2280,7 +2280,7 @@ void launch_sa_dense(hipStream_t st, int n_cu, const DevIndex &ix, int parent, u
 // decreasing size first (the occurrences the strand search will visit, what k_occ_expand counted): longest first, the short ones fill in behind.
 // One workgroup; ranks by counting (n is a few thousand).  Lists longer than the table are left as they are: they are bound by throughput anyway.
 #define ORDER_CAP 6144
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_order_list(int *list, const unsigned int *count, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ)
 {
 	__shared__ unsigned int cost[ORDER_CAP];
@@ -2304,7 +2304,8 @@ k_order_list(int *list, const unsigned int *count, const DevIntv *seeds_dense, c
 }
 void launch_order_list(hipStream_t st, int *list, const unsigned int *count, const DevIntv *seeds_dense, const long long *task_off, const int *task_n, int max_occ)
 {
-	hipLaunchKernelGGL(k_order_list, dim3(1), dim3(1024), 0, st, list, count, seeds_dense, task_off, task_n, max_occ);
+	// (four waves: a workgroup of sixteen waited 13 ms on average for a CU with room for all of them in the pipelined trace; the ranks of 2 400 take 40 us either way)
+	hipLaunchKernelGGL(k_order_list, dim3(1), dim3(256), 0, st, list, count, seeds_dense, task_off, task_n, max_occ);
 }
 
 size_t regions_slab_bytes(int tier) { return tier == 2 ? sizeof(RgBig) : sizeof(RgHuge); }

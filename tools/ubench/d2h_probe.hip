@@ -27,6 +27,8 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 int main(int argc, char **argv)
 {
 	const size_t total = (size_t)1400 << 20, piece = (size_t)8 << 20;
+	if (argc > 1 && atoi(argv[1]) & 1) { if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) printf("hipSetDeviceFlags failed\n"); else printf("hipDeviceScheduleBlockingSync set\n"); }
+	const bool kernel_first = argc > 1 && (atoi(argv[1]) & 2);   // a kernel on the copying stream ahead of every piece (as the product's streams have)
 	hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
 	const int n_cu = prop.multiProcessorCount;
 	void *dev = nullptr, *pin = nullptr; unsigned long long *sink = nullptr;
@@ -61,7 +63,7 @@ int main(int argc, char **argv)
 				const size_t m = total - off < piece ? total - off : piece;
 				char *p = (char*)pin + (size_t)(i & 1) * piece;
 				if (v.kern) hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, v.st, (const uint4*)((char*)dev + off), (uint4*)p, m >> 4);
-				else CHK(hipMemcpyAsync(p, (char*)dev + off, m, hipMemcpyDeviceToHost, v.st));
+				else { if (kernel_first) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, v.st, 100ull, sink); CHK(hipMemcpyAsync(p, (char*)dev + off, m, hipMemcpyDeviceToHost, v.st)); }
 				CHK(hipEventRecord(ev[i & 1], v.st));
 				if (i >= 1) { CHK(hipEventSynchronize(ev[(i - 1) & 1])); memcpy(host + prev_off, (char*)pin + (size_t)((i - 1) & 1) * piece, prev_m); }
 				prev_off = off; prev_m = m;
