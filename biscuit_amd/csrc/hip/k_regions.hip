@@ -1987,7 +1987,7 @@ k_c2r(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, const bsx_s
 			}
 			reg_off[t] = (long long)base;
 			reg_n[t] = status ? -status : nr;
-			if (next_list && (status == 2 || status == 6)) next_list[atomicAdd(next_count, 1u)] = t;
+			if (next_list && (status == 2 || status == 6)) { next_list[atomicAdd(next_count, 1u)] = t; if (P.prof) atomicAdd(counters + 160 + status, 1ull); }
 		}
 		WAVE_SYNC();
 	}
@@ -2182,7 +2182,10 @@ k_regions_mid(DevIndex ix, DevScoring sc, RegParams P, const uint8_t *reads, con
 		int status = rg_task<Store, true, DPT>(S, D, ix, sc, P, reads, l_query, parent, qoff, seeds_dense + uni64(task_off[t]), n_iv, po >= 0 ? pos + po : nullptr, lane, counters, gap_tab, ctg_tab, &X, t);
 		if (status == 11) continue;
 		status = rg_publish(S, t, status, out, out_cap, out_cursor, reg_off, reg_n, lane);
-		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) next_list[atomicAdd(next_count, 1u)] = t;
+		if ((status == 8 || status == 2 || status == 3 || status == 4 || status == 6 || status == 10) && lane == 0) {
+			next_list[atomicAdd(next_count, 1u)] = t;
+			if (P.prof) atomicAdd(counters + 160 + status, 1ull);   // ($BSX_PHASES=2: why this tier hands a strand search on)
+		}
 	}
 	RG_PF_FLUSH(D);
 	RG_DBG_GUARDS("k_regions_mid");

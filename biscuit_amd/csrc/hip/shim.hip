@@ -952,6 +952,8 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 		const bool per_tier = bsx_phases() == 2;
 #define TIER_MARK(name_) do { if (main_seq && trace_tiers && n_marks < 12) { if (!L.tier_ev[n_marks]) HIPCHK(hipEventCreate(&L.tier_ev[n_marks])); HIPCHK(hipEventRecord(L.tier_ev[n_marks], st)); mark_name[n_marks++] = name_; \
 		if (per_tier) { unsigned long long pf_[16]; HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipMemcpy(pf_, ctr + 32, sizeof(pf_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 32, 0, sizeof(pf_))); \
+			{ unsigned long long ds_[12]; HIPCHK(hipMemcpy(ds_, ctr + 160, sizeof(ds_), hipMemcpyDeviceToHost)); HIPCHK(hipMemset(ctr + 160, 0, sizeof(ds_))); \
+			  if (ds_[2] | ds_[3] | ds_[4] | ds_[6] | ds_[8] | ds_[10]) fprintf(stderr, "[M::regions_batch] %s hands on: %llu for their intervals, %llu for their occurrences (or a list too long), %llu chains, %llu tied chain starts, %llu regions, %llu an interval to be walked further\n", name_, ds_[8], ds_[2], ds_[3], ds_[4], ds_[6], ds_[10]); } \
 			if (pf_[11]) fprintf(stderr, "[M::regions_batch] %s: seed loops: %llu seeds reached, %llu skipped as contained, %llu took the extension made ahead, %llu extended in place (%llu extensions, %llu rows)\n", name_, pf_[11], pf_[12], pf_[13], pf_[14], pf_[8], pf_[9]); \
 			double tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) tot_ += (double)pf_[k_]; \
 			if (tot_ > 0) fprintf(stderr, "[M::regions_batch] %s: intervals %.1f%% occurrences %.1f%% chaining %.1f%% weights+order %.1f%% sort %.1f%% filter %.1f%% prologues+seed tests %.1f%% extension %.1f%% of %.0f M wave cycles\n", name_, \
