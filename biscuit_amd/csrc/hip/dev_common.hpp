@@ -50,6 +50,7 @@ struct RegParams {
 	float mask_level, drop_ratio;
 	int32_t prof;          // count wave cycles per stage (tracing only: the counters are contended atomics)
 	int32_t walk_on;       // the HBM tiers walk an over-represented interval past max_occ themselves (0: such strand searches are left to the caller)
+	int32_t ext_win;       // chains -> regions of long reads: an extension's rows in a register window that follows the band (ext_dp_win) instead of in LDS
 	int32_t gap_cap;       // cal_max_gap is tabulated up to this query length (set by each kernel to the size of its table)
 	int32_t flt_len;       // flt_tab has entries for read lengths 0..flt_len
 	const int32_t *flt_tab; // per read length: min_HSP_score of mem_flt_chained_seeds (memchain.c:544-548) when the seed-SW filter runs for

@@ -67,3 +67,26 @@ void launch_extend(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
 	else if (nc <= 8) launch_ext_nc<8>(st, ix, sc, reads, jobs, order, n, res, qcap, n_cu);
 	else launch_ext_nc<32>(st, ix, sc, reads, jobs, order, n, res, qcap, n_cu);
 }
+
+// tests: plain jobs through the register window that follows the band (ext_dp_win, ext_dp.hpp: what the chains -> regions launch of chunks with
+// long reads extends with), a wavefront per job; a job it cannot hold (a band of more than 256 columns, a score of 2^21) is answered X4_DECLINED
+__global__ void __launch_bounds__(256)
+k_extend_win(DevIndex ix, DevScoring sc, const uint8_t *reads, const bsx_ext_job_t *jobs, long long n, bsx_ext_res_t *res)
+{
+	const int lane = wave_lane();
+	const int waves_per_block = blockDim.x >> 6, wave = threadIdx.x >> 6;
+	for (long long jj = (long long)blockIdx.x * waves_per_block + wave; jj < n; jj += (long long)gridDim.x * waves_per_block) {
+		const bsx_ext_job_t J = jobs[jj];
+		const int mx = J.parent ? sc.mx_ct : sc.mx_ga;
+		bsx_ext_res_t r;
+		if (2 * J.w + 1 <= 256 && (long long)J.h0 + (long long)J.qlen * mx < (1 << 21)) r = ext_dp_win<5>(ix, sc, reads, J, lane);
+		else { r.score = X4_DECLINED; r.qle = r.tle = r.gtle = r.gscore = r.max_off = 0; }
+		if (lane == 0) res[jj] = r;
+	}
+}
+void launch_extwin_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res, long long n)
+{
+	long long blocks = (n + 3) / 4;
+	if (blocks > (long long)n_cu * 8) blocks = (long long)n_cu * 8;
+	hipLaunchKernelGGL(k_extend_win, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, st, ix, sc, reads, jobs, n, res);
+}

@@ -1515,6 +1515,8 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						if (J.qlen < 64) res = ext_dp_reg<1>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (J.qlen < 128) res = ext_dp_reg<2>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (WT::QCAP <= 256 || J.qlen < 256) res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
+						else if (P.ext_win && 2 * J.w + 1 <= 256 && (long long)J.h0 + (long long)J.qlen * (parent ? sc.mx_ct : sc.mx_ga) < (1 << 21))
+							res = ext_dp_win<5>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);   // rows in five register slots that follow the band (round 6)
 						else if (2 * J.w + 1 <= 512) { WAVE_SYNC(); res = ext_dp<8>(ix, sc, reads, J, W.Hrow, W.Erow, W.qrow, lane); }   // rows in LDS, the band (<= 8 x 64 columns) in registers
 						else return 2;   // (-w above 127 with reads beyond 256 bases: left to the caller's batch kernels)
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);

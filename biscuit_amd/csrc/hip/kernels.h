@@ -46,6 +46,8 @@ void launch_global(hipStream_t st, const DevIndex &ix, const DevScoring &sc, con
 // launch_ext4_batch: plain ksw_extend2 jobs through the same rows (tests); jobs it cannot hold (query longer than x4_max_query(16),
 // scores of 2^21 or more) are answered with score = X4_DECLINED.
 #define X4_DECLINED (-0x7fffffff)
+// tests: plain jobs through ext_dp_win (ext_dp.hpp: rows in a register window that follows the band, queries of any length), a wavefront per job
+void launch_extwin_batch(hipStream_t st, int n_cu, const DevIndex &ix, const DevScoring &sc, const uint8_t *reads, const bsx_ext_job_t *jobs, bsx_ext_res_t *res, long long n);
 int x4_max_query(int ncq);
 size_t x4_job_bytes(void);
 struct RgXPoolArg;

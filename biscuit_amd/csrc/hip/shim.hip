@@ -723,6 +723,7 @@ static int lane_regions_batch(bsx_device_t *d, int lane, const bsx_opt_t *opt, i
 	R.mask_level = opt->mask_level; R.drop_ratio = opt->drop_ratio; R.prof = bsx_phases() ? 1 : 0;
 	R.gap_cap = -1;
 	R.walk_on = 1;
+	R.ext_win = (int)bsx_tune_long("ext_win", 1);
 	// mem_flt_chained_seeds (memchain.c:537-548) by read length: does the seed-SW filter run, and with which threshold.  Tabulated
 	// here because the rule goes through log() and the float / double conversions of the reference's expression.
 	bool any_flt = false;
@@ -1426,13 +1427,16 @@ static int lane_extend_batch(bsx_device_t *d, int lane, int64_t n, const bsx_ext
 	if (bsx_tune_is_set("ext4")) { // tests: the batch through the quarter-wave kernel of the regions path (k_ext4.hip); jobs it declines fail the call
 		int rc, max_q = 0;
 		for (int64_t i = 0; i < n; ++i) max_q = std::max(max_q, jobs[i].qlen);
-		if (max_q > x4_max_query(16) || n > 0x7fffffff) return BSX_E_ARG;
+		if ((max_q > x4_max_query(16) && bsx_tune_long("ext4", 0) != 3) || n > 0x7fffffff) return BSX_E_ARG;
 		if ((rc = L.jobs.reserve((size_t)n * sizeof(bsx_ext_job_t))) != BSX_OK) return rc;
 		if ((rc = L.res.reserve((size_t)n * sizeof(bsx_ext_res_t))) != BSX_OK) return rc;
 		if ((rc = L.aux.reserve(64)) != BSX_OK) return rc;
 		HIPCHK(hipMemcpyAsync(L.jobs.p, jobs, (size_t)n * sizeof(bsx_ext_job_t), hipMemcpyHostToDevice, L.st));
 		HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
-		launch_ext4_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p, max_q);
+		if (bsx_tune_long("ext4", 0) != 3) launch_ext4_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p, max_q);
+		if (bsx_tune_long("ext4", 0) == 3) { // ... or the wavefront-per-job form whose rows follow the band in a register window (ext_dp_win: the long reads' chains -> regions launch)
+			launch_extwin_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (long long)n);
+		} else
 		if (bsx_tune_long("ext4", 0) == 2) { // then the lane-per-job kernel (k_extl.hip) over the same jobs: its answers replace the others'
 			HIPCHK(hipMemsetAsync(L.aux.p, 0, 64, L.st));
 			launch_extl_batch(L.st, d->n_cu, d->ix, L.sc, (const uint8_t*)L.reads.p, (const bsx_ext_job_t*)L.jobs.p, (bsx_ext_res_t*)L.res.p, (unsigned int)n, (unsigned int*)L.aux.p);

@@ -31,7 +31,8 @@ static knob_t g_knobs[] = {
 	{"tier1c", "[1] 0: no third LDS tier / second chains -> regions launch for ordinary reads (the tier sequence of rounds 2-4)", 0},
 	{"x4", "[1] 0: every extension inline in the chains -> regions loop (no k_x4prep / k_extl / k_ext4 ahead of it)", 0},
 	{"xl", "[1] 0: the narrow extension jobs through k_ext4 as well (no lane-per-job kernel)", 0},
-	{"ext4", "[off] tests: bsx_extend_batch through the quarter-wave kernel (1) / then the lane-per-job kernel (2) of the regions path", 0},
+	{"ext_win", "[1] chunks with long reads: an extension's rows in five register slots that follow the band (ext_dp_win); 0: in LDS (the form of rounds 3-5)", 0},
+	{"ext4", "[off] tests: bsx_extend_batch through the quarter-wave kernel (1) / then the lane-per-job kernel (2) of the regions path / through the wavefront-per-job form with a register window (3)", 0},
 	{"chain_stages", "[3] how consecutive chunks' front halves are chained on the device: 0 none, 1 seeding, 2 seeding and regions, 3 the same but the HBM tiers hold nobody back, 4 strictly one after the other", 0},
 	{"small_copies_unmasked", "[1] the front half's copies of less than 256 KB go through the lane's unmasked stream (the CUs the front-half streams leave alone); 0: through the stream they are ordered on", 0},
 	{"reserve_cu_every", "[0] n >= 2: the front-half streams leave one compute unit in n (of every shader engine of every XCD) to the back half's short batches; < 2: none", 0},

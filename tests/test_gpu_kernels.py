@@ -183,6 +183,68 @@ def test_extend_matches_oracle(small_index, port, device, form, tune):
     assert (pr["score"] > jobs["h0"]).sum() > 50   # real extensions happened
 
 
+def test_extend_window_follows_the_band(small_index, port, device, tune):
+    """ext_dp_win (ext_dp.hpp; round 6): ksw_extend2 with its rows in five register slots of 64 columns that follow the band -- what the chains ->
+    regions launch extends a kilobase read with -- through bsx_extend_batch (ext4=3: a wavefront per job) on queries of up to 1 000 bases: random
+    jobs (bands of 11, 61, 201 and 255 columns, h0 up to 600 so that the first row's non-zero entries reach past the first window) and the reads'
+    own loci (extensions that run for hundreds of rows and move the window a dozen times), against the CPU restatement job by job."""
+    tune("ext4", "3")
+    opt = default_opt()
+    rng = np.random.default_rng(2026)
+    seqs = _reads(small_index, n_pairs=60, read_len=1000, seed=21, frag=(1100, 1500))
+    buf, offs = simdata.read_buffer(seqs)
+    for be in (port, device):
+        be.set_opt(opt)
+        be.set_reads(buf)
+    jobs = _rand_ext_jobs(small_index, seqs, offs, rng, 1500)
+    for k in range(len(jobs)):
+        jobs[k]["w"] = int(rng.choice([100, 100, 5, 30, 127]))
+        if k % 3 == 0:
+            jobs[k]["h0"] = int(rng.integers(1, 600))
+    # a third of the jobs "real": the target is the read's own locus, found by seeding (both directions)
+    tasks = _tasks(seqs, offs)
+    pi, po = port.seed(opt, tasks)
+    from biscuit_amd.api import SA_DT
+    k = 1
+    for t in range(len(tasks)):
+        if po[t + 1] > po[t] and k < len(jobs):
+            # the longest interval of the strand search with a single occurrence
+            best = None
+            for q in range(po[t], po[t + 1]):
+                x0, _, x2, info = [int(v) for v in pi[q]]
+                if x2 == 1 and (best is None or (info & 0xffffffff) - (info >> 32) > best[2] - best[1]):
+                    best = (x0, info >> 32, info & 0xffffffff)
+            if best is None:
+                continue
+            x0, qb, qe = best
+            par = int(tasks[t]["parent"])
+            pos = int(port.sa(np.array([(x0, par, 0)], dtype=SA_DT))[0])
+            L = int(tasks[t]["len"])
+            l_pac = small_index.l_pac
+            if qe < L and pos + L + 150 < 2 * l_pac and not (pos - qb - 150 < l_pac <= pos + L + 150) and pos - qb - 150 > 0:
+                right = k % 2 == 1
+                if right:
+                    jobs[k]["tpos"] = pos + (qe - qb); jobs[k]["qoff"] = int(tasks[t]["qoff"]) + qe; jobs[k]["qlen"] = L - qe
+                    jobs[k]["tlen"] = L - qe + 100; jobs[k]["qdir"] = 1; jobs[k]["tdir"] = 1
+                elif qb > 0:
+                    jobs[k]["tpos"] = pos - 1; jobs[k]["qoff"] = int(tasks[t]["qoff"]) + qb - 1; jobs[k]["qlen"] = qb
+                    jobs[k]["tlen"] = qb + 100; jobs[k]["qdir"] = -1; jobs[k]["tdir"] = -1
+                else:
+                    continue
+                jobs[k]["h0"] = qe - qb
+                jobs[k]["w"] = 100
+                jobs[k]["end_bonus"] = 10
+                jobs[k]["parent"] = par
+                k += 3
+    pr = port.extend(jobs)
+    dr = device.extend(jobs)
+    bad = np.nonzero(pr != dr)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[:3]], pr[bad[:3]], dr[bad[:3]])
+    long_rows = (pr["tle"] > 300).sum()
+    assert long_rows > 20, long_rows     # extensions that moved the window several times
+    assert (jobs["qlen"] > 320).sum() > 500
+
+
 @pytest.mark.parametrize("form", ["quarter_wave_per_job", "lane_per_job"])
 def test_extend_narrow_jobs_quarter_wave(small_index, port, device, tune, form, capfd):
     """k_ext4 (k_ext4.hip: a row of 16 lanes per job) on the jobs the regions path is full of -- extensions from chance matches of
