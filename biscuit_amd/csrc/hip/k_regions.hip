@@ -1299,10 +1299,10 @@ __device__ __forceinline__ int rg_publish(Store &S, int t, int status, bsx_regio
 #define RG_XSEEDS 128    // seeds of one list (main or seeds_extra) of a chain held in LDS; longer lists: the next tier takes the strand search
 #define RG_XREGS 64      // regions of one strand search (a lane each in the containment test); a read inside a high-copy repeat has dozens
 #define RG_XCBLK 16      // chain records staged at a time
-template <int QC, int WC, int XSD, int XRG = RG_XREGS>
+template <int QC, int WC, int XSD, int XRG = RG_XREGS, bool ROWS_ = true>
 struct RgC2rT {
 	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;   // (cal_max_gap tabulated up to GAPCAP; LDS is what bounds the long-read launch)
-	static const bool HBM = false;
+	static const bool HBM = false, ROWS = ROWS_;   // ROWS: LDS for an extension's rows (ext_dp: bands of more than 255 columns of a long read); without them such a strand search is handed on
 	unsigned long long pf[RG_NPF];
 	bsx_region_t regs[XRG];
 	RgXChain xc[RG_XCBLK];   // chains [xc_lo, xc_lo + RG_XCBLK) of the exported record
@@ -1314,11 +1314,13 @@ struct RgC2rT {
 	int n_regs;
 	// long reads: the extension's rows in LDS (ext_dp: registers for the band only, so that the launch keeps several waves per SIMD;
 	// rows in registers would need a slot per 64 query bases, 16 of them for a kilobase)
-	int32_t Hrow[QC > RG_QCAP ? QC + 2 : 1], Erow[QC > RG_QCAP ? QC + 2 : 1];
-	uint8_t qrow[QC > RG_QCAP ? QC : 4];
+	int32_t Hrow[(ROWS_ && QC > RG_QCAP) ? QC + 2 : 1], Erow[(ROWS_ && QC > RG_QCAP) ? QC + 2 : 1];
+	uint8_t qrow[(ROWS_ && QC > RG_QCAP) ? QC : 4];
 };
 typedef RgC2rT<RG_QCAP, RG_WIN, RG_XSEEDS> RgC2r;
-typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;
+// (round 6: no LDS rows -- 9 KB of the wave's 22 -- since the extensions of a long read keep their rows in a register window, ext_dp_win; the few
+// whose band outgrows it, a second band width of 401 columns, go on to k_c2r<RgC2rHL> with the strand search: twelve waves per CU instead of six)
+typedef RgC2rT<RG_QCAP_LONG, 1536, 256, RG_XREGS, false> RgC2rL;
 // The same workspace with its three large tables -- the regions made so far, the window over the record's seeds, the sort keys -- in a slab of
 // HBM per wave (round 6): for the strand searches of reads inside repeat families that outgrow RgC2rB (up to 1024 regions, 1024 seeds a list: what
 // the first HBM tier holds).  Until round 6 those went through that tier's monolithic form, whose extensions run inline, a wavefront each -- 58 % of
@@ -1327,7 +1329,7 @@ typedef RgC2rT<RG_QCAP_LONG, 1536, 256> RgC2rL;
 template <int QC, int WC, int XSD, int XRG>
 struct RgC2rHT {
 	static const int QCAP = QC, WINCAP = WC, XSEEDS = XSD, XREGS = XRG, GAPCAP = QC > RG_QCAP ? RG_QCAP : QC;
-	static const bool HBM = true;
+	static const bool HBM = true, ROWS = true;
 	unsigned long long pf[RG_NPF];
 	bsx_region_t *regs;      // XRG entries in the wave's slab of HBM: written once per region, read a lane per region by the containment test
 	RgXChain xc[RG_XCBLK];
@@ -1517,7 +1519,7 @@ __device__ int rg_c2r(WT &W, const DevIndex &ix, const DevScoring &sc, const Reg
 						else if (WT::QCAP <= 256 || J.qlen < 256) res = ext_dp_reg<RG_NC>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);
 						else if (P.ext_win && 2 * J.w + 1 <= 256 && (long long)J.h0 + (long long)J.qlen * (parent ? sc.mx_ct : sc.mx_ga) < (1 << 21))
 							res = ext_dp_win<5>(ix, sc, reads, J, lane, win_ok > 0 ? W.win : nullptr, rmax0, W.q, qoff);   // rows in five register slots that follow the band (round 6)
-						else if (2 * J.w + 1 <= 512) { WAVE_SYNC(); res = ext_dp<8>(ix, sc, reads, J, W.Hrow, W.Erow, W.qrow, lane); }   // rows in LDS, the band (<= 8 x 64 columns) in registers
+						else if (WT::ROWS && 2 * J.w + 1 <= 512) { WAVE_SYNC(); res = ext_dp<8>(ix, sc, reads, J, W.Hrow, W.Erow, W.qrow, lane); }   // rows in LDS, the band (<= 8 x 64 columns) in registers
 						else return 2;   // (-w above 127 with reads beyond 256 bases: left to the caller's batch kernels)
 						res.score = uni(res.score); res.qle = uni(res.qle); res.tle = uni(res.tle); res.gtle = uni(res.gtle);
 						res.gscore = uni(res.gscore); res.max_off = uni(res.max_off);
@@ -2373,7 +2375,7 @@ void launch_c2r(hipStream_t st, int grid, const DevIndex &ix, const DevScoring &
 	else if (long_reads == 2)   // ordinary reads with many regions or long seed lists: the strand searches k_c2r<RgC2r> declined (X names them)
 		hipLaunchKernelGGL((k_c2r<RgC2rB, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 	else if (long_reads)
-		hipLaunchKernelGGL((k_c2r<RgC2rL, 2>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
+		hipLaunchKernelGGL((k_c2r<RgC2rL, 3>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 	else
 	hipLaunchKernelGGL((k_c2r<RgC2r, 4>), dim3(grid * (4 / C2R_WPB)), dim3(64 * C2R_WPB), 0, st, /* `grid` counts groups of four waves */ ix, sc, P, reads, tasks, X, out, out_cap, out_cursor, reg_off, reg_n, cursor, next_list, next_count, counters, quota, (unsigned char*)nullptr);
 }
