@@ -78,7 +78,7 @@ typedef RgStore<128, 256, 256, 0, 0, unsigned short, short, 64> RgMid;          
 // chunks with long reads (a kilobase against an hg38-sized index: ~360 intervals, ~830 seeds, most of them alone in their piece): still
 // LDS, 62 KB per wave, two workgroups of one wave per CU -- every table access of the HBM tiers below is a memory round trip
 typedef RgStore<640, 1152, 1152, 0, 0, unsigned short, short, 160> RgLongS;   // 49 KB: three workgroups per CU; four fifths of the kilobase reads' strand searches fit
-typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 192> RgLongB;   // 62 KB, two per CU: most of the rest
+typedef RgStore<768, 1536, 1536, 0, 0, unsigned short, short, 288> RgLongB;   // 67 KB, two per CU: most of the rest (288 chain records since round 6: 192 sent 6.7 k strand searches a chunk on to the HBM tier for their chains of several seeds, five times the time each: its launch 110 -> 43 ms, this one's 488 -> 522)
 // ordinary reads inside repeat families (an hg38-like genome: 7 % of the strand searches outgrow RgMid): 23 KB per wave, six workgroups of one wave per CU
 typedef RgStore<256, 512, 512, 0, 0, unsigned short, short, 96> RgMid2;
 typedef RgStore<512, 1024, 1024, 1024, 1024, unsigned short, short> RgBig;
